@@ -48,13 +48,22 @@ def h5_complex(path, ds):
     return a[0::2] + 1j * a[1::2]
 
 
+def to_iq_u8(c, tol):
+    """Invert the dongle conversion (u8-127)/128 (src/capbuf.cpp:174); assert it is lossless to tol."""
+    re = np.round(c.real * 128 + 127)
+    im = np.round(c.imag * 128 + 127)
+    assert re.min() >= 0 and re.max() <= 255 and im.min() >= 0 and im.max() <= 255
+    back = (re - 127) / 128 + 1j * (im - 127) / 128
+    assert np.abs(back - c).max() <= tol
+    iq = np.empty(2 * c.size, np.uint8)
+    iq[0::2] = re.astype(np.uint8)
+    iq[1::2] = im.astype(np.uint8)
+    return iq
+
+
 def main():
     d = itfile.read_it(f"{REF}/test/capbuf_0000.it")
-    q = np.round(d["capbuf"] * 128 + 127)
-    assert np.array_equal((q - 127) / 128, d["capbuf"])
-    iq = np.empty(2 * q.size, np.uint8)
-    iq[0::2] = q.real.astype(np.uint8)
-    iq[1::2] = q.imag.astype(np.uint8)
+    iq = to_iq_u8(d["capbuf"], 0.0)
     np.savez_compressed(f"{HERE}/capbuf_0000.npz", iq_u8=iq, fc=d["fc"])
 
     d = itfile.read_it(f"{REF}/test/test_peak_search.it")
@@ -73,11 +82,7 @@ def main():
 
     m = f"{REF}/Matlab/test_xcorr_pss.mat"
     c = h5_complex(m, "/capbuf")
-    q = np.round(c * 128 + 127)
-    assert np.abs((q - 127) / 128 - c).max() < 1e-14
-    iq = np.empty(2 * q.size, np.uint8)
-    iq[0::2] = q.real.astype(np.uint8)
-    iq[1::2] = q.imag.astype(np.uint8)
+    iq = to_iq_u8(c, 1e-14)
     # parameters from Matlab/test_xcorr_pss.m:23-25
     np.savez_compressed(f"{HERE}/test_xcorr_pss.npz", iq_u8=iq, fc=np.array([739e6]), ds_comb_arm=np.array([2]),
                         f_search_set=np.array([35e3, 40e3, 45e3]))
