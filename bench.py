@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""bench.py -- capture-buffers/s of the searcher hot path on MI355X (driver contract).
+
+A "step" is one pass of the chain over one batch of synthetic 153600-sample, 1.92 Msps
+capture buffers that are ALREADY RESIDENT IN HBM when the timed region starts.  N=1 workload =
+BASELINE.json configs[1]/[2]: PSS correlation over the full +-100 ppm grid at 739 MHz
+(n_f = 31) + peak_search (+ the per-cell stages when --stage full).  With --gpus N (launched
+by torch.distributed.run, one rank per GPU) every rank processes its own shard of buffers
+(weak scaling, no data-path collective) and the detected-cell lists are all-gathered with
+RCCL once per step.
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_CAP = 153600
+FS = 1.92e6
+FC = 739e6
+PEAK_FP32_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense FP32 MFMA peak == packed FP32 vector peak
+PUBLISHED_BUFFERS_PER_S = 1.0 / 6.0   # ~6 s per centre frequency at ppm 100 (dual-core i7-2640)
+
+
+def synth_batch(pkg, n_buf, seed, fc_list):
+    """Deterministic synthetic capture buffers as raw RTL-SDR u8 I/Q bytes."""
+    synth = getattr(pkg, "synth", None)
+    if synth is not None:
+        return synth.make_batch_u8(n_buf, seed, fc_list)
+    # interim generator: recorded golden buffer rotated by a per-buffer offset + quantised noise buffers
+    g = np.load(os.path.join(ROOT, "tests", "golden", "capbuf_0000.npz"))["iq_u8"]
+    rng = np.random.default_rng(seed)
+    out = np.empty((n_buf, 2 * N_CAP), np.uint8)
+    for b in range(n_buf):
+        if b % 4 == 0:
+            out[b] = np.roll(g, 2 * int(rng.integers(0, N_CAP)))
+        else:
+            out[b] = np.clip(np.rint(rng.normal(127.0, 12.0, 2 * N_CAP)), 0, 255).astype(np.uint8)
+    return out
+
+
+def cpu_baseline(pkg, iq_u8, f, fc, stage):
+    """The CPU oracle (a port of the reference's C++ path) on ONE buffer of the same workload,
+    single thread, on this host.  Reported next to the GPU number; never part of `value`."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as O
+    iq = iq_u8.astype(np.float64)
+    cap = ((iq[0::2] - 127.0) / 128.0) + 1j * ((iq[1::2] - 127.0) / 128.0)
+    O.set_threads(1)
+    t0 = time.perf_counter()
+    if stage == "full":
+        cells, peaks = O.search_capbuf(cap, f, fc, fc, FS)
+    else:
+        r = O.xcorr_pss(cap, f, 2, fc, fc, FS)
+        peaks = O.peak_search(r["pow"], r["frq"], O.z_th1(r["sp_incoherent"], r["n_comb_xc"]), f, fc, fc, r["single"], 2)
+    dt = time.perf_counter() - t0
+    ncpu = os.cpu_count() or 1
+    O.set_threads(ncpu)
+    t0 = time.perf_counter()
+    if stage == "full":
+        O.search_capbuf(cap, f, fc, fc, FS)
+    else:
+        O.xcorr_pss(cap, f, 2, fc, fc, FS)
+    dt_mt = time.perf_counter() - t0
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": 1.0 / dt, "unit": "capture-buffers/s", "cores": 1, "kind": "port",
+            "sample": f"1 synthetic buffer, n_f={f.size}, stage={stage}, {dt:.2f} s single-thread "
+                      f"(C oracle, gcc -O3); all {ncpu} cores (OpenMP over lags as the reference): {1.0 / dt_mt:.3f} buffers/s",
+            "cpu_model": model, "n_peaks": len(peaks)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="capture buffers per step per GPU")
+    ap.add_argument("--ppm", type=float, default=100.0)
+    ap.add_argument("--stage", choices=["pss", "full"], default="pss")
+    ap.add_argument("--variant", type=int, default=0, help="0 = MFMA-f32 correlation kernel, 1 = VALU kernel")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import __graft_entry__ as ge
+    pkg = ge.load_package()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+
+    f = pkg.f_search_set_for(FC, args.ppm)
+    stage_mask = pkg.STAGE_FULL if args.stage == "full" else pkg.STAGE_PSS
+    B = args.batch
+    # rank r searches carriers FC + 100 kHz * (r*B + b): the sweep's carrier axis is the shard axis
+    fcs = FC + 100e3 * (np.arange(B) + rank * B)
+    host = synth_batch(pkg, B, 1234 + rank, fcs)
+    d_cap = torch.from_numpy(host).to(dev)            # inputs resident in HBM before timing starts
+    S = pkg.Searcher(local_rank if world > 1 else 0)
+    S.set_xcorr_variant(args.variant)
+    MAXC = 16
+    gather_buf = torch.zeros((world, B, 1 + MAXC * 4), dtype=torch.float64, device=dev) if world > 1 else None
+
+    def step():
+        res = S.search_batch(d_cap.data_ptr(), pkg.FMT_IQ_U8, B, N_CAP, f, fcs, fcs, FS, stage_mask, MAXC)
+        if world > 1:   # RCCL all-gather of the detected-cell list (fixed-size records), nothing else
+            mine = torch.zeros((B, 1 + MAXC * 4), dtype=torch.float64)
+            for b, cells in enumerate(res):
+                mine[b, 0] = len(cells)
+                for i, c in enumerate(cells[:MAXC]):
+                    mine[b, 1 + 4 * i: 5 + 4 * i] = torch.tensor([c.n_id_cell(), c.fc_requested, c.freq_superfine if stage_mask == 3 else c.freq, c.pss_pow])
+            dist.all_gather_into_tensor(gather_buf.view(-1), mine.to(dev).view(-1))
+        return res
+
+    for _ in range(args.warmup):
+        res = step()
+    xc_ms = []
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+        xc_ms.append(S.last_xcorr_ms()[0])
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    n_peaks = sum(len(r) for r in res)
+    if rank == 0:
+        n_f = f.size
+        value = world * B * args.steps / dt
+        # dominant kernel: PSS correlation.  Algorithmic work per buffer:
+        # F = 8*137*3*(N-136)*n_f real flops (reference-faithful count over all lags).
+        flops_per_buf = 8.0 * 137 * 3 * (N_CAP - 136) * n_f
+        flops_consumed = 8.0 * 137 * 3 * 9600 * 15 * n_f       # the 15x9600 lags that are ever used
+        k_ms = float(np.mean(xc_ms))
+        achieved = flops_per_buf * B / (k_ms * 1e-3) / 1e12
+        bytes_per_buf = 1651200 + 230400 * n_f                 # SURVEY.md section 8d compulsory HBM bytes
+        out = {
+            "metric": "capture-buffers/s (1.92 Msps, 153600-samp) full CellSearch; HBM GB/s vs peak",
+            "value": value, "unit": "capture-buffers/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": value / PUBLISHED_BUFFERS_PER_S, "dtype": "f32", "data": "synthetic",
+            "iq_samples_per_s": value * N_CAP,
+            "config": {"workload": ("configs[2]: full searcher chain (PSS+SSS+FOE+TFG+MIB)" if args.stage == "full" else
+                                    "configs[1]: xcorr_pss + peak_search over the full +-100 ppm foe grid") +
+                                   f", one MI355X per rank, {B} x 153600-sample capbufs per step, fc 739 MHz + 100 kHz raster",
+                       "n_f": int(n_f), "batch_per_gpu": B, "stage": args.stage, "ingest": "u8 I/Q resident in HBM",
+                       "xcorr_kernel": "mfma_f32_16x16x4" if args.variant == 0 else "valu_f32",
+                       "parallelism": f"carrier-sweep shard x{world}, RCCL all-gather of cell list" if world > 1 else "single GPU",
+                       "baseline_note": "vs_baseline = value / (1 buffer per ~6 s), doc/CellSearch.html:52-54 (dual-core i7-2640, ppm 100)",
+                       "n_peaks_last_step": n_peaks},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP32_TFLOPS, "traffic": None,
+                         "kernel": "k_xcorr_mfma" if args.variant == 0 else "k_xcorr_valu", "kernel_ms": k_ms,
+                         "flops_per_launch": flops_per_buf * B,
+                         "achieved_consumed_lags_only": flops_consumed * B / (k_ms * 1e-3) / 1e12,
+                         "hbm_algorithmic_GBps": bytes_per_buf * B / (k_ms * 1e-3) / 1e9, "hbm_peak_GBps": 8000.0},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(pkg, host[0], f, float(fcs[0]), args.stage)
+        print(json.dumps(out))
+    S.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,195 @@
+/*
+ * lcs.h -- C ABI of the MI355X-native LTE cell-search hot path (liblcs_amd.so).
+ *
+ * Drop-in boundary for the searcher of Evrytania/LTE-Cell-Scanner: every entry point
+ * below replaces one free function of the reference's include/searcher.h (cited per
+ * function) with plain pointers and sizes -- no IT++ or torch types.  The C++ wrappers
+ * in include/searcher_amd.h re-expose the reference's exact C++ signatures on top of
+ * this ABI; INTEGRATION.md shows the binding a maintainer adds on the reference side.
+ *
+ * Conventions
+ *  - complex arrays are interleaved (re, im); capture buffers are complex<double>
+ *    exactly as itpp::cvec stores them (host entry points) or complex<float> / raw
+ *    u8 I/Q already resident in HBM (device entry points).
+ *  - 2-D outputs [3][9600] are row-major (PSS index major); the reference's itpp::mat is
+ *    column-major, the C++ wrapper transposes.
+ *  - 3-D outputs are [t][idx][foi] with foi fastest, identical to the reference's
+ *    nested-vector vf3d / vcf3d (include/common.h.in:41-44).
+ *  - every function returns LCS_OK (0) or a negative error; "not found" stays in-band in
+ *    lcs_cell (n_id_1 == -1 / n_rb_dl == -1) exactly as in the reference
+ *    (src/CellSearch.cpp:530, 554).
+ *  - a context owns one HIP device + stream + workspace; calls on one context are
+ *    serialised by the caller, different contexts are independent (the reference's
+ *    functions are re-entrant).
+ *  - there is NO CPU fallback: if no gfx950 device is usable, lcs_create fails.
+ */
+#ifndef LCS_H
+#define LCS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LCS_OK 0
+#define LCS_ERR_NO_DEVICE (-1)
+#define LCS_ERR_BAD_ARG (-2)
+#define LCS_ERR_HIP (-3)
+#define LCS_ERR_OVERFLOW (-4)   /* more results than the caller's array holds (outputs truncated) */
+#define LCS_ERR_NOMEM (-5)
+
+#define LCS_CP_UNKNOWN 0
+#define LCS_CP_NORMAL 1
+#define LCS_CP_EXTENDED 2
+
+#define LCS_N_PSS 3
+#define LCS_N_IDX 9600          /* 5 ms at 1.92 Msps */
+#define LCS_TFG_NSC 72
+#define LCS_TFG_MAX_OFDM 854    /* 6 frames + 2 slots, normal CP (src/searcher.cpp:895) */
+
+/* POD mirror of class Cell -- include/common.h.in:101-129, defaults src/common.cpp:36-56. */
+typedef struct lcs_cell {
+  double fc_requested;
+  double fc_programmed;
+  double pss_pow;
+  double freq;
+  double frame_start;
+  double freq_fine;
+  double freq_superfine;
+  int32_t ind;
+  int32_t n_id_2;
+  int32_t n_id_1;
+  int32_t cp_type;        /* LCS_CP_* */
+  int32_t n_ports;
+  int32_t n_rb_dl;
+  int32_t phich_duration; /* 0 UNKNOWN, 1 NORMAL, 2 EXTENDED */
+  int32_t phich_resource; /* 0 UNKNOWN, 1 oneSixth, 2 half, 3 one, 4 two */
+  int32_t sfn;
+  int32_t reserved;
+} lcs_cell;
+
+typedef struct lcs_ctx lcs_ctx;
+
+/* ---- context ------------------------------------------------------------------- */
+/* device < 0: use the current HIP device.  Fails (LCS_ERR_NO_DEVICE) without a GPU. */
+int lcs_create(int device, lcs_ctx **out);
+void lcs_destroy(lcs_ctx *ctx);
+const char *lcs_last_error(const lcs_ctx *ctx);
+const char *lcs_version(void);
+void lcs_cell_init(lcs_cell *c);                      /* src/common.cpp:36-56 */
+/* Knob for A/B measurement of the PSS correlation kernel: 0 = MFMA-f32 tile kernel
+ * (default), 1 = plain VALU kernel.  Both produce bit-identical results. */
+int lcs_set_xcorr_variant(lcs_ctx *ctx, int variant);
+
+/* ---- stage entry points (host buffers in / out) ------------------------------------ */
+
+/* Replaces xcorr_pss -- include/searcher.h:22-41, src/searcher.cpp:389-419
+ * (xc_correlate :113-174, xc_combine :263-308, xc_delay_spread :312-347, sp_est :185-221,
+ * xc_peak_freq :353-383).  xc_re_im and sp are debug outputs of the reference and may be
+ * NULL (raw xc is then never materialised); incoherent may be NULL. */
+int lcs_xcorr_pss(lcs_ctx *ctx, const double *capbuf_re_im, uint32_t n_cap,
+                  const double *f_search_set, uint16_t n_f, uint8_t ds_comb_arm,
+                  double fc_requested, double fc_programmed, double fs_programmed,
+                  double *xc_incoherent_collapsed_pow /*[3][9600]*/,
+                  int32_t *xc_incoherent_collapsed_frq /*[3][9600]*/,
+                  float *xc_incoherent_single /*[3][9600][n_f]*/,
+                  float *xc_incoherent /*[3][9600][n_f] or NULL*/,
+                  double *sp_incoherent /*[9600]*/,
+                  float *xc_re_im /*[3][n_cap-136][n_f][2] or NULL*/,
+                  double *sp /*[n_comb_sp*9600] or NULL*/,
+                  uint16_t *n_comb_xc, uint16_t *n_comb_sp);
+
+/* Replaces peak_search -- include/searcher.h:44-56, src/searcher.cpp:422-510.
+ * Appends up to max_cells records; *n_cells receives the number found. */
+int lcs_peak_search(lcs_ctx *ctx, const double *xc_incoherent_collapsed_pow,
+                    const int32_t *xc_incoherent_collapsed_frq, const double *Z_th1 /*[9600]*/,
+                    const double *f_search_set, uint16_t n_f, double fc_requested,
+                    double fc_programmed, const float *xc_incoherent_single, uint8_t ds_comb_arm,
+                    lcs_cell *cells, int max_cells, int *n_cells);
+
+/* Replaces sss_detect -- include/searcher.h:59-76, src/searcher.cpp:696-761.  The eight
+ * trailing outputs are the reference's "only used for testing" arrays; each may be NULL. */
+int lcs_sss_detect(lcs_ctx *ctx, const lcs_cell *cell, const double *capbuf_re_im, uint32_t n_cap,
+                   double thresh2_n_sigma, double fc_requested, double fc_programmed,
+                   double fs_programmed, lcs_cell *cell_out,
+                   double *sss_h1_np_est /*62*/, double *sss_h2_np_est /*62*/,
+                   double *sss_h1_nrm_est /*62*2*/, double *sss_h2_nrm_est /*62*2*/,
+                   double *sss_h1_ext_est /*62*2*/, double *sss_h2_ext_est /*62*2*/,
+                   double *log_lik_nrm /*[168][2]*/, double *log_lik_ext /*[168][2]*/);
+
+/* Replaces pss_sss_foe -- include/searcher.h:79-85, src/searcher.cpp:767-850. */
+int lcs_pss_sss_foe(lcs_ctx *ctx, const lcs_cell *cell_in, const double *capbuf_re_im,
+                    uint32_t n_cap, double fc_requested, double fc_programmed,
+                    double fs_programmed, lcs_cell *cell_out);
+
+/* Replaces extract_tfg -- include/searcher.h:88-98, src/searcher.cpp:857-935.
+ * tfg is [n_ofdm][72] row-major; *n_ofdm = 854 (normal CP) or 732 (extended). */
+int lcs_extract_tfg(lcs_ctx *ctx, const lcs_cell *cell, const double *capbuf_re_im, uint32_t n_cap,
+                    double fc_requested, double fc_programmed, double fs_programmed,
+                    double *tfg_re_im, double *tfg_timestamp, int *n_ofdm);
+
+/* Replaces tfoec -- include/searcher.h:101-112, src/searcher.cpp:952-1069.  The RS_DL
+ * argument of the reference is a pure function of (n_id_cell, cp_type) and is rebuilt
+ * on the device (src/lte_lib.cpp:305-405). */
+int lcs_tfoec(lcs_ctx *ctx, const lcs_cell *cell, const double *tfg_re_im,
+              const double *tfg_timestamp, int n_ofdm, double fc_requested, double fc_programmed,
+              double *tfg_comp_re_im, double *tfg_comp_timestamp, lcs_cell *cell_out);
+
+/* Replaces decode_mib -- include/searcher.h:115-119, src/searcher.cpp:1526-1692
+ * (chan_est :1369-1477, ce_interp_hex :1223-1362, pbch_extract :1482-1522). */
+int lcs_decode_mib(lcs_ctx *ctx, const lcs_cell *cell, const double *tfg_re_im, int n_ofdm,
+                   lcs_cell *cell_out);
+
+/* ---- fused chain ------------------------------------------------------------------- */
+
+/* One capture buffer through the whole chain of the reference's main loop
+ * (src/CellSearch.cpp:484-558: xcorr_pss, Z_th1, peak_search, then per peak sss_detect,
+ * pss_sss_foe, extract_tfg, tfoec, decode_mib, dropping peaks without SSS / MIB).
+ * The buffer stays resident on the device across all stages.  peaks / n_peaks (nullable)
+ * receive the raw peak_search list. */
+int lcs_search_capbuf(lcs_ctx *ctx, const double *capbuf_re_im, uint32_t n_cap,
+                      const double *f_search_set, uint16_t n_f, double fc_requested,
+                      double fc_programmed, double fs_programmed,
+                      lcs_cell *cells, int max_cells, int *n_cells,
+                      lcs_cell *peaks, int max_peaks, int *n_peaks);
+
+/* Batched, device-resident form used by sweeps and by bench.py: n_buf capture buffers of
+ * n_cap samples each, ALREADY IN HBM, as complex<float> (fmt 0) or raw RTL-SDR u8 I/Q
+ * bytes (fmt 1; (x-127)/128 is applied on the device, src/capbuf.cpp:172-181).
+ * fc_requested / fc_programmed are per buffer (host arrays, n_buf).  cells is
+ * [n_buf][max_cells_per_buf] on the host; n_cells [n_buf].  stage_mask selects how far the
+ * chain runs: 1 = PSS correlation + peak_search only (BASELINE config 2), 3 = full chain. */
+#define LCS_FMT_C64 0
+#define LCS_FMT_IQ_U8 1
+#define LCS_STAGE_PSS 1
+#define LCS_STAGE_FULL 3
+int lcs_search_batch_dev(lcs_ctx *ctx, const void *d_capbufs, int fmt, int n_buf, uint32_t n_cap,
+                         const double *f_search_set, uint16_t n_f, const double *fc_requested,
+                         const double *fc_programmed, double fs_programmed, int stage_mask,
+                         lcs_cell *cells, int max_cells_per_buf, int *n_cells);
+
+/* Enqueue-only variant for timing: same work, results stay on the device until
+ * lcs_batch_collect.  Between enqueue and collect nothing synchronises with the host. */
+int lcs_batch_enqueue(lcs_ctx *ctx, const void *d_capbufs, int fmt, int n_buf, uint32_t n_cap,
+                      const double *f_search_set, uint16_t n_f, const double *fc_requested,
+                      const double *fc_programmed, double fs_programmed, int stage_mask);
+int lcs_batch_collect(lcs_ctx *ctx, lcs_cell *cells, int max_cells_per_buf, int *n_cells);
+/* HIP-event time (ms) of the PSS correlation kernel launches of the last enqueue, and the
+ * number of launches it covers; used by bench.py for the roofline figure. */
+int lcs_last_xcorr_ms(lcs_ctx *ctx, float *ms, int *n_launches);
+/* Stream the context launches on (hipStream_t as void*), for external event timing. */
+void *lcs_stream(lcs_ctx *ctx);
+int lcs_sync(lcs_ctx *ctx);
+
+/* ---- table accessors (tests compare them with the oracle) ---------------------------- */
+int lcs_table_pss_td(int n_id_2, double *out_re_im /*137*2*/);    /* src/lte_lib.cpp:177-188 */
+int lcs_table_pss_fd(int n_id_2, double *out_re_im /*62*2*/);     /* src/lte_lib.cpp:155-161 */
+int lcs_table_sss_fd(int n_id_1, int n_id_2, int slot_num, int32_t *out /*62*/); /* :199-257 */
+int lcs_table_lte_pn(uint32_t c_init, uint32_t len, uint8_t *out);               /* :41-147 */
+double lcs_chi2cdf_inv(double p, double k);                       /* include/dsp.h:188-193 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LCS_H */

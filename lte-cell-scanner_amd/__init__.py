@@ -1,0 +1,259 @@
+"""lte-cell-scanner_amd -- MI355X-native LTE cell-search hot path.
+
+Python host-side mirror of the reference's searcher interface (include/searcher.h:22-119):
+the same seven functions with the same argument meaning, each a thin call through the C ABI
+of liblcs_amd.so (include/lcs.h) into hand-written HIP kernels.  numpy arrays stand in for
+the IT++ containers; 2-D results are [3][9600] row-major, 3-D results [t][idx][foi].
+
+There is deliberately no CPU implementation here: without the HIP library / a GPU every
+call raises (``SearcherError``).  The CPU oracle used by the tests lives in oracle/ and is
+never imported from this package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .capi import LcsCell, FMT_C64, FMT_IQ_U8, STAGE_PSS, STAGE_FULL
+
+FS_LTE = 30720000.0        # include/constants.h:32
+DS_COMB_ARM = 2            # src/CellSearch.cpp:484
+THRESH2_N_SIGMA = 3        # src/CellSearch.cpp:528
+
+
+class SearcherError(RuntimeError):
+    pass
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double)) if a is not None else None
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32)) if a is not None else None
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float)) if a is not None else None
+
+
+def new_cell(**kw) -> LcsCell:
+    c = LcsCell()
+    capi.load().lcs_cell_init(C.byref(c))
+    for k, v in kw.items():
+        setattr(c, k, v)
+    return c
+
+
+def f_search_set_for(freq_start: float, ppm: float) -> np.ndarray:
+    """Frequency-offset grid of the CLI (src/CellSearch.cpp:463-464)."""
+    n_extra = int(np.floor((freq_start * ppm / 1e6 + 2.5e3) / 5e3))
+    return np.arange(-n_extra, n_extra + 1) * 5000.0
+
+
+class Searcher:
+    """One context = one GPU + stream + workspace (lcs_create / lcs_destroy)."""
+
+    def __init__(self, device: int = -1):
+        self._lib = capi.load()
+        h = C.c_void_p()
+        rc = self._lib.lcs_create(device, C.byref(h))
+        if rc != 0:
+            raise SearcherError(f"lcs_create failed: {capi.ERRORS.get(rc, rc)} (an MI355X is required; no CPU fallback)")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.lcs_destroy(self._h)
+            self._h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _chk(self, rc, what, allow_overflow=False):
+        if rc == 0 or (allow_overflow and rc == -4):
+            return rc
+        raise SearcherError(f"{what}: {capi.ERRORS.get(rc, rc)}: {self._lib.lcs_last_error(self._h).decode()}")
+
+    def set_xcorr_variant(self, v: int):
+        self._chk(self._lib.lcs_set_xcorr_variant(self._h, v), "lcs_set_xcorr_variant")
+
+    # ---- searcher.h:22-41 -------------------------------------------------------------
+    def xcorr_pss(self, capbuf, f_search_set, ds_comb_arm, fc_requested, fc_programmed, fs_programmed,
+                  want_incoherent=True, want_xc=False, want_sp=False):
+        cap = np.ascontiguousarray(capbuf, np.complex128)
+        f = np.ascontiguousarray(f_search_set, np.float64)
+        n_cap, n_f = cap.size, f.size
+        out = dict(pow=np.empty((3, 9600)), frq=np.empty((3, 9600), np.int32),
+                   single=np.empty((3, 9600, n_f), np.float32),
+                   incoherent=np.empty((3, 9600, n_f), np.float32) if want_incoherent else None,
+                   sp_incoherent=np.empty(9600))
+        xc = np.empty((3, n_cap - 136, n_f), np.complex64) if want_xc else None
+        sp = np.empty(((n_cap - 136 - 137) // 9600) * 9600) if want_sp else None
+        ncx, ncs = C.c_uint16(0), C.c_uint16(0)
+        rc = self._lib.lcs_xcorr_pss(self._h, _dp(cap), n_cap, _dp(f), n_f, int(ds_comb_arm), fc_requested,
+                                     fc_programmed, fs_programmed, _dp(out["pow"]), _ip(out["frq"]),
+                                     _fp(out["single"]), _fp(out["incoherent"]), _dp(out["sp_incoherent"]),
+                                     xc.ctypes.data_as(C.POINTER(C.c_float)) if want_xc else None, _dp(sp),
+                                     C.byref(ncx), C.byref(ncs))
+        self._chk(rc, "lcs_xcorr_pss")
+        out.update(n_comb_xc=ncx.value, n_comb_sp=ncs.value, xc=xc, sp=sp)
+        return out
+
+    # ---- searcher.h:44-56 -------------------------------------------------------------
+    def peak_search(self, pow_, frq, Z_th1, f_search_set, fc_requested, fc_programmed, single, ds_comb_arm,
+                    max_cells=64):
+        pow_ = np.ascontiguousarray(pow_, np.float64)
+        frq = np.ascontiguousarray(frq, np.int32)
+        Z = np.ascontiguousarray(Z_th1, np.float64)
+        f = np.ascontiguousarray(f_search_set, np.float64)
+        single = np.ascontiguousarray(single, np.float32)
+        cells = (LcsCell * max_cells)()
+        n = C.c_int(0)
+        rc = self._lib.lcs_peak_search(self._h, _dp(pow_), _ip(frq), _dp(Z), _dp(f), f.size, fc_requested,
+                                       fc_programmed, _fp(single), int(ds_comb_arm), cells, max_cells, C.byref(n))
+        self._chk(rc, "lcs_peak_search")
+        return [cells[i].copy() for i in range(n.value)]
+
+    # ---- searcher.h:59-76 -------------------------------------------------------------
+    def sss_detect(self, cell, capbuf, thresh2_n_sigma, fc_requested, fc_programmed, fs_programmed):
+        cap = np.ascontiguousarray(capbuf, np.complex128)
+        out = LcsCell()
+        d = dict(h1_np=np.empty(62), h2_np=np.empty(62), h1_nrm=np.empty(62, np.complex128),
+                 h2_nrm=np.empty(62, np.complex128), h1_ext=np.empty(62, np.complex128),
+                 h2_ext=np.empty(62, np.complex128), ll_nrm=np.empty((168, 2)), ll_ext=np.empty((168, 2)))
+        rc = self._lib.lcs_sss_detect(self._h, C.byref(cell), _dp(cap), cap.size, thresh2_n_sigma, fc_requested,
+                                      fc_programmed, fs_programmed, C.byref(out), _dp(d["h1_np"]), _dp(d["h2_np"]),
+                                      _dp(d["h1_nrm"]), _dp(d["h2_nrm"]), _dp(d["h1_ext"]), _dp(d["h2_ext"]),
+                                      _dp(d["ll_nrm"]), _dp(d["ll_ext"]))
+        self._chk(rc, "lcs_sss_detect")
+        return out, d
+
+    # ---- searcher.h:79-85 -------------------------------------------------------------
+    def pss_sss_foe(self, cell, capbuf, fc_requested, fc_programmed, fs_programmed):
+        cap = np.ascontiguousarray(capbuf, np.complex128)
+        out = LcsCell()
+        rc = self._lib.lcs_pss_sss_foe(self._h, C.byref(cell), _dp(cap), cap.size, fc_requested, fc_programmed,
+                                       fs_programmed, C.byref(out))
+        self._chk(rc, "lcs_pss_sss_foe")
+        return out
+
+    # ---- searcher.h:88-98 -------------------------------------------------------------
+    def extract_tfg(self, cell, capbuf, fc_requested, fc_programmed, fs_programmed):
+        cap = np.ascontiguousarray(capbuf, np.complex128)
+        tfg = np.zeros((854, 72), np.complex128)
+        ts = np.zeros(854)
+        n = C.c_int(0)
+        rc = self._lib.lcs_extract_tfg(self._h, C.byref(cell), _dp(cap), cap.size, fc_requested, fc_programmed,
+                                       fs_programmed, _dp(tfg), _dp(ts), C.byref(n))
+        self._chk(rc, "lcs_extract_tfg")
+        return tfg[:n.value].copy(), ts[:n.value].copy()
+
+    # ---- searcher.h:101-112 -----------------------------------------------------------
+    def tfoec(self, cell, tfg, tfg_timestamp, fc_requested, fc_programmed):
+        tfg = np.ascontiguousarray(tfg, np.complex128)
+        ts = np.ascontiguousarray(tfg_timestamp, np.float64)
+        tfgc, tsc = np.empty_like(tfg), np.empty_like(ts)
+        out = LcsCell()
+        rc = self._lib.lcs_tfoec(self._h, C.byref(cell), _dp(tfg), _dp(ts), tfg.shape[0], fc_requested,
+                                 fc_programmed, _dp(tfgc), _dp(tsc), C.byref(out))
+        self._chk(rc, "lcs_tfoec")
+        return out, tfgc, tsc
+
+    # ---- searcher.h:115-119 -----------------------------------------------------------
+    def decode_mib(self, cell, tfg):
+        tfg = np.ascontiguousarray(tfg, np.complex128)
+        out = LcsCell()
+        rc = self._lib.lcs_decode_mib(self._h, C.byref(cell), _dp(tfg), tfg.shape[0], C.byref(out))
+        self._chk(rc, "lcs_decode_mib")
+        return out
+
+    # ---- CellSearch.cpp:484-558, one buffer -----------------------------------------
+    def search_capbuf(self, capbuf, f_search_set, fc_requested, fc_programmed, fs_programmed, max_cells=64):
+        cap = np.ascontiguousarray(capbuf, np.complex128)
+        f = np.ascontiguousarray(f_search_set, np.float64)
+        cells, peaks = (LcsCell * max_cells)(), (LcsCell * 64)()
+        n, npk = C.c_int(0), C.c_int(0)
+        rc = self._lib.lcs_search_capbuf(self._h, _dp(cap), cap.size, _dp(f), f.size, fc_requested, fc_programmed,
+                                         fs_programmed, cells, max_cells, C.byref(n), peaks, 64, C.byref(npk))
+        self._chk(rc, "lcs_search_capbuf")
+        return [cells[i].copy() for i in range(min(n.value, max_cells))], [peaks[i].copy() for i in range(min(npk.value, 64))]
+
+    # ---- batched, device-resident ---------------------------------------------------
+    def batch_enqueue(self, d_ptr: int, fmt: int, n_buf: int, n_cap: int, f_search_set, fc_requested, fc_programmed,
+                      fs_programmed: float, stage_mask: int = STAGE_FULL):
+        f = np.ascontiguousarray(f_search_set, np.float64)
+        fr = np.ascontiguousarray(np.broadcast_to(np.asarray(fc_requested, np.float64), (n_buf,)))
+        fp_ = np.ascontiguousarray(np.broadcast_to(np.asarray(fc_programmed, np.float64), (n_buf,)))
+        rc = self._lib.lcs_batch_enqueue(self._h, C.c_void_p(d_ptr), fmt, n_buf, n_cap, _dp(f), f.size, _dp(fr),
+                                         _dp(fp_), fs_programmed, stage_mask)
+        self._chk(rc, "lcs_batch_enqueue")
+
+    def batch_collect(self, n_buf: int, max_cells_per_buf: int = 16):
+        cells = (LcsCell * (n_buf * max_cells_per_buf))()
+        cnt = (C.c_int * n_buf)()
+        rc = self._lib.lcs_batch_collect(self._h, cells, max_cells_per_buf, cnt)
+        self._chk(rc, "lcs_batch_collect", allow_overflow=True)
+        return [[cells[b * max_cells_per_buf + i].copy() for i in range(min(cnt[b], max_cells_per_buf))]
+                for b in range(n_buf)]
+
+    def search_batch(self, d_ptr: int, fmt: int, n_buf: int, n_cap: int, f_search_set, fc_requested, fc_programmed,
+                     fs_programmed: float, stage_mask: int = STAGE_FULL, max_cells_per_buf: int = 16):
+        self.batch_enqueue(d_ptr, fmt, n_buf, n_cap, f_search_set, fc_requested, fc_programmed, fs_programmed, stage_mask)
+        return self.batch_collect(n_buf, max_cells_per_buf)
+
+    def last_xcorr_ms(self):
+        ms, n = C.c_float(0), C.c_int(0)
+        self._chk(self._lib.lcs_last_xcorr_ms(self._h, C.byref(ms), C.byref(n)), "lcs_last_xcorr_ms")
+        return ms.value, n.value
+
+    def sync(self):
+        self._chk(self._lib.lcs_sync(self._h), "lcs_sync")
+
+
+def z_th1(sp_incoherent, n_comb_xc, ds_comb_arm=DS_COMB_ARM, thresh1_n_nines=12):
+    """Detection threshold of the CLI main loop (src/CellSearch.cpp:500-503)."""
+    L = capi.load()
+    R_th1 = L.lcs_chi2cdf_inv(1 - pow(10.0, -thresh1_n_nines), 2.0 * n_comb_xc * (2 * ds_comb_arm + 1))
+    rx_cutoff = (6 * 12 * 15e3 / 2 + 4 * 15e3) / (FS_LTE / 16 / 2)
+    return R_th1 * np.asarray(sp_incoherent) / rx_cutoff / 137 / 2 / n_comb_xc / (2 * ds_comb_arm + 1)
+
+
+# ---- table accessors (used by tests) ------------------------------------------------
+def table_pss_td(n_id_2):
+    o = np.empty(137, np.complex128)
+    capi.load().lcs_table_pss_td(n_id_2, _dp(o))
+    return o
+
+
+def table_pss_fd(n_id_2):
+    o = np.empty(62, np.complex128)
+    capi.load().lcs_table_pss_fd(n_id_2, _dp(o))
+    return o
+
+
+def table_sss_fd(n_id_1, n_id_2, slot):
+    o = np.empty(62, np.int32)
+    capi.load().lcs_table_sss_fd(n_id_1, n_id_2, slot, _ip(o))
+    return o
+
+
+def table_lte_pn(c_init, n):
+    o = np.empty(n, np.uint8)
+    capi.load().lcs_table_lte_pn(c_init, n, o.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return o
+
+
+def chi2cdf_inv(p, k):
+    return capi.load().lcs_chi2cdf_inv(p, k)

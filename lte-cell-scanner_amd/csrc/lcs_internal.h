@@ -1,0 +1,139 @@
+// lcs_internal.h -- shared declarations of the MI355X-native searcher (not installed).
+//
+// Device data layout (everything lives in one workspace, slot-major; a "slot" is one
+// capture buffer in flight):
+//   cap32   [S][n_cap]            float2   capture buffer, fp32 (PSS correlation input)
+//   cap64   [S][n_cap]            double2  capture buffer, fp64 (per-peak stages)
+//   tmpl    [S][n_f][3][137]      float2   conj(fshift(pss_td))/137   (searcher.cpp:146-151)
+//   start   [S][NW][n_f]          int      round_i(m*.005*k_factor*fs) (searcher.cpp:298)
+//   smin/kp2[S][NW][G]            int      per (window, 16-template group): first lag offset, tap pairs
+//   btab    [S][NW][G][KP2][64]   float    MFMA B operands: delay-shifted templates
+//   single  [S][3][9600][n_f]     float    xc_incoherent_single
+//   pow/frq [S][3][9600]          double/int
+//   spinc/zth [S][9600]           double
+//   peaks   [S][MAXP] lcs_cell, npeaks [S]
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "../../include/lcs.h"
+
+#define LCS_NW_MAX 16        // incoherent-combining windows (15 for a 153600-sample buffer)
+#define LCS_NF_MAX 128       // frequency hypotheses per call
+#define LCS_TG 16            // templates per MFMA column group
+#define LCS_G_MAX ((3 * LCS_NF_MAX + LCS_TG - 1) / LCS_TG)
+#define LCS_KP2_MAX 128      // tap pairs per (window, group): 137 taps + up to 119 samples of spread
+#define LCS_KP2_UNROLL 4
+#define LCS_LAG_TILE 64      // lags per wave
+#define LCS_PS 336           // LDS plane stride in floats: >= 64 + 2*KP2_MAX, == 16 (mod 32)
+#define LCS_MAXP 64          // peaks kept per capture buffer
+#define LCS_MAX_WORK 512     // cells carried into the TFG/MIB stages per batch
+#define LCS_TFG_ROWS 854
+
+struct SlotParams {
+  double fc_req, fc_prog, fs_prog;
+};
+
+struct XcGeom {
+  uint32_t n_cap;
+  int n_f;
+  int n_tmpl;   // 3*n_f
+  int G;        // ceil(n_tmpl/16)
+  int n_comb;   // n_comb_xc
+  int ds;       // ds_comb_arm
+};
+
+// One "cell work item" for the per-cell stages (TFG / TFOEC / channel estimate / PBCH).
+struct WorkItem {
+  int slot;
+  int peak;      // index into peaks[slot]
+};
+
+struct lcs_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  int xcorr_variant = 0;
+
+  // capacity the workspace is currently sized for
+  int cap_slots = 0;
+  uint32_t cap_n_cap = 0;
+  int cap_n_f = 0;
+  bool cap_debug = false;
+
+  // device buffers
+  float2 *cap32 = nullptr;
+  double2 *cap64 = nullptr;
+  SlotParams *params = nullptr;
+  double *fset = nullptr;
+  float2 *tmpl = nullptr;
+  int *start = nullptr, *smin = nullptr, *kp2 = nullptr;
+  float *btab = nullptr;
+  float *single = nullptr, *incoh = nullptr;
+  double *pow_ = nullptr, *work = nullptr, *spinc = nullptr, *zth = nullptr, *sp = nullptr;
+  int *frq = nullptr;
+  lcs_cell *peaks = nullptr;
+  int *npeaks = nullptr;
+  float2 *xc = nullptr;             // debug: raw correlations [3][n_cap-136][n_f]
+  size_t xc_elems = 0;
+  // per-cell stage buffers
+  WorkItem *work_items = nullptr;
+  int *n_work = nullptr;
+  double2 *tfg = nullptr;           // [MAX_WORK][854][72]
+  double2 *tfg_comp = nullptr;      // [MAX_WORK][854][72]
+  double2 *ce = nullptr;            // [MAX_WORK][4][854][72]
+  double *tfg_ts = nullptr;         // [MAX_WORK][854]
+  double *tfg_ts_comp = nullptr;    // [MAX_WORK][854]
+  double *cell_scratch = nullptr;   // [MAX_WORK][CELL_SCRATCH]
+  lcs_cell *cells_out = nullptr;    // [MAX_WORK]
+  // constant tables on the device
+  double2 *d_pss_td = nullptr;      // [3][137]
+  double2 *d_pss_fd = nullptr;      // [3][62]
+  int8_t *d_sss_fd = nullptr;       // [168][3][2][62]
+  uint8_t *d_pbch_scr = nullptr;    // [504][1920]
+  // host staging
+  void *h_pinned = nullptr;
+  size_t h_pinned_bytes = 0;
+
+  // last batch bookkeeping
+  int last_n_buf = 0;
+  int last_stage_mask = 0;
+  XcGeom last_geo{};
+  hipEvent_t ev_xc0 = nullptr, ev_xc1 = nullptr;
+  int last_xc_launches = 0;
+};
+
+#define HIPCHK(ctx, call)                                                        \
+  do {                                                                           \
+    hipError_t e_ = (call);                                                      \
+    if (e_ != hipSuccess) {                                                      \
+      (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);            \
+      return LCS_ERR_HIP;                                                        \
+    }                                                                            \
+  } while (0)
+
+// ---- host tables (lte_tables.cpp) --------------------------------------------------
+namespace lcs_tables {
+void pss_fd(int n_id_2, double *re_im /*62*2*/);
+void pss_td(int n_id_2, double *re_im /*137*2*/);
+void sss_fd(int n_id_1, int n_id_2, int slot_num, int32_t *out /*62*/);
+void lte_pn(uint32_t c_init, uint32_t len, uint8_t *out);
+double chi2cdf_inv(double p, double k);
+}  // namespace lcs_tables
+
+// ---- kernel launchers (one per .hip file) -------------------------------------------
+// pss_xcorr.hip
+int lcs_launch_ingest(lcs_ctx *c, const void *d_src, int fmt, int n_buf, uint32_t n_cap);
+int lcs_launch_xcorr(lcs_ctx *c, int n_buf, const XcGeom &geo, bool want_incoh, bool time_it);
+int lcs_launch_xc_debug(lcs_ctx *c, const XcGeom &geo);   // raw xc for slot 0 (debug output only)
+// peak_search.hip
+int lcs_launch_peak_search(lcs_ctx *c, int n_buf, const XcGeom &geo, double udb10_m12);
+// sss_foe.hip
+int lcs_launch_sss_foe(lcs_ctx *c, int n_buf, uint32_t n_cap, double thresh2_n_sigma, double *dbg /*device, nullable*/);
+int lcs_launch_foe_only(lcs_ctx *c, uint32_t n_cap);
+// tfg_mib.hip
+int lcs_launch_gather_work(lcs_ctx *c, int n_buf);
+int lcs_launch_tfg(lcs_ctx *c, uint32_t n_cap, int n_items /*upper bound*/);
+int lcs_launch_tfoec(lcs_ctx *c, int n_items);
+int lcs_launch_mib(lcs_ctx *c, int n_items);

@@ -1,0 +1,126 @@
+// peak_search.hip -- greedy PSS peak search, one workgroup per capture buffer.
+//
+// Replaces peak_search (ref src/searcher.cpp:422-510).  The reference loop is inherently
+// sequential (find global max -> threshold -> refine -> cancel -> repeat, a few dozen
+// iterations at most); each iteration is a data-parallel pass over the 3x9600 working copy,
+// so it runs as ONE 1024-thread workgroup per buffer and the chain never leaves the device.
+// Semantics kept: per-row first arg-max then first row with the maximum (= smallest linear
+// index among equal maxima), the uint16 refine loop that yields ind = -1 when
+// peak_ind < ds_comb_arm (quirk Q2), +-274 cancellation in the peak's own row, the no-op
+// "other PSS" loop (quirk Q1, omitted because it has no effect), the -12 dB floor.
+#include "lcs_internal.h"
+
+#define PS_THREADS 1024
+#define PS_MAX_ITER 4096
+
+__device__ __forceinline__ void cell_init(lcs_cell &c) {
+  c.fc_requested = __longlong_as_double(0x7ff8000000000000LL);
+  c.fc_programmed = c.fc_requested; c.pss_pow = c.fc_requested; c.freq = c.fc_requested;
+  c.frame_start = c.fc_requested; c.freq_fine = c.fc_requested; c.freq_superfine = c.fc_requested;
+  c.ind = -1; c.n_id_2 = -1; c.n_id_1 = -1; c.cp_type = LCS_CP_UNKNOWN; c.n_ports = -1; c.n_rb_dl = -1;
+  c.phich_duration = 0; c.phich_resource = 0; c.sfn = -1; c.reserved = 0;
+}
+
+__global__ __launch_bounds__(PS_THREADS) void k_peak_search(const double *__restrict__ pow_, const int *__restrict__ frq,
+                                                             const double *__restrict__ zth,
+                                                             const float *__restrict__ single,
+                                                             const double *__restrict__ fset,
+                                                             const SlotParams *__restrict__ params, double *work,
+                                                             lcs_cell *__restrict__ peaks, int *__restrict__ npeaks,
+                                                             XcGeom geo, double udb10_m12) {
+  const int slot = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int NE = 3 * LCS_N_IDX;
+  const double *pw = pow_ + (size_t)slot * NE;
+  const int *fq = frq + (size_t)slot * NE;
+  const double *z = zth + (size_t)slot * LCS_N_IDX;
+  const float *sg = single + (size_t)slot * NE * geo.n_f;
+  double *wk = work + (size_t)slot * NE;
+  lcs_cell *out = peaks + (size_t)slot * LCS_MAXP;
+
+  __shared__ double s_val[PS_THREADS / 64];
+  __shared__ int s_idx[PS_THREADS / 64];
+  __shared__ double s_peak_pow;
+  __shared__ int s_peak_lin;
+  __shared__ int s_stop;
+
+  for (int e = tid; e < NE; e += PS_THREADS) wk[e] = pw[e];
+  __syncthreads();
+
+  int n = 0;
+  for (int iter = 0; iter < PS_MAX_ITER; ++iter) {
+    // arg-max with "smallest linear index wins ties"
+    double best = wk[tid];
+    int bi = tid;
+    for (int e = tid + PS_THREADS; e < NE; e += PS_THREADS) {
+      const double v = wk[e];
+      if (v > best) { best = v; bi = e; }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+      const double ov = __shfl_down(best, off);
+      const int oi = __shfl_down(bi, off);
+      if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if ((tid & 63) == 0) { s_val[tid >> 6] = best; s_idx[tid >> 6] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+      double b = s_val[0];
+      int i = s_idx[0];
+      for (int k = 1; k < PS_THREADS / 64; ++k)
+        if (s_val[k] > b || (s_val[k] == b && s_idx[k] < i)) { b = s_val[k]; i = s_idx[k]; }
+      const int peak_n_id_2 = i / LCS_N_IDX, peak_ind = i % LCS_N_IDX;
+      const double peak_pow = b;
+      int stop = 0;
+      if (peak_pow < z[peak_ind]) stop = 1;
+      if (!stop) {
+        const int fi = fq[peak_n_id_2 * LCS_N_IDX + peak_ind];
+        double best_pow = -INFINITY;
+        int best_ind = -1;
+        const int ds = geo.ds;
+        // for (uint16 t=peak_ind-ds; t<=peak_ind+ds; t++): t wraps to >=65534 when peak_ind<ds
+        if (peak_ind - ds >= 0) {
+          for (int t = peak_ind - ds; t <= peak_ind + ds; ++t) {
+            const int tw = t % LCS_N_IDX;
+            const float v = sg[((size_t)peak_n_id_2 * LCS_N_IDX + tw) * geo.n_f + fi];
+            if ((double)v > best_pow) { best_pow = v; best_ind = tw; }
+          }
+        }
+        if (n < LCS_MAXP) {
+          lcs_cell c;
+          cell_init(c);
+          c.fc_requested = params[slot].fc_req;
+          c.fc_programmed = params[slot].fc_prog;
+          c.pss_pow = peak_pow;
+          c.ind = best_ind;
+          c.freq = fset[fi];
+          c.n_id_2 = peak_n_id_2;
+          out[n] = c;
+        }
+      }
+      s_peak_pow = peak_pow;
+      s_peak_lin = i;
+      s_stop = stop;
+    }
+    __syncthreads();
+    if (s_stop) break;
+    ++n;
+    const int row = s_peak_lin / LCS_N_IDX, col = s_peak_lin % LCS_N_IDX;
+    for (int t = tid; t <= 2 * 274; t += PS_THREADS) {
+      const int cc = ((col + t - 274) % LCS_N_IDX + LCS_N_IDX) % LCS_N_IDX;
+      wk[row * LCS_N_IDX + cc] = 0;
+    }
+    __syncthreads();
+    const double thresh = s_peak_pow * udb10_m12;
+    for (int e = tid; e < NE; e += PS_THREADS)
+      if (wk[e] < thresh) wk[e] = 0;
+    __syncthreads();
+  }
+  if (tid == 0) npeaks[slot] = n;
+}
+
+int lcs_launch_peak_search(lcs_ctx *c, int n_buf, const XcGeom &geo, double udb10_m12) {
+  hipLaunchKernelGGL(k_peak_search, dim3(n_buf), dim3(PS_THREADS), 0, c->stream, c->pow_, c->frq, c->zth, c->single,
+                     c->fset, c->params, c->work, c->peaks, c->npeaks, geo, udb10_m12);
+  HIPCHK(c, hipGetLastError());
+  return LCS_OK;
+}

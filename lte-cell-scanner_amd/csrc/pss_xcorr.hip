@@ -1,0 +1,443 @@
+// pss_xcorr.hip -- PSS sliding cross-correlation + incoherent combining for gfx950 (MI355X).
+//
+// Replaces xc_correlate (ref src/searcher.cpp:113-174), xc_combine (:263-308),
+// xc_delay_spread (:312-347), sp_est (:185-221) and xc_peak_freq (:353-383).
+//
+// Design:  the reference materialises xc[3][N-136][n_f] (136 MB at n_f=37)
+// and then gathers 15 windows out of it.  Here the 15-window gather is folded into the
+// correlation itself: one wavefront owns a tile of 64 output positions (idx) x 16 templates
+// (a "group" of consecutive (foi, pss) pairs) and walks the 15 windows; per window it stages
+// 64+K' capture samples in LDS (planar, conflict-free), correlates them against the group's
+// templates and accumulates |xc|^2 in registers.  The per-foi window start
+// round_i(m*.005*k_factor*fs) differs between the templates of a group by a few samples; that
+// delay is folded into the template ("B") table, which therefore holds zero-padded, shifted
+// copies of conj(fshift(pss_td))/137.  Raw xc never touches HBM.
+//
+// The complex dot product is evaluated as the real product  [xr -xi ; xi xr] x [tr ; ti]
+// with fp32 FMAs in tap order.  Two interchangeable kernels compute the SAME fma chain:
+//   k_xcorr_mfma : v_mfma_f32_16x16x4_f32 (exact fp32, k-ordered fma chain) -- A operands are
+//                  Toeplitz slices read straight from the LDS planes, B operands are 256-byte
+//                  coalesced rows of the template table;
+//   k_xcorr_valu : lane = output position, template taps broadcast through scalar loads.
+// Their outputs are bit-identical (tests/test_gpu_parity.py).
+#include "lcs_internal.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define NW LCS_NW_MAX
+#define NFM LCS_NF_MAX
+#define GM LCS_G_MAX
+
+// ------------------------------------------------------------------------------ ingest
+// fmt 0: complex<float> in HBM; fmt 1: RTL-SDR u8 I/Q, (x-127)/128 (ref src/capbuf.cpp:172-181);
+// fmt 2: complex<double> already copied into cap64.  Produces both precisions.
+__global__ void k_ingest(const void *__restrict__ src, int fmt, uint32_t n_cap, float2 *__restrict__ cap32,
+                         double2 *__restrict__ cap64) {
+  const int slot = blockIdx.y;
+  const size_t base = (size_t)slot * n_cap;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_cap; i += gridDim.x * blockDim.x) {
+    if (fmt == LCS_FMT_C64) {
+      float2 v = ((const float2 *)src)[base + i];
+      cap32[base + i] = v;
+      cap64[base + i] = make_double2((double)v.x, (double)v.y);
+    } else if (fmt == LCS_FMT_IQ_U8) {
+      uchar2 q = ((const uchar2 *)src)[base + i];
+      double re = ((double)q.x - 127.0) / 128.0, im = ((double)q.y - 127.0) / 128.0;
+      cap64[base + i] = make_double2(re, im);
+      cap32[base + i] = make_float2((float)re, (float)im);
+    } else {
+      double2 v = cap64[base + i];
+      cap32[base + i] = make_float2((float)v.x, (float)v.y);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------- K0a: tables
+// Per slot: window start indices (ref :298), per-(window,group) first offset / tap-pair count,
+// and the frequency-shifted conjugated templates (ref :146-151, dsp.h:40-53).
+__global__ __launch_bounds__(256) void k_prep_tables(const SlotParams *__restrict__ params,
+                                                      const double *__restrict__ fset,
+                                                      const double2 *__restrict__ pss_td, float2 *__restrict__ tmpl,
+                                                      int *__restrict__ start, int *__restrict__ smin,
+                                                      int *__restrict__ kp2, XcGeom geo) {
+  const int slot = blockIdx.x;
+  const SlotParams p = params[slot];
+  __shared__ int s_start[NW][NFM];
+  for (int foi = threadIdx.x; foi < geo.n_f; foi += blockDim.x) {
+    const double kf = (p.fc_req - fset[foi]) / p.fc_prog;
+    for (int w = 0; w < geo.n_comb; ++w) {
+      // round_i(m*.005*k_factor*fs_programmed), evaluated left to right
+      const double v = (((double)w * .005) * kf) * p.fs_prog;
+      const int s = (int)rint(v);
+      s_start[w][foi] = s;
+      start[((size_t)slot * NW + w) * NFM + foi] = s;
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < geo.n_comb * geo.G; i += blockDim.x) {
+    const int w = i / geo.G, g = i % geo.G;
+    const int c_hi = min(g * LCS_TG + LCS_TG - 1, geo.n_tmpl - 1);
+    const int f_lo = (g * LCS_TG) / 3, f_hi = c_hi / 3;
+    int mn = s_start[w][f_lo], mx = mn;
+    for (int f = f_lo + 1; f <= f_hi; ++f) { mn = min(mn, s_start[w][f]); mx = max(mx, s_start[w][f]); }
+    int k2 = (137 + (mx - mn) + 1) / 2;
+    k2 = ((k2 + LCS_KP2_UNROLL - 1) / LCS_KP2_UNROLL) * LCS_KP2_UNROLL;
+    if (k2 > LCS_KP2_MAX - LCS_KP2_UNROLL) k2 = LCS_KP2_MAX - LCS_KP2_UNROLL;   // rejected on the host before launch (lcs_api.hip)
+    smin[((size_t)slot * NW + w) * GM + g] = mn;
+    kp2[((size_t)slot * NW + w) * GM + g] = k2;
+  }
+  for (int i = threadIdx.x; i < geo.n_f * 3 * 137; i += blockDim.x) {
+    const int m = i % 137, t = (i / 137) % 3, foi = i / (137 * 3);
+    const double f_off = fset[foi];
+    const double kf = (p.fc_req - f_off) / p.fc_prog;
+    const double fs = p.fs_prog * kf;
+    const double k = M_PI * f_off / (fs / 2);
+    const double ang = k * (double)m;
+    const double cs = cos(ang), sn = sin(ang);
+    const double2 s = pss_td[t * 137 + m];
+    const double rr = s.x * cs - s.y * sn, ri = s.x * sn + s.y * cs;   // seq*coeff
+    tmpl[(((size_t)slot * NFM + foi) * 3 + t) * 137 + m] = make_float2((float)(rr / 137), (float)(-ri / 137));
+  }
+}
+
+// ---------------------------------------------------------------------- K0b: B operands
+// btab[slot][w][g][kk][l]:  l = 16*k + j,  k = 0..3 -> (tap 2kk: tr, ti ; tap 2kk+1: tr, ti) of
+// template c = 16g + j delayed by start[w][foi(c)] - smin[w][g]; zero outside the 137 taps.
+__global__ __launch_bounds__(256) void k_fill_btab(const float2 *__restrict__ tmpl, const int *__restrict__ start,
+                                                    const int *__restrict__ smin, const int *__restrict__ kp2,
+                                                    float *__restrict__ btab, XcGeom geo) {
+  const int slot = blockIdx.z;
+  const int wg = blockIdx.y;
+  const int w = wg / geo.G, g = wg % geo.G;
+  const int k2 = kp2[((size_t)slot * NW + w) * GM + g];
+  const int s0 = smin[((size_t)slot * NW + w) * GM + g];
+  float *out = btab + (((size_t)slot * geo.n_comb + w) * geo.G + g) * (size_t)(LCS_KP2_MAX * 64);
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < k2 * 64; e += gridDim.x * blockDim.x) {
+    const int kk = e >> 6, l = e & 63;
+    const int c = g * LCS_TG + (l & 15);
+    float v = 0.f;
+    if (c < geo.n_tmpl) {
+      const int foi = c / 3, t = c % 3;
+      const int delta = start[((size_t)slot * NW + w) * NFM + foi] - s0;
+      const int tap = 2 * kk + (l >> 5) - delta;
+      if (tap >= 0 && tap < 137) {
+        const float2 T = tmpl[(((size_t)slot * NFM + foi) * 3 + t) * 137 + tap];
+        v = ((l >> 4) & 1) ? T.y : T.x;
+      }
+    }
+    out[e] = v;
+  }
+}
+
+// ---------------------------------------------------------------- K1: correlate+combine
+__device__ __forceinline__ float pow2sum(float re, float im) { return fmaf(re, re, im * im); }
+
+// Stage `sl` samples starting at lag L0 of this slot's capture buffer into the three LDS
+// planes: [0]=imag, [PS]=real, [2PS]=-imag.  Plane offsets are 0/16/0 (mod 32) banks so that
+// the MFMA A-operand reads (16 lanes from one plane, 16 from another) never collide.
+__device__ __forceinline__ void stage_write(float *buf, const float2 *pre, int sl, int lane) {
+#pragma unroll
+  for (int r = 0; r < 5; ++r) {
+    const int n = lane + 64 * r;
+    if (n < sl) {
+      buf[n] = pre[r].y;
+      buf[LCS_PS + n] = pre[r].x;
+      buf[2 * LCS_PS + n] = -pre[r].y;
+    }
+  }
+}
+__device__ __forceinline__ void stage_load(float2 *pre, const float2 *__restrict__ cap, uint32_t n_cap, int L0, int sl,
+                                           int lane) {
+#pragma unroll
+  for (int r = 0; r < 5; ++r) {
+    const int n = lane + 64 * r;
+    const uint32_t src = (uint32_t)(L0 + n);
+    pre[r] = (n < sl && src < n_cap) ? cap[src] : make_float2(0.f, 0.f);
+  }
+}
+
+__global__ __launch_bounds__(64) void k_xcorr_mfma(const float2 *__restrict__ cap32, const int *__restrict__ smin,
+                                                    const int *__restrict__ kp2, const float *__restrict__ btab,
+                                                    float *__restrict__ single, XcGeom geo) {
+  const int lane = threadIdx.x;
+  const int idx0 = blockIdx.x * LCS_LAG_TILE;
+  const int g = blockIdx.y;
+  const int slot = blockIdx.z;
+  __shared__ float lds[2 * 3 * LCS_PS];
+  const float2 *cap = cap32 + (size_t)slot * geo.n_cap;
+  const int *smin_s = smin + (size_t)slot * NW * GM + g;
+  const int *kp2_s = kp2 + (size_t)slot * NW * GM + g;
+
+  // A-operand lane offsets for v_mfma_f32_16x16x4_f32: lane l supplies A[i=l&15][k=l>>4];
+  // k=0: xr(tap 2kk)  k=1: -xi(tap 2kk)  k=2: xr(tap 2kk+1)  k=3: -xi(tap 2kk+1)   (real part)
+  // k=0: xi           k=1:  xr           k=2: xi             k=3:  xr             (imag part)
+  const int odd = (lane >> 4) & 1;
+  const int a1_off = (odd ? 2 * LCS_PS : LCS_PS) + (lane & 15) + (lane >> 5);
+  const int a2_off = (odd ? LCS_PS : 0) + (lane & 15) + (lane >> 5);
+
+  f32x4 P[4];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) P[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  float2 pre[5];
+  stage_load(pre, cap, geo.n_cap, idx0 + smin_s[0], LCS_LAG_TILE + 2 * kp2_s[0], lane);
+
+  for (int w = 0; w < geo.n_comb; ++w) {
+    const int k2 = kp2_s[w * GM];
+    float *buf = lds + (w & 1) * 3 * LCS_PS;
+    stage_write(buf, pre, LCS_LAG_TILE + 2 * k2, lane);
+    __syncthreads();
+    if (w + 1 < geo.n_comb)
+      stage_load(pre, cap, geo.n_cap, idx0 + smin_s[(w + 1) * GM], LCS_LAG_TILE + 2 * kp2_s[(w + 1) * GM], lane);
+
+    f32x4 aR[4], aI[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) { aR[mt] = (f32x4){0.f, 0.f, 0.f, 0.f}; aI[mt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    const float *bp = btab + (((size_t)slot * geo.n_comb + w) * geo.G + g) * (size_t)(LCS_KP2_MAX * 64) + lane;
+    const float *a1p = buf + a1_off;
+    const float *a2p = buf + a2_off;
+    // B rows are prefetched one unrolled step ahead (k2 <= KP2_MAX - UNROLL, so the row
+    // block after the last one used is still inside this (window, group) slab).
+    float bnext[LCS_KP2_UNROLL];
+#pragma unroll
+    for (int u = 0; u < LCS_KP2_UNROLL; ++u) bnext[u] = bp[u * 64];
+    for (int kk = 0; kk < k2; kk += LCS_KP2_UNROLL) {
+      float b[LCS_KP2_UNROLL];
+#pragma unroll
+      for (int u = 0; u < LCS_KP2_UNROLL; ++u) b[u] = bnext[u];
+#pragma unroll
+      for (int u = 0; u < LCS_KP2_UNROLL; ++u) bnext[u] = bp[(kk + LCS_KP2_UNROLL + u) * 64];
+#pragma unroll
+      for (int u = 0; u < LCS_KP2_UNROLL; ++u) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          const float a1 = a1p[mt * 16 + 2 * (kk + u)];
+          const float a2 = a2p[mt * 16 + 2 * (kk + u)];
+          aR[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b[u], aR[mt], 0, 0, 0);
+          aI[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b[u], aI[mt], 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) P[mt][r] = P[mt][r] + pow2sum(aR[mt][r], aI[mt][r]);
+  }
+
+  // C/D layout of 16x16x4: col = lane&15 (template), row = 4*(lane>>4)+reg (lag within the 16-row tile)
+  const int c = g * LCS_TG + (lane & 15);
+  if (c < geo.n_tmpl) {
+    const int foi = c / 3, t = c % 3;
+    const float ncomb = (float)geo.n_comb;
+    float *o = single + (((size_t)slot * 3 + t) * LCS_N_IDX) * geo.n_f + foi;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int idx = idx0 + mt * 16 + 4 * (lane >> 4) + r;
+        o[(size_t)idx * geo.n_f] = __fdiv_rn(P[mt][r], ncomb);
+      }
+  }
+}
+
+__global__ __launch_bounds__(64) void k_xcorr_valu(const float2 *__restrict__ cap32, const int *__restrict__ smin,
+                                                    const int *__restrict__ kp2, const float *__restrict__ btab,
+                                                    float *__restrict__ single, XcGeom geo) {
+  const int lane = threadIdx.x;
+  const int idx0 = blockIdx.x * LCS_LAG_TILE;
+  const int g = blockIdx.y;
+  const int slot = blockIdx.z;
+  __shared__ float lds[2 * 3 * LCS_PS];
+  const float2 *cap = cap32 + (size_t)slot * geo.n_cap;
+  const int *smin_s = smin + (size_t)slot * NW * GM + g;
+  const int *kp2_s = kp2 + (size_t)slot * NW * GM + g;
+
+  float P[LCS_TG];
+#pragma unroll
+  for (int j = 0; j < LCS_TG; ++j) P[j] = 0.f;
+  float2 pre[5];
+  stage_load(pre, cap, geo.n_cap, idx0 + smin_s[0], LCS_LAG_TILE + 2 * kp2_s[0], lane);
+
+  for (int w = 0; w < geo.n_comb; ++w) {
+    const int k2 = kp2_s[w * GM];
+    float *buf = lds + (w & 1) * 3 * LCS_PS;
+    stage_write(buf, pre, LCS_LAG_TILE + 2 * k2, lane);
+    __syncthreads();
+    if (w + 1 < geo.n_comb)
+      stage_load(pre, cap, geo.n_cap, idx0 + smin_s[(w + 1) * GM], LCS_LAG_TILE + 2 * kp2_s[(w + 1) * GM], lane);
+    float aR[LCS_TG], aI[LCS_TG];
+#pragma unroll
+    for (int j = 0; j < LCS_TG; ++j) { aR[j] = 0.f; aI[j] = 0.f; }
+    // wave-uniform pointer: the compiler turns these reads into scalar loads
+    const float *bt = btab + (((size_t)slot * geo.n_comb + w) * geo.G + g) * (size_t)(LCS_KP2_MAX * 64);
+    for (int tap = 0; tap < 2 * k2; ++tap) {
+      const float xi = buf[lane + tap];
+      const float xr = buf[LCS_PS + lane + tap];
+      const float nxi = -xi;
+      const float *row = bt + (tap >> 1) * 64 + (tap & 1) * 32;
+#pragma unroll
+      for (int j = 0; j < LCS_TG; ++j) {
+        const float tr = row[j], ti = row[16 + j];
+        aR[j] = fmaf(nxi, ti, fmaf(xr, tr, aR[j]));
+        aI[j] = fmaf(xr, ti, fmaf(xi, tr, aI[j]));
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < LCS_TG; ++j) P[j] = P[j] + pow2sum(aR[j], aI[j]);
+  }
+  const float ncomb = (float)geo.n_comb;
+  const int idx = idx0 + lane;
+#pragma unroll
+  for (int j = 0; j < LCS_TG; ++j) {
+    const int c = g * LCS_TG + j;
+    if (c < geo.n_tmpl) {
+      const int foi = c / 3, t = c % 3;
+      single[((((size_t)slot * 3 + t) * LCS_N_IDX) + idx) * geo.n_f + foi] = __fdiv_rn(P[j], ncomb);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------- K2: sp_est
+// sp[t] = mean |capbuf[t..t+273]|^2 (ref :204-211), 15-window mean, rotate by 137 (:214-220),
+// and the detection threshold of the main loop (ref src/CellSearch.cpp:500-503).  The reference
+// updates sp with a serial recurrence; here every window sum is formed directly in fp64 (differs
+// from the recurrence at the 1e-14 relative level).
+struct SpArgs {
+  int n_comb_sp;
+  double R_th1, rx_cutoff;
+  int n_comb_xc, ds;
+};
+__global__ __launch_bounds__(256) void k_sp_est(const double2 *__restrict__ cap64, double *__restrict__ spinc,
+                                                 double *__restrict__ zth, double *__restrict__ sp_dbg,
+                                                 uint32_t n_cap, SpArgs a) {
+  const int slot = blockIdx.y;
+  const int i0 = blockIdx.x * 256;
+  const int tid = threadIdx.x;
+  const double2 *cap = cap64 + (size_t)slot * n_cap;
+  __shared__ double pw[256 + 274];
+  double acc = 0;
+  for (int m = 0; m < a.n_comb_sp; ++m) {
+    const uint32_t base = (uint32_t)m * 9600u + i0;
+    for (int n = tid; n < 256 + 274; n += 256) {
+      const uint32_t s = base + n;
+      double v = 0;
+      if (s < n_cap) { const double2 c = cap[s]; v = c.x * c.x + c.y * c.y; }
+      pw[n] = v;
+    }
+    __syncthreads();
+    double s = 0;
+    for (int j = 0; j < 274; ++j) s += pw[tid + j];
+    s = s / 274;
+    if (sp_dbg && i0 + tid < 9600) sp_dbg[(size_t)slot * a.n_comb_sp * 9600 + (size_t)m * 9600 + i0 + tid] = s;
+    acc += s;
+    __syncthreads();
+  }
+  const int i = i0 + tid;
+  if (i < 9600) {
+    const double v = acc / a.n_comb_sp;
+    const int o = (i + 137) % 9600;
+    spinc[(size_t)slot * 9600 + o] = v;
+    zth[(size_t)slot * 9600 + o] = a.R_th1 * v / a.rx_cutoff / 137 / 2 / a.n_comb_xc / (2 * a.ds + 1);
+  }
+}
+
+// ------------------------------------------------- K3: delay spread + max over frequency
+// ref :312-347 (float adds in the reference's order, circular in idx) and :353-383 (first max).
+__global__ __launch_bounds__(256) void k_collapse(const float *__restrict__ single, float *__restrict__ incoh,
+                                                   double *__restrict__ pow_, int *__restrict__ frq, XcGeom geo) {
+  const int slot = blockIdx.y;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= 3 * LCS_N_IDX) return;
+  const int t = e / LCS_N_IDX, idx = e % LCS_N_IDX;
+  const int n_f = geo.n_f;
+  const float *rows = single + (((size_t)slot * 3 + t) * LCS_N_IDX) * n_f;
+  float *orow = incoh ? incoh + ((((size_t)slot * 3 + t) * LCS_N_IDX) + idx) * n_f : nullptr;
+  const float dsn = (float)(2 * geo.ds + 1);
+  float best = 0.f;
+  int bi = 0;
+  for (int foi = 0; foi < n_f; ++foi) {
+    float v = rows[(size_t)idx * n_f + foi];
+    for (int d = 1; d <= geo.ds; ++d) {
+      const int a = (idx - d + LCS_N_IDX) % LCS_N_IDX, b = (idx + d) % LCS_N_IDX;
+      v = v + (rows[(size_t)a * n_f + foi] + rows[(size_t)b * n_f + foi]);
+    }
+    v = __fdiv_rn(v, dsn);
+    if (orow) orow[foi] = v;
+    if (foi == 0 || v > best) { best = v; bi = foi; }
+  }
+  pow_[(size_t)slot * 3 * LCS_N_IDX + e] = (double)best;
+  frq[(size_t)slot * 3 * LCS_N_IDX + e] = bi;
+}
+
+// ---------------------------------------------------------- debug: raw xc (slot 0 only)
+// The reference returns xc only "for debugging"; reproduced with its arithmetic (fp64
+// accumulate, store as complex<float>) when a caller asks for it.
+__global__ __launch_bounds__(256) void k_xc_debug(const double2 *__restrict__ cap64, const SlotParams *__restrict__ params,
+                                                   const double *__restrict__ fset, const double2 *__restrict__ pss_td,
+                                                   float2 *__restrict__ xc, XcGeom geo) {
+  const int foi = blockIdx.y, t = blockIdx.z;
+  __shared__ double2 temp[137];
+  const SlotParams p = params[0];
+  if (threadIdx.x < 137) {
+    const int m = threadIdx.x;
+    const double f_off = fset[foi];
+    const double kf = (p.fc_req - f_off) / p.fc_prog;
+    const double fs = p.fs_prog * kf;
+    const double k = M_PI * f_off / (fs / 2);
+    const double cs = cos(k * (double)m), sn = sin(k * (double)m);
+    const double2 s = pss_td[t * 137 + m];
+    temp[m] = make_double2((s.x * cs - s.y * sn) / 137, -(s.x * sn + s.y * cs) / 137);
+  }
+  __syncthreads();
+  const uint32_t n_k = geo.n_cap - 136;
+  for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n_k; k += gridDim.x * blockDim.x) {
+    double ar = 0, ai = 0;
+    for (int m = 0; m < 137; ++m) {
+      const double2 a = temp[m], b = cap64[k + m];
+      ar += a.x * b.x - a.y * b.y;
+      ai += a.x * b.y + a.y * b.x;
+    }
+    xc[((size_t)t * n_k + k) * geo.n_f + foi] = make_float2((float)ar, (float)ai);
+  }
+}
+
+// ------------------------------------------------------------------------------ launch
+int lcs_launch_ingest(lcs_ctx *c, const void *d_src, int fmt, int n_buf, uint32_t n_cap) {
+  dim3 grid(128, n_buf);
+  hipLaunchKernelGGL(k_ingest, grid, dim3(256), 0, c->stream, d_src, fmt, n_cap, c->cap32, c->cap64);
+  HIPCHK(c, hipGetLastError());
+  return LCS_OK;
+}
+
+int lcs_launch_xcorr(lcs_ctx *c, int n_buf, const XcGeom &geo, bool want_incoh, bool time_it) {
+  hipLaunchKernelGGL(k_prep_tables, dim3(n_buf), dim3(256), 0, c->stream, c->params, c->fset, c->d_pss_td, c->tmpl,
+                     c->start, c->smin, c->kp2, geo);
+  hipLaunchKernelGGL(k_fill_btab, dim3(8, geo.n_comb * geo.G, n_buf), dim3(256), 0, c->stream, c->tmpl, c->start,
+                     c->smin, c->kp2, c->btab, geo);
+  dim3 grid(LCS_N_IDX / LCS_LAG_TILE, geo.G, n_buf);
+  if (time_it) HIPCHK(c, hipEventRecord(c->ev_xc0, c->stream));
+  if (c->xcorr_variant == 1)
+    hipLaunchKernelGGL(k_xcorr_valu, grid, dim3(64), 0, c->stream, c->cap32, c->smin, c->kp2, c->btab, c->single, geo);
+  else
+    hipLaunchKernelGGL(k_xcorr_mfma, grid, dim3(64), 0, c->stream, c->cap32, c->smin, c->kp2, c->btab, c->single, geo);
+  if (time_it) { HIPCHK(c, hipEventRecord(c->ev_xc1, c->stream)); c->last_xc_launches = 1; }
+  SpArgs a;
+  a.n_comb_sp = (int)((geo.n_cap - 136 - 137) / 9600);
+  a.n_comb_xc = geo.n_comb;
+  a.ds = geo.ds;
+  a.R_th1 = lcs_tables::chi2cdf_inv(1 - pow(10.0, -12), 2.0 * geo.n_comb * (2 * geo.ds + 1));
+  a.rx_cutoff = (6 * 12 * 15e3 / 2 + 4 * 15e3) / (30720000.0 / 16 / 2);
+  hipLaunchKernelGGL(k_sp_est, dim3((LCS_N_IDX + 255) / 256, n_buf), dim3(256), 0, c->stream, c->cap64, c->spinc, c->zth,
+                     c->sp, geo.n_cap, a);
+  hipLaunchKernelGGL(k_collapse, dim3((3 * LCS_N_IDX + 255) / 256, n_buf), dim3(256), 0, c->stream, c->single,
+                     want_incoh ? c->incoh : nullptr, c->pow_, c->frq, geo);
+  HIPCHK(c, hipGetLastError());
+  return LCS_OK;
+}
+
+int lcs_launch_xc_debug(lcs_ctx *c, const XcGeom &geo) {
+  hipLaunchKernelGGL(k_xc_debug, dim3(64, geo.n_f, 3), dim3(256), 0, c->stream, c->cap64, c->params, c->fset,
+                     c->d_pss_td, c->xc, geo);
+  HIPCHK(c, hipGetLastError());
+  return LCS_OK;
+}

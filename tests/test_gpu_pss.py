@@ -1,0 +1,199 @@
+"""GPU parity tests for the PSS stage (xcorr_pss + peak_search) through the C ABI.
+
+Bar (BASELINE.json north_star): PSS peak indices / n_id_2 / frequency indices bit-exact,
+correlation magnitudes within 1e-5 relative of the CPU oracle."""
+import numpy as np
+import pytest
+
+import oracle as O
+from conftest import golden, iq_u8_to_capbuf, f_search_set_for, load_pkg
+
+pytestmark = pytest.mark.gpu
+FS = 1.92e6
+RTOL = 1e-5     # north_star: "correlation magnitudes within 1e-5 relative"
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    return load_pkg()
+
+
+@pytest.fixture(scope="module")
+def S(pkg):
+    s = pkg.Searcher(0)
+    yield s
+    s.close()
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _threads():
+    import os
+    O.set_legacy(False)
+    O.set_threads(min(16, os.cpu_count() or 1))
+
+
+def _check_xcorr(r, ro, what=""):
+    assert r["n_comb_xc"] == ro["n_comb_xc"] and r["n_comb_sp"] == ro["n_comb_sp"]
+    for k in ("single", "incoherent"):
+        if r.get(k) is None:
+            continue
+        err = np.abs(r[k].astype(np.float64) - ro[k]) / ro[k]
+        assert err.max() < RTOL, f"{what} {k}: max rel err {err.max():.3e} at {np.unravel_index(err.argmax(), err.shape)}"
+    assert np.array_equal(r["frq"], ro["frq"]), f"{what}: {np.count_nonzero(r['frq'] != ro['frq'])} frequency indices differ"
+    assert np.abs(r["pow"] - ro["pow"]).max() <= RTOL * ro["pow"].max()
+    assert (np.abs(r["pow"] - ro["pow"]) / ro["pow"]).max() < RTOL
+    assert (np.abs(r["sp_incoherent"] - ro["sp_incoherent"]) / ro["sp_incoherent"]).max() < 1e-11
+
+
+def test_mfma_and_valu_kernels_are_bit_identical(S, capbuf_0000):
+    cap, fc = capbuf_0000
+    f = np.array([-10e3, 30e3, 35e3, 40e3, 95e3, 100e3, 180e3])   # 21 templates: one full + one partial group
+    S.set_xcorr_variant(1)
+    a = S.xcorr_pss(cap, f, 2, fc, fc, FS)
+    S.set_xcorr_variant(0)
+    b = S.xcorr_pss(cap, f, 2, fc, fc, FS)
+    bad = np.argwhere(a["single"] != b["single"])
+    assert bad.size == 0, f"{len(bad)} of {a['single'].size} elements differ, first {bad[:5].tolist()}: " \
+                          f"{a['single'][tuple(bad[0])]} vs {b['single'][tuple(bad[0])]}"
+    assert np.array_equal(a["frq"], b["frq"]) and np.array_equal(a["pow"], b["pow"])
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_xcorr_pss_capbuf_0000_default_grid(S, capbuf_0000, variant):
+    cap, fc = capbuf_0000
+    f = f_search_set_for(fc, 120)                 # 37 hypotheses, the CLI default at 739 MHz
+    S.set_xcorr_variant(variant)
+    r = S.xcorr_pss(cap, f, 2, fc, fc, FS)
+    S.set_xcorr_variant(0)
+    ro = O.xcorr_pss(cap, f, 2, fc, fc, FS)
+    _check_xcorr(r, ro, "capbuf_0000")
+    Z = load_pkg().z_th1(r["sp_incoherent"], r["n_comb_xc"])
+    Zo = O.z_th1(ro["sp_incoherent"], ro["n_comb_xc"])
+    assert (np.abs(Z - Zo) / Zo).max() < 1e-10
+    peaks = S.peak_search(r["pow"], r["frq"], Z, f, fc, fc, r["single"], 2)
+    assert [(p.n_id_2, p.ind, p.freq) for p in peaks] == [(1, 1410, 35000.0), (1, 6990, 35000.0),
+                                                          (2, 1314, 45000.0), (0, 1327, 30000.0)]
+    po = O.peak_search(ro["pow"], ro["frq"], Zo, f, fc, fc, ro["single"], 2)
+    for a, b in zip(peaks, po):
+        assert abs(a.pss_pow - b.pss_pow) < RTOL * b.pss_pow
+        assert a.fc_requested == fc and a.fc_programmed == fc and a.n_id_1 == -1 and np.isnan(a.frame_start)
+
+
+def test_xcorr_pss_noisy_buffer_matches_golden_peaks(S):
+    """test_sss_detect.it: the 24 golden input peaks sit where the collapsed arrays say."""
+    g = golden("test_sss_detect")
+    f = np.arange(20e3, 60e3 + 1, 5e3)
+    fc = float(g["fc"][0])
+    r = S.xcorr_pss(g["capbuf"], f, 2, fc, fc, FS)
+    ro = O.xcorr_pss(g["capbuf"], f, 2, fc, fc, FS)
+    _check_xcorr(r, ro, "test_sss_detect")
+    ind, n2 = g["peaks_ind"] - 1, g["peaks_n_id_2"]
+    assert np.array_equal(f[r["frq"][n2, ind]], g["peaks_freq"].astype(float))
+    assert (np.abs(r["pow"][n2, ind] - g["peaks_pow"]) / g["peaks_pow"]).max() < 2e-4   # SURVEY 4.3 (MATLAB semantics)
+
+
+def test_xcorr_pss_short_buffer_14_windows(S):
+    g = golden("test_xcorr_pss")
+    cap = iq_u8_to_capbuf(g["iq_u8"])
+    fc = float(g["fc"][0])
+    r = S.xcorr_pss(cap, g["f_search_set"], 2, fc, fc, FS)
+    ro = O.xcorr_pss(cap, g["f_search_set"], 2, fc, fc, FS)
+    assert r["n_comb_xc"] == 14 and r["n_comb_sp"] == 14
+    _check_xcorr(r, ro, "135360-sample buffer")
+
+
+def test_xcorr_pss_edge_grids(S, capbuf_0000):
+    """n_f = 1 (tracker mode), unsorted grid, different ds_comb_arm, fc_programmed != fc_requested."""
+    cap, fc = capbuf_0000
+    for f, ds, fcp, fs in (([35e3], 2, fc, FS), ([40e3, -20e3, 35e3, 0.0], 1, fc + 1234.0, FS * (1 + 2e-5)),
+                           ([35e3, 35e3], 0, fc, FS)):
+        f = np.array(f)
+        r = S.xcorr_pss(cap, f, ds, fc, fcp, fs)
+        ro = O.xcorr_pss(cap, f, ds, fc, fcp, fs)
+        _check_xcorr(r, ro, f"grid {f.tolist()} ds={ds}")
+
+
+def test_xcorr_pss_minimum_length_buffer(S, capbuf_0000):
+    cap, fc = capbuf_0000
+    n = 9600 + 136 + 137 + 100            # exactly one combining window
+    f = np.array([30e3, 35e3, 40e3])
+    r = S.xcorr_pss(cap[:n], f, 2, fc, fc, FS)
+    ro = O.xcorr_pss(cap[:n], f, 2, fc, fc, FS)
+    assert r["n_comb_xc"] == 1
+    _check_xcorr(r, ro, "one-window buffer")
+
+
+def test_debug_outputs_xc_and_sp(S, capbuf_0000):
+    cap, fc = capbuf_0000
+    f = np.array([35e3, 40e3])
+    r = S.xcorr_pss(cap, f, 2, fc, fc, FS, want_xc=True, want_sp=True)
+    ro = O.xcorr_pss(cap, f, 2, fc, fc, FS, want_xc=True, want_sp=True)
+    scale = np.abs(ro["xc"]).max()
+    assert np.abs(r["xc"] - ro["xc"]).max() < 1e-6 * scale       # test/test_xcorr_pss.cpp:107 uses 1e-6
+    assert (np.abs(r["sp"] - ro["sp"]) / ro["sp"]).max() < 1e-11
+
+
+def test_peak_search_golden_fixture(S):
+    """test/test_peak_search.it through the GPU peak_search (mirrors test/test_peak_search.cpp)."""
+    g = golden("test_peak_search")
+    pow_ = g["xc_incoherent_collapsed_pow"]
+    frq = g["xc_incoherent_collapsed_frq"] - 1
+    f = g["f_search_set"].astype(float)
+    single = np.repeat(pow_[:, :, None], f.size, axis=2).astype(np.float32)
+    cells = S.peak_search(pow_, frq, g["Z_th1"], f, 739e6, 739e6, single, 0)
+    assert len(cells) == 20
+    for c, p, i, fr, n2 in zip(cells, g["peaks_pow"], g["peaks_ind"] - 1, g["peaks_freq"], g["peaks_n_id_2"]):
+        assert c.pss_pow == p and (c.ind, c.freq, c.n_id_2) == (i, fr, n2)
+
+
+def test_peak_search_quirks(S):
+    """Q2 (peak_ind < ds_comb_arm -> ind = -1), wrap-around cancellation, tie-break order."""
+    f = np.array([0.0, 5000.0])
+    pow_ = np.full((3, 9600), 1e-3)
+    frq = np.zeros((3, 9600), np.int32)
+    single = np.full((3, 9600, 2), 1e-3, np.float32)
+    pow_[2, 1] = 5.0          # peak_ind = 1 < ds = 2 -> refined index -1
+    pow_[0, 9599] = 4.0       # near the wrap
+    single[0, 0, 0] = 9.0     # the refine step must pick idx 0 (= 9600 mod 9600)
+    pow_[1, 4000] = 3.0
+    pow_[2, 4000] = 3.0       # tie: PSS 1 must come first
+    Z = np.full(9600, 2.0)
+    got = S.peak_search(pow_, frq, Z, f, 1e9, 1e9, single, 2)
+    exp = O.peak_search(pow_, frq, Z, f, 1e9, 1e9, single, 2)
+    assert [(c.n_id_2, c.ind, c.freq, c.pss_pow) for c in got] == [(c.n_id_2, c.ind, c.freq, c.pss_pow) for c in exp]
+    assert [(c.n_id_2, c.ind) for c in got] == [(2, -1), (0, 0), (1, 3998), (2, 3998)]
+
+
+def test_batch_device_api_matches_single_calls(S, pkg, capbuf_0000):
+    """Device-resident batch entry point, both ingest formats, per-buffer carrier frequencies."""
+    import torch
+    cap, fc = capbuf_0000
+    g = golden("capbuf_0000")
+    f = f_search_set_for(fc, 100)
+    rng = np.random.default_rng(3)
+    noise_iq = rng.integers(100, 156, size=g["iq_u8"].size, dtype=np.uint8)
+    bufs_u8 = np.stack([g["iq_u8"], noise_iq, g["iq_u8"]])
+    fcs = np.array([fc, fc + 100e3, fc - 200e3])
+    d = torch.from_numpy(bufs_u8).cuda()
+    res = S.search_batch(d.data_ptr(), pkg.FMT_IQ_U8, 3, cap.size, f, fcs, fcs, FS, pkg.STAGE_PSS)
+    d32 = torch.from_numpy(np.stack([iq_u8_to_capbuf(b).astype(np.complex64) for b in bufs_u8])).cuda()
+    res32 = S.search_batch(d32.data_ptr(), pkg.FMT_C64, 3, cap.size, f, fcs, fcs, FS, pkg.STAGE_PSS)
+    for b in range(3):
+        capb = iq_u8_to_capbuf(bufs_u8[b])
+        ro = O.xcorr_pss(capb, f, 2, fcs[b], fcs[b], FS)
+        po = O.peak_search(ro["pow"], ro["frq"], O.z_th1(ro["sp_incoherent"], 15), f, fcs[b], fcs[b], ro["single"], 2)
+        for got in (res[b], res32[b]):
+            assert [(c.n_id_2, c.ind, c.freq) for c in got] == [(c.n_id_2, c.ind, c.freq) for c in po], b
+            for x, y in zip(got, po):
+                assert abs(x.pss_pow - y.pss_pow) < RTOL * y.pss_pow and x.fc_requested == fcs[b]
+    assert len(res[1]) == 0 and len(res[0]) == 4
+
+
+def test_bad_arguments_fail_loudly(S, pkg, capbuf_0000):
+    cap, fc = capbuf_0000
+    with pytest.raises(pkg.SearcherError):
+        S.xcorr_pss(cap, np.array([]), 2, fc, fc, FS)
+    with pytest.raises(pkg.SearcherError):
+        S.xcorr_pss(cap[:5000], np.array([0.0]), 2, fc, fc, FS)
+    with pytest.raises(pkg.SearcherError):          # 6 adjacent hypotheses spanning 30 MHz: too sparse to fuse
+        S.xcorr_pss(cap, np.arange(6) * 6e6, 2, fc, fc, FS)

@@ -1,0 +1,78 @@
+"""CPU-only checks of the product library: it loads, exports every symbol include/lcs.h
+declares, refuses to create a context without a GPU, and its host tables agree with the
+oracle's restatement of the reference table code."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle as O
+from conftest import ROOT, load_pkg
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    return load_pkg()
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    hdr = open(os.path.join(ROOT, "include", "lcs.h")).read()
+    declared = set(re.findall(r"\b(lcs_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"lcs_ctx", "lcs_cell"}
+    lib = pkg.capi.load()
+    missing = [s for s in sorted(declared) if not hasattr(lib, s)]
+    assert not missing, missing
+    assert declared == set(pkg.capi.EXPORTS)
+
+
+def test_cell_struct_layout_and_init(pkg):
+    assert C.sizeof(pkg.LcsCell) == 7 * 8 + 10 * 4 == C.sizeof(O.Cell)
+    c = pkg.new_cell()
+    assert np.isnan(c.fc_requested) and np.isnan(c.freq_superfine)
+    assert (c.ind, c.n_id_2, c.n_id_1, c.cp_type, c.n_ports, c.n_rb_dl, c.sfn) == (-1, -1, -1, 0, -1, -1, -1)
+    assert c.n_id_cell() == -1 and c.n_symb_dl() == -1
+
+
+def test_no_gpu_means_loud_failure(pkg):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(pkg.SearcherError):
+        pkg.Searcher(0)
+
+
+def test_pss_tables_match_oracle(pkg):
+    for t in range(3):
+        assert np.abs(pkg.table_pss_fd(t) - O.pss_fd(t)).max() < 1e-13
+        assert np.abs(pkg.table_pss_td(t) - O.pss_td(t)).max() < 1e-13
+
+
+def test_sss_table_matches_oracle(pkg):
+    for n1 in range(168):
+        for n2 in range(3):
+            for slot in (0, 10):
+                assert np.array_equal(pkg.table_sss_fd(n1, n2, slot), O.sss_fd(n1, n2, slot)), (n1, n2, slot)
+
+
+def test_lte_pn_matches_oracle(pkg):
+    rng = np.random.default_rng(1)
+    for c_init in [0, 1, 277, 503, 2**31 - 1] + [int(x) for x in rng.integers(0, 2**31, 20)]:
+        assert np.array_equal(pkg.table_lte_pn(c_init, 1920), O.lte_pn(c_init, 1920))
+
+
+def test_chi2cdf_inv_matches_oracle_and_scipy(pkg):
+    from scipy.stats import chi2
+    for k in (10, 140, 150, 300):
+        p = 1 - 1e-12
+        assert abs(pkg.chi2cdf_inv(p, k) - O.chi2cdf_inv(p, k)) < 1e-9 * k
+        assert abs(pkg.chi2cdf_inv(p, k) - chi2.ppf(p, k)) < 1e-8 * chi2.ppf(p, k)
+
+
+def test_f_search_set_matches_cli_recipe(pkg):
+    # src/CellSearch.cpp:463-464: ppm 120 @ 739 MHz -> 37 hypotheses, ppm 100 -> 31, ppm 10 -> 3
+    assert pkg.f_search_set_for(739e6, 120).size == 37
+    assert pkg.f_search_set_for(739e6, 100).size == 31
+    assert pkg.f_search_set_for(739e6, 10).size == 3
+    assert pkg.f_search_set_for(715e6, 120).size == 35
