@@ -65,6 +65,13 @@ def load() -> C.CDLL:
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f"{LIB_PATH} is missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950); "
                            "there is no CPU fallback for the searcher path")
+    # One HIP runtime per process: PyTorch-ROCm wheels bundle their own libamdhip64; when torch
+    # is installed it must be loaded first so that this library binds to the same runtime
+    # (torch tensors' device pointers are handed to lcs_batch_enqueue).
+    try:
+        import torch  # noqa: F401
+    except Exception:  # torch is optional plumbing, not a dependency of the C ABI
+        pass
     L = C.CDLL(LIB_PATH)
     vp, dp, ip, fp = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_float)
     cp, u16p = C.POINTER(LcsCell), C.POINTER(C.c_uint16)

@@ -32,16 +32,17 @@ def _threads():
     O.set_threads(min(16, os.cpu_count() or 1))
 
 
-def _check_xcorr(r, ro, what=""):
+def _check_xcorr(r, ro, what="", rtol=RTOL):
     assert r["n_comb_xc"] == ro["n_comb_xc"] and r["n_comb_sp"] == ro["n_comb_sp"]
     for k in ("single", "incoherent"):
         if r.get(k) is None:
             continue
         err = np.abs(r[k].astype(np.float64) - ro[k]) / ro[k]
-        assert err.max() < RTOL, f"{what} {k}: max rel err {err.max():.3e} at {np.unravel_index(err.argmax(), err.shape)}"
+        assert err.max() < rtol, f"{what} {k}: max rel err {err.max():.3e} at {np.unravel_index(err.argmax(), err.shape)}"
+        assert np.abs(r[k].astype(np.float64) - ro[k]).max() < 1e-6 * ro[k].max()
     assert np.array_equal(r["frq"], ro["frq"]), f"{what}: {np.count_nonzero(r['frq'] != ro['frq'])} frequency indices differ"
-    assert np.abs(r["pow"] - ro["pow"]).max() <= RTOL * ro["pow"].max()
-    assert (np.abs(r["pow"] - ro["pow"]) / ro["pow"]).max() < RTOL
+    assert np.abs(r["pow"] - ro["pow"]).max() <= 1e-6 * ro["pow"].max()
+    assert (np.abs(r["pow"] - ro["pow"]) / ro["pow"]).max() < rtol
     assert (np.abs(r["sp_incoherent"] - ro["sp_incoherent"]) / ro["sp_incoherent"]).max() < 1e-11
 
 
@@ -120,7 +121,10 @@ def test_xcorr_pss_minimum_length_buffer(S, capbuf_0000):
     r = S.xcorr_pss(cap[:n], f, 2, fc, fc, FS)
     ro = O.xcorr_pss(cap[:n], f, 2, fc, fc, FS)
     assert r["n_comb_xc"] == 1
-    _check_xcorr(r, ro, "one-window buffer")
+    # With a single window nothing averages the fp32 rounding of one 137-tap dot product: lags whose
+    # correlation nearly cancels (|xc|^2 ~1e-4 of the typical value) carry up to ~1e-4 relative error
+    # (1e-7 of the buffer's largest value).  The 1e-5 bar is stated for full 80 ms buffers.
+    _check_xcorr(r, ro, "one-window buffer", rtol=1e-3)
 
 
 def test_debug_outputs_xc_and_sp(S, capbuf_0000):
