@@ -81,6 +81,27 @@ int ensure_ws(lcs_ctx *c, int n_slots, uint32_t n_cap, int n_f, bool debug) {
   return LCS_OK;
 }
 
+// Buffers of the per-cell stages (allocated on first use: ~3 GB for 512 cells in flight).
+int ensure_percell(lcs_ctx *c) {
+  if (c->percell_ready) return LCS_OK;
+  int rc;
+  const size_t W = LCS_MAX_WORK, GRID = (size_t)LCS_TFG_ROWS * LCS_TFG_NSC;
+#define A(p, n) if ((rc = dev_alloc(c, &c->p, (n))) != LCS_OK) return rc
+  A(work_items, W);
+  A(n_work, 4);
+  A(tfg, W * GRID);
+  A(tfg_comp, W * GRID);
+  A(ce, W * 4 * GRID);
+  A(tfg_ts, W * LCS_TFG_ROWS);
+  A(tfg_ts_comp, W * LCS_TFG_ROWS);
+  A(cell_scratch, W * LCS_CELL_SCRATCH);
+  A(cells_out, W);
+  A(d_dbg, 2048);
+#undef A
+  c->percell_ready = true;
+  return LCS_OK;
+}
+
 // Host-side check that the frequency grid fits the fused combining (see k_prep_tables).
 int validate_grid(lcs_ctx *c, const XcGeom &geo, const double *fset, double fc_req, double fc_prog, double fs_prog) {
   for (int w = 0; w < geo.n_comb; ++w) {
@@ -149,10 +170,15 @@ int lcs_create(int device, lcs_ctx **out) {
       }
   std::vector<uint8_t> scr(504 * 1920);
   for (int id = 0; id < 504; ++id) lcs_tables::lte_pn((uint32_t)id, 1920, &scr[(size_t)id * 1920]);
+  std::vector<uint8_t> derm(2 * 1920, 255);
+  lcs_tables::pbch_deratematch_map(1920, &derm[0]);      // normal CP
+  lcs_tables::pbch_deratematch_map(1728, &derm[1920]);   // extended CP
   bool ok = hipMalloc((void **)&c->d_pss_td, td.size() * sizeof(double)) == hipSuccess &&
             hipMalloc((void **)&c->d_pss_fd, fd.size() * sizeof(double)) == hipSuccess &&
             hipMalloc((void **)&c->d_sss_fd, sss.size()) == hipSuccess &&
             hipMalloc((void **)&c->d_pbch_scr, scr.size()) == hipSuccess &&
+            hipMalloc((void **)&c->d_derm_map, derm.size()) == hipSuccess &&
+            hipMemcpy(c->d_derm_map, derm.data(), derm.size(), hipMemcpyHostToDevice) == hipSuccess &&
             hipMemcpy(c->d_pss_td, td.data(), td.size() * sizeof(double), hipMemcpyHostToDevice) == hipSuccess &&
             hipMemcpy(c->d_pss_fd, fd.data(), fd.size() * sizeof(double), hipMemcpyHostToDevice) == hipSuccess &&
             hipMemcpy(c->d_sss_fd, sss.data(), sss.size(), hipMemcpyHostToDevice) == hipSuccess &&
@@ -169,7 +195,7 @@ void lcs_destroy(lcs_ctx *c) {
   void *ptrs[] = {c->cap32, c->cap64, c->params, c->fset, c->tmpl, c->start, c->smin, c->kp2, c->btab, c->single,
                   c->incoh, c->pow_, c->work, c->spinc, c->zth, c->sp, c->frq, c->peaks, c->npeaks, c->xc,
                   c->work_items, c->n_work, c->tfg, c->tfg_comp, c->ce, c->tfg_ts, c->tfg_ts_comp, c->cell_scratch,
-                  c->cells_out, c->d_pss_td, c->d_pss_fd, c->d_sss_fd, c->d_pbch_scr};
+                  c->cells_out, c->d_pss_td, c->d_pss_fd, c->d_sss_fd, c->d_pbch_scr, c->d_derm_map, c->d_dbg};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   if (c->h_pinned) (void)hipHostFree(c->h_pinned);
   if (c->ev_xc0) (void)hipEventDestroy(c->ev_xc0);
@@ -295,8 +321,14 @@ int lcs_batch_enqueue(lcs_ctx *c, const void *d_capbufs, int fmt, int n_buf, uin
   if ((rc = lcs_launch_xcorr(c, n_buf, geo, false, true))) return rc;
   if ((rc = lcs_launch_peak_search(c, n_buf, geo, std::pow(10.0, -12.0 / 10.0)))) return rc;
   if (stage_mask & 2) {
-    c->err = "full-chain stages are not built into this library yet";
-    return LCS_ERR_BAD_ARG;
+    if ((rc = ensure_percell(c))) return rc;
+    if ((rc = lcs_launch_sss_foe(c, n_buf, n_cap, 3.0 /* THRESH2_N_SIGMA, ref src/CellSearch.cpp:528 */, nullptr))) return rc;
+    if ((rc = lcs_launch_gather_work(c, n_buf))) return rc;
+    if ((rc = lcs_launch_tfg(c, n_cap, 0))) return rc;
+    if ((rc = lcs_launch_rs_build(c))) return rc;
+    if ((rc = lcs_launch_tfoec(c, 0))) return rc;
+    if ((rc = lcs_launch_mib(c, 0))) return rc;
+    if ((rc = lcs_launch_scatter_back(c))) return rc;
   }
   c->last_n_buf = n_buf;
   c->last_stage_mask = stage_mask;
@@ -313,11 +345,19 @@ int lcs_batch_collect(lcs_ctx *c, lcs_cell *cells, int max_cells_per_buf, int *n
   HIPCHK(c, hipMemcpyAsync(cnt.data(), c->npeaks, sizeof(int) * nb, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   int rc = LCS_OK;
+  const bool full = (c->last_stage_mask & 2) != 0;
   for (int b = 0; b < nb; ++b) {
-    const int lim = std::min(std::min(cnt[b], max_cells_per_buf), (int)LCS_MAXP);
-    n_cells[b] = cnt[b];
-    for (int i = 0; i < lim; ++i) cells[(size_t)b * max_cells_per_buf + i] = tmp[(size_t)b * LCS_MAXP + i];
-    if (cnt[b] > lim) rc = LCS_ERR_OVERFLOW;
+    const int np = std::min(cnt[b], (int)LCS_MAXP);
+    if (cnt[b] > LCS_MAXP) rc = LCS_ERR_OVERFLOW;
+    int n = 0;
+    for (int i = 0; i < np; ++i) {
+      const lcs_cell &pc = tmp[(size_t)b * LCS_MAXP + i];
+      // the reference erases peaks without SSS (src/CellSearch.cpp:530-534) or MIB (:554-558)
+      if (full && (pc.n_id_1 == -1 || pc.n_rb_dl == -1)) continue;
+      if (n < max_cells_per_buf) cells[(size_t)b * max_cells_per_buf + n] = pc; else rc = LCS_ERR_OVERFLOW;
+      ++n;
+    }
+    n_cells[b] = n;
   }
   if (rc) c->err = "more results than the output array holds";
   return rc;
@@ -330,6 +370,195 @@ int lcs_search_batch_dev(lcs_ctx *c, const void *d_capbufs, int fmt, int n_buf, 
                              fs_programmed, stage_mask);
   if (rc) return rc;
   return lcs_batch_collect(c, cells, max_cells_per_buf, n_cells);
+}
+
+// ---------------------------------------------------------- single-cell stage entry points
+namespace {
+int upload_cap_and_params(lcs_ctx *c, const double *capbuf, uint32_t n_cap, double fc_req, double fc_prog, double fs_prog) {
+  int rc;
+  if (!capbuf || n_cap < 128) { c->err = "bad capture buffer"; return LCS_ERR_BAD_ARG; }
+  HIPCHK(c, hipSetDevice(c->device));
+  if ((rc = ensure_ws(c, 1, n_cap, std::max(1, c->cap_n_f), false))) return rc;
+  SlotParams p{fc_req, fc_prog, fs_prog};
+  HIPCHK(c, hipMemcpyAsync(c->cap64, capbuf, sizeof(double2) * n_cap, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->params, &p, sizeof(p), hipMemcpyHostToDevice, c->stream));
+  return LCS_OK;
+}
+int put_single_work_item(lcs_ctx *c, const lcs_cell *cell, int n_ofdm) {
+  int rc;
+  if ((rc = ensure_percell(c))) return rc;
+  const WorkItem wi{0, 0};
+  const int one = 1;
+  const double hdr[3] = {(double)n_ofdm, 0.0, 0.0};
+  HIPCHK(c, hipMemcpyAsync(c->work_items, &wi, sizeof(wi), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->n_work, &one, sizeof(int), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->cells_out, cell, sizeof(lcs_cell), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->cell_scratch, hdr, sizeof(hdr), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));   // the sources above are stack variables
+  return LCS_OK;
+}
+int n_ofdm_for(const lcs_cell *cell) {
+  return cell->cp_type == LCS_CP_NORMAL ? 854 : (cell->cp_type == LCS_CP_EXTENDED ? 732 : -1);
+}
+}  // namespace
+
+int lcs_sss_detect(lcs_ctx *c, const lcs_cell *cell, const double *capbuf, uint32_t n_cap, double thresh2_n_sigma,
+                   double fc_req, double fc_prog, double fs_prog, lcs_cell *cell_out, double *h1_np, double *h2_np,
+                   double *h1_nrm, double *h2_nrm, double *h1_ext, double *h2_ext, double *ll_nrm, double *ll_ext) {
+  if (!c || !cell || !cell_out) return LCS_ERR_BAD_ARG;
+  if (cell->n_id_2 < 0 || cell->n_id_2 > 2) { c->err = "cell.n_id_2 must be 0..2"; return LCS_ERR_BAD_ARG; }
+  int rc;
+  if ((rc = upload_cap_and_params(c, capbuf, n_cap, fc_req, fc_prog, fs_prog))) return rc;
+  if ((rc = ensure_percell(c))) return rc;
+  const int one = 1;
+  HIPCHK(c, hipMemcpyAsync(c->peaks, cell, sizeof(lcs_cell), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->npeaks, &one, sizeof(int), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->d_dbg, 0, sizeof(double) * 2048, c->stream));
+  if ((rc = lcs_launch_sss_only(c, n_cap, thresh2_n_sigma, c->d_dbg))) return rc;
+  std::vector<double> dbg(1292);
+  HIPCHK(c, hipMemcpyAsync(cell_out, c->peaks, sizeof(lcs_cell), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(dbg.data(), c->d_dbg, sizeof(double) * dbg.size(), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (h1_np) std::memcpy(h1_np, &dbg[0], 62 * sizeof(double));
+  if (h2_np) std::memcpy(h2_np, &dbg[62], 62 * sizeof(double));
+  if (h1_nrm) std::memcpy(h1_nrm, &dbg[124], 124 * sizeof(double));
+  if (h2_nrm) std::memcpy(h2_nrm, &dbg[248], 124 * sizeof(double));
+  if (h1_ext) std::memcpy(h1_ext, &dbg[372], 124 * sizeof(double));
+  if (h2_ext) std::memcpy(h2_ext, &dbg[496], 124 * sizeof(double));
+  if (ll_nrm) std::memcpy(ll_nrm, &dbg[620], 336 * sizeof(double));
+  if (ll_ext) std::memcpy(ll_ext, &dbg[956], 336 * sizeof(double));
+  return LCS_OK;
+}
+
+int lcs_pss_sss_foe(lcs_ctx *c, const lcs_cell *cell_in, const double *capbuf, uint32_t n_cap, double fc_req,
+                    double fc_prog, double fs_prog, lcs_cell *cell_out) {
+  if (!c || !cell_in || !cell_out) return LCS_ERR_BAD_ARG;
+  if (n_ofdm_for(cell_in) < 0 || cell_in->n_id_1 < 0 || cell_in->n_id_1 > 167 || cell_in->n_id_2 < 0 || cell_in->n_id_2 > 2) {
+    c->err = "pss_sss_foe needs a cell with n_id_1, n_id_2 and a known cp_type";   // the reference throws (src/searcher.cpp:786)
+    return LCS_ERR_BAD_ARG;
+  }
+  int rc;
+  if ((rc = upload_cap_and_params(c, capbuf, n_cap, fc_req, fc_prog, fs_prog))) return rc;
+  const int one = 1;
+  HIPCHK(c, hipMemcpyAsync(c->peaks, cell_in, sizeof(lcs_cell), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->npeaks, &one, sizeof(int), hipMemcpyHostToDevice, c->stream));
+  if ((rc = lcs_launch_foe_only(c, n_cap))) return rc;
+  HIPCHK(c, hipMemcpyAsync(cell_out, c->peaks, sizeof(lcs_cell), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return LCS_OK;
+}
+
+int lcs_extract_tfg(lcs_ctx *c, const lcs_cell *cell, const double *capbuf, uint32_t n_cap, double fc_req,
+                    double fc_prog, double fs_prog, double *tfg, double *tfg_timestamp, int *n_ofdm) {
+  if (!c || !cell || !tfg || !tfg_timestamp || !n_ofdm) return LCS_ERR_BAD_ARG;
+  const int no = n_ofdm_for(cell);
+  if (no < 0) { c->err = "extract_tfg needs a known cp_type"; return LCS_ERR_BAD_ARG; }   // ref :883 throws
+  int rc;
+  if ((rc = upload_cap_and_params(c, capbuf, n_cap, fc_req, fc_prog, fs_prog))) return rc;
+  if ((rc = put_single_work_item(c, cell, no))) return rc;
+  if ((rc = lcs_launch_tfg(c, n_cap, 1))) return rc;
+  double oob = 0;
+  HIPCHK(c, hipMemcpyAsync(tfg, c->tfg, sizeof(double2) * no * LCS_TFG_NSC, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(tfg_timestamp, c->tfg_ts, sizeof(double) * no, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(&oob, c->cell_scratch + 2, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  *n_ofdm = no;
+  if (oob != 0.0) { c->err = "a DFT window falls outside the capture buffer (the reference would read out of bounds)"; return LCS_ERR_BAD_ARG; }
+  return LCS_OK;
+}
+
+int lcs_tfoec(lcs_ctx *c, const lcs_cell *cell, const double *tfg, const double *tfg_timestamp, int n_ofdm,
+              double fc_req, double fc_prog, double *tfg_comp, double *tfg_comp_timestamp, lcs_cell *cell_out) {
+  if (!c || !cell || !tfg || !tfg_timestamp || !tfg_comp || !tfg_comp_timestamp || !cell_out) return LCS_ERR_BAD_ARG;
+  if (n_ofdm_for(cell) < 0 || n_ofdm < 14 || n_ofdm > LCS_TFG_MAX_OFDM || cell->n_id_1 < 0 || cell->n_id_2 < 0) {
+    c->err = "tfoec needs a detected cell and 14..854 OFDM symbols";
+    return LCS_ERR_BAD_ARG;
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc;
+  if ((rc = ensure_ws(c, 1, std::max<uint32_t>(c->cap_n_cap, 153600), std::max(1, c->cap_n_f), false))) return rc;
+  SlotParams p{fc_req, fc_prog, 0.0};
+  HIPCHK(c, hipMemcpyAsync(c->params, &p, sizeof(p), hipMemcpyHostToDevice, c->stream));
+  if ((rc = put_single_work_item(c, cell, n_ofdm))) return rc;
+  HIPCHK(c, hipMemcpyAsync(c->tfg, tfg, sizeof(double2) * n_ofdm * LCS_TFG_NSC, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->tfg_ts, tfg_timestamp, sizeof(double) * n_ofdm, hipMemcpyHostToDevice, c->stream));
+  if ((rc = lcs_launch_rs_build(c))) return rc;
+  if ((rc = lcs_launch_tfoec(c, 1))) return rc;
+  HIPCHK(c, hipMemcpyAsync(tfg_comp, c->tfg_comp, sizeof(double2) * n_ofdm * LCS_TFG_NSC, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(tfg_comp_timestamp, c->tfg_ts_comp, sizeof(double) * n_ofdm, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(cell_out, c->cells_out, sizeof(lcs_cell), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return LCS_OK;
+}
+
+int lcs_decode_mib(lcs_ctx *c, const lcs_cell *cell, const double *tfg, int n_ofdm, lcs_cell *cell_out) {
+  if (!c || !cell || !tfg || !cell_out) return LCS_ERR_BAD_ARG;
+  const int need = n_ofdm_for(cell);
+  if (need < 0 || n_ofdm != need || cell->n_id_1 < 0 || cell->n_id_2 < 0) {
+    c->err = "decode_mib needs a detected cell and its full 854/732-symbol grid";
+    return LCS_ERR_BAD_ARG;
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc;
+  if ((rc = put_single_work_item(c, cell, n_ofdm))) return rc;
+  HIPCHK(c, hipMemcpyAsync(c->tfg_comp, tfg, sizeof(double2) * n_ofdm * LCS_TFG_NSC, hipMemcpyHostToDevice, c->stream));
+  if ((rc = lcs_launch_rs_build(c))) return rc;
+  if ((rc = lcs_launch_mib(c, 1))) return rc;
+  HIPCHK(c, hipMemcpyAsync(cell_out, c->cells_out, sizeof(lcs_cell), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return LCS_OK;
+}
+
+// One host buffer through the whole chain (ref src/CellSearch.cpp:484-558).
+int lcs_search_capbuf(lcs_ctx *c, const double *capbuf, uint32_t n_cap, const double *f_search_set, uint16_t n_f,
+                      double fc_req, double fc_prog, double fs_prog, lcs_cell *cells, int max_cells, int *n_cells,
+                      lcs_cell *peaks, int max_peaks, int *n_peaks) {
+  int rc = check_common(c, n_cap, n_f);
+  if (rc) return rc;
+  if (!capbuf || !f_search_set || !n_cells || (max_cells > 0 && !cells)) { c->err = "null argument"; return LCS_ERR_BAD_ARG; }
+  HIPCHK(c, hipSetDevice(c->device));
+  if ((rc = ensure_ws(c, 1, n_cap, n_f, false))) return rc;
+  if ((rc = ensure_percell(c))) return rc;
+  const XcGeom geo = make_geo(n_cap, n_f, 2);
+  if ((rc = validate_grid(c, geo, f_search_set, fc_req, fc_prog, fs_prog))) return rc;
+  SlotParams p{fc_req, fc_prog, fs_prog};
+  HIPCHK(c, hipMemcpyAsync(c->cap64, capbuf, sizeof(double2) * n_cap, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->fset, f_search_set, sizeof(double) * n_f, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->params, &p, sizeof(p), hipMemcpyHostToDevice, c->stream));
+  if ((rc = lcs_launch_ingest(c, nullptr, 2, 1, n_cap))) return rc;
+  if ((rc = lcs_launch_xcorr(c, 1, geo, false, false))) return rc;
+  if ((rc = lcs_launch_peak_search(c, 1, geo, std::pow(10.0, -12.0 / 10.0)))) return rc;
+  if ((rc = lcs_launch_sss_foe(c, 1, n_cap, 3.0, nullptr))) return rc;
+  if ((rc = lcs_launch_gather_work(c, 1))) return rc;
+  if ((rc = lcs_launch_tfg(c, n_cap, 0))) return rc;
+  if ((rc = lcs_launch_rs_build(c))) return rc;
+  if ((rc = lcs_launch_tfoec(c, 0))) return rc;
+  if ((rc = lcs_launch_mib(c, 0))) return rc;
+  if ((rc = lcs_launch_scatter_back(c))) return rc;
+  std::vector<lcs_cell> tmp(LCS_MAXP);
+  int np = 0;
+  HIPCHK(c, hipMemcpyAsync(tmp.data(), c->peaks, sizeof(lcs_cell) * LCS_MAXP, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(&np, c->npeaks, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  rc = LCS_OK;
+  if (np > LCS_MAXP) { np = LCS_MAXP; rc = LCS_ERR_OVERFLOW; }
+  int n = 0;
+  for (int i = 0; i < np; ++i) {
+    if (peaks && i < max_peaks) {   // the peak_search view of the record (PSS fields only)
+      lcs_cell pk;
+      lcs_cell_init(&pk);
+      pk.fc_requested = tmp[i].fc_requested; pk.fc_programmed = tmp[i].fc_programmed; pk.pss_pow = tmp[i].pss_pow;
+      pk.ind = tmp[i].ind; pk.freq = tmp[i].freq; pk.n_id_2 = tmp[i].n_id_2;
+      peaks[i] = pk;
+    }
+    if (tmp[i].n_id_1 == -1 || tmp[i].n_rb_dl == -1) continue;
+    if (n < max_cells) cells[n] = tmp[i]; else rc = LCS_ERR_OVERFLOW;
+    ++n;
+  }
+  if (n_peaks) *n_peaks = np;
+  *n_cells = n;
+  if (rc) c->err = "more results than the output arrays hold";
+  return rc;
 }
 
 int lcs_last_xcorr_ms(lcs_ctx *c, float *ms, int *n_launches) {

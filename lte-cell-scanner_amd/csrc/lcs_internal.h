@@ -30,6 +30,7 @@
 #define LCS_MAXP 64          // peaks kept per capture buffer
 #define LCS_MAX_WORK 512     // cells carried into the TFG/MIB stages per batch
 #define LCS_TFG_ROWS 854
+#define LCS_CELL_SCRATCH 4608 // doubles of per-cell scratch (RS table, shifts, noise powers, PBCH candidates)
 
 struct SlotParams {
   double fc_req, fc_prog, fs_prog;
@@ -92,6 +93,9 @@ struct lcs_ctx {
   double2 *d_pss_fd = nullptr;      // [3][62]
   int8_t *d_sss_fd = nullptr;       // [168][3][2][62]
   uint8_t *d_pbch_scr = nullptr;    // [504][1920]
+  uint8_t *d_derm_map = nullptr;    // [2][1920]: coded-bit index (stream*40+col) of every rate-matched PBCH bit
+  double *d_dbg = nullptr;          // debug outputs of the single-cell stage entry points
+  bool percell_ready = false;
   // host staging
   void *h_pinned = nullptr;
   size_t h_pinned_bytes = 0;
@@ -120,6 +124,7 @@ void pss_td(int n_id_2, double *re_im /*137*2*/);
 void sss_fd(int n_id_1, int n_id_2, int slot_num, int32_t *out /*62*/);
 void lte_pn(uint32_t c_init, uint32_t len, uint8_t *out);
 double chi2cdf_inv(double p, double k);
+void pbch_deratematch_map(int n_e, uint8_t *out /*n_e*/);   // ref src/lte_lib.cpp:409-463 via :473-478
 }  // namespace lcs_tables
 
 // ---- kernel launchers (one per .hip file) -------------------------------------------
@@ -131,9 +136,12 @@ int lcs_launch_xc_debug(lcs_ctx *c, const XcGeom &geo);   // raw xc for slot 0 (
 int lcs_launch_peak_search(lcs_ctx *c, int n_buf, const XcGeom &geo, double udb10_m12);
 // sss_foe.hip
 int lcs_launch_sss_foe(lcs_ctx *c, int n_buf, uint32_t n_cap, double thresh2_n_sigma, double *dbg /*device, nullable*/);
+int lcs_launch_sss_only(lcs_ctx *c, uint32_t n_cap, double thresh2_n_sigma, double *dbg);
 int lcs_launch_foe_only(lcs_ctx *c, uint32_t n_cap);
 // tfg_mib.hip
 int lcs_launch_gather_work(lcs_ctx *c, int n_buf);
+int lcs_launch_scatter_back(lcs_ctx *c);
+int lcs_launch_rs_build(lcs_ctx *c);
 int lcs_launch_tfg(lcs_ctx *c, uint32_t n_cap, int n_items /*upper bound*/);
 int lcs_launch_tfoec(lcs_ctx *c, int n_items);
 int lcs_launch_mib(lcs_ctx *c, int n_items);

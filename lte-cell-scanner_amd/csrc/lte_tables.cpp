@@ -137,4 +137,26 @@ double chi2cdf_inv(double p, double k) {
   return lo + hi;   // 2 * midpoint
 }
 
+// Which coded bit (stream r in 0..2, column c in 0..39 -> r*40+c) each of the n_e rate-matched
+// PBCH bits carries: 36.212 5.1.4.2 sub-block interleaver (32 columns, the SAME permutation for
+// all three streams, <NULL> padding in front), bit collection stream after stream, circular
+// selection skipping <NULL>s.
+void pbch_deratematch_map(int n_e, uint8_t *out) {
+  static const int perm[32] = {1, 17, 9, 25, 5, 21, 13, 29, 3, 19, 11, 27, 7, 23, 15, 31,
+                               0, 16, 8, 24, 4, 20, 12, 28, 2, 18, 10, 26, 6, 22, 14, 30};
+  const int D = 40, C = 32, R = (D + C - 1) / C, K = R * C, ND = K - D;
+  std::vector<int> w(3 * K);
+  for (int s = 0; s < 3; ++s)
+    for (int col = 0; col < C; ++col)
+      for (int row = 0; row < R; ++row) {
+        const int y = row * C + perm[col];                 // position in the padded input
+        w[s * K + col * R + row] = (y >= ND) ? s * D + (y - ND) : -1;
+      }
+  int k = 0, j = 0;
+  while (k < n_e) {
+    if (w[j] >= 0) out[k++] = (uint8_t)w[j];
+    j = (j + 1) % (3 * K);
+  }
+}
+
 }  // namespace lcs_tables

@@ -1,0 +1,767 @@
+// tfg_mib.hip -- per-cell stages: time/frequency grid, TFOEC, channel estimate, PBCH/MIB decode.
+//
+// Replaces extract_tfg (ref src/searcher.cpp:857-935), tfoec (:952-1069), chan_est (:1369-1477),
+// ce_interp_hex (:1223-1362), pbch_extract (:1482-1522), decode_mib (:1526-1692) and the
+// helpers they use from src/lte_lib.cpp (RS_DL :305-405, lte_demodulate :612-634,
+// lte_conv_deratematch :469-518, lte_conv_decode :538-551, lte_calc_crc :637-663).
+//
+// All arithmetic is fp64 like the reference.  The cells that survived SSS detection in a whole
+// batch of capture buffers are compacted into one work list; every kernel below is a fixed-size
+// grid that strides over that device-side list, so the chain needs no host round trip.
+#include "lcs_internal.h"
+
+#define FS_LTE 30720000.0
+#define N_RB_MAXDL 110
+#define NSC 72
+#define ROWS LCS_TFG_ROWS
+
+// cell_scratch layout (doubles, per work item)
+#define CS_N_OFDM 0
+#define CS_KFACTOR 1
+#define CS_OOB 2
+#define CS_NP 4          // 4 values
+#define CS_CAND 16       // 12 candidates x 4: ok, bits lo (24 bits as double), unused
+#define CS_SHIFT 64      // [140][4] (-1 = no RS)
+#define CS_RS 1024       // [140][12] complex
+#define CS_SIZE LCS_CELL_SCRATCH
+
+struct cd2 { double re, im; };
+__device__ __forceinline__ cd2 mk(double a, double b) { cd2 r; r.re = a; r.im = b; return r; }
+__device__ __forceinline__ cd2 cadd(cd2 a, cd2 b) { return mk(a.re + b.re, a.im + b.im); }
+__device__ __forceinline__ cd2 csub(cd2 a, cd2 b) { return mk(a.re - b.re, a.im - b.im); }
+__device__ __forceinline__ cd2 cmul(cd2 a, cd2 b) { return mk(a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re); }
+__device__ __forceinline__ cd2 cconj(cd2 a) { return mk(a.re, -a.im); }
+__device__ __forceinline__ cd2 cscale(cd2 a, double s) { return mk(a.re * s, a.im * s); }
+__device__ __forceinline__ cd2 cdivr(cd2 a, double s) { return mk(a.re / s, a.im / s); }
+__device__ __forceinline__ double cabs2(cd2 a) { return a.re * a.re + a.im * a.im; }
+__device__ __forceinline__ cd2 ld(const double2 *p) { const double2 v = *p; return mk(v.x, v.y); }
+__device__ __forceinline__ void st(double2 *p, cd2 v) { *p = make_double2(v.re, v.im); }
+// std::complex division for finite operands (libgcc __divdc3 main path)
+__device__ __forceinline__ cd2 cdiv(cd2 x, cd2 y) {
+  const double a = x.re, b = x.im, c = y.re, d = y.im;
+  if (fabs(c) < fabs(d)) {
+    const double ratio = c / d, denom = (c * ratio) + d;
+    return mk(((a * ratio) + b) / denom, ((b * ratio) - a) / denom);
+  }
+  const double ratio = d / c, denom = (d * ratio) + c;
+  return mk(((b * ratio) + a) / denom, (b - (a * ratio)) / denom);
+}
+__device__ __forceinline__ int d_round_i(double x) { return (int)rint(x); }
+__device__ __forceinline__ int d_imod(int k, int n) { int r = k % n; return r < 0 ? r + n : r; }
+__device__ __forceinline__ int cell_n_symb(const lcs_cell &c) { return c.cp_type == LCS_CP_NORMAL ? 7 : (c.cp_type == LCS_CP_EXTENDED ? 6 : -1); }
+__device__ __forceinline__ int cell_id(const lcs_cell &c) { return (c.n_id_1 >= 0 && c.n_id_2 >= 0) ? c.n_id_2 + 3 * c.n_id_1 : -1; }
+__device__ __forceinline__ int cn_of(int i) { return (i < 36) ? (i - 36) : (i - 35); }
+
+// block-wide sum of a complex value (any order; the reference sums sequentially, the
+// difference is at the 1e-16 relative level)
+__device__ cd2 block_sum(cd2 v, cd2 *red /*>= blockDim/64*/) {
+  for (int off = 32; off > 0; off >>= 1) { v.re += __shfl_down(v.re, off); v.im += __shfl_down(v.im, off); }
+  const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[wave] = v;
+  __syncthreads();
+  cd2 s = mk(0, 0);
+  for (int i = 0; i < nw; ++i) s = cadd(s, red[i]);
+  __syncthreads();
+  return s;
+}
+
+// ----------------------------------------------------------------- work-list compaction
+__global__ void k_gather_work(const lcs_cell *__restrict__ peaks, const int *__restrict__ npeaks, int n_buf,
+                              WorkItem *__restrict__ items, int *__restrict__ n_work, lcs_cell *__restrict__ cells) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  int n = 0;
+  for (int s = 0; s < n_buf; ++s) {
+    const int np = min(npeaks[s], LCS_MAXP);
+    for (int p = 0; p < np; ++p) {
+      const lcs_cell c = peaks[(size_t)s * LCS_MAXP + p];
+      if (c.n_id_1 >= 0 && n < LCS_MAX_WORK) { items[n].slot = s; items[n].peak = p; cells[n] = c; ++n; }
+    }
+  }
+  *n_work = n;
+}
+__global__ void k_scatter_back(lcs_cell *__restrict__ peaks, const WorkItem *__restrict__ items,
+                               const int *__restrict__ n_work, const lcs_cell *__restrict__ cells) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < *n_work) peaks[(size_t)items[i].slot * LCS_MAXP + items[i].peak] = cells[i];
+}
+
+// ------------------------------------------------------------ extract_tfg: timestamps
+// ref :875-889 and the running dft_location of :903-920 (kept sequential: each timestamp is a
+// floating-point running sum).
+__global__ void k_tfg_prep(const lcs_cell *__restrict__ cells, const WorkItem *__restrict__ items,
+                           const int *__restrict__ n_work, const SlotParams *__restrict__ params,
+                           double *__restrict__ ts, double *__restrict__ scratch) {
+  const int it = blockIdx.x * blockDim.x + threadIdx.x;
+  if (it >= *n_work) return;
+  const lcs_cell c = cells[it];
+  const SlotParams p = params[items[it].slot];
+  double *sc = scratch + (size_t)it * CS_SIZE;
+  const double k_factor = (p.fc_req - c.freq_fine) / p.fc_prog;
+  const int n_symb = cell_n_symb(c);
+  double loc;
+  if (c.cp_type == LCS_CP_NORMAL) loc = c.frame_start + 10 * 16 / FS_LTE * p.fs_prog * k_factor;
+  else loc = c.frame_start + 32 * 16 / FS_LTE * p.fs_prog * k_factor;
+  if (loc - .01 * p.fs_prog * k_factor > -0.5) loc = loc - .01 * p.fs_prog * k_factor;
+  const int n_ofdm = 6 * 10 * 2 * n_symb + 2 * n_symb;
+  int sym_num = 0;
+  double *t_out = ts + (size_t)it * ROWS;
+  for (int t = 0; t < n_ofdm; ++t) {
+    t_out[t] = loc;
+    if (n_symb == 6) loc += (128 + 32) * 16 / FS_LTE * p.fs_prog * k_factor;
+    else {
+      if (sym_num == 6) loc += (128 + 10) * 16 / FS_LTE * p.fs_prog * k_factor;
+      else loc += (128 + 9) * 16 / FS_LTE * p.fs_prog * k_factor;
+      sym_num = d_imod(sym_num + 1, 7);
+    }
+  }
+  sc[CS_N_OFDM] = (double)n_ofdm;
+  sc[CS_KFACTOR] = k_factor;
+  sc[CS_OOB] = 0.0;
+}
+
+// ------------------------------------------------------------------ extract_tfg: grid
+// 8 OFDM symbols per workgroup pass: frequency-correct 8x128 samples of the capture buffer into
+// LDS (the reference rotates all 153600 samples per cell, ref :892; only the 854x128 that feed a
+// DFT are touched here, with the same absolute-index phase), direct 72-bin DFT, /sqrt(128),
+// then the sub-sample timing phase ramp (ref :923-931).
+#define TFG_SYM 8
+__global__ __launch_bounds__(256) void k_tfg(const lcs_cell *__restrict__ cells, const WorkItem *__restrict__ items,
+                                             const int *__restrict__ n_work, const SlotParams *__restrict__ params,
+                                             const double2 *__restrict__ cap64, uint32_t n_cap,
+                                             const double *__restrict__ ts, double *__restrict__ scratch,
+                                             double2 *__restrict__ tfg) {
+  __shared__ cd2 W[128];
+  __shared__ cd2 win[TFG_SYM][128];
+  __shared__ int s_loc[TFG_SYM];
+  const int tid = threadIdx.x;
+  if (tid < 128) { double s, c; sincospi((double)tid / 64.0, &s, &c); W[tid] = mk(c, -s); }
+  const int nw = *n_work;
+  const int jobs_per_item = (ROWS + TFG_SYM - 1) / TFG_SYM;
+  for (int job = blockIdx.x; job < nw * jobs_per_item; job += gridDim.x) {
+    const int it = job / jobs_per_item, t0 = (job % jobs_per_item) * TFG_SYM;
+    double *sc = scratch + (size_t)it * CS_SIZE;
+    const int n_ofdm = (int)sc[CS_N_OFDM];
+    const double k_factor = sc[CS_KFACTOR];
+    const lcs_cell c = cells[it];
+    const SlotParams p = params[items[it].slot];
+    const double2 *cap = cap64 + (size_t)items[it].slot * n_cap;
+    const double *tsi = ts + (size_t)it * ROWS;
+    const double kk = M_PI * (-c.freq_fine) / ((p.fs_prog * k_factor) / 2);
+    __syncthreads();
+    if (tid < TFG_SYM) s_loc[tid] = (t0 + tid < n_ofdm) ? d_round_i(tsi[t0 + tid]) : 0;
+    __syncthreads();
+    for (int e = tid; e < TFG_SYM * 128; e += 256) {
+      const int s = e >> 7, n = e & 127;
+      cd2 v = mk(0, 0);
+      if (t0 + s < n_ofdm) {
+        const long src = (long)s_loc[s] + n;
+        if (src >= 0 && (uint64_t)src < n_cap) {
+          const double2 x = cap[src];
+          const double ang = kk * (double)src;
+          v = cmul(mk(x.x, x.y), mk(cos(ang), sin(ang)));
+        } else if (n == 0) sc[CS_OOB] = 1.0;   // the reference would read out of bounds here
+      }
+      win[s][n] = v;
+    }
+    __syncthreads();
+    for (int e = tid; e < TFG_SYM * NSC; e += 256) {
+      const int s = e / NSC, i = e % NSC;
+      const int t = t0 + s;
+      if (t >= n_ofdm) continue;
+      const int bin = (i < 36) ? 92 + i : i - 35;
+      cd2 acc = mk(0, 0);
+      for (int n = 0; n < 128; ++n) acc = cadd(acc, cmul(win[s][n], W[(bin * n) & 127]));
+      acc = cdivr(acc, sqrt(128.0));
+      const double ideal = tsi[t];
+      const double late = (double)d_round_i(ideal) - ideal;
+      double k_im = -1.0;
+      k_im = k_im * 2; k_im = k_im * M_PI; k_im = k_im * late; k_im = k_im / 128;
+      const double ph = k_im * (double)cn_of(i);
+      acc = cmul(acc, mk(cos(ph), sin(ph)));
+      st(&tfg[((size_t)it * ROWS + t) * NSC + i], acc);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------ RS_DL
+// ref src/lte_lib.cpp:305-383: CRS values for the 6 centre RBs and the per-port frequency
+// shifts, for every (slot, symbol) that carries RS.  60 Gold sequences per cell.
+__global__ __launch_bounds__(64) void k_rs_build(const lcs_cell *__restrict__ cells, const int *__restrict__ n_work,
+                                                  double *__restrict__ scratch) {
+  for (int it = blockIdx.x; it < *n_work; it += gridDim.x) {
+    const lcs_cell c = cells[it];
+    double *sc = scratch + (size_t)it * CS_SIZE;
+    const int n_symb = cell_n_symb(c), id = cell_id(c);
+    const int tid = threadIdx.x;
+    if (n_symb < 0 || id < 0) continue;
+    for (int e = tid; e < 140 * 4; e += 64) sc[CS_SHIFT + e] = -1.0;
+    __syncthreads();
+    if (tid < 60) {
+      const int slot = tid / 3, t = tid % 3;
+      const int sym = (t == 2) ? (n_symb - 3) : t;
+      const uint32_t n_cp = (c.cp_type == LCS_CP_NORMAL);
+      const uint32_t c_init = (1u << 10) * (7 * (slot + 1) + sym + 1) * (2 * id + 1) + 2 * id + n_cp;
+      uint32_t x1 = 1, x2 = c_init & 0x7fffffffu;
+      const int first = 2 * (N_RB_MAXDL - 6);           // bit index of c(2m) for m = 104
+      uint32_t bits = 0;                                // c(208..231)
+      for (int i = 0; i < 1600 + first + 24; ++i) {
+        if (i >= 1600 + first) bits |= ((x1 ^ x2) & 1u) << (i - 1600 - first);
+        const uint32_t n1 = ((x1 >> 3) ^ x1) & 1u;
+        const uint32_t n2 = ((x2 >> 3) ^ (x2 >> 2) ^ (x2 >> 1) ^ x2) & 1u;
+        x1 = (x1 >> 1) | (n1 << 30);
+        x2 = (x2 >> 1) | (n2 << 30);
+      }
+      const double isq = 1 / pow(2.0, 0.5);
+      const int row = slot * n_symb + sym;
+      for (int k = 0; k < 12; ++k) {
+        sc[CS_RS + (row * 12 + k) * 2] = isq * (1 - 2 * (int)((bits >> (2 * k)) & 1u));
+        sc[CS_RS + (row * 12 + k) * 2 + 1] = isq * (1 - 2 * (int)((bits >> (2 * k + 1)) & 1u));
+      }
+      for (int port = 0; port < 4; ++port) {
+        int v = -1;
+        if (port == 0 && sym == 0) v = 0;
+        else if (port == 0 && sym == n_symb - 3) v = 3;
+        else if (port == 1 && sym == 0) v = 3;
+        else if (port == 1 && sym == n_symb - 3) v = 0;
+        else if (port == 2 && sym == 1) v = 3 * (slot & 1);
+        else if (port == 3 && sym == 1) v = 3 + 3 * (slot & 1);
+        const bool want = (t == 0 || t == 2) ? (port <= 1) : (port >= 2);
+        if (want && v >= 0) sc[CS_SHIFT + row * 4 + port] = (double)((v + id) % 6);
+      }
+    }
+    __syncthreads();
+  }
+}
+__device__ __forceinline__ cd2 rs_val(const double *sc, int n_symb, int slot, int sym, int k) {
+  const int row = slot * n_symb + sym;
+  return mk(sc[CS_RS + (row * 12 + k) * 2], sc[CS_RS + (row * 12 + k) * 2 + 1]);
+}
+__device__ __forceinline__ int rs_shift(const double *sc, int n_symb, int slot, int sym, int port) {
+  return (int)sc[CS_SHIFT + (slot * n_symb + sym) * 4 + port];
+}
+
+// ------------------------------------------------------------------------------ tfoec
+#define TF_THREADS 512
+__global__ __launch_bounds__(TF_THREADS) void k_tfoec(lcs_cell *__restrict__ cells, const WorkItem *__restrict__ items,
+                                                       const int *__restrict__ n_work,
+                                                       const SlotParams *__restrict__ params,
+                                                       const double2 *__restrict__ tfg, const double *__restrict__ ts,
+                                                       double *__restrict__ scratch, double2 *__restrict__ tfg_comp,
+                                                       double *__restrict__ ts_comp) {
+  __shared__ cd2 red[TF_THREADS / 64];
+  __shared__ cd2 comp[NSC];
+  const int tid = threadIdx.x;
+  for (int it = blockIdx.x; it < *n_work; it += gridDim.x) {
+    const lcs_cell c = cells[it];
+    const SlotParams p = params[items[it].slot];
+    const double *sc = scratch + (size_t)it * CS_SIZE;
+    const int n_symb = cell_n_symb(c);
+    const int n_ofdm = (int)sc[CS_N_OFDM];
+    const int n_slot = n_ofdm / n_symb;
+    const double2 *g = tfg + (size_t)it * ROWS * NSC;
+    double2 *gc = tfg_comp + (size_t)it * ROWS * NSC;
+    const double *tsi = ts + (size_t)it * ROWS;
+    double *tsc = ts_comp + (size_t)it * ROWS;
+    // super-fine FOE (ref :970-989)
+    cd2 part = mk(0, 0);
+    for (int e = tid; e < 2 * 12 * (n_slot - 1); e += TF_THREADS) {
+      const int r = e % (n_slot - 1), col = (e / (n_slot - 1)) % 12, st_ = e / ((n_slot - 1) * 12);
+      const int sym = st_ ? (n_symb - 3) : 0;
+      const int sh0 = rs_shift(sc, n_symb, d_imod(r, 20), sym, 0), sh1 = rs_shift(sc, n_symb, d_imod(r + 1, 20), sym, 0);
+      const cd2 a = cmul(ld(&g[(size_t)(r * n_symb + sym) * NSC + sh0 + 6 * col]), cconj(rs_val(sc, n_symb, d_imod(r, 20), sym, col)));
+      const cd2 b = cmul(ld(&g[(size_t)((r + 1) * n_symb + sym) * NSC + sh1 + 6 * col]), cconj(rs_val(sc, n_symb, d_imod(r + 1, 20), sym, col)));
+      part = cadd(part, cmul(cconj(a), b));
+    }
+    const cd2 foe = block_sum(part, red);
+    const double residual_f = atan2(foe.im, foe.re) / (2 * M_PI) / 0.0005;
+    const double k_res = (p.fc_req - residual_f) / p.fc_prog;
+    // FOC + timing phase ramp (ref :992-1005)
+    for (int t = tid; t < n_ofdm; t += TF_THREADS) tsc[t] = k_res * tsi[t];
+    __syncthreads();
+    for (int e = tid; e < n_ofdm * NSC; e += TF_THREADS) {
+      const int t = e / NSC, i = e % NSC;
+      const double tc = k_res * tsi[t];
+      double a_im = 1.0;
+      a_im = a_im * 2; a_im = a_im * M_PI; a_im = a_im * (-residual_f); a_im = a_im * tc; a_im = a_im / (FS_LTE / 16);
+      const double late = tsi[t] - tc;
+      double k_im = -1.0;
+      k_im = k_im * 2; k_im = k_im * M_PI; k_im = k_im * late; k_im = k_im / 128;
+      const double ph = k_im * (double)cn_of(i);
+      const cd2 v = cmul(ld(&g[e]), mk(cos(a_im), sin(a_im)));
+      st(&gc[e], cmul(v, mk(cos(ph), sin(ph))));
+    }
+    __syncthreads();
+    // TOE (ref :1012-1058)
+    part = mk(0, 0);
+    for (int e = tid; e < (2 * n_slot - 1) * 23; e += TF_THREADS) {
+      const int t = e / 23, j = e % 23;
+      const int cur_sym = (t & 1) ? (n_symb - 3) : 0, cur_slot = d_imod(t >> 1, 20), cur_off = (t >> 1) * n_symb + cur_sym;
+      const int cur_sh = rs_shift(sc, n_symb, 0, cur_sym, 0);
+      const int nxt_sym = ((t + 1) & 1) ? (n_symb - 3) : 0, nxt_slot = d_imod((t + 1) >> 1, 20), nxt_off = ((t + 1) >> 1) * n_symb + nxt_sym;
+      const int nxt_sh = rs_shift(sc, n_symb, 0, nxt_sym, 0);
+      int r1_off, r2_off, r1_sh, r2_sh, r1_sym, r2_sym, r1_slot, r2_slot;
+      if (cur_sh < nxt_sh) { r1_off = cur_off; r1_sh = cur_sh; r1_sym = cur_sym; r1_slot = cur_slot; r2_off = nxt_off; r2_sh = nxt_sh; r2_sym = nxt_sym; r2_slot = nxt_slot; }
+      else { r1_off = nxt_off; r1_sh = nxt_sh; r1_sym = nxt_sym; r1_slot = nxt_slot; r2_off = cur_off; r2_sh = cur_sh; r2_sym = cur_sym; r2_slot = cur_slot; }
+      if (j < 12) {   // toe1: conj(r1v[j]) * r2v[j]
+        const cd2 r1 = cmul(ld(&gc[(size_t)r1_off * NSC + r1_sh + 6 * j]), cconj(rs_val(sc, n_symb, r1_slot, r1_sym, j)));
+        const cd2 r2 = cmul(ld(&gc[(size_t)r2_off * NSC + r2_sh + 6 * j]), cconj(rs_val(sc, n_symb, r2_slot, r2_sym, j)));
+        part = cadd(part, cmul(cconj(r1), r2));
+      } else {        // toe2: conj(r2v[i]) * r1v[i+1], i = 0..10
+        const int i = j - 12;
+        const cd2 r2 = cmul(ld(&gc[(size_t)r2_off * NSC + r2_sh + 6 * i]), cconj(rs_val(sc, n_symb, r2_slot, r2_sym, i)));
+        const cd2 r1 = cmul(ld(&gc[(size_t)r1_off * NSC + r1_sh + 6 * (i + 1)]), cconj(rs_val(sc, n_symb, r1_slot, r1_sym, i + 1)));
+        part = cadd(part, cmul(cconj(r2), r1));
+      }
+    }
+    const cd2 toe = block_sum(part, red);
+    const double delay = -atan2(toe.im, toe.re) / 3 / (2 * M_PI / 128);
+    if (tid < NSC) {
+      double k_im = 1.0;
+      k_im = k_im * 2; k_im = k_im * M_PI; k_im = k_im / 128; k_im = k_im * delay;
+      const double ph = k_im * (double)cn_of(tid);
+      comp[tid] = mk(cos(ph), sin(ph));
+    }
+    __syncthreads();
+    for (int e = tid; e < n_ofdm * NSC; e += TF_THREADS) st(&gc[e], cmul(ld(&gc[e]), comp[e % NSC]));
+    if (tid == 0) cells[it].freq_superfine = c.freq_fine + residual_f;
+    __syncthreads();
+  }
+}
+
+// --------------------------------------------------------------------------- chan_est
+// 3x3 complex solve by LU with partial pivoting (IT++ inv -> LAPACK zgetrf/zgetri in the reference)
+__device__ void solve3(cd2 M[3][3], cd2 V[3], cd2 out[3]) {
+  cd2 A[3][4];
+  for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) A[i][j] = M[i][j]; A[i][3] = V[i]; }
+  for (int col = 0; col < 3; ++col) {
+    int piv = col;
+    double best = fabs(A[col][col].re) + fabs(A[col][col].im);
+    for (int r = col + 1; r < 3; ++r) { const double v = fabs(A[r][col].re) + fabs(A[r][col].im); if (v > best) { best = v; piv = r; } }
+    if (piv != col) for (int j = 0; j < 4; ++j) { const cd2 t = A[col][j]; A[col][j] = A[piv][j]; A[piv][j] = t; }
+    for (int r = col + 1; r < 3; ++r) {
+      const cd2 f = cdiv(A[r][col], A[col][col]);
+      for (int j = col; j < 4; ++j) A[r][j] = csub(A[r][j], cmul(f, A[col][j]));
+    }
+  }
+  for (int i = 2; i >= 0; --i) {
+    cd2 s = A[i][3];
+    for (int j = i + 1; j < 3; ++j) s = csub(s, cmul(A[i][j], out[j]));
+    out[i] = cdiv(s, A[i][i]);
+  }
+}
+// ref include/dsp.h:151-185 interp1 (bisection with round_i midpoint, linear, extrapolating)
+__device__ cd2 interp1_c(const double *X, const cd2 *Y, int n, double x) {
+  if (n == 1) return Y[0];
+  unsigned l = 0, r = (unsigned)n - 1;
+  while (r - l > 1) {
+    const unsigned mid = (unsigned)d_round_i((r + l) / 2.0);
+    if (x >= X[mid]) l = mid; else r = mid;
+  }
+  const cd2 d = csub(Y[r], Y[l]);
+  return cadd(Y[l], cdivr(cscale(d, (x - X[l])), (X[r] - X[l])));
+}
+// ref :1200-1213
+__device__ int hex_extend(double *row_x, cd2 *row_val, int len) {
+  if (row_x[0] != 0) {
+    const cd2 d = csub(row_val[1], row_val[0]);
+    const cd2 v = csub(row_val[0], cdivr(cscale(d, row_x[0]), (row_x[1] - row_x[0])));
+    for (int i = len; i > 0; --i) { row_val[i] = row_val[i - 1]; row_x[i] = row_x[i - 1]; }
+    row_val[0] = v; row_x[0] = 0; ++len;
+  }
+  if (row_x[len - 1] != 71) {
+    const cd2 d = csub(row_val[len - 1], row_val[len - 2]);
+    const cd2 v = cadd(row_val[len - 1], cdivr(cscale(d, (71 - row_x[len - 1])), (row_x[len - 1] - row_x[len - 2])));
+    row_val[len] = v; row_x[len] = 71; ++len;
+  }
+  return len;
+}
+
+#define CE_THREADS 256
+#define CE_MAX_RS 256
+__global__ __launch_bounds__(CE_THREADS) void k_chan_est(const lcs_cell *__restrict__ cells, const int *__restrict__ n_work,
+                                                          const double2 *__restrict__ tfg_comp,
+                                                          double *__restrict__ scratch, double2 *__restrict__ ce) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  cd2 *ce_raw = (cd2 *)smem;                          // [CE_MAX_RS][12]
+  cd2 *ce_filt = ce_raw + CE_MAX_RS * 12;             // [CE_MAX_RS][12]
+  int *rs_set = (int *)(ce_filt + CE_MAX_RS * 12);    // [CE_MAX_RS]
+  cd2 *red = (cd2 *)(rs_set + CE_MAX_RS);             // [4]
+  __shared__ int s_nrs;
+  const int tid = threadIdx.x, port = blockIdx.y;
+  for (int it = blockIdx.x; it < *n_work; it += gridDim.x) {
+    const lcs_cell c = cells[it];
+    double *sc = scratch + (size_t)it * CS_SIZE;
+    const int n_symb = cell_n_symb(c);
+    const int n_ofdm = (int)sc[CS_N_OFDM];
+    const double2 *g = tfg_comp + (size_t)it * ROWS * NSC;
+    double2 *out = ce + (((size_t)it * 4 + port) * ROWS) * NSC;
+    __syncthreads();
+    if (tid == 0) {   // rs_set (ref :1383-1392): sorted union for ports 0/1
+      int n = 0;
+      if (port <= 1) {
+        int a = 0, b = n_symb - 3;
+        while (a <= n_ofdm - 1 || b <= n_ofdm - 1) {
+          if (a <= n_ofdm - 1 && (b > n_ofdm - 1 || a <= b)) { rs_set[n++] = a; a += n_symb; }
+          else { rs_set[n++] = b; b += n_symb; }
+        }
+      } else for (int x = 1; x <= n_ofdm - 1; x += n_symb) rs_set[n++] = x;
+      s_nrs = n;
+    }
+    __syncthreads();
+    const int n_rs = s_nrs;
+    // slot_num advances every 2nd RS row for ports 0/1, every row for ports 2/3 (quirk Q9)
+    const int sh0 = rs_shift(sc, n_symb, 0, d_imod(rs_set[0], n_symb), port);
+    const int sh1 = rs_shift(sc, n_symb, d_imod((port >= 2) ? 1 : 0, 20), d_imod(rs_set[1], n_symb), port);
+    for (int e = tid; e < n_rs * 12; e += CE_THREADS) {
+      const int t = e / 12, i = e % 12;
+      const int slot = (port >= 2) ? (t % 20) : ((t >> 1) % 20);
+      const int sym = d_imod(rs_set[t], n_symb);
+      const int sh = rs_shift(sc, n_symb, slot, sym, port);
+      ce_raw[e] = cmul(ld(&g[(size_t)rs_set[t] * NSC + sh + 6 * i]), cconj(rs_val(sc, n_symb, slot, sym, i)));
+    }
+    __syncthreads();
+    // 7-point hexagonal mean (ref :1431-1467)
+    for (int e = tid; e < n_rs * 12; e += CE_THREADS) {
+      const int t = e / 12, k = e % 12;
+      const bool leftmost = ((sh0 < sh1) ? 1 : 0) ^ (t & 1);
+      cd2 total = mk(0, 0);
+      int n_total = 0;
+      for (int i = k - 1; i <= k + 1; ++i) if (i >= 0 && i <= 11) { total = cadd(total, ce_raw[t * 12 + i]); ++n_total; }
+      int lo, hi;
+      if (sh0 == sh1) { lo = k - 1; hi = k + 1; } else if (leftmost) { lo = k - 1; hi = k; } else { lo = k; hi = k + 1; }
+      if (t != 0) {
+        cd2 s = mk(0, 0);
+        for (int i = lo; i <= hi; ++i) if (i >= 0 && i <= 11) { s = cadd(s, ce_raw[(t - 1) * 12 + i]); ++n_total; }
+        total = cadd(total, s);
+      }
+      if (t != n_rs - 1) {
+        cd2 s = mk(0, 0);
+        for (int i = lo; i <= hi; ++i) if (i >= 0 && i <= 11) { s = cadd(s, ce_raw[(t + 1) * 12 + i]); ++n_total; }
+        total = cadd(total, s);
+      }
+      ce_filt[e] = cdivr(total, (double)n_total);
+    }
+    __syncthreads();
+    // noise power (ref :1470)
+    cd2 part = mk(0, 0);
+    for (int e = tid; e < n_rs * 12; e += CE_THREADS) { const cd2 d = csub(ce_filt[e], ce_raw[e]); part.re += d.re * d.re + d.im * d.im; }
+    const cd2 tot = block_sum(part, red);
+    if (tid == 0) sc[CS_NP + port] = tot.re / (n_rs * 12);
+    // piecewise-planar interpolation between consecutive RS rows (ref :1237-1351): one thread
+    // walks the triangle strip of one row pair exactly as the reference does
+    if (tid < NSC) {   // first RS row: plain 1-D interpolation (ref :1250-1252)
+      double x[16]; cd2 v[16]; int n = 0;
+      for (int xx = sh0; xx <= 71; xx += 6) { x[n] = xx; v[n] = ce_filt[n]; ++n; }
+      n = hex_extend(x, v, n);
+      st(&out[(size_t)rs_set[0] * NSC + tid], interp1_c(x, v, n, (double)tid));
+    }
+    for (int t = tid; t <= n_rs - 2; t += CE_THREADS) {
+      double top_x[16], bot_x[16]; cd2 top_v[16], bot_v[16];
+      const int s_top = (t & 1) ? sh1 : sh0, s_bot = (t & 1) ? sh0 : sh1;
+      int n_top = 0, n_bot = 0;
+      for (int xx = s_top; xx <= 71; xx += 6) { top_x[n_top] = xx; top_v[n_top] = ce_filt[t * 12 + n_top]; ++n_top; }
+      n_top = hex_extend(top_x, top_v, n_top);
+      for (int xx = s_bot; xx <= 71; xx += 6) { bot_x[n_bot] = xx; bot_v[n_bot] = ce_filt[(t + 1) * 12 + n_bot]; ++n_bot; }
+      n_bot = hex_extend(bot_x, bot_v, n_bot);
+      int tx[3], ty[3]; cd2 tv[3];
+      int top_last, bot_last;
+      const int y_top = rs_set[t], y_bot = rs_set[t + 1];
+      if (top_x[1] < bot_x[1]) {
+        tx[0] = (int)top_x[0]; ty[0] = y_top; tv[0] = top_v[0];
+        tx[1] = (int)bot_x[0]; ty[1] = y_bot; tv[1] = bot_v[0];
+        tx[2] = (int)top_x[1]; ty[2] = y_top; tv[2] = top_v[1];
+        top_last = 1; bot_last = 0;
+      } else {
+        tx[0] = (int)bot_x[0]; ty[0] = y_bot; tv[0] = bot_v[0];
+        tx[1] = (int)top_x[0]; ty[1] = y_top; tv[1] = top_v[0];
+        tx[2] = (int)bot_x[1]; ty[2] = y_bot; tv[2] = bot_v[1];
+        top_last = 0; bot_last = 1;
+      }
+      const int spacing = y_bot - y_top;
+      int x_off[16];
+      for (int i = 0; i <= spacing; ++i) x_off[i] = 0;
+      for (int guard = 0; guard < 64; ++guard) {
+        cd2 M[3][3], V[3], abc[3];
+        for (int i = 0; i < 3; ++i) { M[i][0] = mk(tx[i], 0); M[i][1] = mk(ty[i], 0); M[i][2] = mk(1, 0); V[i] = tv[i]; }
+        solve3(M, V, abc);
+        const double x1 = tx[1], x2 = tx[2], y1 = ty[1], y2 = ty[2];
+        const double a_l = (x1 - x2) / (y1 - y2);
+        const double b_l = (y1 * x2 - y2 * x1) / (y1 - y2);
+        for (int r = 1; r <= spacing; ++r) {
+          while ((double)x_off[r] <= a_l * (y_top + r) + b_l) {
+            const cd2 v = cadd(cadd(cscale(abc[0], (double)x_off[r]), cscale(abc[1], (double)(y_top + r))), abc[2]);
+            if (x_off[r] <= 71) st(&out[(size_t)(y_top + r) * NSC + x_off[r]], v);
+            ++x_off[r];
+          }
+        }
+        if (x_off[1] == 72 && x_off[spacing] == 72) break;
+        if (ty[2] == y_top) {
+          tx[0] = tx[1]; ty[0] = ty[1]; tv[0] = tv[1]; tx[1] = tx[2]; ty[1] = ty[2]; tv[1] = tv[2];
+          ++bot_last;
+          if (bot_last >= n_bot) break;
+          tx[2] = (int)bot_x[bot_last]; ty[2] = y_bot; tv[2] = bot_v[bot_last];
+        } else {
+          tx[0] = tx[1]; ty[0] = ty[1]; tv[0] = tv[1]; tx[1] = tx[2]; ty[1] = ty[2]; tv[1] = tv[2];
+          ++top_last;
+          if (top_last >= n_top) break;
+          tx[2] = (int)top_x[top_last]; ty[2] = y_top; tv[2] = top_v[top_last];
+        }
+      }
+    }
+    __syncthreads();
+    // rows outside the RS span copy the nearest RS row (ref :1356-1361)
+    const int first = rs_set[0], last = rs_set[n_rs - 1];
+    for (int e = tid; e < n_ofdm * NSC; e += CE_THREADS) {
+      const int t = e / NSC, i = e % NSC;
+      if (t < first) out[e] = out[(size_t)first * NSC + i];
+      else if (t > last) out[e] = out[(size_t)last * NSC + i];
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------ PBCH decode
+// One workgroup per (cell, candidate): candidate = frame_timing_guess*3 + {1,2,4 ports}.
+#define PB_THREADS 256
+__device__ __forceinline__ double trunc_log(double x) {     // itpp::trunc_log
+  if (x == INFINITY) return log(1.79769313486231570815e+308);
+  if (x <= 0) return log(2.22507385850720138309e-308);
+  return log(x);
+}
+__global__ __launch_bounds__(PB_THREADS) void k_pbch(const lcs_cell *__restrict__ cells, const int *__restrict__ n_work,
+                                                      const double2 *__restrict__ tfg_comp, const double2 *__restrict__ ce,
+                                                      double *__restrict__ scratch, const uint8_t *__restrict__ pbch_scr,
+                                                      const uint8_t *__restrict__ derm_map /*[2][1920]*/) {
+  __shared__ cd2 syms[960];
+  __shared__ double npv[960];
+  __shared__ double e_est[1920];
+  __shared__ double d_est[3][40];
+  __shared__ unsigned long long surv[4][40], best_surv[4][40];
+  __shared__ double w_best[4];
+  __shared__ int w_best_ss[4];
+  __shared__ unsigned char c_est[40];
+  const int tid = threadIdx.x, cand = blockIdx.y;
+  const int guess = cand / 3, n_ports = (cand % 3 == 2) ? 4 : (cand % 3) + 1;
+  for (int it = blockIdx.x; it < *n_work; it += gridDim.x) {
+    const lcs_cell c = cells[it];
+    double *sc = scratch + (size_t)it * CS_SIZE;
+    const int n_symb = cell_n_symb(c), id = cell_id(c);
+    const int m_bit = (c.cp_type == LCS_CP_NORMAL) ? 1920 : 1728;
+    const int n_sym = m_bit / 2, per_frame = n_sym / 4;
+    const int v3 = d_imod(id, 3);
+    const int r0 = (v3 == 0) ? 1 : 0, r1 = (v3 == 2) ? 1 : 2;     // the two residues != v3, ascending
+    const double2 *g = tfg_comp + (size_t)it * ROWS * NSC;
+    const double2 *cep = ce + ((size_t)it * 4) * ROWS * NSC;
+    const double np0 = sc[CS_NP + 0], np1 = sc[CS_NP + 1], np2 = sc[CS_NP + 2], np3 = sc[CS_NP + 3];
+    const int start = guess * 10 * 2 * n_symb;
+    __syncthreads();
+    // pbch_extract (ref :1503-1520) + equalisation (ref :1571-1612), one symbol pair per thread
+    for (int pr = tid; pr < n_sym / 2; pr += PB_THREADS) {
+      cd2 x[2], h[4][2];
+      for (int q = 0; q < 2; ++q) {
+        const int idx = 2 * pr + q;
+        const int fr = idx / per_frame;
+        int rem = idx % per_frame, sym;
+        const int n3 = (n_symb == 6) ? 48 : 72;
+        if (rem < 48) sym = 0; else if (rem < 96) { sym = 1; rem -= 48; } else if (rem < 168) { sym = 2; rem -= 96; } else { sym = 3; rem -= 168; }
+        const bool has_rs = (sym == 0) || (sym == 1) || (sym == 3 && n_symb == 6);
+        (void)n3;
+        const int scx = has_rs ? (3 * (rem / 2) + ((rem & 1) ? r1 : r0)) : rem;
+        const int row = start + fr * 10 * 2 * n_symb + n_symb + sym;
+        x[q] = ld(&g[(size_t)row * NSC + scx]);
+        for (int pp = 0; pp < 4; ++pp) h[pp][q] = ld(&cep[((size_t)pp * ROWS + row) * NSC + scx]);
+      }
+      const int t = 2 * pr;
+      if (n_ports == 1) {
+        for (int q = 0; q < 2; ++q) {
+          const cd2 gain = cconj(cdiv(h[0][q], mk(cabs2(h[0][q]), 0)));
+          syms[t + q] = cmul(x[q], gain);
+          npv[t + q] = np0 * cabs2(gain);
+        }
+      } else {
+        cd2 h1, h2;
+        double np_temp;
+        if (n_ports == 2) { h1 = cdivr(cadd(h[0][0], h[0][1]), 2); h2 = cdivr(cadd(h[1][0], h[1][1]), 2); np_temp = (np0 + np1) / 2; }
+        else if ((t & 3) == 0) { h1 = cdivr(cadd(h[0][0], h[0][1]), 2); h2 = cdivr(cadd(h[2][0], h[2][1]), 2); np_temp = (np0 + np2) / 2; }
+        else { h1 = cdivr(cadd(h[1][0], h[1][1]), 2); h2 = cdivr(cadd(h[3][0], h[3][1]), 2); np_temp = (np1 + np3) / 2; }
+        const double scale = h1.re * h1.re + h1.im * h1.im + h2.re * h2.re + h2.im * h2.im;
+        const cd2 s0 = cdivr(cadd(cmul(cconj(h1), x[0]), cmul(h2, cconj(x[1]))), scale);
+        const cd2 s1 = cconj(cdivr(cadd(cmul(mk(-h2.re, h2.im), x[0]), cmul(h1, cconj(x[1]))), scale));
+        const double a1 = hypot(h1.re, h1.im) / scale, a2 = hypot(h2.re, h2.im) / scale;
+        const double npp = (a1 * a1 + a2 * a2) * np_temp;
+        const double s2 = pow(2.0, 0.5);
+        syms[t] = cscale(s0, s2); syms[t + 1] = cscale(s1, s2);
+        npv[t] = npp; npv[t + 1] = npp;
+      }
+    }
+    __syncthreads();
+    // soft demodulation: exact log-MAP as itpp::Modulator::demodulate_soft_bits (LOGMAP) with
+    // rx = sym/sqrt(np), channel = 1/sqrt(np), N0 = 1 (ref src/lte_lib.cpp:628-631); descramble
+    for (int l = tid; l < n_sym; l += PB_THREADS) {
+      const double a = 1 / sqrt(2.0);
+      const cd2 gain = cdiv(mk(1.0, 0), mk(sqrt(npv[l]), 0));
+      const cd2 rx = cmul(syms[l], gain);
+      double metric[4];
+      for (int j = 0; j < 4; ++j) {
+        const cd2 S = mk((j & 2) ? -a : a, (j & 1) ? -a : a);
+        metric[j] = exp(-cabs2(csub(rx, cmul(gain, S))) / 1);
+      }
+      double l0 = trunc_log(metric[0] + metric[1]) - trunc_log(metric[2] + metric[3]);
+      double l1 = trunc_log(metric[0] + metric[2]) - trunc_log(metric[1] + metric[3]);
+      const uint8_t *scr = pbch_scr + (size_t)id * 1920;
+      if (scr[2 * l]) l0 = -l0;
+      if (scr[2 * l + 1]) l1 = -l1;
+      e_est[2 * l] = l0; e_est[2 * l + 1] = l1;
+    }
+    __syncthreads();
+    // de-ratematch: average all observations of each coded bit (ref src/lte_lib.cpp:497-509)
+    if (tid < 120) {
+      const uint8_t *map = derm_map + ((m_bit == 1920) ? 0 : 1920);
+      double s = 0; int cnt = 0;
+      for (int t = 0; t < m_bit; ++t) if (map[t] == tid) { s += e_est[t]; ++cnt; }
+      if (cnt > 1) s = s / cnt;
+      d_est[tid / 40][tid % 40] = s;
+    }
+    __syncthreads();
+    // tail-biting Viterbi, K=7, G=(133,171,165)o: one trellis per start state with the end state
+    // forced equal; lane = trellis state, each of the 4 waves takes 16 start states.
+    {
+      const int wave = tid >> 6, s = tid & 63;
+      double wbest = INFINITY; int wbest_ss = -1;
+      for (int q = 0; q < 16; ++q) {
+        const int ss = wave * 16 + q;
+        double pm = (s == ss) ? 0.0 : INFINITY;
+        for (int t = 0; t < 40; ++t) {
+          // new state s <- predecessors p0 = (s<<1)&63, p1 = p0|1 with input bit b = s>>5
+          const int b = s >> 5, p0 = (s << 1) & 63, p1 = p0 | 1;
+          const double pm0 = __shfl(pm, p0), pm1 = __shfl(pm, p1);
+          const int reg0 = (b << 6) | p0, reg1 = (b << 6) | p1;
+          double m0 = pm0, m1 = pm1;
+          const double rr0 = d_est[0][t], rr1 = d_est[1][t], rr2 = d_est[2][t];
+          m0 += (__popc(reg0 & 0133) & 1) ? rr0 : -rr0; m0 += (__popc(reg0 & 0171) & 1) ? rr1 : -rr1; m0 += (__popc(reg0 & 0165) & 1) ? rr2 : -rr2;
+          m1 += (__popc(reg1 & 0133) & 1) ? rr0 : -rr0; m1 += (__popc(reg1 & 0171) & 1) ? rr1 : -rr1; m1 += (__popc(reg1 & 0165) & 1) ? rr2 : -rr2;
+          const bool take1 = m1 < m0;          // ties keep the lower-numbered predecessor
+          pm = take1 ? m1 : m0;
+          const unsigned long long bal = __ballot(take1);
+          if (s == 0) surv[wave][t] = bal;
+        }
+        const double fin = __shfl(pm, ss);
+        if (fin < wbest) {
+          wbest = fin; wbest_ss = ss;
+          if (s < 40) best_surv[wave][s] = surv[wave][s];
+        }
+      }
+      if (s == 0) { w_best[wave] = wbest; w_best_ss[wave] = wbest_ss; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int bw = 0;
+      for (int w = 1; w < 4; ++w) if (w_best[w] < w_best[bw]) bw = w;
+      int ok = 0;
+      unsigned bits24 = 0;
+      if (w_best_ss[bw] >= 0) {
+        int s = w_best_ss[bw];
+        for (int t = 39; t >= 0; --t) {
+          c_est[t] = (unsigned char)((s >> 5) & 1);
+          const int dec = (int)((best_surv[bw][t] >> s) & 1ull);
+          s = ((s << 1) & 63) | dec;
+        }
+        // CRC-16 (x^16+x^12+x^5+1, zero init) over the 24 payload bits, antenna-port mask
+        unsigned char buf[40];
+        for (int i = 0; i < 40; ++i) buf[i] = (i < 24) ? c_est[i] : 0;
+        const unsigned char poly[17] = {1, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+        for (int i = 0; i < 24; ++i) if (buf[i]) for (int j = 0; j < 17; ++j) buf[i + j] ^= poly[j];
+        ok = 1;
+        for (int t = 0; t < 16; ++t) {
+          int crc = buf[24 + t];
+          if (n_ports == 2) crc = 1 - crc;
+          else if (n_ports == 4 && (t & 1)) crc = 1 - crc;
+          if (crc != c_est[24 + t]) ok = 0;
+        }
+        for (int i = 0; i < 24; ++i) bits24 |= (unsigned)c_est[i] << i;
+      }
+      sc[CS_CAND + cand * 4 + 0] = (double)ok;
+      sc[CS_CAND + cand * 4 + 1] = (double)bits24;
+    }
+    __syncthreads();
+  }
+}
+
+// first passing candidate in the reference's loop order wins (ref :1547, :1567, :1638-1686)
+__global__ void k_mib_select(lcs_cell *__restrict__ cells, const int *__restrict__ n_work, const double *__restrict__ scratch) {
+  const int it = blockIdx.x * blockDim.x + threadIdx.x;
+  if (it >= *n_work) return;
+  const double *sc = scratch + (size_t)it * CS_SIZE;
+  if (sc[CS_OOB] != 0.0) return;
+  for (int cand = 0; cand < 12; ++cand) {
+    if (sc[CS_CAND + cand * 4] == 0.0) continue;
+    const unsigned bits = (unsigned)sc[CS_CAND + cand * 4 + 1];
+    const int guess = cand / 3, n_ports = (cand % 3 == 2) ? 4 : (cand % 3) + 1;
+    lcs_cell c = cells[it];
+    auto bit = [&](int i) { return (int)((bits >> i) & 1u); };
+    c.n_ports = n_ports;
+    const int bw = bit(0) * 4 + bit(1) * 2 + bit(2);
+    const int bwt[6] = {6, 15, 25, 50, 75, 100};
+    if (bw < 6) c.n_rb_dl = bwt[bw];
+    c.phich_duration = bit(3) ? 2 : 1;
+    c.phich_resource = 1 + bit(4) * 2 + bit(5);
+    const signed char sfn_temp = (signed char)(128 * bit(6) + 64 * bit(7) + 32 * bit(8) + 16 * bit(9) + 8 * bit(10) + 4 * bit(11) + 2 * bit(12) + bit(13));   // quirk Q10
+    c.sfn = d_imod((int)sfn_temp * 4 - guess, 1024);
+    cells[it] = c;
+    return;
+  }
+}
+
+// ------------------------------------------------------------------------------ launch
+#define GRID_ITEMS 256
+int lcs_launch_gather_work(lcs_ctx *c, int n_buf) {
+  hipLaunchKernelGGL(k_gather_work, dim3(1), dim3(64), 0, c->stream, c->peaks, c->npeaks, n_buf, c->work_items, c->n_work,
+                     c->cells_out);
+  HIPCHK(c, hipGetLastError());
+  return LCS_OK;
+}
+int lcs_launch_scatter_back(lcs_ctx *c) {
+  hipLaunchKernelGGL(k_scatter_back, dim3((LCS_MAX_WORK + 255) / 256), dim3(256), 0, c->stream, c->peaks, c->work_items,
+                     c->n_work, c->cells_out);
+  HIPCHK(c, hipGetLastError());
+  return LCS_OK;
+}
+int lcs_launch_tfg(lcs_ctx *c, uint32_t n_cap, int n_items) {
+  (void)n_items;
+  hipLaunchKernelGGL(k_tfg_prep, dim3((LCS_MAX_WORK + 63) / 64), dim3(64), 0, c->stream, c->cells_out, c->work_items,
+                     c->n_work, c->params, c->tfg_ts, c->cell_scratch);
+  hipLaunchKernelGGL(k_tfg, dim3(2048), dim3(256), 0, c->stream, c->cells_out, c->work_items, c->n_work, c->params,
+                     c->cap64, n_cap, c->tfg_ts, c->cell_scratch, c->tfg);
+  HIPCHK(c, hipGetLastError());
+  return LCS_OK;
+}
+int lcs_launch_rs_build(lcs_ctx *c) {
+  hipLaunchKernelGGL(k_rs_build, dim3(GRID_ITEMS), dim3(64), 0, c->stream, c->cells_out, c->n_work, c->cell_scratch);
+  HIPCHK(c, hipGetLastError());
+  return LCS_OK;
+}
+int lcs_launch_tfoec(lcs_ctx *c, int n_items) {
+  (void)n_items;
+  hipLaunchKernelGGL(k_tfoec, dim3(GRID_ITEMS), dim3(TF_THREADS), 0, c->stream, c->cells_out, c->work_items, c->n_work,
+                     c->params, c->tfg, c->tfg_ts, c->cell_scratch, c->tfg_comp, c->tfg_ts_comp);
+  HIPCHK(c, hipGetLastError());
+  return LCS_OK;
+}
+int lcs_launch_mib(lcs_ctx *c, int n_items) {
+  (void)n_items;
+  const size_t smem = sizeof(double) * 2 * CE_MAX_RS * 12 * 2 + sizeof(int) * CE_MAX_RS + sizeof(double) * 2 * 4 + 64;
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIPCHK(c, hipFuncSetAttribute((const void *)k_chan_est, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_chan_est, dim3(GRID_ITEMS, 4), dim3(CE_THREADS), smem, c->stream, c->cells_out, c->n_work,
+                     c->tfg_comp, c->cell_scratch, c->ce);
+  hipLaunchKernelGGL(k_pbch, dim3(GRID_ITEMS, 12), dim3(PB_THREADS), 0, c->stream, c->cells_out, c->n_work, c->tfg_comp,
+                     c->ce, c->cell_scratch, c->d_pbch_scr, c->d_derm_map);
+  hipLaunchKernelGGL(k_mib_select, dim3((LCS_MAX_WORK + 63) / 64), dim3(64), 0, c->stream, c->cells_out, c->n_work,
+                     c->cell_scratch);
+  HIPCHK(c, hipGetLastError());
+  return LCS_OK;
+}
