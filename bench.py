@@ -63,7 +63,7 @@ def cpu_baseline(pkg, iq_u8, f, fc, stage):
         r = O.xcorr_pss(cap, f, 2, fc, fc, FS)
         peaks = O.peak_search(r["pow"], r["frq"], O.z_th1(r["sp_incoherent"], r["n_comb_xc"]), f, fc, fc, r["single"], 2)
     dt = time.perf_counter() - t0
-    ncpu = os.cpu_count() or 1
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     O.set_threads(ncpu)
     t0 = time.perf_counter()
     if stage == "full":

@@ -1,0 +1,88 @@
+"""Synthetic capture buffers: CPU check that the generator produces what the oracle decodes,
+GPU check that the product chain and the oracle agree on them (cases the shipped vectors lack:
+extended CP, 1 and 4 antenna ports, other bandwidths, negative offsets, two cells, empty)."""
+import numpy as np
+import pytest
+
+import oracle as O
+from conftest import load_pkg
+
+FS = 1.92e6
+FC = 739e6
+
+CASES = [
+    dict(cells=[dict(n_id_1=92, n_id_2=1, f_off=35e3, t0=1000.3)], snr=10),
+    dict(cells=[dict(n_id_1=10, n_id_2=2, cp_normal=False, n_ports=1, n_rb_dl=25, f_off=-52e3, phich_duration_ext=1, phich_res=0)], snr=5),
+    dict(cells=[dict(n_id_1=167, n_id_2=0, n_ports=4, n_rb_dl=100, f_off=12e3, phich_res=3)], snr=8),
+    dict(cells=[dict(n_id_1=5, n_id_2=0, f_off=20e3), dict(n_id_1=77, n_id_2=2, f_off=21e3, gain_db=-4, n_rb_dl=6)], snr=12),
+    dict(cells=[], snr=0),
+    dict(cells=[dict(n_id_1=33, n_id_2=1, cp_normal=False, n_ports=2, n_rb_dl=15, f_off=-3e3, t0=19100.7)], snr=3),
+    dict(cells=[dict(n_id_1=120, n_id_2=2, n_ports=2, n_rb_dl=75, f_off=71e3, t0=2.2)], snr=-3),
+]
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    return load_pkg()
+
+
+def _gen(pkg, i):
+    cs = CASES[i]
+    return pkg.synth.make_capbuf(100 + i, FC, cs["cells"], cs["snr"])
+
+
+def _truth_key(t):
+    return (t["n_id_cell"], t.get("n_ports", 2), t.get("n_rb_dl", 50), 1 if t.get("cp_normal", True) else 2,
+            2 if t.get("phich_duration_ext", 0) else 1, 1 + t.get("phich_res", 2))
+
+
+@pytest.mark.parametrize("i", [1, 3])
+def test_oracle_decodes_synthetic_cells(pkg, i):
+    O.set_legacy(False)
+    O.set_threads(8)
+    iq, truth = _gen(pkg, i)
+    f = pkg.f_search_set_for(FC, 100)
+    cells, _ = O.search_capbuf(pkg.synth.iq_u8_to_complex(iq), f, FC, FC, FS)
+    got = sorted((c.n_id_cell(), c.n_ports, c.n_rb_dl, c.cp_type, c.phich_duration, c.phich_resource) for c in cells)
+    assert got == sorted(_truth_key(t) for t in truth)
+    for c in cells:
+        t = [t for t in truth if t["n_id_cell"] == c.n_id_cell()][0]
+        assert abs(c.freq_superfine - t["f_off"]) < 60.0
+
+
+def test_pbch_encoder_blocks():
+    pkg = load_pkg()
+    s = pkg.synth
+    # CRC of all-zero payload is zero; tail-biting encoder output length; rate matching repeats 16x
+    assert not s.crc16(np.zeros(24, np.uint8)).any()
+    d = s.conv_encode_tailbite(np.r_[np.ones(1, np.uint8), np.zeros(39, np.uint8)])
+    assert d.shape == (3, 40) and d.sum() == 5 + 5 + 5    # weights of 133, 171, 165 (octal)
+    e = s.conv_ratematch(np.arange(120).reshape(3, 40) % 2, 1920)
+    assert e.size == 1920
+    assert s.pbch_symbols(277, 2, 50, 0, 2, 128, True).size == 960
+    assert s.pbch_symbols(277, 2, 50, 0, 2, 128, False).size == 864
+
+
+@pytest.mark.gpu
+def test_gpu_chain_matches_oracle_on_synthetic_batch(pkg):
+    import os
+    import torch
+    O.set_legacy(False)
+    O.set_threads(min(16, os.cpu_count() or 1))
+    f = pkg.f_search_set_for(FC, 100)
+    bufs, truths = zip(*[_gen(pkg, i) for i in range(len(CASES))])
+    d = torch.from_numpy(np.stack(bufs)).cuda()
+    with pkg.Searcher(0) as S:
+        res = S.search_batch(d.data_ptr(), pkg.FMT_IQ_U8, len(bufs), 153600, f, FC, FC, FS, pkg.STAGE_FULL)
+        pss_only = S.search_batch(d.data_ptr(), pkg.FMT_IQ_U8, len(bufs), 153600, f, FC, FC, FS, pkg.STAGE_PSS)
+    for b, (iq, truth) in enumerate(zip(bufs, truths)):
+        co, po = O.search_capbuf(pkg.synth.iq_u8_to_complex(iq), f, FC, FC, FS)
+        assert [(p.n_id_2, p.ind, p.freq) for p in pss_only[b]] == [(p.n_id_2, p.ind, p.freq) for p in po], b
+        got = res[b]
+        assert len(got) == len(co), (b, [c.n_id_cell() for c in got], [c.n_id_cell() for c in co])
+        for x, y in zip(got, co):
+            for k in ("ind", "n_id_2", "n_id_1", "cp_type", "n_ports", "n_rb_dl", "phich_duration", "phich_resource", "sfn"):
+                assert getattr(x, k) == getattr(y, k), (b, k)
+            assert abs(x.frame_start - y.frame_start) < 1e-6 and abs(x.freq_superfine - y.freq_superfine) < 1e-3
+        assert sorted((c.n_id_cell(), c.n_ports, c.n_rb_dl, c.cp_type, c.phich_duration, c.phich_resource) for c in got) == \
+            sorted(_truth_key(t) for t in truth), b
