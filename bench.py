@@ -94,6 +94,9 @@ def main():
     ap.add_argument("--ppm", type=float, default=100.0)
     ap.add_argument("--stage", choices=["pss", "full"], default="pss")
     ap.add_argument("--variant", type=int, default=0, help="0 = MFMA-f32 correlation kernel, 1 = VALU kernel")
+    ap.add_argument("--pipeline", type=int, default=2,
+                    help="contexts (streams + workspaces) used round-robin: with 2, the latency-bound per-cell "
+                         "stages of step i overlap the PSS correlation of step i+1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -122,13 +125,25 @@ def main():
     fcs = FC + 100e3 * (np.arange(B) + rank * B)
     host = synth_batch(pkg, B, 1234 + rank, fcs)
     d_cap = torch.from_numpy(host).to(dev)            # inputs resident in HBM before timing starts
-    S = pkg.Searcher(local_rank if world > 1 else 0)
-    S.set_xcorr_variant(args.variant)
+    ctxs = [pkg.Searcher(local_rank if world > 1 else 0) for _ in range(max(1, args.pipeline))]
+    for S in ctxs:
+        S.set_xcorr_variant(args.variant)
     MAXC = 16
     gather_buf = torch.zeros((world, B, 1 + MAXC * 4), dtype=torch.float64, device=dev) if world > 1 else None
 
-    def step():
-        res = S.search_batch(d_cap.data_ptr(), pkg.FMT_IQ_U8, B, N_CAP, f, fcs, fcs, FS, stage_mask, MAXC)
+    host_t = {"enqueue": 0.0, "collect": 0.0, "n": 0}
+
+    def enqueue(i):
+        t = time.perf_counter()
+        ctxs[i % len(ctxs)].batch_enqueue(d_cap.data_ptr(), pkg.FMT_IQ_U8, B, N_CAP, f, fcs, fcs, FS, stage_mask)
+        host_t["enqueue"] += time.perf_counter() - t
+
+    def collect(i):
+        t = time.perf_counter()
+        res = ctxs[i % len(ctxs)].batch_collect(B, MAXC)
+        host_t["collect"] += time.perf_counter() - t
+        host_t["n"] += 1
+        host_t.setdefault("stamps", []).append(time.perf_counter())
         if world > 1:   # RCCL all-gather of the detected-cell list (fixed-size records), nothing else
             mine = torch.zeros((B, 1 + MAXC * 4), dtype=torch.float64)
             for b, cells in enumerate(res):
@@ -138,16 +153,36 @@ def main():
             dist.all_gather_into_tensor(gather_buf.view(-1), mine.to(dev).view(-1))
         return res
 
-    for _ in range(args.warmup):
-        res = step()
+    def run(n_steps, xc_ms=None):
+        """n_steps steps, software-pipelined over the contexts: step i is enqueued before step
+        i-(depth-1) is collected, so nothing but the stream of the collected step ever blocks."""
+        depth = len(ctxs)
+        res = None
+        for i in range(n_steps + depth - 1):
+            if i < n_steps:
+                enqueue(i)
+            j = i - (depth - 1)
+            if j >= 0:
+                res = collect(j)
+                if xc_ms is not None:
+                    xc_ms.append(ctxs[j % depth].last_xcorr_ms()[0])
+        return res
+
+    # Pre-conditioning (untimed, like the warm-up): a fresh process shows one ~50 ms stall in its
+    # first few hundred milliseconds of GPU activity (clock / power-state ramp); keep the GPU
+    # busy for ~0.6 s so that it does not land in the timed steps of a short run.
+    t_pre = time.perf_counter()
+    while time.perf_counter() - t_pre < 0.6:
+        run(2)
+    host_t.update(enqueue=0.0, collect=0.0, n=0, stamps=[])
+    if args.warmup:
+        res = run(args.warmup)
     xc_ms = []
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = step()
-        xc_ms.append(S.last_xcorr_ms()[0])
+    res = run(args.steps, xc_ms)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -158,6 +193,12 @@ def main():
         dt = float(t.item())
 
     n_peaks = sum(len(r) for r in res)
+    # the dominant kernel once more, alone on the GPU (no overlap with the other context's kernels)
+    iso_ms = []
+    for _ in range(3):
+        ctxs[0].batch_enqueue(d_cap.data_ptr(), pkg.FMT_IQ_U8, B, N_CAP, f, fcs, fcs, FS, pkg.STAGE_PSS)
+        ctxs[0].batch_collect(B, MAXC)
+        iso_ms.append(ctxs[0].last_xcorr_ms()[0])
     if rank == 0:
         n_f = f.size
         value = world * B * args.steps / dt
@@ -179,12 +220,18 @@ def main():
                                    f", one MI355X per rank, {B} x 153600-sample capbufs per step, fc 739 MHz + 100 kHz raster",
                        "n_f": int(n_f), "batch_per_gpu": B, "stage": args.stage, "ingest": "u8 I/Q resident in HBM",
                        "xcorr_kernel": "mfma_f32_16x16x4" if args.variant == 0 else "valu_f32",
+                       "pipeline_depth": len(ctxs),
                        "parallelism": f"carrier-sweep shard x{world}, RCCL all-gather of cell list" if world > 1 else "single GPU",
                        "baseline_note": "vs_baseline = value / (1 buffer per ~6 s), doc/CellSearch.html:52-54 (dual-core i7-2640, ppm 100)",
-                       "n_peaks_last_step": n_peaks},
+                       "n_peaks_last_step": n_peaks,
+                       "step_done_ms": [round(1e3 * (x - t0), 2) for x in host_t.get("stamps", [])[-args.steps:]],
+                       "host_ms_per_step": {"enqueue": 1e3 * host_t["enqueue"] / max(1, host_t["n"]),
+                                            "collect_incl_wait": 1e3 * host_t["collect"] / max(1, host_t["n"])}},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_TFLOPS, "traffic": None,
                          "kernel": "k_xcorr_mfma" if args.variant == 0 else "k_xcorr_valu", "kernel_ms": k_ms,
+                         "kernel_ms_isolated": float(np.mean(iso_ms)),
+                         "frac_isolated": flops_per_buf * B / (float(np.mean(iso_ms)) * 1e-3) / 1e12 / PEAK_FP32_TFLOPS,
                          "flops_per_launch": flops_per_buf * B,
                          "achieved_consumed_lags_only": flops_consumed * B / (k_ms * 1e-3) / 1e12,
                          "hbm_algorithmic_GBps": bytes_per_buf * B / (k_ms * 1e-3) / 1e9, "hbm_peak_GBps": 8000.0},
@@ -192,7 +239,8 @@ def main():
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pkg, host[0], f, float(fcs[0]), args.stage)
         print(json.dumps(out))
-    S.close()
+    for S in ctxs:
+        S.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -3,6 +3,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <algorithm>
 
 #include "lcs_internal.h"
@@ -61,7 +62,9 @@ int ensure_ws(lcs_ctx *c, int n_slots, uint32_t n_cap, int n_f, bool debug) {
   A(smin, S * LCS_NW_MAX * LCS_G_MAX);
   A(kp2, S * LCS_NW_MAX * LCS_G_MAX);
   A(btab, S * LCS_NW_MAX * G * LCS_KP2_MAX * 64);
-  A(single, S * NE * n_f);
+  A(single, S * G * LCS_N_IDX * LCS_TG);
+  A(sref, NE * n_f);
+  A(sp, S * LCS_NW_MAX * LCS_N_IDX);
   A(pow_, S * NE);
   A(work, S * NE);
   A(frq, S * NE);
@@ -71,7 +74,6 @@ int ensure_ws(lcs_ctx *c, int n_slots, uint32_t n_cap, int n_f, bool debug) {
   A(npeaks, S);
   if (debug) {
     A(incoh, S * NE * n_f);
-    A(sp, S * LCS_NW_MAX * LCS_N_IDX);
   }
 #undef A
   c->cap_slots = n_slots;
@@ -154,9 +156,29 @@ int lcs_create(int device, lcs_ctx **out) {
   if (hipSetDevice(device) != hipSuccess) return LCS_ERR_NO_DEVICE;
   lcs_ctx *c = new lcs_ctx();
   c->device = device;
-  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return LCS_ERR_HIP; }
+  // Two streams per context: the correlation kernel goes to a LOW-priority stream, everything
+  // else (small, latency-bound kernels) to a HIGH-priority one, so that when two contexts are
+  // used round-robin the tail of batch i is not starved by the correlation of batch i+1.
+  int prio_least = 0, prio_greatest = 0;
+  (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+  if (getenv("LCS_NO_PRIO")) prio_least = prio_greatest = 0;   // measurement knob
+  bool ok_streams = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_greatest) == hipSuccess;
+  const char *rsv = getenv("LCS_RESERVE_CUS");   // measurement knob: keep N CUs free of the correlation kernel
+  if (ok_streams && rsv && atoi(rsv) > 0) {
+    hipDeviceProp_t prop;
+    (void)hipGetDeviceProperties(&prop, device);
+    const int n_cu = prop.multiProcessorCount, keep = n_cu - atoi(rsv);
+    std::vector<uint32_t> mask((n_cu + 31) / 32, 0u);
+    for (int i = 0; i < keep; ++i) mask[i / 32] |= 1u << (i % 32);
+    ok_streams = hipExtStreamCreateWithCUMask(&c->stream_xc, (uint32_t)mask.size(), mask.data()) == hipSuccess;
+  } else if (ok_streams) {
+    ok_streams = hipStreamCreateWithPriority(&c->stream_xc, hipStreamNonBlocking, prio_least) == hipSuccess;
+  }
+  if (!ok_streams) { lcs_destroy(c); return LCS_ERR_HIP; }
   (void)hipEventCreate(&c->ev_xc0);
   (void)hipEventCreate(&c->ev_xc1);
+  (void)hipEventCreateWithFlags(&c->ev_pre, hipEventDisableTiming);
+  (void)hipEventCreateWithFlags(&c->ev_post, hipEventDisableTiming);
   // constant tables
   std::vector<double> td(3 * 137 * 2), fd(3 * 62 * 2);
   for (int t = 0; t < 3; ++t) { lcs_tables::pss_td(t, &td[t * 137 * 2]); lcs_tables::pss_fd(t, &fd[t * 62 * 2]); }
@@ -192,15 +214,19 @@ void lcs_destroy(lcs_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->stream_xc) (void)hipStreamSynchronize(c->stream_xc);
   void *ptrs[] = {c->cap32, c->cap64, c->params, c->fset, c->tmpl, c->start, c->smin, c->kp2, c->btab, c->single,
-                  c->incoh, c->pow_, c->work, c->spinc, c->zth, c->sp, c->frq, c->peaks, c->npeaks, c->xc,
+                  c->incoh, c->sref, c->pow_, c->work, c->spinc, c->zth, c->sp, c->frq, c->peaks, c->npeaks, c->xc,
                   c->work_items, c->n_work, c->tfg, c->tfg_comp, c->ce, c->tfg_ts, c->tfg_ts_comp, c->cell_scratch,
                   c->cells_out, c->d_pss_td, c->d_pss_fd, c->d_sss_fd, c->d_pbch_scr, c->d_derm_map, c->d_dbg};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   if (c->h_pinned) (void)hipHostFree(c->h_pinned);
   if (c->ev_xc0) (void)hipEventDestroy(c->ev_xc0);
   if (c->ev_xc1) (void)hipEventDestroy(c->ev_xc1);
+  if (c->ev_pre) (void)hipEventDestroy(c->ev_pre);
+  if (c->ev_post) (void)hipEventDestroy(c->ev_post);
   if (c->stream) (void)hipStreamDestroy(c->stream);
+  if (c->stream_xc) (void)hipStreamDestroy(c->stream_xc);
   delete c;
 }
 
@@ -229,7 +255,7 @@ int lcs_xcorr_pss(lcs_ctx *c, const double *capbuf, uint32_t n_cap, const double
   if (rc) return rc;
   if (!capbuf || !f_search_set || !pow_ || !frq || !single || !sp_incoherent) { c->err = "null argument"; return LCS_ERR_BAD_ARG; }
   HIPCHK(c, hipSetDevice(c->device));
-  const bool debug = incoh || sp;
+  const bool debug = incoh != nullptr;
   if ((rc = ensure_ws(c, 1, n_cap, n_f, debug))) return rc;
   const XcGeom geo = make_geo(n_cap, n_f, ds_comb_arm);
   if ((rc = validate_grid(c, geo, f_search_set, fc_req, fc_prog, fs_prog))) return rc;
@@ -238,15 +264,12 @@ int lcs_xcorr_pss(lcs_ctx *c, const double *capbuf, uint32_t n_cap, const double
   HIPCHK(c, hipMemcpyAsync(c->fset, f_search_set, sizeof(double) * n_f, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->params, &p, sizeof(p), hipMemcpyHostToDevice, c->stream));
   if ((rc = lcs_launch_ingest(c, nullptr, 2, 1, n_cap))) return rc;
-  double *sp_save = c->sp;
-  if (!sp) c->sp = nullptr;   // only materialise sp when asked for
-  rc = lcs_launch_xcorr(c, 1, geo, incoh != nullptr, false);
-  c->sp = sp_save;
-  if (rc) return rc;
+  if ((rc = lcs_launch_xcorr(c, 1, geo, incoh != nullptr, false))) return rc;
+  if ((rc = lcs_launch_single_layout(c, geo, c->sref, 1))) return rc;
   const size_t NE = 3 * LCS_N_IDX;
   HIPCHK(c, hipMemcpyAsync(pow_, c->pow_, sizeof(double) * NE, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(frq, c->frq, sizeof(int) * NE, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipMemcpyAsync(single, c->single, sizeof(float) * NE * n_f, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(single, c->sref, sizeof(float) * NE * n_f, hipMemcpyDeviceToHost, c->stream));
   if (incoh) HIPCHK(c, hipMemcpyAsync(incoh, c->incoh, sizeof(float) * NE * n_f, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(sp_incoherent, c->spinc, sizeof(double) * LCS_N_IDX, hipMemcpyDeviceToHost, c->stream));
   const int ncsp = (int)((n_cap - 136 - 137) / 9600);
@@ -279,9 +302,10 @@ int lcs_peak_search(lcs_ctx *c, const double *pow_, const int32_t *frq, const do
   HIPCHK(c, hipMemcpyAsync(c->frq, frq, sizeof(int) * NE, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->zth, Z_th1, sizeof(double) * LCS_N_IDX, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->fset, f_search_set, sizeof(double) * n_f, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->single, single, sizeof(float) * NE * n_f, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->sref, single, sizeof(float) * NE * n_f, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->params, &p, sizeof(p), hipMemcpyHostToDevice, c->stream));
   XcGeom geo = make_geo(153600, n_f, ds_comb_arm);
+  if ((rc = lcs_launch_single_layout(c, geo, c->sref, 0))) return rc;
   if ((rc = lcs_launch_peak_search(c, 1, geo, std::pow(10.0, -12.0 / 10.0)))) return rc;
   std::vector<lcs_cell> tmp(LCS_MAXP);
   int n = 0;
@@ -339,6 +363,8 @@ int lcs_batch_enqueue(lcs_ctx *c, const void *d_capbufs, int fmt, int n_buf, uin
 int lcs_batch_collect(lcs_ctx *c, lcs_cell *cells, int max_cells_per_buf, int *n_cells) {
   if (!c || !n_cells || c->last_n_buf <= 0) return LCS_ERR_BAD_ARG;
   const int nb = c->last_n_buf;
+  static const bool spin = getenv("LCS_SPIN_WAIT") != nullptr;   // measurement knob
+  if (spin) { while (hipStreamQuery(c->stream) == hipErrorNotReady) {} }
   std::vector<lcs_cell> tmp((size_t)nb * LCS_MAXP);
   std::vector<int> cnt(nb);
   HIPCHK(c, hipMemcpyAsync(tmp.data(), c->peaks, sizeof(lcs_cell) * tmp.size(), hipMemcpyDeviceToHost, c->stream));

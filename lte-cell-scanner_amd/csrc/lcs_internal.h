@@ -8,7 +8,8 @@
 //   start   [S][NW][n_f]          int      round_i(m*.005*k_factor*fs) (searcher.cpp:298)
 //   smin/kp2[S][NW][G]            int      per (window, 16-template group): first lag offset, tap pairs
 //   btab    [S][NW][G][KP2][64]   float    MFMA B operands: delay-shifted templates
-//   single  [S][3][9600][n_f]     float    xc_incoherent_single
+//   single  [S][G][9600][16]      float    xc_incoherent_single, group-major (16 templates = one 64 B row)
+//   sref    [3][9600][n_f]        float    reference-layout staging of single for the stage entry points
 //   pow/frq [S][3][9600]          double/int
 //   spinc/zth [S][9600]           double
 //   peaks   [S][MAXP] lcs_cell, npeaks [S]
@@ -53,7 +54,9 @@ struct WorkItem {
 
 struct lcs_ctx {
   int device = 0;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;      // everything except the PSS correlation (highest priority)
+  hipStream_t stream_xc = nullptr;   // the PSS correlation kernel (lowest priority), see lcs_launch_xcorr
+  hipEvent_t ev_pre = nullptr, ev_post = nullptr;
   std::string err;
   int xcorr_variant = 0;
 
@@ -71,7 +74,7 @@ struct lcs_ctx {
   float2 *tmpl = nullptr;
   int *start = nullptr, *smin = nullptr, *kp2 = nullptr;
   float *btab = nullptr;
-  float *single = nullptr, *incoh = nullptr;
+  float *single = nullptr, *incoh = nullptr, *sref = nullptr;
   double *pow_ = nullptr, *work = nullptr, *spinc = nullptr, *zth = nullptr, *sp = nullptr;
   int *frq = nullptr;
   lcs_cell *peaks = nullptr;
@@ -131,6 +134,7 @@ void pbch_deratematch_map(int n_e, uint8_t *out /*n_e*/);   // ref src/lte_lib.c
 // pss_xcorr.hip
 int lcs_launch_ingest(lcs_ctx *c, const void *d_src, int fmt, int n_buf, uint32_t n_cap);
 int lcs_launch_xcorr(lcs_ctx *c, int n_buf, const XcGeom &geo, bool want_incoh, bool time_it);
+int lcs_launch_single_layout(lcs_ctx *c, const XcGeom &geo, float *ref_layout, int to_ref);   // group-major <-> [t][idx][foi]
 int lcs_launch_xc_debug(lcs_ctx *c, const XcGeom &geo);   // raw xc for slot 0 (debug output only)
 // peak_search.hip
 int lcs_launch_peak_search(lcs_ctx *c, int n_buf, const XcGeom &geo, double udb10_m12);

@@ -34,7 +34,7 @@ __global__ __launch_bounds__(PS_THREADS) void k_peak_search(const double *__rest
   const double *pw = pow_ + (size_t)slot * NE;
   const int *fq = frq + (size_t)slot * NE;
   const double *z = zth + (size_t)slot * LCS_N_IDX;
-  const float *sg = single + (size_t)slot * NE * geo.n_f;
+  const float *sg = single + (size_t)slot * geo.G * LCS_N_IDX * LCS_TG;   // group-major (pss_xcorr.hip)
   double *wk = work + (size_t)slot * NE;
   lcs_cell *out = peaks + (size_t)slot * LCS_MAXP;
 
@@ -81,7 +81,8 @@ __global__ __launch_bounds__(PS_THREADS) void k_peak_search(const double *__rest
         if (peak_ind - ds >= 0) {
           for (int t = peak_ind - ds; t <= peak_ind + ds; ++t) {
             const int tw = t % LCS_N_IDX;
-            const float v = sg[((size_t)peak_n_id_2 * LCS_N_IDX + tw) * geo.n_f + fi];
+            const int cc = fi * 3 + peak_n_id_2;
+            const float v = sg[((size_t)(cc / LCS_TG) * LCS_N_IDX + tw) * LCS_TG + (cc % LCS_TG)];
             if ((double)v > best_pow) { best_pow = v; best_ind = tw; }
           }
         }

@@ -24,6 +24,10 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Internal layout of xc_incoherent_single: sg[slot][g][idx][16] ("group-major"): the 16 templates
+// of a group are one 64-byte row per output position, so a correlation wave writes whole
+// cache lines and k_collapse reads them back fully coalesced.  The reference layout
+// [t][idx][foi] is produced by k_single_to_ref only when a caller asks for that debug output.
 #define NW LCS_NW_MAX
 #define NFM LCS_NF_MAX
 #define GM LCS_G_MAX
@@ -81,7 +85,6 @@ __global__ __launch_bounds__(256) void k_prep_tables(const SlotParams *__restric
     int mn = s_start[w][f_lo], mx = mn;
     for (int f = f_lo + 1; f <= f_hi; ++f) { mn = min(mn, s_start[w][f]); mx = max(mx, s_start[w][f]); }
     int k2 = (137 + (mx - mn) + 1) / 2;
-    k2 = ((k2 + LCS_KP2_UNROLL - 1) / LCS_KP2_UNROLL) * LCS_KP2_UNROLL;
     if (k2 > LCS_KP2_MAX - LCS_KP2_UNROLL) k2 = LCS_KP2_MAX - LCS_KP2_UNROLL;   // rejected on the host before launch (lcs_api.hip)
     smin[((size_t)slot * NW + w) * GM + g] = mn;
     kp2[((size_t)slot * NW + w) * GM + g] = k2;
@@ -156,13 +159,31 @@ __device__ __forceinline__ void stage_load(float2 *pre, const float2 *__restrict
   }
 }
 
+// Block -> (idx tile, group, slot).  With xcd_map the 1-D grid is laid out so that hardware XCD x
+// (observed: workgroup b runs on XCD b % 8) walks slots x, x+8, ... one after the other: the
+// 2.9 MB template table and the 1.2 MB capture buffer of a slot then stay in that XCD's 4 MB L2
+// instead of every L2 seeing every slot.  Placement is a speed matter only.
+__device__ __forceinline__ bool decode_block(const XcGeom &geo, int slot0, int n_slots, int xcd_map, int &tile, int &g,
+                                             int &slot) {
+  const int per_slot = (LCS_N_IDX / LCS_LAG_TILE) * geo.G;
+  int q, s;
+  if (xcd_map) { s = blockIdx.x & 7; q = blockIdx.x >> 3; s += 8 * (q / per_slot); q = q % per_slot; }
+  else { s = blockIdx.x / per_slot; q = blockIdx.x % per_slot; }
+  if (s >= n_slots) return false;
+  slot = slot0 + s;
+  g = q / (LCS_N_IDX / LCS_LAG_TILE);
+  tile = q % (LCS_N_IDX / LCS_LAG_TILE);
+  return true;
+}
+
 __global__ __launch_bounds__(64) void k_xcorr_mfma(const float2 *__restrict__ cap32, const int *__restrict__ smin,
                                                     const int *__restrict__ kp2, const float *__restrict__ btab,
-                                                    float *__restrict__ single, XcGeom geo) {
+                                                    float *__restrict__ sg, XcGeom geo, int slot0, int n_slots,
+                                                    int xcd_map) {
   const int lane = threadIdx.x;
-  const int idx0 = blockIdx.x * LCS_LAG_TILE;
-  const int g = blockIdx.y;
-  const int slot = blockIdx.z;
+  int tile, g, slot;
+  if (!decode_block(geo, slot0, n_slots, xcd_map, tile, g, slot)) return;
+  const int idx0 = tile * LCS_LAG_TILE;
   __shared__ float lds[2 * 3 * LCS_PS];
   const float2 *cap = cap32 + (size_t)slot * geo.n_cap;
   const int *smin_s = smin + (size_t)slot * NW * GM + g;
@@ -201,7 +222,9 @@ __global__ __launch_bounds__(64) void k_xcorr_mfma(const float2 *__restrict__ ca
     float bnext[LCS_KP2_UNROLL];
 #pragma unroll
     for (int u = 0; u < LCS_KP2_UNROLL; ++u) bnext[u] = bp[u * 64];
-    for (int kk = 0; kk < k2; kk += LCS_KP2_UNROLL) {
+    const int k2m = k2 & ~(LCS_KP2_UNROLL - 1);
+    int kk = 0;
+    for (; kk < k2m; kk += LCS_KP2_UNROLL) {
       float b[LCS_KP2_UNROLL];
 #pragma unroll
       for (int u = 0; u < LCS_KP2_UNROLL; ++u) b[u] = bnext[u];
@@ -218,6 +241,19 @@ __global__ __launch_bounds__(64) void k_xcorr_mfma(const float2 *__restrict__ ca
         }
       }
     }
+    // remaining (k2 mod 4) tap pairs: their B rows are already in bnext
+#pragma unroll
+    for (int u = 0; u < LCS_KP2_UNROLL - 1; ++u) {
+      if (kk + u < k2) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          const float a1 = a1p[mt * 16 + 2 * (kk + u)];
+          const float a2 = a2p[mt * 16 + 2 * (kk + u)];
+          aR[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bnext[u], aR[mt], 0, 0, 0);
+          aI[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, bnext[u], aI[mt], 0, 0, 0);
+        }
+      }
+    }
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
@@ -225,28 +261,27 @@ __global__ __launch_bounds__(64) void k_xcorr_mfma(const float2 *__restrict__ ca
   }
 
   // C/D layout of 16x16x4: col = lane&15 (template), row = 4*(lane>>4)+reg (lag within the 16-row tile)
-  const int c = g * LCS_TG + (lane & 15);
-  if (c < geo.n_tmpl) {
-    const int foi = c / 3, t = c % 3;
+  {
     const float ncomb = (float)geo.n_comb;
-    float *o = single + (((size_t)slot * 3 + t) * LCS_N_IDX) * geo.n_f + foi;
+    float *o = sg + (((size_t)slot * geo.G + g) * LCS_N_IDX) * LCS_TG + (lane & 15);
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int idx = idx0 + mt * 16 + 4 * (lane >> 4) + r;
-        o[(size_t)idx * geo.n_f] = __fdiv_rn(P[mt][r], ncomb);
+        o[(size_t)idx * LCS_TG] = __fdiv_rn(P[mt][r], ncomb);      // 16 lanes = one 64-byte row
       }
   }
 }
 
 __global__ __launch_bounds__(64) void k_xcorr_valu(const float2 *__restrict__ cap32, const int *__restrict__ smin,
                                                     const int *__restrict__ kp2, const float *__restrict__ btab,
-                                                    float *__restrict__ single, XcGeom geo) {
+                                                    float *__restrict__ sg, XcGeom geo, int slot0, int n_slots,
+                                                    int xcd_map) {
   const int lane = threadIdx.x;
-  const int idx0 = blockIdx.x * LCS_LAG_TILE;
-  const int g = blockIdx.y;
-  const int slot = blockIdx.z;
+  int tile, g, slot;
+  if (!decode_block(geo, slot0, n_slots, xcd_map, tile, g, slot)) return;
+  const int idx0 = tile * LCS_LAG_TILE;
   __shared__ float lds[2 * 3 * LCS_PS];
   const float2 *cap = cap32 + (size_t)slot * geo.n_cap;
   const int *smin_s = smin + (size_t)slot * NW * GM + g;
@@ -287,14 +322,11 @@ __global__ __launch_bounds__(64) void k_xcorr_valu(const float2 *__restrict__ ca
   }
   const float ncomb = (float)geo.n_comb;
   const int idx = idx0 + lane;
+  float4 *o = (float4 *)(sg + ((((size_t)slot * geo.G + g) * LCS_N_IDX) + idx) * LCS_TG);
 #pragma unroll
-  for (int j = 0; j < LCS_TG; ++j) {
-    const int c = g * LCS_TG + j;
-    if (c < geo.n_tmpl) {
-      const int foi = c / 3, t = c % 3;
-      single[((((size_t)slot * 3 + t) * LCS_N_IDX) + idx) * geo.n_f + foi] = __fdiv_rn(P[j], ncomb);
-    }
-  }
+  for (int j = 0; j < LCS_TG; j += 4)
+    o[j >> 2] = make_float4(__fdiv_rn(P[j], ncomb), __fdiv_rn(P[j + 1], ncomb), __fdiv_rn(P[j + 2], ncomb),
+                            __fdiv_rn(P[j + 3], ncomb));
 }
 
 // ------------------------------------------------------------------------- K2: sp_est
@@ -307,66 +339,103 @@ struct SpArgs {
   double R_th1, rx_cutoff;
   int n_comb_xc, ds;
 };
-__global__ __launch_bounds__(256) void k_sp_est(const double2 *__restrict__ cap64, double *__restrict__ spinc,
-                                                 double *__restrict__ zth, double *__restrict__ sp_dbg,
-                                                 uint32_t n_cap, SpArgs a) {
-  const int slot = blockIdx.y;
+// grid (tiles of 256 positions, windows, slots): sp_all[slot][m][i]
+__global__ __launch_bounds__(256) void k_sp_sums(const double2 *__restrict__ cap64, double *__restrict__ sp_all,
+                                                  uint32_t n_cap, int n_comb_sp) {
+  const int slot = blockIdx.z, m = blockIdx.y;
   const int i0 = blockIdx.x * 256;
   const int tid = threadIdx.x;
   const double2 *cap = cap64 + (size_t)slot * n_cap;
-  __shared__ double pw[256 + 274];
+  __shared__ double pw[256 + 274 + 2];
+  const uint32_t base = (uint32_t)m * 9600u + i0;
+  for (int n = tid; n < 256 + 274; n += 256) {
+    const uint32_t s = base + n;
+    double v = 0;
+    if (s < n_cap) { const double2 c = cap[s]; v = c.x * c.x + c.y * c.y; }
+    pw[n] = v;
+  }
+  __syncthreads();
+  double s0 = 0, s1 = 0;                       // two interleaved chains (even / odd samples)
+  for (int j = 0; j < 274; j += 2) { s0 += pw[tid + j]; s1 += pw[tid + j + 1]; }
+  if (i0 + tid < 9600) sp_all[((size_t)slot * n_comb_sp + m) * 9600 + i0 + tid] = (s0 + s1) / 274;
+}
+__global__ __launch_bounds__(256) void k_sp_fold(const double *__restrict__ sp_all, double *__restrict__ spinc,
+                                                  double *__restrict__ zth, SpArgs a) {
+  const int slot = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= 9600) return;
   double acc = 0;
-  for (int m = 0; m < a.n_comb_sp; ++m) {
-    const uint32_t base = (uint32_t)m * 9600u + i0;
-    for (int n = tid; n < 256 + 274; n += 256) {
-      const uint32_t s = base + n;
-      double v = 0;
-      if (s < n_cap) { const double2 c = cap[s]; v = c.x * c.x + c.y * c.y; }
-      pw[n] = v;
-    }
-    __syncthreads();
-    double s = 0;
-    for (int j = 0; j < 274; ++j) s += pw[tid + j];
-    s = s / 274;
-    if (sp_dbg && i0 + tid < 9600) sp_dbg[(size_t)slot * a.n_comb_sp * 9600 + (size_t)m * 9600 + i0 + tid] = s;
-    acc += s;
-    __syncthreads();
-  }
-  const int i = i0 + tid;
-  if (i < 9600) {
-    const double v = acc / a.n_comb_sp;
-    const int o = (i + 137) % 9600;
-    spinc[(size_t)slot * 9600 + o] = v;
-    zth[(size_t)slot * 9600 + o] = a.R_th1 * v / a.rx_cutoff / 137 / 2 / a.n_comb_xc / (2 * a.ds + 1);
-  }
+  for (int m = 0; m < a.n_comb_sp; ++m) acc += sp_all[((size_t)slot * a.n_comb_sp + m) * 9600 + i];
+  const double v = acc / a.n_comb_sp;
+  const int o = (i + 137) % 9600;
+  spinc[(size_t)slot * 9600 + o] = v;
+  zth[(size_t)slot * 9600 + o] = a.R_th1 * v / a.rx_cutoff / 137 / 2 / a.n_comb_xc / (2 * a.ds + 1);
 }
 
 // ------------------------------------------------- K3: delay spread + max over frequency
 // ref :312-347 (float adds in the reference's order, circular in idx) and :353-383 (first max).
-__global__ __launch_bounds__(256) void k_collapse(const float *__restrict__ single, float *__restrict__ incoh,
+// One thread per output position: it reads the 2*ds+1 neighbouring 64-byte rows of every group
+// (consecutive lanes read consecutive rows: fully coalesced), then scans the templates in
+// ascending (foi, pss) order keeping the first maximum per PSS.
+__global__ __launch_bounds__(128) void k_collapse(const float *__restrict__ sg, float *__restrict__ incoh,
                                                    double *__restrict__ pow_, int *__restrict__ frq, XcGeom geo) {
   const int slot = blockIdx.y;
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= 3 * LCS_N_IDX) return;
-  const int t = e / LCS_N_IDX, idx = e % LCS_N_IDX;
-  const int n_f = geo.n_f;
-  const float *rows = single + (((size_t)slot * 3 + t) * LCS_N_IDX) * n_f;
-  float *orow = incoh ? incoh + ((((size_t)slot * 3 + t) * LCS_N_IDX) + idx) * n_f : nullptr;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= LCS_N_IDX) return;
   const float dsn = (float)(2 * geo.ds + 1);
-  float best = 0.f;
-  int bi = 0;
-  for (int foi = 0; foi < n_f; ++foi) {
-    float v = rows[(size_t)idx * n_f + foi];
+  float best[3] = {0.f, 0.f, 0.f};
+  int bi[3] = {0, 0, 0};
+  for (int g = 0; g < geo.G; ++g) {
+    const float4 *rows = (const float4 *)(sg + (((size_t)slot * geo.G + g) * LCS_N_IDX) * LCS_TG);
+    float v[LCS_TG];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 x = rows[(size_t)idx * 4 + q];
+      v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w;
+    }
     for (int d = 1; d <= geo.ds; ++d) {
       const int a = (idx - d + LCS_N_IDX) % LCS_N_IDX, b = (idx + d) % LCS_N_IDX;
-      v = v + (rows[(size_t)a * n_f + foi] + rows[(size_t)b * n_f + foi]);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 xa = rows[(size_t)a * 4 + q], xb = rows[(size_t)b * 4 + q];
+        v[4 * q] = v[4 * q] + (xa.x + xb.x); v[4 * q + 1] = v[4 * q + 1] + (xa.y + xb.y);
+        v[4 * q + 2] = v[4 * q + 2] + (xa.z + xb.z); v[4 * q + 3] = v[4 * q + 3] + (xa.w + xb.w);
+      }
     }
-    v = __fdiv_rn(v, dsn);
-    if (orow) orow[foi] = v;
-    if (foi == 0 || v > best) { best = v; bi = foi; }
+#pragma unroll
+    for (int j = 0; j < LCS_TG; ++j) {
+      const int c = g * LCS_TG + j;
+      if (c < geo.n_tmpl) {
+        const int foi = c / 3, t = c % 3;
+        const float x = __fdiv_rn(v[j], dsn);
+        if (incoh) incoh[((((size_t)slot * 3 + t) * LCS_N_IDX) + idx) * geo.n_f + foi] = x;
+        if (foi == 0 || x > best[t]) { best[t] = x; bi[t] = foi; }
+      }
+    }
   }
-  pow_[(size_t)slot * 3 * LCS_N_IDX + e] = (double)best;
-  frq[(size_t)slot * 3 * LCS_N_IDX + e] = bi;
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    pow_[((size_t)slot * 3 + t) * LCS_N_IDX + idx] = (double)best[t];
+    frq[((size_t)slot * 3 + t) * LCS_N_IDX + idx] = bi[t];
+  }
+}
+
+// group-major -> reference layout [t][idx][foi] (debug output of the stage entry point) and back
+// (lcs_peak_search receives the reference layout from the caller)
+__global__ __launch_bounds__(256) void k_single_to_ref(const float *__restrict__ sg, float *__restrict__ ref, XcGeom geo,
+                                                        int to_ref) {
+  const int slot = blockIdx.y;
+  const size_t n = (size_t)geo.G * LCS_N_IDX * LCS_TG;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+    const int j = (int)(e % LCS_TG);
+    const int idx = (int)((e / LCS_TG) % LCS_N_IDX);
+    const int g = (int)(e / ((size_t)LCS_TG * LCS_N_IDX));
+    const int c = g * LCS_TG + j;
+    if (c >= geo.n_tmpl) { if (!to_ref) ((float *)sg)[(size_t)slot * n + e] = 0.f; continue; }
+    const int foi = c / 3, t = c % 3;
+    const size_t r = ((((size_t)slot * 3 + t) * LCS_N_IDX) + idx) * geo.n_f + foi;
+    if (to_ref) ref[r] = sg[(size_t)slot * n + e]; else ((float *)sg)[(size_t)slot * n + e] = ref[r];
+  }
 }
 
 // ---------------------------------------------------------- debug: raw xc (slot 0 only)
@@ -409,28 +478,79 @@ int lcs_launch_ingest(lcs_ctx *c, const void *d_src, int fmt, int n_buf, uint32_
   return LCS_OK;
 }
 
+// The correlation kernel saturates the matrix pipes on its own; two of them from different
+// contexts (streams) running side by side only evict each other's template tables from L2
+// (measured: 2 x 8.7 ms overlapped vs 2 x 7.6 ms back to back).  Launches of this one kernel are
+// therefore chained through a per-device event, while everything else a context enqueues (the
+// latency-bound per-cell stages in particular) is free to overlap the next context's correlation.
+#include <mutex>
+#include <cstdlib>
+static std::mutex g_xc_mutex;
+static hipEvent_t g_xc_done[64] = {};
+
 int lcs_launch_xcorr(lcs_ctx *c, int n_buf, const XcGeom &geo, bool want_incoh, bool time_it) {
   hipLaunchKernelGGL(k_prep_tables, dim3(n_buf), dim3(256), 0, c->stream, c->params, c->fset, c->d_pss_td, c->tmpl,
                      c->start, c->smin, c->kp2, geo);
   hipLaunchKernelGGL(k_fill_btab, dim3(8, geo.n_comb * geo.G, n_buf), dim3(256), 0, c->stream, c->tmpl, c->start,
                      c->smin, c->kp2, c->btab, geo);
-  dim3 grid(LCS_N_IDX / LCS_LAG_TILE, geo.G, n_buf);
-  if (time_it) HIPCHK(c, hipEventRecord(c->ev_xc0, c->stream));
-  if (c->xcorr_variant == 1)
-    hipLaunchKernelGGL(k_xcorr_valu, grid, dim3(64), 0, c->stream, c->cap32, c->smin, c->kp2, c->btab, c->single, geo);
-  else
-    hipLaunchKernelGGL(k_xcorr_mfma, grid, dim3(64), 0, c->stream, c->cap32, c->smin, c->kp2, c->btab, c->single, geo);
-  if (time_it) { HIPCHK(c, hipEventRecord(c->ev_xc1, c->stream)); c->last_xc_launches = 1; }
+  // signal-power estimate and threshold do not depend on the correlation: enqueue them first
   SpArgs a;
   a.n_comb_sp = (int)((geo.n_cap - 136 - 137) / 9600);
   a.n_comb_xc = geo.n_comb;
   a.ds = geo.ds;
   a.R_th1 = lcs_tables::chi2cdf_inv(1 - pow(10.0, -12), 2.0 * geo.n_comb * (2 * geo.ds + 1));
   a.rx_cutoff = (6 * 12 * 15e3 / 2 + 4 * 15e3) / (30720000.0 / 16 / 2);
-  hipLaunchKernelGGL(k_sp_est, dim3((LCS_N_IDX + 255) / 256, n_buf), dim3(256), 0, c->stream, c->cap64, c->spinc, c->zth,
-                     c->sp, geo.n_cap, a);
-  hipLaunchKernelGGL(k_collapse, dim3((3 * LCS_N_IDX + 255) / 256, n_buf), dim3(256), 0, c->stream, c->single,
+  hipLaunchKernelGGL(k_sp_sums, dim3((LCS_N_IDX + 255) / 256, a.n_comb_sp, n_buf), dim3(256), 0, c->stream, c->cap64,
+                     c->sp, geo.n_cap, a.n_comb_sp);
+  hipLaunchKernelGGL(k_sp_fold, dim3((LCS_N_IDX + 255) / 256, n_buf), dim3(256), 0, c->stream, c->sp, c->spinc, c->zth, a);
+
+  const int per_slot = (LCS_N_IDX / LCS_LAG_TILE) * geo.G;
+  // slots [0, n8) with the XCD-aware mapping, the remainder with the plain one
+  const int n8 = (n_buf >= 8) ? (n_buf & ~7) : 0;
+  // main stream -> correlation stream hand-off (tables and fp32 buffer are ready)
+  static const bool single_stream = getenv("LCS_SINGLE_STREAM") != nullptr;   // measurement knob
+  hipStream_t sxc = single_stream ? c->stream : c->stream_xc;
+  if (!single_stream) {
+    HIPCHK(c, hipEventRecord(c->ev_pre, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(sxc, c->ev_pre, 0));
+  }
+  {
+    std::lock_guard<std::mutex> lk(g_xc_mutex);
+    hipEvent_t &ev = g_xc_done[c->device & 63];
+    if (!ev) HIPCHK(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    else HIPCHK(c, hipStreamWaitEvent(sxc, ev, 0));
+  }
+  if (time_it) HIPCHK(c, hipEventRecord(c->ev_xc0, sxc));
+  int launches = 0;
+  for (int part = 0; part < 2; ++part) {
+    const int s0 = part ? n8 : 0, ns = part ? n_buf - n8 : n8;
+    if (ns <= 0) continue;
+    const dim3 grid((unsigned)(per_slot * ns));
+    if (c->xcorr_variant == 1)
+      hipLaunchKernelGGL(k_xcorr_valu, grid, dim3(64), 0, sxc, c->cap32, c->smin, c->kp2, c->btab, c->single,
+                         geo, s0, ns, part ? 0 : 1);
+    else
+      hipLaunchKernelGGL(k_xcorr_mfma, grid, dim3(64), 0, sxc, c->cap32, c->smin, c->kp2, c->btab, c->single,
+                         geo, s0, ns, part ? 0 : 1);
+    ++launches;
+  }
+  if (time_it) { HIPCHK(c, hipEventRecord(c->ev_xc1, sxc)); c->last_xc_launches = launches; }
+  {
+    std::lock_guard<std::mutex> lk(g_xc_mutex);
+    HIPCHK(c, hipEventRecord(g_xc_done[c->device & 63], sxc));
+  }
+  if (!single_stream) {
+    HIPCHK(c, hipEventRecord(c->ev_post, sxc));
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_post, 0));
+  }
+  hipLaunchKernelGGL(k_collapse, dim3((LCS_N_IDX + 127) / 128, n_buf), dim3(128), 0, c->stream, c->single,
                      want_incoh ? c->incoh : nullptr, c->pow_, c->frq, geo);
+  HIPCHK(c, hipGetLastError());
+  return LCS_OK;
+}
+
+int lcs_launch_single_layout(lcs_ctx *c, const XcGeom &geo, float *ref_layout, int to_ref) {
+  hipLaunchKernelGGL(k_single_to_ref, dim3(256, 1), dim3(256), 0, c->stream, c->single, ref_layout, geo, to_ref);
   HIPCHK(c, hipGetLastError());
   return LCS_OK;
 }
