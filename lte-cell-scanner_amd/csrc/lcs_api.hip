@@ -192,15 +192,20 @@ int lcs_create(int device, lcs_ctx **out) {
       }
   std::vector<uint8_t> scr(504 * 1920);
   for (int id = 0; id < 504; ++id) lcs_tables::lte_pn((uint32_t)id, 1920, &scr[(size_t)id * 1920]);
-  std::vector<uint8_t> derm(2 * 1920, 255);
-  lcs_tables::pbch_deratematch_map(1920, &derm[0]);      // normal CP
-  lcs_tables::pbch_deratematch_map(1728, &derm[1920]);   // extended CP
+  std::vector<int16_t> derm(2 * 120 * 16, (int16_t)-1);
+  for (int v = 0; v < 2; ++v) {                            // 0: normal CP (1920 bits), 1: extended CP (1728)
+    const int n_e = v ? 1728 : 1920;
+    std::vector<uint8_t> map(n_e);
+    lcs_tables::pbch_deratematch_map(n_e, map.data());
+    int fill[120] = {0};
+    for (int t = 0; t < n_e; ++t) derm[(v * 120 + map[t]) * 16 + fill[map[t]]++] = (int16_t)t;
+  }
   bool ok = hipMalloc((void **)&c->d_pss_td, td.size() * sizeof(double)) == hipSuccess &&
             hipMalloc((void **)&c->d_pss_fd, fd.size() * sizeof(double)) == hipSuccess &&
             hipMalloc((void **)&c->d_sss_fd, sss.size()) == hipSuccess &&
             hipMalloc((void **)&c->d_pbch_scr, scr.size()) == hipSuccess &&
-            hipMalloc((void **)&c->d_derm_map, derm.size()) == hipSuccess &&
-            hipMemcpy(c->d_derm_map, derm.data(), derm.size(), hipMemcpyHostToDevice) == hipSuccess &&
+            hipMalloc((void **)&c->d_derm_inv, derm.size() * sizeof(int16_t)) == hipSuccess &&
+            hipMemcpy(c->d_derm_inv, derm.data(), derm.size() * sizeof(int16_t), hipMemcpyHostToDevice) == hipSuccess &&
             hipMemcpy(c->d_pss_td, td.data(), td.size() * sizeof(double), hipMemcpyHostToDevice) == hipSuccess &&
             hipMemcpy(c->d_pss_fd, fd.data(), fd.size() * sizeof(double), hipMemcpyHostToDevice) == hipSuccess &&
             hipMemcpy(c->d_sss_fd, sss.data(), sss.size(), hipMemcpyHostToDevice) == hipSuccess &&
@@ -218,7 +223,7 @@ void lcs_destroy(lcs_ctx *c) {
   void *ptrs[] = {c->cap32, c->cap64, c->params, c->fset, c->tmpl, c->start, c->smin, c->kp2, c->btab, c->single,
                   c->incoh, c->sref, c->pow_, c->work, c->spinc, c->zth, c->sp, c->frq, c->peaks, c->npeaks, c->xc,
                   c->work_items, c->n_work, c->tfg, c->tfg_comp, c->ce, c->tfg_ts, c->tfg_ts_comp, c->cell_scratch,
-                  c->cells_out, c->d_pss_td, c->d_pss_fd, c->d_sss_fd, c->d_pbch_scr, c->d_derm_map, c->d_dbg};
+                  c->cells_out, c->d_pss_td, c->d_pss_fd, c->d_sss_fd, c->d_pbch_scr, c->d_derm_inv, c->d_dbg};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   if (c->h_pinned) (void)hipHostFree(c->h_pinned);
   if (c->ev_xc0) (void)hipEventDestroy(c->ev_xc0);

@@ -96,7 +96,7 @@ struct lcs_ctx {
   double2 *d_pss_fd = nullptr;      // [3][62]
   int8_t *d_sss_fd = nullptr;       // [168][3][2][62]
   uint8_t *d_pbch_scr = nullptr;    // [504][1920]
-  uint8_t *d_derm_map = nullptr;    // [2][1920]: coded-bit index (stream*40+col) of every rate-matched PBCH bit
+  int16_t *d_derm_inv = nullptr;    // [2][120][16]: for every coded bit (stream*40+col) the rate-matched PBCH bit positions carrying it (ascending, -1 padded)
   double *d_dbg = nullptr;          // debug outputs of the single-cell stage entry points
   bool percell_ready = false;
   // host staging

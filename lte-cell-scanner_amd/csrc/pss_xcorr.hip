@@ -339,25 +339,38 @@ struct SpArgs {
   double R_th1, rx_cutoff;
   int n_comb_xc, ds;
 };
-// grid (tiles of 256 positions, windows, slots): sp_all[slot][m][i]
-__global__ __launch_bounds__(256) void k_sp_sums(const double2 *__restrict__ cap64, double *__restrict__ sp_all,
-                                                  uint32_t n_cap, int n_comb_sp) {
+// grid (tiles of 1024 positions, windows, slots): sp_all[slot][m][i].  Each lane owns 16
+// consecutive positions: one direct 274-sample sum, then 15 sliding updates (the reference's own
+// recurrence, restarted every 16 samples).  LDS index i -> i + i/16 keeps the lanes' 16-sample
+// strides on distinct banks.
+#define SP_SEG 16
+#define SP_TILE (64 * SP_SEG)
+__device__ __forceinline__ int sp_pad(int i) { return i + (i >> 4); }
+__global__ __launch_bounds__(64) void k_sp_sums(const double2 *__restrict__ cap64, double *__restrict__ sp_all,
+                                                 uint32_t n_cap, int n_comb_sp) {
   const int slot = blockIdx.z, m = blockIdx.y;
-  const int i0 = blockIdx.x * 256;
+  const int i0 = blockIdx.x * SP_TILE;
   const int tid = threadIdx.x;
   const double2 *cap = cap64 + (size_t)slot * n_cap;
-  __shared__ double pw[256 + 274 + 2];
+  __shared__ double pw[SP_TILE + 274 + (SP_TILE + 274) / 16 + 2];
   const uint32_t base = (uint32_t)m * 9600u + i0;
-  for (int n = tid; n < 256 + 274; n += 256) {
+  for (int n = tid; n < SP_TILE + 274; n += 64) {
     const uint32_t s = base + n;
     double v = 0;
     if (s < n_cap) { const double2 c = cap[s]; v = c.x * c.x + c.y * c.y; }
-    pw[n] = v;
+    pw[sp_pad(n)] = v;
   }
   __syncthreads();
+  const int b0 = tid * SP_SEG;
   double s0 = 0, s1 = 0;                       // two interleaved chains (even / odd samples)
-  for (int j = 0; j < 274; j += 2) { s0 += pw[tid + j]; s1 += pw[tid + j + 1]; }
-  if (i0 + tid < 9600) sp_all[((size_t)slot * n_comb_sp + m) * 9600 + i0 + tid] = (s0 + s1) / 274;
+  for (int j = 0; j < 274; j += 2) { s0 += pw[sp_pad(b0 + j)]; s1 += pw[sp_pad(b0 + j + 1)]; }
+  double s = s0 + s1;
+  double *o = sp_all + ((size_t)slot * n_comb_sp + m) * 9600;
+  for (int q = 0; q < SP_SEG; ++q) {
+    const int i = i0 + b0 + q;
+    if (q) s = s + (-pw[sp_pad(b0 + q - 1)] + pw[sp_pad(b0 + q + 273)]);
+    if (i < 9600) o[i] = s / 274;
+  }
 }
 __global__ __launch_bounds__(256) void k_sp_fold(const double *__restrict__ sp_all, double *__restrict__ spinc,
                                                   double *__restrict__ zth, SpArgs a) {
@@ -500,7 +513,7 @@ int lcs_launch_xcorr(lcs_ctx *c, int n_buf, const XcGeom &geo, bool want_incoh, 
   a.ds = geo.ds;
   a.R_th1 = lcs_tables::chi2cdf_inv(1 - pow(10.0, -12), 2.0 * geo.n_comb * (2 * geo.ds + 1));
   a.rx_cutoff = (6 * 12 * 15e3 / 2 + 4 * 15e3) / (30720000.0 / 16 / 2);
-  hipLaunchKernelGGL(k_sp_sums, dim3((LCS_N_IDX + 255) / 256, a.n_comb_sp, n_buf), dim3(256), 0, c->stream, c->cap64,
+  hipLaunchKernelGGL(k_sp_sums, dim3((LCS_N_IDX + SP_TILE - 1) / SP_TILE, a.n_comb_sp, n_buf), dim3(64), 0, c->stream, c->cap64,
                      c->sp, geo.n_cap, a.n_comb_sp);
   hipLaunchKernelGGL(k_sp_fold, dim3((LCS_N_IDX + 255) / 256, n_buf), dim3(256), 0, c->stream, c->sp, c->spinc, c->zth, a);
 
@@ -509,6 +522,7 @@ int lcs_launch_xcorr(lcs_ctx *c, int n_buf, const XcGeom &geo, bool want_incoh, 
   const int n8 = (n_buf >= 8) ? (n_buf & ~7) : 0;
   // main stream -> correlation stream hand-off (tables and fp32 buffer are ready)
   static const bool single_stream = getenv("LCS_SINGLE_STREAM") != nullptr;   // measurement knob
+  static const int lds_pad = getenv("LCS_XC_LDS_PAD") ? atoi(getenv("LCS_XC_LDS_PAD")) : 0;   // measurement knob: caps waves/CU
   hipStream_t sxc = single_stream ? c->stream : c->stream_xc;
   if (!single_stream) {
     HIPCHK(c, hipEventRecord(c->ev_pre, c->stream));
@@ -527,10 +541,10 @@ int lcs_launch_xcorr(lcs_ctx *c, int n_buf, const XcGeom &geo, bool want_incoh, 
     if (ns <= 0) continue;
     const dim3 grid((unsigned)(per_slot * ns));
     if (c->xcorr_variant == 1)
-      hipLaunchKernelGGL(k_xcorr_valu, grid, dim3(64), 0, sxc, c->cap32, c->smin, c->kp2, c->btab, c->single,
+      hipLaunchKernelGGL(k_xcorr_valu, grid, dim3(64), lds_pad, sxc, c->cap32, c->smin, c->kp2, c->btab, c->single,
                          geo, s0, ns, part ? 0 : 1);
     else
-      hipLaunchKernelGGL(k_xcorr_mfma, grid, dim3(64), 0, sxc, c->cap32, c->smin, c->kp2, c->btab, c->single,
+      hipLaunchKernelGGL(k_xcorr_mfma, grid, dim3(64), lds_pad, sxc, c->cap32, c->smin, c->kp2, c->btab, c->single,
                          geo, s0, ns, part ? 0 : 1);
     ++launches;
   }

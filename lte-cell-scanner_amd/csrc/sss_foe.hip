@@ -35,12 +35,15 @@ __device__ __forceinline__ int d_range_len(double first, double incr, double las
   return (s1 * s2 >= 0) ? d_floor_i((last - first) / incr) + 1 : 0;
 }
 
-// LDS image of one workgroup
+// LDS image of one workgroup.  Occurrences (half-frames) are processed PASS_OCC at a time:
+// all their windows are staged, transformed, smoothed in parallel.
+#define PASS_OCC 8
+#define PASS_WIN (PASS_OCC * 3)
 struct SfShared {
   cd2 W[128];                 // exp(-j 2 pi m / 128)
-  cd2 win[3][128];            // frequency-corrected, 2-sample-rotated DFT inputs
-  cd2 bins[3][62];            // extracted subcarriers of the 3 windows
-  cd2 h_raw[62];
+  cd2 win[PASS_WIN][128];     // frequency-corrected, 2-sample-rotated DFT inputs of one pass
+  cd2 h_raw[PASS_OCC][62];
+  cd2 aux[PASS_OCC][62];      // FOE: SSS bins of the pass
   cd2 h_sm[MAX_HF][62];
   cd2 s_nrm[MAX_HF][62];
   cd2 s_ext[MAX_HF][62];
@@ -49,45 +52,57 @@ struct SfShared {
   cd2 nrm12[124];
   cd2 ext12[124];
   double ll[2][2][168];       // [nrm/ext][column][n_id_1]
-  cd2 term[62];
-  double red[8];
+  cd2 acc_k[MAX_HF];
 };
 
-// Stage capbuf.mid(loc,128) -> fshift(., foc_freq, fs) -> rotate left by 2 (ref :523-525).
-__device__ void stage_window(const double2 *__restrict__ cap, uint32_t n_cap, long loc, double foc_freq, double fs,
-                             cd2 *win, int tid, int nthreads) {
-  const double k = M_PI * foc_freq / (fs / 2);
-  for (int n = tid; n < 128; n += nthreads) {
-    const int t = (n + 2) & 127;
-    const long src = loc + t;
-    cd2 v = mk(0, 0);
-    if (src >= 0 && (uint64_t)src < n_cap) { const double2 c = cap[src]; v = mk(c.x, c.y); }
-    const cd2 coeff = mk(cos(k * (double)t), sin(k * (double)t));
-    win[n] = cmul(v, coeff);
-  }
-}
-// dft(win)/sqrt(128) at bins [97..127, 1..31] (ref :527-529)
-__device__ __forceinline__ cd2 dft_bin62(const cd2 *win, const cd2 *W, int b) {
-  const int bin = (b < 31) ? 97 + b : b - 30;
-  cd2 acc = mk(0, 0);
-  for (int n = 0; n < 128; ++n) acc = cadd(acc, cmul(win[n], W[(bin * n) & 127]));
-  return cdivr(acc, sqrt(128.0));
+// capbuf.mid(loc,128) -> fshift(., foc_freq, fs) -> rotate left by 2 (ref :523-525), one sample
+__device__ __forceinline__ cd2 stage_sample(const double2 *__restrict__ cap, uint32_t n_cap, long loc, double k, int n) {
+  const int t = (n + 2) & 127;
+  const long src = loc + t;
+  cd2 v = mk(0, 0);
+  if (src >= 0 && (uint64_t)src < n_cap) { const double2 c = cap[src]; v = mk(c.x, c.y); }
+  return cmul(v, mk(cos(k * (double)t), sin(k * (double)t)));
 }
 
-// h_raw -> h_sm (13-tap mean, ref :584-588) and pss_np = sigpower(h_sm-h_raw) (ref :591)
-__device__ void smooth_and_np(SfShared &S, cd2 *h_sm_row, double *np_out, int tid) {
-  if (tid < 62) {
-    const int t = tid;
+// DFT of n_win staged windows at the 62 PSS/SSS bins [97..127, 1..31], /sqrt(128) (ref :527-529).
+// Thread (bin = tid % 62, lane group = tid / 62) handles windows group, group+4, ...: the twiddle
+// is read once per sample and reused for every window of the thread.  Sums run over n ascending.
+template <int MAXW>
+__device__ __forceinline__ void dft62_multi(const SfShared &S, int n_win, int tid, cd2 *out /*[MAXW]*/, int &bin_idx, int &grp) {
+  bin_idx = tid % 62;
+  grp = tid / 62;
+  const int bin = (bin_idx < 31) ? 97 + bin_idx : bin_idx - 30;
+#pragma unroll
+  for (int i = 0; i < MAXW; ++i) out[i] = mk(0, 0);
+  if (tid >= 248) return;
+  for (int n = 0; n < 128; ++n) {
+    const cd2 tw = S.W[(bin * n) & 127];
+#pragma unroll
+    for (int i = 0; i < MAXW; ++i) {
+      const int w = grp + 4 * i;
+      if (w < n_win) out[i] = cadd(out[i], cmul(S.win[w][n], tw));
+    }
+  }
+  const double sq = sqrt(128.0);
+#pragma unroll
+  for (int i = 0; i < MAXW; ++i) out[i] = cdivr(out[i], sq);
+}
+
+// h_raw[kk] -> h_sm (13-tap mean, ref :584-588) and pss_np = sigpower(h_sm-h_raw) (ref :591) for
+// the nk occurrences of a pass; h_sm rows start at h_sm0.
+__device__ void smooth_and_np(SfShared &S, int nk, cd2 (*h_sm0)[62], double *np0, int tid) {
+  for (int e = tid; e < nk * 62; e += SF_THREADS) {
+    const int kk = e / 62, t = e % 62;
     const int lt = (t - 6 > 0) ? t - 6 : 0, rt = (t + 6 < 61) ? t + 6 : 61;
     cd2 s = mk(0, 0);
-    for (int i = lt; i <= rt; ++i) s = cadd(s, S.h_raw[i]);
-    h_sm_row[t] = cdivr(s, (double)(rt - lt + 1));
+    for (int i = lt; i <= rt; ++i) s = cadd(s, S.h_raw[kk][i]);
+    h_sm0[kk][t] = cdivr(s, (double)(rt - lt + 1));
   }
   __syncthreads();
-  if (tid == 0) {
+  if (tid < nk) {
     double r = 0;
-    for (int t = 0; t < 62; ++t) { const cd2 d = csub(h_sm_row[t], S.h_raw[t]); r += d.re * d.re + d.im * d.im; }
-    *np_out = r / 62;
+    for (int t = 0; t < 62; ++t) { const cd2 d = csub(h_sm0[tid][t], S.h_raw[tid][t]); r += d.re * d.re + d.im * d.im; }
+    np0[tid] = r / 62;
   }
   __syncthreads();
 }
@@ -105,23 +120,36 @@ __device__ void dev_sss_detect(SfShared &S, lcs_cell &cell, const double2 *__res
   if (n_pss > MAX_HF) n_pss = MAX_HF;
   if (n_pss < 1) return;
   const double fs = p.fs_prog * k_factor;
+  const double kph = M_PI * (-peak_freq) / (fs / 2);
 
-  for (int k = 0; k < n_pss; ++k) {
-    const uint32_t pss_loc = (uint32_t)d_round_i(peak_loc + k * (k_factor * 9600));
-    const uint32_t pss_dft = pss_loc + 9 - 2;
-    stage_window(cap, n_cap, (long)pss_dft, -peak_freq, fs, S.win[0], tid, SF_THREADS);
-    stage_window(cap, n_cap, (long)pss_dft - 128 - 32, -peak_freq, fs, S.win[1], tid, SF_THREADS);
-    stage_window(cap, n_cap, (long)pss_dft - 128 - 9, -peak_freq, fs, S.win[2], tid, SF_THREADS);
-    __syncthreads();
-    if (tid < 186) {
-      const int w = tid / 62, b = tid % 62;
-      const cd2 v = dft_bin62(S.win[w], S.W, b);
-      if (w == 0) { const double2 f = pss_fd[n_id_2 * 62 + b]; S.h_raw[b] = cmul(v, mk(f.x, -f.y)); }
-      else if (w == 1) S.s_ext[k][b] = v;
-      else S.s_nrm[k][b] = v;
+  for (int k0 = 0; k0 < n_pss; k0 += PASS_OCC) {
+    const int nk = min(PASS_OCC, n_pss - k0);
+    // stage the PSS window, the extended-CP SSS window and the normal-CP SSS window of nk occurrences
+    for (int e = tid; e < nk * 3 * 128; e += SF_THREADS) {
+      const int kk = e / 384, w = (e >> 7) % 3, n = e & 127;
+      const uint32_t pss_loc = (uint32_t)d_round_i(peak_loc + (k0 + kk) * (k_factor * 9600));
+      const long pss_dft = (long)(pss_loc + 9 - 2);
+      const long loc = (w == 0) ? pss_dft : (w == 1 ? pss_dft - 128 - 32 : pss_dft - 128 - 9);
+      S.win[kk * 3 + w][n] = stage_sample(cap, n_cap, loc, kph, n);
     }
     __syncthreads();
-    smooth_and_np(S, S.h_sm[k], &S.pss_np[k], tid);
+    cd2 o[6];
+    int b, grp;
+    dft62_multi<6>(S, nk * 3, tid, o, b, grp);
+    if (tid < 248) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const int wi = grp + 4 * i;
+        if (wi < nk * 3) {
+          const int kk = wi / 3, w = wi % 3;
+          if (w == 0) { const double2 f = pss_fd[n_id_2 * 62 + b]; S.h_raw[kk][b] = cmul(o[i], mk(f.x, -f.y)); }
+          else if (w == 1) S.s_ext[k0 + kk][b] = o[i];
+          else S.s_nrm[k0 + kk][b] = o[i];
+        }
+      }
+    }
+    __syncthreads();
+    smooth_and_np(S, nk, &S.h_sm[k0], &S.pss_np[k0], tid);
   }
   // combine even (h1) / odd (h2) occurrences per subcarrier (ref :618-631)
   if (tid < 124) {
@@ -155,14 +183,10 @@ __device__ void dev_sss_detect(SfShared &S, lcs_cell &cell, const double2 *__res
     const double ang = atan2(acc.im, acc.re);
     const cd2 rot = mk(cos(-ang), sin(-ang));
     double s1 = 0, s2 = 0;
-    for (int i = 0; i < 124; ++i) {
+    for (int i = 0; i < 124; ++i) {      // the two sums of ref :649 keep their own order
       const double tv = (double)(i < 62 ? first[i] : second[i - 62]);
       const cd2 d = csub(cmul(mk(tv, 0), rot), est[i]);
       s1 += (d.re * d.re) / S.np12[i];
-    }
-    for (int i = 0; i < 124; ++i) {
-      const double tv = (double)(i < 62 ? first[i] : second[i - 62]);
-      const cd2 d = csub(cmul(mk(tv, 0), rot), est[i]);
       s2 += (d.im * d.im) / S.np12[i];
     }
     S.ll[ext][col][n1] = -s1 - s2;
@@ -230,52 +254,67 @@ __device__ void dev_pss_sss_foe(SfShared &S, lcs_cell &cell, const double2 *__re
     pss_sss_dist = (int)(uint16_t)d_round_i((128 + 32) * k_factor);   // quirk Q4
     first_sss = cell.frame_start + (960 - 128 - 32 - 128) * 16 / FS_LTE * p.fs_prog * k_factor;
   } else return;
-  int sn;
+  int sn_init;
   first_sss = d_wrap(first_sss, -0.5, 9600 * 2 - 0.5);
-  if (first_sss - 9600 * k_factor > -0.5) { first_sss -= 9600 * k_factor; sn = 10; } else sn = 0;
+  if (first_sss - 9600 * k_factor > -0.5) { first_sss -= 9600 * k_factor; sn_init = 10; } else sn_init = 0;
   const double step = 9600 * 16 / FS_LTE * p.fs_prog * k_factor;
-  const int n_sss = d_range_len(first_sss, step, (double)((int)n_cap - 127 - pss_sss_dist - 100));
+  int n_sss = d_range_len(first_sss, step, (double)((int)n_cap - 127 - pss_sss_dist - 100));
+  if (n_sss > MAX_HF) n_sss = MAX_HF;
   const double fs = p.fs_prog * k_factor;
-  sn = (1 - (sn / 10)) * 10;
-  cd2 M = mk(0, 0);
+  const double kph = M_PI * (-cell.freq) / (fs / 2);
   // exp(J*pi*-freq/(FS_LTE/16/2)*-pss_sss_dist), evaluated left to right (ref :832)
   double ph_im = M_PI;
   ph_im = ph_im * (-cell.freq);
   ph_im = ph_im / (FS_LTE / 16 / 2);
   ph_im = ph_im * (double)(-pss_sss_dist);
   const cd2 ph = mk(cos(ph_im), sin(ph_im));
-  for (int k = 0; k < n_sss; ++k) {
-    sn = (1 - (sn / 10)) * 10;
-    const uint32_t sss_loc = (uint32_t)d_round_i(first_sss + k * step);
-    const uint32_t pss_loc = sss_loc + pss_sss_dist;
-    stage_window(cap, n_cap, (long)pss_loc, -cell.freq, fs, S.win[0], tid, SF_THREADS);
-    stage_window(cap, n_cap, (long)sss_loc, -cell.freq, fs, S.win[1], tid, SF_THREADS);
+  for (int k0 = 0; k0 < n_sss; k0 += PASS_OCC) {
+    const int nk = min(PASS_OCC, n_sss - k0);
+    for (int e = tid; e < nk * 2 * 128; e += SF_THREADS) {
+      const int kk = e >> 8, w = (e >> 7) & 1, n = e & 127;
+      const uint32_t sss_loc = (uint32_t)d_round_i(first_sss + (k0 + kk) * step);
+      const long loc = (w == 0) ? (long)(sss_loc + pss_sss_dist) : (long)sss_loc;
+      S.win[kk * 2 + w][n] = stage_sample(cap, n_cap, loc, kph, n);
+    }
     __syncthreads();
-    if (tid < 124) {
-      const int w = tid / 62, b = tid % 62;
-      const cd2 v = dft_bin62(S.win[w], S.W, b);
-      if (w == 0) { const double2 f = pss_fd[cell.n_id_2 * 62 + b]; S.h_raw[b] = cmul(v, mk(f.x, -f.y)); }
-      else {
-        const double sf = (double)sss_fd[((cell.n_id_1 * 3 + cell.n_id_2) * 2 + (sn != 0)) * 62 + b];
-        S.bins[1][b] = cmul(cmul(v, ph), mk(sf, 0));
+    cd2 o[4];
+    int b, grp;
+    dft62_multi<4>(S, nk * 2, tid, o, b, grp);
+    if (tid < 248) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int wi = grp + 4 * i;
+        if (wi < nk * 2) {
+          const int kk = wi >> 1, w = wi & 1;
+          if (w == 0) { const double2 f = pss_fd[cell.n_id_2 * 62 + b]; S.h_raw[kk][b] = cmul(o[i], mk(f.x, -f.y)); }
+          else {
+            // the slot number toggles with every occurrence, starting from sn_init (ref :800, :813)
+            const int sn = (((k0 + kk) & 1) == 0) ? sn_init : 10 - sn_init;
+            const double sf = (double)sss_fd[((cell.n_id_1 * 3 + cell.n_id_2) * 2 + (sn != 0)) * 62 + b];
+            S.aux[kk][b] = cmul(cmul(o[i], ph), mk(sf, 0));
+          }
+        }
       }
     }
     __syncthreads();
-    smooth_and_np(S, S.h_sm[0], &S.pss_np[0], tid);
-    if (tid < 62) {
-      const double np = S.pss_np[0];
-      const double a2 = cabs2(S.h_sm[0][tid]);
-      const double w = a2 * (1.0 / (2 * a2 * np + np * np));
-      S.term[tid] = cmul(cmul(cconj(S.bins[1][tid]), S.h_raw[tid]), mk(w, 0));
+    smooth_and_np(S, nk, &S.h_sm[k0], &S.pss_np[k0], tid);
+    if (tid < nk) {     // per-occurrence sum over the 62 subcarriers, in subcarrier order (ref :836-843)
+      const double np = S.pss_np[k0 + tid];
+      cd2 acc = mk(0, 0);
+      for (int t = 0; t < 62; ++t) {
+        const double a2 = cabs2(S.h_sm[k0 + tid][t]);
+        const double w = a2 * (1.0 / (2 * a2 * np + np * np));
+        acc = cadd(acc, cmul(cmul(cconj(S.aux[tid][t]), S.h_raw[tid][t]), mk(w, 0)));
+      }
+      S.acc_k[k0 + tid] = acc;
     }
     __syncthreads();
-    cd2 acc = mk(0, 0);
-    for (int t = 0; t < 62; ++t) acc = cadd(acc, S.term[t]);   // every thread: same sequential sum
-    M = cadd(M, acc);
-    __syncthreads();
   }
-  if (tid == 0)
+  if (tid == 0) {
+    cd2 M = mk(0, 0);
+    for (int k = 0; k < n_sss; ++k) M = cadd(M, S.acc_k[k]);
     cell.freq_fine = cell.freq + atan2(M.im, M.re) / (2 * M_PI) / (1 / (p.fs_prog * k_factor) * pss_sss_dist);
+  }
 }
 
 // mode bit 0: run sss_detect, bit 1: run pss_sss_foe (only for cells whose SSS was found)
@@ -286,7 +325,8 @@ __global__ __launch_bounds__(SF_THREADS) void k_sss_foe(lcs_cell *__restrict__ p
                                                          const int8_t *__restrict__ sss_fd, int mode, double *dbg) {
   const int slot = blockIdx.y, pk = blockIdx.x;
   if (pk >= npeaks[slot] || pk >= LCS_MAXP) return;
-  __shared__ SfShared S;
+  extern __shared__ __attribute__((aligned(16))) char sf_smem[];
+  SfShared &S = *reinterpret_cast<SfShared *>(sf_smem);
   __shared__ lcs_cell cell;
   const int tid = threadIdx.x;
   if (tid < 128) { double s, c; sincospi((double)tid / 64.0, &s, &c); S.W[tid] = mk(c, -s); }
@@ -301,8 +341,19 @@ __global__ __launch_bounds__(SF_THREADS) void k_sss_foe(lcs_cell *__restrict__ p
   if (tid == 0) peaks[(size_t)slot * LCS_MAXP + pk] = cell;
 }
 
+static int sf_attr(lcs_ctx *c) {
+  static bool done = false;
+  if (!done) {
+    HIPCHK(c, hipFuncSetAttribute((const void *)k_sss_foe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SfShared)));
+    done = true;
+  }
+  return LCS_OK;
+}
+
 int lcs_launch_sss_foe(lcs_ctx *c, int n_buf, uint32_t n_cap, double thresh2_n_sigma, double *dbg) {
-  hipLaunchKernelGGL(k_sss_foe, dim3(LCS_MAXP, n_buf), dim3(SF_THREADS), 0, c->stream, c->peaks, c->npeaks, c->cap64, n_cap,
+  int rc = sf_attr(c);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_sss_foe, dim3(LCS_MAXP, n_buf), dim3(SF_THREADS), sizeof(SfShared), c->stream, c->peaks, c->npeaks, c->cap64, n_cap,
                      c->params, thresh2_n_sigma, c->d_pss_fd, c->d_sss_fd, 3, dbg);
   HIPCHK(c, hipGetLastError());
   return LCS_OK;
@@ -310,13 +361,17 @@ int lcs_launch_sss_foe(lcs_ctx *c, int n_buf, uint32_t n_cap, double thresh2_n_s
 
 // Single-cell helpers for the stage entry points: peaks[0] of slot 0 holds the cell.
 int lcs_launch_sss_only(lcs_ctx *c, uint32_t n_cap, double thresh2_n_sigma, double *dbg) {
-  hipLaunchKernelGGL(k_sss_foe, dim3(1, 1), dim3(SF_THREADS), 0, c->stream, c->peaks, c->npeaks, c->cap64, n_cap, c->params,
+  int rc = sf_attr(c);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_sss_foe, dim3(1, 1), dim3(SF_THREADS), sizeof(SfShared), c->stream, c->peaks, c->npeaks, c->cap64, n_cap, c->params,
                      thresh2_n_sigma, c->d_pss_fd, c->d_sss_fd, 1, dbg);
   HIPCHK(c, hipGetLastError());
   return LCS_OK;
 }
 int lcs_launch_foe_only(lcs_ctx *c, uint32_t n_cap) {
-  hipLaunchKernelGGL(k_sss_foe, dim3(1, 1), dim3(SF_THREADS), 0, c->stream, c->peaks, c->npeaks, c->cap64, n_cap, c->params,
+  int rc = sf_attr(c);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_sss_foe, dim3(1, 1), dim3(SF_THREADS), sizeof(SfShared), c->stream, c->peaks, c->npeaks, c->cap64, n_cap, c->params,
                      0.0, c->d_pss_fd, c->d_sss_fd, 2, (double *)nullptr);
   HIPCHK(c, hipGetLastError());
   return LCS_OK;

@@ -125,12 +125,13 @@ __global__ void k_tfg_prep(const lcs_cell *__restrict__ cells, const WorkItem *_
 // LDS (the reference rotates all 153600 samples per cell, ref :892; only the 854x128 that feed a
 // DFT are touched here, with the same absolute-index phase), direct 72-bin DFT, /sqrt(128),
 // then the sub-sample timing phase ramp (ref :923-931).
-#define TFG_SYM 8
-__global__ __launch_bounds__(256) void k_tfg(const lcs_cell *__restrict__ cells, const WorkItem *__restrict__ items,
-                                             const int *__restrict__ n_work, const SlotParams *__restrict__ params,
-                                             const double2 *__restrict__ cap64, uint32_t n_cap,
-                                             const double *__restrict__ ts, double *__restrict__ scratch,
-                                             double2 *__restrict__ tfg) {
+#define TFG_SYM 16
+#define TFG_THREADS 288     // 72 bins x 4 symbol groups
+__global__ __launch_bounds__(TFG_THREADS) void k_tfg(const lcs_cell *__restrict__ cells, const WorkItem *__restrict__ items,
+                                                     const int *__restrict__ n_work, const SlotParams *__restrict__ params,
+                                                     const double2 *__restrict__ cap64, uint32_t n_cap,
+                                                     const double *__restrict__ ts, double *__restrict__ scratch,
+                                                     double2 *__restrict__ tfg) {
   __shared__ cd2 W[128];
   __shared__ cd2 win[TFG_SYM][128];
   __shared__ int s_loc[TFG_SYM];
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(256) void k_tfg(const lcs_cell *__restrict__ cells,
     __syncthreads();
     if (tid < TFG_SYM) s_loc[tid] = (t0 + tid < n_ofdm) ? d_round_i(tsi[t0 + tid]) : 0;
     __syncthreads();
-    for (int e = tid; e < TFG_SYM * 128; e += 256) {
+    for (int e = tid; e < TFG_SYM * 128; e += TFG_THREADS) {
       const int s = e >> 7, n = e & 127;
       cd2 v = mk(0, 0);
       if (t0 + s < n_ofdm) {
@@ -165,21 +166,31 @@ __global__ __launch_bounds__(256) void k_tfg(const lcs_cell *__restrict__ cells,
       win[s][n] = v;
     }
     __syncthreads();
-    for (int e = tid; e < TFG_SYM * NSC; e += 256) {
-      const int s = e / NSC, i = e % NSC;
-      const int t = t0 + s;
-      if (t >= n_ofdm) continue;
+    {
+      // thread = (subcarrier i, symbol group g): symbols g, g+4, g+8, g+12 share each twiddle read
+      const int i = tid % NSC, g = tid / NSC;
       const int bin = (i < 36) ? 92 + i : i - 35;
-      cd2 acc = mk(0, 0);
-      for (int n = 0; n < 128; ++n) acc = cadd(acc, cmul(win[s][n], W[(bin * n) & 127]));
-      acc = cdivr(acc, sqrt(128.0));
-      const double ideal = tsi[t];
-      const double late = (double)d_round_i(ideal) - ideal;
-      double k_im = -1.0;
-      k_im = k_im * 2; k_im = k_im * M_PI; k_im = k_im * late; k_im = k_im / 128;
-      const double ph = k_im * (double)cn_of(i);
-      acc = cmul(acc, mk(cos(ph), sin(ph)));
-      st(&tfg[((size_t)it * ROWS + t) * NSC + i], acc);
+      cd2 acc[TFG_SYM / 4];
+#pragma unroll
+      for (int q = 0; q < TFG_SYM / 4; ++q) acc[q] = mk(0, 0);
+      for (int n = 0; n < 128; ++n) {
+        const cd2 tw = W[(bin * n) & 127];
+#pragma unroll
+        for (int q = 0; q < TFG_SYM / 4; ++q) acc[q] = cadd(acc[q], cmul(win[g + 4 * q][n], tw));
+      }
+#pragma unroll
+      for (int q = 0; q < TFG_SYM / 4; ++q) {
+        const int t = t0 + g + 4 * q;
+        if (t >= n_ofdm) continue;
+        cd2 a = cdivr(acc[q], sqrt(128.0));
+        const double ideal = tsi[t];
+        const double late = (double)d_round_i(ideal) - ideal;
+        double k_im = -1.0;
+        k_im = k_im * 2; k_im = k_im * M_PI; k_im = k_im * late; k_im = k_im / 128;
+        const double ph = k_im * (double)cn_of(i);
+        a = cmul(a, mk(cos(ph), sin(ph)));
+        st(&tfg[((size_t)it * ROWS + t) * NSC + i], a);
+      }
     }
   }
 }
@@ -377,6 +388,24 @@ __device__ int hex_extend(double *row_x, cd2 *row_val, int len) {
   return len;
 }
 
+// Vertex i of the (edge-extended) RS row with first RS subcarrier `s` (ref :1200-1213): the 12
+// filtered estimates at s, s+6, ..., plus a linearly extrapolated vertex at subcarrier 0 when
+// s != 0 and at 71 when the row does not end there.
+__device__ __forceinline__ int ext_len(int s) { return 12 + (s != 0) + (s != 5); }
+__device__ __forceinline__ void ext_vertex(const cd2 *row, int s, int i, int &x, cd2 &v) {
+  const int lead = (s != 0);
+  const int j = i - lead;
+  if (j < 0) {                       // left edge: row_val(0)-row_x(0)*(row_val(1)-row_val(0))/(row_x(1)-row_x(0))
+    const cd2 d = csub(row[1], row[0]);
+    v = csub(row[0], cdivr(cscale(d, (double)s), 6.0));
+    x = 0;
+  } else if (j > 11) {               // right edge
+    const cd2 d = csub(row[11], row[10]);
+    v = cadd(row[11], cdivr(cscale(d, (double)(71 - (s + 66))), 6.0));
+    x = 71;
+  } else { v = row[j]; x = s + 6 * j; }
+}
+
 #define CE_THREADS 256
 #define CE_MAX_RS 256
 __global__ __launch_bounds__(CE_THREADS) void k_chan_est(const lcs_cell *__restrict__ cells, const int *__restrict__ n_work,
@@ -457,55 +486,63 @@ __global__ __launch_bounds__(CE_THREADS) void k_chan_est(const lcs_cell *__restr
       st(&out[(size_t)rs_set[0] * NSC + tid], interp1_c(x, v, n, (double)tid));
     }
     for (int t = tid; t <= n_rs - 2; t += CE_THREADS) {
-      double top_x[16], bot_x[16]; cd2 top_v[16], bot_v[16];
       const int s_top = (t & 1) ? sh1 : sh0, s_bot = (t & 1) ? sh0 : sh1;
-      int n_top = 0, n_bot = 0;
-      for (int xx = s_top; xx <= 71; xx += 6) { top_x[n_top] = xx; top_v[n_top] = ce_filt[t * 12 + n_top]; ++n_top; }
-      n_top = hex_extend(top_x, top_v, n_top);
-      for (int xx = s_bot; xx <= 71; xx += 6) { bot_x[n_bot] = xx; bot_v[n_bot] = ce_filt[(t + 1) * 12 + n_bot]; ++n_bot; }
-      n_bot = hex_extend(bot_x, bot_v, n_bot);
-      int tx[3], ty[3]; cd2 tv[3];
-      int top_last, bot_last;
+      const cd2 *top = ce_filt + t * 12, *bot = ce_filt + (t + 1) * 12;
+      const int n_top = ext_len(s_top), n_bot = ext_len(s_bot);
       const int y_top = rs_set[t], y_bot = rs_set[t + 1];
-      if (top_x[1] < bot_x[1]) {
-        tx[0] = (int)top_x[0]; ty[0] = y_top; tv[0] = top_v[0];
-        tx[1] = (int)bot_x[0]; ty[1] = y_bot; tv[1] = bot_v[0];
-        tx[2] = (int)top_x[1]; ty[2] = y_top; tv[2] = top_v[1];
+      int tx[3], ty[3]; cd2 tv[3];
+      int top_last, bot_last, x1t, x1b; cd2 dummy;
+      ext_vertex(top, s_top, 1, x1t, dummy);
+      ext_vertex(bot, s_bot, 1, x1b, dummy);
+      if (x1t < x1b) {
+        ext_vertex(top, s_top, 0, tx[0], tv[0]); ty[0] = y_top;
+        ext_vertex(bot, s_bot, 0, tx[1], tv[1]); ty[1] = y_bot;
+        ext_vertex(top, s_top, 1, tx[2], tv[2]); ty[2] = y_top;
         top_last = 1; bot_last = 0;
       } else {
-        tx[0] = (int)bot_x[0]; ty[0] = y_bot; tv[0] = bot_v[0];
-        tx[1] = (int)top_x[0]; ty[1] = y_top; tv[1] = top_v[0];
-        tx[2] = (int)bot_x[1]; ty[2] = y_bot; tv[2] = bot_v[1];
+        ext_vertex(bot, s_bot, 0, tx[0], tv[0]); ty[0] = y_bot;
+        ext_vertex(top, s_top, 0, tx[1], tv[1]); ty[1] = y_top;
+        ext_vertex(bot, s_bot, 1, tx[2], tv[2]); ty[2] = y_bot;
         top_last = 0; bot_last = 1;
       }
       const int spacing = y_bot - y_top;
-      int x_off[16];
-      for (int i = 0; i <= spacing; ++i) x_off[i] = 0;
+      int x_off[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) x_off[i] = 0;
       for (int guard = 0; guard < 64; ++guard) {
-        cd2 M[3][3], V[3], abc[3];
-        for (int i = 0; i < 3; ++i) { M[i][0] = mk(tx[i], 0); M[i][1] = mk(ty[i], 0); M[i][2] = mk(1, 0); V[i] = tv[i]; }
-        solve3(M, V, abc);
+        // plane through the three vertices (the reference solves the 3x3 system with a LAPACK
+        // inverse, ref :1293-1312; same plane, rounding differs at the 1e-14 level)
+        const double dx1 = tx[1] - tx[0], dy1 = ty[1] - ty[0], dx2 = tx[2] - tx[0], dy2 = ty[2] - ty[0];
+        const double det = dx1 * dy2 - dx2 * dy1;
+        const cd2 d1 = csub(tv[1], tv[0]), d2 = csub(tv[2], tv[0]);
+        const cd2 a_p = cdivr(csub(cscale(d1, dy2), cscale(d2, dy1)), det);
+        const cd2 b_p = cdivr(csub(cscale(d2, dx1), cscale(d1, dx2)), det);
         const double x1 = tx[1], x2 = tx[2], y1 = ty[1], y2 = ty[2];
         const double a_l = (x1 - x2) / (y1 - y2);
         const double b_l = (y1 * x2 - y2 * x1) / (y1 - y2);
-        for (int r = 1; r <= spacing; ++r) {
-          while ((double)x_off[r] <= a_l * (y_top + r) + b_l) {
-            const cd2 v = cadd(cadd(cscale(abc[0], (double)x_off[r]), cscale(abc[1], (double)(y_top + r))), abc[2]);
-            if (x_off[r] <= 71) st(&out[(size_t)(y_top + r) * NSC + x_off[r]], v);
-            ++x_off[r];
+#pragma unroll
+        for (int r = 1; r <= 7; ++r) {
+          if (r <= spacing) {
+            while ((double)x_off[r] <= a_l * (y_top + r) + b_l) {
+              const cd2 v = cadd(cadd(tv[0], cscale(a_p, (double)(x_off[r] - tx[0]))), cscale(b_p, (double)(y_top + r - ty[0])));
+              if (x_off[r] <= 71) st(&out[(size_t)(y_top + r) * NSC + x_off[r]], v);
+              ++x_off[r];
+            }
           }
         }
-        if (x_off[1] == 72 && x_off[spacing] == 72) break;
-        if (ty[2] == y_top) {
-          tx[0] = tx[1]; ty[0] = ty[1]; tv[0] = tv[1]; tx[1] = tx[2]; ty[1] = ty[2]; tv[1] = tv[2];
+        bool done = (x_off[1] == 72);
+#pragma unroll
+        for (int r = 1; r <= 7; ++r) if (r == spacing) done = done && (x_off[r] == 72);
+        if (done) break;
+        tx[0] = tx[1]; ty[0] = ty[1]; tv[0] = tv[1]; tx[1] = tx[2]; ty[1] = ty[2]; tv[1] = tv[2];
+        if (ty[1] == y_top) {
           ++bot_last;
           if (bot_last >= n_bot) break;
-          tx[2] = (int)bot_x[bot_last]; ty[2] = y_bot; tv[2] = bot_v[bot_last];
+          ext_vertex(bot, s_bot, bot_last, tx[2], tv[2]); ty[2] = y_bot;
         } else {
-          tx[0] = tx[1]; ty[0] = ty[1]; tv[0] = tv[1]; tx[1] = tx[2]; ty[1] = ty[2]; tv[1] = tv[2];
           ++top_last;
           if (top_last >= n_top) break;
-          tx[2] = (int)top_x[top_last]; ty[2] = y_top; tv[2] = top_v[top_last];
+          ext_vertex(top, s_top, top_last, tx[2], tv[2]); ty[2] = y_top;
         }
       }
     }
@@ -523,7 +560,8 @@ __global__ __launch_bounds__(CE_THREADS) void k_chan_est(const lcs_cell *__restr
 
 // ------------------------------------------------------------------------ PBCH decode
 // One workgroup per (cell, candidate): candidate = frame_timing_guess*3 + {1,2,4 ports}.
-#define PB_THREADS 256
+#define PB_THREADS 1024
+#define PB_WAVES (PB_THREADS / 64)
 __device__ __forceinline__ double trunc_log(double x) {     // itpp::trunc_log
   if (x == INFINITY) return log(1.79769313486231570815e+308);
   if (x <= 0) return log(2.22507385850720138309e-308);
@@ -532,14 +570,14 @@ __device__ __forceinline__ double trunc_log(double x) {     // itpp::trunc_log
 __global__ __launch_bounds__(PB_THREADS) void k_pbch(const lcs_cell *__restrict__ cells, const int *__restrict__ n_work,
                                                       const double2 *__restrict__ tfg_comp, const double2 *__restrict__ ce,
                                                       double *__restrict__ scratch, const uint8_t *__restrict__ pbch_scr,
-                                                      const uint8_t *__restrict__ derm_map /*[2][1920]*/) {
+                                                      const int16_t *__restrict__ derm_inv /*[2][120][16]*/) {
   __shared__ cd2 syms[960];
   __shared__ double npv[960];
   __shared__ double e_est[1920];
   __shared__ double d_est[3][40];
-  __shared__ unsigned long long surv[4][40], best_surv[4][40];
-  __shared__ double w_best[4];
-  __shared__ int w_best_ss[4];
+  __shared__ unsigned long long surv[PB_WAVES][40], best_surv[PB_WAVES][40];
+  __shared__ double w_best[PB_WAVES];
+  __shared__ int w_best_ss[PB_WAVES];
   __shared__ unsigned char c_est[40];
   const int tid = threadIdx.x, cand = blockIdx.y;
   const int guess = cand / 3, n_ports = (cand % 3 == 2) ? 4 : (cand % 3) + 1;
@@ -617,20 +655,20 @@ __global__ __launch_bounds__(PB_THREADS) void k_pbch(const lcs_cell *__restrict_
     __syncthreads();
     // de-ratematch: average all observations of each coded bit (ref src/lte_lib.cpp:497-509)
     if (tid < 120) {
-      const uint8_t *map = derm_map + ((m_bit == 1920) ? 0 : 1920);
+      const int16_t *lst = derm_inv + ((m_bit == 1920) ? 0 : 120 * 16) + tid * 16;   // ascending bit positions
       double s = 0; int cnt = 0;
-      for (int t = 0; t < m_bit; ++t) if (map[t] == tid) { s += e_est[t]; ++cnt; }
+      for (int q = 0; q < 16; ++q) { const int t = lst[q]; if (t < 0) break; s += e_est[t]; ++cnt; }
       if (cnt > 1) s = s / cnt;
       d_est[tid / 40][tid % 40] = s;
     }
     __syncthreads();
     // tail-biting Viterbi, K=7, G=(133,171,165)o: one trellis per start state with the end state
-    // forced equal; lane = trellis state, each of the 4 waves takes 16 start states.
+    // forced equal; lane = trellis state, each of the 16 waves takes 4 start states.
     {
       const int wave = tid >> 6, s = tid & 63;
       double wbest = INFINITY; int wbest_ss = -1;
-      for (int q = 0; q < 16; ++q) {
-        const int ss = wave * 16 + q;
+      for (int q = 0; q < 64 / PB_WAVES; ++q) {
+        const int ss = wave * (64 / PB_WAVES) + q;
         double pm = (s == ss) ? 0.0 : INFINITY;
         for (int t = 0; t < 40; ++t) {
           // new state s <- predecessors p0 = (s<<1)&63, p1 = p0|1 with input bit b = s>>5
@@ -657,7 +695,7 @@ __global__ __launch_bounds__(PB_THREADS) void k_pbch(const lcs_cell *__restrict_
     __syncthreads();
     if (tid == 0) {
       int bw = 0;
-      for (int w = 1; w < 4; ++w) if (w_best[w] < w_best[bw]) bw = w;
+      for (int w = 1; w < PB_WAVES; ++w) if (w_best[w] < w_best[bw]) bw = w;
       int ok = 0;
       unsigned bits24 = 0;
       if (w_best_ss[bw] >= 0) {
@@ -731,7 +769,7 @@ int lcs_launch_tfg(lcs_ctx *c, uint32_t n_cap, int n_items) {
   (void)n_items;
   hipLaunchKernelGGL(k_tfg_prep, dim3((LCS_MAX_WORK + 63) / 64), dim3(64), 0, c->stream, c->cells_out, c->work_items,
                      c->n_work, c->params, c->tfg_ts, c->cell_scratch);
-  hipLaunchKernelGGL(k_tfg, dim3(2048), dim3(256), 0, c->stream, c->cells_out, c->work_items, c->n_work, c->params,
+  hipLaunchKernelGGL(k_tfg, dim3(2048), dim3(TFG_THREADS), 0, c->stream, c->cells_out, c->work_items, c->n_work, c->params,
                      c->cap64, n_cap, c->tfg_ts, c->cell_scratch, c->tfg);
   HIPCHK(c, hipGetLastError());
   return LCS_OK;
@@ -759,7 +797,7 @@ int lcs_launch_mib(lcs_ctx *c, int n_items) {
   hipLaunchKernelGGL(k_chan_est, dim3(GRID_ITEMS, 4), dim3(CE_THREADS), smem, c->stream, c->cells_out, c->n_work,
                      c->tfg_comp, c->cell_scratch, c->ce);
   hipLaunchKernelGGL(k_pbch, dim3(GRID_ITEMS, 12), dim3(PB_THREADS), 0, c->stream, c->cells_out, c->n_work, c->tfg_comp,
-                     c->ce, c->cell_scratch, c->d_pbch_scr, c->d_derm_map);
+                     c->ce, c->cell_scratch, c->d_pbch_scr, c->d_derm_inv);
   hipLaunchKernelGGL(k_mib_select, dim3((LCS_MAX_WORK + 63) / 64), dim3(64), 0, c->stream, c->cells_out, c->n_work,
                      c->cell_scratch);
   HIPCHK(c, hipGetLastError());
