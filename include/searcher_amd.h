@@ -1,0 +1,223 @@
+// searcher_amd.h -- the reference's searcher call surface (include/searcher.h:22-119) on top of
+// the C ABI of liblcs_amd.so.  Same function names, argument order and meaning; the only extra
+// is the explicit context created once per process/GPU.
+//
+// Container types come from LCS_CONTAINER_NS (default: lcsc, include/lcs_containers.h).  With
+// IT++ installed, compile with -DLCS_CONTAINER_NS=itpp after including <itpp/itbase.h>:
+// itpp::Vec/Mat expose the same length()/rows()/cols()/set_size()/_data() members.
+//
+// Differences to the reference, all forced by the C boundary:
+//  * `Cell` is the POD lcs_cell plus the two member functions callers use (n_id_cell, n_symb_dl);
+//  * RS_DL is not an argument of tfoec/decode_mib: it is a pure function of the cell identity
+//    and is rebuilt on the device (the reference constructs it right before the calls,
+//    src/CellSearch.cpp:545);
+//  * errors: the reference either succeeds or throws a const char*; these wrappers throw
+//    lcs::error carrying the library's message.
+#ifndef SEARCHER_AMD_H
+#define SEARCHER_AMD_H
+
+#include <cmath>
+#include <complex>
+#include <list>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "lcs.h"
+#ifndef LCS_CONTAINER_NS
+#include "lcs_containers.h"
+#define LCS_CONTAINER_NS lcsc
+#endif
+
+// include/common.h.in:41-44
+typedef std::vector<std::vector<std::vector<std::complex<float> > > > vcf3d;
+typedef std::vector<std::vector<std::vector<float> > > vf3d;
+
+namespace lcs {
+namespace cn = LCS_CONTAINER_NS;
+
+struct error : std::runtime_error {
+  explicit error(const std::string &m) : std::runtime_error(m) {}
+};
+
+// class Cell (include/common.h.in:101-129): the POD record with the reference's helpers.
+struct Cell : lcs_cell {
+  Cell() { lcs_cell_init(this); }
+  Cell(const lcs_cell &c) : lcs_cell(c) {}
+  int n_id_cell() const { return (n_id_1 >= 0 && n_id_2 >= 0) ? (n_id_2 + 3 * n_id_1) : -1; }   // src/common.cpp:29-31
+  int n_symb_dl() const { return cp_type == LCS_CP_NORMAL ? 7 : (cp_type == LCS_CP_EXTENDED ? 6 : -1); }
+};
+
+class Searcher {
+ public:
+  explicit Searcher(int device = -1) : h_(0) {
+    const int rc = lcs_create(device, &h_);
+    if (rc != LCS_OK) throw error("lcs_create failed (an MI355X is required; there is no CPU fallback)");
+  }
+  ~Searcher() { lcs_destroy(h_); }
+  lcs_ctx *handle() { return h_; }
+
+  // include/searcher.h:22-41
+  void xcorr_pss(const cn::cvec &capbuf, const cn::vec &f_search_set, unsigned char ds_comb_arm, double fc_requested,
+                 double fc_programmed, double fs_programmed, cn::mat &xc_incoherent_collapsed_pow,
+                 cn::imat &xc_incoherent_collapsed_frq, vf3d &xc_incoherent_single, vf3d &xc_incoherent,
+                 cn::vec &sp_incoherent, vcf3d &xc, cn::vec &sp, unsigned short &n_comb_xc, unsigned short &n_comb_sp,
+                 bool want_xc = false) {
+    const int n_cap = capbuf.length(), n_f = f_search_set.length();
+    std::vector<double> pow_(3 * 9600);
+    std::vector<int> frq(3 * 9600);
+    std::vector<float> single((size_t)3 * 9600 * n_f), inc((size_t)3 * 9600 * n_f);
+    sp_incoherent.set_size(9600);
+    const int ncsp = (n_cap - 136 - 137) / 9600;
+    sp.set_size(ncsp * 9600);
+    std::vector<float> xcbuf;
+    if (want_xc) xcbuf.resize((size_t)3 * (n_cap - 136) * n_f * 2);
+    check(lcs_xcorr_pss(h_, reinterpret_cast<const double *>(capbuf._data()), (uint32_t)n_cap, f_search_set._data(),
+                        (uint16_t)n_f, ds_comb_arm, fc_requested, fc_programmed, fs_programmed, pow_.data(), frq.data(),
+                        single.data(), inc.data(), sp_incoherent._data(), want_xc ? xcbuf.data() : 0, sp._data(),
+                        &n_comb_xc, &n_comb_sp));
+    xc_incoherent_collapsed_pow.set_size(3, 9600);
+    xc_incoherent_collapsed_frq.set_size(3, 9600);
+    for (int t = 0; t < 3; ++t)
+      for (int k = 0; k < 9600; ++k) {
+        xc_incoherent_collapsed_pow(t, k) = pow_[t * 9600 + k];
+        xc_incoherent_collapsed_frq(t, k) = frq[t * 9600 + k];
+      }
+    to3d(single, n_f, xc_incoherent_single);
+    to3d(inc, n_f, xc_incoherent);
+    xc.clear();
+    if (want_xc) {
+      xc.assign(3, std::vector<std::vector<std::complex<float> > >(n_cap - 136, std::vector<std::complex<float> >(n_f)));
+      for (int t = 0; t < 3; ++t)
+        for (int k = 0; k < n_cap - 136; ++k)
+          for (int f = 0; f < n_f; ++f) {
+            const size_t o = (((size_t)t * (n_cap - 136) + k) * n_f + f) * 2;
+            xc[t][k][f] = std::complex<float>(xcbuf[o], xcbuf[o + 1]);
+          }
+    }
+  }
+
+  // include/searcher.h:44-56 (appends to `cells`)
+  void peak_search(const cn::mat &pow_, const cn::imat &frq, const cn::vec &Z_th1, const cn::vec &f_search_set,
+                   double fc_requested, double fc_programmed, const vf3d &xc_incoherent_single,
+                   unsigned char ds_comb_arm, std::list<Cell> &cells) {
+    const int n_f = f_search_set.length();
+    std::vector<double> p(3 * 9600);
+    std::vector<int> q(3 * 9600);
+    for (int t = 0; t < 3; ++t)
+      for (int k = 0; k < 9600; ++k) { p[t * 9600 + k] = pow_(t, k); q[t * 9600 + k] = frq(t, k); }
+    std::vector<float> single((size_t)3 * 9600 * n_f);
+    for (int t = 0; t < 3; ++t)
+      for (int k = 0; k < 9600; ++k)
+        for (int f = 0; f < n_f; ++f) single[((size_t)t * 9600 + k) * n_f + f] = xc_incoherent_single[t][k][f];
+    std::vector<lcs_cell> out(64);
+    int n = 0;
+    check(lcs_peak_search(h_, p.data(), q.data(), Z_th1._data(), f_search_set._data(), (uint16_t)n_f, fc_requested,
+                          fc_programmed, single.data(), ds_comb_arm, out.data(), (int)out.size(), &n));
+    for (int i = 0; i < n; ++i) cells.push_back(Cell(out[i]));
+  }
+
+  // include/searcher.h:59-76
+  Cell sss_detect(const Cell &cell, const cn::cvec &capbuf, double thresh2_n_sigma, double fc_requested,
+                  double fc_programmed, double fs_programmed, cn::vec &sss_h1_np_est, cn::vec &sss_h2_np_est,
+                  cn::cvec &sss_h1_nrm_est, cn::cvec &sss_h2_nrm_est, cn::cvec &sss_h1_ext_est,
+                  cn::cvec &sss_h2_ext_est, cn::mat &log_lik_nrm, cn::mat &log_lik_ext) {
+    sss_h1_np_est.set_size(62); sss_h2_np_est.set_size(62);
+    sss_h1_nrm_est.set_size(62); sss_h2_nrm_est.set_size(62); sss_h1_ext_est.set_size(62); sss_h2_ext_est.set_size(62);
+    std::vector<double> ln(336), le(336);
+    Cell out;
+    check(lcs_sss_detect(h_, &cell, reinterpret_cast<const double *>(capbuf._data()), (uint32_t)capbuf.length(),
+                         thresh2_n_sigma, fc_requested, fc_programmed, fs_programmed, &out, sss_h1_np_est._data(),
+                         sss_h2_np_est._data(), reinterpret_cast<double *>(sss_h1_nrm_est._data()),
+                         reinterpret_cast<double *>(sss_h2_nrm_est._data()), reinterpret_cast<double *>(sss_h1_ext_est._data()),
+                         reinterpret_cast<double *>(sss_h2_ext_est._data()), ln.data(), le.data()));
+    log_lik_nrm.set_size(168, 2); log_lik_ext.set_size(168, 2);
+    for (int t = 0; t < 168; ++t)
+      for (int c = 0; c < 2; ++c) { log_lik_nrm(t, c) = ln[t * 2 + c]; log_lik_ext(t, c) = le[t * 2 + c]; }
+    return out;
+  }
+
+  // include/searcher.h:79-85
+  Cell pss_sss_foe(const Cell &cell_in, const cn::cvec &capbuf, double fc_requested, double fc_programmed,
+                   double fs_programmed) {
+    Cell out;
+    check(lcs_pss_sss_foe(h_, &cell_in, reinterpret_cast<const double *>(capbuf._data()), (uint32_t)capbuf.length(),
+                          fc_requested, fc_programmed, fs_programmed, &out));
+    return out;
+  }
+
+  // include/searcher.h:88-98
+  void extract_tfg(const Cell &cell, const cn::cvec &capbuf_raw, double fc_requested, double fc_programmed,
+                   double fs_programmed, cn::cmat &tfg, cn::vec &tfg_timestamp) {
+    std::vector<double> g((size_t)LCS_TFG_MAX_OFDM * LCS_TFG_NSC * 2), ts(LCS_TFG_MAX_OFDM);
+    int n = 0;
+    check(lcs_extract_tfg(h_, &cell, reinterpret_cast<const double *>(capbuf_raw._data()), (uint32_t)capbuf_raw.length(),
+                          fc_requested, fc_programmed, fs_programmed, g.data(), ts.data(), &n));
+    from_rows(g, n, tfg);
+    tfg_timestamp.set_size(n);
+    for (int t = 0; t < n; ++t) tfg_timestamp(t) = ts[t];
+  }
+
+  // include/searcher.h:101-112 (RS_DL is rebuilt on the device)
+  Cell tfoec(const Cell &cell, const cn::cmat &tfg, const cn::vec &tfg_timestamp, double fc_requested,
+             double fc_programmed, cn::cmat &tfg_comp, cn::vec &tfg_comp_timestamp) {
+    const int n = tfg.rows();
+    std::vector<double> g, gc((size_t)n * LCS_TFG_NSC * 2);
+    to_rows(tfg, g);
+    tfg_comp_timestamp.set_size(n);
+    Cell out;
+    check(lcs_tfoec(h_, &cell, g.data(), tfg_timestamp._data(), n, fc_requested, fc_programmed, gc.data(),
+                    tfg_comp_timestamp._data(), &out));
+    from_rows(gc, n, tfg_comp);
+    return out;
+  }
+
+  // include/searcher.h:115-119
+  Cell decode_mib(const Cell &cell, const cn::cmat &tfg) {
+    std::vector<double> g;
+    to_rows(tfg, g);
+    Cell out;
+    check(lcs_decode_mib(h_, &cell, g.data(), tfg.rows(), &out));
+    return out;
+  }
+
+  // whole per-buffer chain of the CLI main loop, device-resident (src/CellSearch.cpp:484-558)
+  void search_capbuf(const cn::cvec &capbuf, const cn::vec &f_search_set, double fc_requested, double fc_programmed,
+                     double fs_programmed, std::list<Cell> &cells) {
+    std::vector<lcs_cell> out(64);
+    int n = 0;
+    check(lcs_search_capbuf(h_, reinterpret_cast<const double *>(capbuf._data()), (uint32_t)capbuf.length(),
+                            f_search_set._data(), (uint16_t)f_search_set.length(), fc_requested, fc_programmed,
+                            fs_programmed, out.data(), (int)out.size(), &n, 0, 0, 0));
+    for (int i = 0; i < n && i < (int)out.size(); ++i) cells.push_back(Cell(out[i]));
+  }
+
+ private:
+  void check(int rc) {
+    if (rc != LCS_OK) throw error(std::string("liblcs_amd: ") + lcs_last_error(h_));
+  }
+  static void to3d(const std::vector<float> &flat, int n_f, vf3d &out) {
+    out.assign(3, std::vector<std::vector<float> >(9600, std::vector<float>(n_f)));
+    for (int t = 0; t < 3; ++t)
+      for (int k = 0; k < 9600; ++k)
+        for (int f = 0; f < n_f; ++f) out[t][k][f] = flat[((size_t)t * 9600 + k) * n_f + f];
+  }
+  static void to_rows(const cn::cmat &m, std::vector<double> &g) {   // column-major cmat -> [row][72] interleaved
+    g.resize((size_t)m.rows() * m.cols() * 2);
+    for (int r = 0; r < m.rows(); ++r)
+      for (int c = 0; c < m.cols(); ++c) {
+        g[((size_t)r * m.cols() + c) * 2] = m(r, c).real();
+        g[((size_t)r * m.cols() + c) * 2 + 1] = m(r, c).imag();
+      }
+  }
+  static void from_rows(const std::vector<double> &g, int n, cn::cmat &m) {
+    m.set_size(n, LCS_TFG_NSC);
+    for (int r = 0; r < n; ++r)
+      for (int c = 0; c < LCS_TFG_NSC; ++c)
+        m(r, c) = std::complex<double>(g[((size_t)r * LCS_TFG_NSC + c) * 2], g[((size_t)r * LCS_TFG_NSC + c) * 2 + 1]);
+  }
+  lcs_ctx *h_;
+};
+
+}  // namespace lcs
+#endif
