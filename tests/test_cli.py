@@ -56,7 +56,7 @@ def test_fulltest_known_answer(tmp_path):
     assert re.search(r"cell.ID..271", r.stdout) and re.search(r"cell.ID..277", r.stdout)
     assert "Examining center frequency 739 MHz ..." in r.stdout
     assert "CID A      fc   foff RXPWR C nRB P  PR CrystalCorrectionFactor" in r.stdout
-    rows = [l for l in r.stdout.splitlines() if re.match(r"^(277|271) 2    739M 35\.2k", l)]
+    rows = [l for l in r.stdout.splitlines() if re.match(r"^(277|271) 2    739M  35\.2k", l)]
     assert len(rows) == 2, r.stdout
     for l in rows:
         assert re.search(r" N  50 N one 1\.0000476", l), l
