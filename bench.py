@@ -98,6 +98,8 @@ def main():
                     help="contexts (streams + workspaces) used round-robin: with 2, the latency-bound per-cell "
                          "stages of step i overlap the PSS correlation of step i+1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (testing the multi-rank path on one GPU)")
+    ap.add_argument("--share-gpu0", action="store_true", help="testing only: every rank uses GPU 0")
     args = ap.parse_args()
 
     import torch
@@ -112,11 +114,17 @@ def main():
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.share_gpu0:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.dist_backend)
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank if world > 1 else 0)
+    coll_dev = dev if args.dist_backend == "nccl" else torch.device("cpu")
 
     f = pkg.f_search_set_for(FC, args.ppm)
     stage_mask = pkg.STAGE_FULL if args.stage == "full" else pkg.STAGE_PSS
@@ -129,7 +137,7 @@ def main():
     for S in ctxs:
         S.set_xcorr_variant(args.variant)
     MAXC = 16
-    gather_buf = torch.zeros((world, B, 1 + MAXC * 4), dtype=torch.float64, device=dev) if world > 1 else None
+    gather_buf = torch.zeros((world, B, 1 + MAXC * 4), dtype=torch.float64, device=coll_dev) if world > 1 else None
 
     host_t = {"enqueue": 0.0, "collect": 0.0, "n": 0}
 
@@ -138,22 +146,22 @@ def main():
         ctxs[i % len(ctxs)].batch_enqueue(d_cap.data_ptr(), pkg.FMT_IQ_U8, B, N_CAP, f, fcs, fcs, FS, stage_mask)
         host_t["enqueue"] += time.perf_counter() - t
 
-    def collect(i):
+    def collect(i, gather=True):
         t = time.perf_counter()
         res = ctxs[i % len(ctxs)].batch_collect(B, MAXC)
         host_t["collect"] += time.perf_counter() - t
         host_t["n"] += 1
         host_t.setdefault("stamps", []).append(time.perf_counter())
-        if world > 1:   # RCCL all-gather of the detected-cell list (fixed-size records), nothing else
+        if world > 1 and gather:   # RCCL all-gather of the detected-cell list (fixed-size records), nothing else
             mine = torch.zeros((B, 1 + MAXC * 4), dtype=torch.float64)
             for b, cells in enumerate(res):
                 mine[b, 0] = len(cells)
                 for i, c in enumerate(cells[:MAXC]):
                     mine[b, 1 + 4 * i: 5 + 4 * i] = torch.tensor([c.n_id_cell(), c.fc_requested, c.freq_superfine if stage_mask == 3 else c.freq, c.pss_pow])
-            dist.all_gather_into_tensor(gather_buf.view(-1), mine.to(dev).view(-1))
+            dist.all_gather_into_tensor(gather_buf.view(-1), mine.to(coll_dev).view(-1))
         return res
 
-    def run(n_steps, xc_ms=None):
+    def run(n_steps, xc_ms=None, gather=True):
         """n_steps steps, software-pipelined over the contexts: step i is enqueued before step
         i-(depth-1) is collected, so nothing but the stream of the collected step ever blocks."""
         depth = len(ctxs)
@@ -163,7 +171,7 @@ def main():
                 enqueue(i)
             j = i - (depth - 1)
             if j >= 0:
-                res = collect(j)
+                res = collect(j, gather)
                 if xc_ms is not None:
                     xc_ms.append(ctxs[j % depth].last_xcorr_ms()[0])
         return res
@@ -173,7 +181,7 @@ def main():
     # busy for ~0.6 s so that it does not land in the timed steps of a short run.
     t_pre = time.perf_counter()
     while time.perf_counter() - t_pre < 0.6:
-        run(2)
+        run(2, gather=False)      # time-based, so no collective in here (ranks may differ in count)
     host_t.update(enqueue=0.0, collect=0.0, n=0, stamps=[])
     if args.warmup:
         res = run(args.warmup)
@@ -188,7 +196,7 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
