@@ -1,0 +1,93 @@
+"""Size-independent properties of the GPU path at BASELINE sizes (153600 samples, n_f = 31):
+things that must hold exactly, whatever the data, without needing the (slow) CPU oracle."""
+import numpy as np
+import pytest
+
+from conftest import golden, iq_u8_to_capbuf, f_search_set_for, load_pkg
+
+pytestmark = pytest.mark.gpu
+FS = 1.92e6
+FC = 739e6
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    return load_pkg()
+
+
+@pytest.fixture(scope="module")
+def S(pkg):
+    s = pkg.Searcher(0)
+    yield s
+    s.close()
+
+
+@pytest.fixture(scope="module")
+def synth_buf(pkg):
+    iq, _ = pkg.synth.make_capbuf(4242, FC, [dict(n_id_1=41, n_id_2=2, f_off=-18e3), dict(n_id_1=100, n_id_2=0, f_off=-17e3, gain_db=-5)], 6.0)
+    return iq
+
+
+def test_power_of_two_scaling_is_exact(S, pkg, synth_buf):
+    """xcorr is quadratic in the buffer: scaling the input by 2 scales every correlation power by
+    exactly 4 (power-of-two scaling commutes with fp32/fp64 rounding) and moves no decision."""
+    f = f_search_set_for(FC, 100)
+    cap = pkg.synth.iq_u8_to_complex(synth_buf)
+    a = S.xcorr_pss(cap, f, 2, FC, FC, FS)
+    b = S.xcorr_pss(2.0 * cap, f, 2, FC, FC, FS)
+    assert np.array_equal(b["single"], 4.0 * a["single"])
+    assert np.array_equal(b["incoherent"], 4.0 * a["incoherent"])
+    assert np.array_equal(b["pow"], 4.0 * a["pow"]) and np.array_equal(b["frq"], a["frq"])
+    assert np.array_equal(b["sp_incoherent"], 4.0 * a["sp_incoherent"])
+
+
+def test_full_grid_mfma_equals_valu_and_is_repeatable(S, pkg, synth_buf):
+    f = f_search_set_for(FC, 100)
+    cap = pkg.synth.iq_u8_to_complex(synth_buf)
+    S.set_xcorr_variant(0)
+    a = S.xcorr_pss(cap, f, 2, FC, FC, FS, want_incoherent=False)
+    a2 = S.xcorr_pss(cap, f, 2, FC, FC, FS, want_incoherent=False)
+    S.set_xcorr_variant(1)
+    b = S.xcorr_pss(cap, f, 2, FC, FC, FS, want_incoherent=False)
+    S.set_xcorr_variant(0)
+    assert np.array_equal(a["single"], a2["single"]) and np.array_equal(a["pow"], a2["pow"])
+    assert np.array_equal(a["single"], b["single"]) and np.array_equal(a["frq"], b["frq"])
+
+
+def test_batch_slots_are_independent_and_placement_invariant(S, pkg, synth_buf):
+    """19 slots (two XCD-mapped groups of 8 + 3 plainly mapped): a buffer gives the same cells in
+    whatever slot it sits, and the same as the single-buffer entry point."""
+    import torch
+    f = f_search_set_for(FC, 100)
+    g = golden("capbuf_0000")["iq_u8"]
+    rng = np.random.default_rng(11)
+    noise = np.clip(np.rint(rng.normal(127.0, 15.0, g.size)), 0, 255).astype(np.uint8)
+    order = [0, 1, 2, 1, 0, 2, 2, 0, 1, 0, 1, 2, 1, 1, 0, 2, 0, 2, 1]
+    src = [synth_buf, g, noise]
+    d = torch.from_numpy(np.stack([src[i] for i in order])).cuda()
+    res = S.search_batch(d.data_ptr(), pkg.FMT_IQ_U8, len(order), 153600, f, FC, FC, FS, pkg.STAGE_FULL)
+    ref = [S.search_capbuf(iq_u8_to_capbuf(x), f, FC, FC, FS)[0] for x in src]
+    key = lambda c: tuple(c.as_dict().values())
+    for slot, i in enumerate(order):
+        assert [key(c) for c in res[slot]] == [key(c) for c in ref[i]], slot
+    assert sorted(c.n_id_cell() for c in ref[0]) == [125, 300] and [c.n_id_cell() for c in ref[1]] == [277, 271] and ref[2] == []
+
+
+def test_all_zero_buffer_terminates(S, pkg):
+    """Degenerate input (every threshold is 0): the reference's peak_search loop never terminates;
+    the GPU loop is bounded and reports overflow instead of hanging."""
+    with pytest.raises(pkg.SearcherError):
+        S.search_capbuf(np.zeros(153600, np.complex128), f_search_set_for(FC, 100), FC, FC, FS)
+
+
+def test_ragged_buffer_lengths(S, pkg, synth_buf):
+    import oracle as O
+    O.set_threads(16)
+    cap = pkg.synth.iq_u8_to_complex(synth_buf)
+    f = np.array([-20e3, -15e3])
+    for n in (150001, 144237, 60000):
+        r = S.xcorr_pss(cap[:n], f, 2, FC, FC, FS, want_incoherent=False)
+        ro = O.xcorr_pss(cap[:n], f, 2, FC, FC, FS)
+        assert r["n_comb_xc"] == ro["n_comb_xc"] == (n - 236) // 9600 and r["n_comb_sp"] == ro["n_comb_sp"]
+        assert np.array_equal(r["frq"], ro["frq"])
+        assert (np.abs(r["pow"] - ro["pow"]) / ro["pow"]).max() < 1e-5
