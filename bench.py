@@ -215,6 +215,16 @@ def main():
         flops_per_buf = 8.0 * 137 * 3 * (N_CAP - 136) * n_f
         flops_consumed = 8.0 * 137 * 3 * 9600 * 15 * n_f       # the 15x9600 lags that are ever used
         k_ms = float(np.mean(xc_ms))
+        # HBM traffic of the dominant kernel from the PMC counters (FETCH_SIZE / WRITE_SIZE, separate
+        # rocprofv3 passes, corrected as MI355X_MICROARCH.md prescribes): measured per buffer at this
+        # n_f with the default kernel, summary committed under profiles/ -- null when not measured.
+        traffic = None
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_summary.json")))["kernels"]["k_xcorr_mfma"]
+            if int(pm["n_f"]) == int(n_f) and args.variant != 1:
+                traffic = float(pm["hbm_bytes_per_buffer"]) * B
+        except Exception:
+            traffic = None
         achieved = flops_per_buf * B / (k_ms * 1e-3) / 1e12
         bytes_per_buf = 1651200 + 230400 * n_f                 # SURVEY.md section 8d compulsory HBM bytes
         out = {
@@ -227,7 +237,7 @@ def main():
                                     "configs[1]: xcorr_pss + peak_search over the full +-100 ppm foe grid") +
                                    f", one MI355X per rank, {B} x 153600-sample capbufs per step, fc 739 MHz + 100 kHz raster",
                        "n_f": int(n_f), "batch_per_gpu": B, "stage": args.stage, "ingest": "u8 I/Q resident in HBM",
-                       "xcorr_kernel": "mfma_f32_16x16x4" if args.variant == 0 else "valu_f32",
+                       "xcorr_kernel": "valu_f32" if args.variant == 1 else "mfma_f32_16x16x4" + (f"(tuning variant {args.variant})" if args.variant else ""),
                        "pipeline_depth": len(ctxs),
                        "parallelism": f"carrier-sweep shard x{world}, RCCL all-gather of cell list" if world > 1 else "single GPU",
                        "baseline_note": "vs_baseline = value / (1 buffer per ~6 s), doc/CellSearch.html:52-54 (dual-core i7-2640, ppm 100)",
@@ -236,8 +246,10 @@ def main():
                        "host_ms_per_step": {"enqueue": 1e3 * host_t["enqueue"] / max(1, host_t["n"]),
                                             "collect_incl_wait": 1e3 * host_t["collect"] / max(1, host_t["n"])}},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_TFLOPS, "traffic": None,
-                         "kernel": "k_xcorr_mfma" if args.variant == 0 else "k_xcorr_valu", "kernel_ms": k_ms,
+                         "frac": achieved / PEAK_FP32_TFLOPS, "traffic": traffic,
+                         "traffic_note": "HBM bytes per launch from rocprofv3 PMC (2*FETCH_SIZE+WRITE_SIZE)*1024, profiles/r01/pmc_summary.json; "
+                                         "algorithmic bytes of this kernel per launch: %d" % int((8 * N_CAP + 4 * 3 * 9600 * n_f) * B),
+                         "kernel": "k_xcorr_valu" if args.variant == 1 else "k_xcorr_mfma", "kernel_ms": k_ms,
                          "kernel_ms_isolated": float(np.mean(iso_ms)),
                          "frac_isolated": flops_per_buf * B / (float(np.mean(iso_ms)) * 1e-3) / 1e12 / PEAK_FP32_TFLOPS,
                          "flops_per_launch": flops_per_buf * B,

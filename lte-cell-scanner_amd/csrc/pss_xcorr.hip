@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void k_prep_tables(const SlotParams *__restric
 // template c = 16g + j delayed by start[w][foi(c)] - smin[w][g]; zero outside the 137 taps.
 __global__ __launch_bounds__(256) void k_fill_btab(const float2 *__restrict__ tmpl, const int *__restrict__ start,
                                                     const int *__restrict__ smin, const int *__restrict__ kp2,
-                                                    float *__restrict__ btab, XcGeom geo) {
+                                                    float *__restrict__ btab, XcGeom geo, int layout4) {
   const int slot = blockIdx.z;
   const int wg = blockIdx.y;
   const int w = wg / geo.G, g = wg % geo.G;
@@ -128,7 +128,9 @@ __global__ __launch_bounds__(256) void k_fill_btab(const float2 *__restrict__ tm
         v = ((l >> 4) & 1) ? T.y : T.x;
       }
     }
-    out[e] = v;
+    // layout4: the four rows of an unrolled step are interleaved per lane ([kk/4][lane][kk%4]) so
+    // that the MFMA kernel fetches them with one 16-byte load per lane
+    if (layout4) out[(((kk >> 2) * 64 + l) << 2) + (kk & 3)] = v; else out[e] = v;
   }
 }
 
@@ -272,6 +274,113 @@ __global__ __launch_bounds__(64) void k_xcorr_mfma(const float2 *__restrict__ ca
         o[(size_t)idx * LCS_TG] = __fdiv_rn(P[mt][r], ncomb);      // 16 lanes = one 64-byte row
       }
   }
+}
+
+// Tuning variants of the MFMA kernel (A/B partners; bit-identical results): WPS = waves per SIMD the
+// register allocation is bounded for, PREFETCH = next window's samples fetched into registers
+// during the current window and two LDS buffers (otherwise one buffer, staged in place).
+template <int WPS, bool PREFETCH, int UNROLL, int ABL = 0, bool B4 = false>
+__global__ __launch_bounds__(64, WPS) void k_xcorr_mfma_t(const float2 *__restrict__ cap32, const int *__restrict__ smin,
+                                                           const int *__restrict__ kp2, const float *__restrict__ btab,
+                                                           float *__restrict__ sg, XcGeom geo, int slot0, int n_slots,
+                                                           int xcd_map) {
+  const int lane = threadIdx.x;
+  int tile, g, slot;
+  if (!decode_block(geo, slot0, n_slots, xcd_map, tile, g, slot)) return;
+  const int idx0 = tile * LCS_LAG_TILE;
+  __shared__ float lds[(PREFETCH ? 2 : 1) * 3 * LCS_PS];
+  const float2 *cap = cap32 + (size_t)slot * geo.n_cap;
+  const int *smin_s = smin + (size_t)slot * NW * GM + g;
+  const int *kp2_s = kp2 + (size_t)slot * NW * GM + g;
+  const int odd = (lane >> 4) & 1;
+  const int a1_off = (odd ? 2 * LCS_PS : LCS_PS) + (lane & 15) + (lane >> 5);
+  const int a2_off = (odd ? LCS_PS : 0) + (lane & 15) + (lane >> 5);
+  f32x4 P[4];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) P[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float2 pre[5];
+  if (PREFETCH) stage_load(pre, cap, geo.n_cap, idx0 + smin_s[0], LCS_LAG_TILE + 2 * kp2_s[0], lane);
+  for (int w = 0; w < geo.n_comb; ++w) {
+    const int k2 = kp2_s[w * GM];
+    float *buf = lds + (PREFETCH ? (w & 1) * 3 * LCS_PS : 0);
+    if (PREFETCH) {
+      stage_write(buf, pre, LCS_LAG_TILE + 2 * k2, lane);
+      __syncthreads();
+      if (w + 1 < geo.n_comb)
+        stage_load(pre, cap, geo.n_cap, idx0 + smin_s[(w + 1) * GM], LCS_LAG_TILE + 2 * kp2_s[(w + 1) * GM], lane);
+    } else {
+      __syncthreads();   // everybody is done reading the previous window
+      const int sl = LCS_LAG_TILE + 2 * k2, L0 = idx0 + smin_s[w * GM];
+      for (int n = lane; n < sl; n += 64) {
+        const uint32_t src = (uint32_t)(L0 + n);
+        const float2 v = (src < geo.n_cap) ? cap[src] : make_float2(0.f, 0.f);
+        buf[n] = v.y; buf[LCS_PS + n] = v.x; buf[2 * LCS_PS + n] = -v.y;
+      }
+      __syncthreads();
+    }
+    f32x4 aR[4], aI[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) { aR[mt] = (f32x4){0.f, 0.f, 0.f, 0.f}; aI[mt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    const float *bp = btab + (((size_t)slot * geo.n_comb + w) * geo.G + g) * (size_t)(LCS_KP2_MAX * 64) + lane;
+    const float *a1p = buf + a1_off;
+    const float *a2p = buf + a2_off;
+    static_assert(!B4 || UNROLL == 4, "the interleaved B layout is built for 4-step unrolling");
+    const float4 *bp4 = reinterpret_cast<const float4 *>(bp - lane) + lane;   // [kk/4][lane] -> float4
+    float bnext[UNROLL];
+    if (B4) { const float4 t = bp4[0]; bnext[0] = t.x; bnext[1] = t.y; bnext[2] = t.z; bnext[3] = t.w; }
+    else {
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) bnext[u] = bp[u * 64];
+    }
+    const int k2m = k2 - (k2 % UNROLL);
+    int kk = 0;
+    for (; kk < k2m; kk += UNROLL) {
+      float b[UNROLL];
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) b[u] = bnext[u];
+      if (B4) { const float4 t = bp4[((kk >> 2) + 1) * 64]; bnext[0] = t.x; bnext[1] = t.y; bnext[2] = t.z; bnext[3] = t.w; }
+      else {
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) bnext[u] = (ABL & 2) ? bnext[u] : bp[(kk + UNROLL + u) * 64];
+      }
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          // ABLATION builds (measurement only, wrong results): operands not re-read per step
+          const float a1 = (ABL & 1) ? a1p[mt * 16] : a1p[mt * 16 + 2 * (kk + u)];
+          const float a2 = (ABL & 1) ? a2p[mt * 16] : a2p[mt * 16 + 2 * (kk + u)];
+          aR[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b[u], aR[mt], 0, 0, 0);
+          aI[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b[u], aI[mt], 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL - 1; ++u) {
+      if (kk + u < k2) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          const float a1 = a1p[mt * 16 + 2 * (kk + u)];
+          const float a2 = a2p[mt * 16 + 2 * (kk + u)];
+          aR[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bnext[u], aR[mt], 0, 0, 0);
+          aI[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, bnext[u], aI[mt], 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) P[mt][r] = P[mt][r] + pow2sum(aR[mt][r], aI[mt][r]);
+  }
+  const float ncomb = (float)geo.n_comb;
+  float *o = sg + (((size_t)slot * geo.G + g) * LCS_N_IDX) * LCS_TG + (lane & 15);
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int idx = idx0 + mt * 16 + 4 * (lane >> 4) + r;
+      o[(size_t)idx * LCS_TG] = __fdiv_rn(P[mt][r], ncomb);
+    }
 }
 
 __global__ __launch_bounds__(64) void k_xcorr_valu(const float2 *__restrict__ cap32, const int *__restrict__ smin,
@@ -504,8 +613,9 @@ static hipEvent_t g_xc_done[64] = {};
 int lcs_launch_xcorr(lcs_ctx *c, int n_buf, const XcGeom &geo, bool want_incoh, bool time_it) {
   hipLaunchKernelGGL(k_prep_tables, dim3(n_buf), dim3(256), 0, c->stream, c->params, c->fset, c->d_pss_td, c->tmpl,
                      c->start, c->smin, c->kp2, geo);
+  const int layout4 = (c->xcorr_variant == 12 || c->xcorr_variant == 13 || c->xcorr_variant == 14) ? 1 : 0;
   hipLaunchKernelGGL(k_fill_btab, dim3(8, geo.n_comb * geo.G, n_buf), dim3(256), 0, c->stream, c->tmpl, c->start,
-                     c->smin, c->kp2, c->btab, geo);
+                     c->smin, c->kp2, c->btab, geo, layout4);
   // signal-power estimate and threshold do not depend on the correlation: enqueue them first
   SpArgs a;
   a.n_comb_sp = (int)((geo.n_cap - 136 - 137) / 9600);
@@ -540,9 +650,23 @@ int lcs_launch_xcorr(lcs_ctx *c, int n_buf, const XcGeom &geo, bool want_incoh, 
     const int s0 = part ? n8 : 0, ns = part ? n_buf - n8 : n8;
     if (ns <= 0) continue;
     const dim3 grid((unsigned)(per_slot * ns));
+#define XC_ARGS grid, dim3(64), lds_pad, sxc, c->cap32, c->smin, c->kp2, c->btab, c->single, geo, s0, ns, part ? 0 : 1
     if (c->xcorr_variant == 1)
       hipLaunchKernelGGL(k_xcorr_valu, grid, dim3(64), lds_pad, sxc, c->cap32, c->smin, c->kp2, c->btab, c->single,
                          geo, s0, ns, part ? 0 : 1);
+    else if (c->xcorr_variant == 2) hipLaunchKernelGGL((k_xcorr_mfma_t<6, false, 2>), XC_ARGS);
+    else if (c->xcorr_variant == 3) hipLaunchKernelGGL((k_xcorr_mfma_t<5, false, 4>), XC_ARGS);
+    else if (c->xcorr_variant == 4) hipLaunchKernelGGL((k_xcorr_mfma_t<5, true, 2>), XC_ARGS);
+    else if (c->xcorr_variant == 5) hipLaunchKernelGGL((k_xcorr_mfma_t<4, true, 8>), XC_ARGS);
+    else if (c->xcorr_variant == 6) hipLaunchKernelGGL((k_xcorr_mfma_t<8, false, 2>), XC_ARGS);
+    else if (c->xcorr_variant == 7) hipLaunchKernelGGL((k_xcorr_mfma_t<5, false, 4, 1>), XC_ARGS);   // ablation: no A reads
+    else if (c->xcorr_variant == 8) hipLaunchKernelGGL((k_xcorr_mfma_t<5, false, 4, 2>), XC_ARGS);   // ablation: no B loads
+    else if (c->xcorr_variant == 9) hipLaunchKernelGGL((k_xcorr_mfma_t<5, false, 4, 3>), XC_ARGS);   // ablation: MFMA only
+    else if (c->xcorr_variant == 10) hipLaunchKernelGGL((k_xcorr_mfma_t<6, false, 4>), XC_ARGS);
+    else if (c->xcorr_variant == 11) hipLaunchKernelGGL((k_xcorr_mfma_t<4, false, 4>), XC_ARGS);
+    else if (c->xcorr_variant == 12) hipLaunchKernelGGL((k_xcorr_mfma_t<5, false, 4, 0, true>), XC_ARGS);
+    else if (c->xcorr_variant == 13) hipLaunchKernelGGL((k_xcorr_mfma_t<6, false, 4, 0, true>), XC_ARGS);
+    else if (c->xcorr_variant == 14) hipLaunchKernelGGL((k_xcorr_mfma_t<4, true, 4, 0, true>), XC_ARGS);
     else
       hipLaunchKernelGGL(k_xcorr_mfma, grid, dim3(64), lds_pad, sxc, c->cap32, c->smin, c->kp2, c->btab, c->single,
                          geo, s0, ns, part ? 0 : 1);
