@@ -93,7 +93,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="capture buffers per step per GPU")
     ap.add_argument("--ppm", type=float, default=100.0)
     ap.add_argument("--stage", choices=["pss", "full"], default="pss")
-    ap.add_argument("--variant", type=int, default=0, help="0 = MFMA-f32 correlation kernel, 1 = VALU kernel")
+    ap.add_argument("--variant", type=int, default=0, help="PSS correlation kernel: 0 = default MFMA-f32 kernel, 1 = VALU twin, 2..7 tuning variants")
     ap.add_argument("--pipeline", type=int, default=2,
                     help="contexts (streams + workspaces) used round-robin: with 2, the latency-bound per-cell "
                          "stages of step i overlap the PSS correlation of step i+1")
@@ -249,7 +249,7 @@ def main():
                          "frac": achieved / PEAK_FP32_TFLOPS, "traffic": traffic,
                          "traffic_note": "HBM bytes per launch from rocprofv3 PMC (2*FETCH_SIZE+WRITE_SIZE)*1024, profiles/r01/pmc_summary.json; "
                                          "algorithmic bytes of this kernel per launch: %d" % int((8 * N_CAP + 4 * 3 * 9600 * n_f) * B),
-                         "kernel": "k_xcorr_valu" if args.variant == 1 else "k_xcorr_mfma", "kernel_ms": k_ms,
+                         "kernel": {0: "k_xcorr_mfma_blk<4,4,32>", 1: "k_xcorr_valu", 2: "k_xcorr_mfma"}.get(args.variant, f"variant {args.variant}"), "kernel_ms": k_ms,
                          "kernel_ms_isolated": float(np.mean(iso_ms)),
                          "frac_isolated": flops_per_buf * B / (float(np.mean(iso_ms)) * 1e-3) / 1e12 / PEAK_FP32_TFLOPS,
                          "flops_per_launch": flops_per_buf * B,

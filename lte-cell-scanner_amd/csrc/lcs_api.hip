@@ -238,7 +238,7 @@ void lcs_destroy(lcs_ctx *c) {
 const char *lcs_last_error(const lcs_ctx *c) { return c ? c->err.c_str() : "null context"; }
 
 int lcs_set_xcorr_variant(lcs_ctx *c, int variant) {
-  if (!c || variant < 0 || variant > 14) return LCS_ERR_BAD_ARG;
+  if (!c || variant < 0 || variant > 7) return LCS_ERR_BAD_ARG;
   c->xcorr_variant = variant;
   return LCS_OK;
 }

@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void k_prep_tables(const SlotParams *__restric
 // template c = 16g + j delayed by start[w][foi(c)] - smin[w][g]; zero outside the 137 taps.
 __global__ __launch_bounds__(256) void k_fill_btab(const float2 *__restrict__ tmpl, const int *__restrict__ start,
                                                     const int *__restrict__ smin, const int *__restrict__ kp2,
-                                                    float *__restrict__ btab, XcGeom geo, int layout4) {
+                                                    float *__restrict__ btab, XcGeom geo) {
   const int slot = blockIdx.z;
   const int wg = blockIdx.y;
   const int w = wg / geo.G, g = wg % geo.G;
@@ -128,9 +128,7 @@ __global__ __launch_bounds__(256) void k_fill_btab(const float2 *__restrict__ tm
         v = ((l >> 4) & 1) ? T.y : T.x;
       }
     }
-    // layout4: the four rows of an unrolled step are interleaved per lane ([kk/4][lane][kk%4]) so
-    // that the MFMA kernel fetches them with one 16-byte load per lane
-    if (layout4) out[(((kk >> 2) * 64 + l) << 2) + (kk & 3)] = v; else out[e] = v;
+    out[e] = v;
   }
 }
 
@@ -279,7 +277,7 @@ __global__ __launch_bounds__(64) void k_xcorr_mfma(const float2 *__restrict__ ca
 // Tuning variants of the MFMA kernel (A/B partners; bit-identical results): WPS = waves per SIMD the
 // register allocation is bounded for, PREFETCH = next window's samples fetched into registers
 // during the current window and two LDS buffers (otherwise one buffer, staged in place).
-template <int WPS, bool PREFETCH, int UNROLL, int ABL = 0, bool B4 = false>
+template <int WPS, bool PREFETCH, int UNROLL>
 __global__ __launch_bounds__(64, WPS) void k_xcorr_mfma_t(const float2 *__restrict__ cap32, const int *__restrict__ smin,
                                                            const int *__restrict__ kp2, const float *__restrict__ btab,
                                                            float *__restrict__ sg, XcGeom geo, int slot0, int n_slots,
@@ -324,32 +322,23 @@ __global__ __launch_bounds__(64, WPS) void k_xcorr_mfma_t(const float2 *__restri
     const float *bp = btab + (((size_t)slot * geo.n_comb + w) * geo.G + g) * (size_t)(LCS_KP2_MAX * 64) + lane;
     const float *a1p = buf + a1_off;
     const float *a2p = buf + a2_off;
-    static_assert(!B4 || UNROLL == 4, "the interleaved B layout is built for 4-step unrolling");
-    const float4 *bp4 = reinterpret_cast<const float4 *>(bp - lane) + lane;   // [kk/4][lane] -> float4
     float bnext[UNROLL];
-    if (B4) { const float4 t = bp4[0]; bnext[0] = t.x; bnext[1] = t.y; bnext[2] = t.z; bnext[3] = t.w; }
-    else {
 #pragma unroll
-      for (int u = 0; u < UNROLL; ++u) bnext[u] = bp[u * 64];
-    }
+    for (int u = 0; u < UNROLL; ++u) bnext[u] = bp[u * 64];
     const int k2m = k2 - (k2 % UNROLL);
     int kk = 0;
     for (; kk < k2m; kk += UNROLL) {
       float b[UNROLL];
 #pragma unroll
       for (int u = 0; u < UNROLL; ++u) b[u] = bnext[u];
-      if (B4) { const float4 t = bp4[((kk >> 2) + 1) * 64]; bnext[0] = t.x; bnext[1] = t.y; bnext[2] = t.z; bnext[3] = t.w; }
-      else {
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) bnext[u] = (ABL & 2) ? bnext[u] : bp[(kk + UNROLL + u) * 64];
-      }
+      for (int u = 0; u < UNROLL; ++u) bnext[u] = bp[(kk + UNROLL + u) * 64];
 #pragma unroll
       for (int u = 0; u < UNROLL; ++u) {
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
-          // ABLATION builds (measurement only, wrong results): operands not re-read per step
-          const float a1 = (ABL & 1) ? a1p[mt * 16] : a1p[mt * 16 + 2 * (kk + u)];
-          const float a2 = (ABL & 1) ? a2p[mt * 16] : a2p[mt * 16 + 2 * (kk + u)];
+          const float a1 = a1p[mt * 16 + 2 * (kk + u)];
+          const float a2 = a2p[mt * 16 + 2 * (kk + u)];
           aR[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b[u], aR[mt], 0, 0, 0);
           aI[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b[u], aI[mt], 0, 0, 0);
         }
@@ -381,6 +370,142 @@ __global__ __launch_bounds__(64, WPS) void k_xcorr_mfma_t(const float2 *__restri
       const int idx = idx0 + mt * 16 + 4 * (lane >> 4) + r;
       o[(size_t)idx * LCS_TG] = __fdiv_rn(P[mt][r], ncomb);
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 4-wave variant: one 256-thread workgroup owns 4 adjacent lag tiles (256 output positions) of one
+// template group.  The capture window is staged once for the four waves, and the template rows
+// (B operands) go through LDS in double-buffered chunks of 32 tap pairs instead of being fetched
+// from L2 by every wave: 3.6x less L2->CU traffic, B-operand latency at LDS level.  One barrier
+// per chunk.  Same FMA chain as the 1-wave kernels, so results are bit-identical.
+// NWV waves per workgroup (NWV*64 output positions), BCH tap pairs per B chunk.
+template <int WPS, int NWV, int BCH>
+__global__ __launch_bounds__(NWV * 64, WPS) void k_xcorr_mfma_blk(const float2 *__restrict__ cap32, const int *__restrict__ smin,
+                                                              const int *__restrict__ kp2, const float *__restrict__ btab,
+                                                              float *__restrict__ sg, XcGeom geo, int slot0, int n_slots,
+                                                              int xcd_map) {
+  constexpr int NT = NWV * 64;                                   // threads = output positions per workgroup
+  constexpr int BLK_LAGS = NT;
+  constexpr int BLK_TILES = (LCS_N_IDX + BLK_LAGS - 1) / BLK_LAGS;
+  constexpr int PSB = ((BLK_LAGS + 2 * (LCS_KP2_MAX - LCS_KP2_UNROLL) + 31) / 32) * 32 + 16;   // == 16 (mod 32)
+  constexpr int ASTEPS = (BLK_LAGS + 2 * (LCS_KP2_MAX - LCS_KP2_UNROLL) + NT - 1) / NT;        // samples per thread per window
+  constexpr int BSTEPS = (BCH * 16 + NT - 1) / NT;                                             // float4 per thread per chunk
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int per_slot = BLK_TILES * geo.G;
+  int q, sidx;
+  if (xcd_map) { sidx = blockIdx.x & 7; q = blockIdx.x >> 3; sidx += 8 * (q / per_slot); q = q % per_slot; }
+  else { sidx = blockIdx.x / per_slot; q = blockIdx.x % per_slot; }
+  if (sidx >= n_slots) return;
+  const int slot = slot0 + sidx, g = q / BLK_TILES, idx0 = (q % BLK_TILES) * BLK_LAGS;
+  const bool live = idx0 + wave * LCS_LAG_TILE < LCS_N_IDX;      // wave-uniform
+
+  __shared__ float ldsA[2][3 * PSB];
+  __shared__ float ldsB[2][BCH * 64];
+  const float2 *cap = cap32 + (size_t)slot * geo.n_cap;
+  const int *smin_s = smin + (size_t)slot * NW * GM + g;
+  const int *kp2_s = kp2 + (size_t)slot * NW * GM + g;
+  const int odd = (lane >> 4) & 1;
+  const int a1_off = (odd ? 2 * PSB : PSB) + wave * LCS_LAG_TILE + (lane & 15) + (lane >> 5);
+  const int a2_off = (odd ? PSB : 0) + wave * LCS_LAG_TILE + (lane & 15) + (lane >> 5);
+
+  f32x4 P[4];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) P[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // register staging: the capture samples of the next window and the next B chunk
+  float2 preA[ASTEPS];
+  float4 preB[BSTEPS];
+#define BLK_LOAD_A(W)                                                                              \
+  {                                                                                                \
+    const int L0_ = idx0 + smin_s[(W) * GM], sl_ = BLK_LAGS + 2 * kp2_s[(W) * GM];                 \
+    _Pragma("unroll") for (int r_ = 0; r_ < ASTEPS; ++r_) {                                        \
+      const int n_ = tid + NT * r_;                                                                \
+      const uint32_t s_ = (uint32_t)(L0_ + n_);                                                    \
+      preA[r_] = (n_ < sl_ && s_ < geo.n_cap) ? cap[s_] : make_float2(0.f, 0.f);                   \
+    }                                                                                              \
+  }
+#define BLK_LOAD_B(W, C)                                                                           \
+  {                                                                                                \
+    const float4 *src_ = reinterpret_cast<const float4 *>(                                         \
+        btab + (((size_t)slot * geo.n_comb + (W)) * geo.G + g) * (size_t)(LCS_KP2_MAX * 64) + (size_t)(C) * BCH * 64); \
+    _Pragma("unroll") for (int r_ = 0; r_ < BSTEPS; ++r_)                                          \
+      preB[r_] = ((BCH * 16) % NT == 0 || tid + NT * r_ < BCH * 16) ? src_[tid + NT * r_] : make_float4(0.f, 0.f, 0.f, 0.f); \
+  }
+  BLK_LOAD_A(0);
+  BLK_LOAD_B(0, 0);
+  int cb = 0;
+  for (int w = 0; w < geo.n_comb; ++w) {
+    const int k2 = kp2_s[w * GM];
+    const int nch = (k2 + BCH - 1) / BCH;
+    float *bufA = ldsA[w & 1];
+    {
+      const int sl = BLK_LAGS + 2 * k2;
+#pragma unroll
+      for (int r = 0; r < ASTEPS; ++r) {
+        const int n = tid + NT * r;
+        if (n < sl) { bufA[n] = preA[r].y; bufA[PSB + n] = preA[r].x; bufA[2 * PSB + n] = -preA[r].y; }
+      }
+    }
+    if (w + 1 < geo.n_comb) BLK_LOAD_A(w + 1);
+    f32x4 aR[4], aI[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) { aR[mt] = (f32x4){0.f, 0.f, 0.f, 0.f}; aI[mt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    const float *a1p = bufA + a1_off;
+    const float *a2p = bufA + a2_off;
+    for (int c = 0; c < nch; ++c) {
+      float4 *bw = reinterpret_cast<float4 *>(ldsB[cb]);
+#pragma unroll
+      for (int r = 0; r < BSTEPS; ++r)
+        if ((BCH * 16) % NT == 0 || tid + NT * r < BCH * 16) bw[tid + NT * r] = preB[r];
+      if (c + 1 < nch) BLK_LOAD_B(w, c + 1)
+      else if (w + 1 < geo.n_comb) BLK_LOAD_B(w + 1, 0)
+      __syncthreads();
+      const float *bl = ldsB[cb] + lane;
+      const int nr = min(BCH, k2 - c * BCH);
+      const int kbase = c * BCH;
+      const int nr4 = nr & ~3;
+      int kk = 0;
+      for (; kk < nr4; kk += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float b = bl[(kk + u) * 64];
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) {
+            const float a1 = a1p[mt * 16 + 2 * (kbase + kk + u)];
+            const float a2 = a2p[mt * 16 + 2 * (kbase + kk + u)];
+            aR[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b, aR[mt], 0, 0, 0);
+            aI[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b, aI[mt], 0, 0, 0);
+          }
+        }
+      }
+      for (; kk < nr; ++kk) {
+        const float b = bl[kk * 64];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          const float a1 = a1p[mt * 16 + 2 * (kbase + kk)];
+          const float a2 = a2p[mt * 16 + 2 * (kbase + kk)];
+          aR[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b, aR[mt], 0, 0, 0);
+          aI[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b, aI[mt], 0, 0, 0);
+        }
+      }
+      cb ^= 1;
+    }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) P[mt][r] = P[mt][r] + pow2sum(aR[mt][r], aI[mt][r]);
+  }
+  if (live) {
+    const float ncomb = (float)geo.n_comb;
+    float *o = sg + (((size_t)slot * geo.G + g) * LCS_N_IDX) * LCS_TG + (lane & 15);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int idx = idx0 + wave * LCS_LAG_TILE + mt * 16 + 4 * (lane >> 4) + r;
+        o[(size_t)idx * LCS_TG] = __fdiv_rn(P[mt][r], ncomb);
+      }
+  }
 }
 
 __global__ __launch_bounds__(64) void k_xcorr_valu(const float2 *__restrict__ cap32, const int *__restrict__ smin,
@@ -613,9 +738,8 @@ static hipEvent_t g_xc_done[64] = {};
 int lcs_launch_xcorr(lcs_ctx *c, int n_buf, const XcGeom &geo, bool want_incoh, bool time_it) {
   hipLaunchKernelGGL(k_prep_tables, dim3(n_buf), dim3(256), 0, c->stream, c->params, c->fset, c->d_pss_td, c->tmpl,
                      c->start, c->smin, c->kp2, geo);
-  const int layout4 = (c->xcorr_variant == 12 || c->xcorr_variant == 13 || c->xcorr_variant == 14) ? 1 : 0;
   hipLaunchKernelGGL(k_fill_btab, dim3(8, geo.n_comb * geo.G, n_buf), dim3(256), 0, c->stream, c->tmpl, c->start,
-                     c->smin, c->kp2, c->btab, geo, layout4);
+                     c->smin, c->kp2, c->btab, geo);
   // signal-power estimate and threshold do not depend on the correlation: enqueue them first
   SpArgs a;
   a.n_comb_sp = (int)((geo.n_cap - 136 - 137) / 9600);
@@ -649,27 +773,21 @@ int lcs_launch_xcorr(lcs_ctx *c, int n_buf, const XcGeom &geo, bool want_incoh, 
   for (int part = 0; part < 2; ++part) {
     const int s0 = part ? n8 : 0, ns = part ? n_buf - n8 : n8;
     if (ns <= 0) continue;
-    const dim3 grid((unsigned)(per_slot * ns));
-#define XC_ARGS grid, dim3(64), lds_pad, sxc, c->cap32, c->smin, c->kp2, c->btab, c->single, geo, s0, ns, part ? 0 : 1
-    if (c->xcorr_variant == 1)
-      hipLaunchKernelGGL(k_xcorr_valu, grid, dim3(64), lds_pad, sxc, c->cap32, c->smin, c->kp2, c->btab, c->single,
-                         geo, s0, ns, part ? 0 : 1);
-    else if (c->xcorr_variant == 2) hipLaunchKernelGGL((k_xcorr_mfma_t<6, false, 2>), XC_ARGS);
-    else if (c->xcorr_variant == 3) hipLaunchKernelGGL((k_xcorr_mfma_t<5, false, 4>), XC_ARGS);
-    else if (c->xcorr_variant == 4) hipLaunchKernelGGL((k_xcorr_mfma_t<5, true, 2>), XC_ARGS);
-    else if (c->xcorr_variant == 5) hipLaunchKernelGGL((k_xcorr_mfma_t<4, true, 8>), XC_ARGS);
-    else if (c->xcorr_variant == 6) hipLaunchKernelGGL((k_xcorr_mfma_t<8, false, 2>), XC_ARGS);
-    else if (c->xcorr_variant == 7) hipLaunchKernelGGL((k_xcorr_mfma_t<5, false, 4, 1>), XC_ARGS);   // ablation: no A reads
-    else if (c->xcorr_variant == 8) hipLaunchKernelGGL((k_xcorr_mfma_t<5, false, 4, 2>), XC_ARGS);   // ablation: no B loads
-    else if (c->xcorr_variant == 9) hipLaunchKernelGGL((k_xcorr_mfma_t<5, false, 4, 3>), XC_ARGS);   // ablation: MFMA only
-    else if (c->xcorr_variant == 10) hipLaunchKernelGGL((k_xcorr_mfma_t<6, false, 4>), XC_ARGS);
-    else if (c->xcorr_variant == 11) hipLaunchKernelGGL((k_xcorr_mfma_t<4, false, 4>), XC_ARGS);
-    else if (c->xcorr_variant == 12) hipLaunchKernelGGL((k_xcorr_mfma_t<5, false, 4, 0, true>), XC_ARGS);
-    else if (c->xcorr_variant == 13) hipLaunchKernelGGL((k_xcorr_mfma_t<6, false, 4, 0, true>), XC_ARGS);
-    else if (c->xcorr_variant == 14) hipLaunchKernelGGL((k_xcorr_mfma_t<4, true, 4, 0, true>), XC_ARGS);
-    else
-      hipLaunchKernelGGL(k_xcorr_mfma, grid, dim3(64), lds_pad, sxc, c->cap32, c->smin, c->kp2, c->btab, c->single,
-                         geo, s0, ns, part ? 0 : 1);
+#define XCB_LAUNCH(WPS_, NWV_, BCH_)                                                                              \
+  hipLaunchKernelGGL((k_xcorr_mfma_blk<WPS_, NWV_, BCH_>), dim3((unsigned)(((LCS_N_IDX + NWV_ * 64 - 1) / (NWV_ * 64)) * geo.G * ns)), \
+                     dim3(NWV_ * 64), 0, sxc, c->cap32, c->smin, c->kp2, c->btab, c->single, geo, s0, ns, part ? 0 : 1)
+#define XC1_ARGS dim3((unsigned)(per_slot * ns)), dim3(64), lds_pad, sxc, c->cap32, c->smin, c->kp2, c->btab, c->single, geo, s0, ns, part ? 0 : 1
+    switch (c->xcorr_variant) {
+      case 0: XCB_LAUNCH(4, 4, 32); break;                                      // default: 4-wave workgroups, B through LDS
+      case 1: hipLaunchKernelGGL(k_xcorr_valu, XC1_ARGS); break;                // plain-VALU twin
+      case 2: hipLaunchKernelGGL(k_xcorr_mfma, XC1_ARGS); break;                // 1-wave workgroups, B from L2 (round-1 baseline)
+      case 3: hipLaunchKernelGGL((k_xcorr_mfma_t<5, false, 4>), XC1_ARGS); break;
+      case 4: hipLaunchKernelGGL((k_xcorr_mfma_t<6, false, 4>), XC1_ARGS); break;
+      case 5: XCB_LAUNCH(4, 4, 16); break;
+      case 6: XCB_LAUNCH(4, 8, 32); break;
+      case 7: XCB_LAUNCH(4, 2, 32); break;
+      default: XCB_LAUNCH(4, 4, 32); break;
+    }
     ++launches;
   }
   if (time_it) { HIPCHK(c, hipEventRecord(c->ev_xc1, sxc)); c->last_xc_launches = launches; }
