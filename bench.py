@@ -64,6 +64,13 @@ def cpu_baseline(pkg, iq_u8, f, fc, stage):
         peaks = O.peak_search(r["pow"], r["frq"], O.z_th1(r["sp_incoherent"], r["n_comb_xc"]), f, fc, fc, r["single"], 2)
     dt = time.perf_counter() - t0
     ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:   # a container may be allowed far fewer CPUs than it can see
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            ncpu = max(1, min(ncpu, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    ncpu = min(ncpu, 64)      # one socket's worth of physical cores is where this loop stops scaling
     O.set_threads(ncpu)
     t0 = time.perf_counter()
     if stage == "full":
@@ -81,7 +88,7 @@ def cpu_baseline(pkg, iq_u8, f, fc, stage):
         pass
     return {"value": 1.0 / dt, "unit": "capture-buffers/s", "cores": 1, "kind": "port",
             "sample": f"1 synthetic buffer, n_f={f.size}, stage={stage}, {dt:.2f} s single-thread "
-                      f"(C oracle, gcc -O3); all {ncpu} cores (OpenMP over lags as the reference): {1.0 / dt_mt:.3f} buffers/s",
+                      f"(C oracle, gcc -O3); {ncpu} threads (OpenMP over lags as the reference): {1.0 / dt_mt:.3f} buffers/s",
             "cpu_model": model, "n_peaks": len(peaks)}
 
 
@@ -220,8 +227,9 @@ def main():
         # n_f with the default kernel, summary committed under profiles/ -- null when not measured.
         traffic = None
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_summary.json")))["kernels"]["k_xcorr_mfma"]
-            if int(pm["n_f"]) == int(n_f) and args.variant != 1:
+            pmj = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_summary.json")))
+            pm = pmj["kernels"][pmj["dominant_kernel"]]
+            if int(pm["n_f"]) == int(n_f) and args.variant == 0:
                 traffic = float(pm["hbm_bytes_per_buffer"]) * B
         except Exception:
             traffic = None
