@@ -54,7 +54,7 @@ int ensure_ws(lcs_ctx *c, int n_slots, uint32_t n_cap, int n_f, bool debug) {
   int rc;
 #define A(p, n) if ((rc = dev_alloc(c, &c->p, (n))) != LCS_OK) return rc
   A(cap32, S * n_cap);
-  A(cap64, S * n_cap);
+  A(cap64, (size_t)n_cap);
   A(params, S);
   A(fset, (size_t)LCS_NF_MAX);
   A(tmpl, S * LCS_NF_MAX * 3 * 137);
@@ -266,6 +266,7 @@ int lcs_xcorr_pss(lcs_ctx *c, const double *capbuf, uint32_t n_cap, const double
   if ((rc = validate_grid(c, geo, f_search_set, fc_req, fc_prog, fs_prog))) return rc;
   SlotParams p{fc_req, fc_prog, fs_prog};
   HIPCHK(c, hipMemcpyAsync(c->cap64, capbuf, sizeof(double2) * n_cap, hipMemcpyHostToDevice, c->stream));
+  c->cap64_valid = true;
   HIPCHK(c, hipMemcpyAsync(c->fset, f_search_set, sizeof(double) * n_f, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->params, &p, sizeof(p), hipMemcpyHostToDevice, c->stream));
   if ((rc = lcs_launch_ingest(c, nullptr, 2, 1, n_cap))) return rc;
@@ -311,7 +312,7 @@ int lcs_peak_search(lcs_ctx *c, const double *pow_, const int32_t *frq, const do
   HIPCHK(c, hipMemcpyAsync(c->params, &p, sizeof(p), hipMemcpyHostToDevice, c->stream));
   XcGeom geo = make_geo(153600, n_f, ds_comb_arm);
   if ((rc = lcs_launch_single_layout(c, geo, c->sref, 0))) return rc;
-  if ((rc = lcs_launch_peak_search(c, 1, geo, std::pow(10.0, -12.0 / 10.0)))) return rc;
+  if ((rc = lcs_launch_peak_search(c, 1, geo, std::pow(10.0, -12.0 / 10.0), false))) return rc;
   std::vector<lcs_cell> tmp(LCS_MAXP);
   int n = 0;
   HIPCHK(c, hipMemcpyAsync(tmp.data(), c->peaks, sizeof(lcs_cell) * LCS_MAXP, hipMemcpyDeviceToHost, c->stream));
@@ -346,9 +347,10 @@ int lcs_batch_enqueue(lcs_ctx *c, const void *d_capbufs, int fmt, int n_buf, uin
   std::memcpy(hf, f_search_set, sizeof(double) * n_f);
   HIPCHK(c, hipMemcpyAsync(c->params, hp, sizeof(SlotParams) * n_buf, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->fset, hf, sizeof(double) * n_f, hipMemcpyHostToDevice, c->stream));
+  c->cap64_valid = false;
   if ((rc = lcs_launch_ingest(c, d_capbufs, fmt, n_buf, n_cap))) return rc;
   if ((rc = lcs_launch_xcorr(c, n_buf, geo, false, true))) return rc;
-  if ((rc = lcs_launch_peak_search(c, n_buf, geo, std::pow(10.0, -12.0 / 10.0)))) return rc;
+  if ((rc = lcs_launch_peak_search(c, n_buf, geo, std::pow(10.0, -12.0 / 10.0), true))) return rc;
   if (stage_mask & 2) {
     if ((rc = ensure_percell(c))) return rc;
     if ((rc = lcs_launch_sss_foe(c, n_buf, n_cap, 3.0 /* THRESH2_N_SIGMA, ref src/CellSearch.cpp:528 */, nullptr))) return rc;
@@ -412,6 +414,7 @@ int upload_cap_and_params(lcs_ctx *c, const double *capbuf, uint32_t n_cap, doub
   if ((rc = ensure_ws(c, 1, n_cap, std::max(1, c->cap_n_f), false))) return rc;
   SlotParams p{fc_req, fc_prog, fs_prog};
   HIPCHK(c, hipMemcpyAsync(c->cap64, capbuf, sizeof(double2) * n_cap, hipMemcpyHostToDevice, c->stream));
+  c->cap64_valid = true;
   HIPCHK(c, hipMemcpyAsync(c->params, &p, sizeof(p), hipMemcpyHostToDevice, c->stream));
   return LCS_OK;
 }
@@ -554,11 +557,12 @@ int lcs_search_capbuf(lcs_ctx *c, const double *capbuf, uint32_t n_cap, const do
   if ((rc = validate_grid(c, geo, f_search_set, fc_req, fc_prog, fs_prog))) return rc;
   SlotParams p{fc_req, fc_prog, fs_prog};
   HIPCHK(c, hipMemcpyAsync(c->cap64, capbuf, sizeof(double2) * n_cap, hipMemcpyHostToDevice, c->stream));
+  c->cap64_valid = true;
   HIPCHK(c, hipMemcpyAsync(c->fset, f_search_set, sizeof(double) * n_f, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->params, &p, sizeof(p), hipMemcpyHostToDevice, c->stream));
   if ((rc = lcs_launch_ingest(c, nullptr, 2, 1, n_cap))) return rc;
   if ((rc = lcs_launch_xcorr(c, 1, geo, false, false))) return rc;
-  if ((rc = lcs_launch_peak_search(c, 1, geo, std::pow(10.0, -12.0 / 10.0)))) return rc;
+  if ((rc = lcs_launch_peak_search(c, 1, geo, std::pow(10.0, -12.0 / 10.0), true))) return rc;
   if ((rc = lcs_launch_sss_foe(c, 1, n_cap, 3.0, nullptr))) return rc;
   if ((rc = lcs_launch_gather_work(c, 1))) return rc;
   if ((rc = lcs_launch_tfg(c, n_cap, 0))) return rc;

@@ -3,7 +3,7 @@
 // Device data layout (everything lives in one workspace, slot-major; a "slot" is one
 // capture buffer in flight):
 //   cap32   [S][n_cap]            float2   capture buffer, fp32 (PSS correlation input)
-//   cap64   [S][n_cap]            double2  capture buffer, fp64 (per-peak stages)
+//   cap64   [1][n_cap]            double2  fp64 copy, only when a host entry point hands over complex<double>
 //   tmpl    [S][n_f][3][137]      float2   conj(fshift(pss_td))/137   (searcher.cpp:146-151)
 //   start   [S][NW][n_f]          int      round_i(m*.005*k_factor*fs) (searcher.cpp:298)
 //   smin/kp2[S][NW][G]            int      per (window, 16-template group): first lag offset, tap pairs
@@ -46,6 +46,26 @@ struct XcGeom {
   int ds;       // ds_comb_arm
 };
 
+// The capture buffer as the fp64 stages see it: the fp64 copy when one exists (host entry points
+// hand over complex<double>), otherwise the fp32 copy widened on the fly (exact for u8 / float input).
+struct CapView {
+  const float2 *c32;
+  const double2 *c64;
+};
+#ifdef __HIPCC__
+__device__ __forceinline__ CapView cap_view(const float2 *cap32, const double2 *cap64, int slot, uint32_t n_cap) {
+  CapView v;
+  v.c32 = cap32 + (size_t)slot * n_cap;
+  v.c64 = cap64 ? cap64 + (size_t)slot * n_cap : nullptr;
+  return v;
+}
+__device__ __forceinline__ double2 cap_at(const CapView &v, size_t i) {
+  if (v.c64) return v.c64[i];
+  const float2 f = v.c32[i];
+  return make_double2((double)f.x, (double)f.y);
+}
+#endif
+
 // One "cell work item" for the per-cell stages (TFG / TFOEC / channel estimate / PBCH).
 struct WorkItem {
   int slot;
@@ -68,7 +88,8 @@ struct lcs_ctx {
 
   // device buffers
   float2 *cap32 = nullptr;
-  double2 *cap64 = nullptr;
+  double2 *cap64 = nullptr;          // slot 0 only: fp64 copy for the host (complex<double>) entry points
+  bool cap64_valid = false;
   SlotParams *params = nullptr;
   double *fset = nullptr;
   float2 *tmpl = nullptr;
@@ -137,7 +158,7 @@ int lcs_launch_xcorr(lcs_ctx *c, int n_buf, const XcGeom &geo, bool want_incoh, 
 int lcs_launch_single_layout(lcs_ctx *c, const XcGeom &geo, float *ref_layout, int to_ref);   // group-major <-> [t][idx][foi]
 int lcs_launch_xc_debug(lcs_ctx *c, const XcGeom &geo);   // raw xc for slot 0 (debug output only)
 // peak_search.hip
-int lcs_launch_peak_search(lcs_ctx *c, int n_buf, const XcGeom &geo, double udb10_m12);
+int lcs_launch_peak_search(lcs_ctx *c, int n_buf, const XcGeom &geo, double udb10_m12, bool fp32_exact);
 // sss_foe.hip
 int lcs_launch_sss_foe(lcs_ctx *c, int n_buf, uint32_t n_cap, double thresh2_n_sigma, double *dbg /*device, nullable*/);
 int lcs_launch_sss_only(lcs_ctx *c, uint32_t n_cap, double thresh2_n_sigma, double *dbg);

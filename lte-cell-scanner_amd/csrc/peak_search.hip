@@ -21,6 +21,10 @@ __device__ __forceinline__ void cell_init(lcs_cell &c) {
   c.phich_duration = 0; c.phich_resource = 0; c.sfn = -1; c.reserved = 0;
 }
 
+// WT = double: working copy in global memory (stage entry point: arbitrary doubles from the caller);
+// WT = float : working copy in 115 KB of LDS (fused chain: the collapsed powers are fp32 values, so
+//              every comparison below gives the same answer as in fp64).
+template <typename WT>
 __global__ __launch_bounds__(PS_THREADS) void k_peak_search(const double *__restrict__ pow_, const int *__restrict__ frq,
                                                              const double *__restrict__ zth,
                                                              const float *__restrict__ single,
@@ -35,7 +39,8 @@ __global__ __launch_bounds__(PS_THREADS) void k_peak_search(const double *__rest
   const int *fq = frq + (size_t)slot * NE;
   const double *z = zth + (size_t)slot * LCS_N_IDX;
   const float *sg = single + (size_t)slot * geo.G * LCS_N_IDX * LCS_TG;   // group-major (pss_xcorr.hip)
-  double *wk = work + (size_t)slot * NE;
+  extern __shared__ __attribute__((aligned(16))) char ps_smem[];
+  WT *wk = (sizeof(WT) == sizeof(float)) ? reinterpret_cast<WT *>(ps_smem) : reinterpret_cast<WT *>(work + (size_t)slot * NE);
   lcs_cell *out = peaks + (size_t)slot * LCS_MAXP;
 
   __shared__ double s_val[PS_THREADS / 64];
@@ -44,16 +49,16 @@ __global__ __launch_bounds__(PS_THREADS) void k_peak_search(const double *__rest
   __shared__ int s_peak_lin;
   __shared__ int s_stop;
 
-  for (int e = tid; e < NE; e += PS_THREADS) wk[e] = pw[e];
+  for (int e = tid; e < NE; e += PS_THREADS) wk[e] = (WT)pw[e];
   __syncthreads();
 
   int n = 0;
   for (int iter = 0; iter < PS_MAX_ITER; ++iter) {
     // arg-max with "smallest linear index wins ties"
-    double best = wk[tid];
+    double best = (double)wk[tid];
     int bi = tid;
     for (int e = tid + PS_THREADS; e < NE; e += PS_THREADS) {
-      const double v = wk[e];
+      const double v = (double)wk[e];
       if (v > best) { best = v; bi = e; }
     }
     for (int off = 32; off > 0; off >>= 1) {
@@ -108,20 +113,30 @@ __global__ __launch_bounds__(PS_THREADS) void k_peak_search(const double *__rest
     const int row = s_peak_lin / LCS_N_IDX, col = s_peak_lin % LCS_N_IDX;
     for (int t = tid; t <= 2 * 274; t += PS_THREADS) {
       const int cc = ((col + t - 274) % LCS_N_IDX + LCS_N_IDX) % LCS_N_IDX;
-      wk[row * LCS_N_IDX + cc] = 0;
+      wk[row * LCS_N_IDX + cc] = (WT)0;
     }
     __syncthreads();
     const double thresh = s_peak_pow * udb10_m12;
     for (int e = tid; e < NE; e += PS_THREADS)
-      if (wk[e] < thresh) wk[e] = 0;
+      if ((double)wk[e] < thresh) wk[e] = (WT)0;
     __syncthreads();
   }
   if (tid == 0) npeaks[slot] = n;
 }
 
-int lcs_launch_peak_search(lcs_ctx *c, int n_buf, const XcGeom &geo, double udb10_m12) {
-  hipLaunchKernelGGL(k_peak_search, dim3(n_buf), dim3(PS_THREADS), 0, c->stream, c->pow_, c->frq, c->zth, c->single,
-                     c->fset, c->params, c->work, c->peaks, c->npeaks, geo, udb10_m12);
+int lcs_launch_peak_search(lcs_ctx *c, int n_buf, const XcGeom &geo, double udb10_m12, bool fp32_exact) {
+  if (fp32_exact) {
+    const size_t smem = sizeof(float) * 3 * LCS_N_IDX;
+    static bool attr_set = false;
+    if (!attr_set) {
+      HIPCHK(c, hipFuncSetAttribute((const void *)k_peak_search<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(k_peak_search<float>, dim3(n_buf), dim3(PS_THREADS), smem, c->stream, c->pow_, c->frq, c->zth, c->single,
+                       c->fset, c->params, c->work, c->peaks, c->npeaks, geo, udb10_m12);
+  } else
+    hipLaunchKernelGGL(k_peak_search<double>, dim3(n_buf), dim3(PS_THREADS), 0, c->stream, c->pow_, c->frq, c->zth, c->single,
+                       c->fset, c->params, c->work, c->peaks, c->npeaks, geo, udb10_m12);
   HIPCHK(c, hipGetLastError());
   return LCS_OK;
 }

@@ -34,20 +34,19 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------------ ingest
 // fmt 0: complex<float> in HBM; fmt 1: RTL-SDR u8 I/Q, (x-127)/128 (ref src/capbuf.cpp:172-181);
-// fmt 2: complex<double> already copied into cap64.  Produces both precisions.
+// fmt 2: complex<double> already copied into cap64 (host entry points, slot 0 only).
+// For fmt 0/1 the fp32 copy holds the samples exactly (u8/128 and float are both exact in fp32),
+// so no fp64 copy is written: the fp64 stages read cap32 and widen on the fly (cap_at()).
 __global__ void k_ingest(const void *__restrict__ src, int fmt, uint32_t n_cap, float2 *__restrict__ cap32,
                          double2 *__restrict__ cap64) {
   const int slot = blockIdx.y;
   const size_t base = (size_t)slot * n_cap;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_cap; i += gridDim.x * blockDim.x) {
     if (fmt == LCS_FMT_C64) {
-      float2 v = ((const float2 *)src)[base + i];
-      cap32[base + i] = v;
-      cap64[base + i] = make_double2((double)v.x, (double)v.y);
+      cap32[base + i] = ((const float2 *)src)[base + i];
     } else if (fmt == LCS_FMT_IQ_U8) {
       uchar2 q = ((const uchar2 *)src)[base + i];
-      double re = ((double)q.x - 127.0) / 128.0, im = ((double)q.y - 127.0) / 128.0;
-      cap64[base + i] = make_double2(re, im);
+      const double re = ((double)q.x - 127.0) / 128.0, im = ((double)q.y - 127.0) / 128.0;
       cap32[base + i] = make_float2((float)re, (float)im);
     } else {
       double2 v = cap64[base + i];
@@ -580,18 +579,18 @@ struct SpArgs {
 #define SP_SEG 16
 #define SP_TILE (64 * SP_SEG)
 __device__ __forceinline__ int sp_pad(int i) { return i + (i >> 4); }
-__global__ __launch_bounds__(64) void k_sp_sums(const double2 *__restrict__ cap64, double *__restrict__ sp_all,
-                                                 uint32_t n_cap, int n_comb_sp) {
+__global__ __launch_bounds__(64) void k_sp_sums(const float2 *__restrict__ cap32, const double2 *__restrict__ cap64,
+                                                 double *__restrict__ sp_all, uint32_t n_cap, int n_comb_sp) {
   const int slot = blockIdx.z, m = blockIdx.y;
   const int i0 = blockIdx.x * SP_TILE;
   const int tid = threadIdx.x;
-  const double2 *cap = cap64 + (size_t)slot * n_cap;
+  const CapView cap = cap_view(cap32, cap64, slot, n_cap);
   __shared__ double pw[SP_TILE + 274 + (SP_TILE + 274) / 16 + 2];
   const uint32_t base = (uint32_t)m * 9600u + i0;
   for (int n = tid; n < SP_TILE + 274; n += 64) {
     const uint32_t s = base + n;
     double v = 0;
-    if (s < n_cap) { const double2 c = cap[s]; v = c.x * c.x + c.y * c.y; }
+    if (s < n_cap) { const double2 c = cap_at(cap, s); v = c.x * c.x + c.y * c.y; }
     pw[sp_pad(n)] = v;
   }
   __syncthreads();
@@ -747,8 +746,8 @@ int lcs_launch_xcorr(lcs_ctx *c, int n_buf, const XcGeom &geo, bool want_incoh, 
   a.ds = geo.ds;
   a.R_th1 = lcs_tables::chi2cdf_inv(1 - pow(10.0, -12), 2.0 * geo.n_comb * (2 * geo.ds + 1));
   a.rx_cutoff = (6 * 12 * 15e3 / 2 + 4 * 15e3) / (30720000.0 / 16 / 2);
-  hipLaunchKernelGGL(k_sp_sums, dim3((LCS_N_IDX + SP_TILE - 1) / SP_TILE, a.n_comb_sp, n_buf), dim3(64), 0, c->stream, c->cap64,
-                     c->sp, geo.n_cap, a.n_comb_sp);
+  hipLaunchKernelGGL(k_sp_sums, dim3((LCS_N_IDX + SP_TILE - 1) / SP_TILE, a.n_comb_sp, n_buf), dim3(64), 0, c->stream, c->cap32,
+                     c->cap64_valid ? c->cap64 : nullptr, c->sp, geo.n_cap, a.n_comb_sp);
   hipLaunchKernelGGL(k_sp_fold, dim3((LCS_N_IDX + 255) / 256, n_buf), dim3(256), 0, c->stream, c->sp, c->spinc, c->zth, a);
 
   const int per_slot = (LCS_N_IDX / LCS_LAG_TILE) * geo.G;

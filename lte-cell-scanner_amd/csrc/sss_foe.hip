@@ -49,19 +49,23 @@ struct SfShared {
   cd2 s_ext[MAX_HF][62];
   double pss_np[MAX_HF];
   double np12[124];
+  double rnp12[124];          // 1/np12
   cd2 nrm12[124];
   cd2 ext12[124];
   double ll[2][2][168];       // [nrm/ext][column][n_id_1]
   cd2 acc_k[MAX_HF];
+  double dec[4][4];
 };
 
 // capbuf.mid(loc,128) -> fshift(., foc_freq, fs) -> rotate left by 2 (ref :523-525), one sample
-__device__ __forceinline__ cd2 stage_sample(const double2 *__restrict__ cap, uint32_t n_cap, long loc, double k, int n) {
+__device__ __forceinline__ cd2 stage_sample(const CapView &cap, uint32_t n_cap, long loc, double k, int n) {
   const int t = (n + 2) & 127;
   const long src = loc + t;
   cd2 v = mk(0, 0);
-  if (src >= 0 && (uint64_t)src < n_cap) { const double2 c = cap[src]; v = mk(c.x, c.y); }
-  return cmul(v, mk(cos(k * (double)t), sin(k * (double)t)));
+  if (src >= 0 && (uint64_t)src < n_cap) { const double2 c = cap_at(cap, (size_t)src); v = mk(c.x, c.y); }
+  double sn, cs;
+  sincos(k * (double)t, &sn, &cs);
+  return cmul(v, mk(cs, sn));
 }
 
 // DFT of n_win staged windows at the 62 PSS/SSS bins [97..127, 1..31], /sqrt(128) (ref :527-529).
@@ -107,7 +111,7 @@ __device__ void smooth_and_np(SfShared &S, int nk, cd2 (*h_sm0)[62], double *np0
   __syncthreads();
 }
 
-__device__ void dev_sss_detect(SfShared &S, lcs_cell &cell, const double2 *__restrict__ cap, uint32_t n_cap,
+__device__ void dev_sss_detect(SfShared &S, lcs_cell &cell, const CapView &cap, uint32_t n_cap,
                                const SlotParams &p, double thresh2, const double2 *__restrict__ pss_fd,
                                const int8_t *__restrict__ sss_fd, double *dbg) {
   const int tid = threadIdx.x;
@@ -164,6 +168,7 @@ __device__ void dev_sss_detect(SfShared &S, lcs_cell &cell, const double2 *__res
       se = cadd(se, cmul(w, S.s_ext[k][t]));
     }
     S.np12[tid] = np_est;
+    S.rnp12[tid] = 1.0 / np_est;
     S.nrm12[tid] = cscale(sn, np_est);
     S.ext12[tid] = cscale(se, np_est);
   }
@@ -183,38 +188,44 @@ __device__ void dev_sss_detect(SfShared &S, lcs_cell &cell, const double2 *__res
     const double ang = atan2(acc.im, acc.re);
     const cd2 rot = mk(cos(-ang), sin(-ang));
     double s1 = 0, s2 = 0;
-    for (int i = 0; i < 124; ++i) {      // the two sums of ref :649 keep their own order
+    for (int i = 0; i < 124; ++i) {      // the two sums of ref :649 keep their own order; x/np as x*(1/np)
       const double tv = (double)(i < 62 ? first[i] : second[i - 62]);
       const cd2 d = csub(cmul(mk(tv, 0), rot), est[i]);
-      s1 += (d.re * d.re) / S.np12[i];
-      s2 += (d.im * d.im) / S.np12[i];
+      s1 += (d.re * d.re) * S.rnp12[i];
+      s2 += (d.im * d.im) * S.rnp12[i];
     }
     S.ll[ext][col][n1] = -s1 - s2;
   }
   __syncthreads();
+  // decision (ref :719-758): lanes 0..3 each scan one of the four likelihood columns (max, first
+  // arg-max, sum, sum of squares in index order); lane 0 combines them in the reference's order
+  if (tid < 4) {
+    const double *col = &S.ll[tid >> 1][tid & 1][0];
+    double mx = col[0], sum = 0, sq = 0;
+    int am = 0;
+    for (int t = 0; t < 168; ++t) {
+      const double v = col[t];
+      if (v > mx) { mx = v; am = t; }
+      sum += v; sq += v * v;
+    }
+    S.dec[tid][0] = mx; S.dec[tid][1] = (double)am; S.dec[tid][2] = sum; S.dec[tid][3] = sq;
+  }
+  __syncthreads();
   if (tid == 0) {
-    double mx_n = S.ll[0][0][0], mx_e = S.ll[1][0][0];
-    for (int c = 0; c < 2; ++c)
-      for (int t = 0; t < 168; ++t) {
-        if (S.ll[0][c][t] > mx_n) mx_n = S.ll[0][c][t];
-        if (S.ll[1][c][t] > mx_e) mx_e = S.ll[1][c][t];
-      }
+    const double mx_n = (S.dec[1][0] > S.dec[0][0]) ? S.dec[1][0] : S.dec[0][0];
+    const double mx_e = (S.dec[3][0] > S.dec[2][0]) ? S.dec[3][0] : S.dec[2][0];
     const int e = (mx_n > mx_e) ? 0 : 1;
     const int cp_type = e ? LCS_CP_EXTENDED : LCS_CP_NORMAL;
-    double mx0 = S.ll[e][0][0], mx1 = S.ll[e][1][0];
-    for (int t = 1; t < 168; ++t) { if (S.ll[e][0][t] > mx0) mx0 = S.ll[e][0][t]; if (S.ll[e][1][t] > mx1) mx1 = S.ll[e][1][t]; }
+    const double mx0 = S.dec[2 * e][0], mx1 = S.dec[2 * e + 1][0];
     double frame_start = cell.ind + (128 + 9 - 960 - 2) * 16 / FS_LTE * p.fs_prog * k_factor;
     int col;
     if (mx0 > mx1) col = 0;
     else { col = 1; frame_start = frame_start + 9600 * k_factor * 16 / FS_LTE * p.fs_prog * k_factor; }   // k_factor^2: quirk Q3
     frame_start = d_wrap(frame_start, -0.5, (2 * 9600.0 - 0.5) * 16 / FS_LTE * p.fs_prog * k_factor);
-    int n_id_1_est = 0;
-    double lik_final = S.ll[e][col][0];
-    for (int t = 1; t < 168; ++t) if (S.ll[e][col][t] > lik_final) { lik_final = S.ll[e][col][t]; n_id_1_est = t; }
+    const int n_id_1_est = (int)S.dec[2 * e + col][1];
+    const double lik_final = S.dec[2 * e + col][0];
     double sum = 0, sq = 0;
-    for (int m = 0; m < 2; ++m)
-      for (int c = 0; c < 2; ++c)
-        for (int t = 0; t < 168; ++t) { const double v = S.ll[m][c][t]; sum += v; sq += v * v; }
+    for (int q = 0; q < 4; ++q) { sum += S.dec[q][2]; sq += S.dec[q][3]; }
     const int len = 672;
     const double lik_mean = sum / len;
     const double lik_var = (sq - sum * sum / len) / (len - 1);    // itpp::variance (unbiased)
@@ -240,7 +251,7 @@ __device__ void dev_sss_detect(SfShared &S, lcs_cell &cell, const double2 *__res
   __syncthreads();
 }
 
-__device__ void dev_pss_sss_foe(SfShared &S, lcs_cell &cell, const double2 *__restrict__ cap, uint32_t n_cap,
+__device__ void dev_pss_sss_foe(SfShared &S, lcs_cell &cell, const CapView &cap, uint32_t n_cap,
                                 const SlotParams &p, const double2 *__restrict__ pss_fd,
                                 const int8_t *__restrict__ sss_fd) {
   const int tid = threadIdx.x;
@@ -319,6 +330,7 @@ __device__ void dev_pss_sss_foe(SfShared &S, lcs_cell &cell, const double2 *__re
 
 // mode bit 0: run sss_detect, bit 1: run pss_sss_foe (only for cells whose SSS was found)
 __global__ __launch_bounds__(SF_THREADS) void k_sss_foe(lcs_cell *__restrict__ peaks, const int *__restrict__ npeaks,
+                                                         const float2 *__restrict__ cap32,
                                                          const double2 *__restrict__ cap64, uint32_t n_cap,
                                                          const SlotParams *__restrict__ params, double thresh2,
                                                          const double2 *__restrict__ pss_fd,
@@ -332,7 +344,7 @@ __global__ __launch_bounds__(SF_THREADS) void k_sss_foe(lcs_cell *__restrict__ p
   if (tid < 128) { double s, c; sincospi((double)tid / 64.0, &s, &c); S.W[tid] = mk(c, -s); }
   if (tid == 0) cell = peaks[(size_t)slot * LCS_MAXP + pk];
   __syncthreads();
-  const double2 *cap = cap64 + (size_t)slot * n_cap;
+  const CapView cap = cap_view(cap32, cap64, slot, n_cap);
   const SlotParams p = params[slot];
   if (mode & 1) dev_sss_detect(S, cell, cap, n_cap, p, thresh2, pss_fd, sss_fd, dbg);
   __syncthreads();
@@ -353,7 +365,7 @@ static int sf_attr(lcs_ctx *c) {
 int lcs_launch_sss_foe(lcs_ctx *c, int n_buf, uint32_t n_cap, double thresh2_n_sigma, double *dbg) {
   int rc = sf_attr(c);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_sss_foe, dim3(LCS_MAXP, n_buf), dim3(SF_THREADS), sizeof(SfShared), c->stream, c->peaks, c->npeaks, c->cap64, n_cap,
+  hipLaunchKernelGGL(k_sss_foe, dim3(LCS_MAXP, n_buf), dim3(SF_THREADS), sizeof(SfShared), c->stream, c->peaks, c->npeaks, c->cap32, c->cap64_valid ? c->cap64 : nullptr, n_cap,
                      c->params, thresh2_n_sigma, c->d_pss_fd, c->d_sss_fd, 3, dbg);
   HIPCHK(c, hipGetLastError());
   return LCS_OK;
@@ -363,7 +375,7 @@ int lcs_launch_sss_foe(lcs_ctx *c, int n_buf, uint32_t n_cap, double thresh2_n_s
 int lcs_launch_sss_only(lcs_ctx *c, uint32_t n_cap, double thresh2_n_sigma, double *dbg) {
   int rc = sf_attr(c);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_sss_foe, dim3(1, 1), dim3(SF_THREADS), sizeof(SfShared), c->stream, c->peaks, c->npeaks, c->cap64, n_cap, c->params,
+  hipLaunchKernelGGL(k_sss_foe, dim3(1, 1), dim3(SF_THREADS), sizeof(SfShared), c->stream, c->peaks, c->npeaks, c->cap32, c->cap64_valid ? c->cap64 : nullptr, n_cap, c->params,
                      thresh2_n_sigma, c->d_pss_fd, c->d_sss_fd, 1, dbg);
   HIPCHK(c, hipGetLastError());
   return LCS_OK;
@@ -371,7 +383,7 @@ int lcs_launch_sss_only(lcs_ctx *c, uint32_t n_cap, double thresh2_n_sigma, doub
 int lcs_launch_foe_only(lcs_ctx *c, uint32_t n_cap) {
   int rc = sf_attr(c);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_sss_foe, dim3(1, 1), dim3(SF_THREADS), sizeof(SfShared), c->stream, c->peaks, c->npeaks, c->cap64, n_cap, c->params,
+  hipLaunchKernelGGL(k_sss_foe, dim3(1, 1), dim3(SF_THREADS), sizeof(SfShared), c->stream, c->peaks, c->npeaks, c->cap32, c->cap64_valid ? c->cap64 : nullptr, n_cap, c->params,
                      0.0, c->d_pss_fd, c->d_sss_fd, 2, (double *)nullptr);
   HIPCHK(c, hipGetLastError());
   return LCS_OK;

@@ -129,6 +129,7 @@ __global__ void k_tfg_prep(const lcs_cell *__restrict__ cells, const WorkItem *_
 #define TFG_THREADS 288     // 72 bins x 4 symbol groups
 __global__ __launch_bounds__(TFG_THREADS) void k_tfg(const lcs_cell *__restrict__ cells, const WorkItem *__restrict__ items,
                                                      const int *__restrict__ n_work, const SlotParams *__restrict__ params,
+                                                     const float2 *__restrict__ cap32,
                                                      const double2 *__restrict__ cap64, uint32_t n_cap,
                                                      const double *__restrict__ ts, double *__restrict__ scratch,
                                                      double2 *__restrict__ tfg) {
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(TFG_THREADS) void k_tfg(const lcs_cell *__restrict_
     const double k_factor = sc[CS_KFACTOR];
     const lcs_cell c = cells[it];
     const SlotParams p = params[items[it].slot];
-    const double2 *cap = cap64 + (size_t)items[it].slot * n_cap;
+    const CapView cap = cap_view(cap32, cap64, items[it].slot, n_cap);
     const double *tsi = ts + (size_t)it * ROWS;
     const double kk = M_PI * (-c.freq_fine) / ((p.fs_prog * k_factor) / 2);
     __syncthreads();
@@ -158,9 +159,10 @@ __global__ __launch_bounds__(TFG_THREADS) void k_tfg(const lcs_cell *__restrict_
       if (t0 + s < n_ofdm) {
         const long src = (long)s_loc[s] + n;
         if (src >= 0 && (uint64_t)src < n_cap) {
-          const double2 x = cap[src];
-          const double ang = kk * (double)src;
-          v = cmul(mk(x.x, x.y), mk(cos(ang), sin(ang)));
+          const double2 x = cap_at(cap, (size_t)src);
+          double sn, cs;
+          sincos(kk * (double)src, &sn, &cs);
+          v = cmul(mk(x.x, x.y), mk(cs, sn));
         } else if (n == 0) sc[CS_OOB] = 1.0;   // the reference would read out of bounds here
       }
       win[s][n] = v;
@@ -770,7 +772,7 @@ int lcs_launch_tfg(lcs_ctx *c, uint32_t n_cap, int n_items) {
   hipLaunchKernelGGL(k_tfg_prep, dim3((LCS_MAX_WORK + 63) / 64), dim3(64), 0, c->stream, c->cells_out, c->work_items,
                      c->n_work, c->params, c->tfg_ts, c->cell_scratch);
   hipLaunchKernelGGL(k_tfg, dim3(2048), dim3(TFG_THREADS), 0, c->stream, c->cells_out, c->work_items, c->n_work, c->params,
-                     c->cap64, n_cap, c->tfg_ts, c->cell_scratch, c->tfg);
+                     c->cap32, c->cap64_valid ? c->cap64 : nullptr, n_cap, c->tfg_ts, c->cell_scratch, c->tfg);
   HIPCHK(c, hipGetLastError());
   return LCS_OK;
 }
