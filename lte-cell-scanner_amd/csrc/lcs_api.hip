@@ -223,7 +223,8 @@ void lcs_destroy(lcs_ctx *c) {
   void *ptrs[] = {c->cap32, c->cap64, c->params, c->fset, c->tmpl, c->start, c->smin, c->kp2, c->btab, c->single,
                   c->incoh, c->sref, c->pow_, c->work, c->spinc, c->zth, c->sp, c->frq, c->peaks, c->npeaks, c->xc,
                   c->work_items, c->n_work, c->tfg, c->tfg_comp, c->ce, c->tfg_ts, c->tfg_ts_comp, c->cell_scratch,
-                  c->cells_out, c->d_pss_td, c->d_pss_fd, c->d_sss_fd, c->d_pbch_scr, c->d_derm_inv, c->d_dbg};
+                  c->cells_out, c->d_pss_td, c->d_pss_fd, c->d_sss_fd, c->d_pbch_scr, c->d_derm_inv, c->d_dbg, c->pk_items, c->n_pk,
+                  c->sss_ws};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   if (c->h_pinned) (void)hipHostFree(c->h_pinned);
   if (c->ev_xc0) (void)hipEventDestroy(c->ev_xc0);

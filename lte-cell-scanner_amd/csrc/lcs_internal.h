@@ -22,6 +22,10 @@
 
 #define LCS_NW_MAX 16        // incoherent-combining windows (15 for a 153600-sample buffer)
 #define LCS_NF_MAX 128       // frequency hypotheses per call
+// Every kernel other than the PSS correlation is small and latency-bound; in the pipelined chain it
+// shares CUs with the next batch's correlation waves.  Raising the wave priority lets the SIMD
+// arbiter issue these few waves ahead of the MFMA stream instead of round-robin behind 4-5 of them.
+#define LCS_TAIL_PRIO() __builtin_amdgcn_s_setprio(3)
 #define LCS_TG 16            // templates per MFMA column group
 #define LCS_G_MAX ((3 * LCS_NF_MAX + LCS_TG - 1) / LCS_TG)
 #define LCS_KP2_MAX 128      // tap pairs per (window, group): 137 taps + up to 119 samples of spread
@@ -102,6 +106,11 @@ struct lcs_ctx {
   int *npeaks = nullptr;
   float2 *xc = nullptr;             // debug: raw correlations [3][n_cap-136][n_f]
   size_t xc_elems = 0;
+  // SSS / FOE stage (sss_foe.hip): work list of (buffer, peak) pairs and per-(peak, occurrence) records
+  WorkItem *pk_items = nullptr;
+  int *n_pk = nullptr;
+  double *sss_ws = nullptr;
+  size_t sss_ws_items = 0;
   // per-cell stage buffers
   WorkItem *work_items = nullptr;
   int *n_work = nullptr;

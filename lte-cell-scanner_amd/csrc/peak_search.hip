@@ -21,10 +21,9 @@ __device__ __forceinline__ void cell_init(lcs_cell &c) {
   c.phich_duration = 0; c.phich_resource = 0; c.sfn = -1; c.reserved = 0;
 }
 
-// WT = double: working copy in global memory (stage entry point: arbitrary doubles from the caller);
-// WT = float : working copy in 115 KB of LDS (fused chain: the collapsed powers are fp32 values, so
-//              every comparison below gives the same answer as in fp64).
-template <typename WT>
+// Stage entry point (lcs_peak_search: arbitrary doubles from the caller), working copy in global
+// memory.  The fused chain uses k_peak_search_reg below.
+typedef double WT;
 __global__ __launch_bounds__(PS_THREADS) void k_peak_search(const double *__restrict__ pow_, const int *__restrict__ frq,
                                                              const double *__restrict__ zth,
                                                              const float *__restrict__ single,
@@ -39,8 +38,7 @@ __global__ __launch_bounds__(PS_THREADS) void k_peak_search(const double *__rest
   const int *fq = frq + (size_t)slot * NE;
   const double *z = zth + (size_t)slot * LCS_N_IDX;
   const float *sg = single + (size_t)slot * geo.G * LCS_N_IDX * LCS_TG;   // group-major (pss_xcorr.hip)
-  extern __shared__ __attribute__((aligned(16))) char ps_smem[];
-  WT *wk = (sizeof(WT) == sizeof(float)) ? reinterpret_cast<WT *>(ps_smem) : reinterpret_cast<WT *>(work + (size_t)slot * NE);
+  WT *wk = reinterpret_cast<WT *>(work + (size_t)slot * NE);
   lcs_cell *out = peaks + (size_t)slot * LCS_MAXP;
 
   __shared__ double s_val[PS_THREADS / 64];
@@ -124,18 +122,125 @@ __global__ __launch_bounds__(PS_THREADS) void k_peak_search(const double *__rest
   if (tid == 0) npeaks[slot] = n;
 }
 
+// Fused-chain variant: the 3x9600 working copy lives in REGISTERS (113 fp32 per thread of a
+// 256-thread workgroup; the collapsed powers are fp32 values, so fp32 compares are the fp64 ones).
+// A 4-wave workgroup with no LDS to speak of can be placed next to the resident correlation
+// workgroups of the following batch; the 1024-thread version above cannot (it needs 4 free wave
+// slots on every SIMD of one CU at once and waited ~6 ms for them in the pipelined chain).
+#define PSR_THREADS 256
+#define PSR_RPR ((LCS_N_IDX + PSR_THREADS - 1) / PSR_THREADS)   // registers per PSS row (38, last one half padding)
+#define PSR_REGS (3 * PSR_RPR)
+__global__ __launch_bounds__(PSR_THREADS) __attribute__((amdgpu_waves_per_eu(3, 8))) void k_peak_search_reg(const float *__restrict__ pow32, const int *__restrict__ frq,
+                                                                 const double *__restrict__ zth,
+                                                                 const float *__restrict__ single,
+                                                                 const double *__restrict__ fset,
+                                                                 const SlotParams *__restrict__ params,
+                                                                 lcs_cell *__restrict__ peaks, int *__restrict__ npeaks,
+                                                                 XcGeom geo, double udb10_m12) {
+  LCS_TAIL_PRIO();
+  const int slot = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int NE = 3 * LCS_N_IDX;
+  const float *pw = pow32 + (size_t)slot * NE;
+  const int *fq = frq + (size_t)slot * NE;
+  const double *z = zth + (size_t)slot * LCS_N_IDX;
+  const float *sg = single + (size_t)slot * geo.G * LCS_N_IDX * LCS_TG;   // group-major (pss_xcorr.hip)
+  lcs_cell *out = peaks + (size_t)slot * LCS_MAXP;
+
+  __shared__ float s_val[PSR_THREADS / 64];
+  __shared__ int s_idx[PSR_THREADS / 64];
+  __shared__ double s_peak_pow;
+  __shared__ int s_peak_lin;
+  __shared__ int s_stop;
+
+  float v[PSR_REGS];
+  // register r of thread tid holds row r / 38, column (r % 38) * 256 + tid: row and column base are
+  // compile-time per register, and ascending r is ascending linear index (first-maximum rule)
+#pragma unroll
+  for (int r = 0; r < PSR_REGS; ++r) {
+    const int ec = (r % PSR_RPR) * PSR_THREADS + tid;
+    v[r] = (ec < LCS_N_IDX) ? pw[(r / PSR_RPR) * LCS_N_IDX + ec] : -1.0f;   // powers are >= 0: padding never wins
+  }
+
+  int n = 0;
+  for (int iter = 0; iter < PS_MAX_ITER; ++iter) {
+    float best = v[0];
+    int br = 0;
+#pragma unroll
+    for (int r = 1; r < PSR_REGS; ++r)
+      if (v[r] > best) { best = v[r]; br = r; }
+    asm volatile("" : "+v"(br));   // keep the select chain on the small constants r (else 113 hoisted index registers)
+    int bi = (br / PSR_RPR) * LCS_N_IDX + (br % PSR_RPR) * PSR_THREADS + tid;
+    for (int off = 32; off > 0; off >>= 1) {
+      const float ov = __shfl_down(best, off);
+      const int oi = __shfl_down(bi, off);
+      if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if ((tid & 63) == 0) { s_val[tid >> 6] = best; s_idx[tid >> 6] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+      float b = s_val[0];
+      int i = s_idx[0];
+      for (int k = 1; k < PSR_THREADS / 64; ++k)
+        if (s_val[k] > b || (s_val[k] == b && s_idx[k] < i)) { b = s_val[k]; i = s_idx[k]; }
+      const int peak_n_id_2 = i / LCS_N_IDX, peak_ind = i % LCS_N_IDX;
+      const double peak_pow = (double)b;
+      int stop = 0;
+      if (peak_pow < z[peak_ind]) stop = 1;
+      if (!stop) {
+        const int fi = fq[peak_n_id_2 * LCS_N_IDX + peak_ind];
+        double best_pow = -INFINITY;
+        int best_ind = -1;
+        const int ds = geo.ds;
+        if (peak_ind - ds >= 0) {   // uint16 wrap of the reference loop variable, quirk Q2
+          for (int t = peak_ind - ds; t <= peak_ind + ds; ++t) {
+            const int tw = t % LCS_N_IDX;
+            const int cc = fi * 3 + peak_n_id_2;
+            const float sv = sg[((size_t)(cc / LCS_TG) * LCS_N_IDX + tw) * LCS_TG + (cc % LCS_TG)];
+            if ((double)sv > best_pow) { best_pow = sv; best_ind = tw; }
+          }
+        }
+        if (n < LCS_MAXP) {
+          lcs_cell c;
+          cell_init(c);
+          c.fc_requested = params[slot].fc_req;
+          c.fc_programmed = params[slot].fc_prog;
+          c.pss_pow = peak_pow;
+          c.ind = best_ind;
+          c.freq = fset[fi];
+          c.n_id_2 = peak_n_id_2;
+          out[n] = c;
+        }
+      }
+      s_peak_pow = peak_pow;
+      s_peak_lin = i;
+      s_stop = stop;
+    }
+    __syncthreads();
+    if (s_stop) break;
+    ++n;
+    const int row = s_peak_lin / LCS_N_IDX, col = s_peak_lin % LCS_N_IDX;
+    const double thresh = s_peak_pow * udb10_m12;
+    const int tc = tid - col;
+#pragma unroll
+    for (int r = 0; r < PSR_REGS; ++r) {
+      const int d = (r % PSR_RPR) * PSR_THREADS + tc;   // column - col, in (-9600, 9600)
+      const bool real = (r % PSR_RPR != PSR_RPR - 1) || (d + col < LCS_N_IDX);
+      const int ad = d < 0 ? -d : d;                     // circular distance <= 274  <=>  |d| <= 274 or |d| >= 9600 - 274
+      const bool cancel = (r / PSR_RPR == row) && (ad <= 274 || ad >= LCS_N_IDX - 274);
+      if (real && (cancel || (double)v[r] < thresh)) v[r] = 0.0f;
+    }
+    __syncthreads();   // s_* are rewritten by thread 0 in the next iteration
+  }
+  if (tid == 0) npeaks[slot] = n;
+}
+
 int lcs_launch_peak_search(lcs_ctx *c, int n_buf, const XcGeom &geo, double udb10_m12, bool fp32_exact) {
   if (fp32_exact) {
-    const size_t smem = sizeof(float) * 3 * LCS_N_IDX;
-    static bool attr_set = false;
-    if (!attr_set) {
-      HIPCHK(c, hipFuncSetAttribute((const void *)k_peak_search<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-      attr_set = true;
-    }
-    hipLaunchKernelGGL(k_peak_search<float>, dim3(n_buf), dim3(PS_THREADS), smem, c->stream, c->pow_, c->frq, c->zth, c->single,
-                       c->fset, c->params, c->work, c->peaks, c->npeaks, geo, udb10_m12);
+    hipLaunchKernelGGL(k_peak_search_reg, dim3(n_buf), dim3(PSR_THREADS), 0, c->stream, reinterpret_cast<const float *>(c->work), c->frq, c->zth, c->single,
+                       c->fset, c->params, c->peaks, c->npeaks, geo, udb10_m12);
   } else
-    hipLaunchKernelGGL(k_peak_search<double>, dim3(n_buf), dim3(PS_THREADS), 0, c->stream, c->pow_, c->frq, c->zth, c->single,
+    hipLaunchKernelGGL(k_peak_search, dim3(n_buf), dim3(PS_THREADS), 0, c->stream, c->pow_, c->frq, c->zth, c->single,
                        c->fset, c->params, c->work, c->peaks, c->npeaks, geo, udb10_m12);
   HIPCHK(c, hipGetLastError());
   return LCS_OK;

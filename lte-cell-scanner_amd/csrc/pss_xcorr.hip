@@ -39,6 +39,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // so no fp64 copy is written: the fp64 stages read cap32 and widen on the fly (cap_at()).
 __global__ void k_ingest(const void *__restrict__ src, int fmt, uint32_t n_cap, float2 *__restrict__ cap32,
                          double2 *__restrict__ cap64) {
+  LCS_TAIL_PRIO();
   const int slot = blockIdx.y;
   const size_t base = (size_t)slot * n_cap;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_cap; i += gridDim.x * blockDim.x) {
@@ -63,6 +64,7 @@ __global__ __launch_bounds__(256) void k_prep_tables(const SlotParams *__restric
                                                       const double2 *__restrict__ pss_td, float2 *__restrict__ tmpl,
                                                       int *__restrict__ start, int *__restrict__ smin,
                                                       int *__restrict__ kp2, XcGeom geo) {
+  LCS_TAIL_PRIO();
   const int slot = blockIdx.x;
   const SlotParams p = params[slot];
   __shared__ int s_start[NW][NFM];
@@ -108,6 +110,7 @@ __global__ __launch_bounds__(256) void k_prep_tables(const SlotParams *__restric
 __global__ __launch_bounds__(256) void k_fill_btab(const float2 *__restrict__ tmpl, const int *__restrict__ start,
                                                     const int *__restrict__ smin, const int *__restrict__ kp2,
                                                     float *__restrict__ btab, XcGeom geo) {
+  LCS_TAIL_PRIO();
   const int slot = blockIdx.z;
   const int wg = blockIdx.y;
   const int w = wg / geo.G, g = wg % geo.G;
@@ -581,6 +584,7 @@ struct SpArgs {
 __device__ __forceinline__ int sp_pad(int i) { return i + (i >> 4); }
 __global__ __launch_bounds__(64) void k_sp_sums(const float2 *__restrict__ cap32, const double2 *__restrict__ cap64,
                                                  double *__restrict__ sp_all, uint32_t n_cap, int n_comb_sp) {
+  LCS_TAIL_PRIO();
   const int slot = blockIdx.z, m = blockIdx.y;
   const int i0 = blockIdx.x * SP_TILE;
   const int tid = threadIdx.x;
@@ -607,6 +611,7 @@ __global__ __launch_bounds__(64) void k_sp_sums(const float2 *__restrict__ cap32
 }
 __global__ __launch_bounds__(256) void k_sp_fold(const double *__restrict__ sp_all, double *__restrict__ spinc,
                                                   double *__restrict__ zth, SpArgs a) {
+  LCS_TAIL_PRIO();
   const int slot = blockIdx.y;
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= 9600) return;
@@ -624,7 +629,9 @@ __global__ __launch_bounds__(256) void k_sp_fold(const double *__restrict__ sp_a
 // (consecutive lanes read consecutive rows: fully coalesced), then scans the templates in
 // ascending (foi, pss) order keeping the first maximum per PSS.
 __global__ __launch_bounds__(128) void k_collapse(const float *__restrict__ sg, float *__restrict__ incoh,
-                                                   double *__restrict__ pow_, int *__restrict__ frq, XcGeom geo) {
+                                                   double *__restrict__ pow_, float *__restrict__ pow32,
+                                                   int *__restrict__ frq, XcGeom geo) {
+  LCS_TAIL_PRIO();
   const int slot = blockIdx.y;
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= LCS_N_IDX) return;
@@ -662,6 +669,7 @@ __global__ __launch_bounds__(128) void k_collapse(const float *__restrict__ sg, 
 #pragma unroll
   for (int t = 0; t < 3; ++t) {
     pow_[((size_t)slot * 3 + t) * LCS_N_IDX + idx] = (double)best[t];
+    pow32[((size_t)slot * 3 + t) * LCS_N_IDX + idx] = best[t];   // what the fused peak search loads
     frq[((size_t)slot * 3 + t) * LCS_N_IDX + idx] = bi[t];
   }
 }
@@ -755,7 +763,10 @@ int lcs_launch_xcorr(lcs_ctx *c, int n_buf, const XcGeom &geo, bool want_incoh, 
   const int n8 = (n_buf >= 8) ? (n_buf & ~7) : 0;
   // main stream -> correlation stream hand-off (tables and fp32 buffer are ready)
   static const bool single_stream = getenv("LCS_SINGLE_STREAM") != nullptr;   // measurement knob
-  static const int lds_pad = getenv("LCS_XC_LDS_PAD") ? atoi(getenv("LCS_XC_LDS_PAD")) : 0;   // measurement knob: caps waves/CU
+  // Extra dynamic LDS per correlation workgroup: 29 KB + 4 KB caps residency at 4 workgroups per CU
+  // (costs 0.3 % of the kernel) and leaves 30 KB of LDS, 4 wave slots per SIMD and 288 VGPRs per lane
+  // free, enough to place any of the small kernels of the neighbouring batches on every CU.
+  static const int lds_pad = getenv("LCS_XC_LDS_PAD") ? atoi(getenv("LCS_XC_LDS_PAD")) : 4096;
   hipStream_t sxc = single_stream ? c->stream : c->stream_xc;
   if (!single_stream) {
     HIPCHK(c, hipEventRecord(c->ev_pre, c->stream));
@@ -774,7 +785,7 @@ int lcs_launch_xcorr(lcs_ctx *c, int n_buf, const XcGeom &geo, bool want_incoh, 
     if (ns <= 0) continue;
 #define XCB_LAUNCH(WPS_, NWV_, BCH_)                                                                              \
   hipLaunchKernelGGL((k_xcorr_mfma_blk<WPS_, NWV_, BCH_>), dim3((unsigned)(((LCS_N_IDX + NWV_ * 64 - 1) / (NWV_ * 64)) * geo.G * ns)), \
-                     dim3(NWV_ * 64), 0, sxc, c->cap32, c->smin, c->kp2, c->btab, c->single, geo, s0, ns, part ? 0 : 1)
+                     dim3(NWV_ * 64), lds_pad, sxc, c->cap32, c->smin, c->kp2, c->btab, c->single, geo, s0, ns, part ? 0 : 1)
 #define XC1_ARGS dim3((unsigned)(per_slot * ns)), dim3(64), lds_pad, sxc, c->cap32, c->smin, c->kp2, c->btab, c->single, geo, s0, ns, part ? 0 : 1
     switch (c->xcorr_variant) {
       case 0: XCB_LAUNCH(4, 4, 32); break;                                      // default: 4-wave workgroups, B through LDS
@@ -799,7 +810,7 @@ int lcs_launch_xcorr(lcs_ctx *c, int n_buf, const XcGeom &geo, bool want_incoh, 
     HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_post, 0));
   }
   hipLaunchKernelGGL(k_collapse, dim3((LCS_N_IDX + 127) / 128, n_buf), dim3(128), 0, c->stream, c->single,
-                     want_incoh ? c->incoh : nullptr, c->pow_, c->frq, geo);
+                     want_incoh ? c->incoh : nullptr, c->pow_, reinterpret_cast<float *>(c->work), c->frq, geo);
   HIPCHK(c, hipGetLastError());
   return LCS_OK;
 }

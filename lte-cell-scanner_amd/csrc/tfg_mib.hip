@@ -19,7 +19,9 @@
 #define CS_N_OFDM 0
 #define CS_KFACTOR 1
 #define CS_OOB 2
-#define CS_NP 4          // 4 values
+#define CS_NP 4          // 4 values (stage entry points only; the chain sums CS_NPP)
+#define CS_NRS 8         // 4 values: RS rows per port
+#define CS_NPP 32        // [4 ports][CE_NCHUNK <= 8] partial sums of |filtered - raw|^2
 #define CS_CAND 16       // 12 candidates x 4: ok, bits lo (24 bits as double), unused
 #define CS_SHIFT 64      // [140][4] (-1 = no RS)
 #define CS_RS 1024       // [140][12] complex
@@ -69,6 +71,7 @@ __device__ cd2 block_sum(cd2 v, cd2 *red /*>= blockDim/64*/) {
 // ----------------------------------------------------------------- work-list compaction
 __global__ void k_gather_work(const lcs_cell *__restrict__ peaks, const int *__restrict__ npeaks, int n_buf,
                               WorkItem *__restrict__ items, int *__restrict__ n_work, lcs_cell *__restrict__ cells) {
+  LCS_TAIL_PRIO();
   if (blockIdx.x != 0 || threadIdx.x != 0) return;
   int n = 0;
   for (int s = 0; s < n_buf; ++s) {
@@ -82,6 +85,7 @@ __global__ void k_gather_work(const lcs_cell *__restrict__ peaks, const int *__r
 }
 __global__ void k_scatter_back(lcs_cell *__restrict__ peaks, const WorkItem *__restrict__ items,
                                const int *__restrict__ n_work, const lcs_cell *__restrict__ cells) {
+  LCS_TAIL_PRIO();
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < *n_work) peaks[(size_t)items[i].slot * LCS_MAXP + items[i].peak] = cells[i];
 }
@@ -92,6 +96,7 @@ __global__ void k_scatter_back(lcs_cell *__restrict__ peaks, const WorkItem *__r
 __global__ void k_tfg_prep(const lcs_cell *__restrict__ cells, const WorkItem *__restrict__ items,
                            const int *__restrict__ n_work, const SlotParams *__restrict__ params,
                            double *__restrict__ ts, double *__restrict__ scratch) {
+  LCS_TAIL_PRIO();
   const int it = blockIdx.x * blockDim.x + threadIdx.x;
   if (it >= *n_work) return;
   const lcs_cell c = cells[it];
@@ -125,7 +130,7 @@ __global__ void k_tfg_prep(const lcs_cell *__restrict__ cells, const WorkItem *_
 // LDS (the reference rotates all 153600 samples per cell, ref :892; only the 854x128 that feed a
 // DFT are touched here, with the same absolute-index phase), direct 72-bin DFT, /sqrt(128),
 // then the sub-sample timing phase ramp (ref :923-931).
-#define TFG_SYM 16
+#define TFG_SYM 8            // 8 x 2 KB windows + twiddles = 18 KB of LDS: fits beside the correlation kernel's workgroups
 #define TFG_THREADS 288     // 72 bins x 4 symbol groups
 __global__ __launch_bounds__(TFG_THREADS) void k_tfg(const lcs_cell *__restrict__ cells, const WorkItem *__restrict__ items,
                                                      const int *__restrict__ n_work, const SlotParams *__restrict__ params,
@@ -133,6 +138,7 @@ __global__ __launch_bounds__(TFG_THREADS) void k_tfg(const lcs_cell *__restrict_
                                                      const double2 *__restrict__ cap64, uint32_t n_cap,
                                                      const double *__restrict__ ts, double *__restrict__ scratch,
                                                      double2 *__restrict__ tfg) {
+  LCS_TAIL_PRIO();
   __shared__ cd2 W[128];
   __shared__ cd2 win[TFG_SYM][128];
   __shared__ int s_loc[TFG_SYM];
@@ -169,7 +175,7 @@ __global__ __launch_bounds__(TFG_THREADS) void k_tfg(const lcs_cell *__restrict_
     }
     __syncthreads();
     {
-      // thread = (subcarrier i, symbol group g): symbols g, g+4, g+8, g+12 share each twiddle read
+      // thread = (subcarrier i, symbol group g): symbols g, g+4 share each twiddle read
       const int i = tid % NSC, g = tid / NSC;
       const int bin = (i < 36) ? 92 + i : i - 35;
       cd2 acc[TFG_SYM / 4];
@@ -202,6 +208,7 @@ __global__ __launch_bounds__(TFG_THREADS) void k_tfg(const lcs_cell *__restrict_
 // shifts, for every (slot, symbol) that carries RS.  60 Gold sequences per cell.
 __global__ __launch_bounds__(64) void k_rs_build(const lcs_cell *__restrict__ cells, const int *__restrict__ n_work,
                                                   double *__restrict__ scratch) {
+  LCS_TAIL_PRIO();
   for (int it = blockIdx.x; it < *n_work; it += gridDim.x) {
     const lcs_cell c = cells[it];
     double *sc = scratch + (size_t)it * CS_SIZE;
@@ -256,12 +263,13 @@ __device__ __forceinline__ int rs_shift(const double *sc, int n_symb, int slot, 
 
 // ------------------------------------------------------------------------------ tfoec
 #define TF_THREADS 512
-__global__ __launch_bounds__(TF_THREADS) void k_tfoec(lcs_cell *__restrict__ cells, const WorkItem *__restrict__ items,
+__global__ __launch_bounds__(TF_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_tfoec(lcs_cell *__restrict__ cells, const WorkItem *__restrict__ items,
                                                        const int *__restrict__ n_work,
                                                        const SlotParams *__restrict__ params,
                                                        const double2 *__restrict__ tfg, const double *__restrict__ ts,
                                                        double *__restrict__ scratch, double2 *__restrict__ tfg_comp,
                                                        double *__restrict__ ts_comp) {
+  LCS_TAIL_PRIO();
   __shared__ cd2 red[TF_THREADS / 64];
   __shared__ cd2 comp[NSC];
   const int tid = threadIdx.x;
@@ -410,16 +418,18 @@ __device__ __forceinline__ void ext_vertex(const cd2 *row, int s, int i, int &x,
 
 #define CE_THREADS 256
 #define CE_MAX_RS 256
+#define CE_CH 48                                      // RS rows per workgroup: 19 KB of LDS
+#define CE_NCHUNK ((CE_MAX_RS + CE_CH - 1) / CE_CH)   // 6 (scratch holds 8 partials per port)
 __global__ __launch_bounds__(CE_THREADS) void k_chan_est(const lcs_cell *__restrict__ cells, const int *__restrict__ n_work,
                                                           const double2 *__restrict__ tfg_comp,
                                                           double *__restrict__ scratch, double2 *__restrict__ ce) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  cd2 *ce_raw = (cd2 *)smem;                          // [CE_MAX_RS][12]
-  cd2 *ce_filt = ce_raw + CE_MAX_RS * 12;             // [CE_MAX_RS][12]
-  int *rs_set = (int *)(ce_filt + CE_MAX_RS * 12);    // [CE_MAX_RS]
-  cd2 *red = (cd2 *)(rs_set + CE_MAX_RS);             // [4]
+  LCS_TAIL_PRIO();
+  __shared__ cd2 ce_raw[(CE_CH + 3) * 12];     // RS rows r0 .. r1 of this chunk (one halo row each side)
+  __shared__ cd2 ce_filt[(CE_CH + 1) * 12];    // RS rows c0 .. f1
+  __shared__ int rs_set[CE_MAX_RS];
+  __shared__ cd2 red[CE_THREADS / 64];
   __shared__ int s_nrs;
-  const int tid = threadIdx.x, port = blockIdx.y;
+  const int tid = threadIdx.x, port = blockIdx.y, chunk = blockIdx.z;
   for (int it = blockIdx.x; it < *n_work; it += gridDim.x) {
     const lcs_cell c = cells[it];
     double *sc = scratch + (size_t)it * CS_SIZE;
@@ -444,8 +454,16 @@ __global__ __launch_bounds__(CE_THREADS) void k_chan_est(const lcs_cell *__restr
     // slot_num advances every 2nd RS row for ports 0/1, every row for ports 2/3 (quirk Q9)
     const int sh0 = rs_shift(sc, n_symb, 0, d_imod(rs_set[0], n_symb), port);
     const int sh1 = rs_shift(sc, n_symb, d_imod((port >= 2) ? 1 : 0, 20), d_imod(rs_set[1], n_symb), port);
-    for (int e = tid; e < n_rs * 12; e += CE_THREADS) {
-      const int t = e / 12, i = e % 12;
+    // this workgroup: filtered rows and row pairs [c0, c1) of the RS row list
+    const int c0 = chunk * CE_CH, c1 = min(n_rs, c0 + CE_CH);
+    if (c0 >= n_rs) {
+      if (tid == 0) sc[CS_NPP + port * 8 + chunk] = 0.0;
+      continue;
+    }
+    const int f1 = min(c1, n_rs - 1);                          // last filtered row needed (inclusive)
+    const int r0 = max(c0 - 1, 0), r1 = min(f1 + 1, n_rs - 1);  // raw rows needed (inclusive)
+    for (int e = tid; e < (r1 - r0 + 1) * 12; e += CE_THREADS) {
+      const int t = r0 + e / 12, i = e % 12;
       const int slot = (port >= 2) ? (t % 20) : ((t >> 1) % 20);
       const int sym = d_imod(rs_set[t], n_symb);
       const int sh = rs_shift(sc, n_symb, slot, sym, port);
@@ -453,43 +471,48 @@ __global__ __launch_bounds__(CE_THREADS) void k_chan_est(const lcs_cell *__restr
     }
     __syncthreads();
     // 7-point hexagonal mean (ref :1431-1467)
-    for (int e = tid; e < n_rs * 12; e += CE_THREADS) {
-      const int t = e / 12, k = e % 12;
+    for (int e = tid; e < (f1 - c0 + 1) * 12; e += CE_THREADS) {
+      const int t = c0 + e / 12, k = e % 12;
+      const cd2 *raw_t = ce_raw + (t - r0) * 12;
       const bool leftmost = ((sh0 < sh1) ? 1 : 0) ^ (t & 1);
       cd2 total = mk(0, 0);
       int n_total = 0;
-      for (int i = k - 1; i <= k + 1; ++i) if (i >= 0 && i <= 11) { total = cadd(total, ce_raw[t * 12 + i]); ++n_total; }
+      for (int i = k - 1; i <= k + 1; ++i) if (i >= 0 && i <= 11) { total = cadd(total, raw_t[i]); ++n_total; }
       int lo, hi;
       if (sh0 == sh1) { lo = k - 1; hi = k + 1; } else if (leftmost) { lo = k - 1; hi = k; } else { lo = k; hi = k + 1; }
       if (t != 0) {
         cd2 s = mk(0, 0);
-        for (int i = lo; i <= hi; ++i) if (i >= 0 && i <= 11) { s = cadd(s, ce_raw[(t - 1) * 12 + i]); ++n_total; }
+        for (int i = lo; i <= hi; ++i) if (i >= 0 && i <= 11) { s = cadd(s, raw_t[i - 12]); ++n_total; }
         total = cadd(total, s);
       }
       if (t != n_rs - 1) {
         cd2 s = mk(0, 0);
-        for (int i = lo; i <= hi; ++i) if (i >= 0 && i <= 11) { s = cadd(s, ce_raw[(t + 1) * 12 + i]); ++n_total; }
+        for (int i = lo; i <= hi; ++i) if (i >= 0 && i <= 11) { s = cadd(s, raw_t[i + 12]); ++n_total; }
         total = cadd(total, s);
       }
       ce_filt[e] = cdivr(total, (double)n_total);
     }
     __syncthreads();
-    // noise power (ref :1470)
+    // noise power (ref :1470): this chunk's share of sum |filtered - raw|^2; the consumers add the
+    // chunk partials in chunk order and divide by 12 n_rs (np_from_partials)
     cd2 part = mk(0, 0);
-    for (int e = tid; e < n_rs * 12; e += CE_THREADS) { const cd2 d = csub(ce_filt[e], ce_raw[e]); part.re += d.re * d.re + d.im * d.im; }
+    for (int e = tid; e < (c1 - c0) * 12; e += CE_THREADS) {
+      const cd2 d = csub(ce_filt[e], ce_raw[e + (c0 - r0) * 12]);
+      part.re += d.re * d.re + d.im * d.im;
+    }
     const cd2 tot = block_sum(part, red);
-    if (tid == 0) sc[CS_NP + port] = tot.re / (n_rs * 12);
+    if (tid == 0) { sc[CS_NPP + port * 8 + chunk] = tot.re; if (chunk == 0) sc[CS_NRS + port] = (double)n_rs; }
     // piecewise-planar interpolation between consecutive RS rows (ref :1237-1351): one thread
     // walks the triangle strip of one row pair exactly as the reference does
-    if (tid < NSC) {   // first RS row: plain 1-D interpolation (ref :1250-1252)
+    if (chunk == 0 && tid < NSC) {   // first RS row: plain 1-D interpolation (ref :1250-1252)
       double x[16]; cd2 v[16]; int n = 0;
       for (int xx = sh0; xx <= 71; xx += 6) { x[n] = xx; v[n] = ce_filt[n]; ++n; }
       n = hex_extend(x, v, n);
       st(&out[(size_t)rs_set[0] * NSC + tid], interp1_c(x, v, n, (double)tid));
     }
-    for (int t = tid; t <= n_rs - 2; t += CE_THREADS) {
+    for (int t = c0 + tid; t < c1 && t <= n_rs - 2; t += CE_THREADS) {
       const int s_top = (t & 1) ? sh1 : sh0, s_bot = (t & 1) ? sh0 : sh1;
-      const cd2 *top = ce_filt + t * 12, *bot = ce_filt + (t + 1) * 12;
+      const cd2 *top = ce_filt + (t - c0) * 12, *bot = ce_filt + (t + 1 - c0) * 12;
       const int n_top = ext_len(s_top), n_bot = ext_len(s_bot);
       const int y_top = rs_set[t], y_bot = rs_set[t + 1];
       int tx[3], ty[3]; cd2 tv[3];
@@ -550,31 +573,40 @@ __global__ __launch_bounds__(CE_THREADS) void k_chan_est(const lcs_cell *__restr
     }
     __syncthreads();
     // rows outside the RS span copy the nearest RS row (ref :1356-1361)
+    // (the first RS row is written by chunk 0, the last one by the chunk that owns the last row pair)
     const int first = rs_set[0], last = rs_set[n_rs - 1];
-    for (int e = tid; e < n_ofdm * NSC; e += CE_THREADS) {
-      const int t = e / NSC, i = e % NSC;
-      if (t < first) out[e] = out[(size_t)first * NSC + i];
-      else if (t > last) out[e] = out[(size_t)last * NSC + i];
-    }
+    if (chunk == 0)
+      for (int e = tid; e < first * NSC; e += CE_THREADS) out[e] = out[(size_t)first * NSC + e % NSC];
+    if (c1 >= n_rs - 1 && c0 <= max(n_rs - 2, 0))
+      for (int e = (last + 1) * NSC + tid; e < n_ofdm * NSC; e += CE_THREADS) out[e] = out[(size_t)last * NSC + e % NSC];
     __syncthreads();
   }
 }
 
+// sigpower(filtered - raw) of one port from k_chan_est's per-chunk partial sums (ref :1470)
+__device__ __forceinline__ double np_from_partials(const double *sc, int port) {
+  double s = 0;
+  for (int q = 0; q < CE_NCHUNK; ++q) s += sc[CS_NPP + port * 8 + q];
+  return s / ((double)sc[CS_NRS + port] * 12);
+}
+
 // ------------------------------------------------------------------------ PBCH decode
 // One workgroup per (cell, candidate): candidate = frame_timing_guess*3 + {1,2,4 ports}.
-#define PB_THREADS 1024
+// 512 threads and ~21 KB of LDS so the workgroup fits beside the correlation kernel's workgroups:
+// equalised symbols stay in registers (one symbol pair per thread through the soft demodulator),
+// only the 1920 LLRs go through LDS.
+#define PB_THREADS 512
 #define PB_WAVES (PB_THREADS / 64)
 __device__ __forceinline__ double trunc_log(double x) {     // itpp::trunc_log
   if (x == INFINITY) return log(1.79769313486231570815e+308);
   if (x <= 0) return log(2.22507385850720138309e-308);
   return log(x);
 }
-__global__ __launch_bounds__(PB_THREADS) void k_pbch(const lcs_cell *__restrict__ cells, const int *__restrict__ n_work,
+__global__ __launch_bounds__(PB_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_pbch(const lcs_cell *__restrict__ cells, const int *__restrict__ n_work,
                                                       const double2 *__restrict__ tfg_comp, const double2 *__restrict__ ce,
                                                       double *__restrict__ scratch, const uint8_t *__restrict__ pbch_scr,
                                                       const int16_t *__restrict__ derm_inv /*[2][120][16]*/) {
-  __shared__ cd2 syms[960];
-  __shared__ double npv[960];
+  LCS_TAIL_PRIO();
   __shared__ double e_est[1920];
   __shared__ double d_est[3][40];
   __shared__ unsigned long long surv[PB_WAVES][40], best_surv[PB_WAVES][40];
@@ -593,12 +625,13 @@ __global__ __launch_bounds__(PB_THREADS) void k_pbch(const lcs_cell *__restrict_
     const int r0 = (v3 == 0) ? 1 : 0, r1 = (v3 == 2) ? 1 : 2;     // the two residues != v3, ascending
     const double2 *g = tfg_comp + (size_t)it * ROWS * NSC;
     const double2 *cep = ce + ((size_t)it * 4) * ROWS * NSC;
-    const double np0 = sc[CS_NP + 0], np1 = sc[CS_NP + 1], np2 = sc[CS_NP + 2], np3 = sc[CS_NP + 3];
+    const double np0 = np_from_partials(sc, 0), np1 = np_from_partials(sc, 1), np2 = np_from_partials(sc, 2), np3 = np_from_partials(sc, 3);
     const int start = guess * 10 * 2 * n_symb;
     __syncthreads();
     // pbch_extract (ref :1503-1520) + equalisation (ref :1571-1612), one symbol pair per thread
     for (int pr = tid; pr < n_sym / 2; pr += PB_THREADS) {
-      cd2 x[2], h[4][2];
+      cd2 x[2], h[4][2], syms[2];
+      double npv[2];
       for (int q = 0; q < 2; ++q) {
         const int idx = 2 * pr + q;
         const int fr = idx / per_frame;
@@ -616,8 +649,8 @@ __global__ __launch_bounds__(PB_THREADS) void k_pbch(const lcs_cell *__restrict_
       if (n_ports == 1) {
         for (int q = 0; q < 2; ++q) {
           const cd2 gain = cconj(cdiv(h[0][q], mk(cabs2(h[0][q]), 0)));
-          syms[t + q] = cmul(x[q], gain);
-          npv[t + q] = np0 * cabs2(gain);
+          syms[q] = cmul(x[q], gain);
+          npv[q] = np0 * cabs2(gain);
         }
       } else {
         cd2 h1, h2;
@@ -631,17 +664,17 @@ __global__ __launch_bounds__(PB_THREADS) void k_pbch(const lcs_cell *__restrict_
         const double a1 = hypot(h1.re, h1.im) / scale, a2 = hypot(h2.re, h2.im) / scale;
         const double npp = (a1 * a1 + a2 * a2) * np_temp;
         const double s2 = pow(2.0, 0.5);
-        syms[t] = cscale(s0, s2); syms[t + 1] = cscale(s1, s2);
-        npv[t] = npp; npv[t + 1] = npp;
+        syms[0] = cscale(s0, s2); syms[1] = cscale(s1, s2);
+        npv[0] = npp; npv[1] = npp;
       }
-    }
-    __syncthreads();
-    // soft demodulation: exact log-MAP as itpp::Modulator::demodulate_soft_bits (LOGMAP) with
-    // rx = sym/sqrt(np), channel = 1/sqrt(np), N0 = 1 (ref src/lte_lib.cpp:628-631); descramble
-    for (int l = tid; l < n_sym; l += PB_THREADS) {
+      // soft demodulation: exact log-MAP as itpp::Modulator::demodulate_soft_bits (LOGMAP) with
+      // rx = sym/sqrt(np), channel = 1/sqrt(np), N0 = 1 (ref src/lte_lib.cpp:628-631); descramble
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+      const int l = t + q;
       const double a = 1 / sqrt(2.0);
-      const cd2 gain = cdiv(mk(1.0, 0), mk(sqrt(npv[l]), 0));
-      const cd2 rx = cmul(syms[l], gain);
+      const cd2 gain = cdiv(mk(1.0, 0), mk(sqrt(npv[q]), 0));
+      const cd2 rx = cmul(syms[q], gain);
       double metric[4];
       for (int j = 0; j < 4; ++j) {
         const cd2 S = mk((j & 2) ? -a : a, (j & 1) ? -a : a);
@@ -653,6 +686,7 @@ __global__ __launch_bounds__(PB_THREADS) void k_pbch(const lcs_cell *__restrict_
       if (scr[2 * l]) l0 = -l0;
       if (scr[2 * l + 1]) l1 = -l1;
       e_est[2 * l] = l0; e_est[2 * l + 1] = l1;
+      }
     }
     __syncthreads();
     // de-ratematch: average all observations of each coded bit (ref src/lte_lib.cpp:497-509)
@@ -730,6 +764,7 @@ __global__ __launch_bounds__(PB_THREADS) void k_pbch(const lcs_cell *__restrict_
 
 // first passing candidate in the reference's loop order wins (ref :1547, :1567, :1638-1686)
 __global__ void k_mib_select(lcs_cell *__restrict__ cells, const int *__restrict__ n_work, const double *__restrict__ scratch) {
+  LCS_TAIL_PRIO();
   const int it = blockIdx.x * blockDim.x + threadIdx.x;
   if (it >= *n_work) return;
   const double *sc = scratch + (size_t)it * CS_SIZE;
@@ -790,13 +825,7 @@ int lcs_launch_tfoec(lcs_ctx *c, int n_items) {
 }
 int lcs_launch_mib(lcs_ctx *c, int n_items) {
   (void)n_items;
-  const size_t smem = sizeof(double) * 2 * CE_MAX_RS * 12 * 2 + sizeof(int) * CE_MAX_RS + sizeof(double) * 2 * 4 + 64;
-  static bool attr_set = false;
-  if (!attr_set) {
-    HIPCHK(c, hipFuncSetAttribute((const void *)k_chan_est, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(k_chan_est, dim3(GRID_ITEMS, 4), dim3(CE_THREADS), smem, c->stream, c->cells_out, c->n_work,
+  hipLaunchKernelGGL(k_chan_est, dim3(GRID_ITEMS, 4, CE_NCHUNK), dim3(CE_THREADS), 0, c->stream, c->cells_out, c->n_work,
                      c->tfg_comp, c->cell_scratch, c->ce);
   hipLaunchKernelGGL(k_pbch, dim3(GRID_ITEMS, 12), dim3(PB_THREADS), 0, c->stream, c->cells_out, c->n_work, c->tfg_comp,
                      c->ce, c->cell_scratch, c->d_pbch_scr, c->d_derm_inv);
