@@ -249,7 +249,7 @@ def main():
                        "pipeline_depth": len(ctxs),
                        "parallelism": f"carrier-sweep shard x{world}, RCCL all-gather of cell list" if world > 1 else "single GPU",
                        "baseline_note": "vs_baseline = value / (1 buffer per ~6 s), doc/CellSearch.html:52-54 (dual-core i7-2640, ppm 100)",
-                       "n_peaks_last_step": n_peaks,
+                       "n_cells_reported_last_step": n_peaks,
                        "step_done_ms": [round(1e3 * (x - t0), 2) for x in host_t.get("stamps", [])[-args.steps:]],
                        "host_ms_per_step": {"enqueue": 1e3 * host_t["enqueue"] / max(1, host_t["n"]),
                                             "collect_incl_wait": 1e3 * host_t["collect"] / max(1, host_t["n"])}},

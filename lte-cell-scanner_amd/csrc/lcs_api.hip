@@ -200,7 +200,11 @@ int lcs_create(int device, lcs_ctx **out) {
     int fill[120] = {0};
     for (int t = 0; t < n_e; ++t) derm[(v * 120 + map[t]) * 16 + fill[map[t]]++] = (int16_t)t;
   }
+  uint32_t pn_jump[32];
+  lcs_tables::pn_jump_table(1600 + 2 * (110 - 6), pn_jump);
   bool ok = hipMalloc((void **)&c->d_pss_td, td.size() * sizeof(double)) == hipSuccess &&
+            hipMalloc((void **)&c->d_pn_jump, sizeof(pn_jump)) == hipSuccess &&
+            hipMemcpy(c->d_pn_jump, pn_jump, sizeof(pn_jump), hipMemcpyHostToDevice) == hipSuccess &&
             hipMalloc((void **)&c->d_pss_fd, fd.size() * sizeof(double)) == hipSuccess &&
             hipMalloc((void **)&c->d_sss_fd, sss.size()) == hipSuccess &&
             hipMalloc((void **)&c->d_pbch_scr, scr.size()) == hipSuccess &&
@@ -224,7 +228,7 @@ void lcs_destroy(lcs_ctx *c) {
                   c->incoh, c->sref, c->pow_, c->work, c->spinc, c->zth, c->sp, c->frq, c->peaks, c->npeaks, c->xc,
                   c->work_items, c->n_work, c->tfg, c->tfg_comp, c->ce, c->tfg_ts, c->tfg_ts_comp, c->cell_scratch,
                   c->cells_out, c->d_pss_td, c->d_pss_fd, c->d_sss_fd, c->d_pbch_scr, c->d_derm_inv, c->d_dbg, c->pk_items, c->n_pk,
-                  c->sss_ws};
+                  c->sss_ws, c->d_pn_jump};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   if (c->h_pinned) (void)hipHostFree(c->h_pinned);
   if (c->ev_xc0) (void)hipEventDestroy(c->ev_xc0);
@@ -356,8 +360,7 @@ int lcs_batch_enqueue(lcs_ctx *c, const void *d_capbufs, int fmt, int n_buf, uin
     if ((rc = ensure_percell(c))) return rc;
     if ((rc = lcs_launch_sss_foe(c, n_buf, n_cap, 3.0 /* THRESH2_N_SIGMA, ref src/CellSearch.cpp:528 */, nullptr))) return rc;
     if ((rc = lcs_launch_gather_work(c, n_buf))) return rc;
-    if ((rc = lcs_launch_tfg(c, n_cap, 0))) return rc;
-    if ((rc = lcs_launch_rs_build(c))) return rc;
+    if ((rc = lcs_launch_tfg(c, n_cap, true))) return rc;
     if ((rc = lcs_launch_tfoec(c, 0))) return rc;
     if ((rc = lcs_launch_mib(c, 0))) return rc;
     if ((rc = lcs_launch_scatter_back(c))) return rc;
@@ -491,7 +494,7 @@ int lcs_extract_tfg(lcs_ctx *c, const lcs_cell *cell, const double *capbuf, uint
   int rc;
   if ((rc = upload_cap_and_params(c, capbuf, n_cap, fc_req, fc_prog, fs_prog))) return rc;
   if ((rc = put_single_work_item(c, cell, no))) return rc;
-  if ((rc = lcs_launch_tfg(c, n_cap, 1))) return rc;
+  if ((rc = lcs_launch_tfg(c, n_cap, false))) return rc;
   double oob = 0;
   HIPCHK(c, hipMemcpyAsync(tfg, c->tfg, sizeof(double2) * no * LCS_TFG_NSC, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(tfg_timestamp, c->tfg_ts, sizeof(double) * no, hipMemcpyDeviceToHost, c->stream));
@@ -566,8 +569,7 @@ int lcs_search_capbuf(lcs_ctx *c, const double *capbuf, uint32_t n_cap, const do
   if ((rc = lcs_launch_peak_search(c, 1, geo, std::pow(10.0, -12.0 / 10.0), true))) return rc;
   if ((rc = lcs_launch_sss_foe(c, 1, n_cap, 3.0, nullptr))) return rc;
   if ((rc = lcs_launch_gather_work(c, 1))) return rc;
-  if ((rc = lcs_launch_tfg(c, n_cap, 0))) return rc;
-  if ((rc = lcs_launch_rs_build(c))) return rc;
+  if ((rc = lcs_launch_tfg(c, n_cap, true))) return rc;
   if ((rc = lcs_launch_tfoec(c, 0))) return rc;
   if ((rc = lcs_launch_mib(c, 0))) return rc;
   if ((rc = lcs_launch_scatter_back(c))) return rc;

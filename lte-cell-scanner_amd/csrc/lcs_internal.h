@@ -126,6 +126,7 @@ struct lcs_ctx {
   double2 *d_pss_fd = nullptr;      // [3][62]
   int8_t *d_sss_fd = nullptr;       // [168][3][2][62]
   uint8_t *d_pbch_scr = nullptr;    // [504][1920]
+  uint32_t *d_pn_jump = nullptr;    // [32]: Gold-sequence jump-ahead by 1600 + 208 clocks (lcs_tables::pn_jump_table)
   int16_t *d_derm_inv = nullptr;    // [2][120][16]: for every coded bit (stream*40+col) the rate-matched PBCH bit positions carrying it (ascending, -1 padded)
   double *d_dbg = nullptr;          // debug outputs of the single-cell stage entry points
   bool percell_ready = false;
@@ -156,6 +157,7 @@ void pss_fd(int n_id_2, double *re_im /*62*2*/);
 void pss_td(int n_id_2, double *re_im /*137*2*/);
 void sss_fd(int n_id_1, int n_id_2, int slot_num, int32_t *out /*62*/);
 void lte_pn(uint32_t c_init, uint32_t len, uint8_t *out);
+void pn_jump_table(uint32_t steps, uint32_t out[32]);
 double chi2cdf_inv(double p, double k);
 void pbch_deratematch_map(int n_e, uint8_t *out /*n_e*/);   // ref src/lte_lib.cpp:409-463 via :473-478
 }  // namespace lcs_tables
@@ -176,6 +178,6 @@ int lcs_launch_foe_only(lcs_ctx *c, uint32_t n_cap);
 int lcs_launch_gather_work(lcs_ctx *c, int n_buf);
 int lcs_launch_scatter_back(lcs_ctx *c);
 int lcs_launch_rs_build(lcs_ctx *c);
-int lcs_launch_tfg(lcs_ctx *c, uint32_t n_cap, int n_items /*upper bound*/);
+int lcs_launch_tfg(lcs_ctx *c, uint32_t n_cap, bool with_rs /* also build RS_DL (the fused chain) */);
 int lcs_launch_tfoec(lcs_ctx *c, int n_items);
 int lcs_launch_mib(lcs_ctx *c, int n_items);

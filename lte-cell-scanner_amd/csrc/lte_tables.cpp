@@ -95,6 +95,22 @@ void lte_pn(uint32_t c_init, uint32_t len, uint8_t *out) {
   }
 }
 
+// Jump-ahead table for the Gold generator above.  Both LFSRs are linear over GF(2), so the x2
+// register after `steps` clocks is the XOR of out[b] over the set bits b of its initial value
+// (out[b] = register reached from the unit state 1 << b); out[31] is the x1 register after the
+// same number of clocks from its fixed initial state.  The CRS builder (k_cell_prep) uses it to
+// reach c(2 * 104) of 36.211 6.10.1.1 in 31 XORs instead of 1808 clocks.
+void pn_jump_table(uint32_t steps, uint32_t out[32]) {
+  for (int b = 0; b < 32; ++b) {
+    uint32_t x = (b < 31) ? (1u << b) : 1u;
+    for (uint32_t i = 0; i < steps; ++i) {
+      const uint32_t n = (b < 31) ? (((x >> 3) ^ (x >> 2) ^ (x >> 1) ^ x) & 1u) : (((x >> 3) ^ x) & 1u);
+      x = (x >> 1) | (n << 30);
+    }
+    out[b] = x;
+  }
+}
+
 // Inverse chi-square CDF: x with P(k/2, x/2) = p.  Regularised incomplete gamma through the
 // Legendre continued fraction of the upper tail (all uses have p close to 1), solved with
 // a bracketed secant/bisection in log-space of the tail probability.

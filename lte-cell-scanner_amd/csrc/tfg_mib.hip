@@ -16,12 +16,22 @@
 #define ROWS LCS_TFG_ROWS
 
 // cell_scratch layout (doubles, per work item)
+// Phase timestamps of workgroup (0,0,0) for tuning runs (-DLCS_PHASE_TS); compiled out otherwise.
+#ifdef LCS_PHASE_TS
+__device__ unsigned long long lcs_ph_ts[256];
+#define PH(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) lcs_ph_ts[i] = wall_clock64(); } while (0)
+extern "C" int lcs_debug_phase_ts(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(lcs_ph_ts), sizeof(lcs_ph_ts)); }
+#else
+#define PH(i) do { } while (0)
+#endif
 #define CS_N_OFDM 0
 #define CS_KFACTOR 1
 #define CS_OOB 2
-#define CS_NP 4          // 4 values (stage entry points only; the chain sums CS_NPP)
 #define CS_NRS 8         // 4 values: RS rows per port
-#define CS_NPP 32        // [4 ports][CE_NCHUNK <= 8] partial sums of |filtered - raw|^2
+#define CS_NPP 640       // [4 ports][CE_NCHUNK <= 8] partial sums of |filtered - raw|^2
+#define CS_TF_RES 680    // tfoec: residual_f, k_factor_residual, delay
+#define CS_TF_KRES 681
+#define CS_TF_DELAY 682
 #define CS_CAND 16       // 12 candidates x 4: ok, bits lo (24 bits as double), unused
 #define CS_SHIFT 64      // [140][4] (-1 = no RS)
 #define CS_RS 1024       // [140][12] complex
@@ -92,16 +102,8 @@ __global__ void k_scatter_back(lcs_cell *__restrict__ peaks, const WorkItem *__r
 
 // ------------------------------------------------------------ extract_tfg: timestamps
 // ref :875-889 and the running dft_location of :903-920 (kept sequential: each timestamp is a
-// floating-point running sum).
-__global__ void k_tfg_prep(const lcs_cell *__restrict__ cells, const WorkItem *__restrict__ items,
-                           const int *__restrict__ n_work, const SlotParams *__restrict__ params,
-                           double *__restrict__ ts, double *__restrict__ scratch) {
-  LCS_TAIL_PRIO();
-  const int it = blockIdx.x * blockDim.x + threadIdx.x;
-  if (it >= *n_work) return;
-  const lcs_cell c = cells[it];
-  const SlotParams p = params[items[it].slot];
-  double *sc = scratch + (size_t)it * CS_SIZE;
+// floating-point running sum).  One thread per cell.
+__device__ void tfg_timestamps(const lcs_cell &c, const SlotParams &p, double *t_out, double *sc) {
   const double k_factor = (p.fc_req - c.freq_fine) / p.fc_prog;
   const int n_symb = cell_n_symb(c);
   double loc;
@@ -109,15 +111,16 @@ __global__ void k_tfg_prep(const lcs_cell *__restrict__ cells, const WorkItem *_
   else loc = c.frame_start + 32 * 16 / FS_LTE * p.fs_prog * k_factor;
   if (loc - .01 * p.fs_prog * k_factor > -0.5) loc = loc - .01 * p.fs_prog * k_factor;
   const int n_ofdm = 6 * 10 * 2 * n_symb + 2 * n_symb;
+  const double inc_ext = (128 + 32) * 16 / FS_LTE * p.fs_prog * k_factor;
+  const double inc_10 = (128 + 10) * 16 / FS_LTE * p.fs_prog * k_factor;
+  const double inc_9 = (128 + 9) * 16 / FS_LTE * p.fs_prog * k_factor;
   int sym_num = 0;
-  double *t_out = ts + (size_t)it * ROWS;
   for (int t = 0; t < n_ofdm; ++t) {
     t_out[t] = loc;
-    if (n_symb == 6) loc += (128 + 32) * 16 / FS_LTE * p.fs_prog * k_factor;
+    if (n_symb == 6) loc += inc_ext;
     else {
-      if (sym_num == 6) loc += (128 + 10) * 16 / FS_LTE * p.fs_prog * k_factor;
-      else loc += (128 + 9) * 16 / FS_LTE * p.fs_prog * k_factor;
-      sym_num = d_imod(sym_num + 1, 7);
+      loc += (sym_num == 6) ? inc_10 : inc_9;
+      sym_num = (sym_num == 6) ? 0 : sym_num + 1;
     }
   }
   sc[CS_N_OFDM] = (double)n_ofdm;
@@ -125,108 +128,37 @@ __global__ void k_tfg_prep(const lcs_cell *__restrict__ cells, const WorkItem *_
   sc[CS_OOB] = 0.0;
 }
 
-// ------------------------------------------------------------------ extract_tfg: grid
-// 8 OFDM symbols per workgroup pass: frequency-correct 8x128 samples of the capture buffer into
-// LDS (the reference rotates all 153600 samples per cell, ref :892; only the 854x128 that feed a
-// DFT are touched here, with the same absolute-index phase), direct 72-bin DFT, /sqrt(128),
-// then the sub-sample timing phase ramp (ref :923-931).
-#define TFG_SYM 8            // 8 x 2 KB windows + twiddles = 18 KB of LDS: fits beside the correlation kernel's workgroups
-#define TFG_THREADS 288     // 72 bins x 4 symbol groups
-__global__ __launch_bounds__(TFG_THREADS) void k_tfg(const lcs_cell *__restrict__ cells, const WorkItem *__restrict__ items,
-                                                     const int *__restrict__ n_work, const SlotParams *__restrict__ params,
-                                                     const float2 *__restrict__ cap32,
-                                                     const double2 *__restrict__ cap64, uint32_t n_cap,
-                                                     const double *__restrict__ ts, double *__restrict__ scratch,
-                                                     double2 *__restrict__ tfg) {
+// One two-wave workgroup per cell prepares everything the grid kernels need: the first lane of
+// wave 1 walks the OFDM symbol timestamps (mode bit 0) while lanes 0..59 of wave 0 build the
+// cell's CRS table RS_DL (mode bit 1,
+// ref src/lte_lib.cpp:305-383: values for the 6 centre RBs and the per-port frequency shifts of
+// every (slot, symbol) that carries RS, one Gold sequence per lane).
+__global__ __launch_bounds__(128) void k_cell_prep(const lcs_cell *__restrict__ cells, const WorkItem *__restrict__ items,
+                                                  const int *__restrict__ n_work, const SlotParams *__restrict__ params,
+                                                  const uint32_t *__restrict__ pn_jump, double *__restrict__ ts,
+                                                  double *__restrict__ scratch, int mode) {
   LCS_TAIL_PRIO();
-  __shared__ cd2 W[128];
-  __shared__ cd2 win[TFG_SYM][128];
-  __shared__ int s_loc[TFG_SYM];
   const int tid = threadIdx.x;
-  if (tid < 128) { double s, c; sincospi((double)tid / 64.0, &s, &c); W[tid] = mk(c, -s); }
-  const int nw = *n_work;
-  const int jobs_per_item = (ROWS + TFG_SYM - 1) / TFG_SYM;
-  for (int job = blockIdx.x; job < nw * jobs_per_item; job += gridDim.x) {
-    const int it = job / jobs_per_item, t0 = (job % jobs_per_item) * TFG_SYM;
-    double *sc = scratch + (size_t)it * CS_SIZE;
-    const int n_ofdm = (int)sc[CS_N_OFDM];
-    const double k_factor = sc[CS_KFACTOR];
-    const lcs_cell c = cells[it];
-    const SlotParams p = params[items[it].slot];
-    const CapView cap = cap_view(cap32, cap64, items[it].slot, n_cap);
-    const double *tsi = ts + (size_t)it * ROWS;
-    const double kk = M_PI * (-c.freq_fine) / ((p.fs_prog * k_factor) / 2);
-    __syncthreads();
-    if (tid < TFG_SYM) s_loc[tid] = (t0 + tid < n_ofdm) ? d_round_i(tsi[t0 + tid]) : 0;
-    __syncthreads();
-    for (int e = tid; e < TFG_SYM * 128; e += TFG_THREADS) {
-      const int s = e >> 7, n = e & 127;
-      cd2 v = mk(0, 0);
-      if (t0 + s < n_ofdm) {
-        const long src = (long)s_loc[s] + n;
-        if (src >= 0 && (uint64_t)src < n_cap) {
-          const double2 x = cap_at(cap, (size_t)src);
-          double sn, cs;
-          sincos(kk * (double)src, &sn, &cs);
-          v = cmul(mk(x.x, x.y), mk(cs, sn));
-        } else if (n == 0) sc[CS_OOB] = 1.0;   // the reference would read out of bounds here
-      }
-      win[s][n] = v;
-    }
-    __syncthreads();
-    {
-      // thread = (subcarrier i, symbol group g): symbols g, g+4 share each twiddle read
-      const int i = tid % NSC, g = tid / NSC;
-      const int bin = (i < 36) ? 92 + i : i - 35;
-      cd2 acc[TFG_SYM / 4];
-#pragma unroll
-      for (int q = 0; q < TFG_SYM / 4; ++q) acc[q] = mk(0, 0);
-      for (int n = 0; n < 128; ++n) {
-        const cd2 tw = W[(bin * n) & 127];
-#pragma unroll
-        for (int q = 0; q < TFG_SYM / 4; ++q) acc[q] = cadd(acc[q], cmul(win[g + 4 * q][n], tw));
-      }
-#pragma unroll
-      for (int q = 0; q < TFG_SYM / 4; ++q) {
-        const int t = t0 + g + 4 * q;
-        if (t >= n_ofdm) continue;
-        cd2 a = cdivr(acc[q], sqrt(128.0));
-        const double ideal = tsi[t];
-        const double late = (double)d_round_i(ideal) - ideal;
-        double k_im = -1.0;
-        k_im = k_im * 2; k_im = k_im * M_PI; k_im = k_im * late; k_im = k_im / 128;
-        const double ph = k_im * (double)cn_of(i);
-        a = cmul(a, mk(cos(ph), sin(ph)));
-        st(&tfg[((size_t)it * ROWS + t) * NSC + i], a);
-      }
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------ RS_DL
-// ref src/lte_lib.cpp:305-383: CRS values for the 6 centre RBs and the per-port frequency
-// shifts, for every (slot, symbol) that carries RS.  60 Gold sequences per cell.
-__global__ __launch_bounds__(64) void k_rs_build(const lcs_cell *__restrict__ cells, const int *__restrict__ n_work,
-                                                  double *__restrict__ scratch) {
-  LCS_TAIL_PRIO();
   for (int it = blockIdx.x; it < *n_work; it += gridDim.x) {
     const lcs_cell c = cells[it];
     double *sc = scratch + (size_t)it * CS_SIZE;
+    if ((mode & 1) && tid == 64) tfg_timestamps(c, params[items[it].slot], ts + (size_t)it * ROWS, sc);
+    if (!(mode & 2)) continue;
     const int n_symb = cell_n_symb(c), id = cell_id(c);
-    const int tid = threadIdx.x;
     if (n_symb < 0 || id < 0) continue;
-    for (int e = tid; e < 140 * 4; e += 64) sc[CS_SHIFT + e] = -1.0;
+    if (tid < 64) for (int e = tid; e < 140 * 4; e += 64) sc[CS_SHIFT + e] = -1.0;
     __syncthreads();
     if (tid < 60) {
       const int slot = tid / 3, t = tid % 3;
       const int sym = (t == 2) ? (n_symb - 3) : t;
       const uint32_t n_cp = (c.cp_type == LCS_CP_NORMAL);
       const uint32_t c_init = (1u << 10) * (7 * (slot + 1) + sym + 1) * (2 * id + 1) + 2 * id + n_cp;
-      uint32_t x1 = 1, x2 = c_init & 0x7fffffffu;
-      const int first = 2 * (N_RB_MAXDL - 6);           // bit index of c(2m) for m = 104
+      // registers after Nc + 2 * (N_RB_MAXDL - 6) clocks (bit index of c(2m) for m = 104), by jump-ahead
+      uint32_t x1 = pn_jump[31], x2 = 0;
+      for (int b = 0; b < 31; ++b) if ((c_init >> b) & 1u) x2 ^= pn_jump[b];
       uint32_t bits = 0;                                // c(208..231)
-      for (int i = 0; i < 1600 + first + 24; ++i) {
-        if (i >= 1600 + first) bits |= ((x1 ^ x2) & 1u) << (i - 1600 - first);
+      for (int i = 0; i < 24; ++i) {
+        bits |= ((x1 ^ x2) & 1u) << i;
         const uint32_t n1 = ((x1 >> 3) ^ x1) & 1u;
         const uint32_t n2 = ((x2 >> 3) ^ (x2 >> 2) ^ (x2 >> 1) ^ x2) & 1u;
         x1 = (x1 >> 1) | (n1 << 30);
@@ -253,6 +185,102 @@ __global__ __launch_bounds__(64) void k_rs_build(const lcs_cell *__restrict__ ce
     __syncthreads();
   }
 }
+
+// ------------------------------------------------------------------ extract_tfg: grid
+// 8 OFDM symbols per workgroup pass: frequency-correct 8x128 samples of the capture buffer into
+// LDS (the reference rotates all 153600 samples per cell, ref :892; only the 854x128 that feed a
+// DFT are touched here, with the same absolute-index phase), direct 72-bin DFT, /sqrt(128),
+// then the sub-sample timing phase ramp (ref :923-931).
+#define TFG_SYM 8            // 8 x 2 KB windows + twiddles = 18 KB of LDS: fits beside the correlation kernel's workgroups
+#define TFG_THREADS 144     // 36 +-k bin pairs x 4 symbol groups
+__global__ __launch_bounds__(TFG_THREADS) void k_tfg(const lcs_cell *__restrict__ cells, const WorkItem *__restrict__ items,
+                                                     const int *__restrict__ n_work, const SlotParams *__restrict__ params,
+                                                     const float2 *__restrict__ cap32,
+                                                     const double2 *__restrict__ cap64, uint32_t n_cap,
+                                                     const double *__restrict__ ts, double *__restrict__ scratch,
+                                                     double2 *__restrict__ tfg) {
+  LCS_TAIL_PRIO();
+  __shared__ cd2 W[128];
+  __shared__ cd2 win[TFG_SYM][128];
+  __shared__ int s_loc[TFG_SYM];
+  const int tid = threadIdx.x;
+  if (tid < 128) { double s, c; sincospi((double)tid / 64.0, &s, &c); W[tid] = mk(c, -s); }
+  const int nw = *n_work;
+  const int jobs_per_item = (ROWS + TFG_SYM - 1) / TFG_SYM;
+  for (int job = blockIdx.x; job < nw * jobs_per_item; job += gridDim.x) {
+    const int it = job / jobs_per_item, t0 = (job % jobs_per_item) * TFG_SYM;
+    double *sc = scratch + (size_t)it * CS_SIZE;
+    const int n_ofdm = (int)sc[CS_N_OFDM];
+    const double k_factor = sc[CS_KFACTOR];
+    const lcs_cell c = cells[it];
+    const SlotParams p = params[items[it].slot];
+    const CapView cap = cap_view(cap32, cap64, items[it].slot, n_cap);
+    const double *tsi = ts + (size_t)it * ROWS;
+    // fshift phase pi * (-f) / (fs/2) * n (ref dsp.h:40-53) as sincospi((-f)/(fs/2) * n): the absolute
+    // sample index reaches 153600, far into the slow argument-reduction path of sincos
+    const double kk = (-c.freq_fine) / ((p.fs_prog * k_factor) / 2);
+    __syncthreads();
+    PH(30);
+    if (tid < TFG_SYM) s_loc[tid] = (t0 + tid < n_ofdm) ? d_round_i(tsi[t0 + tid]) : 0;
+    __syncthreads();
+    for (int e = tid; e < TFG_SYM * 128; e += TFG_THREADS) {
+      const int s = e >> 7, n = e & 127;
+      cd2 v = mk(0, 0);
+      if (t0 + s < n_ofdm) {
+        const long src = (long)s_loc[s] + n;
+        if (src >= 0 && (uint64_t)src < n_cap) {
+          const double2 x = cap_at(cap, (size_t)src);
+          double sn, cs;
+          sincospi(kk * (double)src, &sn, &cs);
+          v = cmul(mk(x.x, x.y), mk(cs, sn));
+        } else if (n == 0) sc[CS_OOB] = 1.0;   // the reference would read out of bounds here
+      }
+      win[s][n] = v;
+    }
+    __syncthreads();
+    PH(31);
+    {
+      // thread = (bin pair +-k, symbol group g).  Bins k and 128-k have conjugate twiddles, so the
+      // four real products of x*w serve both: x*w = (p-q, r+t), x*conj(w) = (p+q, t-r) -- the same
+      // roundings as two separate complex multiplies, half the multiplies and twiddle reads.
+      const int k = tid % 36 + 1, g = tid / 36;
+      cd2 accp[TFG_SYM / 4], accm[TFG_SYM / 4];
+#pragma unroll
+      for (int q = 0; q < TFG_SYM / 4; ++q) { accp[q] = mk(0, 0); accm[q] = mk(0, 0); }
+      for (int n = 0; n < 128; ++n) {
+        const cd2 tw = W[(k * n) & 127];
+#pragma unroll
+        for (int q = 0; q < TFG_SYM / 4; ++q) {
+          const cd2 x = win[g + 4 * q][n];
+          const double pp = x.re * tw.re, qq = x.im * tw.im, rr = x.re * tw.im, tt = x.im * tw.re;
+          accp[q] = cadd(accp[q], mk(pp - qq, rr + tt));
+          accm[q] = cadd(accm[q], mk(pp + qq, tt - rr));
+        }
+      }
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+      const int i = half ? 35 + k : 36 - k;          // column of subcarrier +k / -k
+      const cd2 *acc = half ? accp : accm;
+#pragma unroll
+      for (int q = 0; q < TFG_SYM / 4; ++q) {
+        const int t = t0 + g + 4 * q;
+        if (t >= n_ofdm) continue;
+        cd2 a = cdivr(acc[q], sqrt(128.0));
+        const double ideal = tsi[t];
+        const double late = (double)d_round_i(ideal) - ideal;
+        double k_im = -1.0;
+        k_im = k_im * 2; k_im = k_im * M_PI; k_im = k_im * late; k_im = k_im / 128;
+        const double ph = k_im * (double)cn_of(i);
+        a = cmul(a, mk(cos(ph), sin(ph)));
+        st(&tfg[((size_t)it * ROWS + t) * NSC + i], a);
+      }
+      }
+      PH(32);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------ RS_DL accessors (table built by k_cell_prep)
 __device__ __forceinline__ cd2 rs_val(const double *sc, int n_symb, int slot, int sym, int k) {
   const int row = slot * n_symb + sym;
   return mk(sc[CS_RS + (row * 12 + k) * 2], sc[CS_RS + (row * 12 + k) * 2 + 1]);
@@ -262,28 +290,44 @@ __device__ __forceinline__ int rs_shift(const double *sc, int n_symb, int slot, 
 }
 
 // ------------------------------------------------------------------------------ tfoec
+// Two kernels: k_tfoec_est (one workgroup per cell) runs the two reductions -- the super-fine
+// frequency estimate over the raw grid and the timing estimate over the frequency-corrected RS
+// positions, correcting just those ~11k samples on the fly -- and k_tfoec_apply applies both
+// corrections to the whole 854x72 grid with every element independent (grid = cells x row tiles).
+// The value written for an element is (tfg * rot_f) * rot_late, then * rot_delay: the reference's
+// order of the three complex products (ref :992-1005, :1061-1064).
+__device__ __forceinline__ cd2 foc_value(const double2 *g, int t, int i, double ts_t, double k_res, double residual_f) {
+  const double tc = k_res * ts_t;
+  double a_im = 1.0;
+  a_im = a_im * 2; a_im = a_im * M_PI; a_im = a_im * (-residual_f); a_im = a_im * tc; a_im = a_im / (FS_LTE / 16);
+  const double late = ts_t - tc;
+  double k_im = -1.0;
+  k_im = k_im * 2; k_im = k_im * M_PI; k_im = k_im * late; k_im = k_im / 128;
+  const double ph = k_im * (double)cn_of(i);
+  const cd2 v = cmul(ld(&g[(size_t)t * NSC + i]), mk(cos(a_im), sin(a_im)));
+  return cmul(v, mk(cos(ph), sin(ph)));
+}
+
 #define TF_THREADS 512
-__global__ __launch_bounds__(TF_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_tfoec(lcs_cell *__restrict__ cells, const WorkItem *__restrict__ items,
-                                                       const int *__restrict__ n_work,
-                                                       const SlotParams *__restrict__ params,
-                                                       const double2 *__restrict__ tfg, const double *__restrict__ ts,
-                                                       double *__restrict__ scratch, double2 *__restrict__ tfg_comp,
-                                                       double *__restrict__ ts_comp) {
+__global__ __launch_bounds__(TF_THREADS) void k_tfoec_est(lcs_cell *__restrict__ cells, const WorkItem *__restrict__ items,
+                                                          const int *__restrict__ n_work,
+                                                          const SlotParams *__restrict__ params,
+                                                          const double2 *__restrict__ tfg, const double *__restrict__ ts,
+                                                          double *__restrict__ scratch, double *__restrict__ ts_comp) {
   LCS_TAIL_PRIO();
   __shared__ cd2 red[TF_THREADS / 64];
-  __shared__ cd2 comp[NSC];
   const int tid = threadIdx.x;
   for (int it = blockIdx.x; it < *n_work; it += gridDim.x) {
     const lcs_cell c = cells[it];
     const SlotParams p = params[items[it].slot];
-    const double *sc = scratch + (size_t)it * CS_SIZE;
+    double *sc = scratch + (size_t)it * CS_SIZE;
     const int n_symb = cell_n_symb(c);
     const int n_ofdm = (int)sc[CS_N_OFDM];
     const int n_slot = n_ofdm / n_symb;
     const double2 *g = tfg + (size_t)it * ROWS * NSC;
-    double2 *gc = tfg_comp + (size_t)it * ROWS * NSC;
     const double *tsi = ts + (size_t)it * ROWS;
     double *tsc = ts_comp + (size_t)it * ROWS;
+    PH(10);
     // super-fine FOE (ref :970-989)
     cd2 part = mk(0, 0);
     for (int e = tid; e < 2 * 12 * (n_slot - 1); e += TF_THREADS) {
@@ -295,25 +339,12 @@ __global__ __launch_bounds__(TF_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8
       part = cadd(part, cmul(cconj(a), b));
     }
     const cd2 foe = block_sum(part, red);
+    PH(11);
     const double residual_f = atan2(foe.im, foe.re) / (2 * M_PI) / 0.0005;
     const double k_res = (p.fc_req - residual_f) / p.fc_prog;
-    // FOC + timing phase ramp (ref :992-1005)
     for (int t = tid; t < n_ofdm; t += TF_THREADS) tsc[t] = k_res * tsi[t];
-    __syncthreads();
-    for (int e = tid; e < n_ofdm * NSC; e += TF_THREADS) {
-      const int t = e / NSC, i = e % NSC;
-      const double tc = k_res * tsi[t];
-      double a_im = 1.0;
-      a_im = a_im * 2; a_im = a_im * M_PI; a_im = a_im * (-residual_f); a_im = a_im * tc; a_im = a_im / (FS_LTE / 16);
-      const double late = tsi[t] - tc;
-      double k_im = -1.0;
-      k_im = k_im * 2; k_im = k_im * M_PI; k_im = k_im * late; k_im = k_im / 128;
-      const double ph = k_im * (double)cn_of(i);
-      const cd2 v = cmul(ld(&g[e]), mk(cos(a_im), sin(a_im)));
-      st(&gc[e], cmul(v, mk(cos(ph), sin(ph))));
-    }
-    __syncthreads();
-    // TOE (ref :1012-1058)
+    // TOE (ref :1012-1058) on the frequency-corrected RS samples
+#define GC(row, col) foc_value(g, (row), (col), tsi[(row)], k_res, residual_f)
     part = mk(0, 0);
     for (int e = tid; e < (2 * n_slot - 1) * 23; e += TF_THREADS) {
       const int t = e / 23, j = e % 23;
@@ -325,28 +356,63 @@ __global__ __launch_bounds__(TF_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8
       if (cur_sh < nxt_sh) { r1_off = cur_off; r1_sh = cur_sh; r1_sym = cur_sym; r1_slot = cur_slot; r2_off = nxt_off; r2_sh = nxt_sh; r2_sym = nxt_sym; r2_slot = nxt_slot; }
       else { r1_off = nxt_off; r1_sh = nxt_sh; r1_sym = nxt_sym; r1_slot = nxt_slot; r2_off = cur_off; r2_sh = cur_sh; r2_sym = cur_sym; r2_slot = cur_slot; }
       if (j < 12) {   // toe1: conj(r1v[j]) * r2v[j]
-        const cd2 r1 = cmul(ld(&gc[(size_t)r1_off * NSC + r1_sh + 6 * j]), cconj(rs_val(sc, n_symb, r1_slot, r1_sym, j)));
-        const cd2 r2 = cmul(ld(&gc[(size_t)r2_off * NSC + r2_sh + 6 * j]), cconj(rs_val(sc, n_symb, r2_slot, r2_sym, j)));
+        const cd2 r1 = cmul(GC(r1_off, r1_sh + 6 * j), cconj(rs_val(sc, n_symb, r1_slot, r1_sym, j)));
+        const cd2 r2 = cmul(GC(r2_off, r2_sh + 6 * j), cconj(rs_val(sc, n_symb, r2_slot, r2_sym, j)));
         part = cadd(part, cmul(cconj(r1), r2));
       } else {        // toe2: conj(r2v[i]) * r1v[i+1], i = 0..10
         const int i = j - 12;
-        const cd2 r2 = cmul(ld(&gc[(size_t)r2_off * NSC + r2_sh + 6 * i]), cconj(rs_val(sc, n_symb, r2_slot, r2_sym, i)));
-        const cd2 r1 = cmul(ld(&gc[(size_t)r1_off * NSC + r1_sh + 6 * (i + 1)]), cconj(rs_val(sc, n_symb, r1_slot, r1_sym, i + 1)));
+        const cd2 r2 = cmul(GC(r2_off, r2_sh + 6 * i), cconj(rs_val(sc, n_symb, r2_slot, r2_sym, i)));
+        const cd2 r1 = cmul(GC(r1_off, r1_sh + 6 * (i + 1)), cconj(rs_val(sc, n_symb, r1_slot, r1_sym, i + 1)));
         part = cadd(part, cmul(cconj(r2), r1));
       }
     }
+#undef GC
     const cd2 toe = block_sum(part, red);
-    const double delay = -atan2(toe.im, toe.re) / 3 / (2 * M_PI / 128);
-    if (tid < NSC) {
-      double k_im = 1.0;
-      k_im = k_im * 2; k_im = k_im * M_PI; k_im = k_im / 128; k_im = k_im * delay;
-      const double ph = k_im * (double)cn_of(tid);
-      comp[tid] = mk(cos(ph), sin(ph));
+    PH(13);
+    if (tid == 0) {
+      sc[CS_TF_RES] = residual_f;
+      sc[CS_TF_KRES] = k_res;
+      sc[CS_TF_DELAY] = -atan2(toe.im, toe.re) / 3 / (2 * M_PI / 128);
+      cells[it].freq_superfine = c.freq_fine + residual_f;
     }
     __syncthreads();
-    for (int e = tid; e < n_ofdm * NSC; e += TF_THREADS) st(&gc[e], cmul(ld(&gc[e]), comp[e % NSC]));
-    if (tid == 0) cells[it].freq_superfine = c.freq_fine + residual_f;
-    __syncthreads();
+    PH(14);
+  }
+}
+
+#define TFA_ROWS 8
+#define TFA_THREADS 192
+__global__ __launch_bounds__(TFA_THREADS) void k_tfoec_apply(const int *__restrict__ n_work, const double2 *__restrict__ tfg,
+                                                             const double *__restrict__ ts, const double *__restrict__ scratch,
+                                                             double2 *__restrict__ tfg_comp) {
+  LCS_TAIL_PRIO();
+  __shared__ cd2 comp[NSC];
+  const int tid = threadIdx.x;
+  const int tiles = (ROWS + TFA_ROWS - 1) / TFA_ROWS;
+  int comp_it = -1;
+  for (int job = blockIdx.x; job < *n_work * tiles; job += gridDim.x) {
+    const int it = job / tiles, t0 = (job % tiles) * TFA_ROWS;
+    const double *sc = scratch + (size_t)it * CS_SIZE;
+    const int n_ofdm = (int)sc[CS_N_OFDM];
+    const double residual_f = sc[CS_TF_RES], k_res = sc[CS_TF_KRES], delay = sc[CS_TF_DELAY];
+    const double2 *g = tfg + (size_t)it * ROWS * NSC;
+    double2 *gc = tfg_comp + (size_t)it * ROWS * NSC;
+    const double *tsi = ts + (size_t)it * ROWS;
+    if (it != comp_it) {     // per-subcarrier rotation of the timing correction (ref :1061-1064)
+      __syncthreads();
+      if (tid < NSC) {
+        double k_im = 1.0;
+        k_im = k_im * 2; k_im = k_im * M_PI; k_im = k_im / 128; k_im = k_im * delay;
+        const double ph = k_im * (double)cn_of(tid);
+        comp[tid] = mk(cos(ph), sin(ph));
+      }
+      __syncthreads();
+      comp_it = it;
+    }
+    for (int e = tid; e < TFA_ROWS * NSC; e += TFA_THREADS) {
+      const int t = t0 + e / NSC, i = e % NSC;
+      if (t < n_ofdm) st(&gc[(size_t)t * NSC + i], cmul(foc_value(g, t, i, tsi[t], k_res, residual_f), comp[i]));
+    }
   }
 }
 
@@ -417,6 +483,15 @@ __device__ __forceinline__ void ext_vertex(const cd2 *row, int s, int i, int &x,
 }
 
 #define CE_THREADS 256
+// RS row list of one port (ref :1383-1392) in closed form: ports 0/1 carry RS in symbols 0 and
+// n_symb-3 of every slot (the sorted union alternates between the two), ports 2/3 in symbol 1.
+__device__ __forceinline__ int ce_rs_row(int port, int n_symb, int t) {
+  return (port <= 1) ? (t >> 1) * n_symb + ((t & 1) ? n_symb - 3 : 0) : 1 + t * n_symb;
+}
+__device__ __forceinline__ int ce_rs_count(int port, int n_symb, int n_ofdm) {
+  if (port <= 1) return (n_ofdm - 1) / n_symb + 1 + ((n_ofdm - 1 >= n_symb - 3) ? (n_ofdm - 1 - (n_symb - 3)) / n_symb + 1 : 0);
+  return (n_ofdm - 1 >= 1) ? (n_ofdm - 2) / n_symb + 1 : 0;
+}
 #define CE_MAX_RS 256
 #define CE_CH 48                                      // RS rows per workgroup: 19 KB of LDS
 #define CE_NCHUNK ((CE_MAX_RS + CE_CH - 1) / CE_CH)   // 6 (scratch holds 8 partials per port)
@@ -426,9 +501,7 @@ __global__ __launch_bounds__(CE_THREADS) void k_chan_est(const lcs_cell *__restr
   LCS_TAIL_PRIO();
   __shared__ cd2 ce_raw[(CE_CH + 3) * 12];     // RS rows r0 .. r1 of this chunk (one halo row each side)
   __shared__ cd2 ce_filt[(CE_CH + 1) * 12];    // RS rows c0 .. f1
-  __shared__ int rs_set[CE_MAX_RS];
   __shared__ cd2 red[CE_THREADS / 64];
-  __shared__ int s_nrs;
   const int tid = threadIdx.x, port = blockIdx.y, chunk = blockIdx.z;
   for (int it = blockIdx.x; it < *n_work; it += gridDim.x) {
     const lcs_cell c = cells[it];
@@ -438,22 +511,12 @@ __global__ __launch_bounds__(CE_THREADS) void k_chan_est(const lcs_cell *__restr
     const double2 *g = tfg_comp + (size_t)it * ROWS * NSC;
     double2 *out = ce + (((size_t)it * 4 + port) * ROWS) * NSC;
     __syncthreads();
-    if (tid == 0) {   // rs_set (ref :1383-1392): sorted union for ports 0/1
-      int n = 0;
-      if (port <= 1) {
-        int a = 0, b = n_symb - 3;
-        while (a <= n_ofdm - 1 || b <= n_ofdm - 1) {
-          if (a <= n_ofdm - 1 && (b > n_ofdm - 1 || a <= b)) { rs_set[n++] = a; a += n_symb; }
-          else { rs_set[n++] = b; b += n_symb; }
-        }
-      } else for (int x = 1; x <= n_ofdm - 1; x += n_symb) rs_set[n++] = x;
-      s_nrs = n;
-    }
-    __syncthreads();
-    const int n_rs = s_nrs;
+#define rs_set(t) ce_rs_row(port, n_symb, (t))
+    const int n_rs = min(ce_rs_count(port, n_symb, n_ofdm), CE_MAX_RS);
     // slot_num advances every 2nd RS row for ports 0/1, every row for ports 2/3 (quirk Q9)
-    const int sh0 = rs_shift(sc, n_symb, 0, d_imod(rs_set[0], n_symb), port);
-    const int sh1 = rs_shift(sc, n_symb, d_imod((port >= 2) ? 1 : 0, 20), d_imod(rs_set[1], n_symb), port);
+    const int sh0 = rs_shift(sc, n_symb, 0, d_imod(rs_set(0), n_symb), port);
+    const int sh1 = rs_shift(sc, n_symb, d_imod((port >= 2) ? 1 : 0, 20), d_imod(rs_set(1), n_symb), port);
+    PH(20);
     // this workgroup: filtered rows and row pairs [c0, c1) of the RS row list
     const int c0 = chunk * CE_CH, c1 = min(n_rs, c0 + CE_CH);
     if (c0 >= n_rs) {
@@ -465,11 +528,12 @@ __global__ __launch_bounds__(CE_THREADS) void k_chan_est(const lcs_cell *__restr
     for (int e = tid; e < (r1 - r0 + 1) * 12; e += CE_THREADS) {
       const int t = r0 + e / 12, i = e % 12;
       const int slot = (port >= 2) ? (t % 20) : ((t >> 1) % 20);
-      const int sym = d_imod(rs_set[t], n_symb);
+      const int sym = d_imod(rs_set(t), n_symb);
       const int sh = rs_shift(sc, n_symb, slot, sym, port);
-      ce_raw[e] = cmul(ld(&g[(size_t)rs_set[t] * NSC + sh + 6 * i]), cconj(rs_val(sc, n_symb, slot, sym, i)));
+      ce_raw[e] = cmul(ld(&g[(size_t)rs_set(t) * NSC + sh + 6 * i]), cconj(rs_val(sc, n_symb, slot, sym, i)));
     }
     __syncthreads();
+    PH(21);
     // 7-point hexagonal mean (ref :1431-1467)
     for (int e = tid; e < (f1 - c0 + 1) * 12; e += CE_THREADS) {
       const int t = c0 + e / 12, k = e % 12;
@@ -493,6 +557,7 @@ __global__ __launch_bounds__(CE_THREADS) void k_chan_est(const lcs_cell *__restr
       ce_filt[e] = cdivr(total, (double)n_total);
     }
     __syncthreads();
+    PH(22);
     // noise power (ref :1470): this chunk's share of sum |filtered - raw|^2; the consumers add the
     // chunk partials in chunk order and divide by 12 n_rs (np_from_partials)
     cd2 part = mk(0, 0);
@@ -505,16 +570,39 @@ __global__ __launch_bounds__(CE_THREADS) void k_chan_est(const lcs_cell *__restr
     // piecewise-planar interpolation between consecutive RS rows (ref :1237-1351): one thread
     // walks the triangle strip of one row pair exactly as the reference does
     if (chunk == 0 && tid < NSC) {   // first RS row: plain 1-D interpolation (ref :1250-1252)
-      double x[16]; cd2 v[16]; int n = 0;
-      for (int xx = sh0; xx <= 71; xx += 6) { x[n] = xx; v[n] = ce_filt[n]; ++n; }
-      n = hex_extend(x, v, n);
-      st(&out[(size_t)rs_set[0] * NSC + tid], interp1_c(x, v, n, (double)tid));
+      // interp1 (ref dsp.h:151-185: bisection with round_i midpoint, linear, extrapolating) over the
+      // edge-extended row, vertices fetched through ext_vertex instead of materialised arrays
+      const int n = ext_len(sh0);
+      const double x = (double)tid;
+      unsigned l = 0, r = (unsigned)n - 1;
+      int xm; cd2 vm;
+      while (r - l > 1) {
+        const unsigned mid = (unsigned)d_round_i((r + l) / 2.0);
+        ext_vertex(ce_filt, sh0, (int)mid, xm, vm);
+        if (x >= (double)xm) l = mid; else r = mid;
+      }
+      int xl, xr; cd2 vl, vr;
+      ext_vertex(ce_filt, sh0, (int)l, xl, vl);
+      ext_vertex(ce_filt, sh0, (int)r, xr, vr);
+      const cd2 d = csub(vr, vl);
+      st(&out[(size_t)rs_set(0) * NSC + tid], cadd(vl, cdivr(cscale(d, (x - (double)xl)), ((double)xr - (double)xl))));
     }
-    for (int t = c0 + tid; t < c1 && t <= n_rs - 2; t += CE_THREADS) {
+    PH(23);
+    // One thread per OUTPUT ROW between the chunk's first and last RS row: it replays the triangle
+    // strip of its row pair exactly as the reference does (same vertex order, same boundary test)
+    // but only emits its own row.  The reference's early exit looks at rows 1 and `spacing` of the
+    // pair; their column counters are advanced too (closed form of the same while loop).
+    const int y_first = rs_set(c0), y_last = rs_set(min(c1, n_rs - 1));
+    for (int yy = y_first + 1 + tid; yy <= y_last; yy += CE_THREADS) {
+      int t;
+      if (port <= 1) {
+        const int j = yy / n_symb, rem = yy - j * n_symb;
+        t = (rem == 0) ? 2 * j - 1 : (rem <= n_symb - 3 ? 2 * j : 2 * j + 1);
+      } else t = (yy - 2) / n_symb;
       const int s_top = (t & 1) ? sh1 : sh0, s_bot = (t & 1) ? sh0 : sh1;
       const cd2 *top = ce_filt + (t - c0) * 12, *bot = ce_filt + (t + 1 - c0) * 12;
       const int n_top = ext_len(s_top), n_bot = ext_len(s_bot);
-      const int y_top = rs_set[t], y_bot = rs_set[t + 1];
+      const int y_top = rs_set(t), y_bot = rs_set(t + 1);
       int tx[3], ty[3]; cd2 tv[3];
       int top_last, bot_last, x1t, x1b; cd2 dummy;
       ext_vertex(top, s_top, 1, x1t, dummy);
@@ -531,34 +619,31 @@ __global__ __launch_bounds__(CE_THREADS) void k_chan_est(const lcs_cell *__restr
         top_last = 0; bot_last = 1;
       }
       const int spacing = y_bot - y_top;
-      int x_off[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) x_off[i] = 0;
+      int x_mine = 0, x_r1 = 0, x_rs = 0;
       for (int guard = 0; guard < 64; ++guard) {
-        // plane through the three vertices (the reference solves the 3x3 system with a LAPACK
-        // inverse, ref :1293-1312; same plane, rounding differs at the 1e-14 level)
-        const double dx1 = tx[1] - tx[0], dy1 = ty[1] - ty[0], dx2 = tx[2] - tx[0], dy2 = ty[2] - ty[0];
-        const double det = dx1 * dy2 - dx2 * dy1;
-        const cd2 d1 = csub(tv[1], tv[0]), d2 = csub(tv[2], tv[0]);
-        const cd2 a_p = cdivr(csub(cscale(d1, dy2), cscale(d2, dy1)), det);
-        const cd2 b_p = cdivr(csub(cscale(d2, dx1), cscale(d1, dx2)), det);
         const double x1 = tx[1], x2 = tx[2], y1 = ty[1], y2 = ty[2];
         const double a_l = (x1 - x2) / (y1 - y2);
         const double b_l = (y1 * x2 - y2 * x1) / (y1 - y2);
-#pragma unroll
-        for (int r = 1; r <= 7; ++r) {
-          if (r <= spacing) {
-            while ((double)x_off[r] <= a_l * (y_top + r) + b_l) {
-              const cd2 v = cadd(cadd(tv[0], cscale(a_p, (double)(x_off[r] - tx[0]))), cscale(b_p, (double)(y_top + r - ty[0])));
-              if (x_off[r] <= 71) st(&out[(size_t)(y_top + r) * NSC + x_off[r]], v);
-              ++x_off[r];
-            }
+        if ((double)x_mine <= a_l * yy + b_l) {
+          // plane through the three vertices (the reference solves the 3x3 system with a LAPACK
+          // inverse, ref :1293-1312; same plane, rounding differs at the 1e-14 level)
+          const double dx1 = tx[1] - tx[0], dy1 = ty[1] - ty[0], dx2 = tx[2] - tx[0], dy2 = ty[2] - ty[0];
+          const double det = dx1 * dy2 - dx2 * dy1;
+          const cd2 d1 = csub(tv[1], tv[0]), d2 = csub(tv[2], tv[0]);
+          const cd2 a_p = cdivr(csub(cscale(d1, dy2), cscale(d2, dy1)), det);
+          const cd2 b_p = cdivr(csub(cscale(d2, dx1), cscale(d1, dx2)), det);
+          while ((double)x_mine <= a_l * yy + b_l) {
+            const cd2 v = cadd(cadd(tv[0], cscale(a_p, (double)(x_mine - tx[0]))), cscale(b_p, (double)(yy - ty[0])));
+            if (x_mine <= 71) st(&out[(size_t)yy * NSC + x_mine], v);
+            ++x_mine;
           }
         }
-        bool done = (x_off[1] == 72);
-#pragma unroll
-        for (int r = 1; r <= 7; ++r) if (r == spacing) done = done && (x_off[r] == 72);
-        if (done) break;
+        {   // while ((double)x <= bound) ++x  ==  x = max(x, floor(bound) + 1)
+          const double bd1 = a_l * (y_top + 1) + b_l, bds = a_l * (y_top + spacing) + b_l;
+          if ((double)x_r1 <= bd1) x_r1 = (int)floor(bd1) + 1;
+          if ((double)x_rs <= bds) x_rs = (int)floor(bds) + 1;
+        }
+        if (x_r1 == 72 && x_rs == 72) break;
         tx[0] = tx[1]; ty[0] = ty[1]; tv[0] = tv[1]; tx[1] = tx[2]; ty[1] = ty[2]; tv[1] = tv[2];
         if (ty[1] == y_top) {
           ++bot_last;
@@ -572,9 +657,10 @@ __global__ __launch_bounds__(CE_THREADS) void k_chan_est(const lcs_cell *__restr
       }
     }
     __syncthreads();
+    PH(24);
     // rows outside the RS span copy the nearest RS row (ref :1356-1361)
     // (the first RS row is written by chunk 0, the last one by the chunk that owns the last row pair)
-    const int first = rs_set[0], last = rs_set[n_rs - 1];
+    const int first = rs_set(0), last = rs_set(n_rs - 1);
     if (chunk == 0)
       for (int e = tid; e < first * NSC; e += CE_THREADS) out[e] = out[(size_t)first * NSC + e % NSC];
     if (c1 >= n_rs - 1 && c0 <= max(n_rs - 2, 0))
@@ -582,6 +668,8 @@ __global__ __launch_bounds__(CE_THREADS) void k_chan_est(const lcs_cell *__restr
     __syncthreads();
   }
 }
+
+#undef rs_set
 
 // sigpower(filtered - raw) of one port from k_chan_est's per-chunk partial sums (ref :1470)
 __device__ __forceinline__ double np_from_partials(const double *sc, int port) {
@@ -602,14 +690,14 @@ __device__ __forceinline__ double trunc_log(double x) {     // itpp::trunc_log
   if (x <= 0) return log(2.22507385850720138309e-308);
   return log(x);
 }
-__global__ __launch_bounds__(PB_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_pbch(const lcs_cell *__restrict__ cells, const int *__restrict__ n_work,
+__global__ __launch_bounds__(PB_THREADS) void k_pbch(const lcs_cell *__restrict__ cells, const int *__restrict__ n_work,
                                                       const double2 *__restrict__ tfg_comp, const double2 *__restrict__ ce,
                                                       double *__restrict__ scratch, const uint8_t *__restrict__ pbch_scr,
                                                       const int16_t *__restrict__ derm_inv /*[2][120][16]*/) {
   LCS_TAIL_PRIO();
   __shared__ double e_est[1920];
   __shared__ double d_est[3][40];
-  __shared__ unsigned long long surv[PB_WAVES][40], best_surv[PB_WAVES][40];
+  __shared__ unsigned long long best_surv[PB_WAVES][40];
   __shared__ double w_best[PB_WAVES];
   __shared__ int w_best_ss[PB_WAVES];
   __shared__ unsigned char c_est[40];
@@ -628,6 +716,7 @@ __global__ __launch_bounds__(PB_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8
     const double np0 = np_from_partials(sc, 0), np1 = np_from_partials(sc, 1), np2 = np_from_partials(sc, 2), np3 = np_from_partials(sc, 3);
     const int start = guess * 10 * 2 * n_symb;
     __syncthreads();
+    PH(0);
     // pbch_extract (ref :1503-1520) + equalisation (ref :1571-1612), one symbol pair per thread
     for (int pr = tid; pr < n_sym / 2; pr += PB_THREADS) {
       cd2 x[2], h[4][2], syms[2];
@@ -689,6 +778,7 @@ __global__ __launch_bounds__(PB_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8
       }
     }
     __syncthreads();
+    PH(1);
     // de-ratematch: average all observations of each coded bit (ref src/lte_lib.cpp:497-509)
     if (tid < 120) {
       const int16_t *lst = derm_inv + ((m_bit == 1920) ? 0 : 120 * 16) + tid * 16;   // ascending bit positions
@@ -698,37 +788,51 @@ __global__ __launch_bounds__(PB_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8
       d_est[tid / 40][tid % 40] = s;
     }
     __syncthreads();
+    PH(2);
     // tail-biting Viterbi, K=7, G=(133,171,165)o: one trellis per start state with the end state
     // forced equal; lane = trellis state, each of the 16 waves takes 4 start states.
     {
+      // each wave runs its 64 / PB_WAVES start states TOGETHER: the trellises are independent, so
+      // their shuffle -> add -> compare chains overlap instead of running back to back.  Lane t
+      // keeps the survivor word of step t for every trellis of the wave in registers.
       const int wave = tid >> 6, s = tid & 63;
-      double wbest = INFINITY; int wbest_ss = -1;
-      for (int q = 0; q < 64 / PB_WAVES; ++q) {
-        const int ss = wave * (64 / PB_WAVES) + q;
-        double pm = (s == ss) ? 0.0 : INFINITY;
-        for (int t = 0; t < 40; ++t) {
-          // new state s <- predecessors p0 = (s<<1)&63, p1 = p0|1 with input bit b = s>>5
-          const int b = s >> 5, p0 = (s << 1) & 63, p1 = p0 | 1;
-          const double pm0 = __shfl(pm, p0), pm1 = __shfl(pm, p1);
-          const int reg0 = (b << 6) | p0, reg1 = (b << 6) | p1;
-          double m0 = pm0, m1 = pm1;
-          const double rr0 = d_est[0][t], rr1 = d_est[1][t], rr2 = d_est[2][t];
-          m0 += (__popc(reg0 & 0133) & 1) ? rr0 : -rr0; m0 += (__popc(reg0 & 0171) & 1) ? rr1 : -rr1; m0 += (__popc(reg0 & 0165) & 1) ? rr2 : -rr2;
-          m1 += (__popc(reg1 & 0133) & 1) ? rr0 : -rr0; m1 += (__popc(reg1 & 0171) & 1) ? rr1 : -rr1; m1 += (__popc(reg1 & 0165) & 1) ? rr2 : -rr2;
+      constexpr int NQ = 64 / PB_WAVES;
+      const int b = s >> 5, p0 = (s << 1) & 63, p1 = p0 | 1;       // new state s <- predecessors p0, p1 with input bit b
+      const int reg0 = (b << 6) | p0, reg1 = (b << 6) | p1;
+      const bool a00 = __popc(reg0 & 0133) & 1, a01 = __popc(reg0 & 0171) & 1, a02 = __popc(reg0 & 0165) & 1;
+      const bool a10 = __popc(reg1 & 0133) & 1, a11 = __popc(reg1 & 0171) & 1, a12 = __popc(reg1 & 0165) & 1;
+      double pm[NQ];
+      unsigned long long my_surv[NQ];
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) { pm[q] = (s == wave * NQ + q) ? 0.0 : INFINITY; my_surv[q] = 0ull; }
+      for (int t = 0; t < 40; ++t) {
+        const double rr0 = d_est[0][t], rr1 = d_est[1][t], rr2 = d_est[2][t];
+        const double c00 = a00 ? rr0 : -rr0, c01 = a01 ? rr1 : -rr1, c02 = a02 ? rr2 : -rr2;
+        const double c10 = a10 ? rr0 : -rr0, c11 = a11 ? rr1 : -rr1, c12 = a12 ? rr2 : -rr2;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          double m0 = __shfl(pm[q], p0), m1 = __shfl(pm[q], p1);
+          m0 += c00; m0 += c01; m0 += c02;
+          m1 += c10; m1 += c11; m1 += c12;
           const bool take1 = m1 < m0;          // ties keep the lower-numbered predecessor
-          pm = take1 ? m1 : m0;
+          pm[q] = take1 ? m1 : m0;
           const unsigned long long bal = __ballot(take1);
-          if (s == 0) surv[wave][t] = bal;
-        }
-        const double fin = __shfl(pm, ss);
-        if (fin < wbest) {
-          wbest = fin; wbest_ss = ss;
-          if (s < 40) best_surv[wave][s] = surv[wave][s];
+          if (s == t) my_surv[q] = bal;
         }
       }
+      double wbest = INFINITY; int wbest_ss = -1;
+      unsigned long long keep = 0ull;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {         // start states in ascending order, strict < : first best wins
+        const int ss = wave * NQ + q;
+        const double fin = __shfl(pm[q], ss);
+        if (fin < wbest) { wbest = fin; wbest_ss = ss; keep = my_surv[q]; }
+      }
+      if (s < 40) best_surv[wave][s] = keep;
       if (s == 0) { w_best[wave] = wbest; w_best_ss[wave] = wbest_ss; }
     }
     __syncthreads();
+    PH(3);
     if (tid == 0) {
       int bw = 0;
       for (int w = 1; w < PB_WAVES; ++w) if (w_best[w] < w_best[bw]) bw = w;
@@ -759,6 +863,7 @@ __global__ __launch_bounds__(PB_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8
       sc[CS_CAND + cand * 4 + 1] = (double)bits24;
     }
     __syncthreads();
+    PH(4);
   }
 }
 
@@ -789,7 +894,7 @@ __global__ void k_mib_select(lcs_cell *__restrict__ cells, const int *__restrict
 }
 
 // ------------------------------------------------------------------------------ launch
-#define GRID_ITEMS 256
+#define GRID_ITEMS 64       // workgroups loop over the work list: enough for a typical batch in one round
 int lcs_launch_gather_work(lcs_ctx *c, int n_buf) {
   hipLaunchKernelGGL(k_gather_work, dim3(1), dim3(64), 0, c->stream, c->peaks, c->npeaks, n_buf, c->work_items, c->n_work,
                      c->cells_out);
@@ -802,24 +907,26 @@ int lcs_launch_scatter_back(lcs_ctx *c) {
   HIPCHK(c, hipGetLastError());
   return LCS_OK;
 }
-int lcs_launch_tfg(lcs_ctx *c, uint32_t n_cap, int n_items) {
-  (void)n_items;
-  hipLaunchKernelGGL(k_tfg_prep, dim3((LCS_MAX_WORK + 63) / 64), dim3(64), 0, c->stream, c->cells_out, c->work_items,
-                     c->n_work, c->params, c->tfg_ts, c->cell_scratch);
-  hipLaunchKernelGGL(k_tfg, dim3(2048), dim3(TFG_THREADS), 0, c->stream, c->cells_out, c->work_items, c->n_work, c->params,
+int lcs_launch_tfg(lcs_ctx *c, uint32_t n_cap, bool with_rs) {
+  hipLaunchKernelGGL(k_cell_prep, dim3(GRID_ITEMS), dim3(128), 0, c->stream, c->cells_out, c->work_items, c->n_work, c->params,
+                     c->d_pn_jump, c->tfg_ts, c->cell_scratch, with_rs ? 3 : 1);
+  hipLaunchKernelGGL(k_tfg, dim3(4096), dim3(TFG_THREADS), 0, c->stream, c->cells_out, c->work_items, c->n_work, c->params,
                      c->cap32, c->cap64_valid ? c->cap64 : nullptr, n_cap, c->tfg_ts, c->cell_scratch, c->tfg);
   HIPCHK(c, hipGetLastError());
   return LCS_OK;
 }
 int lcs_launch_rs_build(lcs_ctx *c) {
-  hipLaunchKernelGGL(k_rs_build, dim3(GRID_ITEMS), dim3(64), 0, c->stream, c->cells_out, c->n_work, c->cell_scratch);
+  hipLaunchKernelGGL(k_cell_prep, dim3(GRID_ITEMS), dim3(128), 0, c->stream, c->cells_out, c->work_items, c->n_work, c->params,
+                     c->d_pn_jump, c->tfg_ts, c->cell_scratch, 2);
   HIPCHK(c, hipGetLastError());
   return LCS_OK;
 }
 int lcs_launch_tfoec(lcs_ctx *c, int n_items) {
   (void)n_items;
-  hipLaunchKernelGGL(k_tfoec, dim3(GRID_ITEMS), dim3(TF_THREADS), 0, c->stream, c->cells_out, c->work_items, c->n_work,
-                     c->params, c->tfg, c->tfg_ts, c->cell_scratch, c->tfg_comp, c->tfg_ts_comp);
+  hipLaunchKernelGGL(k_tfoec_est, dim3(GRID_ITEMS), dim3(TF_THREADS), 0, c->stream, c->cells_out, c->work_items, c->n_work,
+                     c->params, c->tfg, c->tfg_ts, c->cell_scratch, c->tfg_ts_comp);
+  hipLaunchKernelGGL(k_tfoec_apply, dim3(2048), dim3(TFA_THREADS), 0, c->stream, c->n_work, c->tfg, c->tfg_ts, c->cell_scratch,
+                     c->tfg_comp);
   HIPCHK(c, hipGetLastError());
   return LCS_OK;
 }
