@@ -3,8 +3,9 @@
 
 A "step" is one pass of the chain over one batch of synthetic 153600-sample, 1.92 Msps
 capture buffers that are ALREADY RESIDENT IN HBM when the timed region starts.  N=1 workload =
-BASELINE.json configs[1]/[2]: PSS correlation over the full +-100 ppm grid at 739 MHz
-(n_f = 31) + peak_search (+ the per-cell stages when --stage full).  With --gpus N (launched
+BASELINE.json configs[2], the metric's "full CellSearch": PSS correlation over the full +-100 ppm
+grid at 739 MHz (n_f = 31), peak_search and every per-cell stage down to the decoded MIB
+(--stage pss stops after peak_search = configs[1]).  With --gpus N (launched
 by torch.distributed.run, one rank per GPU) every rank processes its own shard of buffers
 (weak scaling, no data-path collective) and the detected-cell lists are all-gathered with
 RCCL once per step.
@@ -99,9 +100,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="capture buffers per step per GPU")
     ap.add_argument("--ppm", type=float, default=100.0)
-    ap.add_argument("--stage", choices=["pss", "full"], default="pss")
+    ap.add_argument("--stage", choices=["pss", "full"], default="full",
+                    help="full = BASELINE configs[2], the whole CellSearch chain (default); pss = configs[1], xcorr_pss + peak_search only")
     ap.add_argument("--variant", type=int, default=0, help="PSS correlation kernel: 0 = default MFMA-f32 kernel, 1 = VALU twin, 2..7 tuning variants")
-    ap.add_argument("--pipeline", type=int, default=2,
+    ap.add_argument("--pipeline", type=int, default=3,
                     help="contexts (streams + workspaces) used round-robin: with 2, the latency-bound per-cell "
                          "stages of step i overlap the PSS correlation of step i+1")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -763,10 +763,10 @@ int lcs_launch_xcorr(lcs_ctx *c, int n_buf, const XcGeom &geo, bool want_incoh, 
   const int n8 = (n_buf >= 8) ? (n_buf & ~7) : 0;
   // main stream -> correlation stream hand-off (tables and fp32 buffer are ready)
   static const bool single_stream = getenv("LCS_SINGLE_STREAM") != nullptr;   // measurement knob
-  // Extra dynamic LDS per correlation workgroup: 29 KB + 4 KB caps residency at 4 workgroups per CU
-  // (costs 0.3 % of the kernel) and leaves 30 KB of LDS, 4 wave slots per SIMD and 288 VGPRs per lane
-  // free, enough to place any of the small kernels of the neighbouring batches on every CU.
-  static const int lds_pad = getenv("LCS_XC_LDS_PAD") ? atoi(getenv("LCS_XC_LDS_PAD")) : 4096;
+  // Tuning knob: extra dynamic LDS per correlation workgroup lowers its residency (106 VGPRs already
+  // cap it at 4 workgroups per CU; 12288 -> 3 per CU, +1 % kernel time) to leave room for the small
+  // kernels of the neighbouring batches.  Measured: no net gain, so the default is 0.
+  static const int lds_pad = getenv("LCS_XC_LDS_PAD") ? atoi(getenv("LCS_XC_LDS_PAD")) : 0;
   hipStream_t sxc = single_stream ? c->stream : c->stream_xc;
   if (!single_stream) {
     HIPCHK(c, hipEventRecord(c->ev_pre, c->stream));

@@ -308,7 +308,7 @@ __device__ __forceinline__ cd2 foc_value(const double2 *g, int t, int i, double 
   return cmul(v, mk(cos(ph), sin(ph)));
 }
 
-#define TF_THREADS 512
+#define TF_THREADS 256     // one wave per SIMD: placeable beside the correlation kernel (VGPR budget)
 __global__ __launch_bounds__(TF_THREADS) void k_tfoec_est(lcs_cell *__restrict__ cells, const WorkItem *__restrict__ items,
                                                           const int *__restrict__ n_work,
                                                           const SlotParams *__restrict__ params,
@@ -680,17 +680,17 @@ __device__ __forceinline__ double np_from_partials(const double *sc, int port) {
 
 // ------------------------------------------------------------------------ PBCH decode
 // One workgroup per (cell, candidate): candidate = frame_timing_guess*3 + {1,2,4 ports}.
-// 512 threads and ~21 KB of LDS so the workgroup fits beside the correlation kernel's workgroups:
-// equalised symbols stay in registers (one symbol pair per thread through the soft demodulator),
-// only the 1920 LLRs go through LDS.
-#define PB_THREADS 512
+// 256 threads (one wave per SIMD, < 288 VGPRs) and ~19 KB of LDS so the workgroup can be placed
+// beside the correlation kernel's resident workgroups: equalised symbols stay in registers (symbol
+// pairs go straight through the soft demodulator), only the 1920 LLRs go through LDS.
+#define PB_THREADS 256
 #define PB_WAVES (PB_THREADS / 64)
 __device__ __forceinline__ double trunc_log(double x) {     // itpp::trunc_log
   if (x == INFINITY) return log(1.79769313486231570815e+308);
   if (x <= 0) return log(2.22507385850720138309e-308);
   return log(x);
 }
-__global__ __launch_bounds__(PB_THREADS) void k_pbch(const lcs_cell *__restrict__ cells, const int *__restrict__ n_work,
+__global__ __launch_bounds__(PB_THREADS) __attribute__((amdgpu_waves_per_eu(3, 8))) void k_pbch(const lcs_cell *__restrict__ cells, const int *__restrict__ n_work,
                                                       const double2 *__restrict__ tfg_comp, const double2 *__restrict__ ce,
                                                       double *__restrict__ scratch, const uint8_t *__restrict__ pbch_scr,
                                                       const int16_t *__restrict__ derm_inv /*[2][120][16]*/) {
