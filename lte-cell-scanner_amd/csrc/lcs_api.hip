@@ -163,6 +163,7 @@ int lcs_create(int device, lcs_ctx **out) {
   (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
   if (getenv("LCS_NO_PRIO")) prio_least = prio_greatest = 0;   // measurement knob
   bool ok_streams = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_greatest) == hipSuccess;
+  if (const char *mw = getenv("LCS_MAX_WORK")) c->max_work = std::max(1, std::min(atoi(mw), (int)LCS_MAX_WORK));
   const char *rsv = getenv("LCS_RESERVE_CUS");   // measurement knob: keep N CUs free of the correlation kernel
   if (ok_streams && rsv && atoi(rsv) > 0) {
     hipDeviceProp_t prop;
@@ -359,11 +360,17 @@ int lcs_batch_enqueue(lcs_ctx *c, const void *d_capbufs, int fmt, int n_buf, uin
   if (stage_mask & 2) {
     if ((rc = ensure_percell(c))) return rc;
     if ((rc = lcs_launch_sss_foe(c, n_buf, n_cap, 3.0 /* THRESH2_N_SIGMA, ref src/CellSearch.cpp:528 */, nullptr))) return rc;
-    if ((rc = lcs_launch_gather_work(c, n_buf))) return rc;
-    if ((rc = lcs_launch_tfg(c, n_cap, true))) return rc;
-    if ((rc = lcs_launch_tfoec(c, 0))) return rc;
-    if ((rc = lcs_launch_mib(c, 0))) return rc;
-    if ((rc = lcs_launch_scatter_back(c))) return rc;
+    // The per-cell stages hold LCS_MAX_WORK cells at a time; rounds are sized for 8 cells per buffer
+    // on average (lcs_batch_collect reports LCS_ERR_OVERFLOW if a batch had more than that).
+    const int rounds = (n_buf * 8 + c->max_work - 1) / c->max_work;
+    for (int r = 0; r < rounds; ++r) {
+      if ((rc = lcs_launch_gather_work(c, n_buf, r * c->max_work))) return rc;
+      if ((rc = lcs_launch_tfg(c, n_cap, true))) return rc;
+      if ((rc = lcs_launch_tfoec(c, 0))) return rc;
+      if ((rc = lcs_launch_mib(c, 0))) return rc;
+      if ((rc = lcs_launch_scatter_back(c))) return rc;
+    }
+    c->last_cell_rounds = rounds;
   }
   c->last_n_buf = n_buf;
   c->last_stage_mask = stage_mask;
@@ -380,9 +387,12 @@ int lcs_batch_collect(lcs_ctx *c, lcs_cell *cells, int max_cells_per_buf, int *n
   std::vector<int> cnt(nb);
   HIPCHK(c, hipMemcpyAsync(tmp.data(), c->peaks, sizeof(lcs_cell) * tmp.size(), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(cnt.data(), c->npeaks, sizeof(int) * nb, hipMemcpyDeviceToHost, c->stream));
+  int work_cnt[2] = {0, 0};
+  const bool full = (c->last_stage_mask & 2) != 0;
+  if (full) HIPCHK(c, hipMemcpyAsync(work_cnt, c->n_work, sizeof(work_cnt), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   int rc = LCS_OK;
-  const bool full = (c->last_stage_mask & 2) != 0;
+  if (full && work_cnt[1] > c->last_cell_rounds * c->max_work) rc = LCS_ERR_OVERFLOW;   // cells beyond the rounds were not decoded
   for (int b = 0; b < nb; ++b) {
     const int np = std::min(cnt[b], (int)LCS_MAXP);
     if (cnt[b] > LCS_MAXP) rc = LCS_ERR_OVERFLOW;
@@ -568,7 +578,7 @@ int lcs_search_capbuf(lcs_ctx *c, const double *capbuf, uint32_t n_cap, const do
   if ((rc = lcs_launch_xcorr(c, 1, geo, false, false))) return rc;
   if ((rc = lcs_launch_peak_search(c, 1, geo, std::pow(10.0, -12.0 / 10.0), true))) return rc;
   if ((rc = lcs_launch_sss_foe(c, 1, n_cap, 3.0, nullptr))) return rc;
-  if ((rc = lcs_launch_gather_work(c, 1))) return rc;
+  if ((rc = lcs_launch_gather_work(c, 1, 0))) return rc;
   if ((rc = lcs_launch_tfg(c, n_cap, true))) return rc;
   if ((rc = lcs_launch_tfoec(c, 0))) return rc;
   if ((rc = lcs_launch_mib(c, 0))) return rc;

@@ -137,6 +137,8 @@ struct lcs_ctx {
   // last batch bookkeeping
   int last_n_buf = 0;
   int last_stage_mask = 0;
+  int max_work = LCS_MAX_WORK;       // cells per per-cell round (LCS_MAX_WORK; the LCS_MAX_WORK environment variable lowers it for tests)
+  int last_cell_rounds = 0;          // per-cell rounds launched for the last batch (LCS_MAX_WORK cells each)
   XcGeom last_geo{};
   hipEvent_t ev_xc0 = nullptr, ev_xc1 = nullptr;
   int last_xc_launches = 0;
@@ -175,7 +177,7 @@ int lcs_launch_sss_foe(lcs_ctx *c, int n_buf, uint32_t n_cap, double thresh2_n_s
 int lcs_launch_sss_only(lcs_ctx *c, uint32_t n_cap, double thresh2_n_sigma, double *dbg);
 int lcs_launch_foe_only(lcs_ctx *c, uint32_t n_cap);
 // tfg_mib.hip
-int lcs_launch_gather_work(lcs_ctx *c, int n_buf);
+int lcs_launch_gather_work(lcs_ctx *c, int n_buf, int skip /* cells already handled by earlier rounds */);
 int lcs_launch_scatter_back(lcs_ctx *c);
 int lcs_launch_rs_build(lcs_ctx *c);
 int lcs_launch_tfg(lcs_ctx *c, uint32_t n_cap, bool with_rs /* also build RS_DL (the fused chain) */);

@@ -79,19 +79,32 @@ __device__ cd2 block_sum(cd2 v, cd2 *red /*>= blockDim/64*/) {
 }
 
 // ----------------------------------------------------------------- work-list compaction
-__global__ void k_gather_work(const lcs_cell *__restrict__ peaks, const int *__restrict__ npeaks, int n_buf,
-                              WorkItem *__restrict__ items, int *__restrict__ n_work, lcs_cell *__restrict__ cells) {
+// One wave: lane = capture buffer (64 at a time); cells that passed SSS are numbered in (buffer, peak)
+// order by a prefix sum over the per-buffer counts; this launch takes numbers [skip, skip + limit).
+// n_work[0] = cells taken, n_work[1] = cells that passed SSS in the whole batch.
+__global__ __launch_bounds__(64) void k_gather_work(const lcs_cell *__restrict__ peaks, const int *__restrict__ npeaks, int n_buf,
+                                                    int skip, int limit, WorkItem *__restrict__ items, int *__restrict__ n_work,
+                                                    lcs_cell *__restrict__ cells) {
   LCS_TAIL_PRIO();
-  if (blockIdx.x != 0 || threadIdx.x != 0) return;
-  int n = 0;
-  for (int s = 0; s < n_buf; ++s) {
-    const int np = min(npeaks[s], LCS_MAXP);
+  const int lane = threadIdx.x;
+  int base = 0;
+  for (int s0 = 0; s0 < n_buf; s0 += 64) {
+    const int s = s0 + lane;
+    const int np = (s < n_buf) ? min(max(npeaks[s], 0), LCS_MAXP) : 0;
+    int cnt = 0;
+    for (int p = 0; p < np; ++p) cnt += (peaks[(size_t)s * LCS_MAXP + p].n_id_1 >= 0);
+    int incl = cnt;
+    for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(incl, off); if (lane >= off) incl += v; }
+    int at = base + incl - cnt - skip;
     for (int p = 0; p < np; ++p) {
       const lcs_cell c = peaks[(size_t)s * LCS_MAXP + p];
-      if (c.n_id_1 >= 0 && n < LCS_MAX_WORK) { items[n].slot = s; items[n].peak = p; cells[n] = c; ++n; }
+      if (c.n_id_1 < 0) continue;
+      if (at >= 0 && at < limit) { items[at].slot = s; items[at].peak = p; cells[at] = c; }
+      ++at;
     }
+    base += __shfl(incl, 63);
   }
-  *n_work = n;
+  if (lane == 0) { n_work[0] = min(max(base - skip, 0), limit); n_work[1] = base; }
 }
 __global__ void k_scatter_back(lcs_cell *__restrict__ peaks, const WorkItem *__restrict__ items,
                                const int *__restrict__ n_work, const lcs_cell *__restrict__ cells) {
@@ -895,8 +908,8 @@ __global__ void k_mib_select(lcs_cell *__restrict__ cells, const int *__restrict
 
 // ------------------------------------------------------------------------------ launch
 #define GRID_ITEMS 64       // workgroups loop over the work list: enough for a typical batch in one round
-int lcs_launch_gather_work(lcs_ctx *c, int n_buf) {
-  hipLaunchKernelGGL(k_gather_work, dim3(1), dim3(64), 0, c->stream, c->peaks, c->npeaks, n_buf, c->work_items, c->n_work,
+int lcs_launch_gather_work(lcs_ctx *c, int n_buf, int skip) {
+  hipLaunchKernelGGL(k_gather_work, dim3(1), dim3(64), 0, c->stream, c->peaks, c->npeaks, n_buf, skip, c->max_work, c->work_items, c->n_work,
                      c->cells_out);
   HIPCHK(c, hipGetLastError());
   return LCS_OK;

@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Reduce gpurun_out/<tag>/ (written by profiles/collect.sh) to the small files kept under profiles/<tag>/.
+
+    python profiles/summarize.py r01
+"""
+import csv, glob, json, os, shutil, sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src, dst = os.path.join(root, "gpurun_out", tag), os.path.join(root, "profiles", tag)
+os.makedirs(dst, exist_ok=True)
+
+for name in ("bench_full_n1.json", "bench_pss_n1.json"):
+    p = os.path.join(src, name)
+    if os.path.exists(p):
+        lines = [l for l in open(p).read().splitlines() if l.startswith("{")]
+        if lines:
+            open(os.path.join(dst, name), "w").write(lines[-1] + "\n")
+
+for d, out in (("stats_full_p1", "kernel_stats_full_chain_b64_nf31_pipeline1.csv"),
+               ("stats_full_default", "kernel_stats_full_chain_b64_nf31_default.csv")):
+    f = glob.glob(os.path.join(src, d, "*", "*_kernel_stats.csv"))
+    if f:
+        shutil.copy(f[0], os.path.join(dst, out))
+f = glob.glob(os.path.join(src, "stats_full_p1", "*", "*_agent_info.csv"))
+if f:
+    shutil.copy(f[0], os.path.join(dst, "agent_info.csv"))
+
+# PMC: average every counter per kernel over its dispatches
+kern = {}
+for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
+    if not os.path.isdir(d):
+        continue
+    for f in glob.glob(os.path.join(d, "*", "*_counter_collection.csv")):
+        acc = {}
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+            acc.setdefault((k, r["Counter_Name"]), {}).setdefault(r["Dispatch_Id"], 0.0)
+            acc[(k, r["Counter_Name"])][r["Dispatch_Id"]] += float(r["Counter_Value"])
+        for (k, c), per in acc.items():
+            kern.setdefault(k, {})[c] = sum(per.values()) / len(per)
+dom = next((k for k in kern if k.startswith("k_xcorr_mfma_blk")), None)
+summary = {
+    "source": "profiles/collect.sh: rocprofv3 --pmc <group> --kernel-trace --output-format csv -- python bench.py --steps 3 "
+              "--warmup 1 --pipeline 1 --no-cpu-baseline, one pass per counter group; values are per-launch averages "
+              "(64 buffers per launch, n_f = 31)",
+    "corrections": "FETCH_SIZE is reported in KiB and, on gfx950, as half of the bytes fetched; WRITE_SIZE in KiB is exact "
+                   "(MI355X_MICROARCH.md, HBM / rocprofv3 section).  hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024",
+    "kernels": kern,
+}
+if dom:
+    k = kern[dom]
+    summary["dominant_kernel"] = dom          # bench.py looks the traffic up under this key
+    d = {}
+    if "FETCH_SIZE" in k and "WRITE_SIZE" in k:
+        d["hbm_bytes_per_launch"] = (2 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in k and "GRBM_GUI_ACTIVE" in k:
+        # busy cycles are summed over the 1024 SIMDs, GRBM_GUI_ACTIVE over the 8 XCDs: per-SIMD busy / per-XCD active
+        d["mfma_pipe_busy_frac"] = (k["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0) / (k["GRBM_GUI_ACTIVE"] / 8.0)
+    if "TCC_HIT_sum" in k and "TCC_MISS_sum" in k:
+        d["l2_hit_rate"] = k["TCC_HIT_sum"] / max(1.0, k["TCC_HIT_sum"] + k["TCC_MISS_sum"])
+    if "SQ_LDS_BANK_CONFLICT" in k:
+        d["lds_bank_conflict_cycles"] = k["SQ_LDS_BANK_CONFLICT"]
+    summary["derived"] = d
+    # fields bench.py reads for roofline.traffic (per buffer, at the n_f / batch the counters were taken at)
+    k["n_f"], k["buffers_per_launch"] = 31, 64
+    if "hbm_bytes_per_launch" in d:
+        k["hbm_bytes_per_launch"] = d["hbm_bytes_per_launch"]
+        k["hbm_bytes_per_buffer"] = d["hbm_bytes_per_launch"] / 64
+json.dump(summary, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1)
+print("wrote", dst, "kernels:", len(kern))

@@ -73,6 +73,25 @@ def test_batch_slots_are_independent_and_placement_invariant(S, pkg, synth_buf):
     assert sorted(c.n_id_cell() for c in ref[0]) == [125, 300] and [c.n_id_cell() for c in ref[1]] == [277, 271] and ref[2] == []
 
 
+def test_per_cell_rounds_and_overflow(S, pkg, synth_buf, monkeypatch):
+    """The per-cell stages take LCS_MAX_WORK cells per round.  With the round size forced down to 3
+    cells, a 19-buffer batch (38 cells past SSS) is decoded in 13 non-empty rounds (plus empty ones)
+    and must return exactly what one big round returns."""
+    import torch
+    f = f_search_set_for(FC, 100)
+    g = golden("capbuf_0000")["iq_u8"]
+    order = [0, 1, 1, 0, 1, 0, 0, 1, 1, 0, 1, 0, 1, 1, 0, 0, 0, 1, 1]
+    src = [synth_buf, g]
+    d = torch.from_numpy(np.stack([src[i] for i in order])).cuda()
+    ref = S.search_batch(d.data_ptr(), pkg.FMT_IQ_U8, len(order), 153600, f, FC, FC, FS, pkg.STAGE_FULL)
+    key = lambda c: tuple(c.as_dict().values())
+    monkeypatch.setenv("LCS_MAX_WORK", "3")
+    with pkg.Searcher(0) as S3:
+        res = S3.search_batch(d.data_ptr(), pkg.FMT_IQ_U8, len(order), 153600, f, FC, FC, FS, pkg.STAGE_FULL)
+    assert [[key(c) for c in r] for r in res] == [[key(c) for c in r] for r in ref]
+    assert sum(len(r) for r in ref) == 2 * len(order)
+
+
 def test_all_zero_buffer_terminates(S, pkg):
     """Degenerate input (every threshold is 0): the reference's peak_search loop never terminates;
     the GPU loop is bounded and reports overflow instead of hanging."""
