@@ -93,6 +93,70 @@ def cpu_baseline(pkg, iq_u8, f, fc, stage):
             "cpu_model": model, "n_peaks": len(peaks)}
 
 
+def stream_bench(pkg, args, rank, world, local_rank, dist):
+    """configs[4]: LTE-Tracker streaming mode, one carrier per GPU ("replicas", no collective in the data
+    path).  A step = one 80 ms host buffer pushed through the captured graph and collected."""
+    import torch
+    fc = FC + 100e3 * rank
+    # the tracked carrier: two cells within the pull-in range of the single hypothesis, every other buffer noise only
+    occ = pkg.synth.make_capbuf(4321 + rank, fc, [dict(n_id_1=33 + rank, n_id_2=1, f_off=900.0, n_ports=2, n_rb_dl=50),
+                                                   dict(n_id_1=120, n_id_2=0, f_off=-700.0, gain_db=-4.0)], 8.0)[0]
+    rng = np.random.default_rng(99 + rank)
+    host = [occ if i % 2 == 0 else np.clip(np.rint(rng.normal(127.0, 12.0, 2 * N_CAP)), 0, 255).astype(np.uint8) for i in range(4)]
+    S = pkg.Searcher(local_rank if world > 1 else 0)
+    S.stream_open(pkg.FMT_IQ_U8, N_CAP, fc, fc, FS)
+    gpu_ms, n_cells = [], 0
+    def step(i):
+        nonlocal n_cells
+        S.stream_push(host[i % len(host)], 0.0)
+        cells, _, ms = S.stream_collect()
+        gpu_ms.append(ms)
+        n_cells = max(n_cells, len(cells))
+    for i in range(args.warmup):
+        step(i)
+    gpu_ms.clear()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    # the same buffers through the eager (launch by launch) chain, for the graph-vs-launches comparison
+    E = pkg.Searcher(local_rank if world > 1 else 0)
+    d_one = torch.from_numpy(np.stack(host)).to(torch.device("cuda", local_rank if world > 1 else 0))
+    fz = np.array([0.0])
+    for i in range(3):
+        E.search_batch(d_one[i % 4].data_ptr(), pkg.FMT_IQ_U8, 1, N_CAP, fz, fc, fc, FS, pkg.STAGE_FULL)
+    t0 = time.perf_counter()
+    for i in range(20):
+        E.search_batch(d_one[i % 4].data_ptr(), pkg.FMT_IQ_U8, 1, N_CAP, fz, fc, fc, FS, pkg.STAGE_FULL)
+    eager_ms = 1e3 * (time.perf_counter() - t0) / 20
+    E.close()
+    if rank == 0:
+        value = world * args.steps / dt
+        print(json.dumps({
+            "metric": "capture-buffers/s (1.92 Msps, 153600-samp) streaming searcher, n_f = 1", "value": value,
+            "unit": "capture-buffers/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[4]: LTE-Tracker streaming mode, one carrier per GPU, one 80 ms u8 I/Q host "
+                                   "buffer per step (PCIe copy included), hipGraph-captured chain, n_f = 1",
+                       "gpu_ms_per_buffer": float(np.mean(gpu_ms)), "realtime_factor": 0.08 * value / world,
+                       "eager_ms_per_buffer_device_resident_input": eager_ms,
+                       "n_cells_in_occupied_buffers": n_cells, "parallelism": "replicas" if world > 1 else "single GPU"}}))
+    S.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -100,8 +164,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="capture buffers per step per GPU")
     ap.add_argument("--ppm", type=float, default=100.0)
-    ap.add_argument("--stage", choices=["pss", "full"], default="full",
-                    help="full = BASELINE configs[2], the whole CellSearch chain (default); pss = configs[1], xcorr_pss + peak_search only")
+    ap.add_argument("--stage", choices=["pss", "full", "stream"], default="full",
+                    help="full = BASELINE configs[2], the whole CellSearch chain (default); pss = configs[1], xcorr_pss + "
+                         "peak_search only; stream = configs[4], one host buffer at a time through the hipGraph-captured "
+                         "single-hypothesis chain (separate, shorter report)")
     ap.add_argument("--variant", type=int, default=0, help="PSS correlation kernel: 0 = default MFMA-f32 kernel, 1 = VALU twin, 2..7 tuning variants")
     ap.add_argument("--pipeline", type=int, default=3,
                     help="contexts (streams + workspaces) used round-robin: with 2, the latency-bound per-cell "
@@ -135,6 +201,8 @@ def main():
     dev = torch.device("cuda", local_rank if world > 1 else 0)
     coll_dev = dev if args.dist_backend == "nccl" else torch.device("cpu")
 
+    if args.stage == "stream":
+        return stream_bench(pkg, args, rank, world, local_rank, dist)
     f = pkg.f_search_set_for(FC, args.ppm)
     stage_mask = pkg.STAGE_FULL if args.stage == "full" else pkg.STAGE_PSS
     B = args.batch

@@ -179,6 +179,21 @@ int lcs_batch_collect(lcs_ctx *ctx, lcs_cell *cells, int max_cells_per_buf, int 
 /* HIP-event time (ms) of the PSS correlation kernel launches of the last enqueue, and the
  * number of launches it covers; used by bench.py for the roofline figure. */
 int lcs_last_xcorr_ms(lcs_ctx *ctx, float *ms, int *n_launches);
+/* ---- streaming mode: LTE-Tracker's searcher thread (src/searcher_thread.cpp:83-246) ----------
+ * One 80 ms capture buffer at a time, a single frequency hypothesis (the tracked frequency offset,
+ * :97-98), cells whose identity is already tracked are reported as re-detected and not decoded again
+ * (:157-177).  lcs_stream_open captures the whole chain once as a hipGraph; lcs_stream_push copies
+ * the HOST buffer (fmt LCS_FMT_C64: n_cap complex<float>, LCS_FMT_IQ_U8: 2*n_cap bytes) into pinned
+ * memory and replays the graph asynchronously; lcs_stream_collect waits for it and returns the NEW
+ * cells (SSS and MIB decoded), the number of tracked cells seen again and the GPU time of the pass.
+ * frame_start is in samples of the pushed buffer; the tracker's 1.92 MHz time base is
+ * frame_start*(FS_LTE/16)/(fs_programmed*k_factor) + capture latency (:224). */
+int lcs_stream_open(lcs_ctx *ctx, int fmt, uint32_t n_cap, double fc_requested, double fc_programmed,
+                    double fs_programmed);
+int lcs_stream_push(lcs_ctx *ctx, const void *samples, double f_off, const int16_t *tracked_n_id_cell, int n_tracked);
+int lcs_stream_collect(lcs_ctx *ctx, lcs_cell *cells, int max_cells, int *n_cells, int *n_redetected, float *gpu_ms);
+int lcs_stream_close(lcs_ctx *ctx);
+
 /* Stream the context launches on (hipStream_t as void*), for external event timing. */
 void *lcs_stream(lcs_ctx *ctx);
 int lcs_sync(lcs_ctx *ctx);

@@ -215,6 +215,31 @@ class Searcher:
         self.batch_enqueue(d_ptr, fmt, n_buf, n_cap, f_search_set, fc_requested, fc_programmed, fs_programmed, stage_mask)
         return self.batch_collect(n_buf, max_cells_per_buf)
 
+    # ---- streaming mode (LTE-Tracker's searcher thread, src/searcher_thread.cpp:83-246) ----
+    def stream_open(self, fmt: int, n_cap: int, fc_requested: float, fc_programmed: float, fs_programmed: float):
+        """Capture the one-buffer, single-hypothesis chain as a hipGraph (see include/lcs.h)."""
+        self._chk(self._lib.lcs_stream_open(self._h, fmt, n_cap, fc_requested, fc_programmed, fs_programmed), "lcs_stream_open")
+        self._stream_fmt, self._stream_n = fmt, n_cap
+
+    def stream_push(self, samples, f_off: float, tracked=()):
+        """samples: host array, uint8 I/Q (2*n_cap) or complex64 (n_cap).  Returns immediately."""
+        a = np.ascontiguousarray(samples, dtype=np.uint8 if self._stream_fmt == FMT_IQ_U8 else np.complex64)
+        assert a.size == (2 if self._stream_fmt == FMT_IQ_U8 else 1) * self._stream_n
+        t = np.ascontiguousarray(np.asarray(list(tracked), dtype=np.int16))
+        self._chk(self._lib.lcs_stream_push(self._h, a.ctypes.data_as(C.c_void_p), float(f_off),
+                                            t.ctypes.data_as(C.POINTER(C.c_int16)), int(t.size)), "lcs_stream_push")
+
+    def stream_collect(self, max_cells: int = 16):
+        """-> (new cells, number of tracked cells seen again, GPU milliseconds of the pass)."""
+        cells = (LcsCell * max_cells)()
+        n, dup, ms = C.c_int(0), C.c_int(0), C.c_float(0)
+        self._chk(self._lib.lcs_stream_collect(self._h, cells, max_cells, C.byref(n), C.byref(dup), C.byref(ms)),
+                  "lcs_stream_collect", allow_overflow=True)
+        return [cells[i].copy() for i in range(min(n.value, max_cells))], dup.value, ms.value
+
+    def stream_close(self):
+        self._chk(self._lib.lcs_stream_close(self._h), "lcs_stream_close")
+
     def last_xcorr_ms(self):
         ms, n = C.c_float(0), C.c_int(0)
         self._chk(self._lib.lcs_last_xcorr_ms(self._h, C.byref(ms), C.byref(n)), "lcs_last_xcorr_ms")

@@ -50,6 +50,7 @@ EXPORTS = [
     "lcs_create", "lcs_destroy", "lcs_last_error", "lcs_version", "lcs_cell_init", "lcs_set_xcorr_variant",
     "lcs_xcorr_pss", "lcs_peak_search", "lcs_sss_detect", "lcs_pss_sss_foe", "lcs_extract_tfg", "lcs_tfoec",
     "lcs_decode_mib", "lcs_search_capbuf", "lcs_search_batch_dev", "lcs_batch_enqueue", "lcs_batch_collect",
+    "lcs_stream_open", "lcs_stream_push", "lcs_stream_collect", "lcs_stream_close",
     "lcs_last_xcorr_ms", "lcs_stream", "lcs_sync", "lcs_table_pss_td", "lcs_table_pss_fd", "lcs_table_sss_fd",
     "lcs_table_lte_pn", "lcs_chi2cdf_inv",
 ]
@@ -100,6 +101,10 @@ def load() -> C.CDLL:
                                        C.c_int, cp, C.c_int, C.POINTER(C.c_int)]
     L.lcs_batch_enqueue.argtypes = [vp, vp, C.c_int, C.c_int, C.c_uint32, dp, C.c_uint16, dp, dp, C.c_double, C.c_int]
     L.lcs_batch_collect.argtypes = [vp, cp, C.c_int, C.POINTER(C.c_int)]
+    L.lcs_stream_open.argtypes = [vp, C.c_int, C.c_uint32, C.c_double, C.c_double, C.c_double]
+    L.lcs_stream_push.argtypes = [vp, vp, C.c_double, C.POINTER(C.c_int16), C.c_int]
+    L.lcs_stream_collect.argtypes = [vp, cp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_float)]
+    L.lcs_stream_close.argtypes = [vp]
     L.lcs_last_xcorr_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]
     L.lcs_stream.argtypes = [vp]
     L.lcs_stream.restype = vp

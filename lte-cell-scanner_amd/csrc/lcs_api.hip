@@ -223,6 +223,7 @@ int lcs_create(int device, lcs_ctx **out) {
 void lcs_destroy(lcs_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
+  if (c->st_open) (void)lcs_stream_close(c);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->stream_xc) (void)hipStreamSynchronize(c->stream_xc);
   void *ptrs[] = {c->cap32, c->cap64, c->params, c->fset, c->tmpl, c->start, c->smin, c->kp2, c->btab, c->single,
@@ -606,6 +607,138 @@ int lcs_search_capbuf(lcs_ctx *c, const double *capbuf, uint32_t n_cap, const do
   if (n_peaks) *n_peaks = np;
   *n_cells = n;
   if (rc) c->err = "more results than the output arrays hold";
+  return rc;
+}
+
+// ---------------------------------------------------------------------------- streaming mode
+// LTE-Tracker's searcher thread (ref src/searcher_thread.cpp:83-246) runs the whole chain on every
+// 80 ms capture buffer with a single frequency hypothesis (the tracked frequency offset, :97-98) and
+// skips cells that are already tracked (:157-177).  Per buffer that is ~25 small launches: here the
+// chain is captured ONCE as a hipGraph and replayed per push.  Everything that changes between
+// pushes (samples, frequency offset, tracked identities) travels through fixed pinned host buffers
+// that the graph's copy nodes read at execution time.
+namespace {
+int stream_chain(lcs_ctx *c) {
+  StreamHost *h = c->st_host;
+  const XcGeom geo = make_geo(c->st_n_cap, 1, 2);
+  int rc;
+  HIPCHK(c, hipMemcpyAsync(c->st_din, c->st_hin, c->st_in_bytes, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->params, &h->p, sizeof(SlotParams), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->fset, &h->f, sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->st_dntracked, &h->n_tracked, sizeof(int), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->st_dtracked, h->tracked, sizeof(h->tracked), hipMemcpyHostToDevice, c->stream));
+  if ((rc = lcs_launch_ingest(c, c->st_din, c->st_fmt, 1, c->st_n_cap))) return rc;
+  if ((rc = lcs_launch_xcorr(c, 1, geo, false, false))) return rc;
+  if ((rc = lcs_launch_peak_search(c, 1, geo, std::pow(10.0, -12.0 / 10.0), true))) return rc;
+  if ((rc = lcs_launch_sss_foe(c, 1, c->st_n_cap, 3.0, nullptr))) return rc;
+  if ((rc = lcs_launch_gather_work(c, 1, 0))) return rc;
+  if ((rc = lcs_launch_tfg(c, c->st_n_cap, true))) return rc;
+  if ((rc = lcs_launch_tfoec(c, 0))) return rc;
+  if ((rc = lcs_launch_mib(c, 0))) return rc;
+  if ((rc = lcs_launch_scatter_back(c))) return rc;
+  HIPCHK(c, hipMemcpyAsync(h->res, c->peaks, sizeof(h->res), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(&h->n_peaks, c->npeaks, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(h->n_work, c->n_work, sizeof(h->n_work), hipMemcpyDeviceToHost, c->stream));
+  return LCS_OK;
+}
+}  // namespace
+
+int lcs_stream_close(lcs_ctx *c) {
+  if (!c) return LCS_ERR_BAD_ARG;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->st_exec) (void)hipGraphExecDestroy(c->st_exec);
+  if (c->st_graph) (void)hipGraphDestroy(c->st_graph);
+  if (c->st_hin) (void)hipHostFree(c->st_hin);
+  if (c->st_host) (void)hipHostFree(c->st_host);
+  if (c->st_din) (void)hipFree(c->st_din);
+  if (c->st_dtracked) (void)hipFree(c->st_dtracked);
+  if (c->st_dntracked) (void)hipFree(c->st_dntracked);
+  if (c->st_ev0) (void)hipEventDestroy(c->st_ev0);
+  if (c->st_ev1) (void)hipEventDestroy(c->st_ev1);
+  c->st_exec = nullptr; c->st_graph = nullptr; c->st_hin = nullptr; c->st_host = nullptr; c->st_din = nullptr;
+  c->st_dtracked = nullptr; c->st_dntracked = nullptr; c->st_ev0 = c->st_ev1 = nullptr;
+  c->st_open = c->st_pending = false;
+  c->single_stream = false;
+  return LCS_OK;
+}
+
+int lcs_stream_open(lcs_ctx *c, int fmt, uint32_t n_cap, double fc_requested, double fc_programmed, double fs_programmed) {
+  int rc = check_common(c, n_cap, 1);
+  if (rc) return rc;
+  if (fmt != LCS_FMT_C64 && fmt != LCS_FMT_IQ_U8) { c->err = "unknown capture format"; return LCS_ERR_BAD_ARG; }
+  if (c->st_open) lcs_stream_close(c);
+  HIPCHK(c, hipSetDevice(c->device));
+  if ((rc = ensure_ws(c, 1, n_cap, 1, false))) return rc;
+  if ((rc = ensure_percell(c))) return rc;
+  c->st_fmt = fmt;
+  c->st_n_cap = n_cap;
+  c->st_in_bytes = (size_t)n_cap * (fmt == LCS_FMT_IQ_U8 ? 2 : sizeof(float2));
+  HIPCHK(c, hipHostMalloc(&c->st_hin, c->st_in_bytes, hipHostMallocDefault));
+  HIPCHK(c, hipHostMalloc((void **)&c->st_host, sizeof(StreamHost), hipHostMallocDefault));
+  HIPCHK(c, hipMalloc(&c->st_din, c->st_in_bytes));
+  HIPCHK(c, hipMalloc((void **)&c->st_dtracked, sizeof(c->st_host->tracked)));
+  HIPCHK(c, hipMalloc((void **)&c->st_dntracked, sizeof(int)));
+  HIPCHK(c, hipEventCreate(&c->st_ev0));
+  HIPCHK(c, hipEventCreate(&c->st_ev1));
+  std::memset(c->st_hin, fmt == LCS_FMT_IQ_U8 ? 127 : 0, c->st_in_bytes);
+  std::memset(c->st_host, 0, sizeof(StreamHost));
+  c->st_host->p = SlotParams{fc_requested, fc_programmed, fs_programmed};
+  c->cap64_valid = false;
+  c->single_stream = true;
+  c->st_open = true;
+  // one eager pass (lazy allocations, function attributes), then the same call sequence under capture
+  if ((rc = stream_chain(c))) { lcs_stream_close(c); return rc; }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+  rc = stream_chain(c);
+  hipGraph_t g = nullptr;
+  const hipError_t e = hipStreamEndCapture(c->stream, &g);
+  if (rc || e != hipSuccess || !g) {
+    if (!rc) { c->err = std::string("hipStreamEndCapture: ") + hipGetErrorString(e); rc = LCS_ERR_HIP; }
+    lcs_stream_close(c);
+    return rc;
+  }
+  c->st_graph = g;
+  HIPCHK(c, hipGraphInstantiate(&c->st_exec, c->st_graph, nullptr, nullptr, 0));
+  return LCS_OK;
+}
+
+int lcs_stream_push(lcs_ctx *c, const void *samples, double f_off, const int16_t *tracked_ids, int n_tracked) {
+  if (!c || !c->st_open || !samples) { if (c) c->err = "stream not open"; return LCS_ERR_BAD_ARG; }
+  if (c->st_pending) { c->err = "previous buffer not collected"; return LCS_ERR_BAD_ARG; }
+  if (n_tracked < 0 || n_tracked > 504 || (n_tracked > 0 && !tracked_ids)) { c->err = "bad tracked list"; return LCS_ERR_BAD_ARG; }
+  HIPCHK(c, hipSetDevice(c->device));
+  std::memcpy(c->st_hin, samples, c->st_in_bytes);
+  c->st_host->f = f_off;
+  c->st_host->n_tracked = n_tracked;
+  for (int i = 0; i < n_tracked; ++i) c->st_host->tracked[i] = tracked_ids[i];
+  HIPCHK(c, hipEventRecord(c->st_ev0, c->stream));
+  HIPCHK(c, hipGraphLaunch(c->st_exec, c->stream));
+  HIPCHK(c, hipEventRecord(c->st_ev1, c->stream));
+  c->st_pending = true;
+  return LCS_OK;
+}
+
+int lcs_stream_collect(lcs_ctx *c, lcs_cell *cells, int max_cells, int *n_cells, int *n_redetected, float *gpu_ms) {
+  if (!c || !c->st_open || !c->st_pending || !n_cells || (max_cells > 0 && !cells)) { if (c) c->err = "nothing to collect"; return LCS_ERR_BAD_ARG; }
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->st_pending = false;
+  if (gpu_ms) HIPCHK(c, hipEventElapsedTime(gpu_ms, c->st_ev0, c->st_ev1));
+  const StreamHost *h = c->st_host;
+  int rc = LCS_OK, n = 0;
+  const int np = std::min(h->n_peaks, (int)LCS_MAXP);
+  if (h->n_peaks > LCS_MAXP || h->n_work[1] > c->max_work) rc = LCS_ERR_OVERFLOW;
+  for (int i = 0; i < np; ++i) {
+    const lcs_cell &pc = h->res[i];
+    if (pc.n_id_1 == -1 || pc.n_rb_dl == -1) continue;     // no SSS / no MIB / already tracked (never decoded)
+    if (n < max_cells) cells[n] = pc; else rc = LCS_ERR_OVERFLOW;
+    ++n;
+  }
+  *n_cells = n;
+  if (n_redetected) *n_redetected = h->n_work[2];
+  if (rc) c->err = "more results than the output array holds";
   return rc;
 }
 

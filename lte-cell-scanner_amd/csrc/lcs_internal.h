@@ -76,6 +76,17 @@ struct WorkItem {
   int peak;      // index into peaks[slot]
 };
 
+// Pinned block shared with the captured graph of the streaming mode.
+struct StreamHost {
+  SlotParams p;
+  double f;
+  int n_tracked;
+  int16_t tracked[504];
+  lcs_cell res[LCS_MAXP];
+  int n_peaks;
+  int n_work[4];
+};
+
 struct lcs_ctx {
   int device = 0;
   hipStream_t stream = nullptr;      // everything except the PSS correlation (highest priority)
@@ -130,6 +141,20 @@ struct lcs_ctx {
   int16_t *d_derm_inv = nullptr;    // [2][120][16]: for every coded bit (stream*40+col) the rate-matched PBCH bit positions carrying it (ascending, -1 padded)
   double *d_dbg = nullptr;          // debug outputs of the single-cell stage entry points
   bool percell_ready = false;
+  // streaming mode (lcs_stream_*): the one-buffer, n_f = 1 chain captured once as a hipGraph; every
+  // per-push input reaches the device through fixed pinned buffers, so the graph never changes
+  bool single_stream = false;        // launch everything on `stream`, no cross-stream events
+  bool st_open = false, st_pending = false;
+  int st_fmt = 0;
+  uint32_t st_n_cap = 0;
+  void *st_hin = nullptr, *st_din = nullptr;      // pinned / device copy of the pushed buffer
+  size_t st_in_bytes = 0;
+  struct StreamHost *st_host = nullptr;           // pinned parameter + result block
+  int16_t *st_dtracked = nullptr;
+  int *st_dntracked = nullptr;
+  hipGraph_t st_graph = nullptr;
+  hipGraphExec_t st_exec = nullptr;
+  hipEvent_t st_ev0 = nullptr, st_ev1 = nullptr;
   // host staging
   void *h_pinned = nullptr;
   size_t h_pinned_bytes = 0;

@@ -762,7 +762,8 @@ int lcs_launch_xcorr(lcs_ctx *c, int n_buf, const XcGeom &geo, bool want_incoh, 
   // slots [0, n8) with the XCD-aware mapping, the remainder with the plain one
   const int n8 = (n_buf >= 8) ? (n_buf & ~7) : 0;
   // main stream -> correlation stream hand-off (tables and fp32 buffer are ready)
-  static const bool single_stream = getenv("LCS_SINGLE_STREAM") != nullptr;   // measurement knob
+  static const bool single_env = getenv("LCS_SINGLE_STREAM") != nullptr;   // measurement knob
+  const bool single_stream = single_env || c->single_stream;   // streaming mode: one stream, no events (graph capture)
   // Tuning knob: extra dynamic LDS per correlation workgroup lowers its residency (106 VGPRs already
   // cap it at 4 workgroups per CU; 12288 -> 3 per CU, +1 % kernel time) to leave room for the small
   // kernels of the neighbouring batches.  Measured: no net gain, so the default is 0.
@@ -772,7 +773,7 @@ int lcs_launch_xcorr(lcs_ctx *c, int n_buf, const XcGeom &geo, bool want_incoh, 
     HIPCHK(c, hipEventRecord(c->ev_pre, c->stream));
     HIPCHK(c, hipStreamWaitEvent(sxc, c->ev_pre, 0));
   }
-  {
+  if (!c->single_stream) {
     std::lock_guard<std::mutex> lk(g_xc_mutex);
     hipEvent_t &ev = g_xc_done[c->device & 63];
     if (!ev) HIPCHK(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
@@ -801,7 +802,7 @@ int lcs_launch_xcorr(lcs_ctx *c, int n_buf, const XcGeom &geo, bool want_incoh, 
     ++launches;
   }
   if (time_it) { HIPCHK(c, hipEventRecord(c->ev_xc1, sxc)); c->last_xc_launches = launches; }
-  {
+  if (!c->single_stream) {
     std::lock_guard<std::mutex> lk(g_xc_mutex);
     HIPCHK(c, hipEventRecord(g_xc_done[c->device & 63], sxc));
   }

@@ -81,30 +81,46 @@ __device__ cd2 block_sum(cd2 v, cd2 *red /*>= blockDim/64*/) {
 // ----------------------------------------------------------------- work-list compaction
 // One wave: lane = capture buffer (64 at a time); cells that passed SSS are numbered in (buffer, peak)
 // order by a prefix sum over the per-buffer counts; this launch takes numbers [skip, skip + limit).
-// n_work[0] = cells taken, n_work[1] = cells that passed SSS in the whole batch.
+// n_work[0] = cells taken, n_work[1] = cells that passed SSS in the whole batch (and are not already
+// tracked), n_work[2] = cells skipped because their identity is in the tracked list (streaming mode,
+// ref src/searcher_thread.cpp:157-177: a re-detected cell is not decoded again).
+__device__ __forceinline__ bool cell_wanted(const lcs_cell &c, const int16_t *tracked, int n_tracked) {
+  if (c.n_id_1 < 0) return false;
+  const int id = c.n_id_2 + 3 * c.n_id_1;
+  for (int i = 0; i < n_tracked; ++i) if (tracked[i] == id) return false;
+  return true;
+}
 __global__ __launch_bounds__(64) void k_gather_work(const lcs_cell *__restrict__ peaks, const int *__restrict__ npeaks, int n_buf,
-                                                    int skip, int limit, WorkItem *__restrict__ items, int *__restrict__ n_work,
-                                                    lcs_cell *__restrict__ cells) {
+                                                    int skip, int limit, const int16_t *__restrict__ tracked,
+                                                    const int *__restrict__ n_tracked_p, WorkItem *__restrict__ items,
+                                                    int *__restrict__ n_work, lcs_cell *__restrict__ cells) {
   LCS_TAIL_PRIO();
   const int lane = threadIdx.x;
-  int base = 0;
+  const int n_tracked = tracked ? *n_tracked_p : 0;
+  int base = 0, dup = 0;
   for (int s0 = 0; s0 < n_buf; s0 += 64) {
     const int s = s0 + lane;
     const int np = (s < n_buf) ? min(max(npeaks[s], 0), LCS_MAXP) : 0;
     int cnt = 0;
-    for (int p = 0; p < np; ++p) cnt += (peaks[(size_t)s * LCS_MAXP + p].n_id_1 >= 0);
+    for (int p = 0; p < np; ++p) {
+      const lcs_cell c = peaks[(size_t)s * LCS_MAXP + p];
+      const bool w = cell_wanted(c, tracked, n_tracked);
+      cnt += w;
+      dup += (c.n_id_1 >= 0 && !w);
+    }
     int incl = cnt;
     for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(incl, off); if (lane >= off) incl += v; }
     int at = base + incl - cnt - skip;
     for (int p = 0; p < np; ++p) {
       const lcs_cell c = peaks[(size_t)s * LCS_MAXP + p];
-      if (c.n_id_1 < 0) continue;
+      if (!cell_wanted(c, tracked, n_tracked)) continue;
       if (at >= 0 && at < limit) { items[at].slot = s; items[at].peak = p; cells[at] = c; }
       ++at;
     }
     base += __shfl(incl, 63);
   }
-  if (lane == 0) { n_work[0] = min(max(base - skip, 0), limit); n_work[1] = base; }
+  for (int off = 32; off > 0; off >>= 1) dup += __shfl_down(dup, off);
+  if (lane == 0) { n_work[0] = min(max(base - skip, 0), limit); n_work[1] = base; n_work[2] = dup; }
 }
 __global__ void k_scatter_back(lcs_cell *__restrict__ peaks, const WorkItem *__restrict__ items,
                                const int *__restrict__ n_work, const lcs_cell *__restrict__ cells) {
@@ -909,7 +925,8 @@ __global__ void k_mib_select(lcs_cell *__restrict__ cells, const int *__restrict
 // ------------------------------------------------------------------------------ launch
 #define GRID_ITEMS 64       // workgroups loop over the work list: enough for a typical batch in one round
 int lcs_launch_gather_work(lcs_ctx *c, int n_buf, int skip) {
-  hipLaunchKernelGGL(k_gather_work, dim3(1), dim3(64), 0, c->stream, c->peaks, c->npeaks, n_buf, skip, c->max_work, c->work_items, c->n_work,
+  hipLaunchKernelGGL(k_gather_work, dim3(1), dim3(64), 0, c->stream, c->peaks, c->npeaks, n_buf, skip, c->max_work,
+                     c->st_open ? c->st_dtracked : nullptr, c->st_dntracked, c->work_items, c->n_work,
                      c->cells_out);
   HIPCHK(c, hipGetLastError());
   return LCS_OK;

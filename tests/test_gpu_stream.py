@@ -1,0 +1,61 @@
+"""Streaming mode (BASELINE configs[4] / SURVEY 8f-2: LTE-Tracker's searcher thread,
+ref src/searcher_thread.cpp:83-246): the hipGraph-captured one-buffer chain must return exactly what
+the eager single-buffer entry point returns for the same buffer and the same single hypothesis, push
+after push, and must leave already-tracked cells undecoded."""
+import numpy as np
+import pytest
+
+from conftest import golden, iq_u8_to_capbuf, load_pkg
+
+pytestmark = pytest.mark.gpu
+FS = 1.92e6
+FC = 739e6
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    return load_pkg()
+
+
+def _key(c):
+    return tuple(c.as_dict().values())
+
+
+def test_stream_graph_matches_eager_chain(pkg):
+    g = golden("capbuf_0000")["iq_u8"]                     # cells 277 and 271 at ~35.2 kHz offset
+    rng = np.random.default_rng(5)
+    noise = np.clip(np.rint(rng.normal(127.0, 15.0, g.size)), 0, 255).astype(np.uint8)
+    syn, _ = pkg.synth.make_capbuf(77, FC, [dict(n_id_1=12, n_id_2=1, f_off=35e3)], 8.0)
+    with pkg.Searcher(0) as S, pkg.Searcher(0) as E:
+        S.stream_open(pkg.FMT_IQ_U8, 153600, FC, FC, FS)
+        for buf, f_off in [(g, 35e3), (noise, 35e3), (syn, 35e3), (g, 35e3), (g, 30e3)]:
+            S.stream_push(buf, f_off)
+            cells, dup, ms = S.stream_collect()
+            ref, _ = E.search_capbuf(iq_u8_to_capbuf(buf), np.array([f_off]), FC, FC, FS)
+            assert [_key(c) for c in cells] == [_key(c) for c in ref]
+            assert dup == 0 and 0.0 < ms < 50.0
+        # tracked cells are seen again but not decoded; the other one is still reported
+        S.stream_push(g, 35e3, tracked=[277])
+        cells, dup, _ = S.stream_collect()
+        assert [c.n_id_cell() for c in cells] == [271] and dup == 1
+        S.stream_push(g, 35e3, tracked=[271, 277, 5])
+        cells, dup, _ = S.stream_collect()
+        assert cells == [] and dup == 2
+        S.stream_close()
+        # the context is usable for batches again after closing the stream
+        ref, _ = S.search_capbuf(iq_u8_to_capbuf(g), np.array([35e3]), FC, FC, FS)
+        assert [c.n_id_cell() for c in ref] == [277, 271]
+
+
+def test_stream_complex64_input_and_misuse(pkg):
+    g = golden("capbuf_0000")["iq_u8"]
+    cap = iq_u8_to_capbuf(g).astype(np.complex64)
+    with pkg.Searcher(0) as S:
+        with pytest.raises(RuntimeError):
+            S._chk(S._lib.lcs_stream_push(S._h, None, 0.0, None, 0), "push before open")
+        S.stream_open(pkg.FMT_C64, 153600, FC, FC, FS)
+        S.stream_push(cap, 35e3)
+        with pytest.raises(RuntimeError):
+            S.stream_push(cap, 35e3)              # previous buffer not collected
+        cells, _, _ = S.stream_collect()
+        assert [c.n_id_cell() for c in cells] == [277, 271]
