@@ -18,6 +18,7 @@ import numpy as np
 from . import capi
 from . import synth
 from . import sweep
+from . import itfile
 from .capi import LcsCell, FMT_C64, FMT_IQ_U8, STAGE_PSS, STAGE_FULL
 
 FS_LTE = 30720000.0        # include/constants.h:32

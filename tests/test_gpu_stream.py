@@ -59,3 +59,16 @@ def test_stream_complex64_input_and_misuse(pkg):
             S.stream_push(cap, 35e3)              # previous buffer not collected
         cells, _, _ = S.stream_collect()
         assert [c.n_id_cell() for c in cells] == [277, 271]
+
+
+def test_sweep_tool_single_gpu(tmp_path):
+    """tools/sweep_cellsearch.py (BASELINE configs[3]) on a 12-carrier slice of the band: the synthetic cells
+    planted on every 4th carrier come back through the full chain, the sharding driver and dedup."""
+    import json, os, subprocess, sys
+    from conftest import ROOT
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "sweep_cellsearch.py"), "-s", "739.0e6", "-e", "740.1e6",
+                          "--occupied-every", "4", "--batch", "8", "--json"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert r["carriers"] == 12 and r["n_gpus"] == 1 and len(r["cells"]) >= 2
+    assert all(0 <= cid < 504 and nrb in (6, 15, 25, 50, 75, 100) for cid, _, nrb, _ in r["cells"])

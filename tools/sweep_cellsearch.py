@@ -1,0 +1,138 @@
+#!/usr/bin/env python3
+"""CellSearch band sweep on N GPUs of one node (BASELINE configs[3]: 715-768 MHz, 531 carriers).
+
+    python tools/sweep_cellsearch.py -s 715e6 -e 768e6                       # one GPU
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \\
+           tools/sweep_cellsearch.py -s 715e6 -e 768e6                       # one rank per GPU
+
+Mirrors the carrier loop of the reference's CLI (src/CellSearch.cpp:465-573): one capture buffer per
+100 kHz raster point, the whole searcher chain on each, `dedup`, the final table.  The carriers are
+sharded block-cyclically over the ranks (lte-cell-scanner_amd/sweep.py); every rank pushes its
+carriers through the device-resident batch API in batches that fit HBM, and the detected-cell records
+are all-gathered ONCE at the end (RCCL).  Capture buffers come from --load DIR (capbuf_NNNN.it files
+as written by `CellSearch --record`) or are synthesised (most carriers empty, every `--occupied-every`-th
+carries 1-2 cells), since a GPU node has no SDR.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+N_CAP, FS = 153600, 1.92e6
+
+
+def freq_formatter(f):     # src/CellSearch.cpp:322-340
+    for lim, div, suf in ((998.0, 1.0, "h"), (998e3, 1e3, "k"), (998e6, 1e6, "m"), (998e9, 1e9, "g")):
+        if abs(f) < lim:
+            return f"{f / div:5.3g}{suf}"
+    return f"{f / 1e12:5.3g}t"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("-s", "--freq-start", type=float, default=715e6)
+    ap.add_argument("-e", "--freq-end", type=float, default=768e6)
+    ap.add_argument("-p", "--ppm", type=float, default=120.0)
+    ap.add_argument("-c", "--correction", type=float, default=1.0)
+    ap.add_argument("-l", "--load", default=None, help="directory with capbuf_NNNN.it files (one per carrier)")
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--occupied-every", type=int, default=16)
+    ap.add_argument("--seed", type=int, default=2024)
+    ap.add_argument("--dist-backend", default="nccl")
+    ap.add_argument("--share-gpu0", action="store_true", help="testing only: every rank uses GPU 0")
+    ap.add_argument("--json", action="store_true", help="print a JSON summary line instead of the table")
+    args = ap.parse_args()
+
+    import torch
+    import __graft_entry__ as ge
+    pkg = ge.load_package()
+    sw = pkg.sweep
+    world, rank, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if args.share_gpu0:
+        local = 0
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.dist_backend)
+
+    # raster handling and the frequency grid exactly as the CLI: n_extra from freq_start only (CellSearch.cpp:463)
+    fs_, fe_ = round(args.freq_start / 100e3) * 100e3, round(args.freq_end / 100e3) * 100e3
+    fcs = sw.fc_search_set(fs_, fe_)
+    f_set = pkg.f_search_set_for(fs_, args.ppm)
+    fs_prog = FS * args.correction
+
+    if args.load:
+        def get_capbufs(idx):
+            out = np.empty((len(idx), 2 * N_CAP), np.uint8)
+            for j, ci in enumerate(idx):
+                cap = np.asarray(pkg.itfile.read_it(os.path.join(args.load, f"capbuf_{ci:04d}.it"))["capbuf"]).ravel()
+                iq = np.empty(2 * N_CAP)
+                iq[0::2], iq[1::2] = cap.real[:N_CAP], cap.imag[:N_CAP]
+                out[j] = np.clip(np.rint(iq * 128.0 + 127.0), 0, 255).astype(np.uint8)
+            return out
+    else:
+        def get_capbufs(idx):       # a carrier's buffer depends on its index only: the same band whatever the sharding
+            out = np.empty((len(idx), 2 * N_CAP), np.uint8)
+            for j, ci in enumerate(idx):
+                rng = np.random.default_rng(args.seed + int(ci))
+                if ci % args.occupied_every == 0:
+                    cells = [dict(n_id_1=int(rng.integers(0, 168)), n_id_2=int(rng.integers(0, 3)), cp_normal=bool(rng.integers(0, 8) != 0),
+                                  n_ports=int((1, 2, 2, 4)[rng.integers(0, 4)]), n_rb_dl=int((6, 15, 25, 50, 75, 100)[rng.integers(0, 6)]),
+                                  f_off=float(rng.uniform(-60e3, 60e3)), gain_db=-3.0 * k) for k in range(1 + int(rng.integers(0, 2)))]
+                    out[j] = pkg.synth.make_capbuf(args.seed + int(ci), float(fcs[ci]), cells, snr_db=float(rng.uniform(0, 10)))[0]
+                else:
+                    out[j] = np.clip(np.rint(rng.normal(127.0, 12.0, 2 * N_CAP)), 0, 255).astype(np.uint8)
+            return out
+
+    S = pkg.Searcher(local)
+
+    def search_fn(bufs, fc):
+        d = torch.from_numpy(np.ascontiguousarray(bufs)).to(dev)
+        return S.search_batch(d.data_ptr(), pkg.FMT_IQ_U8, len(bufs), N_CAP, f_set, fc, fc, fs_prog, pkg.STAGE_FULL)
+
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    final, detected = sw.run_sweep(search_fn, get_capbufs, fcs, rank, world, dist,
+                                   dev if (world > 1 and args.dist_backend == "nccl") else None, batch=args.batch)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if rank == 0:
+        if args.json:
+            print(json.dumps({"carriers": int(len(fcs)), "n_f": int(len(f_set)), "n_gpus": world, "seconds": dt,
+                              "carriers_per_s_incl_generation": len(fcs) / dt,
+                              "cells": [(c["n_id_cell"], c["fc_requested"], c["n_rb_dl"], c["n_ports"]) for c in final]}))
+        elif not final:
+            print("No LTE cells were found...")
+        else:
+            print("Detected the following cells:")
+            print("A: #antenna ports C: CP type ; P: PHICH duration ; PR: PHICH resource type")
+            print("CID A      fc   foff RXPWR C nRB P  PR CrystalCorrectionFactor")
+            for c in final:
+                cp = {1: "N", 2: "E"}.get(c["cp_type"], "U")
+                pd = {1: "N", 2: "E"}.get(c["phich_duration"], "U")
+                pr = {1: "1/6", 2: "half", 3: "one", 4: "two"}.get(c["phich_resource"], "unk")
+                k = (c["fc_requested"] - c["freq_superfine"]) / c["fc_programmed"]
+                print(f"{c['n_id_cell']:3d}{c['n_ports']:2d} {c['fc_requested'] / 1e6:6.5g}M {freq_formatter(c['freq_superfine'])} "
+                      f"{10 * np.log10(c['pss_pow']):5.3g} {cp} {c['n_rb_dl']:3d} {pd} {pr:>3s} {k * args.correction:.14g}")
+    S.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
