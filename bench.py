@@ -168,7 +168,7 @@ def main():
                     help="full = BASELINE configs[2], the whole CellSearch chain (default); pss = configs[1], xcorr_pss + "
                          "peak_search only; stream = configs[4], one host buffer at a time through the hipGraph-captured "
                          "single-hypothesis chain (separate, shorter report)")
-    ap.add_argument("--variant", type=int, default=0, help="PSS correlation kernel: 0 = default MFMA-f32 kernel, 1 = VALU twin, 2..7 tuning variants")
+    ap.add_argument("--variant", type=int, default=0, help="PSS correlation kernel: 0 = default 4-wave MFMA-f32 kernel, 1 = VALU twin, 2 = one-wave MFMA kernel")
     ap.add_argument("--pipeline", type=int, default=3,
                     help="contexts (streams + workspaces) used round-robin: with 2, the latency-bound per-cell "
                          "stages of step i overlap the PSS correlation of step i+1")

@@ -80,7 +80,7 @@ const char *lcs_version(void);
 void lcs_cell_init(lcs_cell *c);                      /* src/common.cpp:36-56 */
 /* Knob for A/B measurement of the PSS correlation kernel: 0 = default (fp32-MFMA, 4-wave
  * workgroups, template rows through LDS), 1 = plain-VALU twin, 2 = 1-wave MFMA kernel with
- * template rows from L2, 3..7 = occupancy / tiling variants.  All produce bit-identical results. */
+ * template rows from L2.  All produce bit-identical results. */
 int lcs_set_xcorr_variant(lcs_ctx *ctx, int variant);
 
 /* ---- stage entry points (host buffers in / out) ------------------------------------ */

@@ -245,7 +245,7 @@ void lcs_destroy(lcs_ctx *c) {
 const char *lcs_last_error(const lcs_ctx *c) { return c ? c->err.c_str() : "null context"; }
 
 int lcs_set_xcorr_variant(lcs_ctx *c, int variant) {
-  if (!c || variant < 0 || variant > 7) return LCS_ERR_BAD_ARG;
+  if (!c || variant < 0 || variant > 2) return LCS_ERR_BAD_ARG;
   c->xcorr_variant = variant;
   return LCS_OK;
 }
@@ -363,6 +363,7 @@ int lcs_batch_enqueue(lcs_ctx *c, const void *d_capbufs, int fmt, int n_buf, uin
     if ((rc = lcs_launch_sss_foe(c, n_buf, n_cap, 3.0 /* THRESH2_N_SIGMA, ref src/CellSearch.cpp:528 */, nullptr))) return rc;
     // The per-cell stages hold LCS_MAX_WORK cells at a time; rounds are sized for 8 cells per buffer
     // on average (lcs_batch_collect reports LCS_ERR_OVERFLOW if a batch had more than that).
+    c->needed_rows_only = true;
     const int rounds = (n_buf * 8 + c->max_work - 1) / c->max_work;
     for (int r = 0; r < rounds; ++r) {
       if ((rc = lcs_launch_gather_work(c, n_buf, r * c->max_work))) return rc;
@@ -505,6 +506,7 @@ int lcs_extract_tfg(lcs_ctx *c, const lcs_cell *cell, const double *capbuf, uint
   int rc;
   if ((rc = upload_cap_and_params(c, capbuf, n_cap, fc_req, fc_prog, fs_prog))) return rc;
   if ((rc = put_single_work_item(c, cell, no))) return rc;
+  c->needed_rows_only = false;
   if ((rc = lcs_launch_tfg(c, n_cap, false))) return rc;
   double oob = 0;
   HIPCHK(c, hipMemcpyAsync(tfg, c->tfg, sizeof(double2) * no * LCS_TFG_NSC, hipMemcpyDeviceToHost, c->stream));
@@ -532,6 +534,7 @@ int lcs_tfoec(lcs_ctx *c, const lcs_cell *cell, const double *tfg, const double 
   HIPCHK(c, hipMemcpyAsync(c->tfg, tfg, sizeof(double2) * n_ofdm * LCS_TFG_NSC, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->tfg_ts, tfg_timestamp, sizeof(double) * n_ofdm, hipMemcpyHostToDevice, c->stream));
   if ((rc = lcs_launch_rs_build(c))) return rc;
+  c->needed_rows_only = false;
   if ((rc = lcs_launch_tfoec(c, 1))) return rc;
   HIPCHK(c, hipMemcpyAsync(tfg_comp, c->tfg_comp, sizeof(double2) * n_ofdm * LCS_TFG_NSC, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(tfg_comp_timestamp, c->tfg_ts_comp, sizeof(double) * n_ofdm, hipMemcpyDeviceToHost, c->stream));
@@ -552,6 +555,7 @@ int lcs_decode_mib(lcs_ctx *c, const lcs_cell *cell, const double *tfg, int n_of
   if ((rc = put_single_work_item(c, cell, n_ofdm))) return rc;
   HIPCHK(c, hipMemcpyAsync(c->tfg_comp, tfg, sizeof(double2) * n_ofdm * LCS_TFG_NSC, hipMemcpyHostToDevice, c->stream));
   if ((rc = lcs_launch_rs_build(c))) return rc;
+  c->needed_rows_only = true;      // decode_mib reads the channel estimate on PBCH rows only
   if ((rc = lcs_launch_mib(c, 1))) return rc;
   HIPCHK(c, hipMemcpyAsync(cell_out, c->cells_out, sizeof(lcs_cell), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -579,6 +583,7 @@ int lcs_search_capbuf(lcs_ctx *c, const double *capbuf, uint32_t n_cap, const do
   if ((rc = lcs_launch_xcorr(c, 1, geo, false, false))) return rc;
   if ((rc = lcs_launch_peak_search(c, 1, geo, std::pow(10.0, -12.0 / 10.0), true))) return rc;
   if ((rc = lcs_launch_sss_foe(c, 1, n_cap, 3.0, nullptr))) return rc;
+  c->needed_rows_only = true;
   if ((rc = lcs_launch_gather_work(c, 1, 0))) return rc;
   if ((rc = lcs_launch_tfg(c, n_cap, true))) return rc;
   if ((rc = lcs_launch_tfoec(c, 0))) return rc;
@@ -631,6 +636,7 @@ int stream_chain(lcs_ctx *c) {
   if ((rc = lcs_launch_xcorr(c, 1, geo, false, false))) return rc;
   if ((rc = lcs_launch_peak_search(c, 1, geo, std::pow(10.0, -12.0 / 10.0), true))) return rc;
   if ((rc = lcs_launch_sss_foe(c, 1, c->st_n_cap, 3.0, nullptr))) return rc;
+  c->needed_rows_only = true;
   if ((rc = lcs_launch_gather_work(c, 1, 0))) return rc;
   if ((rc = lcs_launch_tfg(c, c->st_n_cap, true))) return rc;
   if ((rc = lcs_launch_tfoec(c, 0))) return rc;

@@ -162,6 +162,7 @@ struct lcs_ctx {
   // last batch bookkeeping
   int last_n_buf = 0;
   int last_stage_mask = 0;
+  bool needed_rows_only = false;     // fused chains: compute only the grid rows later stages read (tfg_mib.hip)
   int max_work = LCS_MAX_WORK;       // cells per per-cell round (LCS_MAX_WORK; the LCS_MAX_WORK environment variable lowers it for tests)
   int last_cell_rounds = 0;          // per-cell rounds launched for the last batch (LCS_MAX_WORK cells each)
   XcGeom last_geo{};

@@ -276,104 +276,6 @@ __global__ __launch_bounds__(64) void k_xcorr_mfma(const float2 *__restrict__ ca
   }
 }
 
-// Tuning variants of the MFMA kernel (A/B partners; bit-identical results): WPS = waves per SIMD the
-// register allocation is bounded for, PREFETCH = next window's samples fetched into registers
-// during the current window and two LDS buffers (otherwise one buffer, staged in place).
-template <int WPS, bool PREFETCH, int UNROLL>
-__global__ __launch_bounds__(64, WPS) void k_xcorr_mfma_t(const float2 *__restrict__ cap32, const int *__restrict__ smin,
-                                                           const int *__restrict__ kp2, const float *__restrict__ btab,
-                                                           float *__restrict__ sg, XcGeom geo, int slot0, int n_slots,
-                                                           int xcd_map) {
-  const int lane = threadIdx.x;
-  int tile, g, slot;
-  if (!decode_block(geo, slot0, n_slots, xcd_map, tile, g, slot)) return;
-  const int idx0 = tile * LCS_LAG_TILE;
-  __shared__ float lds[(PREFETCH ? 2 : 1) * 3 * LCS_PS];
-  const float2 *cap = cap32 + (size_t)slot * geo.n_cap;
-  const int *smin_s = smin + (size_t)slot * NW * GM + g;
-  const int *kp2_s = kp2 + (size_t)slot * NW * GM + g;
-  const int odd = (lane >> 4) & 1;
-  const int a1_off = (odd ? 2 * LCS_PS : LCS_PS) + (lane & 15) + (lane >> 5);
-  const int a2_off = (odd ? LCS_PS : 0) + (lane & 15) + (lane >> 5);
-  f32x4 P[4];
-#pragma unroll
-  for (int mt = 0; mt < 4; ++mt) P[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float2 pre[5];
-  if (PREFETCH) stage_load(pre, cap, geo.n_cap, idx0 + smin_s[0], LCS_LAG_TILE + 2 * kp2_s[0], lane);
-  for (int w = 0; w < geo.n_comb; ++w) {
-    const int k2 = kp2_s[w * GM];
-    float *buf = lds + (PREFETCH ? (w & 1) * 3 * LCS_PS : 0);
-    if (PREFETCH) {
-      stage_write(buf, pre, LCS_LAG_TILE + 2 * k2, lane);
-      __syncthreads();
-      if (w + 1 < geo.n_comb)
-        stage_load(pre, cap, geo.n_cap, idx0 + smin_s[(w + 1) * GM], LCS_LAG_TILE + 2 * kp2_s[(w + 1) * GM], lane);
-    } else {
-      __syncthreads();   // everybody is done reading the previous window
-      const int sl = LCS_LAG_TILE + 2 * k2, L0 = idx0 + smin_s[w * GM];
-      for (int n = lane; n < sl; n += 64) {
-        const uint32_t src = (uint32_t)(L0 + n);
-        const float2 v = (src < geo.n_cap) ? cap[src] : make_float2(0.f, 0.f);
-        buf[n] = v.y; buf[LCS_PS + n] = v.x; buf[2 * LCS_PS + n] = -v.y;
-      }
-      __syncthreads();
-    }
-    f32x4 aR[4], aI[4];
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) { aR[mt] = (f32x4){0.f, 0.f, 0.f, 0.f}; aI[mt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-    const float *bp = btab + (((size_t)slot * geo.n_comb + w) * geo.G + g) * (size_t)(LCS_KP2_MAX * 64) + lane;
-    const float *a1p = buf + a1_off;
-    const float *a2p = buf + a2_off;
-    float bnext[UNROLL];
-#pragma unroll
-    for (int u = 0; u < UNROLL; ++u) bnext[u] = bp[u * 64];
-    const int k2m = k2 - (k2 % UNROLL);
-    int kk = 0;
-    for (; kk < k2m; kk += UNROLL) {
-      float b[UNROLL];
-#pragma unroll
-      for (int u = 0; u < UNROLL; ++u) b[u] = bnext[u];
-#pragma unroll
-      for (int u = 0; u < UNROLL; ++u) bnext[u] = bp[(kk + UNROLL + u) * 64];
-#pragma unroll
-      for (int u = 0; u < UNROLL; ++u) {
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-          const float a1 = a1p[mt * 16 + 2 * (kk + u)];
-          const float a2 = a2p[mt * 16 + 2 * (kk + u)];
-          aR[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b[u], aR[mt], 0, 0, 0);
-          aI[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b[u], aI[mt], 0, 0, 0);
-        }
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < UNROLL - 1; ++u) {
-      if (kk + u < k2) {
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-          const float a1 = a1p[mt * 16 + 2 * (kk + u)];
-          const float a2 = a2p[mt * 16 + 2 * (kk + u)];
-          aR[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bnext[u], aR[mt], 0, 0, 0);
-          aI[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, bnext[u], aI[mt], 0, 0, 0);
-        }
-      }
-    }
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) P[mt][r] = P[mt][r] + pow2sum(aR[mt][r], aI[mt][r]);
-  }
-  const float ncomb = (float)geo.n_comb;
-  float *o = sg + (((size_t)slot * geo.G + g) * LCS_N_IDX) * LCS_TG + (lane & 15);
-#pragma unroll
-  for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int idx = idx0 + mt * 16 + 4 * (lane >> 4) + r;
-      o[(size_t)idx * LCS_TG] = __fdiv_rn(P[mt][r], ncomb);
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
 // 4-wave variant: one 256-thread workgroup owns 4 adjacent lag tiles (256 output positions) of one
 // template group.  The capture window is staged once for the four waves, and the template rows
@@ -792,11 +694,6 @@ int lcs_launch_xcorr(lcs_ctx *c, int n_buf, const XcGeom &geo, bool want_incoh, 
       case 0: XCB_LAUNCH(4, 4, 32); break;                                      // default: 4-wave workgroups, B through LDS
       case 1: hipLaunchKernelGGL(k_xcorr_valu, XC1_ARGS); break;                // plain-VALU twin
       case 2: hipLaunchKernelGGL(k_xcorr_mfma, XC1_ARGS); break;                // 1-wave workgroups, B from L2 (round-1 baseline)
-      case 3: hipLaunchKernelGGL((k_xcorr_mfma_t<5, false, 4>), XC1_ARGS); break;
-      case 4: hipLaunchKernelGGL((k_xcorr_mfma_t<6, false, 4>), XC1_ARGS); break;
-      case 5: XCB_LAUNCH(4, 4, 16); break;
-      case 6: XCB_LAUNCH(4, 8, 32); break;
-      case 7: XCB_LAUNCH(4, 2, 32); break;
       default: XCB_LAUNCH(4, 4, 32); break;
     }
     ++launches;

@@ -215,6 +215,18 @@ __global__ __launch_bounds__(128) void k_cell_prep(const lcs_cell *__restrict__ 
   }
 }
 
+// Rows of the time-frequency grid that the fused chain ever reads: the CRS symbols 0, 1, n_symb-3 of
+// every slot (tfoec estimates, channel estimate) and PBCH symbols 0..3 of slot 1 of every frame
+// (decode_mib) -- 45 % of the 854.  The stage entry points produce full grids (`needed_only` = 0).
+__device__ __forceinline__ bool pbch_row(int t, int n_symb) {
+  const int slot = t / n_symb, sym = t - slot * n_symb;
+  return (slot % 20) == 1 && sym <= 3;
+}
+__device__ __forceinline__ bool tfg_row_needed(int t, int n_symb) {
+  const int sym = t % n_symb;
+  return sym == 0 || sym == 1 || sym == n_symb - 3 || pbch_row(t, n_symb);
+}
+
 // ------------------------------------------------------------------ extract_tfg: grid
 // 8 OFDM symbols per workgroup pass: frequency-correct 8x128 samples of the capture buffer into
 // LDS (the reference rotates all 153600 samples per cell, ref :892; only the 854x128 that feed a
@@ -227,17 +239,18 @@ __global__ __launch_bounds__(TFG_THREADS) void k_tfg(const lcs_cell *__restrict_
                                                      const float2 *__restrict__ cap32,
                                                      const double2 *__restrict__ cap64, uint32_t n_cap,
                                                      const double *__restrict__ ts, double *__restrict__ scratch,
-                                                     double2 *__restrict__ tfg) {
+                                                     double2 *__restrict__ tfg, int needed_only) {
   LCS_TAIL_PRIO();
   __shared__ cd2 W[128];
   __shared__ cd2 win[TFG_SYM][128];
-  __shared__ int s_loc[TFG_SYM];
+  __shared__ int s_loc[TFG_SYM], s_row[TFG_SYM];
   const int tid = threadIdx.x;
   if (tid < 128) { double s, c; sincospi((double)tid / 64.0, &s, &c); W[tid] = mk(c, -s); }
   const int nw = *n_work;
-  const int jobs_per_item = (ROWS + TFG_SYM - 1) / TFG_SYM;
+  // a job = 8 consecutive rows (full grid), or the needed rows of one slot pair (at most 5 + 3)
+  const int jobs_per_item = needed_only ? 61 : (ROWS + TFG_SYM - 1) / TFG_SYM;
   for (int job = blockIdx.x; job < nw * jobs_per_item; job += gridDim.x) {
-    const int it = job / jobs_per_item, t0 = (job % jobs_per_item) * TFG_SYM;
+    const int it = job / jobs_per_item, jj = job % jobs_per_item;
     double *sc = scratch + (size_t)it * CS_SIZE;
     const int n_ofdm = (int)sc[CS_N_OFDM];
     const double k_factor = sc[CS_KFACTOR];
@@ -250,12 +263,24 @@ __global__ __launch_bounds__(TFG_THREADS) void k_tfg(const lcs_cell *__restrict_
     const double kk = (-c.freq_fine) / ((p.fs_prog * k_factor) / 2);
     __syncthreads();
     PH(30);
-    if (tid < TFG_SYM) s_loc[tid] = (t0 + tid < n_ofdm) ? d_round_i(tsi[t0 + tid]) : 0;
+    if (tid < TFG_SYM) {
+      int row = -1;
+      if (!needed_only) row = jj * TFG_SYM + tid;
+      else {            // the tid-th needed row of slots 2 jj, 2 jj + 1
+        const int n_symb = cell_n_symb(c), r0 = jj * 2 * n_symb;
+        int k = -1;
+        for (int r = 0; r < 2 * n_symb; ++r)
+          if (tfg_row_needed(r0 + r, n_symb) && ++k == tid) { row = r0 + r; break; }
+      }
+      if (row >= n_ofdm) row = -1;
+      s_row[tid] = row;
+      s_loc[tid] = (row >= 0) ? d_round_i(tsi[row]) : 0;
+    }
     __syncthreads();
     for (int e = tid; e < TFG_SYM * 128; e += TFG_THREADS) {
       const int s = e >> 7, n = e & 127;
       cd2 v = mk(0, 0);
-      if (t0 + s < n_ofdm) {
+      if (s_row[s] >= 0) {
         const long src = (long)s_loc[s] + n;
         if (src >= 0 && (uint64_t)src < n_cap) {
           const double2 x = cap_at(cap, (size_t)src);
@@ -292,8 +317,8 @@ __global__ __launch_bounds__(TFG_THREADS) void k_tfg(const lcs_cell *__restrict_
       const cd2 *acc = half ? accp : accm;
 #pragma unroll
       for (int q = 0; q < TFG_SYM / 4; ++q) {
-        const int t = t0 + g + 4 * q;
-        if (t >= n_ofdm) continue;
+        const int t = s_row[g + 4 * q];
+        if (t < 0) continue;
         cd2 a = cdivr(acc[q], sqrt(128.0));
         const double ideal = tsi[t];
         const double late = (double)d_round_i(ideal) - ideal;
@@ -413,7 +438,8 @@ __global__ __launch_bounds__(TF_THREADS) void k_tfoec_est(lcs_cell *__restrict__
 #define TFA_THREADS 192
 __global__ __launch_bounds__(TFA_THREADS) void k_tfoec_apply(const int *__restrict__ n_work, const double2 *__restrict__ tfg,
                                                              const double *__restrict__ ts, const double *__restrict__ scratch,
-                                                             double2 *__restrict__ tfg_comp) {
+                                                             const lcs_cell *__restrict__ cells, double2 *__restrict__ tfg_comp,
+                                                             int needed_only) {
   LCS_TAIL_PRIO();
   __shared__ cd2 comp[NSC];
   const int tid = threadIdx.x;
@@ -427,6 +453,7 @@ __global__ __launch_bounds__(TFA_THREADS) void k_tfoec_apply(const int *__restri
     const double2 *g = tfg + (size_t)it * ROWS * NSC;
     double2 *gc = tfg_comp + (size_t)it * ROWS * NSC;
     const double *tsi = ts + (size_t)it * ROWS;
+    const int n_symb = cell_n_symb(cells[it]);
     if (it != comp_it) {     // per-subcarrier rotation of the timing correction (ref :1061-1064)
       __syncthreads();
       if (tid < NSC) {
@@ -440,7 +467,8 @@ __global__ __launch_bounds__(TFA_THREADS) void k_tfoec_apply(const int *__restri
     }
     for (int e = tid; e < TFA_ROWS * NSC; e += TFA_THREADS) {
       const int t = t0 + e / NSC, i = e % NSC;
-      if (t < n_ofdm) st(&gc[(size_t)t * NSC + i], cmul(foc_value(g, t, i, tsi[t], k_res, residual_f), comp[i]));
+      if (t < n_ofdm && (!needed_only || tfg_row_needed(t, n_symb)))
+        st(&gc[(size_t)t * NSC + i], cmul(foc_value(g, t, i, tsi[t], k_res, residual_f), comp[i]));
     }
   }
 }
@@ -526,7 +554,7 @@ __device__ __forceinline__ int ce_rs_count(int port, int n_symb, int n_ofdm) {
 #define CE_NCHUNK ((CE_MAX_RS + CE_CH - 1) / CE_CH)   // 6 (scratch holds 8 partials per port)
 __global__ __launch_bounds__(CE_THREADS) void k_chan_est(const lcs_cell *__restrict__ cells, const int *__restrict__ n_work,
                                                           const double2 *__restrict__ tfg_comp,
-                                                          double *__restrict__ scratch, double2 *__restrict__ ce) {
+                                                          double *__restrict__ scratch, double2 *__restrict__ ce, int pbch_only) {
   LCS_TAIL_PRIO();
   __shared__ cd2 ce_raw[(CE_CH + 3) * 12];     // RS rows r0 .. r1 of this chunk (one halo row each side)
   __shared__ cd2 ce_filt[(CE_CH + 1) * 12];    // RS rows c0 .. f1
@@ -623,6 +651,9 @@ __global__ __launch_bounds__(CE_THREADS) void k_chan_est(const lcs_cell *__restr
     // pair; their column counters are advanced too (closed form of the same while loop).
     const int y_first = rs_set(c0), y_last = rs_set(min(c1, n_rs - 1));
     for (int yy = y_first + 1 + tid; yy <= y_last; yy += CE_THREADS) {
+      // the fused chain only ever reads the channel estimate on PBCH rows (`pbch_only`); the last RS row
+      // is kept as the source of the edge copy below
+      if (pbch_only && !pbch_row(yy, n_symb) && yy != rs_set(n_rs - 1)) continue;
       int t;
       if (port <= 1) {
         const int j = yy / n_symb, rem = yy - j * n_symb;
@@ -691,9 +722,11 @@ __global__ __launch_bounds__(CE_THREADS) void k_chan_est(const lcs_cell *__restr
     // (the first RS row is written by chunk 0, the last one by the chunk that owns the last row pair)
     const int first = rs_set(0), last = rs_set(n_rs - 1);
     if (chunk == 0)
-      for (int e = tid; e < first * NSC; e += CE_THREADS) out[e] = out[(size_t)first * NSC + e % NSC];
+      for (int e = tid; e < first * NSC; e += CE_THREADS)
+        if (!pbch_only || pbch_row(e / NSC, n_symb)) out[e] = out[(size_t)first * NSC + e % NSC];
     if (c1 >= n_rs - 1 && c0 <= max(n_rs - 2, 0))
-      for (int e = (last + 1) * NSC + tid; e < n_ofdm * NSC; e += CE_THREADS) out[e] = out[(size_t)last * NSC + e % NSC];
+      for (int e = (last + 1) * NSC + tid; e < n_ofdm * NSC; e += CE_THREADS)
+        if (!pbch_only || pbch_row(e / NSC, n_symb)) out[e] = out[(size_t)last * NSC + e % NSC];
     __syncthreads();
   }
 }
@@ -941,7 +974,7 @@ int lcs_launch_tfg(lcs_ctx *c, uint32_t n_cap, bool with_rs) {
   hipLaunchKernelGGL(k_cell_prep, dim3(GRID_ITEMS), dim3(128), 0, c->stream, c->cells_out, c->work_items, c->n_work, c->params,
                      c->d_pn_jump, c->tfg_ts, c->cell_scratch, with_rs ? 3 : 1);
   hipLaunchKernelGGL(k_tfg, dim3(4096), dim3(TFG_THREADS), 0, c->stream, c->cells_out, c->work_items, c->n_work, c->params,
-                     c->cap32, c->cap64_valid ? c->cap64 : nullptr, n_cap, c->tfg_ts, c->cell_scratch, c->tfg);
+                     c->cap32, c->cap64_valid ? c->cap64 : nullptr, n_cap, c->tfg_ts, c->cell_scratch, c->tfg, c->needed_rows_only ? 1 : 0);
   HIPCHK(c, hipGetLastError());
   return LCS_OK;
 }
@@ -956,14 +989,14 @@ int lcs_launch_tfoec(lcs_ctx *c, int n_items) {
   hipLaunchKernelGGL(k_tfoec_est, dim3(GRID_ITEMS), dim3(TF_THREADS), 0, c->stream, c->cells_out, c->work_items, c->n_work,
                      c->params, c->tfg, c->tfg_ts, c->cell_scratch, c->tfg_ts_comp);
   hipLaunchKernelGGL(k_tfoec_apply, dim3(2048), dim3(TFA_THREADS), 0, c->stream, c->n_work, c->tfg, c->tfg_ts, c->cell_scratch,
-                     c->tfg_comp);
+                     c->cells_out, c->tfg_comp, c->needed_rows_only ? 1 : 0);
   HIPCHK(c, hipGetLastError());
   return LCS_OK;
 }
 int lcs_launch_mib(lcs_ctx *c, int n_items) {
   (void)n_items;
   hipLaunchKernelGGL(k_chan_est, dim3(GRID_ITEMS, 4, CE_NCHUNK), dim3(CE_THREADS), 0, c->stream, c->cells_out, c->n_work,
-                     c->tfg_comp, c->cell_scratch, c->ce);
+                     c->tfg_comp, c->cell_scratch, c->ce, c->needed_rows_only ? 1 : 0);
   hipLaunchKernelGGL(k_pbch, dim3(GRID_ITEMS, 12), dim3(PB_THREADS), 0, c->stream, c->cells_out, c->n_work, c->tfg_comp,
                      c->ce, c->cell_scratch, c->d_pbch_scr, c->d_derm_inv);
   hipLaunchKernelGGL(k_mib_select, dim3((LCS_MAX_WORK + 63) / 64), dim3(64), 0, c->stream, c->cells_out, c->n_work,

@@ -57,7 +57,7 @@ def test_mfma_and_valu_kernels_are_bit_identical(S, capbuf_0000):
     assert bad.size == 0, f"{len(bad)} of {a['single'].size} elements differ, first {bad[:5].tolist()}: " \
                           f"{a['single'][tuple(bad[0])]} vs {b['single'][tuple(bad[0])]}"
     assert np.array_equal(a["frq"], b["frq"]) and np.array_equal(a["pow"], b["pow"])
-    for v in range(2, 8):          # tiling / occupancy variants of the MFMA kernel
+    for v in (2,):                 # the one-wave MFMA kernel
         S.set_xcorr_variant(v)
         c = S.xcorr_pss(cap, f, 2, fc, fc, FS)
         S.set_xcorr_variant(0)
