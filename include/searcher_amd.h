@@ -192,7 +192,45 @@ class Searcher {
     for (int i = 0; i < n && i < (int)out.size(); ++i) cells.push_back(Cell(out[i]));
   }
 
+  // LO calibration step of LTE-Tracker (src/LTE-Tracker.cpp:565-741) on one recorded buffer: search the
+  // +-ppm grid shifted by the current correction (:586), keep the strongest decoded cell (:712-722) and
+  // return its residual frequency offset; *correction_residual gets the factor of :724-731.  Returns
+  // false when no cell could be decoded (the reference loops on a fresh capture in that case).
+  bool kalibrate(const cn::cvec &capbuf, double fc_requested, double fc_programmed, double fs_programmed, double ppm,
+                 double correction, Cell &best, double *correction_residual = 0) {
+    const int n_extra = (int)std::floor((fc_requested * ppm / 1e6 + 2.5e3) / 5e3);
+    cn::vec f_search_set;
+    f_search_set.set_size(2 * n_extra + 1);
+    for (int i = -n_extra; i <= n_extra; ++i) f_search_set._data()[i + n_extra] = (fc_requested * correction - fc_requested) + 5000.0 * i;
+    std::list<Cell> cells;
+    search_capbuf(capbuf, f_search_set, fc_requested, fc_programmed, fs_programmed, cells);
+    if (cells.empty()) return false;
+    bool have = false;
+    for (std::list<Cell>::const_iterator it = cells.begin(); it != cells.end(); ++it)
+      if (!have || it->pss_pow > best.pss_pow) { best = *it; have = true; }
+    const double crystal_freq_actual = fc_programmed - best.freq_superfine;
+    if (correction_residual) *correction_residual = (fc_requested / fc_requested * fc_programmed) / crystal_freq_actual;
+    return true;
+  }
+
+  // Streaming searcher (src/searcher_thread.cpp:83-246): see lcs_stream_* in lcs.h
+  void stream_open(int fmt, uint32_t n_cap, double fc_requested, double fc_programmed, double fs_programmed) {
+    check(lcs_stream_open(h_, fmt, n_cap, fc_requested, fc_programmed, fs_programmed));
+  }
+  void stream_push(const void *samples, double f_off, const std::vector<int16_t> &tracked_n_id_cell) {
+    check(lcs_stream_push(h_, samples, f_off, tracked_n_id_cell.empty() ? 0 : &tracked_n_id_cell[0], (int)tracked_n_id_cell.size()));
+  }
+  int stream_collect(std::list<Cell> &new_cells, float *gpu_ms = 0) {   // returns the number of tracked cells seen again
+    std::vector<lcs_cell> out(LCS_MAX_CELLS_STREAM);
+    int n = 0, dup = 0;
+    check(lcs_stream_collect(h_, out.data(), (int)out.size(), &n, &dup, gpu_ms));
+    for (int i = 0; i < n && i < (int)out.size(); ++i) new_cells.push_back(Cell(out[i]));
+    return dup;
+  }
+  void stream_close() { check(lcs_stream_close(h_)); }
+
  private:
+  enum { LCS_MAX_CELLS_STREAM = 64 };
   void check(int rc) {
     if (rc != LCS_OK) throw error(std::string("liblcs_amd: ") + lcs_last_error(h_));
   }

@@ -250,6 +250,22 @@ class Searcher:
         self._chk(self._lib.lcs_sync(self._h), "lcs_sync")
 
 
+def kalibrate(searcher: "Searcher", capbuf, fc_requested: float, fc_programmed: float, fs_programmed: float,
+              ppm: float = 120.0, correction: float = 1.0):
+    """LO calibration step of LTE-Tracker (src/LTE-Tracker.cpp:565-741) on one capture buffer: search
+    the +-ppm grid shifted by the current correction (:586), take the strongest decoded cell (:712-722)
+    and return (best cell, residual frequency offset, correction_residual of :724-731), or None when no
+    cell was decoded (the reference then tries again on a fresh capture)."""
+    n_extra = int(np.floor((fc_requested * ppm / 1e6 + 2.5e3) / 5e3))
+    f = (fc_requested * correction - fc_requested) + np.arange(-n_extra, n_extra + 1) * 5000.0
+    cells, _ = searcher.search_capbuf(capbuf, f, fc_requested, fc_programmed, fs_programmed)
+    if not cells:
+        return None
+    best = max(cells, key=lambda c: c.pss_pow)
+    crystal_freq_actual = fc_programmed - best.freq_superfine
+    return best, best.freq_superfine, (fc_requested / fc_requested * fc_programmed) / crystal_freq_actual
+
+
 def z_th1(sp_incoherent, n_comb_xc, ds_comb_arm=DS_COMB_ARM, thresh1_n_nines=12):
     """Detection threshold of the CLI main loop (src/CellSearch.cpp:500-503)."""
     L = capi.load()

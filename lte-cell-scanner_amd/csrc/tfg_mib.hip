@@ -350,15 +350,20 @@ __device__ __forceinline__ int rs_shift(const double *sc, int n_symb, int slot, 
 // corrections to the whole 854x72 grid with every element independent (grid = cells x row tiles).
 // The value written for an element is (tfg * rot_f) * rot_late, then * rot_delay: the reference's
 // order of the three complex products (ref :992-1005, :1061-1064).
-__device__ __forceinline__ cd2 foc_value(const double2 *g, int t, int i, double ts_t, double k_res, double residual_f) {
+// rot_f of one row: exp(j 2 pi (-residual_f) ts_comp / (FS_LTE/16)), the same for its 72 subcarriers
+__device__ __forceinline__ cd2 foc_row_rot(double ts_t, double k_res, double residual_f) {
   const double tc = k_res * ts_t;
   double a_im = 1.0;
   a_im = a_im * 2; a_im = a_im * M_PI; a_im = a_im * (-residual_f); a_im = a_im * tc; a_im = a_im / (FS_LTE / 16);
+  return mk(cos(a_im), sin(a_im));
+}
+__device__ __forceinline__ cd2 foc_value(const double2 *g, int t, int i, double ts_t, double k_res, cd2 rot_f) {
+  const double tc = k_res * ts_t;
   const double late = ts_t - tc;
   double k_im = -1.0;
   k_im = k_im * 2; k_im = k_im * M_PI; k_im = k_im * late; k_im = k_im / 128;
   const double ph = k_im * (double)cn_of(i);
-  const cd2 v = cmul(ld(&g[(size_t)t * NSC + i]), mk(cos(a_im), sin(a_im)));
+  const cd2 v = cmul(ld(&g[(size_t)t * NSC + i]), rot_f);
   return cmul(v, mk(cos(ph), sin(ph)));
 }
 
@@ -370,6 +375,7 @@ __global__ __launch_bounds__(TF_THREADS) void k_tfoec_est(lcs_cell *__restrict__
                                                           double *__restrict__ scratch, double *__restrict__ ts_comp) {
   LCS_TAIL_PRIO();
   __shared__ cd2 red[TF_THREADS / 64];
+  __shared__ cd2 rowrot[ROWS];
   const int tid = threadIdx.x;
   for (int it = blockIdx.x; it < *n_work; it += gridDim.x) {
     const lcs_cell c = cells[it];
@@ -396,9 +402,14 @@ __global__ __launch_bounds__(TF_THREADS) void k_tfoec_est(lcs_cell *__restrict__
     PH(11);
     const double residual_f = atan2(foe.im, foe.re) / (2 * M_PI) / 0.0005;
     const double k_res = (p.fc_req - residual_f) / p.fc_prog;
-    for (int t = tid; t < n_ofdm; t += TF_THREADS) tsc[t] = k_res * tsi[t];
+    for (int t = tid; t < n_ofdm; t += TF_THREADS) {
+      tsc[t] = k_res * tsi[t];
+      const int sym = t % n_symb;
+      if (sym == 0 || sym == n_symb - 3) rowrot[t] = foc_row_rot(tsi[t], k_res, residual_f);   // the rows the TOE reads
+    }
+    __syncthreads();
     // TOE (ref :1012-1058) on the frequency-corrected RS samples
-#define GC(row, col) foc_value(g, (row), (col), tsi[(row)], k_res, residual_f)
+#define GC(row, col) foc_value(g, (row), (col), tsi[(row)], k_res, rowrot[(row)])
     part = mk(0, 0);
     for (int e = tid; e < (2 * n_slot - 1) * 23; e += TF_THREADS) {
       const int t = e / 23, j = e % 23;
@@ -442,6 +453,7 @@ __global__ __launch_bounds__(TFA_THREADS) void k_tfoec_apply(const int *__restri
                                                              int needed_only) {
   LCS_TAIL_PRIO();
   __shared__ cd2 comp[NSC];
+  __shared__ cd2 rowrot[TFA_ROWS];
   const int tid = threadIdx.x;
   const int tiles = (ROWS + TFA_ROWS - 1) / TFA_ROWS;
   int comp_it = -1;
@@ -465,10 +477,13 @@ __global__ __launch_bounds__(TFA_THREADS) void k_tfoec_apply(const int *__restri
       __syncthreads();
       comp_it = it;
     }
+    __syncthreads();
+    if (tid < TFA_ROWS && t0 + tid < n_ofdm) rowrot[tid] = foc_row_rot(tsi[t0 + tid], k_res, residual_f);
+    __syncthreads();
     for (int e = tid; e < TFA_ROWS * NSC; e += TFA_THREADS) {
       const int t = t0 + e / NSC, i = e % NSC;
       if (t < n_ofdm && (!needed_only || tfg_row_needed(t, n_symb)))
-        st(&gc[(size_t)t * NSC + i], cmul(foc_value(g, t, i, tsi[t], k_res, residual_f), comp[i]));
+        st(&gc[(size_t)t * NSC + i], cmul(foc_value(g, t, i, tsi[t], k_res, rowrot[e / NSC]), comp[i]));
     }
   }
 }

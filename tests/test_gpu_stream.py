@@ -72,3 +72,16 @@ def test_sweep_tool_single_gpu(tmp_path):
     r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert r["carriers"] == 12 and r["n_gpus"] == 1 and len(r["cells"]) >= 2
     assert all(0 <= cid < 504 and nrb in (6, 15, 25, 50, 75, 100) for cid, _, nrb, _ in r["cells"])
+
+
+def test_kalibrate_on_recorded_buffer(pkg):
+    """LTE-Tracker's calibration step (src/LTE-Tracker.cpp:565-741) on capbuf_0000: the strongest cell is 277
+    and its residual offset gives the crystal correction the CellSearch table prints for it."""
+    cap = iq_u8_to_capbuf(golden("capbuf_0000")["iq_u8"])
+    with pkg.Searcher(0) as S:
+        best, resid, corr = pkg.kalibrate(S, cap, FC, FC, FS, ppm=120.0, correction=1.0)
+        assert best.n_id_cell() == 277 and abs(resid - 35228.46) < 1.0
+        assert abs(corr - FC / (FC - resid)) < 1e-15
+        # a correction that moves the grid by +35 kHz finds the same cell on the shifted grid
+        best2, resid2, _ = pkg.kalibrate(S, cap, FC, FC, FS, ppm=20.0, correction=1.0 + 35e3 / FC)
+        assert best2.n_id_cell() == 277 and abs(resid2 - resid) < 1.0
