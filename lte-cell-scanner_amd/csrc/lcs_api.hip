@@ -76,10 +76,25 @@ int ensure_ws(lcs_ctx *c, int n_slots, uint32_t n_cap, int n_f, bool debug) {
     A(incoh, S * NE * n_f);
   }
 #undef A
+  if (c->capb) { (void)hipFree(c->capb); c->capb = nullptr; }
+  if (c->bt16) { (void)hipFree(c->bt16); c->bt16 = nullptr; }
+  c->bf16_ready = false;
   c->cap_slots = n_slots;
   c->cap_n_cap = n_cap;
   c->cap_n_f = n_f;
   c->cap_debug = debug;
+  return LCS_OK;
+}
+
+// Buffers of the bf16 correlation path (u8 sources), sized like the current workspace.
+int ensure_bf16(lcs_ctx *c) {
+  if (c->bf16_ready) return LCS_OK;
+  const size_t S = (size_t)c->cap_slots;
+  const int G = (3 * c->cap_n_f + LCS_TG - 1) / LCS_TG;
+  int rc;
+  if ((rc = dev_alloc(c, &c->capb, S * c->cap_n_cap))) return rc;
+  if ((rc = dev_alloc(c, &c->bt16, S * LCS_NW_MAX * G * (size_t)(LCS_BF_KB_MAX * 6 * 64)))) return rc;
+  c->bf16_ready = true;
   return LCS_OK;
 }
 
@@ -116,6 +131,7 @@ int validate_grid(lcs_ctx *c, const XcGeom &geo, const double *fset, double fc_r
         const int s = (int)std::rint((((double)w * .005) * kf) * fs_prog);
         if (f == f_lo) { mn = mx = s; } else { mn = std::min(mn, s); mx = std::max(mx, s); }
       }
+      c->grid_max_k2 = std::max(c->grid_max_k2, (137 + (mx - mn) + 1) / 2);
       if ((137 + (mx - mn) + 1) / 2 > LCS_KP2_MAX - LCS_KP2_UNROLL) {
         c->err = "f_search_set too sparse: window-start spread inside one 16-template group exceeds the fused kernel's limit";
         return LCS_ERR_BAD_ARG;
@@ -230,7 +246,7 @@ void lcs_destroy(lcs_ctx *c) {
                   c->incoh, c->sref, c->pow_, c->work, c->spinc, c->zth, c->sp, c->frq, c->peaks, c->npeaks, c->xc,
                   c->work_items, c->n_work, c->tfg, c->tfg_comp, c->ce, c->tfg_ts, c->tfg_ts_comp, c->cell_scratch,
                   c->cells_out, c->d_pss_td, c->d_pss_fd, c->d_sss_fd, c->d_pbch_scr, c->d_derm_inv, c->d_dbg, c->pk_items, c->n_pk,
-                  c->sss_ws, c->d_pn_jump};
+                  c->sss_ws, c->d_pn_jump, c->capb, c->bt16};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   if (c->h_pinned) (void)hipHostFree(c->h_pinned);
   if (c->ev_xc0) (void)hipEventDestroy(c->ev_xc0);
@@ -245,7 +261,7 @@ void lcs_destroy(lcs_ctx *c) {
 const char *lcs_last_error(const lcs_ctx *c) { return c ? c->err.c_str() : "null context"; }
 
 int lcs_set_xcorr_variant(lcs_ctx *c, int variant) {
-  if (!c || variant < 0 || variant > 2) return LCS_ERR_BAD_ARG;
+  if (!c || variant < 0 || variant > 3) return LCS_ERR_BAD_ARG;
   c->xcorr_variant = variant;
   return LCS_OK;
 }
@@ -274,6 +290,7 @@ int lcs_xcorr_pss(lcs_ctx *c, const double *capbuf, uint32_t n_cap, const double
   SlotParams p{fc_req, fc_prog, fs_prog};
   HIPCHK(c, hipMemcpyAsync(c->cap64, capbuf, sizeof(double2) * n_cap, hipMemcpyHostToDevice, c->stream));
   c->cap64_valid = true;
+  c->use_bf16 = false;      // complex<double> input: fp32 correlation
   HIPCHK(c, hipMemcpyAsync(c->fset, f_search_set, sizeof(double) * n_f, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->params, &p, sizeof(p), hipMemcpyHostToDevice, c->stream));
   if ((rc = lcs_launch_ingest(c, nullptr, 2, 1, n_cap))) return rc;
@@ -346,6 +363,7 @@ int lcs_batch_enqueue(lcs_ctx *c, const void *d_capbufs, int fmt, int n_buf, uin
   if ((rc = pinned(c, sizeof(SlotParams) * n_buf + sizeof(double) * LCS_NF_MAX))) return rc;
   SlotParams *hp = (SlotParams *)c->h_pinned;
   double *hf = (double *)(hp + n_buf);
+  c->grid_max_k2 = 0;
   for (int i = 0; i < n_buf; ++i) {
     hp[i] = SlotParams{fc_requested[i], fc_programmed[i], fs_programmed};
     if (i == 0 || fc_requested[i] != fc_requested[i - 1] || fc_programmed[i] != fc_programmed[i - 1])
@@ -355,6 +373,10 @@ int lcs_batch_enqueue(lcs_ctx *c, const void *d_capbufs, int fmt, int n_buf, uin
   HIPCHK(c, hipMemcpyAsync(c->params, hp, sizeof(SlotParams) * n_buf, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->fset, hf, sizeof(double) * n_f, hipMemcpyHostToDevice, c->stream));
   c->cap64_valid = false;
+  // u8 I/Q is exact in bf16: the correlation runs as three exact bf16 products per tap (pss_xcorr_bf16.hip)
+  static const bool no_bf16 = getenv("LCS_NO_BF16") != nullptr;   // measurement knob
+  c->use_bf16 = fmt == LCS_FMT_IQ_U8 && c->xcorr_variant == 0 && !no_bf16 && 2 * c->grid_max_k2 <= 16 * LCS_BF_KB_MAX;
+  if (c->use_bf16 && (rc = ensure_bf16(c))) return rc;
   if ((rc = lcs_launch_ingest(c, d_capbufs, fmt, n_buf, n_cap))) return rc;
   if ((rc = lcs_launch_xcorr(c, n_buf, geo, false, true))) return rc;
   if ((rc = lcs_launch_peak_search(c, n_buf, geo, std::pow(10.0, -12.0 / 10.0), true))) return rc;
@@ -577,6 +599,7 @@ int lcs_search_capbuf(lcs_ctx *c, const double *capbuf, uint32_t n_cap, const do
   SlotParams p{fc_req, fc_prog, fs_prog};
   HIPCHK(c, hipMemcpyAsync(c->cap64, capbuf, sizeof(double2) * n_cap, hipMemcpyHostToDevice, c->stream));
   c->cap64_valid = true;
+  c->use_bf16 = false;      // complex<double> input: fp32 correlation
   HIPCHK(c, hipMemcpyAsync(c->fset, f_search_set, sizeof(double) * n_f, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->params, &p, sizeof(p), hipMemcpyHostToDevice, c->stream));
   if ((rc = lcs_launch_ingest(c, nullptr, 2, 1, n_cap))) return rc;
@@ -627,6 +650,7 @@ int stream_chain(lcs_ctx *c) {
   StreamHost *h = c->st_host;
   const XcGeom geo = make_geo(c->st_n_cap, 1, 2);
   int rc;
+  c->use_bf16 = c->st_fmt == LCS_FMT_IQ_U8 && c->xcorr_variant == 0 && getenv("LCS_NO_BF16") == nullptr;
   HIPCHK(c, hipMemcpyAsync(c->st_din, c->st_hin, c->st_in_bytes, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->params, &h->p, sizeof(SlotParams), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->fset, &h->f, sizeof(double), hipMemcpyHostToDevice, c->stream));
@@ -677,6 +701,7 @@ int lcs_stream_open(lcs_ctx *c, int fmt, uint32_t n_cap, double fc_requested, do
   HIPCHK(c, hipSetDevice(c->device));
   if ((rc = ensure_ws(c, 1, n_cap, 1, false))) return rc;
   if ((rc = ensure_percell(c))) return rc;
+  if (fmt == LCS_FMT_IQ_U8 && (rc = ensure_bf16(c))) return rc;
   c->st_fmt = fmt;
   c->st_n_cap = n_cap;
   c->st_in_bytes = (size_t)n_cap * (fmt == LCS_FMT_IQ_U8 ? 2 : sizeof(float2));

@@ -25,7 +25,11 @@
 // Every kernel other than the PSS correlation is small and latency-bound; in the pipelined chain it
 // shares CUs with the next batch's correlation waves.  Raising the wave priority lets the SIMD
 // arbiter issue these few waves ahead of the MFMA stream instead of round-robin behind 4-5 of them.
+#ifdef LCS_NO_TAIL_PRIO
+#define LCS_TAIL_PRIO() do { } while (0)
+#else
 #define LCS_TAIL_PRIO() __builtin_amdgcn_s_setprio(3)
+#endif
 #define LCS_TG 16            // templates per MFMA column group
 #define LCS_G_MAX ((3 * LCS_NF_MAX + LCS_TG - 1) / LCS_TG)
 #define LCS_KP2_MAX 128      // tap pairs per (window, group): 137 taps + up to 119 samples of spread
@@ -33,6 +37,7 @@
 #define LCS_LAG_TILE 64      // lags per wave
 #define LCS_PS 336           // LDS plane stride in floats: >= 64 + 2*KP2_MAX, == 16 (mod 32)
 #define LCS_MAXP 64          // peaks kept per capture buffer
+#define LCS_BF_KB_MAX 10     // 16-tap blocks of the bf16 correlation kernel: taps + window-start spread <= 160
 #define LCS_MAX_WORK 512     // cells carried into the TFG/MIB stages per batch
 #define LCS_TFG_ROWS 854
 #define LCS_CELL_SCRATCH 4608 // doubles of per-cell scratch (RS table, shifts, noise powers, PBCH candidates)
@@ -103,6 +108,11 @@ struct lcs_ctx {
 
   // device buffers
   float2 *cap32 = nullptr;
+  uint32_t *capb = nullptr;          // capture buffer as (re, im) bf16 pairs -- written for u8 I/Q sources, where it is exact
+  uint4 *bt16 = nullptr;             // bf16 three-term template operands (pss_xcorr_bf16.hip)
+  bool bf16_ready = false;           // capb / bt16 allocated for the current workspace geometry
+  bool use_bf16 = false;             // this batch runs the bf16x3 correlation kernel
+  int grid_max_k2 = 0;               // largest tap-pair count (137 taps + window-start spread) seen by validate_grid
   double2 *cap64 = nullptr;          // slot 0 only: fp64 copy for the host (complex<double>) entry points
   bool cap64_valid = false;
   SlotParams *params = nullptr;
@@ -194,6 +204,9 @@ void pbch_deratematch_map(int n_e, uint8_t *out /*n_e*/);   // ref src/lte_lib.c
 // pss_xcorr.hip
 int lcs_launch_ingest(lcs_ctx *c, const void *d_src, int fmt, int n_buf, uint32_t n_cap);
 int lcs_launch_xcorr(lcs_ctx *c, int n_buf, const XcGeom &geo, bool want_incoh, bool time_it);
+// pss_xcorr_bf16.hip
+int lcs_launch_fill_btab_bf16(lcs_ctx *c, int n_buf, const XcGeom &geo);
+int lcs_launch_xcorr_bf16(lcs_ctx *c, hipStream_t sxc, const XcGeom &geo, int slot0, int n_slots, int xcd_map);
 int lcs_launch_single_layout(lcs_ctx *c, const XcGeom &geo, float *ref_layout, int to_ref);   // group-major <-> [t][idx][foi]
 int lcs_launch_xc_debug(lcs_ctx *c, const XcGeom &geo);   // raw xc for slot 0 (debug output only)
 // peak_search.hip

@@ -1,0 +1,256 @@
+// pss_xcorr_bf16.hip -- the PSS correlation for capture buffers that are EXACT in bf16.
+//
+// RTL-SDR samples are (u8 - 127) / 128: eight significant bits, i.e. exactly representable in
+// bfloat16.  The fp32 templates are split exactly into three bf16 terms (t = t1 + t2 + t3, 8 + 8 + 8
+// significand bits), every product sample * t_i is exact in fp32, and the matrix cores accumulate in
+// fp32: three v_mfma_f32_16x16x32_bf16 evaluate the same dot product as the fp32 kernel (same inputs,
+// fp32 accumulation, different summation order: deviation ~1e-7 relative, parity bar 1e-5) at 16/3
+// times the fp32 MFMA rate.  Same fused formulation as pss_xcorr.hip (correlation + 15-window
+// incoherent combining, window-start delays folded into the template table).
+//
+// Operands.  The complex product is taken as a real GEMM with K = 2 * taps:
+//   A[lag][2m], A[lag][2m+1] = xr[lag+m], xi[lag+m]      -- the capture buffer as it lies in memory
+//   B_re[2m], B_re[2m+1] = tr[m], -ti[m] ;  B_im[2m], B_im[2m+1] = ti[m], tr[m]
+// so one A operand feeds both the real and the imaginary accumulator.  A 16x16x32 MFMA consumes 16
+// taps; lane (i, kg) of the A operand holds the four consecutive samples lag_i + 16 kb + 4 kg .. +3
+// (16 bytes).  A is Toeplitz, so the operand of (lag sub-tile mt, tap block kb) depends on mt + kb
+// only: a wave keeps a sliding window of 8 operands in registers and reads ONE new operand per tap
+// block from LDS (4 dwords) for its 8 sub-tiles x 6 MFMAs.
+//
+// Tiling.  A 256-thread workgroup owns 512 output positions x one 16-template group; each wave 128
+// positions (8 sub-tiles of 16).  Per window the capture samples are staged once into LDS; the
+// template operands (6 x 1 KB per tap block: {re, im} x 3 split terms) stream through LDS double
+// buffered, one barrier per tap block.
+#include "lcs_internal.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+#define NW LCS_NW_MAX
+#define NFM LCS_NF_MAX
+#define GM LCS_G_MAX
+
+#define BF_LAGS 512
+#define BF_TILES ((LCS_N_IDX + BF_LAGS - 1) / BF_LAGS)
+#define BF_MT 8
+#define BF_AW (BF_LAGS + 16 * LCS_BF_KB_MAX + 16)     // staged samples per window
+#define BF_OPS 6                                      // B operands per tap block: re1 re2 re3 im1 im2 im3
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#define AS_BF(x) __builtin_bit_cast(bf16x8, (x))
+
+__device__ __forceinline__ uint32_t bf16_rne(float v) {   // finite inputs only
+  const uint32_t u = __float_as_uint(v);
+  return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ float bf16_val(uint32_t h) { return __uint_as_float(h << 16); }
+
+// bt16[slot][w][g][kb][op][lane] (uint4 = 8 bf16): lane (n, kg) holds k = 8 kg .. 8 kg + 7 of template
+// column c = 16 g + n, i.e. taps 16 kb + 4 kg .. +3 of the template delayed by start[w][foi(c)] - smin[w][g]
+// (zero outside its 137 taps), as (tr, -ti) pairs for the real and (ti, tr) pairs for the imaginary output.
+__global__ __launch_bounds__(256) void k_fill_btab_bf16(const float2 *__restrict__ tmpl, const int *__restrict__ start,
+                                                        const int *__restrict__ smin, const int *__restrict__ kp2,
+                                                        uint4 *__restrict__ bt16, XcGeom geo) {
+  LCS_TAIL_PRIO();
+  const int slot = blockIdx.z;
+  const int wg = blockIdx.y;
+  const int w = wg / geo.G, g = wg % geo.G;
+  const int k2 = kp2[((size_t)slot * NW + w) * GM + g];
+  const int s0 = smin[((size_t)slot * NW + w) * GM + g];
+  const int nkb = min((2 * k2 + 15) / 16, LCS_BF_KB_MAX);
+  uint4 *out = bt16 + (((size_t)slot * geo.n_comb + w) * geo.G + g) * (size_t)(LCS_BF_KB_MAX * BF_OPS * 64);
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < nkb * 64; e += gridDim.x * blockDim.x) {
+    const int kb = e >> 6, lane = e & 63;
+    const int c = g * LCS_TG + (lane & 15), kg = lane >> 4;
+    float vre[8], vim[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { vre[j] = 0.f; vim[j] = 0.f; }
+    if (c < geo.n_tmpl) {
+      const int foi = c / 3, t = c % 3;
+      const int delta = start[((size_t)slot * NW + w) * NFM + foi] - s0;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int tap = 16 * kb + 4 * kg + m - delta;
+        if (tap >= 0 && tap < 137) {
+          const float2 T = tmpl[(((size_t)slot * NFM + foi) * 3 + t) * 137 + tap];
+          vre[2 * m] = T.x; vre[2 * m + 1] = -T.y;
+          vim[2 * m] = T.y; vim[2 * m + 1] = T.x;
+        }
+      }
+    }
+    uint32_t h[BF_OPS][8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        float r = p ? vim[j] : vre[j];
+#pragma unroll
+        for (int sidx = 0; sidx < 3; ++sidx) {          // exact three-term split: r = h1 + h2 + h3
+          const uint32_t hb = bf16_rne(r);
+          h[3 * p + sidx][j] = hb;
+          r = r - bf16_val(hb);
+        }
+      }
+    }
+#pragma unroll
+    for (int op = 0; op < BF_OPS; ++op) {
+      uint4 q;
+      q.x = h[op][0] | (h[op][1] << 16); q.y = h[op][2] | (h[op][3] << 16);
+      q.z = h[op][4] | (h[op][5] << 16); q.w = h[op][6] | (h[op][7] << 16);
+      out[((size_t)kb * BF_OPS + op) * 64 + lane] = q;
+    }
+  }
+}
+
+__device__ __forceinline__ float pow2sum_bf(float re, float im) { return fmaf(re, re, im * im); }
+
+__global__ __launch_bounds__(256, 2) void k_xcorr_bf16x3(const uint32_t *__restrict__ capb, const int *__restrict__ smin,
+                                                         const int *__restrict__ kp2, const uint4 *__restrict__ bt16,
+                                                         float *__restrict__ sg, XcGeom geo, int slot0, int n_slots,
+                                                         int xcd_map) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int per_slot = BF_TILES * geo.G;
+  int q, sidx;
+  if (xcd_map) { sidx = blockIdx.x & 7; q = blockIdx.x >> 3; sidx += 8 * (q / per_slot); q = q % per_slot; }
+  else { sidx = blockIdx.x / per_slot; q = blockIdx.x % per_slot; }
+  if (sidx >= n_slots) return;
+  const int slot = slot0 + sidx, g = q / BF_TILES, idx0 = (q % BF_TILES) * BF_LAGS;
+  const int widx0 = idx0 + wave * (BF_MT * 16);
+  // live sub-tiles of this wave (wave-uniform): the last workgroup of a row runs past idx 9599
+  const int n_mt = min(max((LCS_N_IDX - widx0 + 15) / 16, 0), BF_MT);
+
+  __shared__ uint32_t ldsA[2][BF_AW];
+  __shared__ uint4 ldsB[2][BF_OPS * 64];
+  const uint32_t *cap = capb + (size_t)slot * geo.n_cap;
+  const int *smin_s = smin + (size_t)slot * NW * GM + g;
+  const int *kp2_s = kp2 + (size_t)slot * NW * GM + g;
+  const uint4 *bt_s = bt16 + ((size_t)slot * geo.n_comb * geo.G + g) * (size_t)(LCS_BF_KB_MAX * BF_OPS * 64);
+  const size_t bt_wstride = (size_t)geo.G * (LCS_BF_KB_MAX * BF_OPS * 64);
+  const int a_off = wave * (BF_MT * 16) + (lane & 15) + 4 * (lane >> 4);
+
+  f32x4 P[BF_MT];
+#pragma unroll
+  for (int mt = 0; mt < BF_MT; ++mt) P[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  constexpr int ASTEPS = (BF_AW + 255) / 256;
+  constexpr int BSTEPS = (BF_OPS * 64 + 255) / 256;
+  uint32_t preA[ASTEPS];
+  uint4 preB[BSTEPS];
+#define BF_LOAD_A(W)                                                                   \
+  {                                                                                    \
+    const int L0_ = idx0 + smin_s[(W) * GM];                                           \
+    _Pragma("unroll") for (int r_ = 0; r_ < ASTEPS; ++r_) {                            \
+      const int n_ = tid + 256 * r_;                                                   \
+      const uint32_t s_ = (uint32_t)(L0_ + n_);                                        \
+      preA[r_] = (n_ < BF_AW && s_ < geo.n_cap) ? cap[s_] : 0u;                        \
+    }                                                                                  \
+  }
+#define BF_LOAD_B(W, KB)                                                               \
+  {                                                                                    \
+    const uint4 *src_ = bt_s + (size_t)(W) * bt_wstride + (size_t)(KB) * (BF_OPS * 64); \
+    _Pragma("unroll") for (int r_ = 0; r_ < BSTEPS; ++r_)                              \
+      preB[r_] = (tid + 256 * r_ < BF_OPS * 64) ? src_[tid + 256 * r_] : make_uint4(0u, 0u, 0u, 0u); \
+  }
+#define BF_READ_A(DST, S)                                                              \
+  {                                                                                    \
+    const uint32_t *p_ = bufA + a_off + 16 * (S);                                      \
+    (DST) = (u32x4){p_[0], p_[1], p_[2], p_[3]};                                       \
+  }
+  // Pipeline: LDS buffer cb holds the B operands of tap block (w, kb); preB holds the block after it
+  // (already requested from L2); during the MFMAs of (w, kb) preB is written to the other buffer and
+  // the block after that is requested.  One barrier per tap block plus one per window (capture samples).
+  BF_LOAD_A(0);
+  BF_LOAD_B(0, 0);
+#pragma unroll
+  for (int r = 0; r < BSTEPS; ++r)
+    if (tid + 256 * r < BF_OPS * 64) ldsB[0][tid + 256 * r] = preB[r];
+  int cb = 0;
+  int nkb = min((2 * kp2_s[0] + 15) / 16, LCS_BF_KB_MAX);
+  if (nkb > 1) BF_LOAD_B(0, 1)
+  else if (geo.n_comb > 1) BF_LOAD_B(1, 0)
+  for (int w = 0; w < geo.n_comb; ++w) {
+    const int nkb_next = (w + 1 < geo.n_comb) ? min((2 * kp2_s[(w + 1) * GM] + 15) / 16, LCS_BF_KB_MAX) : 0;
+    uint32_t *bufA = ldsA[w & 1];
+#pragma unroll
+    for (int r = 0; r < ASTEPS; ++r) {
+      const int n = tid + 256 * r;
+      if (n < BF_AW) bufA[n] = preA[r];
+    }
+    if (w + 1 < geo.n_comb) BF_LOAD_A(w + 1);
+    __syncthreads();
+    f32x4 aR[BF_MT], aI[BF_MT];
+#pragma unroll
+    for (int mt = 0; mt < BF_MT; ++mt) { aR[mt] = (f32x4){0.f, 0.f, 0.f, 0.f}; aI[mt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    u32x4 Aw[BF_MT];
+#pragma unroll
+    for (int s = 0; s < BF_MT - 1; ++s) BF_READ_A(Aw[s], s);
+#pragma unroll 1
+    for (int kb = 0; kb < nkb; ++kb) {
+      BF_READ_A(Aw[BF_MT - 1], kb + BF_MT - 1);
+      u32x4 B[BF_OPS];
+#pragma unroll
+      for (int op = 0; op < BF_OPS; ++op) { const uint4 t_ = ldsB[cb][op * 64 + lane]; B[op] = (u32x4){t_.x, t_.y, t_.z, t_.w}; }
+      // hand the prefetched block to the other LDS buffer and request the one after it
+      const bool more_w = kb + 1 < nkb;                       // next block is in this window
+      if (more_w || w + 1 < geo.n_comb) {
+#pragma unroll
+        for (int r = 0; r < BSTEPS; ++r)
+          if (tid + 256 * r < BF_OPS * 64) ldsB[cb ^ 1][tid + 256 * r] = preB[r];
+        if (kb + 2 < nkb) BF_LOAD_B(w, kb + 2)
+        else if (more_w) { if (w + 1 < geo.n_comb) BF_LOAD_B(w + 1, 0) }
+        else if (nkb_next > 1) BF_LOAD_B(w + 1, 1)
+        else if (w + 2 < geo.n_comb) BF_LOAD_B(w + 2, 0)
+      }
+#pragma unroll
+      for (int mt = 0; mt < BF_MT; ++mt) {
+        if (mt < n_mt) {                  // wave-uniform
+          aR[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AS_BF(Aw[mt]), AS_BF(B[0]), aR[mt], 0, 0, 0);
+          aI[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AS_BF(Aw[mt]), AS_BF(B[3]), aI[mt], 0, 0, 0);
+          aR[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AS_BF(Aw[mt]), AS_BF(B[1]), aR[mt], 0, 0, 0);
+          aI[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AS_BF(Aw[mt]), AS_BF(B[4]), aI[mt], 0, 0, 0);
+          aR[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AS_BF(Aw[mt]), AS_BF(B[2]), aR[mt], 0, 0, 0);
+          aI[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AS_BF(Aw[mt]), AS_BF(B[5]), aI[mt], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < BF_MT - 1; ++s) Aw[s] = Aw[s + 1];   // slide the Toeplitz window
+      __syncthreads();
+      cb ^= 1;
+    }
+#pragma unroll
+    for (int mt = 0; mt < BF_MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) P[mt][r] = P[mt][r] + pow2sum_bf(aR[mt][r], aI[mt][r]);
+    nkb = nkb_next;
+  }
+#undef BF_LOAD_A
+#undef BF_LOAD_B
+#undef BF_READ_A
+  const float ncomb = (float)geo.n_comb;
+  float *o = sg + (((size_t)slot * geo.G + g) * LCS_N_IDX) * LCS_TG + (lane & 15);
+#pragma unroll
+  for (int mt = 0; mt < BF_MT; ++mt) {
+    if (mt < n_mt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int idx = widx0 + mt * 16 + 4 * (lane >> 4) + r;
+        if (idx < LCS_N_IDX) o[(size_t)idx * LCS_TG] = __fdiv_rn(P[mt][r], ncomb);
+      }
+    }
+  }
+}
+
+// Launch both kernels of the bf16 path for slots [0, n_buf) on `sxc`; table fill goes to the main stream.
+int lcs_launch_fill_btab_bf16(lcs_ctx *c, int n_buf, const XcGeom &geo) {
+  hipLaunchKernelGGL(k_fill_btab_bf16, dim3(4, geo.n_comb * geo.G, n_buf), dim3(256), 0, c->stream, c->tmpl, c->start, c->smin,
+                     c->kp2, c->bt16, geo);
+  HIPCHK(c, hipGetLastError());
+  return LCS_OK;
+}
+int lcs_launch_xcorr_bf16(lcs_ctx *c, hipStream_t sxc, const XcGeom &geo, int slot0, int n_slots, int xcd_map) {
+  const unsigned grid = (unsigned)(BF_TILES * geo.G * n_slots);
+  hipLaunchKernelGGL(k_xcorr_bf16x3, dim3(grid), dim3(256), 0, sxc, c->capb, c->smin, c->kp2, c->bt16, c->single, geo, slot0,
+                     n_slots, xcd_map);
+  HIPCHK(c, hipGetLastError());
+  return LCS_OK;
+}

@@ -67,10 +67,48 @@ def test_batch_slots_are_independent_and_placement_invariant(S, pkg, synth_buf):
     d = torch.from_numpy(np.stack([src[i] for i in order])).cuda()
     res = S.search_batch(d.data_ptr(), pkg.FMT_IQ_U8, len(order), 153600, f, FC, FC, FS, pkg.STAGE_FULL)
     ref = [S.search_capbuf(iq_u8_to_capbuf(x), f, FC, FC, FS)[0] for x in src]
-    key = lambda c: tuple(c.as_dict().values())
+    key = lambda c: tuple(v for k, v in c.as_dict().items() if k != "pss_pow")   # the batch ran the bf16 kernel, the host call fp32
     for slot, i in enumerate(order):
         assert [key(c) for c in res[slot]] == [key(c) for c in ref[i]], slot
+        assert all(abs(a.pss_pow - b.pss_pow) <= 2e-6 * b.pss_pow for a, b in zip(res[slot], ref[i]))
+    for slot, i in enumerate(order):       # and a buffer gives bit-identical records in whatever slot it sits
+        first = order.index(i)
+        assert [tuple(c.as_dict().values()) for c in res[slot]] == [tuple(c.as_dict().values()) for c in res[first]]
     assert sorted(c.n_id_cell() for c in ref[0]) == [125, 300] and [c.n_id_cell() for c in ref[1]] == [277, 271] and ref[2] == []
+
+
+def test_bf16_three_term_correlation_matches_fp32(S, pkg, synth_buf):
+    """u8 I/Q sources take the bf16 three-term MFMA kernel (exact products, fp32 accumulation); variant 3
+    forces the fp32 kernel on the same device-resident bytes.  Every identity must agree and the
+    correlation powers must agree far inside the 1e-5 parity bar."""
+    import torch
+    f = f_search_set_for(FC, 100)
+    g = golden("capbuf_0000")["iq_u8"]
+    rng = np.random.default_rng(3)
+    noise = np.clip(np.rint(rng.normal(127.0, 20.0, g.size)), 0, 255).astype(np.uint8)
+    bufs = [synth_buf, g, noise, np.roll(g, 2 * 4321), np.roll(synth_buf, 2 * 777), g, noise, synth_buf, g]   # 8 XCD-mapped + 1
+    d = torch.from_numpy(np.stack(bufs)).cuda()
+    out = {}
+    for v in (0, 3):
+        S.set_xcorr_variant(v)
+        out[v] = S.search_batch(d.data_ptr(), pkg.FMT_IQ_U8, len(bufs), 153600, f, FC, FC, FS, pkg.STAGE_PSS, max_cells_per_buf=64)
+    S.set_xcorr_variant(0)
+    n = 0
+    for a, b in zip(out[0], out[3]):
+        assert [(c.n_id_2, c.ind, c.freq) for c in a] == [(c.n_id_2, c.ind, c.freq) for c in b]
+        for ca, cb in zip(a, b):
+            assert abs(ca.pss_pow - cb.pss_pow) <= 2e-6 * cb.pss_pow
+            n += 1
+    assert n >= 10
+    # and the decoded cells of the full chain are the same records except for that last-digit power
+    full = {}
+    for v in (0, 3):
+        S.set_xcorr_variant(v)
+        full[v] = S.search_batch(d.data_ptr(), pkg.FMT_IQ_U8, len(bufs), 153600, f, FC, FC, FS, pkg.STAGE_FULL)
+    S.set_xcorr_variant(0)
+    strip = lambda c: tuple(v for k, v in c.as_dict().items() if k != "pss_pow")
+    assert [[strip(c) for c in r] for r in full[0]] == [[strip(c) for c in r] for r in full[3]]
+    assert [c.n_id_cell() for c in full[0][1]] == [277, 271]
 
 
 def test_per_cell_rounds_and_overflow(S, pkg, synth_buf, monkeypatch):
