@@ -18,9 +18,9 @@
 // block from LDS (4 dwords) for its 8 sub-tiles x 6 MFMAs.
 //
 // Tiling.  A 256-thread workgroup owns 512 output positions x one 16-template group; each wave 128
-// positions (8 sub-tiles of 16).  Per window the capture samples are staged once into LDS; the
-// template operands (6 x 1 KB per tap block: {re, im} x 3 split terms) stream through LDS double
-// buffered, one barrier per tap block.
+// positions (8 sub-tiles of 16).  Per window the capture samples are staged once into LDS (one barrier
+// per window); the template operands (6 x 1 KB per tap block: {re, im} x 3 split terms) are read by
+// every wave straight from L2/L1, one or two blocks ahead.
 #include "lcs_internal.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -104,10 +104,15 @@ __global__ __launch_bounds__(256) void k_fill_btab_bf16(const float2 *__restrict
 
 __device__ __forceinline__ float pow2sum_bf(float re, float im) { return fmaf(re, re, im * im); }
 
-__global__ __launch_bounds__(256, 2) void k_xcorr_bf16x3(const uint32_t *__restrict__ capb, const int *__restrict__ smin,
-                                                         const int *__restrict__ kp2, const uint4 *__restrict__ bt16,
-                                                         float *__restrict__ sg, XcGeom geo, int slot0, int n_slots,
-                                                         int xcd_map) {
+// General kernel (any tap-block count per window, a loop over the blocks): every wave reads its six B
+// operands per tap block straight from global memory (the four waves of a workgroup hit the same
+// lines within a microsecond: one L2 fetch, L1 hits for the rest), two blocks ahead.  No barrier
+// inside a window, so the waves of a workgroup drift apart and keep the matrix pipe fed while one of
+// them waits.  (Staging the operands through LDS with a barrier per block was 3 % slower.)
+__global__ __launch_bounds__(256, 2) void k_xcorr_bf16x3_loop(const uint32_t *__restrict__ capb, const int *__restrict__ smin,
+                                                                const int *__restrict__ kp2, const uint4 *__restrict__ bt16,
+                                                                float *__restrict__ sg, XcGeom geo, int slot0, int n_slots,
+                                                                int xcd_map) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int per_slot = BF_TILES * geo.G;
   int q, sidx;
@@ -116,26 +121,21 @@ __global__ __launch_bounds__(256, 2) void k_xcorr_bf16x3(const uint32_t *__restr
   if (sidx >= n_slots) return;
   const int slot = slot0 + sidx, g = q / BF_TILES, idx0 = (q % BF_TILES) * BF_LAGS;
   const int widx0 = idx0 + wave * (BF_MT * 16);
-  // live sub-tiles of this wave (wave-uniform): the last workgroup of a row runs past idx 9599
   const int n_mt = min(max((LCS_N_IDX - widx0 + 15) / 16, 0), BF_MT);
 
   __shared__ uint32_t ldsA[2][BF_AW];
-  __shared__ uint4 ldsB[2][BF_OPS * 64];
   const uint32_t *cap = capb + (size_t)slot * geo.n_cap;
   const int *smin_s = smin + (size_t)slot * NW * GM + g;
   const int *kp2_s = kp2 + (size_t)slot * NW * GM + g;
-  const uint4 *bt_s = bt16 + ((size_t)slot * geo.n_comb * geo.G + g) * (size_t)(LCS_BF_KB_MAX * BF_OPS * 64);
+  const uint4 *bt_s = bt16 + ((size_t)slot * geo.n_comb * geo.G + g) * (size_t)(LCS_BF_KB_MAX * BF_OPS * 64) + lane;
   const size_t bt_wstride = (size_t)geo.G * (LCS_BF_KB_MAX * BF_OPS * 64);
   const int a_off = wave * (BF_MT * 16) + (lane & 15) + 4 * (lane >> 4);
 
   f32x4 P[BF_MT];
 #pragma unroll
   for (int mt = 0; mt < BF_MT; ++mt) P[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
   constexpr int ASTEPS = (BF_AW + 255) / 256;
-  constexpr int BSTEPS = (BF_OPS * 64 + 255) / 256;
   uint32_t preA[ASTEPS];
-  uint4 preB[BSTEPS];
 #define BF_LOAD_A(W)                                                                   \
   {                                                                                    \
     const int L0_ = idx0 + smin_s[(W) * GM];                                           \
@@ -145,31 +145,31 @@ __global__ __launch_bounds__(256, 2) void k_xcorr_bf16x3(const uint32_t *__restr
       preA[r_] = (n_ < BF_AW && s_ < geo.n_cap) ? cap[s_] : 0u;                        \
     }                                                                                  \
   }
-#define BF_LOAD_B(W, KB)                                                               \
+#define BF_GLOAD_B(DST, W, KB)                                                         \
   {                                                                                    \
     const uint4 *src_ = bt_s + (size_t)(W) * bt_wstride + (size_t)(KB) * (BF_OPS * 64); \
-    _Pragma("unroll") for (int r_ = 0; r_ < BSTEPS; ++r_)                              \
-      preB[r_] = (tid + 256 * r_ < BF_OPS * 64) ? src_[tid + 256 * r_] : make_uint4(0u, 0u, 0u, 0u); \
+    _Pragma("unroll") for (int op_ = 0; op_ < BF_OPS; ++op_) {                         \
+      const uint4 t_ = src_[op_ * 64];                                                 \
+      (DST)[op_] = (u32x4){t_.x, t_.y, t_.z, t_.w};                                    \
+    }                                                                                  \
   }
 #define BF_READ_A(DST, S)                                                              \
   {                                                                                    \
     const uint32_t *p_ = bufA + a_off + 16 * (S);                                      \
     (DST) = (u32x4){p_[0], p_[1], p_[2], p_[3]};                                       \
   }
-  // Pipeline: LDS buffer cb holds the B operands of tap block (w, kb); preB holds the block after it
-  // (already requested from L2); during the MFMAs of (w, kb) preB is written to the other buffer and
-  // the block after that is requested.  One barrier per tap block plus one per window (capture samples).
-  BF_LOAD_A(0);
-  BF_LOAD_B(0, 0);
-#pragma unroll
-  for (int r = 0; r < BSTEPS; ++r)
-    if (tid + 256 * r < BF_OPS * 64) ldsB[0][tid + 256 * r] = preB[r];
-  int cb = 0;
+  // the sequence of tap blocks over all windows is walked with a two-deep register queue
+  u32x4 Bq0[BF_OPS], Bq1[BF_OPS], Bnew[BF_OPS];
   int nkb = min((2 * kp2_s[0] + 15) / 16, LCS_BF_KB_MAX);
-  if (nkb > 1) BF_LOAD_B(0, 1)
-  else if (geo.n_comb > 1) BF_LOAD_B(1, 0)
+  BF_LOAD_A(0);
+  BF_GLOAD_B(Bq0, 0, 0);
+  // position of the block that Bq1 / Bnew refer to
+  int pw = 0, pk = 1, pn = nkb;                   // (window, block, blocks in that window) of the next block to request
+  if (pk >= pn) { pw = 1; pk = 0; pn = (pw < geo.n_comb) ? min((2 * kp2_s[pw * GM] + 15) / 16, LCS_BF_KB_MAX) : 0; }
+  if (pw < geo.n_comb) BF_GLOAD_B(Bq1, pw, pk);
+  ++pk;
+  if (pk >= pn) { ++pw; pk = 0; pn = (pw < geo.n_comb) ? min((2 * kp2_s[pw * GM] + 15) / 16, LCS_BF_KB_MAX) : 0; }
   for (int w = 0; w < geo.n_comb; ++w) {
-    const int nkb_next = (w + 1 < geo.n_comb) ? min((2 * kp2_s[(w + 1) * GM] + 15) / 16, LCS_BF_KB_MAX) : 0;
     uint32_t *bufA = ldsA[w & 1];
 #pragma unroll
     for (int r = 0; r < ASTEPS; ++r) {
@@ -186,46 +186,145 @@ __global__ __launch_bounds__(256, 2) void k_xcorr_bf16x3(const uint32_t *__restr
     for (int s = 0; s < BF_MT - 1; ++s) BF_READ_A(Aw[s], s);
 #pragma unroll 1
     for (int kb = 0; kb < nkb; ++kb) {
+      if (pw < geo.n_comb) BF_GLOAD_B(Bnew, pw, pk);
+      ++pk;
+      if (pk >= pn) { ++pw; pk = 0; pn = (pw < geo.n_comb) ? min((2 * kp2_s[pw * GM] + 15) / 16, LCS_BF_KB_MAX) : 0; }
       BF_READ_A(Aw[BF_MT - 1], kb + BF_MT - 1);
-      u32x4 B[BF_OPS];
-#pragma unroll
-      for (int op = 0; op < BF_OPS; ++op) { const uint4 t_ = ldsB[cb][op * 64 + lane]; B[op] = (u32x4){t_.x, t_.y, t_.z, t_.w}; }
-      // hand the prefetched block to the other LDS buffer and request the one after it
-      const bool more_w = kb + 1 < nkb;                       // next block is in this window
-      if (more_w || w + 1 < geo.n_comb) {
-#pragma unroll
-        for (int r = 0; r < BSTEPS; ++r)
-          if (tid + 256 * r < BF_OPS * 64) ldsB[cb ^ 1][tid + 256 * r] = preB[r];
-        if (kb + 2 < nkb) BF_LOAD_B(w, kb + 2)
-        else if (more_w) { if (w + 1 < geo.n_comb) BF_LOAD_B(w + 1, 0) }
-        else if (nkb_next > 1) BF_LOAD_B(w + 1, 1)
-        else if (w + 2 < geo.n_comb) BF_LOAD_B(w + 2, 0)
-      }
 #pragma unroll
       for (int mt = 0; mt < BF_MT; ++mt) {
-        if (mt < n_mt) {                  // wave-uniform
-          aR[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AS_BF(Aw[mt]), AS_BF(B[0]), aR[mt], 0, 0, 0);
-          aI[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AS_BF(Aw[mt]), AS_BF(B[3]), aI[mt], 0, 0, 0);
-          aR[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AS_BF(Aw[mt]), AS_BF(B[1]), aR[mt], 0, 0, 0);
-          aI[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AS_BF(Aw[mt]), AS_BF(B[4]), aI[mt], 0, 0, 0);
-          aR[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AS_BF(Aw[mt]), AS_BF(B[2]), aR[mt], 0, 0, 0);
-          aI[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AS_BF(Aw[mt]), AS_BF(B[5]), aI[mt], 0, 0, 0);
+        if (mt < n_mt) {
+          aR[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AS_BF(Aw[mt]), AS_BF(Bq0[0]), aR[mt], 0, 0, 0);
+          aI[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AS_BF(Aw[mt]), AS_BF(Bq0[3]), aI[mt], 0, 0, 0);
+          aR[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AS_BF(Aw[mt]), AS_BF(Bq0[1]), aR[mt], 0, 0, 0);
+          aI[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AS_BF(Aw[mt]), AS_BF(Bq0[4]), aI[mt], 0, 0, 0);
+          aR[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AS_BF(Aw[mt]), AS_BF(Bq0[2]), aR[mt], 0, 0, 0);
+          aI[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AS_BF(Aw[mt]), AS_BF(Bq0[5]), aI[mt], 0, 0, 0);
         }
       }
 #pragma unroll
-      for (int s = 0; s < BF_MT - 1; ++s) Aw[s] = Aw[s + 1];   // slide the Toeplitz window
-      __syncthreads();
-      cb ^= 1;
+      for (int s = 0; s < BF_MT - 1; ++s) Aw[s] = Aw[s + 1];
+#pragma unroll
+      for (int op = 0; op < BF_OPS; ++op) { Bq0[op] = Bq1[op]; Bq1[op] = Bnew[op]; }
     }
 #pragma unroll
     for (int mt = 0; mt < BF_MT; ++mt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) P[mt][r] = P[mt][r] + pow2sum_bf(aR[mt][r], aI[mt][r]);
-    nkb = nkb_next;
+    nkb = (w + 1 < geo.n_comb) ? min((2 * kp2_s[(w + 1) * GM] + 15) / 16, LCS_BF_KB_MAX) : 0;
   }
 #undef BF_LOAD_A
-#undef BF_LOAD_B
+#undef BF_GLOAD_B
 #undef BF_READ_A
+  const float ncomb = (float)geo.n_comb;
+  float *o = sg + (((size_t)slot * geo.G + g) * LCS_N_IDX) * LCS_TG + (lane & 15);
+#pragma unroll
+  for (int mt = 0; mt < BF_MT; ++mt) {
+    if (mt < n_mt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int idx = widx0 + mt * 16 + 4 * (lane >> 4) + r;
+        if (idx < LCS_N_IDX) o[(size_t)idx * LCS_TG] = __fdiv_rn(P[mt][r], ncomb);
+      }
+    }
+  }
+}
+
+// Straight-line kernel for the common case that every (window, group) has the same number of tap
+// blocks (9 when 137 taps + window-start spread <= 144: any +-ppm grid of the CLI): the blocks of a
+// window are unrolled, so the Toeplitz window and the operand queue are pure register renaming (no
+// v_mov rotation), and the 48 MFMAs of a block are ordered split-term-major so that MFMAs into the
+// same accumulator are 16 instructions apart.  1.78 ms per 64-buffer launch against 1.95 ms for the loop.
+#define BF_MFMA_BLOCK(AW, S0, BQ)                                                                         \
+  _Pragma("unroll") for (int sp_ = 0; sp_ < 3; ++sp_) {                                                   \
+    _Pragma("unroll") for (int mt_ = 0; mt_ < BF_MT; ++mt_) {                                             \
+      if (mt_ < n_mt) {                                                                                   \
+        aR[mt_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AS_BF(AW[(S0) + mt_]), AS_BF(BQ[sp_]), aR[mt_], 0, 0, 0);     \
+        aI[mt_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AS_BF(AW[(S0) + mt_]), AS_BF(BQ[3 + sp_]), aI[mt_], 0, 0, 0); \
+      }                                                                                                   \
+    }                                                                                                     \
+  }
+template <int NKB>     // tap blocks per window, the same for every (window, group) of the launch (host-checked)
+__global__ __launch_bounds__(256, 2) void k_xcorr_bf16x3_unrolled(const uint32_t *__restrict__ capb, const int *__restrict__ smin,
+                                                                  const int *__restrict__ kp2, const uint4 *__restrict__ bt16,
+                                                                  float *__restrict__ sg, XcGeom geo, int slot0, int n_slots,
+                                                                  int xcd_map) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int per_slot = BF_TILES * geo.G;
+  int q, sidx;
+  if (xcd_map) { sidx = blockIdx.x & 7; q = blockIdx.x >> 3; sidx += 8 * (q / per_slot); q = q % per_slot; }
+  else { sidx = blockIdx.x / per_slot; q = blockIdx.x % per_slot; }
+  if (sidx >= n_slots) return;
+  const int slot = slot0 + sidx, g = q / BF_TILES, idx0 = (q % BF_TILES) * BF_LAGS;
+  const int widx0 = idx0 + wave * (BF_MT * 16);
+  const int n_mt = min(max((LCS_N_IDX - widx0 + 15) / 16, 0), BF_MT);
+
+  __shared__ uint32_t ldsA[2][BF_AW];
+  const uint32_t *cap = capb + (size_t)slot * geo.n_cap;
+  const int *smin_s = smin + (size_t)slot * NW * GM + g;
+  (void)kp2;
+  const uint4 *bt_s = bt16 + ((size_t)slot * geo.n_comb * geo.G + g) * (size_t)(LCS_BF_KB_MAX * BF_OPS * 64) + lane;
+  const size_t bt_wstride = (size_t)geo.G * (LCS_BF_KB_MAX * BF_OPS * 64);
+  const int a_off = wave * (BF_MT * 16) + (lane & 15) + 4 * (lane >> 4);
+
+  f32x4 P[BF_MT];
+#pragma unroll
+  for (int mt = 0; mt < BF_MT; ++mt) P[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  constexpr int ASTEPS = (BF_AW + 255) / 256;
+  uint32_t preA[ASTEPS];
+#define BF_LOAD_A(W)                                                                   \
+  {                                                                                    \
+    const int L0_ = idx0 + smin_s[(W) * GM];                                           \
+    _Pragma("unroll") for (int r_ = 0; r_ < ASTEPS; ++r_) {                            \
+      const int n_ = tid + 256 * r_;                                                   \
+      const uint32_t s_ = (uint32_t)(L0_ + n_);                                        \
+      preA[r_] = (n_ < BF_AW && s_ < geo.n_cap) ? cap[s_] : 0u;                        \
+    }                                                                                  \
+  }
+#define BF_GLOAD_B(DST, W, KB)                                                         \
+  {                                                                                    \
+    const uint4 *src_ = bt_s + (size_t)(W) * bt_wstride + (size_t)(KB) * (BF_OPS * 64); \
+    _Pragma("unroll") for (int op_ = 0; op_ < BF_OPS; ++op_) {                         \
+      const uint4 t_ = src_[op_ * 64];                                                 \
+      (DST)[op_] = (u32x4){t_.x, t_.y, t_.z, t_.w};                                    \
+    }                                                                                  \
+  }
+  u32x4 Bq[NKB + 1][BF_OPS];      // static indices only: block kb of the window, +1 = first one of the next
+  BF_LOAD_A(0);
+  BF_GLOAD_B(Bq[0], 0, 0);
+  for (int w = 0; w < geo.n_comb; ++w) {
+    const bool has_next = w + 1 < geo.n_comb;
+    uint32_t *bufA = ldsA[w & 1];
+#pragma unroll
+    for (int r = 0; r < ASTEPS; ++r) {
+      const int n = tid + 256 * r;
+      if (n < BF_AW) bufA[n] = preA[r];
+    }
+    if (has_next) BF_LOAD_A(w + 1);
+    __syncthreads();
+    f32x4 aR[BF_MT], aI[BF_MT];
+#pragma unroll
+    for (int mt = 0; mt < BF_MT; ++mt) { aR[mt] = (f32x4){0.f, 0.f, 0.f, 0.f}; aI[mt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    u32x4 Aw[NKB + BF_MT - 1];
+#pragma unroll
+    for (int s = 0; s < BF_MT - 1; ++s) { const uint32_t *p_ = bufA + a_off + 16 * s; Aw[s] = (u32x4){p_[0], p_[1], p_[2], p_[3]}; }
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+      // request the next block: in this window, or block 0 of the next one
+      if (kb + 1 < NKB) BF_GLOAD_B(Bq[kb + 1], w, kb + 1)
+      else if (has_next) BF_GLOAD_B(Bq[kb + 1], w + 1, 0)
+      { const uint32_t *p_ = bufA + a_off + 16 * (kb + BF_MT - 1); Aw[kb + BF_MT - 1] = (u32x4){p_[0], p_[1], p_[2], p_[3]}; }
+      BF_MFMA_BLOCK(Aw, kb, Bq[kb]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int op = 0; op < BF_OPS; ++op) Bq[0][op] = Bq[NKB][op];
+#pragma unroll
+    for (int mt = 0; mt < BF_MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) P[mt][r] = P[mt][r] + pow2sum_bf(aR[mt][r], aI[mt][r]);
+  }
+#undef BF_LOAD_A
+#undef BF_GLOAD_B
   const float ncomb = (float)geo.n_comb;
   float *o = sg + (((size_t)slot * geo.G + g) * LCS_N_IDX) * LCS_TG + (lane & 15);
 #pragma unroll
@@ -249,8 +348,13 @@ int lcs_launch_fill_btab_bf16(lcs_ctx *c, int n_buf, const XcGeom &geo) {
 }
 int lcs_launch_xcorr_bf16(lcs_ctx *c, hipStream_t sxc, const XcGeom &geo, int slot0, int n_slots, int xcd_map) {
   const unsigned grid = (unsigned)(BF_TILES * geo.G * n_slots);
-  hipLaunchKernelGGL(k_xcorr_bf16x3, dim3(grid), dim3(256), 0, sxc, c->capb, c->smin, c->kp2, c->bt16, c->single, geo, slot0,
-                     n_slots, xcd_map);
+  static const bool force_loop = getenv("LCS_BF16_LOOP") != nullptr;   // tuning knob
+  if (c->grid_max_k2 <= 72 && !force_loop)   // every (window, group) has exactly 9 tap blocks (137 taps + spread <= 144)
+    hipLaunchKernelGGL(k_xcorr_bf16x3_unrolled<9>, dim3(grid), dim3(256), 0, sxc, c->capb, c->smin, c->kp2, c->bt16, c->single, geo,
+                       slot0, n_slots, xcd_map);
+  else
+    hipLaunchKernelGGL(k_xcorr_bf16x3_loop, dim3(grid), dim3(256), 0, sxc, c->capb, c->smin, c->kp2, c->bt16, c->single, geo,
+                       slot0, n_slots, xcd_map);
   HIPCHK(c, hipGetLastError());
   return LCS_OK;
 }

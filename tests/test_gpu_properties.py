@@ -109,6 +109,20 @@ def test_bf16_three_term_correlation_matches_fp32(S, pkg, synth_buf):
     strip = lambda c: tuple(v for k, v in c.as_dict().items() if k != "pss_pow")
     assert [[strip(c) for c in r] for r in full[0]] == [[strip(c) for c in r] for r in full[3]]
     assert [c.n_id_cell() for c in full[0][1]] == [277, 271]
+    # a 10 kHz grid spreads the window starts of one template group over more than 7 samples: more than 9
+    # tap blocks per window, which takes the looping bf16 kernel instead of the unrolled one
+    f10 = np.arange(-10, 11) * 10e3
+    wide = {}
+    for v in (0, 3):
+        S.set_xcorr_variant(v)
+        wide[v] = S.search_batch(d.data_ptr(), pkg.FMT_IQ_U8, len(bufs), 153600, f10, FC, FC, FS, pkg.STAGE_PSS, max_cells_per_buf=64)
+    S.set_xcorr_variant(0)
+    m = 0
+    for a, b in zip(wide[0], wide[3]):
+        assert [(c.n_id_2, c.ind, c.freq) for c in a] == [(c.n_id_2, c.ind, c.freq) for c in b]
+        assert all(abs(ca.pss_pow - cb.pss_pow) <= 2e-6 * cb.pss_pow for ca, cb in zip(a, b))
+        m += len(a)
+    assert m >= 8
 
 
 def test_per_cell_rounds_and_overflow(S, pkg, synth_buf, monkeypatch):
