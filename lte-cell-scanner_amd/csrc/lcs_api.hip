@@ -93,7 +93,7 @@ int ensure_bf16(lcs_ctx *c) {
   const int G = (3 * c->cap_n_f + LCS_TG - 1) / LCS_TG;
   int rc;
   if ((rc = dev_alloc(c, &c->capb, S * c->cap_n_cap))) return rc;
-  if ((rc = dev_alloc(c, &c->bt16, S * LCS_NW_MAX * G * (size_t)(LCS_BF_KB_MAX * 6 * 64)))) return rc;
+  if ((rc = dev_alloc(c, &c->bt16, S * LCS_NW_MAX * G * (size_t)(LCS_BF_KB_MAX * 3 * 64)))) return rc;
   c->bf16_ready = true;
   return LCS_OK;
 }
@@ -282,6 +282,7 @@ int lcs_xcorr_pss(lcs_ctx *c, const double *capbuf, uint32_t n_cap, const double
   int rc = check_common(c, n_cap, n_f);
   if (rc) return rc;
   if (!capbuf || !f_search_set || !pow_ || !frq || !single || !sp_incoherent) { c->err = "null argument"; return LCS_ERR_BAD_ARG; }
+  if (ds_comb_arm > 8) { c->err = "ds_comb_arm > 8 is not supported (the reference uses 2)"; return LCS_ERR_BAD_ARG; }
   HIPCHK(c, hipSetDevice(c->device));
   const bool debug = incoh != nullptr;
   if ((rc = ensure_ws(c, 1, n_cap, n_f, debug))) return rc;

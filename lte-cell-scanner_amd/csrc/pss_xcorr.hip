@@ -481,7 +481,8 @@ struct SpArgs {
   int n_comb_xc, ds;
 };
 // grid (tiles of 1024 positions, windows, slots): sp_all[slot][m][i].  Each lane owns 16
-// consecutive positions: one direct 274-sample sum, then 15 sliding updates (the reference's own
+// consecutive positions: the 274-sample sum of its first position is formed from 17 sixteen-sample
+// segment sums (shared through LDS) plus two samples, then 15 sliding updates (the reference's own
 // recurrence, restarted every 16 samples).  LDS index i -> i + i/16 keeps the lanes' 16-sample
 // strides on distinct banks.
 #define SP_SEG 16
@@ -496,23 +497,45 @@ __global__ __launch_bounds__(64) void k_sp_sums(const float2 *__restrict__ cap32
   const CapView cap = cap_view(cap32, cap64, slot, n_cap);
   __shared__ double pw[SP_TILE + 274 + (SP_TILE + 274) / 16 + 2];
   const uint32_t base = (uint32_t)m * 9600u + i0;
-  for (int n = tid; n < SP_TILE + 274; n += 64) {
-    const uint32_t s = base + n;
-    double v = 0;
-    if (s < n_cap) { const double2 c = cap_at(cap, s); v = c.x * c.x + c.y * c.y; }
-    pw[sp_pad(n)] = v;
+  constexpr int SP_LD = (SP_TILE + 274 + 63) / 64;     // loads per lane: issued back to back, then consumed
+  double2 c[SP_LD];
+#pragma unroll
+  for (int r = 0; r < SP_LD; ++r) {
+    const uint32_t s = base + tid + 64 * r;
+    c[r] = (tid + 64 * r < SP_TILE + 274 && s < n_cap) ? cap_at(cap, s) : make_double2(0.0, 0.0);
   }
+#pragma unroll
+  for (int r = 0; r < SP_LD; ++r) {
+    const int n = tid + 64 * r;
+    if (n < SP_TILE + 274) pw[sp_pad(n)] = c[r].x * c[r].x + c[r].y * c[r].y;
+  }
+  __shared__ double seg[64 + 18];
   __syncthreads();
   const int b0 = tid * SP_SEG;
-  double s0 = 0, s1 = 0;                       // two interleaved chains (even / odd samples)
-  for (int j = 0; j < 274; j += 2) { s0 += pw[sp_pad(b0 + j)]; s1 += pw[sp_pad(b0 + j + 1)]; }
-  double s = s0 + s1;
-  double *o = sp_all + ((size_t)slot * n_comb_sp + m) * 9600;
-  for (int q = 0; q < SP_SEG; ++q) {
-    const int i = i0 + b0 + q;
-    if (q) s = s + (-pw[sp_pad(b0 + q - 1)] + pw[sp_pad(b0 + q + 273)]);
-    if (i < 9600) o[i] = s / 274;
+  for (int k = tid; k < 64 + 17; k += 64) {     // segment sums of the tile and of the 272 samples behind it
+    double a = 0;
+#pragma unroll
+    for (int j = 0; j < SP_SEG; ++j) a += pw[sp_pad(k * SP_SEG + j)];
+    seg[k] = a;
   }
+  __syncthreads();
+  double s = 0;
+#pragma unroll
+  for (int k = 0; k < 17; ++k) s += seg[tid + k];
+  s = s + (pw[sp_pad(b0 + 272)] + pw[sp_pad(b0 + 273)]);
+  double *o = sp_all + ((size_t)slot * n_comb_sp + m) * 9600;
+  double res[SP_SEG];
+#pragma unroll
+  for (int q = 0; q < SP_SEG; ++q) {
+    if (q) s = s + (-pw[sp_pad(b0 + q - 1)] + pw[sp_pad(b0 + q + 273)]);
+    res[q] = s / 274;
+  }
+  __syncthreads();                 // everyone is done reading pw: reuse it to turn the lane-major results around
+#pragma unroll
+  for (int q = 0; q < SP_SEG; ++q) pw[sp_pad(b0 + q)] = res[q];
+  __syncthreads();
+  for (int n = tid; n < SP_TILE; n += 64)
+    if (i0 + n < 9600) o[i0 + n] = pw[sp_pad(n)];      // coalesced rows instead of 128-byte-strided stores
 }
 __global__ __launch_bounds__(256) void k_sp_fold(const double *__restrict__ sp_all, double *__restrict__ spinc,
                                                   double *__restrict__ zth, SpArgs a) {
@@ -537,40 +560,50 @@ __global__ __launch_bounds__(128) void k_collapse(const float *__restrict__ sg, 
                                                    double *__restrict__ pow_, float *__restrict__ pow32,
                                                    int *__restrict__ frq, XcGeom geo) {
   LCS_TAIL_PRIO();
-  const int slot = blockIdx.y;
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= LCS_N_IDX) return;
+  // the 128 + 2*ds rows (64 bytes each) a workgroup needs from one group are loaded once, coalesced, into LDS
+  constexpr int CT = 128, CH = 8;                  // positions per workgroup, halo rows each side (ds <= 8)
+  __shared__ float tile[(CT + 2 * CH) * (LCS_TG + 1)];
+  const int slot = blockIdx.y, tid = threadIdx.x;
+  const int idx0 = blockIdx.x * CT;
+  const int idx = idx0 + tid;
+  const int ds = min(geo.ds, CH);
   const float dsn = (float)(2 * geo.ds + 1);
   float best[3] = {0.f, 0.f, 0.f};
   int bi[3] = {0, 0, 0};
   for (int g = 0; g < geo.G; ++g) {
     const float4 *rows = (const float4 *)(sg + (((size_t)slot * geo.G + g) * LCS_N_IDX) * LCS_TG);
-    float v[LCS_TG];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float4 x = rows[(size_t)idx * 4 + q];
-      v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w;
+    __syncthreads();
+    for (int e = tid; e < (CT + 2 * ds) * 4; e += CT) {
+      const int r = e >> 2, q = e & 3;
+      const int src = ((idx0 - ds + r) % LCS_N_IDX + LCS_N_IDX) % LCS_N_IDX;      // circular in idx (ref :336)
+      const float4 x = rows[(size_t)src * 4 + q];
+      float *t = tile + r * (LCS_TG + 1) + 4 * q;
+      t[0] = x.x; t[1] = x.y; t[2] = x.z; t[3] = x.w;
     }
-    for (int d = 1; d <= geo.ds; ++d) {
-      const int a = (idx - d + LCS_N_IDX) % LCS_N_IDX, b = (idx + d) % LCS_N_IDX;
+    __syncthreads();
+    if (idx < LCS_N_IDX) {
+      float v[LCS_TG];
+      const float *me = tile + (tid + ds) * (LCS_TG + 1);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float4 xa = rows[(size_t)a * 4 + q], xb = rows[(size_t)b * 4 + q];
-        v[4 * q] = v[4 * q] + (xa.x + xb.x); v[4 * q + 1] = v[4 * q + 1] + (xa.y + xb.y);
-        v[4 * q + 2] = v[4 * q + 2] + (xa.z + xb.z); v[4 * q + 3] = v[4 * q + 3] + (xa.w + xb.w);
+      for (int j = 0; j < LCS_TG; ++j) v[j] = me[j];
+      for (int d = 1; d <= ds; ++d) {
+        const float *pa = me - d * (LCS_TG + 1), *pb = me + d * (LCS_TG + 1);
+#pragma unroll
+        for (int j = 0; j < LCS_TG; ++j) v[j] = v[j] + (pa[j] + pb[j]);
       }
-    }
 #pragma unroll
-    for (int j = 0; j < LCS_TG; ++j) {
-      const int c = g * LCS_TG + j;
-      if (c < geo.n_tmpl) {
-        const int foi = c / 3, t = c % 3;
-        const float x = __fdiv_rn(v[j], dsn);
-        if (incoh) incoh[((((size_t)slot * 3 + t) * LCS_N_IDX) + idx) * geo.n_f + foi] = x;
-        if (foi == 0 || x > best[t]) { best[t] = x; bi[t] = foi; }
+      for (int j = 0; j < LCS_TG; ++j) {
+        const int c = g * LCS_TG + j;
+        if (c < geo.n_tmpl) {
+          const int foi = c / 3, t = c % 3;
+          const float x = __fdiv_rn(v[j], dsn);
+          if (incoh) incoh[((((size_t)slot * 3 + t) * LCS_N_IDX) + idx) * geo.n_f + foi] = x;
+          if (foi == 0 || x > best[t]) { best[t] = x; bi[t] = foi; }
+        }
       }
     }
   }
+  if (idx >= LCS_N_IDX) return;
 #pragma unroll
   for (int t = 0; t < 3; ++t) {
     pow_[((size_t)slot * 3 + t) * LCS_N_IDX + idx] = (double)best[t];

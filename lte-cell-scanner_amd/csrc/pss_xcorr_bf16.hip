@@ -35,6 +35,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define BF_MT 8
 #define BF_AW (BF_LAGS + 16 * LCS_BF_KB_MAX + 16)     // staged samples per window
 #define BF_OPS 6                                      // B operands per tap block: re1 re2 re3 im1 im2 im3
+#define BF_TOPS 3                                     // stored per tap block: the three split terms as (tr, ti) pairs
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #define AS_BF(x) __builtin_bit_cast(bf16x8, (x))
@@ -45,9 +46,10 @@ __device__ __forceinline__ uint32_t bf16_rne(float v) {   // finite inputs only
 }
 __device__ __forceinline__ float bf16_val(uint32_t h) { return __uint_as_float(h << 16); }
 
-// bt16[slot][w][g][kb][op][lane] (uint4 = 8 bf16): lane (n, kg) holds k = 8 kg .. 8 kg + 7 of template
-// column c = 16 g + n, i.e. taps 16 kb + 4 kg .. +3 of the template delayed by start[w][foi(c)] - smin[w][g]
-// (zero outside its 137 taps), as (tr, -ti) pairs for the real and (ti, tr) pairs for the imaginary output.
+// bt16[slot][w][g][kb][term][lane] (uint4 = 8 bf16): lane (n, kg) holds taps 16 kb + 4 kg .. +3 of template
+// column c = 16 g + n delayed by start[w][foi(c)] - smin[w][g] (zero outside its 137 taps) as (tr, ti)
+// pairs, one uint4 per split term.  The correlation kernels derive the two MFMA operands from it in
+// registers: real output (tr, -ti) = sign flip of the high halves, imaginary output (ti, tr) = half swap.
 __global__ __launch_bounds__(256) void k_fill_btab_bf16(const float2 *__restrict__ tmpl, const int *__restrict__ start,
                                                         const int *__restrict__ smin, const int *__restrict__ kp2,
                                                         uint4 *__restrict__ bt16, XcGeom geo) {
@@ -58,13 +60,13 @@ __global__ __launch_bounds__(256) void k_fill_btab_bf16(const float2 *__restrict
   const int k2 = kp2[((size_t)slot * NW + w) * GM + g];
   const int s0 = smin[((size_t)slot * NW + w) * GM + g];
   const int nkb = min((2 * k2 + 15) / 16, LCS_BF_KB_MAX);
-  uint4 *out = bt16 + (((size_t)slot * geo.n_comb + w) * geo.G + g) * (size_t)(LCS_BF_KB_MAX * BF_OPS * 64);
+  uint4 *out = bt16 + (((size_t)slot * geo.n_comb + w) * geo.G + g) * (size_t)(LCS_BF_KB_MAX * BF_TOPS * 64);
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < nkb * 64; e += gridDim.x * blockDim.x) {
     const int kb = e >> 6, lane = e & 63;
     const int c = g * LCS_TG + (lane & 15), kg = lane >> 4;
-    float vre[8], vim[8];
+    float v[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { vre[j] = 0.f; vim[j] = 0.f; }
+    for (int j = 0; j < 8; ++j) v[j] = 0.f;
     if (c < geo.n_tmpl) {
       const int foi = c / 3, t = c % 3;
       const int delta = start[((size_t)slot * NW + w) * NFM + foi] - s0;
@@ -73,36 +75,38 @@ __global__ __launch_bounds__(256) void k_fill_btab_bf16(const float2 *__restrict
         const int tap = 16 * kb + 4 * kg + m - delta;
         if (tap >= 0 && tap < 137) {
           const float2 T = tmpl[(((size_t)slot * NFM + foi) * 3 + t) * 137 + tap];
-          vre[2 * m] = T.x; vre[2 * m + 1] = -T.y;
-          vim[2 * m] = T.y; vim[2 * m + 1] = T.x;
+          v[2 * m] = T.x; v[2 * m + 1] = T.y;
         }
       }
     }
-    uint32_t h[BF_OPS][8];
+    uint32_t h[BF_TOPS][8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
+      float r = v[j];
 #pragma unroll
-      for (int p = 0; p < 2; ++p) {
-        float r = p ? vim[j] : vre[j];
-#pragma unroll
-        for (int sidx = 0; sidx < 3; ++sidx) {          // exact three-term split: r = h1 + h2 + h3
-          const uint32_t hb = bf16_rne(r);
-          h[3 * p + sidx][j] = hb;
-          r = r - bf16_val(hb);
-        }
+      for (int sidx = 0; sidx < BF_TOPS; ++sidx) {          // exact three-term split: r = h1 + h2 + h3
+        const uint32_t hb = bf16_rne(r);
+        h[sidx][j] = hb;
+        r = r - bf16_val(hb);
       }
     }
 #pragma unroll
-    for (int op = 0; op < BF_OPS; ++op) {
+    for (int op = 0; op < BF_TOPS; ++op) {
       uint4 q;
       q.x = h[op][0] | (h[op][1] << 16); q.y = h[op][2] | (h[op][3] << 16);
       q.z = h[op][4] | (h[op][5] << 16); q.w = h[op][6] | (h[op][7] << 16);
-      out[((size_t)kb * BF_OPS + op) * 64 + lane] = q;
+      out[((size_t)kb * BF_TOPS + op) * 64 + lane] = q;
     }
   }
 }
 
 __device__ __forceinline__ float pow2sum_bf(float re, float im) { return fmaf(re, re, im * im); }
+// (tr, ti) pairs -> operand of the real output (tr, -ti) and of the imaginary output (ti, tr)
+__device__ __forceinline__ u32x4 bf_op_re(u32x4 x) { return x ^ (u32x4){0x80000000u, 0x80000000u, 0x80000000u, 0x80000000u}; }
+__device__ __forceinline__ u32x4 bf_op_im(u32x4 x) {
+  return (u32x4){__builtin_amdgcn_alignbit(x[0], x[0], 16), __builtin_amdgcn_alignbit(x[1], x[1], 16),
+                 __builtin_amdgcn_alignbit(x[2], x[2], 16), __builtin_amdgcn_alignbit(x[3], x[3], 16)};
+}
 
 // General kernel (any tap-block count per window, a loop over the blocks): every wave reads its six B
 // operands per tap block straight from global memory (the four waves of a workgroup hit the same
@@ -127,8 +131,8 @@ __global__ __launch_bounds__(256, 2) void k_xcorr_bf16x3_loop(const uint32_t *__
   const uint32_t *cap = capb + (size_t)slot * geo.n_cap;
   const int *smin_s = smin + (size_t)slot * NW * GM + g;
   const int *kp2_s = kp2 + (size_t)slot * NW * GM + g;
-  const uint4 *bt_s = bt16 + ((size_t)slot * geo.n_comb * geo.G + g) * (size_t)(LCS_BF_KB_MAX * BF_OPS * 64) + lane;
-  const size_t bt_wstride = (size_t)geo.G * (LCS_BF_KB_MAX * BF_OPS * 64);
+  const uint4 *bt_s = bt16 + ((size_t)slot * geo.n_comb * geo.G + g) * (size_t)(LCS_BF_KB_MAX * BF_TOPS * 64) + lane;
+  const size_t bt_wstride = (size_t)geo.G * (LCS_BF_KB_MAX * BF_TOPS * 64);
   const int a_off = wave * (BF_MT * 16) + (lane & 15) + 4 * (lane >> 4);
 
   f32x4 P[BF_MT];
@@ -147,8 +151,8 @@ __global__ __launch_bounds__(256, 2) void k_xcorr_bf16x3_loop(const uint32_t *__
   }
 #define BF_GLOAD_B(DST, W, KB)                                                         \
   {                                                                                    \
-    const uint4 *src_ = bt_s + (size_t)(W) * bt_wstride + (size_t)(KB) * (BF_OPS * 64); \
-    _Pragma("unroll") for (int op_ = 0; op_ < BF_OPS; ++op_) {                         \
+    const uint4 *src_ = bt_s + (size_t)(W) * bt_wstride + (size_t)(KB) * (BF_TOPS * 64); \
+    _Pragma("unroll") for (int op_ = 0; op_ < BF_TOPS; ++op_) {                        \
       const uint4 t_ = src_[op_ * 64];                                                 \
       (DST)[op_] = (u32x4){t_.x, t_.y, t_.z, t_.w};                                    \
     }                                                                                  \
@@ -159,7 +163,7 @@ __global__ __launch_bounds__(256, 2) void k_xcorr_bf16x3_loop(const uint32_t *__
     (DST) = (u32x4){p_[0], p_[1], p_[2], p_[3]};                                       \
   }
   // the sequence of tap blocks over all windows is walked with a two-deep register queue
-  u32x4 Bq0[BF_OPS], Bq1[BF_OPS], Bnew[BF_OPS];
+  u32x4 Bq0[BF_TOPS], Bq1[BF_TOPS], Bnew[BF_TOPS];
   int nkb = min((2 * kp2_s[0] + 15) / 16, LCS_BF_KB_MAX);
   BF_LOAD_A(0);
   BF_GLOAD_B(Bq0, 0, 0);
@@ -190,21 +194,24 @@ __global__ __launch_bounds__(256, 2) void k_xcorr_bf16x3_loop(const uint32_t *__
       ++pk;
       if (pk >= pn) { ++pw; pk = 0; pn = (pw < geo.n_comb) ? min((2 * kp2_s[pw * GM] + 15) / 16, LCS_BF_KB_MAX) : 0; }
       BF_READ_A(Aw[BF_MT - 1], kb + BF_MT - 1);
+      u32x4 Bop[BF_OPS];
+#pragma unroll
+      for (int t3 = 0; t3 < BF_TOPS; ++t3) { Bop[t3] = bf_op_re(Bq0[t3]); Bop[3 + t3] = bf_op_im(Bq0[t3]); }
 #pragma unroll
       for (int mt = 0; mt < BF_MT; ++mt) {
         if (mt < n_mt) {
-          aR[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AS_BF(Aw[mt]), AS_BF(Bq0[0]), aR[mt], 0, 0, 0);
-          aI[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AS_BF(Aw[mt]), AS_BF(Bq0[3]), aI[mt], 0, 0, 0);
-          aR[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AS_BF(Aw[mt]), AS_BF(Bq0[1]), aR[mt], 0, 0, 0);
-          aI[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AS_BF(Aw[mt]), AS_BF(Bq0[4]), aI[mt], 0, 0, 0);
-          aR[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AS_BF(Aw[mt]), AS_BF(Bq0[2]), aR[mt], 0, 0, 0);
-          aI[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AS_BF(Aw[mt]), AS_BF(Bq0[5]), aI[mt], 0, 0, 0);
+          aR[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AS_BF(Aw[mt]), AS_BF(Bop[0]), aR[mt], 0, 0, 0);
+          aI[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AS_BF(Aw[mt]), AS_BF(Bop[3]), aI[mt], 0, 0, 0);
+          aR[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AS_BF(Aw[mt]), AS_BF(Bop[1]), aR[mt], 0, 0, 0);
+          aI[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AS_BF(Aw[mt]), AS_BF(Bop[4]), aI[mt], 0, 0, 0);
+          aR[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AS_BF(Aw[mt]), AS_BF(Bop[2]), aR[mt], 0, 0, 0);
+          aI[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AS_BF(Aw[mt]), AS_BF(Bop[5]), aI[mt], 0, 0, 0);
         }
       }
 #pragma unroll
       for (int s = 0; s < BF_MT - 1; ++s) Aw[s] = Aw[s + 1];
 #pragma unroll
-      for (int op = 0; op < BF_OPS; ++op) { Bq0[op] = Bq1[op]; Bq1[op] = Bnew[op]; }
+      for (int op = 0; op < BF_TOPS; ++op) { Bq0[op] = Bq1[op]; Bq1[op] = Bnew[op]; }
     }
 #pragma unroll
     for (int mt = 0; mt < BF_MT; ++mt)
@@ -234,13 +241,13 @@ __global__ __launch_bounds__(256, 2) void k_xcorr_bf16x3_loop(const uint32_t *__
 // window are unrolled, so the Toeplitz window and the operand queue are pure register renaming (no
 // v_mov rotation), and the 48 MFMAs of a block are ordered split-term-major so that MFMAs into the
 // same accumulator are 16 instructions apart.  1.78 ms per 64-buffer launch against 1.95 ms for the loop.
-#define BF_MFMA_BLOCK(AW, S0, BQ)                                                                         \
+// (sub-tiles past idx 9599 in the last workgroup of a row are computed and dropped: no branch in the block)
+#define BF_MFMA_BLOCK(AW, S0, BT)                                                                         \
   _Pragma("unroll") for (int sp_ = 0; sp_ < 3; ++sp_) {                                                   \
+    const u32x4 bre_ = bf_op_re(BT[sp_]), bim_ = bf_op_im(BT[sp_]);                                       \
     _Pragma("unroll") for (int mt_ = 0; mt_ < BF_MT; ++mt_) {                                             \
-      if (mt_ < n_mt) {                                                                                   \
-        aR[mt_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AS_BF(AW[(S0) + mt_]), AS_BF(BQ[sp_]), aR[mt_], 0, 0, 0);     \
-        aI[mt_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AS_BF(AW[(S0) + mt_]), AS_BF(BQ[3 + sp_]), aI[mt_], 0, 0, 0); \
-      }                                                                                                   \
+      aR[mt_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AS_BF(AW[(S0) + mt_]), AS_BF(bre_), aR[mt_], 0, 0, 0); \
+      aI[mt_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AS_BF(AW[(S0) + mt_]), AS_BF(bim_), aI[mt_], 0, 0, 0); \
     }                                                                                                     \
   }
 template <int NKB>     // tap blocks per window, the same for every (window, group) of the launch (host-checked)
@@ -262,8 +269,8 @@ __global__ __launch_bounds__(256, 2) void k_xcorr_bf16x3_unrolled(const uint32_t
   const uint32_t *cap = capb + (size_t)slot * geo.n_cap;
   const int *smin_s = smin + (size_t)slot * NW * GM + g;
   (void)kp2;
-  const uint4 *bt_s = bt16 + ((size_t)slot * geo.n_comb * geo.G + g) * (size_t)(LCS_BF_KB_MAX * BF_OPS * 64) + lane;
-  const size_t bt_wstride = (size_t)geo.G * (LCS_BF_KB_MAX * BF_OPS * 64);
+  const uint4 *bt_s = bt16 + ((size_t)slot * geo.n_comb * geo.G + g) * (size_t)(LCS_BF_KB_MAX * BF_TOPS * 64) + lane;
+  const size_t bt_wstride = (size_t)geo.G * (LCS_BF_KB_MAX * BF_TOPS * 64);
   const int a_off = wave * (BF_MT * 16) + (lane & 15) + 4 * (lane >> 4);
 
   f32x4 P[BF_MT];
@@ -282,15 +289,16 @@ __global__ __launch_bounds__(256, 2) void k_xcorr_bf16x3_unrolled(const uint32_t
   }
 #define BF_GLOAD_B(DST, W, KB)                                                         \
   {                                                                                    \
-    const uint4 *src_ = bt_s + (size_t)(W) * bt_wstride + (size_t)(KB) * (BF_OPS * 64); \
-    _Pragma("unroll") for (int op_ = 0; op_ < BF_OPS; ++op_) {                         \
+    const uint4 *src_ = bt_s + (size_t)(W) * bt_wstride + (size_t)(KB) * (BF_TOPS * 64); \
+    _Pragma("unroll") for (int op_ = 0; op_ < BF_TOPS; ++op_) {                        \
       const uint4 t_ = src_[op_ * 64];                                                 \
       (DST)[op_] = (u32x4){t_.x, t_.y, t_.z, t_.w};                                    \
     }                                                                                  \
   }
-  u32x4 Bq[NKB + 1][BF_OPS];      // static indices only: block kb of the window, +1 = first one of the next
+  u32x4 Bq[NKB + 2][BF_TOPS];     // static indices only: block kb of the window, +2 = first two of the next
   BF_LOAD_A(0);
   BF_GLOAD_B(Bq[0], 0, 0);
+  BF_GLOAD_B(Bq[1], 0, 1);
   for (int w = 0; w < geo.n_comb; ++w) {
     const bool has_next = w + 1 < geo.n_comb;
     uint32_t *bufA = ldsA[w & 1];
@@ -309,15 +317,15 @@ __global__ __launch_bounds__(256, 2) void k_xcorr_bf16x3_unrolled(const uint32_t
     for (int s = 0; s < BF_MT - 1; ++s) { const uint32_t *p_ = bufA + a_off + 16 * s; Aw[s] = (u32x4){p_[0], p_[1], p_[2], p_[3]}; }
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
-      // request the next block: in this window, or block 0 of the next one
-      if (kb + 1 < NKB) BF_GLOAD_B(Bq[kb + 1], w, kb + 1)
-      else if (has_next) BF_GLOAD_B(Bq[kb + 1], w + 1, 0)
+      // request the block two ahead: in this window, or block 0 / 1 of the next one
+      if (kb + 2 < NKB) BF_GLOAD_B(Bq[kb + 2], w, kb + 2)
+      else if (has_next) BF_GLOAD_B(Bq[kb + 2], w + 1, kb + 2 - NKB)
       { const uint32_t *p_ = bufA + a_off + 16 * (kb + BF_MT - 1); Aw[kb + BF_MT - 1] = (u32x4){p_[0], p_[1], p_[2], p_[3]}; }
       BF_MFMA_BLOCK(Aw, kb, Bq[kb]);
       __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
-    for (int op = 0; op < BF_OPS; ++op) Bq[0][op] = Bq[NKB][op];
+    for (int op = 0; op < BF_TOPS; ++op) { Bq[0][op] = Bq[NKB][op]; Bq[1][op] = Bq[NKB + 1][op]; }
 #pragma unroll
     for (int mt = 0; mt < BF_MT; ++mt)
 #pragma unroll
