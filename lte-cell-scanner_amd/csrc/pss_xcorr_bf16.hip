@@ -250,22 +250,23 @@ __global__ __launch_bounds__(256, 2) void k_xcorr_bf16x3_loop(const uint32_t *__
       aI[mt_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AS_BF(AW[(S0) + mt_]), AS_BF(bim_), aI[mt_], 0, 0, 0); \
     }                                                                                                     \
   }
-template <int NKB>     // tap blocks per window, the same for every (window, group) of the launch (host-checked)
-__global__ __launch_bounds__(256, 2) void k_xcorr_bf16x3_unrolled(const uint32_t *__restrict__ capb, const int *__restrict__ smin,
+template <int NKB, int NWV>   // NKB tap blocks per window, the same for every (window, group) of the launch (host-checked); NWV waves
+__global__ __launch_bounds__(NWV * 64, 2) void k_xcorr_bf16x3_unrolled(const uint32_t *__restrict__ capb, const int *__restrict__ smin,
                                                                   const int *__restrict__ kp2, const uint4 *__restrict__ bt16,
                                                                   float *__restrict__ sg, XcGeom geo, int slot0, int n_slots,
                                                                   int xcd_map) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int per_slot = BF_TILES * geo.G;
+  constexpr int NT = NWV * 64, LAGS = NWV * BF_MT * 16, TILES = (LCS_N_IDX + LAGS - 1) / LAGS, AWN = LAGS + 16 * LCS_BF_KB_MAX + 16;
+  const int per_slot = TILES * geo.G;
   int q, sidx;
   if (xcd_map) { sidx = blockIdx.x & 7; q = blockIdx.x >> 3; sidx += 8 * (q / per_slot); q = q % per_slot; }
   else { sidx = blockIdx.x / per_slot; q = blockIdx.x % per_slot; }
   if (sidx >= n_slots) return;
-  const int slot = slot0 + sidx, g = q / BF_TILES, idx0 = (q % BF_TILES) * BF_LAGS;
+  const int slot = slot0 + sidx, g = q / TILES, idx0 = (q % TILES) * LAGS;
   const int widx0 = idx0 + wave * (BF_MT * 16);
   const int n_mt = min(max((LCS_N_IDX - widx0 + 15) / 16, 0), BF_MT);
 
-  __shared__ uint32_t ldsA[2][BF_AW];
+  __shared__ uint32_t ldsA[2][AWN];
   const uint32_t *cap = capb + (size_t)slot * geo.n_cap;
   const int *smin_s = smin + (size_t)slot * NW * GM + g;
   (void)kp2;
@@ -276,15 +277,15 @@ __global__ __launch_bounds__(256, 2) void k_xcorr_bf16x3_unrolled(const uint32_t
   f32x4 P[BF_MT];
 #pragma unroll
   for (int mt = 0; mt < BF_MT; ++mt) P[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  constexpr int ASTEPS = (BF_AW + 255) / 256;
+  constexpr int ASTEPS = (AWN + NT - 1) / NT;
   uint32_t preA[ASTEPS];
 #define BF_LOAD_A(W)                                                                   \
   {                                                                                    \
     const int L0_ = idx0 + smin_s[(W) * GM];                                           \
     _Pragma("unroll") for (int r_ = 0; r_ < ASTEPS; ++r_) {                            \
-      const int n_ = tid + 256 * r_;                                                   \
+      const int n_ = tid + NT * r_;                                                    \
       const uint32_t s_ = (uint32_t)(L0_ + n_);                                        \
-      preA[r_] = (n_ < BF_AW && s_ < geo.n_cap) ? cap[s_] : 0u;                        \
+      preA[r_] = (n_ < AWN && s_ < geo.n_cap) ? cap[s_] : 0u;                          \
     }                                                                                  \
   }
 #define BF_GLOAD_B(DST, W, KB)                                                         \
@@ -304,8 +305,8 @@ __global__ __launch_bounds__(256, 2) void k_xcorr_bf16x3_unrolled(const uint32_t
     uint32_t *bufA = ldsA[w & 1];
 #pragma unroll
     for (int r = 0; r < ASTEPS; ++r) {
-      const int n = tid + 256 * r;
-      if (n < BF_AW) bufA[n] = preA[r];
+      const int n = tid + NT * r;
+      if (n < AWN) bufA[n] = preA[r];
     }
     if (has_next) BF_LOAD_A(w + 1);
     __syncthreads();
@@ -357,9 +358,12 @@ int lcs_launch_fill_btab_bf16(lcs_ctx *c, int n_buf, const XcGeom &geo) {
 int lcs_launch_xcorr_bf16(lcs_ctx *c, hipStream_t sxc, const XcGeom &geo, int slot0, int n_slots, int xcd_map) {
   const unsigned grid = (unsigned)(BF_TILES * geo.G * n_slots);
   static const bool force_loop = getenv("LCS_BF16_LOOP") != nullptr;   // tuning knob
-  if (c->grid_max_k2 <= 72 && !force_loop)   // every (window, group) has exactly 9 tap blocks (137 taps + spread <= 144)
-    hipLaunchKernelGGL(k_xcorr_bf16x3_unrolled<9>, dim3(grid), dim3(256), 0, sxc, c->capb, c->smin, c->kp2, c->bt16, c->single, geo,
-                       slot0, n_slots, xcd_map);
+  // every (window, group) has exactly 9 tap blocks (137 taps + spread <= 144): the straight-line kernel, 4 waves per
+  // workgroup (1- and 2-wave workgroups run the kernel as fast in isolation but leave the small kernels of the
+  // neighbouring batches fewer openings: -13 % in the pipelined chain)
+  if (c->grid_max_k2 <= 72 && !force_loop)
+    hipLaunchKernelGGL((k_xcorr_bf16x3_unrolled<9, 4>), dim3(grid), dim3(256), 0, sxc, c->capb, c->smin, c->kp2, c->bt16, c->single,
+                       geo, slot0, n_slots, xcd_map);
   else
     hipLaunchKernelGGL(k_xcorr_bf16x3_loop, dim3(grid), dim3(256), 0, sxc, c->capb, c->smin, c->kp2, c->bt16, c->single, geo,
                        slot0, n_slots, xcd_map);
