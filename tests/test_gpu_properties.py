@@ -125,6 +125,27 @@ def test_bf16_three_term_correlation_matches_fp32(S, pkg, synth_buf):
     assert m >= 8
 
 
+def test_bf16_kernel_short_buffers_and_single_hypothesis(S, pkg, synth_buf):
+    """The bf16 kernel on shapes away from the benchmark's: 135360-sample buffers (14 combining windows, the
+    Matlab/test_xcorr_pss.mat length), a single frequency hypothesis (one template group, 3 of its 16 columns
+    used) and a 3-entry grid -- always against the fp32 kernel on the same device-resident bytes."""
+    import torch
+    g = golden("capbuf_0000")["iq_u8"]
+    n_short = 135360
+    bufs = np.stack([g[:2 * n_short], synth_buf[:2 * n_short], np.roll(g, 2 * 999)[:2 * n_short]])
+    d = torch.from_numpy(np.ascontiguousarray(bufs)).cuda()
+    for f in (np.array([35e3]), np.array([30e3, 35e3, 40e3]), f_search_set_for(FC, 100)):
+        out = {}
+        for v in (0, 3):
+            S.set_xcorr_variant(v)
+            out[v] = S.search_batch(d.data_ptr(), pkg.FMT_IQ_U8, 3, n_short, f, FC, FC, FS, pkg.STAGE_PSS, max_cells_per_buf=64)
+        S.set_xcorr_variant(0)
+        for a, b in zip(out[0], out[3]):
+            assert [(c.n_id_2, c.ind, c.freq) for c in a] == [(c.n_id_2, c.ind, c.freq) for c in b]
+            assert all(abs(ca.pss_pow - cb.pss_pow) <= 2e-6 * cb.pss_pow for ca, cb in zip(a, b))
+        assert len(out[0][0]) >= 1
+
+
 def test_per_cell_rounds_and_overflow(S, pkg, synth_buf, monkeypatch):
     """The per-cell stages take LCS_MAX_WORK cells per round.  With the round size forced down to 3
     cells, a 19-buffer batch (38 cells past SSS) is decoded in 13 non-empty rounds (plus empty ones)
