@@ -296,10 +296,14 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_xcorr_bf16x3_unrolled(const uin
       (DST)[op_] = (u32x4){t_.x, t_.y, t_.z, t_.w};                                    \
     }                                                                                  \
   }
-  u32x4 Bq[NKB + 2][BF_TOPS];     // static indices only: block kb of the window, +2 = first two of the next
+#ifndef LCS_BF16_DEPTH
+#define LCS_BF16_DEPTH 2          // operand blocks requested ahead of use
+#endif
+  constexpr int PD = LCS_BF16_DEPTH;
+  u32x4 Bq[NKB + PD][BF_TOPS];    // static indices only: block kb of the window, +PD = first ones of the next
   BF_LOAD_A(0);
-  BF_GLOAD_B(Bq[0], 0, 0);
-  BF_GLOAD_B(Bq[1], 0, 1);
+#pragma unroll
+  for (int i = 0; i < PD; ++i) BF_GLOAD_B(Bq[i], 0, i);
   for (int w = 0; w < geo.n_comb; ++w) {
     const bool has_next = w + 1 < geo.n_comb;
     uint32_t *bufA = ldsA[w & 1];
@@ -318,15 +322,19 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_xcorr_bf16x3_unrolled(const uin
     for (int s = 0; s < BF_MT - 1; ++s) { const uint32_t *p_ = bufA + a_off + 16 * s; Aw[s] = (u32x4){p_[0], p_[1], p_[2], p_[3]}; }
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
-      // request the block two ahead: in this window, or block 0 / 1 of the next one
-      if (kb + 2 < NKB) BF_GLOAD_B(Bq[kb + 2], w, kb + 2)
-      else if (has_next) BF_GLOAD_B(Bq[kb + 2], w + 1, kb + 2 - NKB)
+      // request the block PD ahead: in this window, or one of the first PD blocks of the next one
+      if (kb + PD < NKB) BF_GLOAD_B(Bq[kb + PD], w, kb + PD)
+      else if (has_next) BF_GLOAD_B(Bq[kb + PD], w + 1, kb + PD - NKB)
       { const uint32_t *p_ = bufA + a_off + 16 * (kb + BF_MT - 1); Aw[kb + BF_MT - 1] = (u32x4){p_[0], p_[1], p_[2], p_[3]}; }
       BF_MFMA_BLOCK(Aw, kb, Bq[kb]);
+#ifndef LCS_BF16_NO_SCHED_BARRIER
       __builtin_amdgcn_sched_barrier(0);
+#endif
     }
 #pragma unroll
-    for (int op = 0; op < BF_TOPS; ++op) { Bq[0][op] = Bq[NKB][op]; Bq[1][op] = Bq[NKB + 1][op]; }
+    for (int op = 0; op < BF_TOPS; ++op)
+#pragma unroll
+      for (int i = 0; i < PD; ++i) Bq[i][op] = Bq[NKB + i][op];
 #pragma unroll
     for (int mt = 0; mt < BF_MT; ++mt)
 #pragma unroll
