@@ -30,9 +30,14 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define NFM LCS_NF_MAX
 #define GM LCS_G_MAX
 
-#define BF_LAGS 512
+#define BF_LAGS (4 * BF_MT * 16)
 #define BF_TILES ((LCS_N_IDX + BF_LAGS - 1) / BF_LAGS)
-#define BF_MT 8
+#ifndef BF_MT
+#define BF_MT 8                                        // 16-lag sub-tiles per wave
+#endif
+#ifndef BF_WPS
+#define BF_WPS 2                                       // waves per SIMD the unrolled kernel is compiled for
+#endif
 #define BF_AW (BF_LAGS + 16 * LCS_BF_KB_MAX + 16)     // staged samples per window
 #define BF_OPS 6                                      // B operands per tap block: re1 re2 re3 im1 im2 im3
 #define BF_TOPS 3                                     // stored per tap block: the three split terms as (tr, ti) pairs
@@ -242,16 +247,19 @@ __global__ __launch_bounds__(256, 2) void k_xcorr_bf16x3_loop(const uint32_t *__
 // v_mov rotation), and the 48 MFMAs of a block are ordered split-term-major so that MFMAs into the
 // same accumulator are 16 instructions apart.  1.78 ms per 64-buffer launch against 1.95 ms for the loop.
 // (sub-tiles past idx 9599 in the last workgroup of a row are computed and dropped: no branch in the block)
-#define BF_MFMA_BLOCK(AW, S0, BT)                                                                         \
+#define BF_MFMA_BLOCK(AW, S0, BT, FIRST)                                                                  \
   _Pragma("unroll") for (int sp_ = 0; sp_ < 3; ++sp_) {                                                   \
     const u32x4 bre_ = bf_op_re(BT[sp_]), bim_ = bf_op_im(BT[sp_]);                                       \
     _Pragma("unroll") for (int mt_ = 0; mt_ < BF_MT; ++mt_) {                                             \
-      aR[mt_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AS_BF(AW[(S0) + mt_]), AS_BF(bre_), aR[mt_], 0, 0, 0); \
-      aI[mt_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AS_BF(AW[(S0) + mt_]), AS_BF(bim_), aI[mt_], 0, 0, 0); \
+      /* the first MFMA of a window starts from the inline constant 0 instead of a zeroed register */     \
+      const f32x4 cr_ = ((FIRST) && sp_ == 0) ? (f32x4){0.f, 0.f, 0.f, 0.f} : aR[mt_];                    \
+      const f32x4 ci_ = ((FIRST) && sp_ == 0) ? (f32x4){0.f, 0.f, 0.f, 0.f} : aI[mt_];                    \
+      aR[mt_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AS_BF(AW[(S0) + mt_]), AS_BF(bre_), cr_, 0, 0, 0); \
+      aI[mt_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AS_BF(AW[(S0) + mt_]), AS_BF(bim_), ci_, 0, 0, 0); \
     }                                                                                                     \
   }
 template <int NKB, int NWV>   // NKB tap blocks per window, the same for every (window, group) of the launch (host-checked); NWV waves
-__global__ __launch_bounds__(NWV * 64, 2) void k_xcorr_bf16x3_unrolled(const uint32_t *__restrict__ capb, const int *__restrict__ smin,
+__global__ __launch_bounds__(NWV * 64, BF_WPS) void k_xcorr_bf16x3_unrolled(const uint32_t *__restrict__ capb, const int *__restrict__ smin,
                                                                   const int *__restrict__ kp2, const uint4 *__restrict__ bt16,
                                                                   float *__restrict__ sg, XcGeom geo, int slot0, int n_slots,
                                                                   int xcd_map) {
@@ -315,8 +323,6 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_xcorr_bf16x3_unrolled(const uin
     if (has_next) BF_LOAD_A(w + 1);
     __syncthreads();
     f32x4 aR[BF_MT], aI[BF_MT];
-#pragma unroll
-    for (int mt = 0; mt < BF_MT; ++mt) { aR[mt] = (f32x4){0.f, 0.f, 0.f, 0.f}; aI[mt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
     u32x4 Aw[NKB + BF_MT - 1];
 #pragma unroll
     for (int s = 0; s < BF_MT - 1; ++s) { const uint32_t *p_ = bufA + a_off + 16 * s; Aw[s] = (u32x4){p_[0], p_[1], p_[2], p_[3]}; }
@@ -326,7 +332,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_xcorr_bf16x3_unrolled(const uin
       if (kb + PD < NKB) BF_GLOAD_B(Bq[kb + PD], w, kb + PD)
       else if (has_next) BF_GLOAD_B(Bq[kb + PD], w + 1, kb + PD - NKB)
       { const uint32_t *p_ = bufA + a_off + 16 * (kb + BF_MT - 1); Aw[kb + BF_MT - 1] = (u32x4){p_[0], p_[1], p_[2], p_[3]}; }
-      BF_MFMA_BLOCK(Aw, kb, Bq[kb]);
+      BF_MFMA_BLOCK(Aw, kb, Bq[kb], kb == 0);
 #ifndef LCS_BF16_NO_SCHED_BARRIER
       __builtin_amdgcn_sched_barrier(0);
 #endif

@@ -230,10 +230,10 @@ __device__ __forceinline__ bool tfg_row_needed(int t, int n_symb) {
 // ------------------------------------------------------------------ extract_tfg: grid
 // 8 OFDM symbols per workgroup pass: frequency-correct 8x128 samples of the capture buffer into
 // LDS (the reference rotates all 153600 samples per cell, ref :892; only the 854x128 that feed a
-// DFT are touched here, with the same absolute-index phase), direct 72-bin DFT, /sqrt(128),
-// then the sub-sample timing phase ramp (ref :923-931).
-#define TFG_SYM 8            // 8 x 2 KB windows + twiddles = 18 KB of LDS: fits beside the correlation kernel's workgroups
-#define TFG_THREADS 144     // 36 +-k bin pairs x 4 symbol groups
+// DFT are touched here, with the same absolute-index phase), 128-point FFT, the 72 occupied bins
+// /sqrt(128), then the sub-sample timing phase ramp (ref :923-931).
+#define TFG_SYM 8            // 8 x 2 KB windows + twiddles = 18 KB of LDS
+#define TFG_THREADS 256     // 4 waves: wave v transforms windows v and v + 4, one radix-2 butterfly per lane and stage
 __global__ __launch_bounds__(TFG_THREADS) void k_tfg(const lcs_cell *__restrict__ cells, const WorkItem *__restrict__ items,
                                                      const int *__restrict__ n_work, const SlotParams *__restrict__ params,
                                                      const float2 *__restrict__ cap32,
@@ -294,32 +294,30 @@ __global__ __launch_bounds__(TFG_THREADS) void k_tfg(const lcs_cell *__restrict_
     __syncthreads();
     PH(31);
     {
-      // thread = (bin pair +-k, symbol group g).  Bins k and 128-k have conjugate twiddles, so the
-      // four real products of x*w serve both: x*w = (p-q, r+t), x*conj(w) = (p+q, t-r) -- the same
-      // roundings as two separate complex multiplies, half the multiplies and twiddle reads.
-      const int k = tid % 36 + 1, g = tid / 36;
-      cd2 accp[TFG_SYM / 4], accm[TFG_SYM / 4];
+      // 128-point decimation-in-frequency FFT in place (natural order in, bit-reversed order out), like
+      // the reference's FFTW call (ref :904): 7 stages of 64 butterflies; 72 of the 128 bins are kept.
+      const int lane = tid & 63, wv = tid >> 6;
 #pragma unroll
-      for (int q = 0; q < TFG_SYM / 4; ++q) { accp[q] = mk(0, 0); accm[q] = mk(0, 0); }
-      for (int n = 0; n < 128; ++n) {
-        const cd2 tw = W[(k * n) & 127];
+      for (int stg = 0; stg < 7; ++stg) {
+        const int half = 64 >> stg;
+        const int pos = lane & (half - 1);
+        const int i0 = ((lane >> (6 - stg)) << (7 - stg)) + pos, i1 = i0 + half;
+        const cd2 tw = W[pos << stg];
 #pragma unroll
-        for (int q = 0; q < TFG_SYM / 4; ++q) {
-          const cd2 x = win[g + 4 * q][n];
-          const double pp = x.re * tw.re, qq = x.im * tw.im, rr = x.re * tw.im, tt = x.im * tw.re;
-          accp[q] = cadd(accp[q], mk(pp - qq, rr + tt));
-          accm[q] = cadd(accm[q], mk(pp + qq, tt - rr));
+        for (int pass = 0; pass < 2; ++pass) {
+          cd2 *x = win[wv + 4 * pass];
+          const cd2 a = x[i0], b = x[i1];
+          x[i0] = cadd(a, b);
+          x[i1] = cmul(csub(a, b), tw);
         }
+        __syncthreads();
       }
-#pragma unroll
-      for (int half = 0; half < 2; ++half) {
-      const int i = half ? 35 + k : 36 - k;          // column of subcarrier +k / -k
-      const cd2 *acc = half ? accp : accm;
-#pragma unroll
-      for (int q = 0; q < TFG_SYM / 4; ++q) {
-        const int t = s_row[g + 4 * q];
+      for (int e = tid; e < TFG_SYM * NSC; e += TFG_THREADS) {
+        const int sidx = e / NSC, i = e % NSC;
+        const int t = s_row[sidx];
         if (t < 0) continue;
-        cd2 a = cdivr(acc[q], sqrt(128.0));
+        const int bin = (i < 36) ? 92 + i : i - 35;
+        cd2 a = cdivr(win[sidx][__brev((unsigned)bin) >> 25], sqrt(128.0));
         const double ideal = tsi[t];
         const double late = (double)d_round_i(ideal) - ideal;
         double k_im = -1.0;
@@ -327,7 +325,6 @@ __global__ __launch_bounds__(TFG_THREADS) void k_tfg(const lcs_cell *__restrict_
         const double ph = k_im * (double)cn_of(i);
         a = cmul(a, mk(cos(ph), sin(ph)));
         st(&tfg[((size_t)it * ROWS + t) * NSC + i], a);
-      }
       }
       PH(32);
     }
