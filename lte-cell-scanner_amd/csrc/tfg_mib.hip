@@ -31,7 +31,7 @@ extern "C" int lcs_debug_phase_ts(unsigned long long *out) { return (int)hipMemc
 #define CS_NPP 640       // [4 ports][CE_NCHUNK <= 8] partial sums of |filtered - raw|^2
 #define CS_TF_RES 680    // tfoec: residual_f, k_factor_residual, delay
 #define CS_TF_KRES 681
-#define CS_TF_DELAY 682
+#define CS_TF_TOE 684     // 4 complex partial sums of the timing estimate (k_tfoec_est parts), summed in part order
 #define CS_CAND 16       // 12 candidates x 4: ok, bits lo (24 bits as double), unused
 #define CS_SHIFT 64      // [140][4] (-1 = no RS)
 #define CS_RS 1024       // [140][12] complex
@@ -143,13 +143,16 @@ __device__ void tfg_timestamps(const lcs_cell &c, const SlotParams &p, double *t
   const double inc_ext = (128 + 32) * 16 / FS_LTE * p.fs_prog * k_factor;
   const double inc_10 = (128 + 10) * 16 / FS_LTE * p.fs_prog * k_factor;
   const double inc_9 = (128 + 9) * 16 / FS_LTE * p.fs_prog * k_factor;
-  int sym_num = 0;
-  for (int t = 0; t < n_ofdm; ++t) {
-    t_out[t] = loc;
-    if (n_symb == 6) loc += inc_ext;
-    else {
-      loc += (sym_num == 6) ? inc_10 : inc_9;
-      sym_num = (sym_num == 6) ? 0 : sym_num + 1;
+  // one slot per iteration: the same running sum, without per-symbol bookkeeping in the dependent chain
+  if (n_symb == 6) {
+    for (int sl = 0; sl < n_ofdm / 6; ++sl) {
+#pragma unroll
+      for (int q = 0; q < 6; ++q) { t_out[sl * 6 + q] = loc; loc += inc_ext; }
+    }
+  } else {
+    for (int sl = 0; sl < n_ofdm / 7; ++sl) {
+#pragma unroll
+      for (int q = 0; q < 7; ++q) { t_out[sl * 7 + q] = loc; loc += (q == 6) ? inc_10 : inc_9; }
     }
   }
   sc[CS_N_OFDM] = (double)n_ofdm;
@@ -364,7 +367,8 @@ __device__ __forceinline__ cd2 foc_value(const double2 *g, int t, int i, double 
   return cmul(v, mk(cos(ph), sin(ph)));
 }
 
-#define TF_THREADS 256     // one wave per SIMD: placeable beside the correlation kernel (VGPR budget)
+#define TF_THREADS 256
+#define TF_PARTS 4
 __global__ __launch_bounds__(TF_THREADS) void k_tfoec_est(lcs_cell *__restrict__ cells, const WorkItem *__restrict__ items,
                                                           const int *__restrict__ n_work,
                                                           const SlotParams *__restrict__ params,
@@ -373,7 +377,7 @@ __global__ __launch_bounds__(TF_THREADS) void k_tfoec_est(lcs_cell *__restrict__
   LCS_TAIL_PRIO();
   __shared__ cd2 red[TF_THREADS / 64];
   __shared__ cd2 rowrot[ROWS];
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, part_idx = blockIdx.y;     // the timing-estimate sum is split over TF_PARTS workgroups
   for (int it = blockIdx.x; it < *n_work; it += gridDim.x) {
     const lcs_cell c = cells[it];
     const SlotParams p = params[items[it].slot];
@@ -400,7 +404,7 @@ __global__ __launch_bounds__(TF_THREADS) void k_tfoec_est(lcs_cell *__restrict__
     const double residual_f = atan2(foe.im, foe.re) / (2 * M_PI) / 0.0005;
     const double k_res = (p.fc_req - residual_f) / p.fc_prog;
     for (int t = tid; t < n_ofdm; t += TF_THREADS) {
-      tsc[t] = k_res * tsi[t];
+      if (part_idx == 0) tsc[t] = k_res * tsi[t];
       const int sym = t % n_symb;
       if (sym == 0 || sym == n_symb - 3) rowrot[t] = foc_row_rot(tsi[t], k_res, residual_f);   // the rows the TOE reads
     }
@@ -408,7 +412,8 @@ __global__ __launch_bounds__(TF_THREADS) void k_tfoec_est(lcs_cell *__restrict__
     // TOE (ref :1012-1058) on the frequency-corrected RS samples
 #define GC(row, col) foc_value(g, (row), (col), tsi[(row)], k_res, rowrot[(row)])
     part = mk(0, 0);
-    for (int e = tid; e < (2 * n_slot - 1) * 23; e += TF_THREADS) {
+    const int n_toe = (2 * n_slot - 1) * 23, per_part = (n_toe + TF_PARTS - 1) / TF_PARTS;
+    for (int e = part_idx * per_part + tid; e < min(n_toe, (part_idx + 1) * per_part); e += TF_THREADS) {
       const int t = e / 23, j = e % 23;
       const int cur_sym = (t & 1) ? (n_symb - 3) : 0, cur_slot = d_imod(t >> 1, 20), cur_off = (t >> 1) * n_symb + cur_sym;
       const int cur_sh = rs_shift(sc, n_symb, 0, cur_sym, 0);
@@ -432,10 +437,13 @@ __global__ __launch_bounds__(TF_THREADS) void k_tfoec_est(lcs_cell *__restrict__
     const cd2 toe = block_sum(part, red);
     PH(13);
     if (tid == 0) {
-      sc[CS_TF_RES] = residual_f;
-      sc[CS_TF_KRES] = k_res;
-      sc[CS_TF_DELAY] = -atan2(toe.im, toe.re) / 3 / (2 * M_PI / 128);
-      cells[it].freq_superfine = c.freq_fine + residual_f;
+      sc[CS_TF_TOE + 2 * part_idx] = toe.re;
+      sc[CS_TF_TOE + 2 * part_idx + 1] = toe.im;
+      if (part_idx == 0) {
+        sc[CS_TF_RES] = residual_f;
+        sc[CS_TF_KRES] = k_res;
+        cells[it].freq_superfine = c.freq_fine + residual_f;
+      }
     }
     __syncthreads();
     PH(14);
@@ -458,7 +466,10 @@ __global__ __launch_bounds__(TFA_THREADS) void k_tfoec_apply(const int *__restri
     const int it = job / tiles, t0 = (job % tiles) * TFA_ROWS;
     const double *sc = scratch + (size_t)it * CS_SIZE;
     const int n_ofdm = (int)sc[CS_N_OFDM];
-    const double residual_f = sc[CS_TF_RES], k_res = sc[CS_TF_KRES], delay = sc[CS_TF_DELAY];
+    const double residual_f = sc[CS_TF_RES], k_res = sc[CS_TF_KRES];
+    cd2 toe = mk(0, 0);
+    for (int q = 0; q < TF_PARTS; ++q) toe = cadd(toe, mk(sc[CS_TF_TOE + 2 * q], sc[CS_TF_TOE + 2 * q + 1]));
+    const double delay = -atan2(toe.im, toe.re) / 3 / (2 * M_PI / 128);          // ref :1058
     const double2 *g = tfg + (size_t)it * ROWS * NSC;
     double2 *gc = tfg_comp + (size_t)it * ROWS * NSC;
     const double *tsi = ts + (size_t)it * ROWS;
@@ -998,7 +1009,7 @@ int lcs_launch_rs_build(lcs_ctx *c) {
 }
 int lcs_launch_tfoec(lcs_ctx *c, int n_items) {
   (void)n_items;
-  hipLaunchKernelGGL(k_tfoec_est, dim3(GRID_ITEMS), dim3(TF_THREADS), 0, c->stream, c->cells_out, c->work_items, c->n_work,
+  hipLaunchKernelGGL(k_tfoec_est, dim3(GRID_ITEMS, TF_PARTS), dim3(TF_THREADS), 0, c->stream, c->cells_out, c->work_items, c->n_work,
                      c->params, c->tfg, c->tfg_ts, c->cell_scratch, c->tfg_ts_comp);
   hipLaunchKernelGGL(k_tfoec_apply, dim3(2048), dim3(TFA_THREADS), 0, c->stream, c->n_work, c->tfg, c->tfg_ts, c->cell_scratch,
                      c->cells_out, c->tfg_comp, c->needed_rows_only ? 1 : 0);
