@@ -23,6 +23,11 @@ import time
 
 import numpy as np
 
+# more streams than the default 4 hardware queues per process are in flight (3 contexts x 2 streams + the
+# collective library): give each its own queue (same single-process throughput; without it two processes
+# sharing ONE GPU, as in the gloo test setup, stall in the launch path)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 N_CAP, FS = 153600, 1.92e6
