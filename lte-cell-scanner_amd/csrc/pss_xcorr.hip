@@ -13,13 +13,17 @@
 // delay is folded into the template ("B") table, which therefore holds zero-padded, shifted
 // copies of conj(fshift(pss_td))/137.  Raw xc never touches HBM.
 //
-// The complex dot product is evaluated as the real product  [xr -xi ; xi xr] x [tr ; ti]
-// with fp32 FMAs in tap order.  Two interchangeable kernels compute the SAME fma chain:
-//   k_xcorr_mfma : v_mfma_f32_16x16x4_f32 (exact fp32, k-ordered fma chain) -- A operands are
-//                  Toeplitz slices read straight from the LDS planes, B operands are 256-byte
-//                  coalesced rows of the template table;
-//   k_xcorr_valu : lane = output position, template taps broadcast through scalar loads.
-// Their outputs are bit-identical (tests/test_gpu_parity.py).
+// This file: ingest, tables, signal-power estimate, collapse, and the fp32 correlation kernels, used for
+// sources that are not exact in bfloat16 (complex<float> / complex<double> buffers); raw RTL-SDR u8 I/Q
+// takes the bf16 three-term kernel of pss_xcorr_bf16.hip.  The complex dot product is evaluated as the
+// real product  [xr -xi ; xi xr] x [tr ; ti]  with fp32 FMAs in tap order.  Three interchangeable
+// kernels compute the SAME fma chain:
+//   k_xcorr_mfma_blk : v_mfma_f32_16x16x4_f32 (exact fp32, k-ordered fma chain), 4-wave workgroups, A
+//                      operands are Toeplitz slices read straight from LDS planes, B operands (template
+//                      rows) stream through LDS -- the default;
+//   k_xcorr_mfma     : the same with one-wave workgroups and B rows from L2;
+//   k_xcorr_valu     : lane = output position, template taps broadcast through scalar loads.
+// Their outputs are bit-identical (tests/test_gpu_pss.py).
 #include "lcs_internal.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
