@@ -35,6 +35,7 @@ FS = 1.92e6
 FC = 739e6
 PEAK_FP32_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense FP32 MFMA peak == packed FP32 vector peak
 PEAK_BF16_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense BF16 MFMA peak (~2.5 PFLOP/s)
+PEAK_I8_TOPS = 5000.0         # MI355X_MICROARCH.md: I8 MFMA "~2x bf16 rate" (no spec line; 16x16x64 micro-benchmark ceiling 3944 TOPS)
 PUBLISHED_BUFFERS_PER_S = 1.0 / 6.0   # ~6 s per centre frequency at ppm 100 (dual-core i7-2640)
 
 
@@ -174,7 +175,7 @@ def main():
                     help="full = BASELINE configs[2], the whole CellSearch chain (default); pss = configs[1], xcorr_pss + "
                          "peak_search only; stream = configs[4], one host buffer at a time through the hipGraph-captured "
                          "single-hypothesis chain (separate, shorter report)")
-    ap.add_argument("--variant", type=int, default=0, help="PSS correlation kernel: 0 = default (bf16 three-term MFMA kernel for the u8 input), 1 = fp32 VALU twin, 2 = one-wave fp32 MFMA kernel, 3 = 4-wave fp32 MFMA kernel")
+    ap.add_argument("--variant", type=int, default=0, help="PSS correlation kernel: 0 = default (int8 three-digit MFMA kernel for the u8 input), 1 = fp32 VALU twin, 2 = one-wave fp32 MFMA kernel, 3 = 4-wave fp32 MFMA kernel, 4 = bf16 three-term MFMA kernel")
     ap.add_argument("--pipeline", type=int, default=3,
                     help="contexts (streams + workspaces) used round-robin: with 2, the latency-bound per-cell "
                          "stages of step i overlap the PSS correlation of step i+1")
@@ -312,9 +313,11 @@ def main():
         # Which kernel ran: u8 sources take the bf16 three-term kernel (every fp32 product a*t is formed as
         # a*t1 + a*t2 + a*t3 with exact bf16 factors, i.e. 3 MFMA MACs per algorithmic MAC), anything else
         # and the --variant knobs the fp32 kernels.
-        bf16 = args.variant == 0 and os.environ.get("LCS_NO_BF16") is None
-        macs_factor, peak = (3.0, PEAK_BF16_TFLOPS) if bf16 else (1.0, PEAK_FP32_TFLOPS)
-        kname = "k_xcorr_bf16x3_unrolled<9>" if bf16 else {0: "k_xcorr_mfma_blk<4,4,32>", 1: "k_xcorr_valu", 2: "k_xcorr_mfma", 3: "k_xcorr_mfma_blk<4,4,32>"}.get(args.variant)
+        i8 = args.variant == 0 and os.environ.get("LCS_NO_I8") is None
+        bf16 = (not i8) and (args.variant == 4 or (args.variant == 0 and os.environ.get("LCS_NO_BF16") is None))
+        macs_factor, peak = (3.0, PEAK_I8_TOPS) if i8 else ((3.0, PEAK_BF16_TFLOPS) if bf16 else (1.0, PEAK_FP32_TFLOPS))
+        kname = "k_xcorr_i8x3" if i8 else ("k_xcorr_bf16x3_unrolled<9>" if bf16 else
+                                            {0: "k_xcorr_mfma_blk<4,4,32>", 1: "k_xcorr_valu", 2: "k_xcorr_mfma", 3: "k_xcorr_mfma_blk<4,4,32>"}.get(args.variant))
         achieved = macs_factor * flops_per_buf * B / (k_ms * 1e-3) / 1e12
         bytes_per_buf = 1651200 + 230400 * n_f                 # SURVEY.md section 8d compulsory HBM bytes
         out = {
@@ -322,13 +325,15 @@ def main():
             "value": value, "unit": "capture-buffers/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": value / PUBLISHED_BUFFERS_PER_S,
-            "dtype": "bf16x3 products (exact), f32 accumulate" if bf16 else "f32", "data": "synthetic",
+            "dtype": ("i8 x 3 base-256 digits of 24-bit integer templates, i32 accumulate (exact)" if i8 else
+                      "bf16x3 products (exact), f32 accumulate" if bf16 else "f32"), "data": "synthetic",
             "iq_samples_per_s": value * N_CAP,
             "config": {"workload": ("configs[2]: full searcher chain (PSS+SSS+FOE+TFG+MIB)" if args.stage == "full" else
                                     "configs[1]: xcorr_pss + peak_search over the full +-100 ppm foe grid") +
                                    f", one MI355X per rank, {B} x 153600-sample capbufs per step, fc 739 MHz + 100 kHz raster",
                        "n_f": int(n_f), "batch_per_gpu": B, "stage": args.stage, "ingest": "u8 I/Q resident in HBM",
-                       "xcorr_kernel": "mfma_f32_16x16x32_bf16, three exact bf16 terms per fp32 template tap" if bf16 else
+                       "xcorr_kernel": "mfma_i32_16x16x64_i8, three int8 digits per 24-bit integer template tap" if i8 else
+                                       "mfma_f32_16x16x32_bf16, three exact bf16 terms per fp32 template tap" if bf16 else
                                        ("valu_f32" if args.variant == 1 else "mfma_f32_16x16x4_f32"),
                        "pipeline_depth": len(ctxs),
                        "parallelism": f"carrier-sweep shard x{world}, RCCL all-gather of cell list" if world > 1 else "single GPU",
@@ -337,15 +342,18 @@ def main():
                        "step_done_ms": [round(1e3 * (x - t0), 2) for x in host_t.get("stamps", [])[-args.steps:]],
                        "host_ms_per_step": {"enqueue": 1e3 * host_t["enqueue"] / max(1, host_t["n"]),
                                             "collect_incl_wait": 1e3 * host_t["collect"] / max(1, host_t["n"])}},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TOP/s" if i8 else "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic,
-                         "flops_note": ("achieved = 3 x the algorithmic flops of SURVEY 8d (three exact bf16 MACs realise one fp32 MAC) / kernel time, "
+                         "flops_note": ("achieved = 3 x the algorithmic flops of SURVEY 8d (three int8 digit MACs realise one MAC with a 24-bit "
+                                        "integer template tap) / kernel time, against 2x the dense bf16 MFMA peak (the 16x16x64 i8 micro-benchmark "
+                                        "ceiling is 3944 TOP/s); fp32_equivalent_tflops counts the algorithmic flops once") if i8 else
+                                       ("achieved = 3 x the algorithmic flops of SURVEY 8d (three exact bf16 MACs realise one fp32 MAC) / kernel time, "
                                         "against the dense bf16 MFMA peak; fp32_equivalent_tflops counts the algorithmic flops once") if bf16 else
                                        "achieved = algorithmic flops of SURVEY 8d / kernel time, against the fp32 MFMA peak",
                          "fp32_equivalent_tflops": flops_per_buf * B / (k_ms * 1e-3) / 1e12,
                          "traffic_note": "HBM bytes per launch from rocprofv3 PMC (2*FETCH_SIZE+WRITE_SIZE)*1024, profiles/r01/pmc_summary.json; "
                                          "algorithmic bytes of this kernel per launch (capture buffer in, xc_incoherent_single out): %d"
-                                         % int(((4 if bf16 else 8) * N_CAP + 4 * 3 * 9600 * n_f) * B),
+                                         % int(((2 if i8 else 4 if bf16 else 8) * N_CAP + 4 * 3 * 9600 * n_f) * B),
                          "kernel": kname, "kernel_ms": k_ms,
                          "kernel_ms_isolated": float(np.mean(iso_ms)),
                          "frac_isolated": macs_factor * flops_per_buf * B / (float(np.mean(iso_ms)) * 1e-3) / 1e12 / peak,

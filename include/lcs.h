@@ -78,11 +78,13 @@ void lcs_destroy(lcs_ctx *ctx);
 const char *lcs_last_error(const lcs_ctx *ctx);
 const char *lcs_version(void);
 void lcs_cell_init(lcs_cell *c);                      /* src/common.cpp:36-56 */
-/* Knob for A/B measurement of the PSS correlation kernel: 0 = default: fp32-MFMA kernel (4-wave
- * workgroups, template rows through LDS), and for u8 I/Q sources -- exact in bf16 -- the three-term
- * bf16 MFMA kernel (same products, fp32 accumulation); 1 = plain-VALU twin, 2 = 1-wave fp32 MFMA kernel
- * with template rows from L2, 3 = the fp32 kernel of variant 0 for every source.  1, 2, 3 produce
- * bit-identical results; the bf16 kernel agrees with them to ~1e-7 relative. */
+/* Knob for A/B measurement of the PSS correlation kernel.  0 = default: chosen by the source format --
+ * raw RTL-SDR u8 I/Q is exact in int8 and bfloat16 and takes the int8 three-digit MFMA kernel (templates
+ * quantised to 24-bit integers, exact integer accumulation; the bf16 three-term kernel when the frequency
+ * grid is too sparse for it), every other source the fp32 MFMA kernel (4-wave workgroups, template rows
+ * through LDS).  1 = plain-VALU fp32 twin, 2 = 1-wave fp32 MFMA kernel with template rows from L2, 3 = the
+ * fp32 kernel of variant 0 for every source, 4 = the bf16 kernel for u8 sources.  1, 2, 3 are bit-identical;
+ * the int8 and bf16 kernels agree with them to ~1e-7 relative. */
 int lcs_set_xcorr_variant(lcs_ctx *ctx, int variant);
 
 /* ---- stage entry points (host buffers in / out) ------------------------------------ */

@@ -76,6 +76,11 @@ int ensure_ws(lcs_ctx *c, int n_slots, uint32_t n_cap, int n_f, bool debug) {
     A(incoh, S * NE * n_f);
   }
 #undef A
+  if (c->cap8) { (void)hipFree(c->cap8); c->cap8 = nullptr; }
+  if (c->bt8) { (void)hipFree(c->bt8); c->bt8 = nullptr; }
+  if (c->tq) { (void)hipFree(c->tq); c->tq = nullptr; }
+  if (c->tsc) { (void)hipFree(c->tsc); c->tsc = nullptr; }
+  c->i8_ready = false;
   if (c->capb) { (void)hipFree(c->capb); c->capb = nullptr; }
   if (c->bt16) { (void)hipFree(c->bt16); c->bt16 = nullptr; }
   c->bf16_ready = false;
@@ -95,6 +100,20 @@ int ensure_bf16(lcs_ctx *c) {
   if ((rc = dev_alloc(c, &c->capb, S * c->cap_n_cap))) return rc;
   if ((rc = dev_alloc(c, &c->bt16, S * LCS_NW_MAX * G * (size_t)(LCS_BF_KB_MAX * 3 * 64)))) return rc;
   c->bf16_ready = true;
+  return LCS_OK;
+}
+
+// Buffers of the int8 correlation path (u8 sources), sized like the current workspace.
+int ensure_i8(lcs_ctx *c) {
+  if (c->i8_ready) return LCS_OK;
+  const size_t S = (size_t)c->cap_slots;
+  const int G = (3 * c->cap_n_f + LCS_TG - 1) / LCS_TG;
+  int rc;
+  if ((rc = dev_alloc(c, &c->cap8, S * c->cap_n_cap))) return rc;
+  if ((rc = dev_alloc(c, &c->bt8, S * LCS_NW_MAX * G * (size_t)(3 * LCS_I8_KB * 2 * 64)))) return rc;
+  if ((rc = dev_alloc(c, &c->tq, S * LCS_G_MAX * LCS_TG))) return rc;
+  if ((rc = dev_alloc(c, &c->tsc, S * LCS_G_MAX * LCS_TG))) return rc;
+  c->i8_ready = true;
   return LCS_OK;
 }
 
@@ -246,7 +265,7 @@ void lcs_destroy(lcs_ctx *c) {
                   c->incoh, c->sref, c->pow_, c->work, c->spinc, c->zth, c->sp, c->frq, c->peaks, c->npeaks, c->xc,
                   c->work_items, c->n_work, c->tfg, c->tfg_comp, c->ce, c->tfg_ts, c->tfg_ts_comp, c->cell_scratch,
                   c->cells_out, c->d_pss_td, c->d_pss_fd, c->d_sss_fd, c->d_pbch_scr, c->d_derm_inv, c->d_dbg, c->pk_items, c->n_pk,
-                  c->sss_ws, c->d_pn_jump, c->capb, c->bt16};
+                  c->sss_ws, c->d_pn_jump, c->capb, c->bt16, c->cap8, c->bt8, c->tq, c->tsc};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   if (c->h_pinned) (void)hipHostFree(c->h_pinned);
   if (c->ev_xc0) (void)hipEventDestroy(c->ev_xc0);
@@ -261,7 +280,7 @@ void lcs_destroy(lcs_ctx *c) {
 const char *lcs_last_error(const lcs_ctx *c) { return c ? c->err.c_str() : "null context"; }
 
 int lcs_set_xcorr_variant(lcs_ctx *c, int variant) {
-  if (!c || variant < 0 || variant > 3) return LCS_ERR_BAD_ARG;
+  if (!c || variant < 0 || variant > 4) return LCS_ERR_BAD_ARG;
   c->xcorr_variant = variant;
   return LCS_OK;
 }
@@ -292,6 +311,7 @@ int lcs_xcorr_pss(lcs_ctx *c, const double *capbuf, uint32_t n_cap, const double
   HIPCHK(c, hipMemcpyAsync(c->cap64, capbuf, sizeof(double2) * n_cap, hipMemcpyHostToDevice, c->stream));
   c->cap64_valid = true;
   c->use_bf16 = false;      // complex<double> input: fp32 correlation
+  c->use_i8 = false;
   HIPCHK(c, hipMemcpyAsync(c->fset, f_search_set, sizeof(double) * n_f, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->params, &p, sizeof(p), hipMemcpyHostToDevice, c->stream));
   if ((rc = lcs_launch_ingest(c, nullptr, 2, 1, n_cap))) return rc;
@@ -377,7 +397,14 @@ int lcs_batch_enqueue(lcs_ctx *c, const void *d_capbufs, int fmt, int n_buf, uin
   // u8 I/Q is exact in bf16: the correlation runs as three exact bf16 products per tap (pss_xcorr_bf16.hip)
   static const bool no_bf16 = getenv("LCS_NO_BF16") != nullptr;   // measurement knob
   c->use_bf16 = fmt == LCS_FMT_IQ_U8 && c->xcorr_variant == 0 && !no_bf16 && 2 * c->grid_max_k2 <= 16 * LCS_BF_KB_MAX;
+  // ... and exact in int8: the int8 three-digit kernel (pss_xcorr_i8.hip) is the fastest form; it needs
+  // 137 taps + window-start spread <= 160
+  static const bool no_i8 = getenv("LCS_NO_I8") != nullptr;        // measurement knob
+  c->use_i8 = fmt == LCS_FMT_IQ_U8 && c->xcorr_variant == 0 && !no_i8 && 2 * c->grid_max_k2 <= 32 * LCS_I8_KB;
+  if (c->xcorr_variant == 4) c->use_bf16 = fmt == LCS_FMT_IQ_U8 && 2 * c->grid_max_k2 <= 16 * LCS_BF_KB_MAX;   // variant 4: bf16 kernel
+  if (c->use_i8) c->use_bf16 = false;
   if (c->use_bf16 && (rc = ensure_bf16(c))) return rc;
+  if (c->use_i8 && (rc = ensure_i8(c))) return rc;
   if ((rc = lcs_launch_ingest(c, d_capbufs, fmt, n_buf, n_cap))) return rc;
   if ((rc = lcs_launch_xcorr(c, n_buf, geo, false, true))) return rc;
   if ((rc = lcs_launch_peak_search(c, n_buf, geo, std::pow(10.0, -12.0 / 10.0), true))) return rc;
@@ -601,6 +628,7 @@ int lcs_search_capbuf(lcs_ctx *c, const double *capbuf, uint32_t n_cap, const do
   HIPCHK(c, hipMemcpyAsync(c->cap64, capbuf, sizeof(double2) * n_cap, hipMemcpyHostToDevice, c->stream));
   c->cap64_valid = true;
   c->use_bf16 = false;      // complex<double> input: fp32 correlation
+  c->use_i8 = false;
   HIPCHK(c, hipMemcpyAsync(c->fset, f_search_set, sizeof(double) * n_f, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->params, &p, sizeof(p), hipMemcpyHostToDevice, c->stream));
   if ((rc = lcs_launch_ingest(c, nullptr, 2, 1, n_cap))) return rc;
@@ -651,7 +679,8 @@ int stream_chain(lcs_ctx *c) {
   StreamHost *h = c->st_host;
   const XcGeom geo = make_geo(c->st_n_cap, 1, 2);
   int rc;
-  c->use_bf16 = c->st_fmt == LCS_FMT_IQ_U8 && c->xcorr_variant == 0 && getenv("LCS_NO_BF16") == nullptr;
+  c->use_i8 = c->st_fmt == LCS_FMT_IQ_U8 && c->xcorr_variant == 0 && getenv("LCS_NO_I8") == nullptr;
+  c->use_bf16 = !c->use_i8 && c->st_fmt == LCS_FMT_IQ_U8 && (c->xcorr_variant == 0 || c->xcorr_variant == 4) && getenv("LCS_NO_BF16") == nullptr;
   HIPCHK(c, hipMemcpyAsync(c->st_din, c->st_hin, c->st_in_bytes, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->params, &h->p, sizeof(SlotParams), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->fset, &h->f, sizeof(double), hipMemcpyHostToDevice, c->stream));
@@ -702,7 +731,7 @@ int lcs_stream_open(lcs_ctx *c, int fmt, uint32_t n_cap, double fc_requested, do
   HIPCHK(c, hipSetDevice(c->device));
   if ((rc = ensure_ws(c, 1, n_cap, 1, false))) return rc;
   if ((rc = ensure_percell(c))) return rc;
-  if (fmt == LCS_FMT_IQ_U8 && (rc = ensure_bf16(c))) return rc;
+  if (fmt == LCS_FMT_IQ_U8 && ((rc = ensure_bf16(c)) || (rc = ensure_i8(c)))) return rc;
   c->st_fmt = fmt;
   c->st_n_cap = n_cap;
   c->st_in_bytes = (size_t)n_cap * (fmt == LCS_FMT_IQ_U8 ? 2 : sizeof(float2));

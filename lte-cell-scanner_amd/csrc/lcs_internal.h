@@ -37,6 +37,7 @@
 #define LCS_LAG_TILE 64      // lags per wave
 #define LCS_PS 336           // LDS plane stride in floats: >= 64 + 2*KP2_MAX, == 16 (mod 32)
 #define LCS_MAXP 64          // peaks kept per capture buffer
+#define LCS_I8_KB 5          // 32-tap blocks of the int8 correlation kernel: taps + window-start spread <= 160
 #define LCS_BF_KB_MAX 10     // 16-tap blocks of the bf16 correlation kernel: taps + window-start spread <= 160
 #define LCS_MAX_WORK 512     // cells carried into the TFG/MIB stages per batch
 #define LCS_TFG_ROWS 854
@@ -110,6 +111,11 @@ struct lcs_ctx {
   float2 *cap32 = nullptr;
   uint32_t *capb = nullptr;          // capture buffer as (re, im) bf16 pairs -- written for u8 I/Q sources, where it is exact
   uint4 *bt16 = nullptr;             // bf16 three-term template operands (pss_xcorr_bf16.hip)
+  uint16_t *cap8 = nullptr;          // capture buffer as (re, im) int8 pairs 127 - u8 (pss_xcorr_i8.hip)
+  uint4 *bt8 = nullptr;              // int8 three-digit template operands
+  double *tq = nullptr;              // per template: integer scale q
+  float *tsc = nullptr;              // per template: 1 / (128 q)
+  bool i8_ready = false, use_i8 = false;
   bool bf16_ready = false;           // capb / bt16 allocated for the current workspace geometry
   bool use_bf16 = false;             // this batch runs the bf16x3 correlation kernel
   int grid_max_k2 = 0;               // largest tap-pair count (137 taps + window-start spread) seen by validate_grid
@@ -204,6 +210,9 @@ void pbch_deratematch_map(int n_e, uint8_t *out /*n_e*/);   // ref src/lte_lib.c
 // pss_xcorr.hip
 int lcs_launch_ingest(lcs_ctx *c, const void *d_src, int fmt, int n_buf, uint32_t n_cap);
 int lcs_launch_xcorr(lcs_ctx *c, int n_buf, const XcGeom &geo, bool want_incoh, bool time_it);
+// pss_xcorr_i8.hip
+int lcs_launch_fill_btab_i8(lcs_ctx *c, int n_buf, const XcGeom &geo);
+int lcs_launch_xcorr_i8(lcs_ctx *c, hipStream_t sxc, const XcGeom &geo, int slot0, int n_slots, int xcd_map);
 // pss_xcorr_bf16.hip
 int lcs_launch_fill_btab_bf16(lcs_ctx *c, int n_buf, const XcGeom &geo);
 int lcs_launch_xcorr_bf16(lcs_ctx *c, hipStream_t sxc, const XcGeom &geo, int slot0, int n_slots, int xcd_map);

@@ -44,7 +44,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // u8 samples are also exact in bf16 (8 significant bits): capb gets the (re, im) bf16 pair of every sample
 // for the bf16 correlation kernel (pss_xcorr_bf16.hip).
 __global__ void k_ingest(const void *__restrict__ src, int fmt, uint32_t n_cap, float2 *__restrict__ cap32,
-                         double2 *__restrict__ cap64, uint32_t *__restrict__ capb) {
+                         double2 *__restrict__ cap64, uint32_t *__restrict__ capb, uint16_t *__restrict__ cap8) {
   LCS_TAIL_PRIO();
   const int slot = blockIdx.y;
   const size_t base = (size_t)slot * n_cap;
@@ -56,6 +56,7 @@ __global__ void k_ingest(const void *__restrict__ src, int fmt, uint32_t n_cap, 
       const double re = ((double)q.x - 127.0) / 128.0, im = ((double)q.y - 127.0) / 128.0;
       cap32[base + i] = make_float2((float)re, (float)im);
       if (capb) capb[base + i] = (__float_as_uint((float)re) >> 16) | (__float_as_uint((float)im) & 0xffff0000u);
+      if (cap8) cap8[base + i] = (uint16_t)(((127 - (int)q.x) & 255) | (((127 - (int)q.y) & 255) << 8));   // int8 pair 127 - u8
     } else {
       double2 v = cap64[base + i];
       cap32[base + i] = make_float2((float)v.x, (float)v.y);
@@ -670,7 +671,7 @@ __global__ __launch_bounds__(256) void k_xc_debug(const double2 *__restrict__ ca
 int lcs_launch_ingest(lcs_ctx *c, const void *d_src, int fmt, int n_buf, uint32_t n_cap) {
   dim3 grid(128, n_buf);
   hipLaunchKernelGGL(k_ingest, grid, dim3(256), 0, c->stream, d_src, fmt, n_cap, c->cap32, c->cap64,
-                     (c->use_bf16 && fmt == LCS_FMT_IQ_U8) ? c->capb : nullptr);
+                     (c->use_bf16 && fmt == LCS_FMT_IQ_U8) ? c->capb : nullptr, (c->use_i8 && fmt == LCS_FMT_IQ_U8) ? c->cap8 : nullptr);
   HIPCHK(c, hipGetLastError());
   return LCS_OK;
 }
@@ -688,7 +689,10 @@ static hipEvent_t g_xc_done[64] = {};
 int lcs_launch_xcorr(lcs_ctx *c, int n_buf, const XcGeom &geo, bool want_incoh, bool time_it) {
   hipLaunchKernelGGL(k_prep_tables, dim3(n_buf), dim3(256), 0, c->stream, c->params, c->fset, c->d_pss_td, c->tmpl,
                      c->start, c->smin, c->kp2, geo);
-  if (c->use_bf16) {
+  if (c->use_i8) {
+    int rc_ = lcs_launch_fill_btab_i8(c, n_buf, geo);
+    if (rc_) return rc_;
+  } else if (c->use_bf16) {
     int rc_ = lcs_launch_fill_btab_bf16(c, n_buf, geo);
     if (rc_) return rc_;
   } else
@@ -735,6 +739,12 @@ int lcs_launch_xcorr(lcs_ctx *c, int n_buf, const XcGeom &geo, bool want_incoh, 
   hipLaunchKernelGGL((k_xcorr_mfma_blk<WPS_, NWV_, BCH_>), dim3((unsigned)(((LCS_N_IDX + NWV_ * 64 - 1) / (NWV_ * 64)) * geo.G * ns)), \
                      dim3(NWV_ * 64), lds_pad, sxc, c->cap32, c->smin, c->kp2, c->btab, c->single, geo, s0, ns, part ? 0 : 1)
 #define XC1_ARGS dim3((unsigned)(per_slot * ns)), dim3(64), lds_pad, sxc, c->cap32, c->smin, c->kp2, c->btab, c->single, geo, s0, ns, part ? 0 : 1
+    if (c->use_i8) {                                                            // u8 sources: int8 three-digit kernel
+      int rc_ = lcs_launch_xcorr_i8(c, sxc, geo, s0, ns, part ? 0 : 1);
+      if (rc_) return rc_;
+      ++launches;
+      continue;
+    }
     if (c->use_bf16) {                                                          // u8 sources: exact bf16 three-term kernel
       int rc_ = lcs_launch_xcorr_bf16(c, sxc, geo, s0, ns, part ? 0 : 1);
       if (rc_) return rc_;
@@ -742,7 +752,7 @@ int lcs_launch_xcorr(lcs_ctx *c, int n_buf, const XcGeom &geo, bool want_incoh, 
       continue;
     }
     switch (c->xcorr_variant) {
-      case 0: case 3: XCB_LAUNCH(4, 4, 32); break;                              // fp32: 4-wave workgroups, B through LDS
+      case 0: case 3: case 4: XCB_LAUNCH(4, 4, 32); break;                      // fp32: 4-wave workgroups, B through LDS
       case 1: hipLaunchKernelGGL(k_xcorr_valu, XC1_ARGS); break;                // plain-VALU twin
       case 2: hipLaunchKernelGGL(k_xcorr_mfma, XC1_ARGS); break;                // 1-wave workgroups, B from L2 (round-1 baseline)
       default: XCB_LAUNCH(4, 4, 32); break;

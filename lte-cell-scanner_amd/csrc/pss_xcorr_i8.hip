@@ -1,0 +1,284 @@
+// pss_xcorr_i8.hip -- the PSS correlation for RTL-SDR (u8 I/Q) capture buffers on the int8 matrix cores.
+//
+// An RTL-SDR sample is the integer (u8 - 127) scaled by 1/128.  The fp32 template taps of one template are
+// scaled by a per-template constant q and rounded to 24-bit integers (|T_int| <= 8.3e6: quantisation error
+// <= 6e-8 of the template's largest tap, below fp32 rounding), which split EXACTLY into three signed base-256
+// digits.  v_mfma_i32_16x16x64_i8 multiplies int8 samples with int8 digits and accumulates in int32 -- exact
+// integer arithmetic, no summation-order effects.  The three digit sums are recombined as
+// ((S2 * 256) + S1) * 256 + S0 in fp32 (two roundings), scaled by 1 / (128 q), squared and accumulated like
+// the other kernels.  16x16x64 consumes 32 taps per instruction at ~2x the bf16 rate: 240 MFMAs per
+// wave-window instead of 432 for the bf16 three-term kernel.
+//
+// Operands.  Real GEMM with K = 2 * taps.  The capture buffer is stored as int8 pairs a = 127 - u8 (so that
+// all 256 codes fit: -128 .. 127; the correlation changes sign, its power does not) in natural (re, im) order =
+// the A operand; B_re = digits of (tr, -ti), B_im = digits of (ti, tr), so one A operand feeds both
+// accumulators.  Lane (i, kg) of an A operand holds the 8 consecutive samples lag_i + 32 kb + 8 kg .. +7
+// (16 bytes); the Toeplitz operand of (lag sub-tile mt, tap block kb) depends on mt + 2 kb only.  Samples
+// are 2 bytes, lanes start at any sample: LDS holds the window twice, the second copy shifted by one sample,
+// so that every lane reads 4 aligned dwords from the copy matching its parity.
+//
+// Tiling as in pss_xcorr_bf16.hip: 256-thread workgroup = 384 output positions x one 16-template group, 6
+// sub-tiles per wave (25 workgroups cover the 9600 positions exactly); per window 3 digit passes x 5 tap
+// blocks, fully unrolled; B operands straight from L2/L1 four blocks ahead.  Digit 2 has its own int32
+// accumulator; digits 1 and 0 share one (shifted left by 8 between the passes), so int -> float conversion
+// happens twice per output and window, not per digit.  1.25 ms per 64-buffer launch (bf16 kernel: 1.65 ms).
+#include "lcs_internal.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+#define NW LCS_NW_MAX
+#define NFM LCS_NF_MAX
+#define GM LCS_G_MAX
+
+#ifndef I8_MT
+#define I8_MT 6
+#endif
+#define I8_LAGS (4 * I8_MT * 16)
+#define I8_TILES ((LCS_N_IDX + I8_LAGS - 1) / I8_LAGS)
+#define I8_NKB LCS_I8_KB                                  // 32-tap blocks per window: 137 taps + spread <= 160
+#define I8_AW (I8_LAGS + 32 * I8_NKB + 32)                // staged samples per window
+#define I8_QMAX 8300000.0                                 // |T_int| bound: three balanced base-256 digits reach 8 355 711
+
+// Per template (slot, foi, t): q = I8_QMAX / max tap magnitude; sc = 1 / (128 q) converts the integer
+// correlation back to the reference's units.
+__global__ __launch_bounds__(64) void k_i8_scales(const float2 *__restrict__ tmpl, double *__restrict__ tq,
+                                                  float *__restrict__ sc, XcGeom geo) {
+  LCS_TAIL_PRIO();
+  const int slot = blockIdx.x;
+  for (int c = threadIdx.x; c < geo.G * LCS_TG; c += 64) {
+    double q = 0.0;
+    float s = 0.f;
+    if (c < geo.n_tmpl) {
+      const int foi = c / 3, t = c % 3;
+      const float2 *T = tmpl + (((size_t)slot * NFM + foi) * 3 + t) * 137;
+      float mx = 0.f;
+      for (int m = 0; m < 137; ++m) mx = fmaxf(mx, fmaxf(fabsf(T[m].x), fabsf(T[m].y)));
+      q = (mx > 0.f) ? I8_QMAX / (double)mx : 0.0;
+      s = (q > 0.0) ? (float)(1.0 / (128.0 * q)) : 0.f;
+    }
+    tq[(size_t)slot * GM * LCS_TG + c] = q;
+    sc[(size_t)slot * GM * LCS_TG + c] = s;
+  }
+}
+
+__device__ __forceinline__ void digits3(int v, int &d0, int &d1, int &d2) {   // v = d0 + 256 d1 + 65536 d2, digits in [-128, 127]
+  d0 = ((v + 128) & 255) - 128;
+  const int v1 = (v - d0) >> 8;          // exact: v - d0 is a multiple of 256
+  d1 = ((v1 + 128) & 255) - 128;
+  d2 = (v1 - d1) >> 8;
+}
+
+// bt8[slot][w][g][digit][kb][op][lane] (uint4 = 16 int8): lane (n, kg) holds taps 32 kb + 8 kg .. +7 of template
+// column c = 16 g + n delayed by start[w][foi(c)] - smin[w][g] (zero outside its 137 taps), as digit `digit` of
+// the integer pairs (tr, -ti) (op 0, real output) or (ti, tr) (op 1, imaginary output).
+__global__ __launch_bounds__(256) void k_fill_btab_i8(const float2 *__restrict__ tmpl, const int *__restrict__ start,
+                                                      const int *__restrict__ smin, const double *__restrict__ tq,
+                                                      uint4 *__restrict__ bt8, XcGeom geo) {
+  LCS_TAIL_PRIO();
+  const int slot = blockIdx.z;
+  const int wg = blockIdx.y;
+  const int w = wg / geo.G, g = wg % geo.G;
+  const int s0 = smin[((size_t)slot * NW + w) * GM + g];
+  uint4 *out = bt8 + (((size_t)slot * geo.n_comb + w) * geo.G + g) * (size_t)(3 * I8_NKB * 2 * 64);
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < I8_NKB * 64; e += gridDim.x * blockDim.x) {
+    const int kb = e >> 6, lane = e & 63;
+    const int c = g * LCS_TG + (lane & 15), kg = lane >> 4;
+    int vre[16], vim[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { vre[j] = 0; vim[j] = 0; }
+    if (c < geo.n_tmpl) {
+      const int foi = c / 3, t = c % 3;
+      const int delta = start[((size_t)slot * NW + w) * NFM + foi] - s0;
+      const double q = tq[(size_t)slot * GM * LCS_TG + c];
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        const int tap = 32 * kb + 8 * kg + m - delta;
+        if (tap >= 0 && tap < 137) {
+          const float2 T = tmpl[(((size_t)slot * NFM + foi) * 3 + t) * 137 + tap];
+          const int tr = (int)rint((double)T.x * q), ti = (int)rint((double)T.y * q);
+          vre[2 * m] = tr; vre[2 * m + 1] = -ti;
+          vim[2 * m] = ti; vim[2 * m + 1] = tr;
+        }
+      }
+    }
+    uint32_t pk[3][2][4];
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+#pragma unroll
+      for (int op = 0; op < 2; ++op)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pk[d][op][r] = 0u;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+#pragma unroll
+      for (int op = 0; op < 2; ++op) {
+        int d0, d1, d2;
+        digits3(op ? vim[j] : vre[j], d0, d1, d2);
+        const int sh = 8 * (j & 3);
+        pk[0][op][j >> 2] |= (uint32_t)(d0 & 255) << sh;
+        pk[1][op][j >> 2] |= (uint32_t)(d1 & 255) << sh;
+        pk[2][op][j >> 2] |= (uint32_t)(d2 & 255) << sh;
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+#pragma unroll
+      for (int op = 0; op < 2; ++op)
+        out[(((size_t)d * I8_NKB + kb) * 2 + op) * 64 + lane] = make_uint4(pk[d][op][0], pk[d][op][1], pk[d][op][2], pk[d][op][3]);
+  }
+}
+
+__device__ __forceinline__ float pow2sum_i8(float re, float im) { return fmaf(re, re, im * im); }
+
+__global__ __launch_bounds__(256, 2) void k_xcorr_i8x3(const uint16_t *__restrict__ cap8, const int *__restrict__ smin,
+                                                       const uint4 *__restrict__ bt8, const float *__restrict__ sc,
+                                                       float *__restrict__ sg, XcGeom geo, int slot0, int n_slots,
+                                                       int xcd_map) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int per_slot = I8_TILES * geo.G;
+  int q, sidx;
+  if (xcd_map) { sidx = blockIdx.x & 7; q = blockIdx.x >> 3; sidx += 8 * (q / per_slot); q = q % per_slot; }
+  else { sidx = blockIdx.x / per_slot; q = blockIdx.x % per_slot; }
+  if (sidx >= n_slots) return;
+  const int slot = slot0 + sidx, g = q / I8_TILES, idx0 = (q % I8_TILES) * I8_LAGS;
+  const int widx0 = idx0 + wave * (I8_MT * 16);
+
+  // two copies of the staged window (uint16 per sample): [0] natural, [1] shifted down by one sample
+  __shared__ uint32_t ldsA[2][2][I8_AW / 2 + 2];
+  const uint16_t *cap = cap8 + (size_t)slot * geo.n_cap;
+  const int *smin_s = smin + (size_t)slot * NW * GM + g;
+  const uint4 *bt_s = bt8 + ((size_t)slot * geo.n_comb * geo.G + g) * (size_t)(3 * I8_NKB * 2 * 64) + lane;
+  const size_t bt_wstride = (size_t)geo.G * (3 * I8_NKB * 2 * 64);
+  const float my_sc = sc[(size_t)slot * GM * LCS_TG + g * LCS_TG + (lane & 15)];
+  // first sample of this lane's operand s = 0; its parity picks the LDS copy, then dword index (p - par) / 2
+  const int p0 = wave * (I8_MT * 16) + (lane & 15) + 8 * (lane >> 4);
+  const int par = p0 & 1;
+  const int a_dw = (p0 - par) >> 1;
+
+  f32x4 P[I8_MT];
+#pragma unroll
+  for (int mt = 0; mt < I8_MT; ++mt) P[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  constexpr int ASTEPS = (I8_AW + 255) / 256;
+  uint32_t preA[ASTEPS];      // one sample (uint16) per entry
+#define I8_LOAD_A(W)                                                                   \
+  {                                                                                    \
+    const int L0_ = idx0 + smin_s[(W) * GM];                                           \
+    _Pragma("unroll") for (int r_ = 0; r_ < ASTEPS; ++r_) {                            \
+      const int n_ = tid + 256 * r_;                                                   \
+      const uint32_t s_ = (uint32_t)(L0_ + n_);                                        \
+      preA[r_] = (n_ < I8_AW && s_ < geo.n_cap) ? (uint32_t)cap[s_] : 0u;              \
+    }                                                                                  \
+  }
+#define I8_GLOAD_B(DST, W, BLK)                                                        \
+  {                                                                                    \
+    const uint4 *src_ = bt_s + (size_t)(W) * bt_wstride + (size_t)(BLK) * (2 * 64);     \
+    _Pragma("unroll") for (int op_ = 0; op_ < 2; ++op_) {                              \
+      const uint4 t_ = src_[op_ * 64];                                                 \
+      (DST)[op_] = (i32x4){(int)t_.x, (int)t_.y, (int)t_.z, (int)t_.w};                \
+    }                                                                                  \
+  }
+  constexpr int NBLK = 3 * I8_NKB;        // blocks per window in execution order: digit 2 (kb 0..4), digit 1, digit 0
+#ifndef LCS_I8_DEPTH
+#define LCS_I8_DEPTH 4          // operand blocks requested ahead of use (measured: 1 -> 1.75 ms, 2 -> 1.36, 4 -> 1.25, 6 -> 1.85 (spills))
+#endif
+  constexpr int PD = LCS_I8_DEPTH;
+  i32x4 Bq[NBLK + PD][2];
+  I8_LOAD_A(0);
+  // table order is [digit][kb]; execution order is digit 2, 1, 0: block b -> table block (2 - b / NKB) * NKB + b % NKB
+#define I8_TBLK(b) ((2 - (b) / I8_NKB) * I8_NKB + (b) % I8_NKB)
+#pragma unroll
+  for (int i = 0; i < PD; ++i) I8_GLOAD_B(Bq[i], 0, I8_TBLK(i));
+  for (int w = 0; w < geo.n_comb; ++w) {
+    const bool has_next = w + 1 < geo.n_comb;
+    uint16_t *nat = reinterpret_cast<uint16_t *>(ldsA[w & 1][0]);
+    uint16_t *shf = reinterpret_cast<uint16_t *>(ldsA[w & 1][1]);
+#pragma unroll
+    for (int r = 0; r < ASTEPS; ++r) {
+      const int n = tid + 256 * r;
+      if (n < I8_AW) { nat[n] = (uint16_t)preA[r]; if (n > 0) shf[n - 1] = (uint16_t)preA[r]; }
+    }
+    if (has_next) I8_LOAD_A(w + 1);
+    __syncthreads();
+    const uint32_t *bufA = ldsA[w & 1][par] + a_dw;
+    // digit 2 accumulates into (tR, tI); digits 1 and 0 share one int32 accumulator: after the digit-1 pass it is
+    // shifted left by 8 and the digit-0 products are added on top (|S1| <= 274 * 128 * 128 = 4.5e6, so
+    // 256 S1 + S0 stays below 2^31): one int -> float conversion per digit group instead of per digit.
+    i32x4 tR[I8_MT], tI[I8_MT], aR[I8_MT], aI[I8_MT];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      i32x4 Aw[2 * I8_NKB + I8_MT - 1];
+#pragma unroll
+      for (int s = 0; s < I8_MT - 2; ++s) { const uint32_t *p_ = bufA + 8 * s; Aw[s] = (i32x4){(int)p_[0], (int)p_[1], (int)p_[2], (int)p_[3]}; }
+#pragma unroll
+      for (int kb = 0; kb < I8_NKB; ++kb) {
+        const int b = d * I8_NKB + kb;
+        if (b + PD < NBLK) I8_GLOAD_B(Bq[b + PD], w, I8_TBLK(b + PD))
+        else if (has_next) I8_GLOAD_B(Bq[b + PD], w + 1, I8_TBLK(b + PD - NBLK))
+#pragma unroll
+        for (int s = 2 * kb + I8_MT - 2; s < 2 * kb + I8_MT; ++s) {
+          const uint32_t *p_ = bufA + 8 * s;
+          Aw[s] = (i32x4){(int)p_[0], (int)p_[1], (int)p_[2], (int)p_[3]};
+        }
+#pragma unroll
+        for (int mt = 0; mt < I8_MT; ++mt) {
+          if (d == 0) {
+            const i32x4 cr = (kb == 0) ? (i32x4){0, 0, 0, 0} : tR[mt];
+            const i32x4 ci = (kb == 0) ? (i32x4){0, 0, 0, 0} : tI[mt];
+            tR[mt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Aw[2 * kb + mt], Bq[b][0], cr, 0, 0, 0);
+            tI[mt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Aw[2 * kb + mt], Bq[b][1], ci, 0, 0, 0);
+          } else {
+            const i32x4 cr = (d == 1 && kb == 0) ? (i32x4){0, 0, 0, 0} : aR[mt];
+            const i32x4 ci = (d == 1 && kb == 0) ? (i32x4){0, 0, 0, 0} : aI[mt];
+            aR[mt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Aw[2 * kb + mt], Bq[b][0], cr, 0, 0, 0);
+            aI[mt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Aw[2 * kb + mt], Bq[b][1], ci, 0, 0, 0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (d == 1) {
+#pragma unroll
+        for (int mt = 0; mt < I8_MT; ++mt) { aR[mt] = aR[mt] << 8; aI[mt] = aI[mt] << 8; }
+      }
+    }
+#pragma unroll
+    for (int op = 0; op < 2; ++op)
+#pragma unroll
+      for (int i = 0; i < PD; ++i) Bq[i][op] = Bq[NBLK + i][op];
+#pragma unroll
+    for (int mt = 0; mt < I8_MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float xr = fmaf((float)tR[mt][r], 65536.f, (float)aR[mt][r]) * my_sc;     // (S2 * 65536 + (256 S1 + S0)) / (128 q)
+        const float xi = fmaf((float)tI[mt][r], 65536.f, (float)aI[mt][r]) * my_sc;
+        P[mt][r] = P[mt][r] + pow2sum_i8(xr, xi);
+      }
+  }
+#undef I8_LOAD_A
+#undef I8_GLOAD_B
+#undef I8_TBLK
+  const float ncomb = (float)geo.n_comb;
+  float *o = sg + (((size_t)slot * geo.G + g) * LCS_N_IDX) * LCS_TG + (lane & 15);
+#pragma unroll
+  for (int mt = 0; mt < I8_MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int idx = widx0 + mt * 16 + 4 * (lane >> 4) + r;
+      if (idx < LCS_N_IDX) o[(size_t)idx * LCS_TG] = __fdiv_rn(P[mt][r], ncomb);
+    }
+}
+
+int lcs_launch_fill_btab_i8(lcs_ctx *c, int n_buf, const XcGeom &geo) {
+  hipLaunchKernelGGL(k_i8_scales, dim3(n_buf), dim3(64), 0, c->stream, c->tmpl, c->tq, c->tsc, geo);
+  hipLaunchKernelGGL(k_fill_btab_i8, dim3(2, geo.n_comb * geo.G, n_buf), dim3(256), 0, c->stream, c->tmpl, c->start, c->smin,
+                     c->tq, c->bt8, geo);
+  HIPCHK(c, hipGetLastError());
+  return LCS_OK;
+}
+int lcs_launch_xcorr_i8(lcs_ctx *c, hipStream_t sxc, const XcGeom &geo, int slot0, int n_slots, int xcd_map) {
+  const unsigned grid = (unsigned)(I8_TILES * geo.G * n_slots);
+  hipLaunchKernelGGL(k_xcorr_i8x3, dim3(grid), dim3(256), 0, sxc, c->cap8, c->smin, c->bt8, c->tsc, c->single, geo, slot0,
+                     n_slots, xcd_map);
+  HIPCHK(c, hipGetLastError());
+  return LCS_OK;
+}

@@ -39,7 +39,7 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
             acc[(k, r["Counter_Name"])][r["Dispatch_Id"]] += float(r["Counter_Value"])
         for (k, c), per in acc.items():
             kern.setdefault(k, {})[c] = sum(per.values()) / len(per)
-dom = next((k for k in kern if k.startswith("k_xcorr_bf16x3")), None) or next((k for k in kern if k.startswith("k_xcorr_mfma_blk")), None)
+dom = next((k for k in kern if k.startswith("k_xcorr_i8x3")), None) or next((k for k in kern if k.startswith("k_xcorr_bf16x3")), None) or next((k for k in kern if k.startswith("k_xcorr_mfma_blk")), None)
 summary = {
     "source": "profiles/collect.sh: rocprofv3 --pmc <group> --kernel-trace --output-format csv -- python bench.py --steps 3 "
               "--warmup 1 --pipeline 1 --no-cpu-baseline, one pass per counter group; values are per-launch averages "

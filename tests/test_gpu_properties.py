@@ -67,7 +67,7 @@ def test_batch_slots_are_independent_and_placement_invariant(S, pkg, synth_buf):
     d = torch.from_numpy(np.stack([src[i] for i in order])).cuda()
     res = S.search_batch(d.data_ptr(), pkg.FMT_IQ_U8, len(order), 153600, f, FC, FC, FS, pkg.STAGE_FULL)
     ref = [S.search_capbuf(iq_u8_to_capbuf(x), f, FC, FC, FS)[0] for x in src]
-    key = lambda c: tuple(v for k, v in c.as_dict().items() if k != "pss_pow")   # the batch ran the bf16 kernel, the host call fp32
+    key = lambda c: tuple(v for k, v in c.as_dict().items() if k != "pss_pow")   # the batch ran the int8 kernel, the host call fp32
     for slot, i in enumerate(order):
         assert [key(c) for c in res[slot]] == [key(c) for c in ref[i]], slot
         assert all(abs(a.pss_pow - b.pss_pow) <= 2e-6 * b.pss_pow for a, b in zip(res[slot], ref[i]))
@@ -78,8 +78,9 @@ def test_batch_slots_are_independent_and_placement_invariant(S, pkg, synth_buf):
 
 
 def test_bf16_three_term_correlation_matches_fp32(S, pkg, synth_buf):
-    """u8 I/Q sources take the bf16 three-term MFMA kernel (exact products, fp32 accumulation); variant 3
-    forces the fp32 kernel on the same device-resident bytes.  Every identity must agree and the
+    """u8 I/Q sources take the int8 three-digit MFMA kernel (variant 0: 24-bit integer templates, exact
+    integer accumulation) or the bf16 three-term kernel (variant 4: exact products, fp32 accumulation);
+    variant 3 forces the fp32 kernel on the same device-resident bytes.  Every identity must agree and the
     correlation powers must agree far inside the 1e-5 parity bar."""
     import torch
     f = f_search_set_for(FC, 100)
@@ -89,40 +90,44 @@ def test_bf16_three_term_correlation_matches_fp32(S, pkg, synth_buf):
     bufs = [synth_buf, g, noise, np.roll(g, 2 * 4321), np.roll(synth_buf, 2 * 777), g, noise, synth_buf, g]   # 8 XCD-mapped + 1
     d = torch.from_numpy(np.stack(bufs)).cuda()
     out = {}
-    for v in (0, 3):
+    for v in (0, 4, 3):
         S.set_xcorr_variant(v)
         out[v] = S.search_batch(d.data_ptr(), pkg.FMT_IQ_U8, len(bufs), 153600, f, FC, FC, FS, pkg.STAGE_PSS, max_cells_per_buf=64)
     S.set_xcorr_variant(0)
     n = 0
-    for a, b in zip(out[0], out[3]):
-        assert [(c.n_id_2, c.ind, c.freq) for c in a] == [(c.n_id_2, c.ind, c.freq) for c in b]
-        for ca, cb in zip(a, b):
-            assert abs(ca.pss_pow - cb.pss_pow) <= 2e-6 * cb.pss_pow
-            n += 1
-    assert n >= 10
+    for v in (0, 4):
+        for a, b in zip(out[v], out[3]):
+            assert [(c.n_id_2, c.ind, c.freq) for c in a] == [(c.n_id_2, c.ind, c.freq) for c in b], v
+            for ca, cb in zip(a, b):
+                assert abs(ca.pss_pow - cb.pss_pow) <= 2e-6 * cb.pss_pow, v
+                n += 1
+    assert n >= 20
     # and the decoded cells of the full chain are the same records except for that last-digit power
     full = {}
-    for v in (0, 3):
+    for v in (0, 4, 3):
         S.set_xcorr_variant(v)
         full[v] = S.search_batch(d.data_ptr(), pkg.FMT_IQ_U8, len(bufs), 153600, f, FC, FC, FS, pkg.STAGE_FULL)
     S.set_xcorr_variant(0)
     strip = lambda c: tuple(v for k, v in c.as_dict().items() if k != "pss_pow")
     assert [[strip(c) for c in r] for r in full[0]] == [[strip(c) for c in r] for r in full[3]]
+    assert [[strip(c) for c in r] for r in full[4]] == [[strip(c) for c in r] for r in full[3]]
     assert [c.n_id_cell() for c in full[0][1]] == [277, 271]
     # a 10 kHz grid spreads the window starts of one template group over more than 7 samples: more than 9
-    # tap blocks per window, which takes the looping bf16 kernel instead of the unrolled one
+    # 16-tap blocks per window, which takes the looping bf16 kernel instead of the unrolled one (the int8
+    # kernel's five 32-tap blocks still hold it)
     f10 = np.arange(-10, 11) * 10e3
     wide = {}
-    for v in (0, 3):
+    for v in (0, 4, 3):
         S.set_xcorr_variant(v)
         wide[v] = S.search_batch(d.data_ptr(), pkg.FMT_IQ_U8, len(bufs), 153600, f10, FC, FC, FS, pkg.STAGE_PSS, max_cells_per_buf=64)
     S.set_xcorr_variant(0)
     m = 0
-    for a, b in zip(wide[0], wide[3]):
-        assert [(c.n_id_2, c.ind, c.freq) for c in a] == [(c.n_id_2, c.ind, c.freq) for c in b]
-        assert all(abs(ca.pss_pow - cb.pss_pow) <= 2e-6 * cb.pss_pow for ca, cb in zip(a, b))
-        m += len(a)
-    assert m >= 8
+    for v in (0, 4):
+        for a, b in zip(wide[v], wide[3]):
+            assert [(c.n_id_2, c.ind, c.freq) for c in a] == [(c.n_id_2, c.ind, c.freq) for c in b], v
+            assert all(abs(ca.pss_pow - cb.pss_pow) <= 2e-6 * cb.pss_pow for ca, cb in zip(a, b)), v
+            m += len(a)
+    assert m >= 16
 
 
 def test_bf16_kernel_short_buffers_and_single_hypothesis(S, pkg, synth_buf):
@@ -136,13 +141,14 @@ def test_bf16_kernel_short_buffers_and_single_hypothesis(S, pkg, synth_buf):
     d = torch.from_numpy(np.ascontiguousarray(bufs)).cuda()
     for f in (np.array([35e3]), np.array([30e3, 35e3, 40e3]), f_search_set_for(FC, 100)):
         out = {}
-        for v in (0, 3):
+        for v in (0, 4, 3):
             S.set_xcorr_variant(v)
             out[v] = S.search_batch(d.data_ptr(), pkg.FMT_IQ_U8, 3, n_short, f, FC, FC, FS, pkg.STAGE_PSS, max_cells_per_buf=64)
         S.set_xcorr_variant(0)
-        for a, b in zip(out[0], out[3]):
-            assert [(c.n_id_2, c.ind, c.freq) for c in a] == [(c.n_id_2, c.ind, c.freq) for c in b]
-            assert all(abs(ca.pss_pow - cb.pss_pow) <= 2e-6 * cb.pss_pow for ca, cb in zip(a, b))
+        for v in (0, 4):
+            for a, b in zip(out[v], out[3]):
+                assert [(c.n_id_2, c.ind, c.freq) for c in a] == [(c.n_id_2, c.ind, c.freq) for c in b], v
+                assert all(abs(ca.pss_pow - cb.pss_pow) <= 2e-6 * cb.pss_pow for ca, cb in zip(a, b)), v
         assert len(out[0][0]) >= 1
 
 
