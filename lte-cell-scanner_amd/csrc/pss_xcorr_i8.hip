@@ -42,23 +42,27 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 // Per template (slot, foi, t): q = I8_QMAX / max tap magnitude; sc = 1 / (128 q) converts the integer
 // correlation back to the reference's units.
-__global__ __launch_bounds__(64) void k_i8_scales(const float2 *__restrict__ tmpl, double *__restrict__ tq,
-                                                  float *__restrict__ sc, XcGeom geo) {
+__global__ __launch_bounds__(256) void k_i8_scales(const float2 *__restrict__ tmpl, double *__restrict__ tq,
+                                                   float *__restrict__ sc, XcGeom geo) {
   LCS_TAIL_PRIO();
   const int slot = blockIdx.x;
-  for (int c = threadIdx.x; c < geo.G * LCS_TG; c += 64) {
-    double q = 0.0;
-    float s = 0.f;
+  __shared__ float part[LCS_G_MAX * LCS_TG][4];
+  for (int e = threadIdx.x; e < geo.G * LCS_TG * 4; e += 256) {      // 4 threads per template, 35 taps each
+    const int c = e >> 2, qd = e & 3;
+    float mx = 0.f;
     if (c < geo.n_tmpl) {
       const int foi = c / 3, t = c % 3;
       const float2 *T = tmpl + (((size_t)slot * NFM + foi) * 3 + t) * 137;
-      float mx = 0.f;
-      for (int m = 0; m < 137; ++m) mx = fmaxf(mx, fmaxf(fabsf(T[m].x), fabsf(T[m].y)));
-      q = (mx > 0.f) ? I8_QMAX / (double)mx : 0.0;
-      s = (q > 0.0) ? (float)(1.0 / (128.0 * q)) : 0.f;
+      for (int m = qd * 35; m < min(137, qd * 35 + 35); ++m) mx = fmaxf(mx, fmaxf(fabsf(T[m].x), fabsf(T[m].y)));
     }
+    part[c][qd] = mx;
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < geo.G * LCS_TG; c += 256) {
+    const float mx = fmaxf(fmaxf(part[c][0], part[c][1]), fmaxf(part[c][2], part[c][3]));
+    const double q = (mx > 0.f) ? I8_QMAX / (double)mx : 0.0;
     tq[(size_t)slot * GM * LCS_TG + c] = q;
-    sc[(size_t)slot * GM * LCS_TG + c] = s;
+    sc[(size_t)slot * GM * LCS_TG + c] = (q > 0.0) ? (float)(1.0 / (128.0 * q)) : 0.f;
   }
 }
 
@@ -248,9 +252,9 @@ __global__ __launch_bounds__(256, 2) void k_xcorr_i8x3(const uint16_t *__restric
 #pragma unroll
     for (int mt = 0; mt < I8_MT; ++mt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float xr = fmaf((float)tR[mt][r], 65536.f, (float)aR[mt][r]) * my_sc;     // (S2 * 65536 + (256 S1 + S0)) / (128 q)
-        const float xi = fmaf((float)tI[mt][r], 65536.f, (float)aI[mt][r]) * my_sc;
+      for (int r = 0; r < 4; ++r) {     // power of the integer correlation S2 * 65536 + (256 S1 + S0); scaled by 1 / (128 q)^2 at the end
+        const float xr = fmaf((float)tR[mt][r], 65536.f, (float)aR[mt][r]);
+        const float xi = fmaf((float)tI[mt][r], 65536.f, (float)aI[mt][r]);
         P[mt][r] = P[mt][r] + pow2sum_i8(xr, xi);
       }
   }
@@ -264,12 +268,12 @@ __global__ __launch_bounds__(256, 2) void k_xcorr_i8x3(const uint16_t *__restric
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int idx = widx0 + mt * 16 + 4 * (lane >> 4) + r;
-      if (idx < LCS_N_IDX) o[(size_t)idx * LCS_TG] = __fdiv_rn(P[mt][r], ncomb);
+      if (idx < LCS_N_IDX) o[(size_t)idx * LCS_TG] = __fdiv_rn(P[mt][r] * (my_sc * my_sc), ncomb);
     }
 }
 
 int lcs_launch_fill_btab_i8(lcs_ctx *c, int n_buf, const XcGeom &geo) {
-  hipLaunchKernelGGL(k_i8_scales, dim3(n_buf), dim3(64), 0, c->stream, c->tmpl, c->tq, c->tsc, geo);
+  hipLaunchKernelGGL(k_i8_scales, dim3(n_buf), dim3(256), 0, c->stream, c->tmpl, c->tq, c->tsc, geo);
   hipLaunchKernelGGL(k_fill_btab_i8, dim3(2, geo.n_comb * geo.G, n_buf), dim3(256), 0, c->stream, c->tmpl, c->start, c->smin,
                      c->tq, c->bt8, geo);
   HIPCHK(c, hipGetLastError());
