@@ -17,11 +17,11 @@
 // are 2 bytes, lanes start at any sample: LDS holds the window twice, the second copy shifted by one sample,
 // so that every lane reads 4 aligned dwords from the copy matching its parity.
 //
-// Tiling as in pss_xcorr_bf16.hip: 256-thread workgroup = 384 output positions x one 16-template group, 6
-// sub-tiles per wave (25 workgroups cover the 9600 positions exactly); per window 3 digit passes x 5 tap
-// blocks, fully unrolled; B operands straight from L2/L1 four blocks ahead.  Digit 2 has its own int32
-// accumulator; digits 1 and 0 share one (shifted left by 8 between the passes), so int -> float conversion
-// happens twice per output and window, not per digit.  1.25 ms per 64-buffer launch (bf16 kernel: 1.65 ms).
+// Tiling as in pss_xcorr_bf16.hip: 256-thread workgroup = 512 output positions x one 16-template group, 8
+// sub-tiles per wave; per window 3 digit passes x 5 tap blocks, fully unrolled; the window's B operands
+// (30 KB) are staged in LDS next to the capture samples.  Digit 2 has its own int32 accumulator; digits 1
+// and 0 share one (shifted left by 8 between the passes), so int -> float conversion happens twice per
+// output and window, not per digit.  1.23 ms per 64-buffer launch (bf16 kernel: 1.65 ms).
 #include "lcs_internal.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -32,7 +32,7 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 #define GM LCS_G_MAX
 
 #ifndef I8_MT
-#define I8_MT 6
+#define I8_MT 8                                          // 16-lag sub-tiles per wave
 #endif
 #define I8_LAGS (4 * I8_MT * 16)
 #define I8_TILES ((LCS_N_IDX + I8_LAGS - 1) / I8_LAGS)
@@ -135,6 +135,11 @@ __global__ __launch_bounds__(256) void k_fill_btab_i8(const float2 *__restrict__
 
 __device__ __forceinline__ float pow2sum_i8(float re, float im) { return fmaf(re, re, im * im); }
 
+// The whole operand set of a window (30 KB) goes through LDS once per workgroup and window, written together
+// with the capture samples before the window's single barrier: no global-load latency in the block loop and
+// few operand registers, which is what lets a wave hold 8 sub-tiles.  (Reading the operands straight from
+// L2/L1 instead needed a four-block-deep register prefetch and 6 sub-tiles per wave: 1.25 ms against 1.23 ms
+// alone, 35.8 k against 37.3 k buffers/s in the pipelined chain.)
 __global__ __launch_bounds__(256, 2) void k_xcorr_i8x3(const uint16_t *__restrict__ cap8, const int *__restrict__ smin,
                                                        const uint4 *__restrict__ bt8, const float *__restrict__ sc,
                                                        float *__restrict__ sg, XcGeom geo, int slot0, int n_slots,
@@ -150,9 +155,12 @@ __global__ __launch_bounds__(256, 2) void k_xcorr_i8x3(const uint16_t *__restric
 
   // two copies of the staged window (uint16 per sample): [0] natural, [1] shifted down by one sample
   __shared__ uint32_t ldsA[2][2][I8_AW / 2 + 2];
+  constexpr int NBLK = 3 * I8_NKB;        // blocks per window in execution order: digit 2 (kb 0..4), digit 1, digit 0
+  constexpr int BW = NBLK * 2 * 64;       // uint4 per window: the whole operand set of one (window, group), 30 KB
+  __shared__ uint4 ldsB[2][BW];
   const uint16_t *cap = cap8 + (size_t)slot * geo.n_cap;
   const int *smin_s = smin + (size_t)slot * NW * GM + g;
-  const uint4 *bt_s = bt8 + ((size_t)slot * geo.n_comb * geo.G + g) * (size_t)(3 * I8_NKB * 2 * 64) + lane;
+  const uint4 *bt_s = bt8 + ((size_t)slot * geo.n_comb * geo.G + g) * (size_t)(3 * I8_NKB * 2 * 64);
   const size_t bt_wstride = (size_t)geo.G * (3 * I8_NKB * 2 * 64);
   const float my_sc = sc[(size_t)slot * GM * LCS_TG + g * LCS_TG + (lane & 15)];
   // first sample of this lane's operand s = 0; its parity picks the LDS copy, then dword index (p - par) / 2
@@ -174,25 +182,18 @@ __global__ __launch_bounds__(256, 2) void k_xcorr_i8x3(const uint16_t *__restric
       preA[r_] = (n_ < I8_AW && s_ < geo.n_cap) ? (uint32_t)cap[s_] : 0u;              \
     }                                                                                  \
   }
-#define I8_GLOAD_B(DST, W, BLK)                                                        \
+  constexpr int BSTEPS = (BW + 255) / 256;
+  uint4 preB[BSTEPS];
+#define I8_LOAD_BW(W)                                                                  \
   {                                                                                    \
-    const uint4 *src_ = bt_s + (size_t)(W) * bt_wstride + (size_t)(BLK) * (2 * 64);     \
-    _Pragma("unroll") for (int op_ = 0; op_ < 2; ++op_) {                              \
-      const uint4 t_ = src_[op_ * 64];                                                 \
-      (DST)[op_] = (i32x4){(int)t_.x, (int)t_.y, (int)t_.z, (int)t_.w};                \
-    }                                                                                  \
+    const uint4 *src_ = bt_s + (size_t)(W) * bt_wstride;                               \
+    _Pragma("unroll") for (int r_ = 0; r_ < BSTEPS; ++r_)                              \
+      preB[r_] = (tid + 256 * r_ < BW) ? src_[tid + 256 * r_] : make_uint4(0u, 0u, 0u, 0u); \
   }
-  constexpr int NBLK = 3 * I8_NKB;        // blocks per window in execution order: digit 2 (kb 0..4), digit 1, digit 0
-#ifndef LCS_I8_DEPTH
-#define LCS_I8_DEPTH 4          // operand blocks requested ahead of use (measured: 1 -> 1.75 ms, 2 -> 1.36, 4 -> 1.25, 6 -> 1.85 (spills))
-#endif
-  constexpr int PD = LCS_I8_DEPTH;
-  i32x4 Bq[NBLK + PD][2];
   I8_LOAD_A(0);
+  I8_LOAD_BW(0);
   // table order is [digit][kb]; execution order is digit 2, 1, 0: block b -> table block (2 - b / NKB) * NKB + b % NKB
 #define I8_TBLK(b) ((2 - (b) / I8_NKB) * I8_NKB + (b) % I8_NKB)
-#pragma unroll
-  for (int i = 0; i < PD; ++i) I8_GLOAD_B(Bq[i], 0, I8_TBLK(i));
   for (int w = 0; w < geo.n_comb; ++w) {
     const bool has_next = w + 1 < geo.n_comb;
     uint16_t *nat = reinterpret_cast<uint16_t *>(ldsA[w & 1][0]);
@@ -202,8 +203,12 @@ __global__ __launch_bounds__(256, 2) void k_xcorr_i8x3(const uint16_t *__restric
       const int n = tid + 256 * r;
       if (n < I8_AW) { nat[n] = (uint16_t)preA[r]; if (n > 0) shf[n - 1] = (uint16_t)preA[r]; }
     }
-    if (has_next) I8_LOAD_A(w + 1);
+#pragma unroll
+    for (int r = 0; r < BSTEPS; ++r)
+      if (tid + 256 * r < BW) ldsB[w & 1][tid + 256 * r] = preB[r];
+    if (has_next) { I8_LOAD_A(w + 1); I8_LOAD_BW(w + 1); }
     __syncthreads();
+    const uint4 *bl = ldsB[w & 1] + lane;
     const uint32_t *bufA = ldsA[w & 1][par] + a_dw;
     // digit 2 accumulates into (tR, tI); digits 1 and 0 share one int32 accumulator: after the digit-1 pass it is
     // shifted left by 8 and the digit-0 products are added on top (|S1| <= 274 * 128 * 128 = 4.5e6, so
@@ -217,8 +222,9 @@ __global__ __launch_bounds__(256, 2) void k_xcorr_i8x3(const uint16_t *__restric
 #pragma unroll
       for (int kb = 0; kb < I8_NKB; ++kb) {
         const int b = d * I8_NKB + kb;
-        if (b + PD < NBLK) I8_GLOAD_B(Bq[b + PD], w, I8_TBLK(b + PD))
-        else if (has_next) I8_GLOAD_B(Bq[b + PD], w + 1, I8_TBLK(b + PD - NBLK))
+        i32x4 Bop[2];
+#pragma unroll
+        for (int op = 0; op < 2; ++op) { const uint4 t_ = bl[(I8_TBLK(b) * 2 + op) * 64]; Bop[op] = (i32x4){(int)t_.x, (int)t_.y, (int)t_.z, (int)t_.w}; }
 #pragma unroll
         for (int s = 2 * kb + I8_MT - 2; s < 2 * kb + I8_MT; ++s) {
           const uint32_t *p_ = bufA + 8 * s;
@@ -229,13 +235,13 @@ __global__ __launch_bounds__(256, 2) void k_xcorr_i8x3(const uint16_t *__restric
           if (d == 0) {
             const i32x4 cr = (kb == 0) ? (i32x4){0, 0, 0, 0} : tR[mt];
             const i32x4 ci = (kb == 0) ? (i32x4){0, 0, 0, 0} : tI[mt];
-            tR[mt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Aw[2 * kb + mt], Bq[b][0], cr, 0, 0, 0);
-            tI[mt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Aw[2 * kb + mt], Bq[b][1], ci, 0, 0, 0);
+            tR[mt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Aw[2 * kb + mt], Bop[0], cr, 0, 0, 0);
+            tI[mt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Aw[2 * kb + mt], Bop[1], ci, 0, 0, 0);
           } else {
             const i32x4 cr = (d == 1 && kb == 0) ? (i32x4){0, 0, 0, 0} : aR[mt];
             const i32x4 ci = (d == 1 && kb == 0) ? (i32x4){0, 0, 0, 0} : aI[mt];
-            aR[mt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Aw[2 * kb + mt], Bq[b][0], cr, 0, 0, 0);
-            aI[mt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Aw[2 * kb + mt], Bq[b][1], ci, 0, 0, 0);
+            aR[mt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Aw[2 * kb + mt], Bop[0], cr, 0, 0, 0);
+            aI[mt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Aw[2 * kb + mt], Bop[1], ci, 0, 0, 0);
           }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -246,10 +252,6 @@ __global__ __launch_bounds__(256, 2) void k_xcorr_i8x3(const uint16_t *__restric
       }
     }
 #pragma unroll
-    for (int op = 0; op < 2; ++op)
-#pragma unroll
-      for (int i = 0; i < PD; ++i) Bq[i][op] = Bq[NBLK + i][op];
-#pragma unroll
     for (int mt = 0; mt < I8_MT; ++mt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {     // power of the integer correlation S2 * 65536 + (256 S1 + S0); scaled by 1 / (128 q)^2 at the end
@@ -259,7 +261,7 @@ __global__ __launch_bounds__(256, 2) void k_xcorr_i8x3(const uint16_t *__restric
       }
   }
 #undef I8_LOAD_A
-#undef I8_GLOAD_B
+#undef I8_LOAD_BW
 #undef I8_TBLK
   const float ncomb = (float)geo.n_comb;
   float *o = sg + (((size_t)slot * geo.G + g) * LCS_N_IDX) * LCS_TG + (lane & 15);
