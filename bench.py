@@ -359,7 +359,10 @@ def main():
                          "frac_isolated": macs_factor * flops_per_buf * B / (float(np.mean(iso_ms)) * 1e-3) / 1e12 / peak,
                          "flops_per_launch": macs_factor * flops_per_buf * B,
                          "achieved_consumed_lags_only": macs_factor * flops_consumed * B / (k_ms * 1e-3) / 1e12,
-                         "hbm_algorithmic_GBps": bytes_per_buf * B / (k_ms * 1e-3) / 1e9, "hbm_peak_GBps": 8000.0},
+                         "hbm_algorithmic_GBps": bytes_per_buf * B / (k_ms * 1e-3) / 1e9, "hbm_peak_GBps": 8000.0,
+                         "hbm_frac_algorithmic": bytes_per_buf * B / (k_ms * 1e-3) / 1e9 / 8000.0,
+                         "hbm_measured_GBps": (traffic / (k_ms * 1e-3) / 1e9) if traffic else None,
+                         "hbm_frac_measured": (traffic / (k_ms * 1e-3) / 1e9 / 8000.0) if traffic else None},
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pkg, host[0], f, float(fcs[0]), args.stage)
