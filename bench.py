@@ -299,6 +299,14 @@ def main():
         flops_per_buf = 8.0 * 137 * 3 * (N_CAP - 136) * n_f
         flops_consumed = 8.0 * 137 * 3 * 9600 * 15 * n_f       # the 15x9600 lags that are ever used
         k_ms = float(np.mean(xc_ms))
+        # Which kernel ran: u8 sources take the int8 three-digit kernel (24-bit integer templates as three int8
+        # digits, i.e. 3 MFMA MACs per algorithmic MAC) or, with LCS_NO_I8 / --variant 4, the bf16 three-term kernel
+        # (a*t = a*t1 + a*t2 + a*t3 with exact bf16 factors); --variant 1..3 the fp32 kernels.
+        i8 = args.variant == 0 and os.environ.get("LCS_NO_I8") is None
+        bf16 = (not i8) and (args.variant == 4 or (args.variant == 0 and os.environ.get("LCS_NO_BF16") is None))
+        macs_factor, peak = (3.0, PEAK_I8_TOPS) if i8 else ((3.0, PEAK_BF16_TFLOPS) if bf16 else (1.0, PEAK_FP32_TFLOPS))
+        kname = "k_xcorr_i8x3" if i8 else ("k_xcorr_bf16x3_unrolled<9>" if bf16 else
+                                            {0: "k_xcorr_mfma_blk<4,4,32>", 1: "k_xcorr_valu", 2: "k_xcorr_mfma", 3: "k_xcorr_mfma_blk<4,4,32>"}.get(args.variant))
         # HBM traffic of the dominant kernel from the PMC counters (FETCH_SIZE / WRITE_SIZE, separate
         # rocprofv3 passes, corrected as MI355X_MICROARCH.md prescribes): measured per buffer at this
         # n_f with the default kernel, summary committed under profiles/ -- null when not measured.
@@ -310,14 +318,6 @@ def main():
                 traffic = float(pm["hbm_bytes_per_buffer"]) * B
         except Exception:
             traffic = None
-        # Which kernel ran: u8 sources take the bf16 three-term kernel (every fp32 product a*t is formed as
-        # a*t1 + a*t2 + a*t3 with exact bf16 factors, i.e. 3 MFMA MACs per algorithmic MAC), anything else
-        # and the --variant knobs the fp32 kernels.
-        i8 = args.variant == 0 and os.environ.get("LCS_NO_I8") is None
-        bf16 = (not i8) and (args.variant == 4 or (args.variant == 0 and os.environ.get("LCS_NO_BF16") is None))
-        macs_factor, peak = (3.0, PEAK_I8_TOPS) if i8 else ((3.0, PEAK_BF16_TFLOPS) if bf16 else (1.0, PEAK_FP32_TFLOPS))
-        kname = "k_xcorr_i8x3" if i8 else ("k_xcorr_bf16x3_unrolled<9>" if bf16 else
-                                            {0: "k_xcorr_mfma_blk<4,4,32>", 1: "k_xcorr_valu", 2: "k_xcorr_mfma", 3: "k_xcorr_mfma_blk<4,4,32>"}.get(args.variant))
         achieved = macs_factor * flops_per_buf * B / (k_ms * 1e-3) / 1e12
         bytes_per_buf = 1651200 + 230400 * n_f                 # SURVEY.md section 8d compulsory HBM bytes
         out = {

@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblcs_amd.so")
+LIB_PATH = os.environ.get("LCS_AMD_LIB") or os.path.join(_HERE, "liblcs_amd.so")   # env: developer knob for A/B builds
 
 LCS_OK = 0
 FMT_C64, FMT_IQ_U8 = 0, 1

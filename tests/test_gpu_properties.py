@@ -189,3 +189,47 @@ def test_ragged_buffer_lengths(S, pkg, synth_buf):
         assert r["n_comb_xc"] == ro["n_comb_xc"] == (n - 236) // 9600 and r["n_comb_sp"] == ro["n_comb_sp"]
         assert np.array_equal(r["frq"], ro["frq"])
         assert (np.abs(r["pow"] - ro["pow"]) / ro["pow"]).max() < 1e-5
+
+
+_MODE_SCRIPT = r"""
+import json, os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from conftest import golden, f_search_set_for, load_pkg
+import torch
+pkg = load_pkg()
+g = golden("capbuf_0000")["iq_u8"]
+bufs = [g, np.roll(g, 2 * 4321), g[::-1].copy()]
+d = torch.from_numpy(np.stack(bufs)).cuda()
+out = []
+with pkg.Searcher(0) as S:
+    for f in (f_search_set_for(739e6, 100), np.arange(-10, 11) * 10e3):
+        r = S.search_batch(d.data_ptr(), pkg.FMT_IQ_U8, len(bufs), 153600, f, 739e6, 739e6, 1.92e6, pkg.STAGE_PSS, max_cells_per_buf=64)
+        out.append([[(c.n_id_2, c.ind, c.freq, float(c.pss_pow).hex()) for c in b] for b in r])
+print("RESULT" + json.dumps(out))
+"""
+
+
+def test_int8_kernel_modes_are_bit_identical():
+    """The int8 correlation is exact integer arithmetic with one fixed recombination, so the default kernel
+    (LDS-DMA staging, prefetched operands), the gathering variant (operands fetched from the compact digit
+    table through per-lane DMA addresses) and the first, register-staged kernel must return the same bits --
+    on the bench grid and on a 10 kHz grid whose window starts spread over many samples."""
+    import json
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    res = {}
+    for mode in ("", "gather", "rs"):
+        env = dict(os.environ)
+        env.pop("LCS_I8_KERNEL", None)
+        if mode:
+            env["LCS_I8_KERNEL"] = mode
+        p = subprocess.run([sys.executable, "-c", _MODE_SCRIPT, here], env=env, capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr[-2000:]
+        line = [l for l in p.stdout.splitlines() if l.startswith("RESULT")][-1]
+        res[mode] = json.loads(line[len("RESULT"):])
+    assert sum(len(b) for grid in res[""] for b in grid) >= 10
+    assert res["gather"] == res[""]
+    assert res["rs"] == res[""]
