@@ -44,6 +44,10 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 #define I8_TILES ((LCS_N_IDX + I8_LAGS - 1) / I8_LAGS)
 #define I8_NKB LCS_I8_KB                                  // 32-tap blocks per window: 137 taps + spread <= 160
 #define I8_AW (I8_LAGS + 32 * I8_NKB + 32)                // staged samples per window
+// dwords per staged copy: I8_AW / 2 is a multiple of 32, + 16 puts the shifted copy 16 banks away from the natural
+// one, so the even-lag lanes (natural copy, banks 0..12 of a 32-lane group) and the odd-lag lanes (shifted copy)
+// of one ds_read never meet on a bank (with + 2 they did: SQ_LDS_BANK_CONFLICT = 16 % of the kernel's cycles)
+#define I8_ACOPY (I8_AW / 2 + 16)
 #define I8_QMAX 8300000.0                                 // |T_int| bound: three balanced base-256 digits reach 8 355 711
 
 // Per template (slot, foi, t): q = I8_QMAX / max tap magnitude; sc = 1 / (128 q) converts the integer
@@ -160,7 +164,7 @@ __global__ __launch_bounds__(256, 2) void k_xcorr_i8x3_rs(const uint16_t *__rest
   const int widx0 = idx0 + wave * (I8_MT * 16);
 
   // two copies of the staged window (uint16 per sample): [0] natural, [1] shifted down by one sample
-  __shared__ uint32_t ldsA[2][2][I8_AW / 2 + 2];
+  __shared__ uint32_t ldsA[2][2][I8_ACOPY];
   constexpr int NBLK = 3 * I8_NKB;        // blocks per window in execution order: digit 2 (kb 0..4), digit 1, digit 0
   constexpr int BW = NBLK * 2 * 64;       // uint4 per window: the whole operand set of one (window, group), 30 KB
   __shared__ uint4 ldsB[2][BW];
@@ -356,7 +360,7 @@ __global__ __launch_bounds__(256, 2) void k_xcorr_i8x3(const uint16_t *__restric
   const int slot = slot0 + sidx, g = q / I8_TILES, idx0 = (q % I8_TILES) * I8_LAGS;
   const int widx0 = idx0 + wave * (I8_MT * 16);
 
-  __shared__ uint32_t ldsA[2][2][I8_AW / 2 + 2];
+  __shared__ uint32_t ldsA[2][2][I8_ACOPY];
   constexpr int NBLK = 3 * I8_NKB;
   constexpr int BW = NBLK * 2 * 64;       // uint4 per window (30 KB), table order [digit][kb][op][lane]
   constexpr int NCH = BW / 64;            // 1 KiB chunks: one global_load_lds_dwordx4 per wave each
