@@ -1,14 +1,19 @@
 #!/usr/bin/env python3
 """bench.py -- capture-buffers/s of the searcher hot path on MI355X (driver contract).
 
-A "step" is one pass of the chain over one batch of synthetic 153600-sample, 1.92 Msps
-capture buffers that are ALREADY RESIDENT IN HBM when the timed region starts.  N=1 workload =
+A "step" is one pass of the chain over --batches-per-step (32) batches of --batch (64) synthetic
+153600-sample, 1.92 Msps capture buffers that are ALREADY RESIDENT IN HBM when the timed region
+starts (2048 buffers per step: the default 20 steps time ~1 s of GPU work).  N=1 workload =
 BASELINE.json configs[2], the metric's "full CellSearch": PSS correlation over the full +-100 ppm
 grid at 739 MHz (n_f = 31), peak_search and every per-cell stage down to the decoded MIB
 (--stage pss stops after peak_search = configs[1]).  With --gpus N (launched
-by torch.distributed.run, one rank per GPU) every rank processes its own shard of buffers
-(weak scaling, no data-path collective) and the detected-cell lists are all-gathered with
-RCCL once per step.
+by torch.distributed.run, one rank per GPU) every rank processes its own shard of carriers
+(weak scaling, no data-path collective); the detected-cell records of a step are all-gathered with
+RCCL by ONE asynchronous collective per step that is waited for a step later, off the critical path.
+
+The run verifies itself: every batch collected inside the timed, pipelined region must return the
+same bytes as a sequential single-context run of the same buffers afterwards, and buffer 0 is
+checked against the CPU oracle ("verified" in the JSON line).
 
 Prints ONE JSON line on rank 0.
 """
@@ -35,8 +40,8 @@ FS = 1.92e6
 FC = 739e6
 PEAK_FP32_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense FP32 MFMA peak == packed FP32 vector peak
 PEAK_BF16_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense BF16 MFMA peak (~2.5 PFLOP/s)
-PEAK_I8_TOPS = 5000.0         # MI355X_MICROARCH.md: I8 MFMA "~2x bf16 rate" (no spec line; 16x16x64 micro-benchmark ceiling 3944 TOPS)
 PUBLISHED_BUFFERS_PER_S = 1.0 / 6.0   # ~6 s per centre frequency at ppm 100 (dual-core i7-2640)
+PEAK_I8_TOPS = 5000.0         # MI355X_MICROARCH.md: I8 MFMA "~2x bf16 rate" (no spec line; 16x16x64 micro-benchmark ceiling 3944 TOPS)
 
 
 def synth_batch(pkg, n_buf, seed, fc_list):
@@ -56,20 +61,26 @@ def synth_batch(pkg, n_buf, seed, fc_list):
     return out
 
 
-def cpu_baseline(pkg, iq_u8, f, fc, stage):
-    """The CPU oracle (a port of the reference's C++ path) on ONE buffer of the same workload,
-    single thread, on this host.  Reported next to the GPU number; never part of `value`."""
+def cpu_baseline(pkg, host_u8, f, fcs, stage, n_sample=4):
+    """The CPU oracle (a C port of the reference's path, oracle/lcs_oracle.c) on the first `n_sample` buffers of
+    the same workload, single thread, then with OpenMP over the lags as the reference does, on this host.
+    Reported next to the GPU number; never part of `value`.  Returns (report, the oracle's cells of buffer 0)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as O
-    iq = iq_u8.astype(np.float64)
-    cap = ((iq[0::2] - 127.0) / 128.0) + 1j * ((iq[1::2] - 127.0) / 128.0)
+    caps = []
+    for b in range(n_sample):
+        iq = host_u8[b].astype(np.float64)
+        caps.append(((iq[0::2] - 127.0) / 128.0) + 1j * ((iq[1::2] - 127.0) / 128.0))
+
+    def one(cap, fc):
+        if stage == "full":
+            return O.search_capbuf(cap, f, fc, fc, FS)[0]
+        r = O.xcorr_pss(cap, f, 2, fc, fc, FS)
+        return O.peak_search(r["pow"], r["frq"], O.z_th1(r["sp_incoherent"], r["n_comb_xc"]), f, fc, fc, r["single"], 2)
+
     O.set_threads(1)
     t0 = time.perf_counter()
-    if stage == "full":
-        cells, peaks = O.search_capbuf(cap, f, fc, fc, FS)
-    else:
-        r = O.xcorr_pss(cap, f, 2, fc, fc, FS)
-        peaks = O.peak_search(r["pow"], r["frq"], O.z_th1(r["sp_incoherent"], r["n_comb_xc"]), f, fc, fc, r["single"], 2)
+    res = [one(c, float(fc)) for c, fc in zip(caps, fcs)]
     dt = time.perf_counter() - t0
     ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     try:   # a container may be allowed far fewer CPUs than it can see
@@ -81,10 +92,8 @@ def cpu_baseline(pkg, iq_u8, f, fc, stage):
     ncpu = min(ncpu, 64)      # one socket's worth of physical cores is where this loop stops scaling
     O.set_threads(ncpu)
     t0 = time.perf_counter()
-    if stage == "full":
-        O.search_capbuf(cap, f, fc, fc, FS)
-    else:
-        O.xcorr_pss(cap, f, 2, fc, fc, FS)
+    for c, fc in zip(caps, fcs):
+        one(c, float(fc))
     dt_mt = time.perf_counter() - t0
     model = ""
     try:
@@ -94,10 +103,10 @@ def cpu_baseline(pkg, iq_u8, f, fc, stage):
                 break
     except OSError:
         pass
-    return {"value": 1.0 / dt, "unit": "capture-buffers/s", "cores": 1, "kind": "port",
-            "sample": f"1 synthetic buffer, n_f={f.size}, stage={stage}, {dt:.2f} s single-thread "
-                      f"(C oracle, gcc -O3); {ncpu} threads (OpenMP over lags as the reference): {1.0 / dt_mt:.3f} buffers/s",
-            "cpu_model": model, "n_peaks": len(peaks)}
+    return ({"value": n_sample / dt, "unit": "capture-buffers/s", "cores": 1, "kind": "port",
+             "sample": f"{n_sample} synthetic buffers of the bench batch, n_f={f.size}, stage={stage}, {dt:.2f} s single-thread "
+                       f"(C oracle, gcc -O3); {ncpu} threads (OpenMP over lags as the reference): {n_sample / dt_mt:.3f} buffers/s",
+             "cpu_model": model, "n_results": [len(r) for r in res]}, res[0])
 
 
 def stream_bench(pkg, args, rank, world, local_rank, dist):
@@ -164,21 +173,40 @@ def stream_bench(pkg, args, rank, world, local_rank, dist):
         dist.destroy_process_group()
 
 
+def kernel_source_sha():
+    """sha256 over the sources of the dominant kernel: roofline.traffic is only reported when the committed PMC
+    summary was collected from exactly this code."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("pss_xcorr_i8.hip", "pss_xcorr.hip", "lcs_internal.h"):
+        h.update(open(os.path.join(ROOT, "lte-cell-scanner_amd", "csrc", name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def digest(rec, cnt):
+    """Bytes of the valid records of one collected batch (order and every field, NaNs included)."""
+    return b"".join([cnt.tobytes()] + [rec[b, :cnt[b]].tobytes() for b in range(len(cnt))])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=64, help="capture buffers per step per GPU")
+    ap.add_argument("--batch", type=int, default=64, help="capture buffers per enqueue (one correlation launch) per GPU")
+    ap.add_argument("--batches-per-step", type=int, default=32, help="enqueues per step: a step is batch x this many buffers per GPU")
+    ap.add_argument("--distinct", type=int, default=4, help="distinct resident batches the enqueues cycle through")
     ap.add_argument("--ppm", type=float, default=100.0)
     ap.add_argument("--stage", choices=["pss", "full", "stream"], default="full",
                     help="full = BASELINE configs[2], the whole CellSearch chain (default); pss = configs[1], xcorr_pss + "
                          "peak_search only; stream = configs[4], one host buffer at a time through the hipGraph-captured "
                          "single-hypothesis chain (separate, shorter report)")
-    ap.add_argument("--variant", type=int, default=0, help="PSS correlation kernel: 0 = default (int8 three-digit MFMA kernel for the u8 input), 1 = fp32 VALU twin, 2 = one-wave fp32 MFMA kernel, 3 = 4-wave fp32 MFMA kernel, 4 = bf16 three-term MFMA kernel")
+    ap.add_argument("--input", choices=["u8", "c64"], default="u8",
+                    help="resident input format: raw RTL-SDR u8 I/Q (int8 MFMA correlation kernel, default) or complex<float> "
+                         "(fp32 MFMA correlation kernel)")
     ap.add_argument("--pipeline", type=int, default=3,
-                    help="contexts (streams + workspaces) used round-robin: with 2, the latency-bound per-cell "
-                         "stages of step i overlap the PSS correlation of step i+1")
+                    help="contexts (streams + workspaces) used round-robin: the latency-bound per-cell "
+                         "stages of batch i overlap the PSS correlation of batch i+1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (testing the multi-rank path on one GPU)")
     ap.add_argument("--share-gpu0", action="store_true", help="testing only: every rank uses GPU 0")
@@ -212,69 +240,108 @@ def main():
         return stream_bench(pkg, args, rank, world, local_rank, dist)
     f = pkg.f_search_set_for(FC, args.ppm)
     stage_mask = pkg.STAGE_FULL if args.stage == "full" else pkg.STAGE_PSS
-    B = args.batch
+    B, K, D = args.batch, args.batches_per_step, max(1, args.distinct)
+    fmt = pkg.FMT_IQ_U8 if args.input == "u8" else pkg.FMT_C64
     # rank r searches carriers FC + 100 kHz * (r*B + b): the sweep's carrier axis is the shard axis
     fcs = FC + 100e3 * (np.arange(B) + rank * B)
     host = synth_batch(pkg, B, 1234 + rank, fcs)
-    d_cap = torch.from_numpy(host).to(dev)            # inputs resident in HBM before timing starts
+    base = torch.from_numpy(host).to(dev)
+    # D distinct resident batches: the synthetic base batch and copies rotated in time by whole samples on the device
+    # (cells move, frame timing changes, every correlation value changes).  Inputs are in HBM before timing starts.
+    d_caps = [base if d == 0 else torch.roll(base, shifts=2 * 1117 * d, dims=1).contiguous() for d in range(D)]
+    if fmt == pkg.FMT_C64:
+        d_caps = [torch.view_as_complex(((x.to(torch.float32) - 127.0) / 128.0).view(B, N_CAP, 2).contiguous()) for x in d_caps]
+    torch.cuda.synchronize()
     ctxs = [pkg.Searcher(local_rank if world > 1 else 0) for _ in range(max(1, args.pipeline))]
-    for S in ctxs:
-        S.set_xcorr_variant(args.variant)
     MAXC = 16
-    gather_buf = torch.zeros((world, B, 1 + MAXC * 4), dtype=torch.float64, device=coll_dev) if world > 1 else None
+    # one fixed-size record block per step for the all-gather: [n, then n x (n_id_cell, fc, f_off, pss_pow, sfn)]
+    MAXREC = 64 * K
+    gather_in = [torch.zeros(1 + 5 * MAXREC, dtype=torch.float64, pin_memory=(coll_dev.type == "cuda")) for _ in range(2)] if world > 1 else None
+    gather_dev = [torch.zeros(1 + 5 * MAXREC, dtype=torch.float64, device=coll_dev) for _ in range(2)] if world > 1 else None
+    gather_out = [torch.zeros((world, 1 + 5 * MAXREC), dtype=torch.float64, device=coll_dev) for _ in range(2)] if world > 1 else None
+    pending = {"work": None}
 
     host_t = {"enqueue": 0.0, "collect": 0.0, "n": 0}
+    seen = {}            # distinct-batch index -> digest of the first collect; every later collect must match
+    state = {"mismatch": 0, "collected": 0}
 
     def enqueue(i):
         t = time.perf_counter()
-        ctxs[i % len(ctxs)].batch_enqueue(d_cap.data_ptr(), pkg.FMT_IQ_U8, B, N_CAP, f, fcs, fcs, FS, stage_mask)
+        ctxs[i % len(ctxs)].batch_enqueue(d_caps[i % D].data_ptr(), fmt, B, N_CAP, f, fcs, fcs, FS, stage_mask)
         host_t["enqueue"] += time.perf_counter() - t
 
-    def collect(i, gather=True):
+    def collect(i):
         t = time.perf_counter()
-        res = ctxs[i % len(ctxs)].batch_collect(B, MAXC)
+        rec, cnt = ctxs[i % len(ctxs)].batch_collect_raw(B, MAXC)
         host_t["collect"] += time.perf_counter() - t
         host_t["n"] += 1
-        host_t.setdefault("stamps", []).append(time.perf_counter())
-        if world > 1 and gather:   # RCCL all-gather of the detected-cell list (fixed-size records), nothing else
-            mine = torch.zeros((B, 1 + MAXC * 4), dtype=torch.float64)
-            for b, cells in enumerate(res):
-                mine[b, 0] = len(cells)
-                for i, c in enumerate(cells[:MAXC]):
-                    mine[b, 1 + 4 * i: 5 + 4 * i] = torch.tensor([c.n_id_cell(), c.fc_requested, c.freq_superfine if stage_mask == 3 else c.freq, c.pss_pow])
-            dist.all_gather_into_tensor(gather_buf.view(-1), mine.to(coll_dev).view(-1))
-        return res
+        dg = digest(rec, cnt)
+        if seen.setdefault(i % D, dg) != dg:
+            state["mismatch"] += 1
+        state["collected"] += 1
+        return rec, cnt
 
-    def run(n_steps, xc_ms=None, gather=True):
-        """n_steps steps, software-pipelined over the contexts: step i is enqueued before step
-        i-(depth-1) is collected, so nothing but the stream of the collected step ever blocks."""
+    def gather_step(step_idx, recs):
+        """ONE asynchronous all-gather of this step's cell records; the previous step's is waited for first (it has had
+        a whole step to complete), so the collective never sits on the critical path."""
+        if pending["work"] is not None:
+            pending["work"].wait()
+        valid = np.concatenate([r[b, :c[b]] for r, c in recs for b in range(len(c))]) if recs else np.zeros(0, pkg.capi.cell_dtype())
+        n = min(len(valid), MAXREC)
+        buf = gather_in[step_idx % 2].numpy()
+        buf[0] = n
+        if n:
+            v = valid[:n]
+            blk = np.stack([(v["n_id_2"] + 3 * v["n_id_1"]).astype(np.float64), v["fc_requested"],
+                            v["freq_superfine"] if stage_mask == 3 else v["freq"], v["pss_pow"], v["sfn"].astype(np.float64)], axis=1)
+            buf[1:1 + 5 * n] = blk.reshape(-1)
+        gather_dev[step_idx % 2].copy_(gather_in[step_idx % 2], non_blocking=True)
+        pending["work"] = dist.all_gather_into_tensor(gather_out[step_idx % 2].view(-1), gather_dev[step_idx % 2], async_op=True)
+
+    def run(n_steps, xc_ms=None, gather=True, step_ms=None, first_step=0):
+        """n_steps steps of K batches each, software-pipelined over the contexts: batch i is enqueued before batch
+        i-(depth-1) is collected, so nothing but the stream of the collected batch ever blocks."""
         depth = len(ctxs)
-        res = None
-        for i in range(n_steps + depth - 1):
-            if i < n_steps:
+        total = n_steps * K
+        recs, last = [], None
+        t_prev = time.perf_counter()
+        for i in range(total + depth - 1):
+            if i < total:
                 enqueue(i)
             j = i - (depth - 1)
             if j >= 0:
-                res = collect(j, gather)
+                last = collect(j)
+                recs.append(last)
                 if xc_ms is not None:
                     xc_ms.append(ctxs[j % depth].last_xcorr_ms()[0])
-        return res
+                if (j + 1) % K == 0:
+                    if world > 1 and gather:
+                        gather_step(first_step + j // K, recs)
+                    recs = []
+                    if step_ms is not None:
+                        now = time.perf_counter()
+                        step_ms.append(1e3 * (now - t_prev))
+                        t_prev = now
+        return last
 
     # Pre-conditioning (untimed, like the warm-up): a fresh process shows one ~50 ms stall in its
     # first few hundred milliseconds of GPU activity (clock / power-state ramp); keep the GPU
     # busy for ~0.6 s so that it does not land in the timed steps of a short run.
     t_pre = time.perf_counter()
     while time.perf_counter() - t_pre < 0.6:
-        run(2, gather=False)      # time-based, so no collective in here (ranks may differ in count)
-    host_t.update(enqueue=0.0, collect=0.0, n=0, stamps=[])
+        run(1, gather=False)      # time-based, so no collective in here (ranks may differ in count)
+    host_t.update(enqueue=0.0, collect=0.0, n=0)
     if args.warmup:
-        res = run(args.warmup)
-    xc_ms = []
+        run(args.warmup, first_step=0)
+    xc_ms, step_ms = [], []
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    res = run(args.steps, xc_ms)
+    last = run(args.steps, xc_ms, step_ms=step_ms, first_step=args.warmup)
+    if pending["work"] is not None:
+        pending["work"].wait()
+        pending["work"] = None
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -284,88 +351,120 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    n_peaks = sum(len(r) for r in res)
-    # the dominant kernel once more, alone on the GPU (no overlap with the other context's kernels)
+    # ---- verification (outside the timed region) -------------------------------------------------------------
+    # (1) every pipelined collect of a distinct batch returned identical bytes (state["mismatch"] == 0);
+    # (2) a sequential, single-context, synchronous run of each distinct batch returns those bytes too;
+    # (3) buffer 0 of batch 0 against the CPU oracle (done in the cpu_baseline leg below, rank 0).
+    seq_ok = True
     iso_ms = []
-    for _ in range(3):
-        ctxs[0].batch_enqueue(d_cap.data_ptr(), pkg.FMT_IQ_U8, B, N_CAP, f, fcs, fcs, FS, pkg.STAGE_PSS)
-        ctxs[0].batch_collect(B, MAXC)
-        iso_ms.append(ctxs[0].last_xcorr_ms()[0])
+    n_cells_per_batch = []
+    for d in range(D):
+        ctxs[0].batch_enqueue(d_caps[d].data_ptr(), fmt, B, N_CAP, f, fcs, fcs, FS, stage_mask)
+        rec, cnt = ctxs[0].batch_collect_raw(B, MAXC)
+        iso_ms.append(ctxs[0].last_xcorr_ms()[0])       # the dominant kernel alone on the GPU (nothing overlaps it here)
+        n_cells_per_batch.append(int(cnt.sum()))
+        seq_ok = seq_ok and (seen.get(d) == digest(rec, cnt))
+        if d == 0:
+            rec0, cnt0 = rec.copy(), cnt.copy()
+    kname, executed_ops = ctxs[0].last_xcorr_info()
+    verify = {"pipelined_collects": state["collected"], "pipelined_mismatches": state["mismatch"],
+              "sequential_run_identical": bool(seq_ok), "oracle_buffer0": None}
+
     if rank == 0:
         n_f = f.size
-        value = world * B * args.steps / dt
+        n_buffers = world * B * K * args.steps
+        value = n_buffers / dt
         # dominant kernel: PSS correlation.  Algorithmic work per buffer:
-        # F = 8*137*3*(N-136)*n_f real flops (reference-faithful count over all lags).
+        # F = 8*137*3*(N-136)*n_f real flops (reference-faithful count over all lags); the consumed subset is the
+        # 15 x 9600 lags xc_combine reads.
         flops_per_buf = 8.0 * 137 * 3 * (N_CAP - 136) * n_f
-        flops_consumed = 8.0 * 137 * 3 * 9600 * 15 * n_f       # the 15x9600 lags that are ever used
+        flops_consumed = 8.0 * 137 * 3 * 9600 * 15 * n_f
         k_ms = float(np.mean(xc_ms))
-        # Which kernel ran: u8 sources take the int8 three-digit kernel (24-bit integer templates as three int8
-        # digits, i.e. 3 MFMA MACs per algorithmic MAC) or, with LCS_NO_I8 / --variant 4, the bf16 three-term kernel
-        # (a*t = a*t1 + a*t2 + a*t3 with exact bf16 factors); --variant 1..3 the fp32 kernels.
-        i8 = args.variant == 0 and os.environ.get("LCS_NO_I8") is None
-        bf16 = (not i8) and (args.variant == 4 or (args.variant == 0 and os.environ.get("LCS_NO_BF16") is None))
-        macs_factor, peak = (3.0, PEAK_I8_TOPS) if i8 else ((3.0, PEAK_BF16_TFLOPS) if bf16 else (1.0, PEAK_FP32_TFLOPS))
-        kname = "k_xcorr_i8x3" if i8 else ("k_xcorr_bf16x3_unrolled<9>" if bf16 else
-                                            {0: "k_xcorr_mfma_blk<4,4,32>", 1: "k_xcorr_valu", 2: "k_xcorr_mfma", 3: "k_xcorr_mfma_blk<4,4,32>"}.get(args.variant))
-        # HBM traffic of the dominant kernel from the PMC counters (FETCH_SIZE / WRITE_SIZE, separate
-        # rocprofv3 passes, corrected as MI355X_MICROARCH.md prescribes): measured per buffer at this
-        # n_f with the default kernel, summary committed under profiles/ -- null when not measured.
-        traffic = None
-        try:
-            pmj = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_summary.json")))
-            pm = pmj["kernels"][pmj["dominant_kernel"]]
-            if int(pm["n_f"]) == int(n_f) and pmj["dominant_kernel"].startswith(kname.split("<")[0]):
-                traffic = float(pm["hbm_bytes_per_buffer"]) * B
-        except Exception:
-            traffic = None
-        achieved = macs_factor * flops_per_buf * B / (k_ms * 1e-3) / 1e12
+        k_iso = float(np.mean(iso_ms))
+        i8 = kname.startswith("k_xcorr_i8")
+        peak = PEAK_I8_TOPS if i8 else PEAK_FP32_TFLOPS
+        # HBM traffic of the dominant kernel from the PMC counters (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 passes,
+        # corrected as MI355X_MICROARCH.md prescribes), taken from the committed summary ONLY if it was collected from
+        # exactly the kernel sources that are running now.
+        traffic, traffic_src = None, None
+        for tag in ("r02", "r01"):
+            try:
+                pmj = json.load(open(os.path.join(ROOT, "profiles", tag, "pmc_summary.json")))
+                pm = pmj["kernels"][pmj["dominant_kernel"]]
+                if (pmj.get("kernel_source_sha") == kernel_source_sha() and int(pm["n_f"]) == int(n_f)
+                        and pmj["dominant_kernel"].startswith(kname.split("<")[0])):
+                    traffic, traffic_src = float(pm["hbm_bytes_per_buffer"]) * B, f"profiles/{tag}/pmc_summary.json"
+                    break
+            except Exception:
+                continue
+        achieved = flops_per_buf * B / (k_ms * 1e-3) / 1e12
         bytes_per_buf = 1651200 + 230400 * n_f                 # SURVEY.md section 8d compulsory HBM bytes
+        sm = np.asarray(step_ms)
         out = {
             "metric": "capture-buffers/s (1.92 Msps, 153600-samp) full CellSearch; HBM GB/s vs peak",
             "value": value, "unit": "capture-buffers/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": value / PUBLISHED_BUFFERS_PER_S,
-            "dtype": ("i8 x 3 base-256 digits of 24-bit integer templates, i32 accumulate (exact)" if i8 else
-                      "bf16x3 products (exact), f32 accumulate" if bf16 else "f32"), "data": "synthetic",
+            "dtype": ("i8 x 3 base-256 digits of 24-bit integer templates, i32 accumulate (exact)" if i8 else "f32"),
+            "data": "synthetic", "verified": bool(seq_ok and state["mismatch"] == 0),
             "iq_samples_per_s": value * N_CAP,
             "config": {"workload": ("configs[2]: full searcher chain (PSS+SSS+FOE+TFG+MIB)" if args.stage == "full" else
                                     "configs[1]: xcorr_pss + peak_search over the full +-100 ppm foe grid") +
-                                   f", one MI355X per rank, {B} x 153600-sample capbufs per step, fc 739 MHz + 100 kHz raster",
-                       "n_f": int(n_f), "batch_per_gpu": B, "stage": args.stage, "ingest": "u8 I/Q resident in HBM",
-                       "xcorr_kernel": "mfma_i32_16x16x64_i8, three int8 digits per 24-bit integer template tap" if i8 else
-                                       "mfma_f32_16x16x32_bf16, three exact bf16 terms per fp32 template tap" if bf16 else
-                                       ("valu_f32" if args.variant == 1 else "mfma_f32_16x16x4_f32"),
+                                   f", one MI355X per rank, step = {K} batches x {B} = {K * B} 153600-sample capbufs per GPU, "
+                                   f"fc 739 MHz + 100 kHz raster, {D} distinct resident batches",
+                       "n_f": int(n_f), "batch_per_gpu": B, "batches_per_step": K, "buffers_per_step_per_gpu": B * K,
+                       "buffers_timed": n_buffers, "timed_region_s": dt, "stage": args.stage,
+                       "ingest": "u8 I/Q resident in HBM" if fmt == pkg.FMT_IQ_U8 else "complex<float> resident in HBM",
+                       "xcorr_kernel": "mfma_i32_16x16x64_i8, three int8 digits per 24-bit integer template tap" if i8 else "mfma_f32_16x16x4_f32",
                        "pipeline_depth": len(ctxs),
-                       "parallelism": f"carrier-sweep shard x{world}, RCCL all-gather of cell list" if world > 1 else "single GPU",
-                       "baseline_note": "vs_baseline = value / (1 buffer per ~6 s), doc/CellSearch.html:52-54 (dual-core i7-2640, ppm 100)",
-                       "n_cells_reported_last_step": n_peaks,
-                       "step_done_ms": [round(1e3 * (x - t0), 2) for x in host_t.get("stamps", [])[-args.steps:]],
-                       "host_ms_per_step": {"enqueue": 1e3 * host_t["enqueue"] / max(1, host_t["n"]),
-                                            "collect_incl_wait": 1e3 * host_t["collect"] / max(1, host_t["n"])}},
+                       "parallelism": f"carrier-sweep shard x{world}, one async RCCL all-gather of the cell records per step" if world > 1 else "single GPU",
+                       "baseline_note": "vs_baseline = value / (1 buffer per ~6 s), doc/CellSearch.html:52-54 (dual-core i7-2640, ppm 100; BASELINE.md section 1)",
+                       "cells_per_distinct_batch": n_cells_per_batch,
+                       "ms_per_batch": 1e3 * dt / (args.steps * K),
+                       "step_ms": {"min": float(sm.min()), "median": float(np.median(sm)), "max": float(sm.max())} if sm.size else None,
+                       "host_ms_per_batch": {"enqueue": 1e3 * host_t["enqueue"] / max(1, host_t["n"]),
+                                             "collect_incl_wait": 1e3 * host_t["collect"] / max(1, host_t["n"])}},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TOP/s" if i8 else "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic,
-                         "flops_note": ("achieved = 3 x the algorithmic flops of SURVEY 8d (three int8 digit MACs realise one MAC with a 24-bit "
-                                        "integer template tap) / kernel time, against 2x the dense bf16 MFMA peak (the 16x16x64 i8 micro-benchmark "
-                                        "ceiling is 3944 TOP/s); fp32_equivalent_tflops counts the algorithmic flops once") if i8 else
-                                       ("achieved = 3 x the algorithmic flops of SURVEY 8d (three exact bf16 MACs realise one fp32 MAC) / kernel time, "
-                                        "against the dense bf16 MFMA peak; fp32_equivalent_tflops counts the algorithmic flops once") if bf16 else
-                                       "achieved = algorithmic flops of SURVEY 8d / kernel time, against the fp32 MFMA peak",
-                         "fp32_equivalent_tflops": flops_per_buf * B / (k_ms * 1e-3) / 1e12,
-                         "traffic_note": "HBM bytes per launch from rocprofv3 PMC (2*FETCH_SIZE+WRITE_SIZE)*1024, profiles/r01/pmc_summary.json; "
-                                         "algorithmic bytes of this kernel per launch (capture buffer in, xc_incoherent_single out): %d"
-                                         % int(((2 if i8 else 4 if bf16 else 8) * N_CAP + 4 * 3 * 9600 * n_f) * B),
-                         "kernel": kname, "kernel_ms": k_ms,
-                         "kernel_ms_isolated": float(np.mean(iso_ms)),
-                         "frac_isolated": macs_factor * flops_per_buf * B / (float(np.mean(iso_ms)) * 1e-3) / 1e12 / peak,
-                         "flops_per_launch": macs_factor * flops_per_buf * B,
-                         "achieved_consumed_lags_only": macs_factor * flops_consumed * B / (k_ms * 1e-3) / 1e12,
+                         "frac_algorithmic": flops_consumed * B / (k_ms * 1e-3) / 1e12 / peak,
+                         "frac_executed": (executed_ops / (k_ms * 1e-3) / 1e12 / peak) if executed_ops else None,
+                         "note": ("achieved = SURVEY 8(d) algorithmic flops of one launch (8*137*3*(N-136)*n_f per buffer x %d buffers, counted ONCE) / "
+                                  "the kernel's mean duration inside the timed region (HIP events on its stream); peak = dense int8 MFMA, 2x the bf16 "
+                                  "figure of MI355X_MICROARCH.md (16x16x64 issues every ~18 cycles, 32x32x32 every 32: both measure 4.3-4.4 POP/s at the "
+                                  "sustained clock, tools/microbench/mfma_rate.hip).  frac_algorithmic counts only the 15 x 9600 lags that are consumed; "
+                                  "frac_executed counts the MFMA work issued (x3 digits, 160 of 137 taps, 96 of 93 columns)." % B) if i8 else
+                                 "achieved = SURVEY 8(d) algorithmic flops / kernel time, against the fp32 MFMA peak",
+                         "kernel": kname, "kernel_ms": k_ms, "kernel_ms_isolated": k_iso,
+                         "frac_isolated": flops_per_buf * B / (k_iso * 1e-3) / 1e12 / peak,
+                         "frac_executed_isolated": (executed_ops / (k_iso * 1e-3) / 1e12 / peak) if executed_ops else None,
+                         "flops_per_launch": flops_per_buf * B, "executed_ops_per_launch": executed_ops or None,
+                         "traffic_source": traffic_src,
+                         "traffic_note": "HBM bytes per launch from rocprofv3 PMC (2*FETCH_SIZE+WRITE_SIZE)*1024, reported only when the committed "
+                                         "summary's kernel_source_sha equals the running sources'; algorithmic bytes of this kernel per launch "
+                                         "(capture buffer in, xc_incoherent_single out): %d" % int(((2 if i8 else 8) * N_CAP + 4 * 3 * 9600 * n_f) * B),
+                         "kernel_source_sha": kernel_source_sha(),
                          "hbm_algorithmic_GBps": bytes_per_buf * B / (k_ms * 1e-3) / 1e9, "hbm_peak_GBps": 8000.0,
                          "hbm_frac_algorithmic": bytes_per_buf * B / (k_ms * 1e-3) / 1e9 / 8000.0,
                          "hbm_measured_GBps": (traffic / (k_ms * 1e-3) / 1e9) if traffic else None,
                          "hbm_frac_measured": (traffic / (k_ms * 1e-3) / 1e9 / 8000.0) if traffic else None},
         }
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(pkg, host[0], f, float(fcs[0]), args.stage)
+            cb, ocells = cpu_baseline(pkg, host, f, fcs, args.stage)
+            out["cpu_baseline"] = cb
+            # (3) the GPU's records for buffer 0 against the oracle's: identities exact, powers 1e-5, frequencies 1e-3 Hz
+            got = rec0[0, :cnt0[0]]
+            ok = len(got) == len(ocells)
+            for g_, o_ in zip(got, ocells):
+                ok = ok and (int(g_["n_id_2"]), int(g_["ind"]), float(g_["freq"])) == (o_.n_id_2, o_.ind, o_.freq)
+                ok = ok and abs(float(g_["pss_pow"]) - o_.pss_pow) <= 1e-5 * o_.pss_pow
+                if args.stage == "full":
+                    ok = ok and (int(g_["n_id_1"]), int(g_["cp_type"]), int(g_["n_ports"]), int(g_["n_rb_dl"]), int(g_["phich_duration"]),
+                                 int(g_["phich_resource"]), int(g_["sfn"])) == (o_.n_id_1, o_.cp_type, o_.n_ports, o_.n_rb_dl,
+                                                                                 o_.phich_duration, o_.phich_resource, o_.sfn)
+                    ok = ok and abs(float(g_["freq_superfine"]) - o_.freq_superfine) < 1e-3
+            verify["oracle_buffer0"] = bool(ok)
+            out["verified"] = bool(out["verified"] and ok)
+        out["verify"] = verify
         print(json.dumps(out))
     for S in ctxs:
         S.close()

@@ -18,6 +18,10 @@
  *  - every function returns LCS_OK (0) or a negative error; "not found" stays in-band in
  *    lcs_cell (n_id_1 == -1 / n_rb_dl == -1) exactly as in the reference
  *    (src/CellSearch.cpp:530, 554).
+ *  - correlation kernel: raw RTL-SDR u8 I/Q (LCS_FMT_IQ_U8) is exact in int8 and runs on the int8 matrix cores
+ *    (templates as 24-bit integers in three int8 digits, exact int32 accumulation) when the frequency grid is
+ *    dense enough (137 taps + window-start spread inside a 16-template group <= 160); every other source, and
+ *    sparser grids, take the fp32 MFMA kernel.  Both agree with the reference to ~1e-7 relative.
  *  - a context owns one HIP device + stream + workspace; calls on one context are
  *    serialised by the caller, different contexts are independent (the reference's
  *    functions are re-entrant).
@@ -78,14 +82,10 @@ void lcs_destroy(lcs_ctx *ctx);
 const char *lcs_last_error(const lcs_ctx *ctx);
 const char *lcs_version(void);
 void lcs_cell_init(lcs_cell *c);                      /* src/common.cpp:36-56 */
-/* Knob for A/B measurement of the PSS correlation kernel.  0 = default: chosen by the source format --
- * raw RTL-SDR u8 I/Q is exact in int8 and bfloat16 and takes the int8 three-digit MFMA kernel (templates
- * quantised to 24-bit integers, exact integer accumulation; the bf16 three-term kernel when the frequency
- * grid is too sparse for it), every other source the fp32 MFMA kernel (4-wave workgroups, template rows
- * through LDS).  1 = plain-VALU fp32 twin, 2 = 1-wave fp32 MFMA kernel with template rows from L2, 3 = the
- * fp32 kernel of variant 0 for every source, 4 = the bf16 kernel for u8 sources.  1, 2, 3 are bit-identical;
- * the int8 and bf16 kernels agree with them to ~1e-7 relative. */
-int lcs_set_xcorr_variant(lcs_ctx *ctx, int variant);
+/* Memory-footprint limit: the per-cell stages (time-frequency grid, channel estimate, PBCH) hold at most n
+ * detected cells at a time (default and maximum 512, ~6 MB each); a batch with more cells is processed in
+ * rounds.  Results do not depend on it. */
+int lcs_set_max_cells_in_flight(lcs_ctx *ctx, int n);
 
 /* ---- stage entry points (host buffers in / out) ------------------------------------ */
 
@@ -174,15 +174,34 @@ int lcs_search_batch_dev(lcs_ctx *ctx, const void *d_capbufs, int fmt, int n_buf
                          const double *fc_programmed, double fs_programmed, int stage_mask,
                          lcs_cell *cells, int max_cells_per_buf, int *n_cells);
 
+/* The same for buffers in HOST memory (copied to the device by the call): what a caller holding recorded
+ * capbuf_NNNN.it files or dongle bytes uses.  RTL-SDR captures are exactly (u8-127)/128 (src/capbuf.cpp:172-181):
+ * handing them over as LCS_FMT_IQ_U8 moves 8x fewer bytes than complex<double> and takes the int8 correlation
+ * kernel. */
+int lcs_search_batch_host(lcs_ctx *ctx, const void *h_capbufs, int fmt, int n_buf, uint32_t n_cap,
+                          const double *f_search_set, uint16_t n_f, const double *fc_requested,
+                          const double *fc_programmed, double fs_programmed, int stage_mask,
+                          lcs_cell *cells, int max_cells_per_buf, int *n_cells);
+
 /* Enqueue-only variant for timing: same work, results stay on the device until
  * lcs_batch_collect.  Between enqueue and collect nothing synchronises with the host. */
 int lcs_batch_enqueue(lcs_ctx *ctx, const void *d_capbufs, int fmt, int n_buf, uint32_t n_cap,
                       const double *f_search_set, uint16_t n_f, const double *fc_requested,
                       const double *fc_programmed, double fs_programmed, int stage_mask);
 int lcs_batch_collect(lcs_ctx *ctx, lcs_cell *cells, int max_cells_per_buf, int *n_cells);
+/* Debug readback of the last batch (after lcs_batch_collect / lcs_search_batch_*): the xcorr_pss outputs of
+ * buffer `buf` in the layouts of lcs_xcorr_pss, plus the detection threshold Z_th1 (src/CellSearch.cpp:500-503).
+ * Every pointer may be NULL.  This is how the tests pin the batched kernels to the oracle array by array. */
+int lcs_batch_readback(lcs_ctx *ctx, int buf, float *xc_incoherent_single /*[3][9600][n_f]*/,
+                       double *xc_incoherent_collapsed_pow /*[3][9600]*/, int32_t *xc_incoherent_collapsed_frq /*[3][9600]*/,
+                       double *sp_incoherent /*[9600]*/, double *z_th1 /*[9600]*/);
 /* HIP-event time (ms) of the PSS correlation kernel launches of the last enqueue, and the
  * number of launches it covers; used by bench.py for the roofline figure. */
 int lcs_last_xcorr_ms(lcs_ctx *ctx, float *ms, int *n_launches);
+/* Which correlation kernel the last enqueue launched and the matrix-core operations (2 x multiply-accumulates,
+ * padding included) those launches executed -- 0 when the kernel does not count them.  For bench.py's
+ * roofline.frac_executed. */
+int lcs_last_xcorr_info(lcs_ctx *ctx, double *executed_ops, const char **kernel);
 /* ---- streaming mode: LTE-Tracker's searcher thread (src/searcher_thread.cpp:83-246) ----------
  * One 80 ms capture buffer at a time, a single frequency hypothesis (the tracked frequency offset,
  * :97-98), cells whose identity is already tracked are reported as re-detected and not decoded again
@@ -191,7 +210,10 @@ int lcs_last_xcorr_ms(lcs_ctx *ctx, float *ms, int *n_launches);
  * memory and replays the graph asynchronously; lcs_stream_collect waits for it and returns the NEW
  * cells (SSS and MIB decoded), the number of tracked cells seen again and the GPU time of the pass.
  * frame_start is in samples of the pushed buffer; the tracker's 1.92 MHz time base is
- * frame_start*(FS_LTE/16)/(fs_programmed*k_factor) + capture latency (:224). */
+ * frame_start*(FS_LTE/16)/(fs_programmed*k_factor) + capture latency (:224).
+ * While a stream is open the captured graph holds the context's workspace addresses: any other call on the
+ * same context that would need a larger workspace (more buffers, a longer n_cap, more hypotheses) fails with
+ * LCS_ERR_BAD_ARG until lcs_stream_close; use a second context for such work. */
 int lcs_stream_open(lcs_ctx *ctx, int fmt, uint32_t n_cap, double fc_requested, double fc_programmed,
                     double fs_programmed);
 int lcs_stream_push(lcs_ctx *ctx, const void *samples, double f_off, const int16_t *tracked_n_id_cell, int n_tracked);

@@ -89,8 +89,8 @@ class Searcher:
             return rc
         raise SearcherError(f"{what}: {capi.ERRORS.get(rc, rc)}: {self._lib.lcs_last_error(self._h).decode()}")
 
-    def set_xcorr_variant(self, v: int):
-        self._chk(self._lib.lcs_set_xcorr_variant(self._h, v), "lcs_set_xcorr_variant")
+    def set_max_cells_in_flight(self, n: int):
+        self._chk(self._lib.lcs_set_max_cells_in_flight(self._h, n), "lcs_set_max_cells_in_flight")
 
     # ---- searcher.h:22-41 -------------------------------------------------------------
     def xcorr_pss(self, capbuf, f_search_set, ds_comb_arm, fc_requested, fc_programmed, fs_programmed,
@@ -204,10 +204,42 @@ class Searcher:
         self._chk(rc, "lcs_batch_enqueue")
 
     def batch_collect(self, n_buf: int, max_cells_per_buf: int = 16):
+        """-> per-buffer cell lists.  LCS_ERR_OVERFLOW (more peaks / cells than the library's or the caller's
+        arrays hold: results truncated) is surfaced as a warning and kept in ``self.last_overflow``."""
         cells = (LcsCell * (n_buf * max_cells_per_buf))()
         cnt = (C.c_int * n_buf)()
         rc = self._lib.lcs_batch_collect(self._h, cells, max_cells_per_buf, cnt)
-        self._chk(rc, "lcs_batch_collect", allow_overflow=True)
+        self._note_overflow(self._chk(rc, "lcs_batch_collect", allow_overflow=True), "lcs_batch_collect")
+        return [[cells[b * max_cells_per_buf + i].copy() for i in range(min(cnt[b], max_cells_per_buf))]
+                for b in range(n_buf)]
+
+    def _note_overflow(self, rc, what):
+        self.last_overflow = rc == -4
+        if self.last_overflow:
+            import warnings
+            warnings.warn(f"{what}: LCS_ERR_OVERFLOW: {self._lib.lcs_last_error(self._h).decode()} (results truncated)",
+                          RuntimeWarning, stacklevel=3)
+
+    def batch_readback(self, buf: int, n_f: int):
+        """xcorr_pss outputs of buffer `buf` of the last batch in the reference's layouts (debug)."""
+        out = dict(single=np.empty((3, 9600, n_f), np.float32), pow=np.empty((3, 9600)), frq=np.empty((3, 9600), np.int32),
+                   sp_incoherent=np.empty(9600), z_th1=np.empty(9600))
+        self._chk(self._lib.lcs_batch_readback(self._h, buf, _fp(out["single"]), _dp(out["pow"]), _ip(out["frq"]),
+                                               _dp(out["sp_incoherent"]), _dp(out["z_th1"])), "lcs_batch_readback")
+        return out
+
+    def search_batch_host(self, h_capbufs, fmt: int, n_buf: int, n_cap: int, f_search_set, fc_requested, fc_programmed,
+                          fs_programmed: float, stage_mask: int = STAGE_FULL, max_cells_per_buf: int = 16):
+        a = np.ascontiguousarray(h_capbufs, dtype=np.uint8 if fmt == FMT_IQ_U8 else np.complex64)
+        assert a.size == n_buf * n_cap * (2 if fmt == FMT_IQ_U8 else 1)
+        f = np.ascontiguousarray(f_search_set, np.float64)
+        fr = np.ascontiguousarray(np.broadcast_to(np.asarray(fc_requested, np.float64), (n_buf,)))
+        fp_ = np.ascontiguousarray(np.broadcast_to(np.asarray(fc_programmed, np.float64), (n_buf,)))
+        cells = (LcsCell * (n_buf * max_cells_per_buf))()
+        cnt = (C.c_int * n_buf)()
+        rc = self._lib.lcs_search_batch_host(self._h, a.ctypes.data_as(C.c_void_p), fmt, n_buf, n_cap, _dp(f), f.size, _dp(fr),
+                                             _dp(fp_), fs_programmed, stage_mask, cells, max_cells_per_buf, cnt)
+        self._note_overflow(self._chk(rc, "lcs_search_batch_host", allow_overflow=True), "lcs_search_batch_host")
         return [[cells[b * max_cells_per_buf + i].copy() for i in range(min(cnt[b], max_cells_per_buf))]
                 for b in range(n_buf)]
 
@@ -234,8 +266,8 @@ class Searcher:
         """-> (new cells, number of tracked cells seen again, GPU milliseconds of the pass)."""
         cells = (LcsCell * max_cells)()
         n, dup, ms = C.c_int(0), C.c_int(0), C.c_float(0)
-        self._chk(self._lib.lcs_stream_collect(self._h, cells, max_cells, C.byref(n), C.byref(dup), C.byref(ms)),
-                  "lcs_stream_collect", allow_overflow=True)
+        self._note_overflow(self._chk(self._lib.lcs_stream_collect(self._h, cells, max_cells, C.byref(n), C.byref(dup), C.byref(ms)),
+                                      "lcs_stream_collect", allow_overflow=True), "lcs_stream_collect")
         return [cells[i].copy() for i in range(min(n.value, max_cells))], dup.value, ms.value
 
     def stream_close(self):
@@ -245,6 +277,22 @@ class Searcher:
         ms, n = C.c_float(0), C.c_int(0)
         self._chk(self._lib.lcs_last_xcorr_ms(self._h, C.byref(ms), C.byref(n)), "lcs_last_xcorr_ms")
         return ms.value, n.value
+
+    def last_xcorr_info(self):
+        """-> (kernel name, matrix-core operations executed by the last enqueue's correlation launches)."""
+        ops, name = C.c_double(0), C.c_char_p()
+        self._chk(self._lib.lcs_last_xcorr_info(self._h, C.byref(ops), C.byref(name)), "lcs_last_xcorr_info")
+        return (name.value or b"").decode(), ops.value
+
+    def batch_collect_raw(self, n_buf: int, max_cells_per_buf: int = 16):
+        """Like batch_collect but without building Python objects: (records [n_buf][max_cells] as a numpy structured
+        array with lcs_cell's layout, counts [n_buf])."""
+        rec = np.zeros((n_buf, max_cells_per_buf), capi.cell_dtype())
+        cnt = np.zeros(n_buf, np.int32)
+        rc = self._lib.lcs_batch_collect(self._h, rec.ctypes.data_as(C.POINTER(LcsCell)), max_cells_per_buf,
+                                         cnt.ctypes.data_as(C.POINTER(C.c_int)))
+        self._note_overflow(self._chk(rc, "lcs_batch_collect", allow_overflow=True), "lcs_batch_collect")
+        return rec, cnt
 
     def sync(self):
         self._chk(self._lib.lcs_sync(self._h), "lcs_sync")

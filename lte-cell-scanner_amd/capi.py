@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("LCS_AMD_LIB") or os.path.join(_HERE, "liblcs_amd.so")   # env: developer knob for A/B builds
+LIB_PATH = os.path.join(_HERE, "liblcs_amd.so")
 
 LCS_OK = 0
 FMT_C64, FMT_IQ_U8 = 0, 1
@@ -46,12 +46,20 @@ class LcsCell(C.Structure):
         return "LcsCell(" + ", ".join(f"{k}={v}" for k, v in self.as_dict().items()) + ")"
 
 
+def cell_dtype():
+    """numpy structured dtype with the layout of lcs_cell (zero-copy views of result arrays)."""
+    import numpy as np
+    m = {C.c_double: "<f8", C.c_int32: "<i4"}
+    return np.dtype([(n, m[t]) for n, t in LcsCell._fields_])
+
+
 EXPORTS = [
-    "lcs_create", "lcs_destroy", "lcs_last_error", "lcs_version", "lcs_cell_init", "lcs_set_xcorr_variant",
+    "lcs_create", "lcs_destroy", "lcs_last_error", "lcs_version", "lcs_cell_init", "lcs_set_max_cells_in_flight",
     "lcs_xcorr_pss", "lcs_peak_search", "lcs_sss_detect", "lcs_pss_sss_foe", "lcs_extract_tfg", "lcs_tfoec",
-    "lcs_decode_mib", "lcs_search_capbuf", "lcs_search_batch_dev", "lcs_batch_enqueue", "lcs_batch_collect",
+    "lcs_decode_mib", "lcs_search_capbuf", "lcs_search_batch_dev", "lcs_search_batch_host", "lcs_batch_enqueue",
+    "lcs_batch_collect", "lcs_batch_readback",
     "lcs_stream_open", "lcs_stream_push", "lcs_stream_collect", "lcs_stream_close",
-    "lcs_last_xcorr_ms", "lcs_stream", "lcs_sync", "lcs_table_pss_td", "lcs_table_pss_fd", "lcs_table_sss_fd",
+    "lcs_last_xcorr_ms", "lcs_last_xcorr_info", "lcs_stream", "lcs_sync", "lcs_table_pss_td", "lcs_table_pss_fd", "lcs_table_sss_fd",
     "lcs_table_lte_pn", "lcs_chi2cdf_inv",
 ]
 
@@ -84,7 +92,7 @@ def load() -> C.CDLL:
     L.lcs_version.restype = C.c_char_p
     L.lcs_cell_init.argtypes = [cp]
     L.lcs_cell_init.restype = None
-    L.lcs_set_xcorr_variant.argtypes = [vp, C.c_int]
+    L.lcs_set_max_cells_in_flight.argtypes = [vp, C.c_int]
     L.lcs_xcorr_pss.argtypes = [vp, dp, C.c_uint32, dp, C.c_uint16, C.c_uint8, C.c_double, C.c_double, C.c_double,
                                 dp, ip, fp, fp, dp, fp, dp, u16p, u16p]
     L.lcs_peak_search.argtypes = [vp, dp, ip, dp, dp, C.c_uint16, C.c_double, C.c_double, fp, C.c_uint8, cp, C.c_int,
@@ -99,6 +107,8 @@ def load() -> C.CDLL:
                                     cp, C.c_int, C.POINTER(C.c_int), cp, C.c_int, C.POINTER(C.c_int)]
     L.lcs_search_batch_dev.argtypes = [vp, vp, C.c_int, C.c_int, C.c_uint32, dp, C.c_uint16, dp, dp, C.c_double,
                                        C.c_int, cp, C.c_int, C.POINTER(C.c_int)]
+    L.lcs_search_batch_host.argtypes = L.lcs_search_batch_dev.argtypes
+    L.lcs_batch_readback.argtypes = [vp, C.c_int, fp, dp, ip, dp, dp]
     L.lcs_batch_enqueue.argtypes = [vp, vp, C.c_int, C.c_int, C.c_uint32, dp, C.c_uint16, dp, dp, C.c_double, C.c_int]
     L.lcs_batch_collect.argtypes = [vp, cp, C.c_int, C.POINTER(C.c_int)]
     L.lcs_stream_open.argtypes = [vp, C.c_int, C.c_uint32, C.c_double, C.c_double, C.c_double]
@@ -106,6 +116,7 @@ def load() -> C.CDLL:
     L.lcs_stream_collect.argtypes = [vp, cp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_float)]
     L.lcs_stream_close.argtypes = [vp]
     L.lcs_last_xcorr_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]
+    L.lcs_last_xcorr_info.argtypes = [vp, dp, C.POINTER(C.c_char_p)]
     L.lcs_stream.argtypes = [vp]
     L.lcs_stream.restype = vp
     L.lcs_sync.argtypes = [vp]

@@ -44,6 +44,10 @@ XcGeom make_geo(uint32_t n_cap, int n_f, int ds) {
 // Grow the workspace so that n_slots buffers of n_cap samples with n_f hypotheses fit.
 int ensure_ws(lcs_ctx *c, int n_slots, uint32_t n_cap, int n_f, bool debug) {
   if (n_slots <= c->cap_slots && n_cap <= c->cap_n_cap && n_f <= c->cap_n_f && (!debug || c->cap_debug)) return LCS_OK;
+  if (c->st_open) {     // the captured graph of the streaming mode holds the current buffers' addresses
+    c->err = "this call needs a larger workspace than the open stream was captured with: lcs_stream_close first";
+    return LCS_ERR_BAD_ARG;
+  }
   n_slots = std::max(n_slots, c->cap_slots);
   n_cap = std::max(n_cap, c->cap_n_cap);
   n_f = std::max(n_f, c->cap_n_f);
@@ -81,9 +85,6 @@ int ensure_ws(lcs_ctx *c, int n_slots, uint32_t n_cap, int n_f, bool debug) {
   if (c->tq) { (void)hipFree(c->tq); c->tq = nullptr; }
   if (c->tsc) { (void)hipFree(c->tsc); c->tsc = nullptr; }
   c->i8_ready = false;
-  if (c->capb) { (void)hipFree(c->capb); c->capb = nullptr; }
-  if (c->bt16) { (void)hipFree(c->bt16); c->bt16 = nullptr; }
-  c->bf16_ready = false;
   c->cap_slots = n_slots;
   c->cap_n_cap = n_cap;
   c->cap_n_f = n_f;
@@ -91,21 +92,10 @@ int ensure_ws(lcs_ctx *c, int n_slots, uint32_t n_cap, int n_f, bool debug) {
   return LCS_OK;
 }
 
-// Buffers of the bf16 correlation path (u8 sources), sized like the current workspace.
-int ensure_bf16(lcs_ctx *c) {
-  if (c->bf16_ready) return LCS_OK;
-  const size_t S = (size_t)c->cap_slots;
-  const int G = (3 * c->cap_n_f + LCS_TG - 1) / LCS_TG;
-  int rc;
-  if ((rc = dev_alloc(c, &c->capb, S * c->cap_n_cap))) return rc;
-  if ((rc = dev_alloc(c, &c->bt16, S * LCS_NW_MAX * G * (size_t)(LCS_BF_KB_MAX * 3 * 64)))) return rc;
-  c->bf16_ready = true;
-  return LCS_OK;
-}
-
 // Buffers of the int8 correlation path (u8 sources), sized like the current workspace.
 int ensure_i8(lcs_ctx *c) {
   if (c->i8_ready) return LCS_OK;
+  if (c->st_open) { c->err = "int8 buffers cannot be (re)allocated while a stream is open: lcs_stream_close first"; return LCS_ERR_BAD_ARG; }
   const size_t S = (size_t)c->cap_slots;
   const int G = (3 * c->cap_n_f + LCS_TG - 1) / LCS_TG;
   int rc;
@@ -196,20 +186,8 @@ int lcs_create(int device, lcs_ctx **out) {
   // used round-robin the tail of batch i is not starved by the correlation of batch i+1.
   int prio_least = 0, prio_greatest = 0;
   (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
-  if (getenv("LCS_NO_PRIO")) prio_least = prio_greatest = 0;   // measurement knob
   bool ok_streams = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_greatest) == hipSuccess;
-  if (const char *mw = getenv("LCS_MAX_WORK")) c->max_work = std::max(1, std::min(atoi(mw), (int)LCS_MAX_WORK));
-  const char *rsv = getenv("LCS_RESERVE_CUS");   // measurement knob: keep N CUs free of the correlation kernel
-  if (ok_streams && rsv && atoi(rsv) > 0) {
-    hipDeviceProp_t prop;
-    (void)hipGetDeviceProperties(&prop, device);
-    const int n_cu = prop.multiProcessorCount, keep = n_cu - atoi(rsv);
-    std::vector<uint32_t> mask((n_cu + 31) / 32, 0u);
-    for (int i = 0; i < keep; ++i) mask[i / 32] |= 1u << (i % 32);
-    ok_streams = hipExtStreamCreateWithCUMask(&c->stream_xc, (uint32_t)mask.size(), mask.data()) == hipSuccess;
-  } else if (ok_streams) {
-    ok_streams = hipStreamCreateWithPriority(&c->stream_xc, hipStreamNonBlocking, prio_least) == hipSuccess;
-  }
+  ok_streams = ok_streams && hipStreamCreateWithPriority(&c->stream_xc, hipStreamNonBlocking, prio_least) == hipSuccess;
   if (!ok_streams) { lcs_destroy(c); return LCS_ERR_HIP; }
   (void)hipEventCreate(&c->ev_xc0);
   (void)hipEventCreate(&c->ev_xc1);
@@ -265,7 +243,7 @@ void lcs_destroy(lcs_ctx *c) {
                   c->incoh, c->sref, c->pow_, c->work, c->spinc, c->zth, c->sp, c->frq, c->peaks, c->npeaks, c->xc,
                   c->work_items, c->n_work, c->tfg, c->tfg_comp, c->ce, c->tfg_ts, c->tfg_ts_comp, c->cell_scratch,
                   c->cells_out, c->d_pss_td, c->d_pss_fd, c->d_sss_fd, c->d_pbch_scr, c->d_derm_inv, c->d_dbg, c->pk_items, c->n_pk,
-                  c->sss_ws, c->d_pn_jump, c->capb, c->bt16, c->cap8, c->bt8, c->tq, c->tsc};
+                  c->sss_ws, c->d_pn_jump, c->cap8, c->bt8, c->tq, c->tsc, c->h2d};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   if (c->h_pinned) (void)hipHostFree(c->h_pinned);
   if (c->ev_xc0) (void)hipEventDestroy(c->ev_xc0);
@@ -279,9 +257,9 @@ void lcs_destroy(lcs_ctx *c) {
 
 const char *lcs_last_error(const lcs_ctx *c) { return c ? c->err.c_str() : "null context"; }
 
-int lcs_set_xcorr_variant(lcs_ctx *c, int variant) {
-  if (!c || variant < 0 || variant > 4) return LCS_ERR_BAD_ARG;
-  c->xcorr_variant = variant;
+int lcs_set_max_cells_in_flight(lcs_ctx *c, int n) {
+  if (!c || n < 1) return LCS_ERR_BAD_ARG;
+  c->max_work = std::min(n, (int)LCS_MAX_WORK);
   return LCS_OK;
 }
 
@@ -310,13 +288,12 @@ int lcs_xcorr_pss(lcs_ctx *c, const double *capbuf, uint32_t n_cap, const double
   SlotParams p{fc_req, fc_prog, fs_prog};
   HIPCHK(c, hipMemcpyAsync(c->cap64, capbuf, sizeof(double2) * n_cap, hipMemcpyHostToDevice, c->stream));
   c->cap64_valid = true;
-  c->use_bf16 = false;      // complex<double> input: fp32 correlation
-  c->use_i8 = false;
+  c->use_i8 = false;        // complex<double> input: fp32 correlation
   HIPCHK(c, hipMemcpyAsync(c->fset, f_search_set, sizeof(double) * n_f, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->params, &p, sizeof(p), hipMemcpyHostToDevice, c->stream));
   if ((rc = lcs_launch_ingest(c, nullptr, 2, 1, n_cap))) return rc;
   if ((rc = lcs_launch_xcorr(c, 1, geo, incoh != nullptr, false))) return rc;
-  if ((rc = lcs_launch_single_layout(c, geo, c->sref, 1))) return rc;
+  if ((rc = lcs_launch_single_layout(c, geo, 0, c->sref, 1))) return rc;
   const size_t NE = 3 * LCS_N_IDX;
   HIPCHK(c, hipMemcpyAsync(pow_, c->pow_, sizeof(double) * NE, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(frq, c->frq, sizeof(int) * NE, hipMemcpyDeviceToHost, c->stream));
@@ -356,7 +333,7 @@ int lcs_peak_search(lcs_ctx *c, const double *pow_, const int32_t *frq, const do
   HIPCHK(c, hipMemcpyAsync(c->sref, single, sizeof(float) * NE * n_f, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->params, &p, sizeof(p), hipMemcpyHostToDevice, c->stream));
   XcGeom geo = make_geo(153600, n_f, ds_comb_arm);
-  if ((rc = lcs_launch_single_layout(c, geo, c->sref, 0))) return rc;
+  if ((rc = lcs_launch_single_layout(c, geo, 0, c->sref, 0))) return rc;
   if ((rc = lcs_launch_peak_search(c, 1, geo, std::pow(10.0, -12.0 / 10.0), false))) return rc;
   std::vector<lcs_cell> tmp(LCS_MAXP);
   int n = 0;
@@ -394,16 +371,9 @@ int lcs_batch_enqueue(lcs_ctx *c, const void *d_capbufs, int fmt, int n_buf, uin
   HIPCHK(c, hipMemcpyAsync(c->params, hp, sizeof(SlotParams) * n_buf, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->fset, hf, sizeof(double) * n_f, hipMemcpyHostToDevice, c->stream));
   c->cap64_valid = false;
-  // u8 I/Q is exact in bf16: the correlation runs as three exact bf16 products per tap (pss_xcorr_bf16.hip)
-  static const bool no_bf16 = getenv("LCS_NO_BF16") != nullptr;   // measurement knob
-  c->use_bf16 = fmt == LCS_FMT_IQ_U8 && c->xcorr_variant == 0 && !no_bf16 && 2 * c->grid_max_k2 <= 16 * LCS_BF_KB_MAX;
-  // ... and exact in int8: the int8 three-digit kernel (pss_xcorr_i8.hip) is the fastest form; it needs
-  // 137 taps + window-start spread <= 160
-  static const bool no_i8 = getenv("LCS_NO_I8") != nullptr;        // measurement knob
-  c->use_i8 = fmt == LCS_FMT_IQ_U8 && c->xcorr_variant == 0 && !no_i8 && 2 * c->grid_max_k2 <= 32 * LCS_I8_KB;
-  if (c->xcorr_variant == 4) c->use_bf16 = fmt == LCS_FMT_IQ_U8 && 2 * c->grid_max_k2 <= 16 * LCS_BF_KB_MAX;   // variant 4: bf16 kernel
-  if (c->use_i8) c->use_bf16 = false;
-  if (c->use_bf16 && (rc = ensure_bf16(c))) return rc;
+  // u8 I/Q is exact in int8: the int8 three-digit kernel (pss_xcorr_i8.hip); it needs 137 taps + window-start
+  // spread <= 160 inside every 16-template group, sparser grids (and every other source) take the fp32 kernel
+  c->use_i8 = fmt == LCS_FMT_IQ_U8 && 2 * c->grid_max_k2 <= 32 * LCS_I8_KB;
   if (c->use_i8 && (rc = ensure_i8(c))) return rc;
   if ((rc = lcs_launch_ingest(c, d_capbufs, fmt, n_buf, n_cap))) return rc;
   if ((rc = lcs_launch_xcorr(c, n_buf, geo, false, true))) return rc;
@@ -433,8 +403,6 @@ int lcs_batch_enqueue(lcs_ctx *c, const void *d_capbufs, int fmt, int n_buf, uin
 int lcs_batch_collect(lcs_ctx *c, lcs_cell *cells, int max_cells_per_buf, int *n_cells) {
   if (!c || !n_cells || c->last_n_buf <= 0) return LCS_ERR_BAD_ARG;
   const int nb = c->last_n_buf;
-  static const bool spin = getenv("LCS_SPIN_WAIT") != nullptr;   // measurement knob
-  if (spin) { while (hipStreamQuery(c->stream) == hipErrorNotReady) {} }
   std::vector<lcs_cell> tmp((size_t)nb * LCS_MAXP);
   std::vector<int> cnt(nb);
   HIPCHK(c, hipMemcpyAsync(tmp.data(), c->peaks, sizeof(lcs_cell) * tmp.size(), hipMemcpyDeviceToHost, c->stream));
@@ -471,6 +439,47 @@ int lcs_search_batch_dev(lcs_ctx *c, const void *d_capbufs, int fmt, int n_buf, 
   return lcs_batch_collect(c, cells, max_cells_per_buf, n_cells);
 }
 
+// Host-buffer form of lcs_search_batch_dev: the buffers are copied into a device staging area owned by the
+// context (u8 I/Q: 307 KB per buffer instead of the 2.46 MB of complex<double>) and then take the same path.
+int lcs_search_batch_host(lcs_ctx *c, const void *h_capbufs, int fmt, int n_buf, uint32_t n_cap, const double *f_search_set,
+                          uint16_t n_f, const double *fc_requested, const double *fc_programmed, double fs_programmed,
+                          int stage_mask, lcs_cell *cells, int max_cells_per_buf, int *n_cells) {
+  if (!c) return LCS_ERR_BAD_ARG;
+  if (!h_capbufs || n_buf < 1 || (fmt != LCS_FMT_C64 && fmt != LCS_FMT_IQ_U8)) { c->err = "bad argument"; return LCS_ERR_BAD_ARG; }
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t bytes = (size_t)n_buf * n_cap * (fmt == LCS_FMT_IQ_U8 ? 2 : sizeof(float2));
+  if (bytes > c->h2d_bytes) {
+    if (c->st_open) { c->err = "lcs_stream_close first"; return LCS_ERR_BAD_ARG; }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->h2d) (void)hipFree(c->h2d);
+    c->h2d = nullptr; c->h2d_bytes = 0;
+    HIPCHK(c, hipMalloc(&c->h2d, bytes));
+    c->h2d_bytes = bytes;
+  }
+  HIPCHK(c, hipMemcpyAsync(c->h2d, h_capbufs, bytes, hipMemcpyHostToDevice, c->stream));
+  return lcs_search_batch_dev(c, c->h2d, fmt, n_buf, n_cap, f_search_set, n_f, fc_requested, fc_programmed, fs_programmed,
+                              stage_mask, cells, max_cells_per_buf, n_cells);
+}
+
+// Debug readback: the xcorr_pss outputs of buffer `buf` of the last batch, in the reference's layouts.
+int lcs_batch_readback(lcs_ctx *c, int buf, float *single, double *pow_, int32_t *frq, double *sp_incoherent, double *z_th1) {
+  if (!c || c->last_n_buf <= 0 || buf < 0 || buf >= c->last_n_buf) { if (c) c->err = "no such buffer in the last batch"; return LCS_ERR_BAD_ARG; }
+  HIPCHK(c, hipSetDevice(c->device));
+  const XcGeom &geo = c->last_geo;
+  const size_t NE = 3 * LCS_N_IDX;
+  int rc;
+  if (single) {
+    if ((rc = lcs_launch_single_layout(c, geo, buf, c->sref, 1))) return rc;
+    HIPCHK(c, hipMemcpyAsync(single, c->sref, sizeof(float) * NE * geo.n_f, hipMemcpyDeviceToHost, c->stream));
+  }
+  if (pow_) HIPCHK(c, hipMemcpyAsync(pow_, c->pow_ + (size_t)buf * NE, sizeof(double) * NE, hipMemcpyDeviceToHost, c->stream));
+  if (frq) HIPCHK(c, hipMemcpyAsync(frq, c->frq + (size_t)buf * NE, sizeof(int) * NE, hipMemcpyDeviceToHost, c->stream));
+  if (sp_incoherent) HIPCHK(c, hipMemcpyAsync(sp_incoherent, c->spinc + (size_t)buf * LCS_N_IDX, sizeof(double) * LCS_N_IDX, hipMemcpyDeviceToHost, c->stream));
+  if (z_th1) HIPCHK(c, hipMemcpyAsync(z_th1, c->zth + (size_t)buf * LCS_N_IDX, sizeof(double) * LCS_N_IDX, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return LCS_OK;
+}
+
 // ---------------------------------------------------------- single-cell stage entry points
 namespace {
 int upload_cap_and_params(lcs_ctx *c, const double *capbuf, uint32_t n_cap, double fc_req, double fc_prog, double fs_prog) {
@@ -478,10 +487,10 @@ int upload_cap_and_params(lcs_ctx *c, const double *capbuf, uint32_t n_cap, doub
   if (!capbuf || n_cap < 128) { c->err = "bad capture buffer"; return LCS_ERR_BAD_ARG; }
   HIPCHK(c, hipSetDevice(c->device));
   if ((rc = ensure_ws(c, 1, n_cap, std::max(1, c->cap_n_f), false))) return rc;
-  SlotParams p{fc_req, fc_prog, fs_prog};
+  c->h_params = SlotParams{fc_req, fc_prog, fs_prog};      // outlives the asynchronous copy (the callers synchronise later)
   HIPCHK(c, hipMemcpyAsync(c->cap64, capbuf, sizeof(double2) * n_cap, hipMemcpyHostToDevice, c->stream));
   c->cap64_valid = true;
-  HIPCHK(c, hipMemcpyAsync(c->params, &p, sizeof(p), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->params, &c->h_params, sizeof(SlotParams), hipMemcpyHostToDevice, c->stream));
   return LCS_OK;
 }
 int put_single_work_item(lcs_ctx *c, const lcs_cell *cell, int n_ofdm) {
@@ -627,8 +636,7 @@ int lcs_search_capbuf(lcs_ctx *c, const double *capbuf, uint32_t n_cap, const do
   SlotParams p{fc_req, fc_prog, fs_prog};
   HIPCHK(c, hipMemcpyAsync(c->cap64, capbuf, sizeof(double2) * n_cap, hipMemcpyHostToDevice, c->stream));
   c->cap64_valid = true;
-  c->use_bf16 = false;      // complex<double> input: fp32 correlation
-  c->use_i8 = false;
+  c->use_i8 = false;        // complex<double> input: fp32 correlation
   HIPCHK(c, hipMemcpyAsync(c->fset, f_search_set, sizeof(double) * n_f, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->params, &p, sizeof(p), hipMemcpyHostToDevice, c->stream));
   if ((rc = lcs_launch_ingest(c, nullptr, 2, 1, n_cap))) return rc;
@@ -679,8 +687,7 @@ int stream_chain(lcs_ctx *c) {
   StreamHost *h = c->st_host;
   const XcGeom geo = make_geo(c->st_n_cap, 1, 2);
   int rc;
-  c->use_i8 = c->st_fmt == LCS_FMT_IQ_U8 && c->xcorr_variant == 0 && getenv("LCS_NO_I8") == nullptr;
-  c->use_bf16 = !c->use_i8 && c->st_fmt == LCS_FMT_IQ_U8 && (c->xcorr_variant == 0 || c->xcorr_variant == 4) && getenv("LCS_NO_BF16") == nullptr;
+  c->use_i8 = c->st_fmt == LCS_FMT_IQ_U8;      // one hypothesis: no window-start spread, the int8 kernel always fits
   HIPCHK(c, hipMemcpyAsync(c->st_din, c->st_hin, c->st_in_bytes, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->params, &h->p, sizeof(SlotParams), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->fset, &h->f, sizeof(double), hipMemcpyHostToDevice, c->stream));
@@ -731,7 +738,7 @@ int lcs_stream_open(lcs_ctx *c, int fmt, uint32_t n_cap, double fc_requested, do
   HIPCHK(c, hipSetDevice(c->device));
   if ((rc = ensure_ws(c, 1, n_cap, 1, false))) return rc;
   if ((rc = ensure_percell(c))) return rc;
-  if (fmt == LCS_FMT_IQ_U8 && ((rc = ensure_bf16(c)) || (rc = ensure_i8(c)))) return rc;
+  if (fmt == LCS_FMT_IQ_U8 && (rc = ensure_i8(c))) return rc;
   c->st_fmt = fmt;
   c->st_n_cap = n_cap;
   c->st_in_bytes = (size_t)n_cap * (fmt == LCS_FMT_IQ_U8 ? 2 : sizeof(float2));
@@ -808,6 +815,13 @@ int lcs_last_xcorr_ms(lcs_ctx *c, float *ms, int *n_launches) {
   HIPCHK(c, hipEventSynchronize(c->ev_xc1));
   HIPCHK(c, hipEventElapsedTime(ms, c->ev_xc0, c->ev_xc1));
   if (n_launches) *n_launches = c->last_xc_launches;
+  return LCS_OK;
+}
+
+int lcs_last_xcorr_info(lcs_ctx *c, double *executed_ops, const char **kernel) {
+  if (!c) return LCS_ERR_BAD_ARG;
+  if (executed_ops) *executed_ops = c->last_xc_ops;
+  if (kernel) *kernel = c->last_xc_kernel;
   return LCS_OK;
 }
 

@@ -25,11 +25,7 @@
 // Every kernel other than the PSS correlation is small and latency-bound; in the pipelined chain it
 // shares CUs with the next batch's correlation waves.  Raising the wave priority lets the SIMD
 // arbiter issue these few waves ahead of the MFMA stream instead of round-robin behind 4-5 of them.
-#ifdef LCS_NO_TAIL_PRIO
-#define LCS_TAIL_PRIO() do { } while (0)
-#else
 #define LCS_TAIL_PRIO() __builtin_amdgcn_s_setprio(3)
-#endif
 #define LCS_TG 16            // templates per MFMA column group
 #define LCS_G_MAX ((3 * LCS_NF_MAX + LCS_TG - 1) / LCS_TG)
 #define LCS_KP2_MAX 128      // tap pairs per (window, group): 137 taps + up to 119 samples of spread
@@ -38,7 +34,6 @@
 #define LCS_PS 336           // LDS plane stride in floats: >= 64 + 2*KP2_MAX, == 16 (mod 32)
 #define LCS_MAXP 64          // peaks kept per capture buffer
 #define LCS_I8_KB 5          // 32-tap blocks of the int8 correlation kernel: taps + window-start spread <= 160
-#define LCS_BF_KB_MAX 10     // 16-tap blocks of the bf16 correlation kernel: taps + window-start spread <= 160
 #define LCS_MAX_WORK 512     // cells carried into the TFG/MIB stages per batch
 #define LCS_TFG_ROWS 854
 #define LCS_CELL_SCRATCH 4608 // doubles of per-cell scratch (RS table, shifts, noise powers, PBCH candidates)
@@ -99,7 +94,6 @@ struct lcs_ctx {
   hipStream_t stream_xc = nullptr;   // the PSS correlation kernel (lowest priority), see lcs_launch_xcorr
   hipEvent_t ev_pre = nullptr, ev_post = nullptr;
   std::string err;
-  int xcorr_variant = 0;
 
   // capacity the workspace is currently sized for
   int cap_slots = 0;
@@ -109,15 +103,11 @@ struct lcs_ctx {
 
   // device buffers
   float2 *cap32 = nullptr;
-  uint32_t *capb = nullptr;          // capture buffer as (re, im) bf16 pairs -- written for u8 I/Q sources, where it is exact
-  uint4 *bt16 = nullptr;             // bf16 three-term template operands (pss_xcorr_bf16.hip)
   uint16_t *cap8 = nullptr;          // capture buffer as (re, im) int8 pairs 127 - u8 (pss_xcorr_i8.hip)
   uint4 *bt8 = nullptr;              // int8 three-digit template operands
   double *tq = nullptr;              // per template: integer scale q
   float *tsc = nullptr;              // per template: 1 / (128 q)
   bool i8_ready = false, use_i8 = false;
-  bool bf16_ready = false;           // capb / bt16 allocated for the current workspace geometry
-  bool use_bf16 = false;             // this batch runs the bf16x3 correlation kernel
   int grid_max_k2 = 0;               // largest tap-pair count (137 taps + window-start spread) seen by validate_grid
   double2 *cap64 = nullptr;          // slot 0 only: fp64 copy for the host (complex<double>) entry points
   bool cap64_valid = false;
@@ -172,18 +162,23 @@ struct lcs_ctx {
   hipGraphExec_t st_exec = nullptr;
   hipEvent_t st_ev0 = nullptr, st_ev1 = nullptr;
   // host staging
+  SlotParams h_params{};             // source of asynchronous parameter uploads of the single-buffer entry points
   void *h_pinned = nullptr;
   size_t h_pinned_bytes = 0;
+  void *h2d = nullptr;               // device staging of lcs_search_batch_host
+  size_t h2d_bytes = 0;
 
   // last batch bookkeeping
   int last_n_buf = 0;
   int last_stage_mask = 0;
   bool needed_rows_only = false;     // fused chains: compute only the grid rows later stages read (tfg_mib.hip)
-  int max_work = LCS_MAX_WORK;       // cells per per-cell round (LCS_MAX_WORK; the LCS_MAX_WORK environment variable lowers it for tests)
+  int max_work = LCS_MAX_WORK;       // cells per per-cell round (lcs_set_max_cells_in_flight)
   int last_cell_rounds = 0;          // per-cell rounds launched for the last batch (LCS_MAX_WORK cells each)
   XcGeom last_geo{};
   hipEvent_t ev_xc0 = nullptr, ev_xc1 = nullptr;
   int last_xc_launches = 0;
+  double last_xc_ops = 0;            // matrix-core operations (2 x MACs) the correlation launches of the last batch executed
+  const char *last_xc_kernel = "";
 };
 
 #define HIPCHK(ctx, call)                                                        \
@@ -210,13 +205,11 @@ void pbch_deratematch_map(int n_e, uint8_t *out /*n_e*/);   // ref src/lte_lib.c
 // pss_xcorr.hip
 int lcs_launch_ingest(lcs_ctx *c, const void *d_src, int fmt, int n_buf, uint32_t n_cap);
 int lcs_launch_xcorr(lcs_ctx *c, int n_buf, const XcGeom &geo, bool want_incoh, bool time_it);
+int lcs_launch_single_layout(lcs_ctx *c, const XcGeom &geo, int slot, float *ref_layout, int to_ref);   // group-major <-> [t][idx][foi]
 // pss_xcorr_i8.hip
 int lcs_launch_fill_btab_i8(lcs_ctx *c, int n_buf, const XcGeom &geo);
 int lcs_launch_xcorr_i8(lcs_ctx *c, hipStream_t sxc, const XcGeom &geo, int slot0, int n_slots, int xcd_map);
-// pss_xcorr_bf16.hip
-int lcs_launch_fill_btab_bf16(lcs_ctx *c, int n_buf, const XcGeom &geo);
-int lcs_launch_xcorr_bf16(lcs_ctx *c, hipStream_t sxc, const XcGeom &geo, int slot0, int n_slots, int xcd_map);
-int lcs_launch_single_layout(lcs_ctx *c, const XcGeom &geo, float *ref_layout, int to_ref);   // group-major <-> [t][idx][foi]
+
 int lcs_launch_xc_debug(lcs_ctx *c, const XcGeom &geo);   // raw xc for slot 0 (debug output only)
 // peak_search.hip
 int lcs_launch_peak_search(lcs_ctx *c, int n_buf, const XcGeom &geo, double udb10_m12, bool fp32_exact);

@@ -13,17 +13,12 @@
 // delay is folded into the template ("B") table, which therefore holds zero-padded, shifted
 // copies of conj(fshift(pss_td))/137.  Raw xc never touches HBM.
 //
-// This file: ingest, tables, signal-power estimate, collapse, and the fp32 correlation kernels, used for
-// sources that are not exact in bfloat16 (complex<float> / complex<double> buffers); raw RTL-SDR u8 I/Q
-// takes the bf16 three-term kernel of pss_xcorr_bf16.hip.  The complex dot product is evaluated as the
-// real product  [xr -xi ; xi xr] x [tr ; ti]  with fp32 FMAs in tap order.  Three interchangeable
-// kernels compute the SAME fma chain:
-//   k_xcorr_mfma_blk : v_mfma_f32_16x16x4_f32 (exact fp32, k-ordered fma chain), 4-wave workgroups, A
-//                      operands are Toeplitz slices read straight from LDS planes, B operands (template
-//                      rows) stream through LDS -- the default;
-//   k_xcorr_mfma     : the same with one-wave workgroups and B rows from L2;
-//   k_xcorr_valu     : lane = output position, template taps broadcast through scalar loads.
-// Their outputs are bit-identical (tests/test_gpu_pss.py).
+// This file: ingest, tables, signal-power estimate, collapse, and the fp32 correlation kernel
+// k_xcorr_mfma_blk, used for sources that are not exact in int8 (complex<float> / complex<double> buffers);
+// raw RTL-SDR u8 I/Q takes the int8 three-digit kernel of pss_xcorr_i8.hip.  The complex dot product is
+// evaluated as the real product  [xr -xi ; xi xr] x [tr ; ti]  on v_mfma_f32_16x16x4_f32 (exact fp32, a
+// k-ordered fma chain): 4-wave workgroups, A operands are Toeplitz slices read straight from LDS planes, B
+// operands (template rows) stream through LDS.
 #include "lcs_internal.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -41,10 +36,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // fmt 2: complex<double> already copied into cap64 (host entry points, slot 0 only).
 // For fmt 0/1 the fp32 copy holds the samples exactly (u8/128 and float are both exact in fp32),
 // so no fp64 copy is written: the fp64 stages read cap32 and widen on the fly (cap_at()).
-// u8 samples are also exact in bf16 (8 significant bits): capb gets the (re, im) bf16 pair of every sample
-// for the bf16 correlation kernel (pss_xcorr_bf16.hip).
+// u8 samples are also exact in int8: cap8 gets the (re, im) int8 pair 127 - u8 of every sample for the int8
+// correlation kernel (pss_xcorr_i8.hip).
 __global__ void k_ingest(const void *__restrict__ src, int fmt, uint32_t n_cap, float2 *__restrict__ cap32,
-                         double2 *__restrict__ cap64, uint32_t *__restrict__ capb, uint16_t *__restrict__ cap8) {
+                         double2 *__restrict__ cap64, uint16_t *__restrict__ cap8) {
   LCS_TAIL_PRIO();
   const int slot = blockIdx.y;
   const size_t base = (size_t)slot * n_cap;
@@ -55,7 +50,6 @@ __global__ void k_ingest(const void *__restrict__ src, int fmt, uint32_t n_cap, 
       uchar2 q = ((const uchar2 *)src)[base + i];
       const double re = ((double)q.x - 127.0) / 128.0, im = ((double)q.y - 127.0) / 128.0;
       cap32[base + i] = make_float2((float)re, (float)im);
-      if (capb) capb[base + i] = (__float_as_uint((float)re) >> 16) | (__float_as_uint((float)im) & 0xffff0000u);
       if (cap8) cap8[base + i] = (uint16_t)(((127 - (int)q.x) & 255) | (((127 - (int)q.y) & 255) << 8));   // int8 pair 127 - u8
     } else {
       double2 v = cap64[base + i];
@@ -145,151 +139,14 @@ __global__ __launch_bounds__(256) void k_fill_btab(const float2 *__restrict__ tm
 // ---------------------------------------------------------------- K1: correlate+combine
 __device__ __forceinline__ float pow2sum(float re, float im) { return fmaf(re, re, im * im); }
 
-// Stage `sl` samples starting at lag L0 of this slot's capture buffer into the three LDS
-// planes: [0]=imag, [PS]=real, [2PS]=-imag.  Plane offsets are 0/16/0 (mod 32) banks so that
-// the MFMA A-operand reads (16 lanes from one plane, 16 from another) never collide.
-__device__ __forceinline__ void stage_write(float *buf, const float2 *pre, int sl, int lane) {
-#pragma unroll
-  for (int r = 0; r < 5; ++r) {
-    const int n = lane + 64 * r;
-    if (n < sl) {
-      buf[n] = pre[r].y;
-      buf[LCS_PS + n] = pre[r].x;
-      buf[2 * LCS_PS + n] = -pre[r].y;
-    }
-  }
-}
-__device__ __forceinline__ void stage_load(float2 *pre, const float2 *__restrict__ cap, uint32_t n_cap, int L0, int sl,
-                                           int lane) {
-#pragma unroll
-  for (int r = 0; r < 5; ++r) {
-    const int n = lane + 64 * r;
-    const uint32_t src = (uint32_t)(L0 + n);
-    pre[r] = (n < sl && src < n_cap) ? cap[src] : make_float2(0.f, 0.f);
-  }
-}
-
-// Block -> (idx tile, group, slot).  With xcd_map the 1-D grid is laid out so that hardware XCD x
-// (observed: workgroup b runs on XCD b % 8) walks slots x, x+8, ... one after the other: the
-// 2.9 MB template table and the 1.2 MB capture buffer of a slot then stay in that XCD's 4 MB L2
-// instead of every L2 seeing every slot.  Placement is a speed matter only.
-__device__ __forceinline__ bool decode_block(const XcGeom &geo, int slot0, int n_slots, int xcd_map, int &tile, int &g,
-                                             int &slot) {
-  const int per_slot = (LCS_N_IDX / LCS_LAG_TILE) * geo.G;
-  int q, s;
-  if (xcd_map) { s = blockIdx.x & 7; q = blockIdx.x >> 3; s += 8 * (q / per_slot); q = q % per_slot; }
-  else { s = blockIdx.x / per_slot; q = blockIdx.x % per_slot; }
-  if (s >= n_slots) return false;
-  slot = slot0 + s;
-  g = q / (LCS_N_IDX / LCS_LAG_TILE);
-  tile = q % (LCS_N_IDX / LCS_LAG_TILE);
-  return true;
-}
-
-__global__ __launch_bounds__(64) void k_xcorr_mfma(const float2 *__restrict__ cap32, const int *__restrict__ smin,
-                                                    const int *__restrict__ kp2, const float *__restrict__ btab,
-                                                    float *__restrict__ sg, XcGeom geo, int slot0, int n_slots,
-                                                    int xcd_map) {
-  const int lane = threadIdx.x;
-  int tile, g, slot;
-  if (!decode_block(geo, slot0, n_slots, xcd_map, tile, g, slot)) return;
-  const int idx0 = tile * LCS_LAG_TILE;
-  __shared__ float lds[2 * 3 * LCS_PS];
-  const float2 *cap = cap32 + (size_t)slot * geo.n_cap;
-  const int *smin_s = smin + (size_t)slot * NW * GM + g;
-  const int *kp2_s = kp2 + (size_t)slot * NW * GM + g;
-
-  // A-operand lane offsets for v_mfma_f32_16x16x4_f32: lane l supplies A[i=l&15][k=l>>4];
-  // k=0: xr(tap 2kk)  k=1: -xi(tap 2kk)  k=2: xr(tap 2kk+1)  k=3: -xi(tap 2kk+1)   (real part)
-  // k=0: xi           k=1:  xr           k=2: xi             k=3:  xr             (imag part)
-  const int odd = (lane >> 4) & 1;
-  const int a1_off = (odd ? 2 * LCS_PS : LCS_PS) + (lane & 15) + (lane >> 5);
-  const int a2_off = (odd ? LCS_PS : 0) + (lane & 15) + (lane >> 5);
-
-  f32x4 P[4];
-#pragma unroll
-  for (int mt = 0; mt < 4; ++mt) P[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  float2 pre[5];
-  stage_load(pre, cap, geo.n_cap, idx0 + smin_s[0], LCS_LAG_TILE + 2 * kp2_s[0], lane);
-
-  for (int w = 0; w < geo.n_comb; ++w) {
-    const int k2 = kp2_s[w * GM];
-    float *buf = lds + (w & 1) * 3 * LCS_PS;
-    stage_write(buf, pre, LCS_LAG_TILE + 2 * k2, lane);
-    __syncthreads();
-    if (w + 1 < geo.n_comb)
-      stage_load(pre, cap, geo.n_cap, idx0 + smin_s[(w + 1) * GM], LCS_LAG_TILE + 2 * kp2_s[(w + 1) * GM], lane);
-
-    f32x4 aR[4], aI[4];
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) { aR[mt] = (f32x4){0.f, 0.f, 0.f, 0.f}; aI[mt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-    const float *bp = btab + (((size_t)slot * geo.n_comb + w) * geo.G + g) * (size_t)(LCS_KP2_MAX * 64) + lane;
-    const float *a1p = buf + a1_off;
-    const float *a2p = buf + a2_off;
-    // B rows are prefetched one unrolled step ahead (k2 <= KP2_MAX - UNROLL, so the row
-    // block after the last one used is still inside this (window, group) slab).
-    float bnext[LCS_KP2_UNROLL];
-#pragma unroll
-    for (int u = 0; u < LCS_KP2_UNROLL; ++u) bnext[u] = bp[u * 64];
-    const int k2m = k2 & ~(LCS_KP2_UNROLL - 1);
-    int kk = 0;
-    for (; kk < k2m; kk += LCS_KP2_UNROLL) {
-      float b[LCS_KP2_UNROLL];
-#pragma unroll
-      for (int u = 0; u < LCS_KP2_UNROLL; ++u) b[u] = bnext[u];
-#pragma unroll
-      for (int u = 0; u < LCS_KP2_UNROLL; ++u) bnext[u] = bp[(kk + LCS_KP2_UNROLL + u) * 64];
-#pragma unroll
-      for (int u = 0; u < LCS_KP2_UNROLL; ++u) {
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-          const float a1 = a1p[mt * 16 + 2 * (kk + u)];
-          const float a2 = a2p[mt * 16 + 2 * (kk + u)];
-          aR[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b[u], aR[mt], 0, 0, 0);
-          aI[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b[u], aI[mt], 0, 0, 0);
-        }
-      }
-    }
-    // remaining (k2 mod 4) tap pairs: their B rows are already in bnext
-#pragma unroll
-    for (int u = 0; u < LCS_KP2_UNROLL - 1; ++u) {
-      if (kk + u < k2) {
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-          const float a1 = a1p[mt * 16 + 2 * (kk + u)];
-          const float a2 = a2p[mt * 16 + 2 * (kk + u)];
-          aR[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bnext[u], aR[mt], 0, 0, 0);
-          aI[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, bnext[u], aI[mt], 0, 0, 0);
-        }
-      }
-    }
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) P[mt][r] = P[mt][r] + pow2sum(aR[mt][r], aI[mt][r]);
-  }
-
-  // C/D layout of 16x16x4: col = lane&15 (template), row = 4*(lane>>4)+reg (lag within the 16-row tile)
-  {
-    const float ncomb = (float)geo.n_comb;
-    float *o = sg + (((size_t)slot * geo.G + g) * LCS_N_IDX) * LCS_TG + (lane & 15);
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int idx = idx0 + mt * 16 + 4 * (lane >> 4) + r;
-        o[(size_t)idx * LCS_TG] = __fdiv_rn(P[mt][r], ncomb);      // 16 lanes = one 64-byte row
-      }
-  }
-}
-
 // ---------------------------------------------------------------------------------------------
-// 4-wave variant: one 256-thread workgroup owns 4 adjacent lag tiles (256 output positions) of one
-// template group.  The capture window is staged once for the four waves, and the template rows
-// (B operands) go through LDS in double-buffered chunks of 32 tap pairs instead of being fetched
-// from L2 by every wave: 3.6x less L2->CU traffic, B-operand latency at LDS level.  One barrier
-// per chunk.  Same FMA chain as the 1-wave kernels, so results are bit-identical.
+// One 256-thread workgroup owns 4 adjacent lag tiles (256 output positions) of one template group.  The
+// capture window is staged once for the four waves, and the template rows (B operands) go through LDS in
+// double-buffered chunks of 32 tap pairs instead of being fetched from L2 by every wave (3.6x less L2->CU
+// traffic, B-operand latency at LDS level).  One barrier per chunk.  With xcd_map the 1-D grid is laid out so
+// that hardware XCD x (observed: workgroup b runs on XCD b % 8) walks slots x, x+8, ... one after the other:
+// the 2.9 MB template table and the 1.2 MB capture buffer of a slot then stay in that XCD's 4 MB L2 instead
+// of every L2 seeing every slot.  Placement is a speed matter only.
 // NWV waves per workgroup (NWV*64 output positions), BCH tap pairs per B chunk.
 template <int WPS, int NWV, int BCH>
 __global__ __launch_bounds__(NWV * 64, WPS) void k_xcorr_mfma_blk(const float2 *__restrict__ cap32, const int *__restrict__ smin,
@@ -418,61 +275,6 @@ __global__ __launch_bounds__(NWV * 64, WPS) void k_xcorr_mfma_blk(const float2 *
         o[(size_t)idx * LCS_TG] = __fdiv_rn(P[mt][r], ncomb);
       }
   }
-}
-
-__global__ __launch_bounds__(64) void k_xcorr_valu(const float2 *__restrict__ cap32, const int *__restrict__ smin,
-                                                    const int *__restrict__ kp2, const float *__restrict__ btab,
-                                                    float *__restrict__ sg, XcGeom geo, int slot0, int n_slots,
-                                                    int xcd_map) {
-  const int lane = threadIdx.x;
-  int tile, g, slot;
-  if (!decode_block(geo, slot0, n_slots, xcd_map, tile, g, slot)) return;
-  const int idx0 = tile * LCS_LAG_TILE;
-  __shared__ float lds[2 * 3 * LCS_PS];
-  const float2 *cap = cap32 + (size_t)slot * geo.n_cap;
-  const int *smin_s = smin + (size_t)slot * NW * GM + g;
-  const int *kp2_s = kp2 + (size_t)slot * NW * GM + g;
-
-  float P[LCS_TG];
-#pragma unroll
-  for (int j = 0; j < LCS_TG; ++j) P[j] = 0.f;
-  float2 pre[5];
-  stage_load(pre, cap, geo.n_cap, idx0 + smin_s[0], LCS_LAG_TILE + 2 * kp2_s[0], lane);
-
-  for (int w = 0; w < geo.n_comb; ++w) {
-    const int k2 = kp2_s[w * GM];
-    float *buf = lds + (w & 1) * 3 * LCS_PS;
-    stage_write(buf, pre, LCS_LAG_TILE + 2 * k2, lane);
-    __syncthreads();
-    if (w + 1 < geo.n_comb)
-      stage_load(pre, cap, geo.n_cap, idx0 + smin_s[(w + 1) * GM], LCS_LAG_TILE + 2 * kp2_s[(w + 1) * GM], lane);
-    float aR[LCS_TG], aI[LCS_TG];
-#pragma unroll
-    for (int j = 0; j < LCS_TG; ++j) { aR[j] = 0.f; aI[j] = 0.f; }
-    // wave-uniform pointer: the compiler turns these reads into scalar loads
-    const float *bt = btab + (((size_t)slot * geo.n_comb + w) * geo.G + g) * (size_t)(LCS_KP2_MAX * 64);
-    for (int tap = 0; tap < 2 * k2; ++tap) {
-      const float xi = buf[lane + tap];
-      const float xr = buf[LCS_PS + lane + tap];
-      const float nxi = -xi;
-      const float *row = bt + (tap >> 1) * 64 + (tap & 1) * 32;
-#pragma unroll
-      for (int j = 0; j < LCS_TG; ++j) {
-        const float tr = row[j], ti = row[16 + j];
-        aR[j] = fmaf(nxi, ti, fmaf(xr, tr, aR[j]));
-        aI[j] = fmaf(xr, ti, fmaf(xi, tr, aI[j]));
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < LCS_TG; ++j) P[j] = P[j] + pow2sum(aR[j], aI[j]);
-  }
-  const float ncomb = (float)geo.n_comb;
-  const int idx = idx0 + lane;
-  float4 *o = (float4 *)(sg + ((((size_t)slot * geo.G + g) * LCS_N_IDX) + idx) * LCS_TG);
-#pragma unroll
-  for (int j = 0; j < LCS_TG; j += 4)
-    o[j >> 2] = make_float4(__fdiv_rn(P[j], ncomb), __fdiv_rn(P[j + 1], ncomb), __fdiv_rn(P[j + 2], ncomb),
-                            __fdiv_rn(P[j + 3], ncomb));
 }
 
 // ------------------------------------------------------------------------- K2: sp_est
@@ -671,7 +473,7 @@ __global__ __launch_bounds__(256) void k_xc_debug(const double2 *__restrict__ ca
 int lcs_launch_ingest(lcs_ctx *c, const void *d_src, int fmt, int n_buf, uint32_t n_cap) {
   dim3 grid(128, n_buf);
   hipLaunchKernelGGL(k_ingest, grid, dim3(256), 0, c->stream, d_src, fmt, n_cap, c->cap32, c->cap64,
-                     (c->use_bf16 && fmt == LCS_FMT_IQ_U8) ? c->capb : nullptr, (c->use_i8 && fmt == LCS_FMT_IQ_U8) ? c->cap8 : nullptr);
+                     (c->use_i8 && fmt == LCS_FMT_IQ_U8) ? c->cap8 : nullptr);
   HIPCHK(c, hipGetLastError());
   return LCS_OK;
 }
@@ -682,7 +484,6 @@ int lcs_launch_ingest(lcs_ctx *c, const void *d_src, int fmt, int n_buf, uint32_
 // therefore chained through a per-device event, while everything else a context enqueues (the
 // latency-bound per-cell stages in particular) is free to overlap the next context's correlation.
 #include <mutex>
-#include <cstdlib>
 static std::mutex g_xc_mutex;
 static hipEvent_t g_xc_done[64] = {};
 
@@ -691,9 +492,6 @@ int lcs_launch_xcorr(lcs_ctx *c, int n_buf, const XcGeom &geo, bool want_incoh, 
                      c->start, c->smin, c->kp2, geo);
   if (c->use_i8) {
     int rc_ = lcs_launch_fill_btab_i8(c, n_buf, geo);
-    if (rc_) return rc_;
-  } else if (c->use_bf16) {
-    int rc_ = lcs_launch_fill_btab_bf16(c, n_buf, geo);
     if (rc_) return rc_;
   } else
     hipLaunchKernelGGL(k_fill_btab, dim3(8, geo.n_comb * geo.G, n_buf), dim3(256), 0, c->stream, c->tmpl, c->start,
@@ -709,22 +507,15 @@ int lcs_launch_xcorr(lcs_ctx *c, int n_buf, const XcGeom &geo, bool want_incoh, 
                      c->cap64_valid ? c->cap64 : nullptr, c->sp, geo.n_cap, a.n_comb_sp);
   hipLaunchKernelGGL(k_sp_fold, dim3((LCS_N_IDX + 255) / 256, n_buf), dim3(256), 0, c->stream, c->sp, c->spinc, c->zth, a);
 
-  const int per_slot = (LCS_N_IDX / LCS_LAG_TILE) * geo.G;
   // slots [0, n8) with the XCD-aware mapping, the remainder with the plain one
   const int n8 = (n_buf >= 8) ? (n_buf & ~7) : 0;
-  // main stream -> correlation stream hand-off (tables and fp32 buffer are ready)
-  static const bool single_env = getenv("LCS_SINGLE_STREAM") != nullptr;   // measurement knob
-  const bool single_stream = single_env || c->single_stream;   // streaming mode: one stream, no events (graph capture)
-  // Tuning knob: extra dynamic LDS per correlation workgroup lowers its residency (106 VGPRs already
-  // cap it at 4 workgroups per CU; 12288 -> 3 per CU, +1 % kernel time) to leave room for the small
-  // kernels of the neighbouring batches.  Measured: no net gain, so the default is 0.
-  static const int lds_pad = getenv("LCS_XC_LDS_PAD") ? atoi(getenv("LCS_XC_LDS_PAD")) : 0;
+  // main stream -> correlation stream hand-off (tables and capture buffer are ready); the streaming mode runs
+  // everything on one stream with no events, so that the chain can be captured as a graph
+  const bool single_stream = c->single_stream;
   hipStream_t sxc = single_stream ? c->stream : c->stream_xc;
   if (!single_stream) {
     HIPCHK(c, hipEventRecord(c->ev_pre, c->stream));
     HIPCHK(c, hipStreamWaitEvent(sxc, c->ev_pre, 0));
-  }
-  if (!c->single_stream) {
     std::lock_guard<std::mutex> lk(g_xc_mutex);
     hipEvent_t &ev = g_xc_done[c->device & 63];
     if (!ev) HIPCHK(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
@@ -732,39 +523,27 @@ int lcs_launch_xcorr(lcs_ctx *c, int n_buf, const XcGeom &geo, bool want_incoh, 
   }
   if (time_it) HIPCHK(c, hipEventRecord(c->ev_xc0, sxc));
   int launches = 0;
+  c->last_xc_ops = 0;
+  c->last_xc_kernel = "k_xcorr_mfma_blk<4,4,32>";
   for (int part = 0; part < 2; ++part) {
     const int s0 = part ? n8 : 0, ns = part ? n_buf - n8 : n8;
     if (ns <= 0) continue;
-#define XCB_LAUNCH(WPS_, NWV_, BCH_)                                                                              \
-  hipLaunchKernelGGL((k_xcorr_mfma_blk<WPS_, NWV_, BCH_>), dim3((unsigned)(((LCS_N_IDX + NWV_ * 64 - 1) / (NWV_ * 64)) * geo.G * ns)), \
-                     dim3(NWV_ * 64), lds_pad, sxc, c->cap32, c->smin, c->kp2, c->btab, c->single, geo, s0, ns, part ? 0 : 1)
-#define XC1_ARGS dim3((unsigned)(per_slot * ns)), dim3(64), lds_pad, sxc, c->cap32, c->smin, c->kp2, c->btab, c->single, geo, s0, ns, part ? 0 : 1
     if (c->use_i8) {                                                            // u8 sources: int8 three-digit kernel
       int rc_ = lcs_launch_xcorr_i8(c, sxc, geo, s0, ns, part ? 0 : 1);
       if (rc_) return rc_;
-      ++launches;
-      continue;
-    }
-    if (c->use_bf16) {                                                          // u8 sources: exact bf16 three-term kernel
-      int rc_ = lcs_launch_xcorr_bf16(c, sxc, geo, s0, ns, part ? 0 : 1);
-      if (rc_) return rc_;
-      ++launches;
-      continue;
-    }
-    switch (c->xcorr_variant) {
-      case 0: case 3: case 4: XCB_LAUNCH(4, 4, 32); break;                      // fp32: 4-wave workgroups, B through LDS
-      case 1: hipLaunchKernelGGL(k_xcorr_valu, XC1_ARGS); break;                // plain-VALU twin
-      case 2: hipLaunchKernelGGL(k_xcorr_mfma, XC1_ARGS); break;                // 1-wave workgroups, B from L2 (round-1 baseline)
-      default: XCB_LAUNCH(4, 4, 32); break;
+    } else {                                                                    // fp32: 4-wave workgroups, B through LDS
+      constexpr int NWV = 4;
+      hipLaunchKernelGGL((k_xcorr_mfma_blk<4, NWV, 32>), dim3((unsigned)(((LCS_N_IDX + NWV * 64 - 1) / (NWV * 64)) * geo.G * ns)),
+                         dim3(NWV * 64), 0, sxc, c->cap32, c->smin, c->kp2, c->btab, c->single, geo, s0, ns, part ? 0 : 1);
     }
     ++launches;
   }
   if (time_it) { HIPCHK(c, hipEventRecord(c->ev_xc1, sxc)); c->last_xc_launches = launches; }
-  if (!c->single_stream) {
-    std::lock_guard<std::mutex> lk(g_xc_mutex);
-    HIPCHK(c, hipEventRecord(g_xc_done[c->device & 63], sxc));
-  }
   if (!single_stream) {
+    {
+      std::lock_guard<std::mutex> lk(g_xc_mutex);
+      HIPCHK(c, hipEventRecord(g_xc_done[c->device & 63], sxc));
+    }
     HIPCHK(c, hipEventRecord(c->ev_post, sxc));
     HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_post, 0));
   }
@@ -774,8 +553,9 @@ int lcs_launch_xcorr(lcs_ctx *c, int n_buf, const XcGeom &geo, bool want_incoh, 
   return LCS_OK;
 }
 
-int lcs_launch_single_layout(lcs_ctx *c, const XcGeom &geo, float *ref_layout, int to_ref) {
-  hipLaunchKernelGGL(k_single_to_ref, dim3(256, 1), dim3(256), 0, c->stream, c->single, ref_layout, geo, to_ref);
+int lcs_launch_single_layout(lcs_ctx *c, const XcGeom &geo, int slot, float *ref_layout, int to_ref) {
+  float *sg = c->single + (size_t)slot * geo.G * LCS_N_IDX * LCS_TG;      // the kernel sees one slot
+  hipLaunchKernelGGL(k_single_to_ref, dim3(256, 1), dim3(256), 0, c->stream, sg, ref_layout, geo, to_ref);
   HIPCHK(c, hipGetLastError());
   return LCS_OK;
 }

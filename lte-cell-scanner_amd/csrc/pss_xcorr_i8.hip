@@ -23,12 +23,10 @@
 // and 0 share one (shifted left by 8 between the passes), so int -> float conversion happens twice per
 // output and window, not per digit.
 //
-// k_xcorr_i8x3 (default): B operands go global -> LDS by LDS-DMA (global_load_lds_dwordx4), one window ahead;
-// the operands of tap block e + 1 are read from LDS behind the first MFMA pair of block e; the digit passes walk
-// the tap blocks boustrophedon.  1.14 ms per 64-buffer launch.  k_xcorr_i8x3_rs: the first version (operands
-// staged through registers, LDS reads in front of each block), 1.22-1.23 ms; kept for A/B runs.
+// k_xcorr_i8x3: B operands go global -> LDS by LDS-DMA (global_load_lds_dwordx4), one window ahead; the
+// operands of tap block e + 1 are read from LDS behind the first MFMA pair of block e; the digit passes walk
+// the tap blocks boustrophedon.
 #include "lcs_internal.h"
-#include <cstring>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -145,195 +143,6 @@ __global__ __launch_bounds__(256) void k_fill_btab_i8(const float2 *__restrict__
 
 __device__ __forceinline__ float pow2sum_i8(float re, float im) { return fmaf(re, re, im * im); }
 
-// The whole operand set of a window (30 KB) goes through LDS once per workgroup and window, written together
-// with the capture samples before the window's single barrier: no global-load latency in the block loop and
-// few operand registers, which is what lets a wave hold 8 sub-tiles.  (Reading the operands straight from
-// L2/L1 instead needed a four-block-deep register prefetch and 6 sub-tiles per wave: 1.25 ms against 1.23 ms
-// alone, 35.8 k against 37.3 k buffers/s in the pipelined chain.)
-__global__ __launch_bounds__(256, 2) void k_xcorr_i8x3_rs(const uint16_t *__restrict__ cap8, const int *__restrict__ smin,
-                                                       const uint4 *__restrict__ bt8, const float *__restrict__ sc,
-                                                       float *__restrict__ sg, XcGeom geo, int slot0, int n_slots,
-                                                       int xcd_map) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int per_slot = I8_TILES * geo.G;
-  int q, sidx;
-  if (xcd_map) { sidx = blockIdx.x & 7; q = blockIdx.x >> 3; sidx += 8 * (q / per_slot); q = q % per_slot; }
-  else { sidx = blockIdx.x / per_slot; q = blockIdx.x % per_slot; }
-  if (sidx >= n_slots) return;
-  const int slot = slot0 + sidx, g = q / I8_TILES, idx0 = (q % I8_TILES) * I8_LAGS;
-  const int widx0 = idx0 + wave * (I8_MT * 16);
-
-  // two copies of the staged window (uint16 per sample): [0] natural, [1] shifted down by one sample
-  __shared__ uint32_t ldsA[2][2][I8_ACOPY];
-  constexpr int NBLK = 3 * I8_NKB;        // blocks per window in execution order: digit 2 (kb 0..4), digit 1, digit 0
-  constexpr int BW = NBLK * 2 * 64;       // uint4 per window: the whole operand set of one (window, group), 30 KB
-  __shared__ uint4 ldsB[2][BW];
-  const uint16_t *cap = cap8 + (size_t)slot * geo.n_cap;
-  const int *smin_s = smin + (size_t)slot * NW * GM + g;
-  const uint4 *bt_s = bt8 + ((size_t)slot * geo.n_comb * geo.G + g) * (size_t)(3 * I8_NKB * 2 * 64);
-  const size_t bt_wstride = (size_t)geo.G * (3 * I8_NKB * 2 * 64);
-  const float my_sc = sc[(size_t)slot * GM * LCS_TG + g * LCS_TG + (lane & 15)];
-  // first sample of this lane's operand s = 0; its parity picks the LDS copy, then dword index (p - par) / 2
-  const int p0 = wave * (I8_MT * 16) + (lane & 15) + 8 * (lane >> 4);
-  const int par = p0 & 1;
-  const int a_dw = (p0 - par) >> 1;
-
-  f32x4 P[I8_MT];
-#pragma unroll
-  for (int mt = 0; mt < I8_MT; ++mt) P[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  constexpr int ASTEPS = (I8_AW + 255) / 256;
-  uint32_t preA[ASTEPS];      // one sample (uint16) per entry
-#define I8_LOAD_A(W)                                                                   \
-  {                                                                                    \
-    const int L0_ = idx0 + smin_s[(W) * GM];                                           \
-    _Pragma("unroll") for (int r_ = 0; r_ < ASTEPS; ++r_) {                            \
-      const int n_ = tid + 256 * r_;                                                   \
-      const uint32_t s_ = (uint32_t)(L0_ + n_);                                        \
-      preA[r_] = (n_ < I8_AW && s_ < geo.n_cap) ? (uint32_t)cap[s_] : 0u;              \
-    }                                                                                  \
-  }
-  constexpr int BSTEPS = (BW + 255) / 256;
-  uint4 preB[BSTEPS];
-#define I8_LOAD_BW(W)                                                                  \
-  {                                                                                    \
-    const uint4 *src_ = bt_s + (size_t)(W) * bt_wstride;                               \
-    _Pragma("unroll") for (int r_ = 0; r_ < BSTEPS; ++r_)                              \
-      preB[r_] = (tid + 256 * r_ < BW) ? src_[tid + 256 * r_] : make_uint4(0u, 0u, 0u, 0u); \
-  }
-  I8_LOAD_A(0);
-  I8_LOAD_BW(0);
-  // table order is [digit][kb]; execution order is digit 2, 1, 0: block b -> table block (2 - b / NKB) * NKB + b % NKB
-#define I8_TBLK(b) ((2 - (b) / I8_NKB) * I8_NKB + (b) % I8_NKB)
-  for (int w = 0; w < geo.n_comb; ++w) {
-    const bool has_next = w + 1 < geo.n_comb;
-    uint16_t *nat = reinterpret_cast<uint16_t *>(ldsA[w & 1][0]);
-    uint16_t *shf = reinterpret_cast<uint16_t *>(ldsA[w & 1][1]);
-#pragma unroll
-    for (int r = 0; r < ASTEPS; ++r) {
-      const int n = tid + 256 * r;
-      if (n < I8_AW) { nat[n] = (uint16_t)preA[r]; if (n > 0) shf[n - 1] = (uint16_t)preA[r]; }
-    }
-#pragma unroll
-    for (int r = 0; r < BSTEPS; ++r)
-      if (tid + 256 * r < BW) ldsB[w & 1][tid + 256 * r] = preB[r];
-    if (has_next) { I8_LOAD_A(w + 1); I8_LOAD_BW(w + 1); }
-    __syncthreads();
-    const uint4 *bl = ldsB[w & 1] + lane;
-    const uint32_t *bufA = ldsA[w & 1][par] + a_dw;
-    // digit 2 accumulates into (tR, tI); digits 1 and 0 share one int32 accumulator: after the digit-1 pass it is
-    // shifted left by 8 and the digit-0 products are added on top (|S1| <= 274 * 128 * 128 = 4.5e6, so
-    // 256 S1 + S0 stays below 2^31): one int -> float conversion per digit group instead of per digit.
-    i32x4 tR[I8_MT], tI[I8_MT], aR[I8_MT], aI[I8_MT];
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-      i32x4 Aw[2 * I8_NKB + I8_MT - 1];
-#pragma unroll
-      for (int s = 0; s < I8_MT - 2; ++s) { const uint32_t *p_ = bufA + 8 * s; Aw[s] = (i32x4){(int)p_[0], (int)p_[1], (int)p_[2], (int)p_[3]}; }
-#pragma unroll
-      for (int kb = 0; kb < I8_NKB; ++kb) {
-        const int b = d * I8_NKB + kb;
-        i32x4 Bop[2];
-#pragma unroll
-        for (int op = 0; op < 2; ++op) { const uint4 t_ = bl[(I8_TBLK(b) * 2 + op) * 64]; Bop[op] = (i32x4){(int)t_.x, (int)t_.y, (int)t_.z, (int)t_.w}; }
-#pragma unroll
-        for (int s = 2 * kb + I8_MT - 2; s < 2 * kb + I8_MT; ++s) {
-          const uint32_t *p_ = bufA + 8 * s;
-          Aw[s] = (i32x4){(int)p_[0], (int)p_[1], (int)p_[2], (int)p_[3]};
-        }
-#pragma unroll
-        for (int mt = 0; mt < I8_MT; ++mt) {
-          if (d == 0) {
-            const i32x4 cr = (kb == 0) ? (i32x4){0, 0, 0, 0} : tR[mt];
-            const i32x4 ci = (kb == 0) ? (i32x4){0, 0, 0, 0} : tI[mt];
-            tR[mt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Aw[2 * kb + mt], Bop[0], cr, 0, 0, 0);
-            tI[mt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Aw[2 * kb + mt], Bop[1], ci, 0, 0, 0);
-          } else {
-            const i32x4 cr = (d == 1 && kb == 0) ? (i32x4){0, 0, 0, 0} : aR[mt];
-            const i32x4 ci = (d == 1 && kb == 0) ? (i32x4){0, 0, 0, 0} : aI[mt];
-            aR[mt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Aw[2 * kb + mt], Bop[0], cr, 0, 0, 0);
-            aI[mt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Aw[2 * kb + mt], Bop[1], ci, 0, 0, 0);
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      if (d == 1) {
-#pragma unroll
-        for (int mt = 0; mt < I8_MT; ++mt) { aR[mt] = aR[mt] << 8; aI[mt] = aI[mt] << 8; }
-      }
-    }
-#pragma unroll
-    for (int mt = 0; mt < I8_MT; ++mt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {     // power of the integer correlation S2 * 65536 + (256 S1 + S0); scaled by 1 / (128 q)^2 at the end
-        const float xr = fmaf((float)tR[mt][r], 65536.f, (float)aR[mt][r]);
-        const float xi = fmaf((float)tI[mt][r], 65536.f, (float)aI[mt][r]);
-        P[mt][r] = P[mt][r] + pow2sum_i8(xr, xi);
-      }
-  }
-#undef I8_LOAD_A
-#undef I8_LOAD_BW
-#undef I8_TBLK
-  const float ncomb = (float)geo.n_comb;
-  float *o = sg + (((size_t)slot * geo.G + g) * LCS_N_IDX) * LCS_TG + (lane & 15);
-#pragma unroll
-  for (int mt = 0; mt < I8_MT; ++mt)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int idx = widx0 + mt * 16 + 4 * (lane >> 4) + r;
-      if (idx < LCS_N_IDX) o[(size_t)idx * LCS_TG] = __fdiv_rn(P[mt][r] * (my_sc * my_sc), ncomb);
-    }
-}
-
-// Compact operand source for the gathering kernel: per (slot, 16-template group) the digit pairs of every
-// template column as plain tap sequences, dt8[slot][g][copy 2][digit 3][op 2][n 16][I8_DT_COL dwords].  Dword i
-// of a column holds taps (2 i - 24 + copy, 2 i - 23 + copy) as byte pairs (op 0: (tr, -ti), op 1: (ti, tr)),
-// zero outside the 137 taps: a window's B operand of lane (n, kg), tap block kb is the 4 dwords starting at
-// 16 kb + 4 kg + 12 - (delta + par) / 2 of copy par = delta & 1 -- the per-window delay is applied by the
-// address, so nothing per window is ever tabulated (71 KB per (slot, group) instead of 450 KB).
-#define I8_DT_COL 93                                      // odd dword stride per column
-#define I8_DT_DW (2 * 6 * 16 * I8_DT_COL)
-__global__ __launch_bounds__(256) void k_fill_dtab_i8(const float2 *__restrict__ tmpl, const double *__restrict__ tq,
-                                                      uint32_t *__restrict__ dt8, XcGeom geo) {
-  LCS_TAIL_PRIO();
-  const int g = blockIdx.x, slot = blockIdx.y;
-  uint32_t *out = dt8 + ((size_t)slot * geo.G + g) * I8_DT_DW;
-  for (int e = threadIdx.x; e < 2 * 16 * I8_DT_COL; e += 256) {
-    const int cp = e / (16 * I8_DT_COL), n = (e / I8_DT_COL) % 16, i = e % I8_DT_COL;
-    const int c = g * LCS_TG + n;
-    int v[2][4];      // [op][byte]: op 0 (tr0, -ti0, tr1, -ti1), op 1 (ti0, tr0, ti1, tr1)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) { v[0][b] = 0; v[1][b] = 0; }
-    if (c < geo.n_tmpl) {
-      const int foi = c / 3, t = c % 3;
-      const double q = tq[(size_t)slot * GM * LCS_TG + c];
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int tap = 2 * i + h - 24 + cp;
-        if (tap >= 0 && tap < 137) {
-          const float2 T = tmpl[(((size_t)slot * NFM + foi) * 3 + t) * 137 + tap];
-          const int tr = (int)rint((double)T.x * q), ti = (int)rint((double)T.y * q);
-          v[0][2 * h] = tr; v[0][2 * h + 1] = -ti;
-          v[1][2 * h] = ti; v[1][2 * h + 1] = tr;
-        }
-      }
-    }
-#pragma unroll
-    for (int op = 0; op < 2; ++op) {
-      uint32_t pk[3] = {0u, 0u, 0u};
-#pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        int d0, d1, d2;
-        digits3(v[op][b], d0, d1, d2);
-        pk[0] |= (uint32_t)(d0 & 255) << (8 * b);
-        pk[1] |= (uint32_t)(d1 & 255) << (8 * b);
-        pk[2] |= (uint32_t)(d2 & 255) << (8 * b);
-      }
-#pragma unroll
-      for (int dg = 0; dg < 3; ++dg) out[(((size_t)cp * 6 + dg * 2 + op) * 16 + n) * I8_DT_COL + i] = pk[dg];
-    }
-  }
-}
-
 // The default kernel.  The window's B operands are copied global -> LDS by the LDS-DMA path (global_load_lds_dwordx4:
 // no staging registers, no ds_write pass), issued one window ahead right behind the barrier; the registers that
 // frees pay for a one-block-deep operand prefetch: the B operands and the two new A operands of tap block e + 1
@@ -344,11 +153,8 @@ __global__ __launch_bounds__(256) void k_fill_dtab_i8(const float2 *__restrict__
 // after window 0 1.083; without the barrier 1.118; with 10 instead of 15 tap blocks 0.847 -- i.e. 0.059 ms per
 // tap block against 0.045 at the nominal int8 MFMA rate (the 16x16x64 micro-benchmark reaches 78 % of nominal:
 // the blocks run at the instruction's own ceiling) plus ~0.26 ms of per-window costs.
-// GD = true: the B operands are gathered by the DMA from the compact digit table (k_fill_dtab_i8), each lane's source
-// address carrying its column's delay; GD = false: copied from the per-window table of k_fill_btab_i8.
-template <bool GD>
 __global__ __launch_bounds__(256, 2) void k_xcorr_i8x3(const uint16_t *__restrict__ cap8, const int *__restrict__ smin,
-                                                          const int *__restrict__ start, const uint4 *__restrict__ bt8,
+                                                          const uint4 *__restrict__ bt8,
                                                           const float *__restrict__ sc, float *__restrict__ sg, XcGeom geo,
                                                           int slot0, int n_slots, int xcd_map) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -369,12 +175,6 @@ __global__ __launch_bounds__(256, 2) void k_xcorr_i8x3(const uint16_t *__restric
   const int *smin_s = smin + (size_t)slot * NW * GM + g;
   const uint4 *bt_s = bt8 + ((size_t)slot * geo.n_comb * geo.G + g) * (size_t)BW + lane;
   const size_t bt_wstride = (size_t)geo.G * BW;
-  // gather mode: this lane's column in the compact table and its per-window delay
-  const uint32_t *dt_s = reinterpret_cast<const uint32_t *>(bt8) + ((size_t)slot * geo.G + g) * I8_DT_DW +
-                         (lane & 15) * I8_DT_COL + 4 * (lane >> 4) + 12;
-  const int my_foi = min(g * LCS_TG + (lane & 15), geo.n_tmpl - 1) / 3;
-  const int *start_s = start + (size_t)slot * NW * NFM + my_foi;
-  int dl_next = 0;
   const float my_sc = sc[(size_t)slot * GM * LCS_TG + g * LCS_TG + (lane & 15)];
   const int p0 = wave * (I8_MT * 16) + (lane & 15) + 8 * (lane >> 4);
   const int par = p0 & 1;
@@ -397,26 +197,12 @@ __global__ __launch_bounds__(256, 2) void k_xcorr_i8x3(const uint16_t *__restric
 #define I8_DMA_B(W)                                                                                          \
   {                                                                                                          \
     uint4 *dst_ = ldsB[(W) & 1];                                                                             \
-    if constexpr (GD) {                                                                                      \
-      const int par_ = dl_next & 1;                                                                          \
-      const uint32_t *src_ = dt_s + par_ * (6 * 16 * I8_DT_COL) - ((dl_next + par_) >> 1);                   \
-      _Pragma("unroll") for (int c_ = 0; c_ < (NCH + 3) / 4; ++c_) {                                         \
-        const int ch_ = wave + 4 * c_;        /* chunk = (digit, kb, op) in table order */                   \
-        const int dgop_ = (ch_ / (2 * I8_NKB)) * 2 + (ch_ & 1), kb_ = (ch_ >> 1) % I8_NKB;                   \
-        if (ch_ < NCH)                                                                                       \
-          __builtin_amdgcn_global_load_lds(                                                                  \
-              (const __attribute__((address_space(1))) void *)(src_ + dgop_ * (16 * I8_DT_COL) + 16 * kb_),  \
-              (__attribute__((address_space(3))) void *)(dst_ + ch_ * 64), 16, 0, 0);                        \
-      }                                                                                                      \
-      dl_next = ((W) + 1 < geo.n_comb) ? start_s[((W) + 1) * NFM] - smin_s[((W) + 1) * GM] : 0;              \
-    } else {                                                                                                 \
-      const uint4 *src_ = bt_s + (size_t)(W) * bt_wstride;                                                   \
-      _Pragma("unroll") for (int c_ = 0; c_ < (NCH + 3) / 4; ++c_) {                                         \
-        const int ch_ = wave + 4 * c_;                                                                       \
-        if (ch_ < NCH)                                                                                       \
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src_ + ch_ * 64), \
-                                           (__attribute__((address_space(3))) void *)(dst_ + ch_ * 64), 16, 0, 0); \
-      }                                                                                                      \
+    const uint4 *src_ = bt_s + (size_t)(W) * bt_wstride;                                                     \
+    _Pragma("unroll") for (int c_ = 0; c_ < (NCH + 3) / 4; ++c_) {                                           \
+      const int ch_ = wave + 4 * c_;          /* chunk = (digit, kb, op) in table order */                   \
+      if (ch_ < NCH)                                                                                         \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src_ + ch_ * 64),  \
+                                         (__attribute__((address_space(3))) void *)(dst_ + ch_ * 64), 16, 0, 0); \
     }                                                                                                        \
   }
 #define I8_RD_A(S) { const uint32_t *p_ = bufA + 8 * (S); Aw[S] = (i32x4){(int)p_[0], (int)p_[1], (int)p_[2], (int)p_[3]}; }
@@ -430,7 +216,6 @@ __global__ __launch_bounds__(256, 2) void k_xcorr_i8x3(const uint16_t *__restric
     }                                                                                                        \
   }
   I8_LOAD_A(0);
-  if constexpr (GD) dl_next = start_s[0] - smin_s[0];
   I8_DMA_B(0);
   for (int w = 0; w < geo.n_comb; ++w) {
     const bool has_next = w + 1 < geo.n_comb;
@@ -522,39 +307,20 @@ __global__ __launch_bounds__(256, 2) void k_xcorr_i8x3(const uint16_t *__restric
     }
 }
 
-// LCS_I8_KERNEL (developer knob): unset = k_xcorr_i8x3<false> (LDS-DMA staging + operand prefetch), "gather" =
-// k_xcorr_i8x3<true> (same, operands gathered from the compact digit table), "rs" = the register-staged k_xcorr_i8x3_rs.
-static int i8_kernel_mode() {
-  static const int mode = [] {
-    const char *e = getenv("LCS_I8_KERNEL");
-    if (!e) return 1;
-    return !strcmp(e, "gather") ? 2 : !strcmp(e, "rs") ? 0 : 1;
-  }();
-  return mode;
-}
 int lcs_launch_fill_btab_i8(lcs_ctx *c, int n_buf, const XcGeom &geo) {
   hipLaunchKernelGGL(k_i8_scales, dim3(n_buf), dim3(256), 0, c->stream, c->tmpl, c->tq, c->tsc, geo);
-  if (i8_kernel_mode() == 2)
-    hipLaunchKernelGGL(k_fill_dtab_i8, dim3(geo.G, n_buf), dim3(256), 0, c->stream, c->tmpl, c->tq,
-                       reinterpret_cast<uint32_t *>(c->bt8), geo);
-  else
-    hipLaunchKernelGGL(k_fill_btab_i8, dim3(2, geo.n_comb * geo.G, n_buf), dim3(256), 0, c->stream, c->tmpl, c->start, c->smin,
-                       c->tq, c->bt8, geo);
+  hipLaunchKernelGGL(k_fill_btab_i8, dim3(2, geo.n_comb * geo.G, n_buf), dim3(256), 0, c->stream, c->tmpl, c->start, c->smin,
+                     c->tq, c->bt8, geo);
   HIPCHK(c, hipGetLastError());
   return LCS_OK;
 }
 int lcs_launch_xcorr_i8(lcs_ctx *c, hipStream_t sxc, const XcGeom &geo, int slot0, int n_slots, int xcd_map) {
   const unsigned grid = (unsigned)(I8_TILES * geo.G * n_slots);
-  const int mode = i8_kernel_mode();
-  if (mode == 2)
-    hipLaunchKernelGGL(k_xcorr_i8x3<true>, dim3(grid), dim3(256), 0, sxc, c->cap8, c->smin, c->start, c->bt8, c->tsc, c->single,
-                       geo, slot0, n_slots, xcd_map);
-  else if (mode == 1)
-    hipLaunchKernelGGL(k_xcorr_i8x3<false>, dim3(grid), dim3(256), 0, sxc, c->cap8, c->smin, c->start, c->bt8, c->tsc, c->single,
-                       geo, slot0, n_slots, xcd_map);
-  else
-    hipLaunchKernelGGL(k_xcorr_i8x3_rs, dim3(grid), dim3(256), 0, sxc, c->cap8, c->smin, c->bt8, c->tsc, c->single, geo, slot0,
-                       n_slots, xcd_map);
+  hipLaunchKernelGGL(k_xcorr_i8x3, dim3(grid), dim3(256), 0, sxc, c->cap8, c->smin, c->bt8, c->tsc, c->single, geo, slot0,
+                     n_slots, xcd_map);
   HIPCHK(c, hipGetLastError());
+  // executed work: per wave and window 3 digits x I8_NKB tap blocks x I8_MT sub-tiles x (re, im) MFMAs of 16x16x64 MACs
+  c->last_xc_ops += (double)grid * 4 * geo.n_comb * (3.0 * I8_NKB * I8_MT * 2) * (2.0 * 16 * 16 * 64);
+  c->last_xc_kernel = "k_xcorr_i8x3";
   return LCS_OK;
 }

@@ -41,17 +41,12 @@ def test_power_of_two_scaling_is_exact(S, pkg, synth_buf):
     assert np.array_equal(b["sp_incoherent"], 4.0 * a["sp_incoherent"])
 
 
-def test_full_grid_mfma_equals_valu_and_is_repeatable(S, pkg, synth_buf):
+def test_full_grid_is_repeatable(S, pkg, synth_buf):
     f = f_search_set_for(FC, 100)
     cap = pkg.synth.iq_u8_to_complex(synth_buf)
-    S.set_xcorr_variant(0)
     a = S.xcorr_pss(cap, f, 2, FC, FC, FS, want_incoherent=False)
     a2 = S.xcorr_pss(cap, f, 2, FC, FC, FS, want_incoherent=False)
-    S.set_xcorr_variant(1)
-    b = S.xcorr_pss(cap, f, 2, FC, FC, FS, want_incoherent=False)
-    S.set_xcorr_variant(0)
-    assert np.array_equal(a["single"], a2["single"]) and np.array_equal(a["pow"], a2["pow"])
-    assert np.array_equal(a["single"], b["single"]) and np.array_equal(a["frq"], b["frq"])
+    assert np.array_equal(a["single"], a2["single"]) and np.array_equal(a["pow"], a2["pow"]) and np.array_equal(a["frq"], a2["frq"])
 
 
 def test_batch_slots_are_independent_and_placement_invariant(S, pkg, synth_buf):
@@ -77,83 +72,35 @@ def test_batch_slots_are_independent_and_placement_invariant(S, pkg, synth_buf):
     assert sorted(c.n_id_cell() for c in ref[0]) == [125, 300] and [c.n_id_cell() for c in ref[1]] == [277, 271] and ref[2] == []
 
 
-def test_bf16_three_term_correlation_matches_fp32(S, pkg, synth_buf):
-    """u8 I/Q sources take the int8 three-digit MFMA kernel (variant 0: 24-bit integer templates, exact
-    integer accumulation) or the bf16 three-term kernel (variant 4: exact products, fp32 accumulation);
-    variant 3 forces the fp32 kernel on the same device-resident bytes.  Every identity must agree and the
-    correlation powers must agree far inside the 1e-5 parity bar."""
+def test_u8_and_complex_float_sources_agree(S, pkg, synth_buf):
+    """u8 I/Q sources take the int8 three-digit MFMA kernel (24-bit integer templates, exact integer accumulation),
+    the same samples handed over as complex<float> take the fp32 MFMA kernel.  Every identity must agree and the
+    correlation powers must agree far inside the 1e-5 parity bar -- on 9 slots (8 XCD-mapped + 1), through the
+    whole chain, and on a 10 kHz grid whose window starts spread over many samples inside one template group."""
     import torch
     f = f_search_set_for(FC, 100)
     g = golden("capbuf_0000")["iq_u8"]
     rng = np.random.default_rng(3)
     noise = np.clip(np.rint(rng.normal(127.0, 20.0, g.size)), 0, 255).astype(np.uint8)
-    bufs = [synth_buf, g, noise, np.roll(g, 2 * 4321), np.roll(synth_buf, 2 * 777), g, noise, synth_buf, g]   # 8 XCD-mapped + 1
-    d = torch.from_numpy(np.stack(bufs)).cuda()
-    out = {}
-    for v in (0, 4, 3):
-        S.set_xcorr_variant(v)
-        out[v] = S.search_batch(d.data_ptr(), pkg.FMT_IQ_U8, len(bufs), 153600, f, FC, FC, FS, pkg.STAGE_PSS, max_cells_per_buf=64)
-    S.set_xcorr_variant(0)
-    n = 0
-    for v in (0, 4):
-        for a, b in zip(out[v], out[3]):
-            assert [(c.n_id_2, c.ind, c.freq) for c in a] == [(c.n_id_2, c.ind, c.freq) for c in b], v
-            for ca, cb in zip(a, b):
-                assert abs(ca.pss_pow - cb.pss_pow) <= 2e-6 * cb.pss_pow, v
-                n += 1
-    assert n >= 20
-    # and the decoded cells of the full chain are the same records except for that last-digit power
-    full = {}
-    for v in (0, 4, 3):
-        S.set_xcorr_variant(v)
-        full[v] = S.search_batch(d.data_ptr(), pkg.FMT_IQ_U8, len(bufs), 153600, f, FC, FC, FS, pkg.STAGE_FULL)
-    S.set_xcorr_variant(0)
-    strip = lambda c: tuple(v for k, v in c.as_dict().items() if k != "pss_pow")
-    assert [[strip(c) for c in r] for r in full[0]] == [[strip(c) for c in r] for r in full[3]]
-    assert [[strip(c) for c in r] for r in full[4]] == [[strip(c) for c in r] for r in full[3]]
-    assert [c.n_id_cell() for c in full[0][1]] == [277, 271]
-    # a 10 kHz grid spreads the window starts of one template group over more than 7 samples: more than 9
-    # 16-tap blocks per window, which takes the looping bf16 kernel instead of the unrolled one (the int8
-    # kernel's five 32-tap blocks still hold it)
-    f10 = np.arange(-10, 11) * 10e3
-    wide = {}
-    for v in (0, 4, 3):
-        S.set_xcorr_variant(v)
-        wide[v] = S.search_batch(d.data_ptr(), pkg.FMT_IQ_U8, len(bufs), 153600, f10, FC, FC, FS, pkg.STAGE_PSS, max_cells_per_buf=64)
-    S.set_xcorr_variant(0)
-    m = 0
-    for v in (0, 4):
-        for a, b in zip(wide[v], wide[3]):
-            assert [(c.n_id_2, c.ind, c.freq) for c in a] == [(c.n_id_2, c.ind, c.freq) for c in b], v
-            assert all(abs(ca.pss_pow - cb.pss_pow) <= 2e-6 * cb.pss_pow for ca, cb in zip(a, b)), v
-            m += len(a)
-    assert m >= 16
+    bufs = [synth_buf, g, noise, np.roll(g, 2 * 4321), np.roll(synth_buf, 2 * 777), g, noise, synth_buf, g]
+    d8 = torch.from_numpy(np.stack(bufs)).cuda()
+    d32 = torch.from_numpy(np.stack([iq_u8_to_capbuf(b).astype(np.complex64) for b in bufs])).cuda()
+    strip = lambda c: tuple(None if v != v else v for k, v in c.as_dict().items() if k != "pss_pow")   # NaN -> None
+    for grid, stage, floor in ((f, pkg.STAGE_PSS, 20), (f, pkg.STAGE_FULL, 8), (np.arange(-10, 11) * 10e3, pkg.STAGE_PSS, 16)):
+        a = S.search_batch(d8.data_ptr(), pkg.FMT_IQ_U8, len(bufs), 153600, grid, FC, FC, FS, stage, max_cells_per_buf=64)
+        b = S.search_batch(d32.data_ptr(), pkg.FMT_C64, len(bufs), 153600, grid, FC, FC, FS, stage, max_cells_per_buf=64)
+        n = 0
+        for ra, rb in zip(a, b):
+            assert [strip(c) for c in ra] == [strip(c) for c in rb]
+            assert all(abs(ca.pss_pow - cb.pss_pow) <= 2e-6 * cb.pss_pow for ca, cb in zip(ra, rb))
+            n += len(ra)
+        assert n >= floor
+        if stage == pkg.STAGE_FULL:
+            assert [c.n_id_cell() for c in a[1]] == [277, 271]
 
 
-def test_bf16_kernel_short_buffers_and_single_hypothesis(S, pkg, synth_buf):
-    """The bf16 kernel on shapes away from the benchmark's: 135360-sample buffers (14 combining windows, the
-    Matlab/test_xcorr_pss.mat length), a single frequency hypothesis (one template group, 3 of its 16 columns
-    used) and a 3-entry grid -- always against the fp32 kernel on the same device-resident bytes."""
-    import torch
-    g = golden("capbuf_0000")["iq_u8"]
-    n_short = 135360
-    bufs = np.stack([g[:2 * n_short], synth_buf[:2 * n_short], np.roll(g, 2 * 999)[:2 * n_short]])
-    d = torch.from_numpy(np.ascontiguousarray(bufs)).cuda()
-    for f in (np.array([35e3]), np.array([30e3, 35e3, 40e3]), f_search_set_for(FC, 100)):
-        out = {}
-        for v in (0, 4, 3):
-            S.set_xcorr_variant(v)
-            out[v] = S.search_batch(d.data_ptr(), pkg.FMT_IQ_U8, 3, n_short, f, FC, FC, FS, pkg.STAGE_PSS, max_cells_per_buf=64)
-        S.set_xcorr_variant(0)
-        for v in (0, 4):
-            for a, b in zip(out[v], out[3]):
-                assert [(c.n_id_2, c.ind, c.freq) for c in a] == [(c.n_id_2, c.ind, c.freq) for c in b], v
-                assert all(abs(ca.pss_pow - cb.pss_pow) <= 2e-6 * cb.pss_pow for ca, cb in zip(a, b)), v
-        assert len(out[0][0]) >= 1
-
-
-def test_per_cell_rounds_and_overflow(S, pkg, synth_buf, monkeypatch):
-    """The per-cell stages take LCS_MAX_WORK cells per round.  With the round size forced down to 3
+def test_per_cell_rounds_and_overflow(S, pkg, synth_buf):
+    """The per-cell stages hold lcs_set_max_cells_in_flight cells per round.  With the round size forced down to 3
     cells, a 19-buffer batch (38 cells past SSS) is decoded in 13 non-empty rounds (plus empty ones)
     and must return exactly what one big round returns."""
     import torch
@@ -164,8 +111,8 @@ def test_per_cell_rounds_and_overflow(S, pkg, synth_buf, monkeypatch):
     d = torch.from_numpy(np.stack([src[i] for i in order])).cuda()
     ref = S.search_batch(d.data_ptr(), pkg.FMT_IQ_U8, len(order), 153600, f, FC, FC, FS, pkg.STAGE_FULL)
     key = lambda c: tuple(c.as_dict().values())
-    monkeypatch.setenv("LCS_MAX_WORK", "3")
     with pkg.Searcher(0) as S3:
+        S3.set_max_cells_in_flight(3)
         res = S3.search_batch(d.data_ptr(), pkg.FMT_IQ_U8, len(order), 153600, f, FC, FC, FS, pkg.STAGE_FULL)
     assert [[key(c) for c in r] for r in res] == [[key(c) for c in r] for r in ref]
     assert sum(len(r) for r in ref) == 2 * len(order)
@@ -189,47 +136,3 @@ def test_ragged_buffer_lengths(S, pkg, synth_buf):
         assert r["n_comb_xc"] == ro["n_comb_xc"] == (n - 236) // 9600 and r["n_comb_sp"] == ro["n_comb_sp"]
         assert np.array_equal(r["frq"], ro["frq"])
         assert (np.abs(r["pow"] - ro["pow"]) / ro["pow"]).max() < 1e-5
-
-
-_MODE_SCRIPT = r"""
-import json, os, sys
-import numpy as np
-sys.path.insert(0, sys.argv[1])
-from conftest import golden, f_search_set_for, load_pkg
-import torch
-pkg = load_pkg()
-g = golden("capbuf_0000")["iq_u8"]
-bufs = [g, np.roll(g, 2 * 4321), g[::-1].copy()]
-d = torch.from_numpy(np.stack(bufs)).cuda()
-out = []
-with pkg.Searcher(0) as S:
-    for f in (f_search_set_for(739e6, 100), np.arange(-10, 11) * 10e3):
-        r = S.search_batch(d.data_ptr(), pkg.FMT_IQ_U8, len(bufs), 153600, f, 739e6, 739e6, 1.92e6, pkg.STAGE_PSS, max_cells_per_buf=64)
-        out.append([[(c.n_id_2, c.ind, c.freq, float(c.pss_pow).hex()) for c in b] for b in r])
-print("RESULT" + json.dumps(out))
-"""
-
-
-def test_int8_kernel_modes_are_bit_identical():
-    """The int8 correlation is exact integer arithmetic with one fixed recombination, so the default kernel
-    (LDS-DMA staging, prefetched operands), the gathering variant (operands fetched from the compact digit
-    table through per-lane DMA addresses) and the first, register-staged kernel must return the same bits --
-    on the bench grid and on a 10 kHz grid whose window starts spread over many samples."""
-    import json
-    import os
-    import subprocess
-    import sys
-    here = os.path.dirname(os.path.abspath(__file__))
-    res = {}
-    for mode in ("", "gather", "rs"):
-        env = dict(os.environ)
-        env.pop("LCS_I8_KERNEL", None)
-        if mode:
-            env["LCS_I8_KERNEL"] = mode
-        p = subprocess.run([sys.executable, "-c", _MODE_SCRIPT, here], env=env, capture_output=True, text=True, timeout=300)
-        assert p.returncode == 0, p.stderr[-2000:]
-        line = [l for l in p.stdout.splitlines() if l.startswith("RESULT")][-1]
-        res[mode] = json.loads(line[len("RESULT"):])
-    assert sum(len(b) for grid in res[""] for b in grid) >= 10
-    assert res["gather"] == res[""]
-    assert res["rs"] == res[""]

@@ -89,40 +89,3 @@ def test_quantised_template_correlation_is_within_the_parity_bar():
     assert rel.max() < 1e-6, rel.max()
     big = exact > 1e-3 * exact.max()
     assert (np.abs(got[big].astype(np.float64) - exact[big]) / exact[big]).max() < 1e-5
-
-
-def test_gather_addressing_reproduces_the_per_window_operand_table():
-    """The gathering variant of the kernel (LCS_I8_KERNEL=gather) fetches a window's B operands from a compact
-    per-(buffer, group) table of plain tap sequences, the column delay carried by the address; the default kernel
-    copies them from a per-window table.  numpy restatement of both layouts (k_fill_btab_i8, k_fill_dtab_i8 +
-    the I8_DMA_B address arithmetic): for every delay the kernel admits they must hold the same bytes."""
-    rng = np.random.default_rng(5)
-    NKB, COL = 5, 93
-    # integer "digit" bytes per (op, column, tap, component): any injective filling will do
-    vals = rng.integers(-128, 128, (2, 16, 137, 2)).astype(np.int8)
-
-    def tap_pair(op, n, tap):
-        return vals[op, n, tap] if 0 <= tap < 137 else np.zeros(2, np.int8)
-
-    # compact table: [copy][op][n][dword i] -> 4 bytes = taps (2i - 24 + copy, 2i - 23 + copy) x (first, second)
-    compact = np.zeros((2, 2, 16, COL, 4), np.int8)
-    for cp in range(2):
-        for op in range(2):
-            for n in range(16):
-                for i in range(COL):
-                    for h in range(2):
-                        compact[cp, op, n, i, 2 * h:2 * h + 2] = tap_pair(op, n, 2 * i + h - 24 + cp)
-    for trial in range(40):
-        delta = rng.integers(0, 24, 16) if trial else np.full(16, 23)
-        for kb in range(NKB):
-            for lane in range(64):
-                n, kg = lane & 15, lane >> 4
-                for op in range(2):
-                    # per-window table entry (k_fill_btab_i8): bytes (2m, 2m+1) = pair of tap 32 kb + 8 kg + m - delta
-                    want = np.concatenate([tap_pair(op, n, 32 * kb + 8 * kg + m - delta[n]) for m in range(8)])
-                    # gather (I8_DMA_B): copy = delta & 1, dwords 16 kb + 4 kg + 12 - (delta + copy) / 2 .. + 3
-                    par = int(delta[n]) & 1
-                    i0 = 16 * kb + 4 * kg + 12 - ((int(delta[n]) + par) >> 1)
-                    assert 0 <= i0 and i0 + 3 < COL
-                    got = compact[par, op, n, i0:i0 + 4].reshape(-1)
-                    assert np.array_equal(got, want), (trial, kb, lane, op)
