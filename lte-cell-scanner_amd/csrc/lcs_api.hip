@@ -81,6 +81,7 @@ int ensure_ws(lcs_ctx *c, int n_slots, uint32_t n_cap, int n_f, bool debug) {
   }
 #undef A
   if (c->cap8) { (void)hipFree(c->cap8); c->cap8 = nullptr; }
+  if (c->cap8s) { (void)hipFree(c->cap8s); c->cap8s = nullptr; }
   if (c->bt8) { (void)hipFree(c->bt8); c->bt8 = nullptr; }
   if (c->tq) { (void)hipFree(c->tq); c->tq = nullptr; }
   if (c->tsc) { (void)hipFree(c->tsc); c->tsc = nullptr; }
@@ -99,7 +100,8 @@ int ensure_i8(lcs_ctx *c) {
   const size_t S = (size_t)c->cap_slots;
   const int G = (3 * c->cap_n_f + LCS_TG - 1) / LCS_TG;
   int rc;
-  if ((rc = dev_alloc(c, &c->cap8, S * c->cap_n_cap))) return rc;
+  const size_t n8 = S * lcs_cap8_stride(c->cap_n_cap);
+  if ((rc = dev_alloc(c, &c->cap8, n8)) || (rc = dev_alloc(c, &c->cap8s, n8))) return rc;
   if ((rc = dev_alloc(c, &c->bt8, S * LCS_NW_MAX * G * (size_t)(3 * LCS_I8_KB * 2 * 64)))) return rc;
   if ((rc = dev_alloc(c, &c->tq, S * LCS_G_MAX * LCS_TG))) return rc;
   if ((rc = dev_alloc(c, &c->tsc, S * LCS_G_MAX * LCS_TG))) return rc;
@@ -243,7 +245,7 @@ void lcs_destroy(lcs_ctx *c) {
                   c->incoh, c->sref, c->pow_, c->work, c->spinc, c->zth, c->sp, c->frq, c->peaks, c->npeaks, c->xc,
                   c->work_items, c->n_work, c->tfg, c->tfg_comp, c->ce, c->tfg_ts, c->tfg_ts_comp, c->cell_scratch,
                   c->cells_out, c->d_pss_td, c->d_pss_fd, c->d_sss_fd, c->d_pbch_scr, c->d_derm_inv, c->d_dbg, c->pk_items, c->n_pk,
-                  c->sss_ws, c->d_pn_jump, c->cap8, c->bt8, c->tq, c->tsc, c->h2d};
+                  c->sss_ws, c->d_pn_jump, c->cap8, c->cap8s, c->bt8, c->tq, c->tsc, c->h2d};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   if (c->h_pinned) (void)hipHostFree(c->h_pinned);
   if (c->ev_xc0) (void)hipEventDestroy(c->ev_xc0);
@@ -374,7 +376,7 @@ int lcs_batch_enqueue(lcs_ctx *c, const void *d_capbufs, int fmt, int n_buf, uin
   // u8 I/Q is exact in int8: the int8 three-digit kernel (pss_xcorr_i8.hip); it needs 137 taps + window-start
   // spread <= 160 inside every 16-template group, sparser grids (and every other source) take the fp32 kernel
   c->use_i8 = fmt == LCS_FMT_IQ_U8 && 2 * c->grid_max_k2 <= 32 * LCS_I8_KB;
-  if (c->use_i8 && (rc = ensure_i8(c))) return rc;
+  if (fmt == LCS_FMT_IQ_U8 && (rc = ensure_i8(c))) return rc;      // int8 copies: every u8 source (the fp64 stages read them)
   if ((rc = lcs_launch_ingest(c, d_capbufs, fmt, n_buf, n_cap))) return rc;
   if ((rc = lcs_launch_xcorr(c, n_buf, geo, false, true))) return rc;
   if ((rc = lcs_launch_peak_search(c, n_buf, geo, std::pow(10.0, -12.0 / 10.0), true))) return rc;

@@ -26,6 +26,15 @@
 // shares CUs with the next batch's correlation waves.  Raising the wave priority lets the SIMD
 // arbiter issue these few waves ahead of the MFMA stream instead of round-robin behind 4-5 of them.
 #define LCS_TAIL_PRIO() __builtin_amdgcn_s_setprio(3)
+// The wide, memory-bound kernels of the chain loop over their jobs with at most LCS_GRID_CAP workgroups per launch.
+// A correlation grid keeps two workgroups resident on every CU; a small kernel's workgroup can only start where one
+// of them retires, and the high-priority queue wins every freed slot: a kernel with thousands of short workgroups
+// takes the chip over for its duration.  Measured (tools/microbench notes in DESIGN.md): capping the grids lowers the
+// correlation's slowdown under load but stretches the chain more than it gains (caps of 64/128/256 workgroups:
+// 28.3 k / 37.0 k / 39.9 k buffers/s against 40.6 k uncapped), so the cap is set where it never binds.
+#ifndef LCS_GRID_CAP
+#define LCS_GRID_CAP (1 << 20)
+#endif
 #define LCS_TG 16            // templates per MFMA column group
 #define LCS_G_MAX ((3 * LCS_NF_MAX + LCS_TG - 1) / LCS_TG)
 #define LCS_KP2_MAX 128      // tap pairs per (window, group): 137 taps + up to 119 samples of spread
@@ -51,21 +60,39 @@ struct XcGeom {
   int ds;       // ds_comb_arm
 };
 
-// The capture buffer as the fp64 stages see it: the fp64 copy when one exists (host entry points
-// hand over complex<double>), otherwise the fp32 copy widened on the fly (exact for u8 / float input).
+// int8 copies of a u8 capture buffer: slot stride in samples (a multiple of 8, so that every slot starts 16-byte
+// aligned) with LCS_I8_PAD zero samples behind the data -- the correlation kernel's LDS-DMA reads run past n_cap
+#define LCS_I8_PAD 1024
+__host__ __device__ static inline size_t lcs_cap8_stride(uint32_t n_cap) { return (((size_t)n_cap + 7) & ~(size_t)7) + LCS_I8_PAD; }
+
+// The capture buffers as the fp64 stages see them (exactly one pointer is set): the fp64 copy when a host entry
+// point handed over complex<double>; the int8 pairs 127 - u8 of an RTL-SDR source ((u8-127)/128 = -a/128, exact);
+// otherwise the fp32 copy widened on the fly (exact for float input).
+struct CapSrc {
+  const float2 *c32;
+  const double2 *c64;
+  const uint16_t *c8;
+  uint32_t n_cap;
+};
 struct CapView {
   const float2 *c32;
   const double2 *c64;
+  const uint16_t *c8;
 };
 #ifdef __HIPCC__
-__device__ __forceinline__ CapView cap_view(const float2 *cap32, const double2 *cap64, int slot, uint32_t n_cap) {
+__device__ __forceinline__ CapView cap_view(const CapSrc &s, int slot) {
   CapView v;
-  v.c32 = cap32 + (size_t)slot * n_cap;
-  v.c64 = cap64 ? cap64 + (size_t)slot * n_cap : nullptr;
+  v.c32 = s.c32 ? s.c32 + (size_t)slot * s.n_cap : nullptr;
+  v.c64 = s.c64 ? s.c64 + (size_t)slot * s.n_cap : nullptr;
+  v.c8 = s.c8 ? s.c8 + (size_t)slot * lcs_cap8_stride(s.n_cap) : nullptr;
   return v;
 }
 __device__ __forceinline__ double2 cap_at(const CapView &v, size_t i) {
   if (v.c64) return v.c64[i];
+  if (v.c8) {
+    const uint32_t p = v.c8[i];
+    return make_double2(-(double)(int)(int8_t)(p & 255u) / 128.0, -(double)(int)(int8_t)(p >> 8) / 128.0);
+  }
   const float2 f = v.c32[i];
   return make_double2((double)f.x, (double)f.y);
 }
@@ -103,11 +130,13 @@ struct lcs_ctx {
 
   // device buffers
   float2 *cap32 = nullptr;
-  uint16_t *cap8 = nullptr;          // capture buffer as (re, im) int8 pairs 127 - u8 (pss_xcorr_i8.hip)
+  uint16_t *cap8 = nullptr;          // capture buffers as (re, im) int8 pairs 127 - u8, slot stride lcs_cap8_stride (pss_xcorr_i8.hip)
+  uint16_t *cap8s = nullptr;         // the same shifted down by one sample: cap8s[i] = cap8[i + 1]
   uint4 *bt8 = nullptr;              // int8 three-digit template operands
   double *tq = nullptr;              // per template: integer scale q
   float *tsc = nullptr;              // per template: 1 / (128 q)
   bool i8_ready = false, use_i8 = false;
+  bool src_u8 = false;               // the resident buffers came from a u8 source: the fp64 stages read cap8
   int grid_max_k2 = 0;               // largest tap-pair count (137 taps + window-start spread) seen by validate_grid
   double2 *cap64 = nullptr;          // slot 0 only: fp64 copy for the host (complex<double>) entry points
   bool cap64_valid = false;
@@ -203,6 +232,7 @@ void pbch_deratematch_map(int n_e, uint8_t *out /*n_e*/);   // ref src/lte_lib.c
 
 // ---- kernel launchers (one per .hip file) -------------------------------------------
 // pss_xcorr.hip
+CapSrc lcs_cap_src(const lcs_ctx *c, uint32_t n_cap);   // which copy of the capture buffers the fp64 stages read
 int lcs_launch_ingest(lcs_ctx *c, const void *d_src, int fmt, int n_buf, uint32_t n_cap);
 int lcs_launch_xcorr(lcs_ctx *c, int n_buf, const XcGeom &geo, bool want_incoh, bool time_it);
 int lcs_launch_single_layout(lcs_ctx *c, const XcGeom &geo, int slot, float *ref_layout, int to_ref);   // group-major <-> [t][idx][foi]

@@ -20,6 +20,7 @@
 // k-ordered fma chain): 4-wave workgroups, A operands are Toeplitz slices read straight from LDS planes, B
 // operands (template rows) stream through LDS.
 #include "lcs_internal.h"
+#include <algorithm>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -32,28 +33,71 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define GM LCS_G_MAX
 
 // ------------------------------------------------------------------------------ ingest
-// fmt 0: complex<float> in HBM; fmt 1: RTL-SDR u8 I/Q, (x-127)/128 (ref src/capbuf.cpp:172-181);
-// fmt 2: complex<double> already copied into cap64 (host entry points, slot 0 only).
-// For fmt 0/1 the fp32 copy holds the samples exactly (u8/128 and float are both exact in fp32),
-// so no fp64 copy is written: the fp64 stages read cap32 and widen on the fly (cap_at()).
-// u8 samples are also exact in int8: cap8 gets the (re, im) int8 pair 127 - u8 of every sample for the int8
-// correlation kernel (pss_xcorr_i8.hip).
+// fmt 0: complex<float> in HBM -> cap32; fmt 2: complex<double> already copied into cap64 (host entry points, slot 0
+// only) -> cap32 for the fp32 correlation.  For fmt 0 the fp32 copy holds the samples exactly, so no fp64 copy is
+// written: the fp64 stages read cap32 and widen on the fly (cap_at()).
 __global__ void k_ingest(const void *__restrict__ src, int fmt, uint32_t n_cap, float2 *__restrict__ cap32,
-                         double2 *__restrict__ cap64, uint16_t *__restrict__ cap8) {
+                         const double2 *__restrict__ cap64) {
   LCS_TAIL_PRIO();
   const int slot = blockIdx.y;
   const size_t base = (size_t)slot * n_cap;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_cap; i += gridDim.x * blockDim.x) {
     if (fmt == LCS_FMT_C64) {
       cap32[base + i] = ((const float2 *)src)[base + i];
-    } else if (fmt == LCS_FMT_IQ_U8) {
-      uchar2 q = ((const uchar2 *)src)[base + i];
-      const double re = ((double)q.x - 127.0) / 128.0, im = ((double)q.y - 127.0) / 128.0;
-      cap32[base + i] = make_float2((float)re, (float)im);
-      if (cap8) cap8[base + i] = (uint16_t)(((127 - (int)q.x) & 255) | (((127 - (int)q.y) & 255) << 8));   // int8 pair 127 - u8
     } else {
-      double2 v = cap64[base + i];
+      const double2 v = cap64[base + i];
       cap32[base + i] = make_float2((float)v.x, (float)v.y);
+    }
+  }
+}
+
+// fmt 1: RTL-SDR u8 I/Q, (x-127)/128 (ref src/capbuf.cpp:172-181).  A sample is the integer 127 - u8 (all 256 codes
+// fit an int8; the sign is absorbed where the value is used) scaled by -1/128: cap8 gets the (re, im) int8 pair of
+// every sample, cap8s the same sequence shifted down by one sample (the correlation kernel's LDS-DMA copies dwords,
+// i.e. sample PAIRS: with both phases in memory every window start is dword aligned), both zero-padded behind
+// n_cap up to the slot stride.  Nothing wider is stored: the int8 kernel multiplies these bytes, the fp64 stages
+// widen them on the fly (cap_at()), and when the frequency grid is too sparse for the int8 kernel the fp32 copy
+// cap32 is written as well.  One thread = 8 samples = one 16-byte load and two 16-byte stores.
+__global__ __launch_bounds__(256) void k_ingest_u8(const uint8_t *__restrict__ src, uint32_t n_cap, uint16_t *__restrict__ cap8,
+                                                   uint16_t *__restrict__ cap8s, float2 *__restrict__ cap32) {
+  LCS_TAIL_PRIO();
+  const int slot = blockIdx.y;
+  const size_t stride = lcs_cap8_stride(n_cap);
+  const uint8_t *in = src + (size_t)slot * n_cap * 2;
+  const bool aligned = (((size_t)in) & 15) == 0;
+  for (size_t i0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 8; i0 < stride; i0 += (size_t)gridDim.x * blockDim.x * 8) {
+    uint32_t v[9];      // packed int8 pairs of samples i0 .. i0 + 8
+    if (aligned && i0 + 8 <= n_cap) {
+      const uint4 q = *reinterpret_cast<const uint4 *>(in + 2 * i0);
+      const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const uint32_t pr = (w[j >> 1] >> (16 * (j & 1))) & 0xffffu;      // (re, im) bytes of sample i0 + j
+        v[j] = ((127u - (pr & 255u)) & 255u) | (((127u - (pr >> 8)) & 255u) << 8);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        uint32_t x = 0;
+        if (i0 + j < n_cap) { const uchar2 q = reinterpret_cast<const uchar2 *>(in)[i0 + j]; x = ((127u - q.x) & 255u) | (((127u - q.y) & 255u) << 8); }
+        v[j] = x;
+      }
+    }
+    {
+      uint32_t x = 0;
+      if (i0 + 8 < n_cap) { const uchar2 q = reinterpret_cast<const uchar2 *>(in)[i0 + 8]; x = ((127u - q.x) & 255u) | (((127u - q.y) & 255u) << 8); }
+      v[8] = x;
+    }
+    uint4 a, b;
+    a.x = v[0] | (v[1] << 16); a.y = v[2] | (v[3] << 16); a.z = v[4] | (v[5] << 16); a.w = v[6] | (v[7] << 16);
+    b.x = v[1] | (v[2] << 16); b.y = v[3] | (v[4] << 16); b.z = v[5] | (v[6] << 16); b.w = v[7] | (v[8] << 16);
+    *reinterpret_cast<uint4 *>(cap8 + (size_t)slot * stride + i0) = a;
+    *reinterpret_cast<uint4 *>(cap8s + (size_t)slot * stride + i0) = b;
+    if (cap32) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (i0 + j < n_cap)
+          cap32[(size_t)slot * n_cap + i0 + j] = make_float2(-(float)(int)(int8_t)(v[j] & 255u) / 128.f, -(float)(int)(int8_t)(v[j] >> 8) / 128.f);
     }
   }
 }
@@ -111,15 +155,16 @@ __global__ __launch_bounds__(256) void k_prep_tables(const SlotParams *__restric
 // template c = 16g + j delayed by start[w][foi(c)] - smin[w][g]; zero outside the 137 taps.
 __global__ __launch_bounds__(256) void k_fill_btab(const float2 *__restrict__ tmpl, const int *__restrict__ start,
                                                     const int *__restrict__ smin, const int *__restrict__ kp2,
-                                                    float *__restrict__ btab, XcGeom geo) {
+                                                    float *__restrict__ btab, XcGeom geo, int n_buf) {
   LCS_TAIL_PRIO();
-  const int slot = blockIdx.z;
-  const int wg = blockIdx.y;
+  for (int vb = blockIdx.x; vb < geo.n_comb * geo.G * n_buf; vb += gridDim.x) {     // one (window, group) table of one slot per job
+  const int slot = vb / (geo.n_comb * geo.G);
+  const int wg = vb % (geo.n_comb * geo.G);
   const int w = wg / geo.G, g = wg % geo.G;
   const int k2 = kp2[((size_t)slot * NW + w) * GM + g];
   const int s0 = smin[((size_t)slot * NW + w) * GM + g];
   float *out = btab + (((size_t)slot * geo.n_comb + w) * geo.G + g) * (size_t)(LCS_KP2_MAX * 64);
-  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < k2 * 64; e += gridDim.x * blockDim.x) {
+  for (int e = threadIdx.x; e < k2 * 64; e += blockDim.x) {
     const int kk = e >> 6, l = e & 63;
     const int c = g * LCS_TG + (l & 15);
     float v = 0.f;
@@ -133,6 +178,7 @@ __global__ __launch_bounds__(256) void k_fill_btab(const float2 *__restrict__ tm
       }
     }
     out[e] = v;
+  }
   }
 }
 
@@ -295,14 +341,18 @@ struct SpArgs {
 #define SP_SEG 16
 #define SP_TILE (64 * SP_SEG)
 __device__ __forceinline__ int sp_pad(int i) { return i + (i >> 4); }
-__global__ __launch_bounds__(64) void k_sp_sums(const float2 *__restrict__ cap32, const double2 *__restrict__ cap64,
-                                                 double *__restrict__ sp_all, uint32_t n_cap, int n_comb_sp) {
+__global__ __launch_bounds__(64) void k_sp_sums(const CapSrc src, double *__restrict__ sp_all, uint32_t n_cap, int n_comb_sp,
+                                                 int n_buf) {
   LCS_TAIL_PRIO();
-  const int slot = blockIdx.z, m = blockIdx.y;
-  const int i0 = blockIdx.x * SP_TILE;
-  const int tid = threadIdx.x;
-  const CapView cap = cap_view(cap32, cap64, slot, n_cap);
+  constexpr int NT = (LCS_N_IDX + SP_TILE - 1) / SP_TILE;
   __shared__ double pw[SP_TILE + 274 + (SP_TILE + 274) / 16 + 2];
+  __shared__ double seg[64 + 18];
+  const int tid = threadIdx.x;
+  for (int vb = blockIdx.x; vb < NT * n_comb_sp * n_buf; vb += gridDim.x) {      // (tile, window, slot), tile fastest
+  const int slot = vb / (NT * n_comb_sp), m = (vb / NT) % n_comb_sp;
+  const int i0 = (vb % NT) * SP_TILE;
+  const CapView cap = cap_view(src, slot);
+  __syncthreads();                 // the previous job's readers of pw / seg are done
   const uint32_t base = (uint32_t)m * 9600u + i0;
   constexpr int SP_LD = (SP_TILE + 274 + 63) / 64;     // loads per lane: issued back to back, then consumed
   double2 c[SP_LD];
@@ -316,7 +366,6 @@ __global__ __launch_bounds__(64) void k_sp_sums(const float2 *__restrict__ cap32
     const int n = tid + 64 * r;
     if (n < SP_TILE + 274) pw[sp_pad(n)] = c[r].x * c[r].x + c[r].y * c[r].y;
   }
-  __shared__ double seg[64 + 18];
   __syncthreads();
   const int b0 = tid * SP_SEG;
   for (int k = tid; k < 64 + 17; k += 64) {     // segment sums of the tile and of the 272 samples behind it
@@ -343,19 +392,20 @@ __global__ __launch_bounds__(64) void k_sp_sums(const float2 *__restrict__ cap32
   __syncthreads();
   for (int n = tid; n < SP_TILE; n += 64)
     if (i0 + n < 9600) o[i0 + n] = pw[sp_pad(n)];      // coalesced rows instead of 128-byte-strided stores
+  }
 }
 __global__ __launch_bounds__(256) void k_sp_fold(const double *__restrict__ sp_all, double *__restrict__ spinc,
-                                                  double *__restrict__ zth, SpArgs a) {
+                                                  double *__restrict__ zth, SpArgs a, int n_buf) {
   LCS_TAIL_PRIO();
-  const int slot = blockIdx.y;
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= 9600) return;
-  double acc = 0;
-  for (int m = 0; m < a.n_comb_sp; ++m) acc += sp_all[((size_t)slot * a.n_comb_sp + m) * 9600 + i];
-  const double v = acc / a.n_comb_sp;
-  const int o = (i + 137) % 9600;
-  spinc[(size_t)slot * 9600 + o] = v;
-  zth[(size_t)slot * 9600 + o] = a.R_th1 * v / a.rx_cutoff / 137 / 2 / a.n_comb_xc / (2 * a.ds + 1);
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < n_buf * 9600; e += gridDim.x * 256) {
+    const int slot = e / 9600, i = e % 9600;
+    double acc = 0;
+    for (int m = 0; m < a.n_comb_sp; ++m) acc += sp_all[((size_t)slot * a.n_comb_sp + m) * 9600 + i];
+    const double v = acc / a.n_comb_sp;
+    const int o = (i + 137) % 9600;
+    spinc[(size_t)slot * 9600 + o] = v;
+    zth[(size_t)slot * 9600 + o] = a.R_th1 * v / a.rx_cutoff / 137 / 2 / a.n_comb_xc / (2 * a.ds + 1);
+  }
 }
 
 // ------------------------------------------------- K3: delay spread + max over frequency
@@ -365,16 +415,19 @@ __global__ __launch_bounds__(256) void k_sp_fold(const double *__restrict__ sp_a
 // ascending (foi, pss) order keeping the first maximum per PSS.
 __global__ __launch_bounds__(128) void k_collapse(const float *__restrict__ sg, float *__restrict__ incoh,
                                                    double *__restrict__ pow_, float *__restrict__ pow32,
-                                                   int *__restrict__ frq, XcGeom geo) {
+                                                   int *__restrict__ frq, XcGeom geo, int n_buf) {
   LCS_TAIL_PRIO();
   // the 128 + 2*ds rows (64 bytes each) a workgroup needs from one group are loaded once, coalesced, into LDS
   constexpr int CT = 128, CH = 8;                  // positions per workgroup, halo rows each side (ds <= 8)
   __shared__ float tile[(CT + 2 * CH) * (LCS_TG + 1)];
-  const int slot = blockIdx.y, tid = threadIdx.x;
-  const int idx0 = blockIdx.x * CT;
-  const int idx = idx0 + tid;
+  const int tid = threadIdx.x;
   const int ds = min(geo.ds, CH);
   const float dsn = (float)(2 * geo.ds + 1);
+  constexpr int NT = (LCS_N_IDX + CT - 1) / CT;
+  for (int vb = blockIdx.x; vb < NT * n_buf; vb += gridDim.x) {       // (position tile, slot), tile fastest
+  const int slot = vb / NT;
+  const int idx0 = (vb % NT) * CT;
+  const int idx = idx0 + tid;
   float best[3] = {0.f, 0.f, 0.f};
   int bi[3] = {0, 0, 0};
   for (int g = 0; g < geo.G; ++g) {
@@ -410,12 +463,14 @@ __global__ __launch_bounds__(128) void k_collapse(const float *__restrict__ sg, 
       }
     }
   }
-  if (idx >= LCS_N_IDX) return;
+  if (idx < LCS_N_IDX) {
 #pragma unroll
-  for (int t = 0; t < 3; ++t) {
-    pow_[((size_t)slot * 3 + t) * LCS_N_IDX + idx] = (double)best[t];
-    pow32[((size_t)slot * 3 + t) * LCS_N_IDX + idx] = best[t];   // what the fused peak search loads
-    frq[((size_t)slot * 3 + t) * LCS_N_IDX + idx] = bi[t];
+    for (int t = 0; t < 3; ++t) {
+      pow_[((size_t)slot * 3 + t) * LCS_N_IDX + idx] = (double)best[t];
+      pow32[((size_t)slot * 3 + t) * LCS_N_IDX + idx] = best[t];   // what the fused peak search loads
+      frq[((size_t)slot * 3 + t) * LCS_N_IDX + idx] = bi[t];
+    }
+  }
   }
 }
 
@@ -470,10 +525,24 @@ __global__ __launch_bounds__(256) void k_xc_debug(const double2 *__restrict__ ca
 }
 
 // ------------------------------------------------------------------------------ launch
+CapSrc lcs_cap_src(const lcs_ctx *c, uint32_t n_cap) {
+  CapSrc s{nullptr, nullptr, nullptr, n_cap};
+  if (c->cap64_valid) s.c64 = c->cap64;
+  else if (c->src_u8) s.c8 = c->cap8;
+  else s.c32 = c->cap32;
+  return s;
+}
+
 int lcs_launch_ingest(lcs_ctx *c, const void *d_src, int fmt, int n_buf, uint32_t n_cap) {
-  dim3 grid(128, n_buf);
-  hipLaunchKernelGGL(k_ingest, grid, dim3(256), 0, c->stream, d_src, fmt, n_cap, c->cap32, c->cap64,
-                     (c->use_i8 && fmt == LCS_FMT_IQ_U8) ? c->cap8 : nullptr);
+  c->src_u8 = fmt == LCS_FMT_IQ_U8;
+  if (fmt == LCS_FMT_IQ_U8) {
+    const unsigned nb = std::max(1u, std::min((unsigned)((lcs_cap8_stride(n_cap) / 8 + 255) / 256), (unsigned)(LCS_GRID_CAP / n_buf)));
+    hipLaunchKernelGGL(k_ingest_u8, dim3(nb, n_buf), dim3(256), 0, c->stream, (const uint8_t *)d_src, n_cap, c->cap8, c->cap8s,
+                       c->use_i8 ? nullptr : c->cap32);
+  } else {
+    hipLaunchKernelGGL(k_ingest, dim3(std::max(1, std::min(128, LCS_GRID_CAP / n_buf)), n_buf), dim3(256), 0, c->stream, d_src, fmt,
+                       n_cap, c->cap32, c->cap64);
+  }
   HIPCHK(c, hipGetLastError());
   return LCS_OK;
 }
@@ -494,8 +563,8 @@ int lcs_launch_xcorr(lcs_ctx *c, int n_buf, const XcGeom &geo, bool want_incoh, 
     int rc_ = lcs_launch_fill_btab_i8(c, n_buf, geo);
     if (rc_) return rc_;
   } else
-    hipLaunchKernelGGL(k_fill_btab, dim3(8, geo.n_comb * geo.G, n_buf), dim3(256), 0, c->stream, c->tmpl, c->start,
-                       c->smin, c->kp2, c->btab, geo);
+    hipLaunchKernelGGL(k_fill_btab, dim3(std::min(geo.n_comb * geo.G * n_buf, LCS_GRID_CAP)), dim3(256), 0, c->stream, c->tmpl,
+                       c->start, c->smin, c->kp2, c->btab, geo, n_buf);
   // signal-power estimate and threshold do not depend on the correlation: enqueue them first
   SpArgs a;
   a.n_comb_sp = (int)((geo.n_cap - 136 - 137) / 9600);
@@ -503,9 +572,10 @@ int lcs_launch_xcorr(lcs_ctx *c, int n_buf, const XcGeom &geo, bool want_incoh, 
   a.ds = geo.ds;
   a.R_th1 = lcs_tables::chi2cdf_inv(1 - pow(10.0, -12), 2.0 * geo.n_comb * (2 * geo.ds + 1));
   a.rx_cutoff = (6 * 12 * 15e3 / 2 + 4 * 15e3) / (30720000.0 / 16 / 2);
-  hipLaunchKernelGGL(k_sp_sums, dim3((LCS_N_IDX + SP_TILE - 1) / SP_TILE, a.n_comb_sp, n_buf), dim3(64), 0, c->stream, c->cap32,
-                     c->cap64_valid ? c->cap64 : nullptr, c->sp, geo.n_cap, a.n_comb_sp);
-  hipLaunchKernelGGL(k_sp_fold, dim3((LCS_N_IDX + 255) / 256, n_buf), dim3(256), 0, c->stream, c->sp, c->spinc, c->zth, a);
+  hipLaunchKernelGGL(k_sp_sums, dim3(std::min(((LCS_N_IDX + SP_TILE - 1) / SP_TILE) * a.n_comb_sp * n_buf, 4 * LCS_GRID_CAP)), dim3(64), 0,
+                     c->stream, lcs_cap_src(c, geo.n_cap), c->sp, geo.n_cap, a.n_comb_sp, n_buf);       // one-wave workgroups
+  hipLaunchKernelGGL(k_sp_fold, dim3(std::min((n_buf * LCS_N_IDX + 255) / 256, LCS_GRID_CAP)), dim3(256), 0, c->stream, c->sp, c->spinc,
+                     c->zth, a, n_buf);
 
   // slots [0, n8) with the XCD-aware mapping, the remainder with the plain one
   const int n8 = (n_buf >= 8) ? (n_buf & ~7) : 0;
@@ -547,8 +617,8 @@ int lcs_launch_xcorr(lcs_ctx *c, int n_buf, const XcGeom &geo, bool want_incoh, 
     HIPCHK(c, hipEventRecord(c->ev_post, sxc));
     HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_post, 0));
   }
-  hipLaunchKernelGGL(k_collapse, dim3((LCS_N_IDX + 127) / 128, n_buf), dim3(128), 0, c->stream, c->single,
-                     want_incoh ? c->incoh : nullptr, c->pow_, reinterpret_cast<float *>(c->work), c->frq, geo);
+  hipLaunchKernelGGL(k_collapse, dim3(std::min(((LCS_N_IDX + 127) / 128) * n_buf, 2 * LCS_GRID_CAP)), dim3(128), 0, c->stream, c->single,
+                     want_incoh ? c->incoh : nullptr, c->pow_, reinterpret_cast<float *>(c->work), c->frq, geo, n_buf);
   HIPCHK(c, hipGetLastError());
   return LCS_OK;
 }

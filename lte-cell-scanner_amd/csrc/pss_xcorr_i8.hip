@@ -27,6 +27,7 @@
 // operands of tap block e + 1 are read from LDS behind the first MFMA pair of block e; the digit passes walk
 // the tap blocks boustrophedon.
 #include "lcs_internal.h"
+#include <algorithm>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -42,10 +43,11 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 #define I8_TILES ((LCS_N_IDX + I8_LAGS - 1) / I8_LAGS)
 #define I8_NKB LCS_I8_KB                                  // 32-tap blocks per window: 137 taps + spread <= 160
 #define I8_AW (I8_LAGS + 32 * I8_NKB + 32)                // staged samples per window
-// dwords per staged copy: I8_AW / 2 is a multiple of 32, + 16 puts the shifted copy 16 banks away from the natural
-// one, so the even-lag lanes (natural copy, banks 0..12 of a 32-lane group) and the odd-lag lanes (shifted copy)
-// of one ds_read never meet on a bank (with + 2 they did: SQ_LDS_BANK_CONFLICT = 16 % of the kernel's cycles)
-#define I8_ACOPY (I8_AW / 2 + 16)
+#define I8_ADW (((I8_AW / 2 + 63) / 64) * 64)             // dwords per staged copy: whole 64-dword LDS-DMA chunks
+// I8_ADW is a multiple of 32, + 16 puts the shifted copy 16 banks away from the natural one, so the even-lag lanes
+// (natural copy, banks 0..12 of a 32-lane group) and the odd-lag lanes (shifted copy) of one ds_read never meet
+// on a bank (with + 2 they did: SQ_LDS_BANK_CONFLICT = 16 % of the kernel's cycles)
+#define I8_ACOPY (I8_ADW + 16)
 #define I8_QMAX 8300000.0                                 // |T_int| bound: three balanced base-256 digits reach 8 355 711
 
 // Per template (slot, foi, t): q = I8_QMAX / max tap magnitude; sc = 1 / (128 q) converts the integer
@@ -141,20 +143,22 @@ __global__ __launch_bounds__(256) void k_fill_btab_i8(const float2 *__restrict__
   }
 }
 
-__device__ __forceinline__ float pow2sum_i8(float re, float im) { return fmaf(re, re, im * im); }
-
-// The default kernel.  The window's B operands are copied global -> LDS by the LDS-DMA path (global_load_lds_dwordx4:
-// no staging registers, no ds_write pass), issued one window ahead right behind the barrier; the registers that
-// frees pay for a one-block-deep operand prefetch: the B operands and the two new A operands of tap block e + 1
-// are read from LDS behind the first MFMA pair of block e, so the LDS latency sits under 14 MFMAs instead of in
-// front of every block.  The digit passes walk the tap blocks boustrophedon (digit 2: kb 0..4, digit 1: kb 4..0,
-// digit 0: kb 0..4) so the sliding A window never restarts: 32 A-operand reads per window instead of 48.
-// Measured with parts removed (isolated, 64 buffers): 1.142 ms; without the epilogue 1.078; without any staging
-// after window 0 1.083; without the barrier 1.118; with 10 instead of 15 tap blocks 0.847 -- i.e. 0.059 ms per
-// tap block against 0.045 at the nominal int8 MFMA rate (the 16x16x64 micro-benchmark reaches 78 % of nominal:
-// the blocks run at the instruction's own ceiling) plus ~0.26 ms of per-window costs.
-__global__ __launch_bounds__(256, 2) void k_xcorr_i8x3(const uint16_t *__restrict__ cap8, const int *__restrict__ smin,
-                                                          const uint4 *__restrict__ bt8,
+// Everything a window needs reaches LDS by LDS-DMA (global_load_lds: no staging registers, no ds_write pass), issued
+// one window ahead right behind the barrier: the B operands (30 KB, dwordx4 chunks of the per-window table) and the
+// capture samples -- two copies of the window, natural and shifted by one sample, each a run of dwords (= sample pairs)
+// taken from cap8 or cap8s, whichever holds the window start dword aligned.  The registers that frees pay for a
+// one-block-deep operand prefetch: the B operands and the two new A operands of tap block e + 1 are read from LDS
+// behind the first MFMA pair of block e, so the LDS latency sits under 14 MFMAs instead of in front of every
+// block.  The digit passes walk the tap blocks boustrophedon (digit 2: kb 0..4, digit 1: kb 4..0, digit 0: kb 0..4)
+// so the sliding A window never restarts: 32 A-operand reads per window instead of 48.
+// Epilogue work is spread under the MFMA stream where its inputs allow: the digit-2 sums are converted to float
+// while the digit-1 pass runs, the << 8 of the shared digit-1/0 accumulator sits in front of each sub-tile's first
+// digit-0 MFMA; what is left behind the last block is 6 VALU operations per output.
+// Measured (isolated, 64 buffers, 16x16x64 issues every ~18 cycles: tools/microbench/mfma_rate.hip): the 15 tap
+// blocks of a window run at the MFMA issue rate (0.059 ms per block-launch); the rest is per-window and
+// per-workgroup cost (barrier, epilogue, prologue of each of the 15 workgroup rounds, last round 25 % full).
+__global__ __launch_bounds__(256, 2) void k_xcorr_i8x3(const uint16_t *__restrict__ cap8, const uint16_t *__restrict__ cap8s,
+                                                          const int *__restrict__ smin, const uint4 *__restrict__ bt8,
                                                           const float *__restrict__ sc, float *__restrict__ sg, XcGeom geo,
                                                           int slot0, int n_slots, int xcd_map) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -170,8 +174,11 @@ __global__ __launch_bounds__(256, 2) void k_xcorr_i8x3(const uint16_t *__restric
   constexpr int NBLK = 3 * I8_NKB;
   constexpr int BW = NBLK * 2 * 64;       // uint4 per window (30 KB), table order [digit][kb][op][lane]
   constexpr int NCH = BW / 64;            // 1 KiB chunks: one global_load_lds_dwordx4 per wave each
+  constexpr int NCA = 2 * (I8_ADW / 64);  // 256-byte chunks of the two sample copies: one global_load_lds_dword per wave each
   __shared__ uint4 ldsB[2][BW];
-  const uint16_t *cap = cap8 + (size_t)slot * geo.n_cap;
+  const size_t cstride = lcs_cap8_stride(geo.n_cap);
+  const uint32_t *capd = reinterpret_cast<const uint32_t *>(cap8 + (size_t)slot * cstride) + lane;     // dword j = samples (2j, 2j+1)
+  const uint32_t *capsd = reinterpret_cast<const uint32_t *>(cap8s + (size_t)slot * cstride) + lane;   // dword j = samples (2j+1, 2j+2)
   const int *smin_s = smin + (size_t)slot * NW * GM + g;
   const uint4 *bt_s = bt8 + ((size_t)slot * geo.n_comb * geo.G + g) * (size_t)BW + lane;
   const size_t bt_wstride = (size_t)geo.G * BW;
@@ -183,19 +190,21 @@ __global__ __launch_bounds__(256, 2) void k_xcorr_i8x3(const uint16_t *__restric
   f32x4 P[I8_MT];
 #pragma unroll
   for (int mt = 0; mt < I8_MT; ++mt) P[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  constexpr int ASTEPS = (I8_AW + 255) / 256;
-  uint32_t preA[ASTEPS];
-#define I8_LOAD_A(W)                                                                   \
-  {                                                                                    \
-    const int L0_ = idx0 + smin_s[(W) * GM];                                           \
-    _Pragma("unroll") for (int r_ = 0; r_ < ASTEPS; ++r_) {                            \
-      const int n_ = tid + 256 * r_;                                                   \
-      const uint32_t s_ = (uint32_t)(L0_ + n_);                                        \
-      preA[r_] = (n_ < I8_AW && s_ < geo.n_cap) ? (uint32_t)cap[s_] : 0u;              \
-    }                                                                                  \
-  }
-#define I8_DMA_B(W)                                                                                          \
+  // window W: samples L0 .. of this slot as the natural copy (dword i = samples L0 + 2i, L0 + 2i + 1) and the shifted
+  // one (L0 + 2i + 1, L0 + 2i + 2); an odd L0 swaps the roles of cap8 and cap8s
+#define I8_DMA(W)                                                                                            \
   {                                                                                                          \
+    const int L0_ = idx0 + smin_s[(W) * GM], h_ = L0_ >> 1;                                                  \
+    const uint32_t *nat_ = ((L0_ & 1) ? capsd : capd) + h_;                                                  \
+    const uint32_t *shf_ = (L0_ & 1) ? capd + h_ + 1 : capsd + h_;                                           \
+    _Pragma("unroll") for (int c_ = 0; c_ < (NCA + 3) / 4; ++c_) {                                           \
+      const int ca_ = wave + 4 * c_;          /* chunk = (copy, 64-dword piece) */                           \
+      if (ca_ < NCA) {                                                                                       \
+        const int cp_ = ca_ / (I8_ADW / 64), k_ = ca_ % (I8_ADW / 64);                                       \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)((cp_ ? shf_ : nat_) + 64 * k_), \
+                                         (__attribute__((address_space(3))) void *)(ldsA[(W) & 1][cp_] + 64 * k_), 4, 0, 0); \
+      }                                                                                                      \
+    }                                                                                                        \
     uint4 *dst_ = ldsB[(W) & 1];                                                                             \
     const uint4 *src_ = bt_s + (size_t)(W) * bt_wstride;                                                     \
     _Pragma("unroll") for (int c_ = 0; c_ < (NCH + 3) / 4; ++c_) {                                           \
@@ -215,22 +224,17 @@ __global__ __launch_bounds__(256, 2) void k_xcorr_i8x3(const uint16_t *__restric
       Bq[Q][op_] = (i32x4){(int)t_.x, (int)t_.y, (int)t_.z, (int)t_.w};                                      \
     }                                                                                                        \
   }
-  I8_LOAD_A(0);
-  I8_DMA_B(0);
+  I8_DMA(0);
   for (int w = 0; w < geo.n_comb; ++w) {
-    const bool has_next = w + 1 < geo.n_comb;
-    uint16_t *nat = reinterpret_cast<uint16_t *>(ldsA[w & 1][0]);
-    uint16_t *shf = reinterpret_cast<uint16_t *>(ldsA[w & 1][1]);
-#pragma unroll
-    for (int r = 0; r < ASTEPS; ++r) {
-      const int n = tid + 256 * r;
-      if (n < I8_AW) { nat[n] = (uint16_t)preA[r]; if (n > 0) shf[n - 1] = (uint16_t)preA[r]; }
-    }
-    __syncthreads();                       // also drains this wave's LDS-DMA chunks of window w (vmcnt(0))
-    if (has_next) { I8_LOAD_A(w + 1); I8_DMA_B(w + 1); }     // buffers (w + 1) & 1: last read in window w - 1
+    __syncthreads();                       // drains this wave's LDS-DMA chunks of window w (vmcnt(0)), then everybody's
+    if (w + 1 < geo.n_comb) I8_DMA(w + 1); // buffers (w + 1) & 1: last read in window w - 1
     const uint4 *bl = ldsB[w & 1] + lane;
     const uint32_t *bufA = ldsA[w & 1][par] + a_dw;
+    // digit 2 accumulates into (tR, tI); digits 1 and 0 share one int32 accumulator: after the digit-1 pass it is
+    // shifted left by 8 and the digit-0 products are added on top (|S1| <= 274 * 128 * 128 = 4.5e6, so
+    // 256 S1 + S0 stays below 2^31): one int -> float conversion per digit group instead of per digit.
     i32x4 tR[I8_MT], tI[I8_MT], aR[I8_MT], aI[I8_MT];
+    f32x4 fR[I8_MT], fI[I8_MT];            // float(S2): exact, |S2| < 2^24
     i32x4 Aw[2 * I8_NKB + I8_MT - 2];
     i32x4 Bq[2][2];
 #pragma unroll
@@ -244,8 +248,8 @@ __global__ __launch_bounds__(256, 2) void k_xcorr_i8x3(const uint16_t *__restric
       tR[MT] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Aw[2 * kb + (MT)], Bq[e & 1][0], cr, 0, 0, 0);          \
       tI[MT] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Aw[2 * kb + (MT)], Bq[e & 1][1], ci, 0, 0, 0);          \
     } else {                                                                                                 \
-      const i32x4 cr = (d == 1 && j == 0) ? (i32x4){0, 0, 0, 0} : aR[MT];                                    \
-      const i32x4 ci = (d == 1 && j == 0) ? (i32x4){0, 0, 0, 0} : aI[MT];                                    \
+      const i32x4 cr = (d == 1 && j == 0) ? (i32x4){0, 0, 0, 0} : (d == 2 && j == 0) ? aR[MT] << 8 : aR[MT]; \
+      const i32x4 ci = (d == 1 && j == 0) ? (i32x4){0, 0, 0, 0} : (d == 2 && j == 0) ? aI[MT] << 8 : aI[MT]; \
       aR[MT] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Aw[2 * kb + (MT)], Bq[e & 1][0], cr, 0, 0, 0);          \
       aI[MT] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Aw[2 * kb + (MT)], Bq[e & 1][1], ci, 0, 0, 0);          \
     }                                                                                                        \
@@ -256,7 +260,7 @@ __global__ __launch_bounds__(256, 2) void k_xcorr_i8x3(const uint16_t *__restric
       const int kb = (d == 1) ? I8_NKB - 1 - j : j;
       // The first MFMA pair of block e carries the wait for block e's operands (read during block e - 1); the reads
       // for block e + 1 are issued behind it, so that every s_waitcnt lgkmcnt(0) the compiler places finds only
-      // reads that have had 14 MFMAs (224 cycles) to complete.
+      // reads that have had 14 MFMAs to complete.
       I8_PF_MFMA(0);
       __builtin_amdgcn_sched_barrier(0);
       if (e + 1 < NBLK) {                  // operands of block e + 1
@@ -276,24 +280,25 @@ __global__ __launch_bounds__(256, 2) void k_xcorr_i8x3(const uint16_t *__restric
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int mt = 1; mt < I8_MT; ++mt) I8_PF_MFMA(mt);
-      __builtin_amdgcn_sched_barrier(0);
-      if (d == 1 && j == I8_NKB - 1) {
+      if (d == 1) {                        // digit-1 pass: the finished digit-2 sums of sub-tiles j, j + NKB go to float
 #pragma unroll
-        for (int mt = 0; mt < I8_MT; ++mt) { aR[mt] = aR[mt] << 8; aI[mt] = aI[mt] << 8; }
+        for (int mt = j; mt < I8_MT; mt += I8_NKB)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { fR[mt][r] = (float)tR[mt][r]; fI[mt][r] = (float)tI[mt][r]; }
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
 #undef I8_PF_MFMA
 #pragma unroll
     for (int mt = 0; mt < I8_MT; ++mt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float xr = fmaf((float)tR[mt][r], 65536.f, (float)aR[mt][r]);
-        const float xi = fmaf((float)tI[mt][r], 65536.f, (float)aI[mt][r]);
-        P[mt][r] = P[mt][r] + pow2sum_i8(xr, xi);
+      for (int r = 0; r < 4; ++r) {     // integer correlation S2 * 65536 + (256 S1 + S0) in fp32; scaled by 1 / (128 q)^2 at the end
+        const float xr = fmaf(fR[mt][r], 65536.f, (float)aR[mt][r]);
+        const float xi = fmaf(fI[mt][r], 65536.f, (float)aI[mt][r]);
+        P[mt][r] = fmaf(xi, xi, fmaf(xr, xr, P[mt][r]));
       }
   }
-#undef I8_LOAD_A
-#undef I8_DMA_B
+#undef I8_DMA
 #undef I8_RD_A
 #undef I8_RD_B
   const float ncomb = (float)geo.n_comb;
@@ -316,7 +321,7 @@ int lcs_launch_fill_btab_i8(lcs_ctx *c, int n_buf, const XcGeom &geo) {
 }
 int lcs_launch_xcorr_i8(lcs_ctx *c, hipStream_t sxc, const XcGeom &geo, int slot0, int n_slots, int xcd_map) {
   const unsigned grid = (unsigned)(I8_TILES * geo.G * n_slots);
-  hipLaunchKernelGGL(k_xcorr_i8x3, dim3(grid), dim3(256), 0, sxc, c->cap8, c->smin, c->bt8, c->tsc, c->single, geo, slot0,
+  hipLaunchKernelGGL(k_xcorr_i8x3, dim3(grid), dim3(256), 0, sxc, c->cap8, c->cap8s, c->smin, c->bt8, c->tsc, c->single, geo, slot0,
                      n_slots, xcd_map);
   HIPCHK(c, hipGetLastError());
   // executed work: per wave and window 3 digits x I8_NKB tap blocks x I8_MT sub-tiles x (re, im) MFMAs of 16x16x64 MACs

@@ -126,7 +126,7 @@ __device__ __forceinline__ SssGeo sss_geometry(const lcs_cell &cell, const SlotP
 #define SW_THREADS 192
 __global__ __launch_bounds__(SW_THREADS) void k_sss_win(const lcs_cell *__restrict__ peaks, const WorkItem *__restrict__ items,
                                                         const int *__restrict__ n_items,
-                                                        const float2 *__restrict__ cap32, const double2 *__restrict__ cap64,
+                                                        const CapSrc src,
                                                         uint32_t n_cap, const SlotParams *__restrict__ params,
                                                         const double2 *__restrict__ pss_fd, double *__restrict__ ws) {
   LCS_TAIL_PRIO();
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(SW_THREADS) void k_sss_win(const lcs_cell *__restri
     const SlotParams p = params[slot];
     const SssGeo g = sss_geometry(cell, p, n_cap);
     if (k >= g.n_pss) continue;
-    const CapView cap = cap_view(cap32, cap64, slot, n_cap);
+    const CapView cap = cap_view(src, slot);
     double *rec = ws + (size_t)it * SW_ITEM + (size_t)k * SW_REC;
     __syncthreads();
     {   // the PSS window, the extended-CP SSS window and the normal-CP SSS window (ref :578-597)
@@ -328,7 +328,7 @@ __device__ __forceinline__ FoeGeo foe_geometry(const lcs_cell &cell, const SlotP
 #define FW_THREADS 128
 __global__ __launch_bounds__(FW_THREADS) void k_foe_win(const lcs_cell *__restrict__ peaks, const WorkItem *__restrict__ items,
                                                         const int *__restrict__ n_items,
-                                                        const float2 *__restrict__ cap32, const double2 *__restrict__ cap64,
+                                                        const CapSrc src,
                                                         uint32_t n_cap, const SlotParams *__restrict__ params,
                                                         const double2 *__restrict__ pss_fd, const int8_t *__restrict__ sss_fd,
                                                         double *__restrict__ ws) {
@@ -346,7 +346,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_foe_win(const lcs_cell *__restri
     const SlotParams p = params[slot];
     const FoeGeo g = foe_geometry(cell, p, n_cap);
     if (!g.ok || k >= g.n_sss) continue;
-    const CapView cap = cap_view(cap32, cap64, slot, n_cap);
+    const CapView cap = cap_view(src, slot);
     double *rec = ws + (size_t)it * SW_ITEM + (size_t)k * SW_REC;
     __syncthreads();
     {
@@ -420,20 +420,20 @@ static int run_sss_foe(lcs_ctx *c, int n_buf, uint32_t n_cap, double thresh2, in
     if (!c->n_pk) HIPCHK(c, hipMalloc((void **)&c->n_pk, 4 * sizeof(int)));
     c->sss_ws_items = cap_items;
   }
-  const double2 *c64 = c->cap64_valid ? c->cap64 : nullptr;
+  const CapSrc src = lcs_cap_src(c, n_cap);
   // enough workgroups for every (peak, occurrence) of a typical batch to be resident at once; the
   // kernels loop over the work list, so larger batches only take more rounds
   const int win_grid = (int)std::min<size_t>(cap_items * MAX_HF, 4096);
   const int item_grid = (int)std::min<size_t>(cap_items, 1024);
   hipLaunchKernelGGL(k_peak_list, dim3(1), dim3(64), 0, c->stream, c->npeaks, n_buf, c->pk_items, c->n_pk);
   if (mode & 1) {
-    hipLaunchKernelGGL(k_sss_win, dim3(win_grid), dim3(SW_THREADS), 0, c->stream, c->peaks, c->pk_items, c->n_pk, c->cap32, c64,
+    hipLaunchKernelGGL(k_sss_win, dim3(win_grid), dim3(SW_THREADS), 0, c->stream, c->peaks, c->pk_items, c->n_pk, src,
                        n_cap, c->params, c->d_pss_fd, c->sss_ws);
     hipLaunchKernelGGL(k_sss_ml, dim3(item_grid), dim3(SF_THREADS), 0, c->stream, c->peaks, c->pk_items, c->n_pk, n_cap,
                        c->params, thresh2, c->d_sss_fd, c->sss_ws, dbg);
   }
   if (mode & 2) {
-    hipLaunchKernelGGL(k_foe_win, dim3(win_grid), dim3(FW_THREADS), 0, c->stream, c->peaks, c->pk_items, c->n_pk, c->cap32, c64,
+    hipLaunchKernelGGL(k_foe_win, dim3(win_grid), dim3(FW_THREADS), 0, c->stream, c->peaks, c->pk_items, c->n_pk, src,
                        n_cap, c->params, c->d_pss_fd, c->d_sss_fd, c->sss_ws);
     hipLaunchKernelGGL(k_foe_fin, dim3((unsigned)((cap_items + 63) / 64)), dim3(64), 0, c->stream, c->peaks, c->pk_items,
                        c->n_pk, n_cap, c->params, c->sss_ws);

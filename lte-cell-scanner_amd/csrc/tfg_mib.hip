@@ -239,8 +239,7 @@ __device__ __forceinline__ bool tfg_row_needed(int t, int n_symb) {
 #define TFG_THREADS 256     // 4 waves: wave v transforms windows v and v + 4, one radix-2 butterfly per lane and stage
 __global__ __launch_bounds__(TFG_THREADS) void k_tfg(const lcs_cell *__restrict__ cells, const WorkItem *__restrict__ items,
                                                      const int *__restrict__ n_work, const SlotParams *__restrict__ params,
-                                                     const float2 *__restrict__ cap32,
-                                                     const double2 *__restrict__ cap64, uint32_t n_cap,
+                                                     const CapSrc src, uint32_t n_cap,
                                                      const double *__restrict__ ts, double *__restrict__ scratch,
                                                      double2 *__restrict__ tfg, int needed_only) {
   LCS_TAIL_PRIO();
@@ -259,7 +258,7 @@ __global__ __launch_bounds__(TFG_THREADS) void k_tfg(const lcs_cell *__restrict_
     const double k_factor = sc[CS_KFACTOR];
     const lcs_cell c = cells[it];
     const SlotParams p = params[items[it].slot];
-    const CapView cap = cap_view(cap32, cap64, items[it].slot, n_cap);
+    const CapView cap = cap_view(src, items[it].slot);
     const double *tsi = ts + (size_t)it * ROWS;
     // fshift phase pi * (-f) / (fs/2) * n (ref dsp.h:40-53) as sincospi((-f)/(fs/2) * n): the absolute
     // sample index reaches 153600, far into the slow argument-reduction path of sincos
@@ -997,7 +996,7 @@ int lcs_launch_tfg(lcs_ctx *c, uint32_t n_cap, bool with_rs) {
   hipLaunchKernelGGL(k_cell_prep, dim3(GRID_ITEMS), dim3(128), 0, c->stream, c->cells_out, c->work_items, c->n_work, c->params,
                      c->d_pn_jump, c->tfg_ts, c->cell_scratch, with_rs ? 3 : 1);
   hipLaunchKernelGGL(k_tfg, dim3(4096), dim3(TFG_THREADS), 0, c->stream, c->cells_out, c->work_items, c->n_work, c->params,
-                     c->cap32, c->cap64_valid ? c->cap64 : nullptr, n_cap, c->tfg_ts, c->cell_scratch, c->tfg, c->needed_rows_only ? 1 : 0);
+                     lcs_cap_src(c, n_cap), n_cap, c->tfg_ts, c->cell_scratch, c->tfg, c->needed_rows_only ? 1 : 0);
   HIPCHK(c, hipGetLastError());
   return LCS_OK;
 }
