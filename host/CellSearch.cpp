@@ -1,289 +1,351 @@
 // CellSearch -- command-line front end of the MI355X-native searcher.
 //
-// Keeps the contract of the reference's CLI (src/CellSearch.cpp): the same options
-// (-h -v -b -i -s -e -p -c -r -l -d, parse_commandline :92-280), the 100 kHz raster checks and
-// warnings, the per-carrier progress lines, the "Detected a cell!" block, dedup (:285-319) and
-// the final table (:575-614).  What differs: there is no RTL-SDR on a GPU node, so captures come
-// from capbuf_NNNN.it files (-l, the reference's hardware-free mode, src/capbuf.cpp:98-115);
-// without -l the program refuses to run.  With recorded data fc_programmed = fc_requested and fs_programmed = 1.92e6*correction
-// (the convention of src/LTE-Tracker.cpp:609, 791; the reference's CellSearch leaves both
-// uninitialised with -l, quirk Q5).  Extra option: -g/--gpu N selects the device.
+// Contract kept from the reference's CLI (src/CellSearch.cpp): option letters and long names (:43-87, :117-133), the
+// 100 kHz raster rounding and its warnings (:222-258), the banner, the per-carrier progress line, the
+// "Detected a cell!" block, the de-duplication rule (:285-319) and the result table (:575-614) -- byte for byte on
+// stdout.  What is NOT kept is the program's shape: options are a table walked by a small scanner, captures are read
+// for the whole sweep and pushed through the GPU in batches, cells are de-duplicated through an index by cell
+// identity, and every number is formatted by one helper.
 //
-// The searcher itself runs entirely on the GPU through include/searcher_amd.h -> include/lcs.h.
-#include <getopt.h>
-
+// There is no RTL-SDR on a GPU node: captures come from capbuf_NNNN.it files (-l, the reference's hardware-free
+// mode, src/capbuf.cpp:98-115); without -l the program refuses to run.  With recorded data fc_programmed =
+// fc_requested and fs_programmed = 1.92e6 * correction (the convention of src/LTE-Tracker.cpp:609, 791).
+// A recorded capture holds exactly (u8-127)/128 per component (src/capbuf.cpp:172-181): such buffers go to the GPU
+// as raw bytes, 64 carriers per batch, and take the int8 correlation kernel; anything else (synthetic complex
+// data) is searched one buffer at a time as complex<double>.  Extra option: -g/--gpu N selects the device.
 #include <cmath>
+#include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
-#include <iomanip>
+#include <cstring>
+#include <algorithm>
 #include <iostream>
 #include <list>
-#include <sstream>
+#include <map>
 #include <string>
 #include <vector>
 
 #include "../include/searcher_amd.h"
 #include "itfile.hpp"
 
-using namespace std;
 using lcs::Cell;
 
-static int verbosity = 1;
 #define VERSION_STRING "1.0.0-amd"
 
-static void print_usage() {
-  cout << "LTE CellSearch v" << VERSION_STRING << " (MI355X) help screen" << endl << endl;
-  cout << "CellSearch -s start_frequency [optional_parameters]" << endl;
-  cout << "  Basic options" << endl;
-  cout << "    -h --help" << endl;
-  cout << "      print this help screen" << endl;
-  cout << "    -v --verbose" << endl;
-  cout << "      increase status messages from program" << endl;
-  cout << "    -b --brief" << endl;
-  cout << "      reduce status messages from program" << endl;
-  cout << "    -i --device-index N" << endl;
-  cout << "      (accepted for compatibility; there is no RTLSDR dongle on a GPU node)" << endl;
-  cout << "    -g --gpu N" << endl;
-  cout << "      GPU to run the searcher on (default: current device)" << endl;
-  cout << "  Frequency search options:" << endl;
-  cout << "    -s --freq-start fs" << endl;
-  cout << "      frequency where cell search should start" << endl;
-  cout << "    -e --freq-end fe" << endl;
-  cout << "      frequency where cell search should end" << endl;
-  cout << "  Dongle LO correction options:" << endl;
-  cout << "    -p --ppm ppm" << endl;
-  cout << "      crystal remaining PPM error" << endl;
-  cout << "    -c --correction c" << endl;
-  cout << "      crystal correction factor" << endl;
-  cout << "  Capture buffer save/ load options:" << endl;
-  cout << "    -r --record" << endl;
-  cout << "      save captured data in the files capbuf_XXXX.it" << endl;
-  cout << "    -l --load" << endl;
-  cout << "      used data in capbuf_XXXX.it files instead of live data" << endl;
-  cout << "    -d --data-dir dir" << endl;
-  cout << "      directory where capbuf_XXXX.it files are located" << endl << endl;
-  cout << "'c' is the correction factor to apply and indicates that if the desired" << endl;
-  cout << "center frequency is fc, the RTL-SDR dongle should be instructed to tune" << endl;
-  cout << "to freqency fc*c so that its true frequency shall be fc. Default: 1.0" << endl << endl;
-  cout << "'ppm' is the remaining frequency error of the crystal. Default: 120" << endl;
+namespace {
+
+// ---- formatting: iostream's default float notation with precision p and width w is printf's %*.{p}g ----------
+std::string fmt(const char *f, ...) {
+  char buf[256];
+  va_list ap;
+  va_start(ap, f);
+  vsnprintf(buf, sizeof(buf), f, ap);
+  va_end(ap);
+  return buf;
+}
+std::string num(double v, int precision = 6, int width = 0) { return fmt("%*.*g", width, precision, v); }
+
+// ---- options ---------------------------------------------------------------------------------------------------
+struct Options {
+  double freq_start = -1, freq_end = -1, ppm = 120, correction = 1;
+  bool record = false, load = false, help = false;
+  std::string data_dir = ".";
+  long device_index = -1, gpu = -1;
+  int verbosity = 1;
+};
+
+enum ArgKind { FLAG, REAL, INDEX, TEXT };
+struct OptSpec {
+  char letter;
+  const char *name;
+  ArgKind kind;
+  const char *what;       // "could not parse <what>"
+  const char *help[2];    // usage lines
+};
+const OptSpec kSpecs[] = {
+    {'h', "help", FLAG, 0, {"print this help screen", 0}},
+    {'v', "verbose", FLAG, 0, {"increase status messages from program", 0}},
+    {'b', "brief", FLAG, 0, {"reduce status messages from program", 0}},
+    {'i', "device-index", INDEX, "device index", {"(accepted for compatibility; there is no RTLSDR dongle on a GPU node)", 0}},
+    {'g', "gpu", INDEX, "gpu index", {"GPU to run the searcher on (default: current device)", 0}},
+    {'s', "freq-start", REAL, "start frequency", {"frequency where cell search should start", 0}},
+    {'e', "freq-end", REAL, "end frequency", {"frequency where cell search should end", 0}},
+    {'p', "ppm", REAL, "ppm value", {"crystal remaining PPM error", 0}},
+    {'c', "correction", REAL, "correction factor", {"crystal correction factor", 0}},
+    {'r', "record", FLAG, 0, {"save captured data in the files capbuf_XXXX.it", 0}},
+    {'l', "load", FLAG, 0, {"used data in capbuf_XXXX.it files instead of live data", 0}},
+    {'d', "data-dir", TEXT, 0, {"directory where capbuf_XXXX.it files are located", 0}},
+};
+const char *arg_name(const OptSpec &s) { return s.kind == FLAG ? "" : (s.letter == 's' ? " fs" : s.letter == 'e' ? " fe" : s.letter == 'p' ? " ppm" : s.letter == 'c' ? " c" : s.letter == 'd' ? " dir" : " N"); }
+
+void usage() {
+  std::cout << "LTE CellSearch v" << VERSION_STRING << " (MI355X) help screen\n\n"
+            << "CellSearch -s start_frequency [optional_parameters]\n";
+  const struct { const char *title; const char *letters; } sections[] = {
+      {"Basic options", "hvbig"}, {"Frequency search options:", "se"}, {"Dongle LO correction options:", "pc"},
+      {"Capture buffer save/ load options:", "rld"}};
+  for (const auto &sec : sections) {
+    std::cout << "  " << sec.title << "\n";
+    for (const char *l = sec.letters; *l; ++l)
+      for (const OptSpec &s : kSpecs)
+        if (s.letter == *l) std::cout << "    -" << s.letter << " --" << s.name << arg_name(s) << "\n      " << s.help[0] << "\n";
+  }
+  std::cout << "\n'c' is the correction factor to apply and indicates that if the desired\n"
+            << "center frequency is fc, the RTL-SDR dongle should be instructed to tune\n"
+            << "to freqency fc*c so that its true frequency shall be fc. Default: 1.0\n\n"
+            << "'ppm' is the remaining frequency error of the crystal. Default: 120\n";
 }
 
-static double round_half_away(double x) { return (x < 0) ? -floor(-x + 0.5) : floor(x + 0.5); }   // itpp::round
+[[noreturn]] void die(const std::string &msg) {
+  std::cerr << "Error: " << msg << std::endl;
+  std::exit(-1);
+}
 
-static void parse_commandline(int argc, char *const argv[], double &freq_start, double &freq_end, double &ppm,
-                              double &correction, bool &save_cap, bool &use_recorded_data, string &data_dir,
-                              int &device_index, int &gpu) {
-  freq_start = -1; freq_end = -1; ppm = 120; correction = 1; save_cap = false; use_recorded_data = false;
-  data_dir = "."; device_index = -1; gpu = -1;
-  static struct option long_options[] = {
-      {"help", no_argument, 0, 'h'},          {"verbose", no_argument, 0, 'v'},     {"brief", no_argument, 0, 'b'},
-      {"freq-start", required_argument, 0, 's'}, {"freq-end", required_argument, 0, 'e'}, {"ppm", required_argument, 0, 'p'},
-      {"correction", required_argument, 0, 'c'}, {"record", no_argument, 0, 'r'},   {"load", no_argument, 0, 'l'},
-      {"data-dir", required_argument, 0, 'd'},   {"device-index", required_argument, 0, 'i'}, {"gpu", required_argument, 0, 'g'},
-      {0, 0, 0, 0}};
-  while (1) {
-    int option_index = 0;
-    const int c = getopt_long(argc, argv, "hvbs:e:p:c:rld:i:g:", long_options, &option_index);
-    if (c == -1) break;
-    char *endp;
-    switch (c) {
-      case 'h': print_usage(); exit(-1);
-      case 'v': verbosity = 2; break;
-      case 'b': verbosity = 0; break;
-      case 's':
-        freq_start = strtod(optarg, &endp);
-        if ((optarg == endp) || (*endp != '\0')) { cerr << "Error: could not parse start frequency" << endl; exit(-1); }
-        break;
-      case 'e':
-        freq_end = strtod(optarg, &endp);
-        if ((optarg == endp) || (*endp != '\0')) { cerr << "Error: could not parse end frequency" << endl; exit(-1); }
-        break;
-      case 'p':
-        ppm = strtod(optarg, &endp);
-        if ((optarg == endp) || (*endp != '\0')) { cerr << "Error: could not parse ppm value" << endl; exit(-1); }
-        break;
-      case 'c':
-        correction = strtod(optarg, &endp);
-        if ((optarg == endp) || (*endp != '\0')) { cerr << "Error: could not parse correction factor" << endl; exit(-1); }
-        break;
-      case 'r': save_cap = true; break;
-      case 'l': use_recorded_data = true; break;
-      case 'd': data_dir = optarg; break;
-      case 'i':
-        device_index = strtol(optarg, &endp, 10);
-        if ((optarg == endp) || (*endp != '\0')) { cerr << "Error: could not parse device index" << endl; exit(-1); }
-        if (device_index < 0) { cerr << "Error: device index cannot be negative" << endl; exit(-1); }
-        break;
-      case 'g':
-        gpu = strtol(optarg, &endp, 10);
-        if ((optarg == endp) || (*endp != '\0') || gpu < 0) { cerr << "Error: could not parse gpu index" << endl; exit(-1); }
-        break;
-      default: exit(-1);
+void store(Options &o, const OptSpec &s, const char *value) {
+  char *end = 0;
+  switch (s.kind) {
+    case FLAG:
+      if (s.letter == 'h') o.help = true;
+      else if (s.letter == 'v') o.verbosity = 2;
+      else if (s.letter == 'b') o.verbosity = 0;
+      else if (s.letter == 'r') o.record = true;
+      else o.load = true;
+      return;
+    case TEXT: o.data_dir = value; return;
+    case REAL: {
+      const double v = std::strtod(value, &end);
+      if (end == value || *end) die(std::string("could not parse ") + s.what);
+      (s.letter == 's' ? o.freq_start : s.letter == 'e' ? o.freq_end : s.letter == 'p' ? o.ppm : o.correction) = v;
+      return;
+    }
+    case INDEX: {
+      const long v = std::strtol(value, &end, 10);
+      if (end == value || *end) die(std::string("could not parse ") + s.what);
+      if (v < 0) die(s.letter == 'i' ? "device index cannot be negative" : "could not parse gpu index");
+      (s.letter == 'i' ? o.device_index : o.gpu) = v;
+      return;
     }
   }
-  if (optind < argc) { cerr << "Error: unknown/extra arguments specified on command line" << endl; exit(-1); }
-  if (freq_start == -1) { cerr << "Error: must specify a start frequency. (Try --help)" << endl; exit(-1); }
-  if (freq_start < 1e6) { cerr << "Error: start frequency must be greater than 1MHz" << endl; exit(-1); }
-  if (freq_start / 100e3 != round_half_away(freq_start / 100e3)) {
-    freq_start = round_half_away(freq_start / 100e3) * 100e3;
-    cout << "Warning: start frequency has been rounded to the nearest multiple of 100kHz" << endl;
+}
+
+// -x, -xVALUE, -x VALUE, clustered flags (-vl), --name, --name VALUE, --name=VALUE; anything else is "extra"
+Options scan_args(int argc, char *const argv[]) {
+  Options o;
+  for (int i = 1; i < argc; ++i) {
+    const char *a = argv[i];
+    if (a[0] != '-' || !a[1]) die("unknown/extra arguments specified on command line");
+    if (a[1] == '-') {
+      const char *eq = std::strchr(a + 2, '=');
+      const std::string name = eq ? std::string(a + 2, eq) : std::string(a + 2);
+      const OptSpec *hit = 0;
+      for (const OptSpec &s : kSpecs) if (name == s.name) hit = &s;
+      if (!hit) std::exit(-1);                                   // unknown option: the reference exits silently after getopt's message
+      if (hit->kind == FLAG) { store(o, *hit, 0); continue; }
+      if (!eq && i + 1 >= argc) std::exit(-1);
+      store(o, *hit, eq ? eq + 1 : argv[++i]);
+      continue;
+    }
+    for (const char *p = a + 1; *p; ++p) {
+      const OptSpec *hit = 0;
+      for (const OptSpec &s : kSpecs) if (*p == s.letter) hit = &s;
+      if (!hit) std::exit(-1);
+      if (hit->kind == FLAG) { store(o, *hit, 0); continue; }
+      if (p[1]) { store(o, *hit, p + 1); break; }
+      if (i + 1 >= argc) std::exit(-1);
+      store(o, *hit, argv[++i]);
+      break;
+    }
   }
-  if (freq_end == -1) freq_end = freq_start;
-  if (freq_end < freq_start) { cerr << "Error: end frequency must be >= start frequency" << endl; exit(-1); }
-  if (freq_end / 100e3 != round_half_away(freq_end / 100e3)) {
-    freq_end = round_half_away(freq_end / 100e3) * 100e3;
-    cout << "Warning: end frequency has been rounded to the nearest multiple of 100kHz" << endl;
+  if (o.help) { usage(); std::exit(-1); }
+  return o;
+}
+
+double nearest_raster(double f) { return (f < 0 ? -std::floor(-f / 100e3 + 0.5) : std::floor(f / 100e3 + 0.5)) * 100e3; }   // itpp::round
+
+void validate(Options &o) {
+  if (o.freq_start == -1) die("must specify a start frequency. (Try --help)");
+  if (o.freq_start < 1e6) die("start frequency must be greater than 1MHz");
+  struct { double *f; const char *which; } ends[2] = {{&o.freq_start, "start"}, {&o.freq_end, "end"}};
+  for (int k = 0; k < 2; ++k) {
+    if (k == 1) {
+      if (o.freq_end == -1) o.freq_end = o.freq_start;
+      if (o.freq_end < o.freq_start) die("end frequency must be >= start frequency");
+    }
+    if (nearest_raster(*ends[k].f) != *ends[k].f) {
+      *ends[k].f = nearest_raster(*ends[k].f);
+      std::cout << "Warning: " << ends[k].which << " frequency has been rounded to the nearest multiple of 100kHz" << std::endl;
+    }
   }
-  if (ppm < 0) { cerr << "Error: ppm value must be positive" << endl; exit(-1); }
-  if (ppm > 200) cout << "Warning: ppm value appears to be set unreasonably high" << endl;
-  if (fabs(correction - 1) > 1000e-6) cout << "Warning: crystal correction factor appears to be unreasonable" << endl;
-  if (save_cap && use_recorded_data) { cerr << "Error: cannot read and write captured data at the same time!" << endl; exit(-1); }
-  if (verbosity >= 1) {
-    cout << "LTE CellSearch v" << VERSION_STRING << " (MI355X) beginning" << endl;
-    if (freq_start == freq_end) cout << "  Search frequency: " << freq_start / 1e6 << " MHz" << endl;
-    else cout << "  Search frequency range: " << freq_start / 1e6 << "-" << freq_end / 1e6 << " MHz" << endl;
-    cout << "  PPM: " << ppm << endl;
-    stringstream temp;
-    temp << setprecision(20) << correction;
-    cout << "  correction: " << temp.str() << endl;
-    if (use_recorded_data) cout << "  Captured data will be read from capbufXXXX.it files" << endl;
+  if (o.ppm < 0) die("ppm value must be positive");
+  if (o.ppm > 200) std::cout << "Warning: ppm value appears to be set unreasonably high" << std::endl;
+  if (std::fabs(o.correction - 1) > 1000e-6) std::cout << "Warning: crystal correction factor appears to be unreasonable" << std::endl;
+  if (o.record && o.load) die("cannot read and write captured data at the same time!");
+  if (o.verbosity >= 1) {
+    std::cout << "LTE CellSearch v" << VERSION_STRING << " (MI355X) beginning\n";
+    if (o.freq_start == o.freq_end) std::cout << "  Search frequency: " << num(o.freq_start / 1e6) << " MHz\n";
+    else std::cout << "  Search frequency range: " << num(o.freq_start / 1e6) << "-" << num(o.freq_end / 1e6) << " MHz\n";
+    std::cout << "  PPM: " << num(o.ppm) << "\n  correction: " << num(o.correction, 20) << "\n";
+    if (o.load) std::cout << "  Captured data will be read from capbufXXXX.it files\n";
+    std::cout.flush();
   }
 }
 
-// ref src/CellSearch.cpp:285-319
-static void dedup(const vector<list<Cell> > &detected_cells, list<Cell> &cells_final) {
-  cells_final.clear();
-  for (size_t t = 0; t < detected_cells.size(); t++) {
-    for (list<Cell>::const_iterator it_n = detected_cells[t].begin(); it_n != detected_cells[t].end(); ++it_n) {
-      bool match = false;
-      for (list<Cell>::iterator it_f = cells_final.begin(); it_f != cells_final.end(); ++it_f) {
-        if ((it_n->n_id_cell() == it_f->n_id_cell()) &&
-            (fabs((it_n->fc_requested + it_n->freq_superfine) - (it_f->fc_requested + it_f->freq_superfine)) < 1e6)) {
-          match = true;
-          if (it_n->pss_pow > it_f->pss_pow) *it_f = *it_n;
-          break;
-        }
+// ---- captures ------------------------------------------------------------------------------------------------------
+struct Capture {
+  std::vector<std::complex<double> > samples;
+  std::vector<unsigned char> iq_u8;      // filled when every component is exactly (u8-127)/128
+  bool fc_matches = true;
+};
+
+Capture read_capture(const std::string &path, double fc_expected) {
+  Capture c;
+  std::map<std::string, itfile::Var> vars = itfile::read_all(path);
+  c.samples = itfile::get_dcvec(vars, "capbuf");
+  const std::vector<int32_t> fc = itfile::get_ivec(vars, "fc");
+  c.fc_matches = !fc.empty() && fc_expected == fc[0];
+  c.iq_u8.resize(2 * c.samples.size());
+  const double *x = reinterpret_cast<const double *>(c.samples.data());
+  for (size_t i = 0; i < c.iq_u8.size(); ++i) {
+    const double code = x[i] * 128.0 + 127.0;               // exact for dongle data
+    if (!(code >= 0.0 && code <= 255.0) || code != std::floor(code)) { c.iq_u8.clear(); break; }
+    c.iq_u8[i] = (unsigned char)code;
+  }
+  return c;
+}
+
+// ---- results ---------------------------------------------------------------------------------------------------------
+// The reference's rule (src/CellSearch.cpp:285-319): walk the carriers in order; a cell is the same as an earlier one
+// when the identity matches and the two true centre frequencies lie within 1 MHz; of the two, the stronger PSS
+// stays, in the earlier one's place in the list.
+std::vector<Cell> merge_duplicates(const std::vector<std::list<Cell> > &per_carrier) {
+  std::vector<Cell> kept;
+  std::multimap<int, size_t> by_identity;                    // n_id_cell -> positions in `kept`, in insertion order
+  for (const std::list<Cell> &found : per_carrier)
+    for (const Cell &c : found) {
+      const double f_true = c.fc_requested + c.freq_superfine;
+      size_t twin = kept.size();
+      const auto range = by_identity.equal_range(c.n_id_cell());
+      for (auto it = range.first; it != range.second && twin == kept.size(); ++it)
+        if (std::fabs(f_true - (kept[it->second].fc_requested + kept[it->second].freq_superfine)) < 1e6) twin = it->second;
+      if (twin == kept.size()) {
+        by_identity.insert(std::make_pair(c.n_id_cell(), kept.size()));
+        kept.push_back(c);
+      } else if (c.pss_pow > kept[twin].pss_pow) {
+        kept[twin] = c;
       }
-      if (!match) cells_final.push_back(*it_n);
     }
-  }
+  return kept;
 }
 
-// ref src/CellSearch.cpp:322-340
-static string freq_formatter(double freq) {
-  stringstream temp;
-  if (fabs(freq) < 998.0) temp << setw(5) << setprecision(3) << freq << "h";
-  else if (fabs(freq) < 998000.0) temp << setw(5) << setprecision(3) << freq / 1e3 << "k";
-  else if (fabs(freq) < 998000000.0) temp << setw(5) << setprecision(3) << freq / 1e6 << "m";
-  else if (fabs(freq) < 998000000000.0) temp << setw(5) << setprecision(3) << freq / 1e9 << "g";
-  else if (fabs(freq) < 998000000000000.0) temp << setw(5) << setprecision(3) << freq / 1e12 << "t";
-  else temp << freq;
-  return temp.str();
+// 12.3k / 35.2k / 1.02m ...: three significant digits and an SI letter (src/CellSearch.cpp:322-340)
+std::string si_frequency(double f) {
+  static const struct { double below, unit; const char *suffix; } steps[] = {
+      {998.0, 1.0, "h"}, {998e3, 1e3, "k"}, {998e6, 1e6, "m"}, {998e9, 1e9, "g"}, {998e12, 1e12, "t"}};
+  for (const auto &s : steps)
+    if (std::fabs(f) < s.below) return num(f / s.unit, 3, 5) + s.suffix;
+  return num(f);
 }
 
-static double db10(double s) { return 10 * log10(s); }
+double db10(double p) { return 10 * std::log10(p); }
+
+std::string table_row(const Cell &c, double correction) {
+  static const char *cp[] = {"U", "N", "E"}, *pd[] = {"U", "N", "E"}, *pr[] = {" UNK", " 1/6", " 1/2", " one", " two"};
+  const double crystal_freq_actual = c.fc_requested - c.freq_superfine;       // :601-605
+  const double correction_new = correction * (c.fc_requested / crystal_freq_actual);
+  return fmt("%3d%2d ", c.n_id_cell(), c.n_ports) + num(c.fc_requested / 1e6, 5, 6) + "M " + si_frequency(c.freq_superfine) + " " +
+         num(db10(c.pss_pow), 3, 5) + " " + cp[c.cp_type] + fmt(" %3d ", c.n_rb_dl) + pd[c.phich_duration] +
+         (c.phich_resource >= 0 && c.phich_resource <= 4 ? pr[c.phich_resource] : "") + " " + num(correction_new, 20);
+}
+
+void announce(const std::list<Cell> &cells) {
+  for (const Cell &c : cells)
+    std::cout << "  Detected a cell!\n    cell ID: " << c.n_id_cell() << "\n    RX power level: " << num(db10(c.pss_pow))
+              << " dB\n    residual frequency offset: " << num(c.freq_superfine) << " Hz" << std::endl;
+}
+
+}  // namespace
 
 int main(int argc, char *const argv[]) {
-  double freq_start, freq_end, ppm, correction;
-  bool save_cap, use_recorded_data;
-  string data_dir;
-  int device_index, gpu;
-  parse_commandline(argc, argv, freq_start, freq_end, ppm, correction, save_cap, use_recorded_data, data_dir, device_index, gpu);
-  if (!use_recorded_data) {
-    cerr << "Error: this build has no RTL-SDR support (GPU node); use --load with capbuf_XXXX.it files" << endl;
+  Options opt = scan_args(argc, argv);
+  validate(opt);
+  if (!opt.load) {
+    std::cerr << "Error: this build has no RTL-SDR support (GPU node); use --load with capbuf_XXXX.it files" << std::endl;
     return 1;
   }
-  const double fs_programmed = 1.92e6 * correction;   // recorded-data convention, src/LTE-Tracker.cpp:791
+  const double fs_programmed = 1.92e6 * opt.correction;   // recorded-data convention, src/LTE-Tracker.cpp:791
 
-  // frequency-offset and carrier grids (src/CellSearch.cpp:463-465)
-  const int n_extra = (int)floor((freq_start * ppm / 1e6 + 2.5e3) / 5e3);
+  // frequency-offset hypotheses and carrier raster (src/CellSearch.cpp:463-465; n_extra uses freq_start only)
+  const int n_extra = (int)std::floor((opt.freq_start * opt.ppm / 1e6 + 2.5e3) / 5e3);
   lcsc::vec f_search_set(2 * n_extra + 1);
-  for (int i = 0; i < 2 * n_extra + 1; ++i) f_search_set(i) = -n_extra * 5000.0 + 5000.0 * i;
-  const int n_fc = (int)floor((freq_end - freq_start) / 100e3) + 1;
+  for (int i = 0; i <= 2 * n_extra; ++i) f_search_set(i) = 5000.0 * (i - n_extra);
+  const int n_fc = (int)std::floor((opt.freq_end - opt.freq_start) / 100e3) + 1;
 
-  lcs::Searcher *searcher = 0;
   try {
-    searcher = new lcs::Searcher(gpu);
-  } catch (const std::exception &e) {
-    cerr << "Error: " << e.what() << endl;
+    lcs::Searcher searcher((int)opt.gpu);
+    std::vector<std::list<Cell> > detected(n_fc);
+    const int kBatch = 64;                                   // carriers per GPU batch (one correlation launch)
+    for (int first = 0; first < n_fc; first += kBatch) {
+      const int n = std::min(kBatch, n_fc - first);
+      // read the batch's captures
+      std::vector<Capture> caps(n);
+      for (int k = 0; k < n; ++k) {
+        const std::string path = opt.data_dir + fmt("/capbuf_%04d.it", first + k);
+        if (opt.verbosity >= 2) std::cout << "Reading captured data from file: " << path << std::endl;
+        caps[k] = read_capture(path, opt.freq_start + 100e3 * (first + k));
+      }
+      // raw-byte captures of one length go through the int8 path together; the rest one by one as complex<double>
+      std::vector<int> bytes_idx;
+      for (int k = 0; k < n; ++k)
+        if (!caps[k].iq_u8.empty() && caps[k].samples.size() == caps[0].samples.size()) bytes_idx.push_back(k);
+      if (!bytes_idx.empty()) {
+        const size_t n_cap = caps[bytes_idx[0]].samples.size();
+        std::vector<unsigned char> host(bytes_idx.size() * 2 * n_cap);
+        std::vector<double> fcs(bytes_idx.size());
+        for (size_t j = 0; j < bytes_idx.size(); ++j) {
+          std::memcpy(&host[j * 2 * n_cap], caps[bytes_idx[j]].iq_u8.data(), 2 * n_cap);
+          fcs[j] = opt.freq_start + 100e3 * (first + bytes_idx[j]);
+        }
+        std::vector<std::list<Cell> > found;
+        searcher.search_batch_host(host.data(), LCS_FMT_IQ_U8, (int)bytes_idx.size(), (uint32_t)n_cap, f_search_set, fcs, fcs,
+                                   fs_programmed, found);
+        if (searcher.last_batch_overflowed()) std::cerr << "Warning: more cells than the result arrays hold; list truncated" << std::endl;
+        for (size_t j = 0; j < bytes_idx.size(); ++j) detected[first + bytes_idx[j]].swap(found[j]);
+      }
+      for (int k = 0; k < n; ++k) {
+        const double fc_requested = opt.freq_start + 100e3 * (first + k);
+        const bool batched = std::find(bytes_idx.begin(), bytes_idx.end(), k) != bytes_idx.end();
+        if (!batched) {
+          lcsc::cvec capbuf((int)caps[k].samples.size());
+          std::memcpy(capbuf._data(), caps[k].samples.data(), caps[k].samples.size() * sizeof(std::complex<double>));
+          searcher.search_capbuf(capbuf, f_search_set, fc_requested, fc_requested, fs_programmed, detected[first + k]);
+        }
+        // the reference's per-carrier report, in carrier order
+        if (opt.verbosity >= 1) std::cout << "Examining center frequency " << num(fc_requested / 1e6) << " MHz ..." << std::endl;
+        if (!caps[k].fc_matches)
+          std::cout << "Warning: while reading capture buffer " << first + k << ", the read\n"
+                    << "center frequency did not match the expected center frequency." << std::endl;
+        if (opt.verbosity >= 2) std::cout << "  PSS correlation, peak search, SSS, FOE, TFG and MIB decoding ran on the GPU ("
+                                          << (batched ? "int8 batch" : "fp32 single buffer") << ")" << std::endl;
+        if (opt.verbosity >= 1) announce(detected[first + k]);
+      }
+    }
+
+    const std::vector<Cell> cells = merge_duplicates(detected);
+    if (cells.empty()) {
+      std::cout << "No LTE cells were found..." << std::endl;
+    } else {
+      std::cout << "Detected the following cells:\n"
+                << "A: #antenna ports C: CP type ; P: PHICH duration ; PR: PHICH resource type\n"
+                << "CID A      fc   foff RXPWR C nRB P  PR CrystalCorrectionFactor\n";
+      for (const Cell &c : cells) std::cout << table_row(c, opt.correction) << "\n";
+      std::cout.flush();
+    }
+  } catch (const lcs::error &e) {
+    std::cerr << "Error: " << e.what() << std::endl;
     return 2;
-  }
-
-  vector<list<Cell> > detected_cells(n_fc);
-  for (int fci = 0; fci < n_fc; fci++) {
-    const double fc_requested = freq_start + 100e3 * fci;
-    if (verbosity >= 1) cout << "Examining center frequency " << fc_requested / 1e6 << " MHz ..." << endl;
-    stringstream filename;
-    filename << data_dir << "/capbuf_" << setw(4) << setfill('0') << fci << ".it";
-    if (verbosity >= 2) cout << "Reading captured data from file: " << filename.str() << endl;
-    lcsc::cvec capbuf;
-    try {
-      map<string, itfile::Var> vars = itfile::read_all(filename.str());
-      vector<complex<double> > cb = itfile::get_dcvec(vars, "capbuf");
-      vector<int32_t> fc_v = itfile::get_ivec(vars, "fc");
-      capbuf.set_size((int)cb.size());
-      for (size_t i = 0; i < cb.size(); ++i) capbuf((int)i) = cb[i];
-      if (fc_v.empty() || fc_requested != fc_v[0]) {
-        cout << "Warning: while reading capture buffer " << fci << ", the read" << endl;
-        cout << "center frequency did not match the expected center frequency." << endl;
-      }
-    } catch (const std::exception &e) {
-      cerr << "Error: " << e.what() << endl;
-      delete searcher;
-      return 3;
-    }
-    const double fc_programmed = fc_requested;
-    if (verbosity >= 2) cout << "  Calculating PSS correlations and examining correlation peaks (GPU)..." << endl;
-    try {
-      searcher->search_capbuf(capbuf, f_search_set, fc_requested, fc_programmed, fs_programmed, detected_cells[fci]);
-    } catch (const std::exception &e) {
-      cerr << "Error: " << e.what() << endl;
-      delete searcher;
-      return 4;
-    }
-    if (verbosity >= 1) {
-      for (list<Cell>::iterator it = detected_cells[fci].begin(); it != detected_cells[fci].end(); ++it) {
-        cout << "  Detected a cell!" << endl;
-        cout << "    cell ID: " << it->n_id_cell() << endl;
-        cout << "    RX power level: " << db10(it->pss_pow) << " dB" << endl;
-        cout << "    residual frequency offset: " << it->freq_superfine << " Hz" << endl;
-      }
-    }
-  }
-  delete searcher;
-
-  list<Cell> cells_final;
-  dedup(detected_cells, cells_final);
-  if (cells_final.size() == 0) {
-    cout << "No LTE cells were found..." << endl;
-  } else {
-    cout << "Detected the following cells:" << endl;
-    cout << "A: #antenna ports C: CP type ; P: PHICH duration ; PR: PHICH resource type" << endl;
-    cout << "CID A      fc   foff RXPWR C nRB P  PR CrystalCorrectionFactor" << endl;
-    for (list<Cell>::iterator it = cells_final.begin(); it != cells_final.end(); ++it) {
-      stringstream ss;
-      ss << setw(3) << it->n_id_cell();
-      ss << setw(2) << it->n_ports;
-      ss << " " << setw(6) << setprecision(5) << it->fc_requested / 1e6 << "M";
-      ss << " " << freq_formatter(it->freq_superfine);
-      ss << " " << setw(5) << setprecision(3) << db10(it->pss_pow);
-      ss << " " << ((it->cp_type == LCS_CP_NORMAL) ? "N" : ((it->cp_type == LCS_CP_UNKNOWN) ? "U" : "E"));
-      ss << " " << setw(3) << it->n_rb_dl;
-      ss << " " << ((it->phich_duration == 1) ? "N" : ((it->phich_duration == 0) ? "U" : "E"));
-      switch (it->phich_resource) {
-        case 0: ss << " UNK"; break;
-        case 1: ss << " 1/6"; break;
-        case 2: ss << " 1/2"; break;
-        case 3: ss << " one"; break;
-        case 4: ss << " two"; break;
-      }
-      const double true_location = it->fc_requested;
-      const double crystal_freq_actual = it->fc_requested - it->freq_superfine;
-      const double correction_residual = true_location / crystal_freq_actual;
-      const double correction_new = correction * correction_residual;
-      ss << " " << setprecision(20) << correction_new;
-      cout << ss.str() << endl;
-    }
+  } catch (const std::exception &e) {
+    std::cerr << "Error: " << e.what() << std::endl;
+    return 3;
   }
   return 0;
 }

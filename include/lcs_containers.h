@@ -30,6 +30,7 @@ class Vec {
   const T &operator[](int i) const { return d_[i]; }
   T *_data() { return d_.data(); }
   const T *_data() const { return d_.data(); }
+  void del(int i) { d_.erase(d_.begin() + i); }       // itpp::Vec::del
 
  private:
   std::vector<T> d_;

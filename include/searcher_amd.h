@@ -192,6 +192,25 @@ class Searcher {
     for (int i = 0; i < n && i < (int)out.size(); ++i) cells.push_back(Cell(out[i]));
   }
 
+  // A sweep's worth of recorded captures at once (the carrier loop of src/CellSearch.cpp:471-569): n_buf host buffers
+  // of n_cap samples each as raw RTL-SDR bytes (LCS_FMT_IQ_U8; captures are exactly (u8-127)/128, src/capbuf.cpp:
+  // 172-181) or complex<float> (LCS_FMT_C64), one carrier frequency per buffer.  cells[b] receives buffer b's cells.
+  void search_batch_host(const void *h_capbufs, int fmt, int n_buf, uint32_t n_cap, const cn::vec &f_search_set,
+                         const std::vector<double> &fc_requested, const std::vector<double> &fc_programmed,
+                         double fs_programmed, std::vector<std::list<Cell> > &cells, int max_cells_per_buf = 16) {
+    std::vector<lcs_cell> out((size_t)n_buf * max_cells_per_buf);
+    std::vector<int> cnt(n_buf);
+    const int rc = lcs_search_batch_host(h_, h_capbufs, fmt, n_buf, n_cap, f_search_set._data(), (uint16_t)f_search_set.length(),
+                                         &fc_requested[0], &fc_programmed[0], fs_programmed, LCS_STAGE_FULL, out.data(),
+                                         max_cells_per_buf, cnt.data());
+    if (rc != LCS_OK && rc != LCS_ERR_OVERFLOW) check(rc);
+    overflowed_ = rc == LCS_ERR_OVERFLOW;
+    cells.assign(n_buf, std::list<Cell>());
+    for (int b = 0; b < n_buf; ++b)
+      for (int i = 0; i < cnt[b] && i < max_cells_per_buf; ++i) cells[b].push_back(Cell(out[(size_t)b * max_cells_per_buf + i]));
+  }
+  bool last_batch_overflowed() const { return overflowed_; }     // more cells than the arrays hold: results truncated
+
   // LO calibration step of LTE-Tracker (src/LTE-Tracker.cpp:565-741) on one recorded buffer: search the
   // +-ppm grid shifted by the current correction (:586), keep the strongest decoded cell (:712-722) and
   // return its residual frequency offset; *correction_residual gets the factor of :724-731.  Returns
@@ -255,6 +274,7 @@ class Searcher {
         m(r, c) = std::complex<double>(g[((size_t)r * LCS_TFG_NSC + c) * 2], g[((size_t)r * LCS_TFG_NSC + c) * 2 + 1]);
   }
   lcs_ctx *h_;
+  bool overflowed_ = false;
 };
 
 }  // namespace lcs

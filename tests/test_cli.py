@@ -9,6 +9,7 @@ import pytest
 from conftest import ROOT, golden, iq_u8_to_capbuf, load_pkg
 
 EXE = os.path.join(ROOT, "host", "CellSearch")
+SHIM = os.path.join(ROOT, "host", "test_shim")
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -21,6 +22,7 @@ def _run(args, **kw):
 
 
 def test_help_lists_reference_options():
+    assert _run(["--help"]).stdout == _run(["-h"]).stdout
     out = _run(["-h"]).stdout
     for opt in ("-s --freq-start", "-e --freq-end", "-p --ppm", "-c --correction", "-r --record", "-l --load",
                 "-d --data-dir", "-i --device-index", "-v --verbose", "-b --brief"):
@@ -34,6 +36,42 @@ def test_argument_errors_match_reference_messages():
     r = _run(["-s", "739049999", "-l", "-d", "/nonexistent"])
     assert "start frequency has been rounded to the nearest multiple of 100kHz" in r.stdout
     assert "use --load" in _run(["-s", "739e6"]).stderr
+
+
+def test_option_forms_and_cli_source_is_not_a_transcription():
+    """Short/long/attached/= forms of one option all parse; and the CLI shares the reference's strings, not its code:
+    with string literals and comments removed, few of its token 12-grams may occur in src/CellSearch.cpp."""
+    for form in (["-s", "739e6"], ["-s739e6"], ["--freq-start", "739e6"], ["--freq-start=739e6"]):
+        r = _run(form + ["-b"])
+        assert "use --load" in r.stderr, (form, r.stderr)
+    assert "could not parse ppm value" in _run(["-s", "739e6", "-p", "12x"]).stderr
+    assert "unknown/extra arguments" in _run(["-s", "739e6", "stray"]).stderr
+    ref = "/root/reference/src/CellSearch.cpp"
+    if not os.path.exists(ref):
+        pytest.skip("reference tree not present on this box")
+
+    def tokens(path):
+        t = open(path).read()
+        t = re.sub(r"/\*.*?\*/", " ", t, flags=re.S)
+        t = re.sub(r"//[^\n]*", " ", t)
+        t = re.sub(r'"(?:\\.|[^"\\])*"', '""', t)
+        return re.findall(r"[A-Za-z_][A-Za-z_0-9]*|\d+(?:\.\d+)?(?:[eE][-+]?\d+)?|\S", t)
+
+    mine, theirs = tokens(os.path.join(ROOT, "host", "CellSearch.cpp")), tokens(ref)
+    grams = {tuple(theirs[i:i + 12]) for i in range(len(theirs) - 11)}
+    hit = sum(tuple(mine[i:i + 12]) in grams for i in range(len(mine) - 11))
+    assert hit / max(1, len(mine) - 11) < 0.05, hit / (len(mine) - 11)
+
+
+def test_shim_links_against_the_reference_signatures_and_del_oob():
+    """host/searcher_shim.cpp defines the reference's eight free functions (include/searcher.h:22-124) with their exact
+    signatures; host/test_shim.cpp calls them like src/CellSearch.cpp:484-558 does.  del_oob is host-only."""
+    r = subprocess.run([SHIM, "--del-oob"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and "del_oob ok" in r.stdout
+    syms = subprocess.run(["nm", "-C", os.path.join(ROOT, "host", "searcher_shim.o")], capture_output=True, text=True).stdout
+    for fn in ("xcorr_pss(", "peak_search(", "sss_detect(", "pss_sss_foe(", "extract_tfg(", "tfoec(", "decode_mib(", "del_oob("):
+        assert re.search(r" T " + re.escape(fn), syms), fn
+    assert re.search(r" T tfoec\(Cell const&, .*RS_DL const&", syms) and re.search(r" T decode_mib\(Cell const&, .*RS_DL const&\)", syms)
 
 
 def test_no_gpu_is_a_loud_failure():
@@ -65,3 +103,42 @@ def test_fulltest_known_answer(tmp_path):
     pkg_it.write_it(str(tmp_path / "capbuf_0000.it"), {"capbuf": noise, "fc": np.array([800000000], np.int32)})
     r = _run(["-s", "800000000", "-l", "-d", str(tmp_path), "-b"])
     assert r.returncode == 0 and "No LTE cells were found..." in r.stdout
+
+
+@pytest.mark.gpu
+def test_shim_runs_the_reference_call_sequence(tmp_path):
+    """The reference's seven functions, called in the reference's order through the shim, decode the golden buffer."""
+    pkg = load_pkg()
+    g = golden("capbuf_0000")
+    pkg_it = __import__("importlib").import_module("lte_cell_scanner_amd.itfile")
+    pkg_it.write_it(str(tmp_path / "capbuf_0000.it"), {"capbuf": iq_u8_to_capbuf(g["iq_u8"]), "fc": g["fc"].astype(np.int32)})
+    r = subprocess.run([SHIM, str(tmp_path / "capbuf_0000.it")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    assert "n_comb_xc 15 n_comb_sp 15 peaks 4" in r.stdout
+    rows = [l.split() for l in r.stdout.splitlines() if l.startswith("cell ")]
+    got = {int(x[1]): dict(zip(x[2::2], x[3::2])) for x in rows}
+    assert sorted(got) == [271, 277]
+    assert got[277]["sfn"] == "74" and got[271]["sfn"] == "22" and all(v["ports"] == "2" and v["n_rb_dl"] == "50" and v["tfg_rows"] == "854" for v in got.values())
+    assert abs(float(got[277]["freq_superfine"]) - 35228.46) < 0.5 and abs(float(got[271]["freq_superfine"]) - 35231.34) < 0.5
+
+
+@pytest.mark.gpu
+def test_sweep_mixes_byte_exact_and_arbitrary_captures(tmp_path):
+    """Three carriers: two recorded (byte-exact -> one int8 batch), one arbitrary complex buffer in between (-> single
+    fp32 search).  Output order, duplicate merging across carriers and the table must follow the reference's rules."""
+    pkg = load_pkg()
+    g = golden("capbuf_0000")
+    it = __import__("importlib").import_module("lte_cell_scanner_amd.itfile")
+    cap = iq_u8_to_capbuf(g["iq_u8"])
+    rng = np.random.default_rng(5)
+    arb = 0.05 * (rng.normal(size=153600) + 1j * rng.normal(size=153600))
+    it.write_it(str(tmp_path / "capbuf_0000.it"), {"capbuf": cap, "fc": np.array([738900000], np.int32)})
+    it.write_it(str(tmp_path / "capbuf_0001.it"), {"capbuf": arb, "fc": np.array([739000000], np.int32)})
+    it.write_it(str(tmp_path / "capbuf_0002.it"), {"capbuf": 0.5 * cap, "fc": np.array([739100000], np.int32)})   # not byte-exact any more... half-codes
+    r = _run(["-s", "738.9e6", "-e", "739.1e6", "-l", "-d", str(tmp_path)])
+    assert r.returncode == 0, r.stderr
+    ex = [l for l in r.stdout.splitlines() if l.startswith("Examining")]
+    assert ex == ["Examining center frequency 738.9 MHz ...", "Examining center frequency 739 MHz ...", "Examining center frequency 739.1 MHz ..."]
+    # the same two cells are seen on carriers 0 and 2 (200 kHz apart: within the 1 MHz merge window); the stronger copy (carrier 0) stays
+    table = r.stdout.split("CrystalCorrectionFactor\n")[1].splitlines()
+    assert len(table) == 2 and all(re.match(r"^(277|271) 2  738\.9M", l) for l in table), table
