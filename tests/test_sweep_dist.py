@@ -1,6 +1,8 @@
-"""The multi-GPU path (carrier sweep sharded over ranks + one all-gather of cell records) on CPU:
-world_size 2 over gloo.  The per-buffer searcher is stood in for by the CPU oracle here (tests
-only) -- what is under test is the sharding, the record packing, the collective and dedup."""
+"""The multi-GPU paths on CPU, world_size 2 over gloo: (1) the carrier sweep sharded over ranks + one all-gather of
+cell records, (2) the frequency-hypothesis split of ONE buffer with its packed MAX-with-index all-reduce.  The
+per-buffer searcher is stood in for by the CPU oracle here (tests only) -- what is under test is the sharding, the
+record packing, the collectives, the tie-break and dedup.  The `-m gpu` tests at the bottom run the same drivers with
+the real GPU searcher under two ranks sharing one GPU."""
 import os
 import subprocess
 import sys
@@ -56,16 +58,46 @@ WORKER = textwrap.dedent("""
 """)
 
 
-def _run(world, tmp_path):
+FOE_WORKER = textwrap.dedent("""
+    import os, sys, json, hashlib
+    import numpy as np
+    import torch, torch.distributed as dist
+    sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "oracle")); sys.path.insert(0, os.path.join({root!r}, "tests"))
+    from conftest import load_pkg, golden, iq_u8_to_capbuf
+    pkg = load_pkg()
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    use_gpu = {use_gpu!r}
+    if world > 1:
+        dist.init_process_group("gloo")
+    if use_gpu:
+        S = pkg.Searcher(0)
+        stages = pkg.sweep.SearcherStages(S, pkg.z_th1)
+    else:
+        import oracle as O
+        O.set_threads(2)
+        stages = O
+    cap = iq_u8_to_capbuf(golden("capbuf_0000")["iq_u8"])
+    f = np.array([25e3, 30e3, 35e3, 35e3, 40e3, 45e3, 50e3])        # duplicate hypothesis: the tie must go to the lower index
+    cells, arr = pkg.sweep.search_capbuf_foe_split(stages, cap, f, 739e6, 739e6, 1.92e6, rank, world, dist if world > 1 else None)
+    if rank == 0:
+        print("RESULT " + json.dumps(dict(cells=[(c["n_id_cell"], c["n_rb_dl"], c["sfn"], c["ind"], c["freq"], repr(c["pss_pow"]), repr(c["freq_superfine"])) for c in cells],
+                                          pow=hashlib.sha256(arr["pow"].tobytes()).hexdigest(), frq=hashlib.sha256(arr["frq"].tobytes()).hexdigest(),
+                                          n_dup_wins=int(np.count_nonzero(arr["frq"] == 3)))))
+    if world > 1:
+        dist.destroy_process_group()
+""")
+
+
+def _run(world, tmp_path, worker=None, port="29541", **fmt):
     script = tmp_path / "worker.py"
-    script.write_text(WORKER.format(root=ROOT))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", OMP_NUM_THREADS="2")
+    script.write_text((worker or WORKER).format(root=ROOT, **fmt))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, OMP_NUM_THREADS="2", GPU_MAX_HW_QUEUES="8")
     if world == 1:
         env.update(RANK="0", WORLD_SIZE="1")
         cmd = [sys.executable, str(script)]
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
-               "--master-addr", "127.0.0.1", "--master-port", "29541", str(script)]
+               "--master-addr", "127.0.0.1", "--master-port", port, str(script)]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("RESULT ")][-1]
@@ -81,3 +113,49 @@ def test_two_rank_sweep_matches_single_rank(tmp_path):
     assert one["per"][1] == [277, 271] and one["per"][2] == [277, 271]
     # each cell is reported once after dedup (the two sightings are 100 kHz apart)
     assert sorted(c[0] for c in one["final"]) == [271, 277] and all(c[2] == 50 for c in one["final"])
+
+
+def test_pack_unpack_and_tie_break():
+    """bits(pow) << 32 | ~foi: MAX over ranks = the reference's first maximum over the frequency axis (:369-382)."""
+    sw = load_pkg().sweep
+    pow_a, frq_a = np.array([[0.5, 0.25, 0.0, 1e-30]]), np.array([[4, 2, 0, 1]])
+    pow_b, frq_b = np.array([[0.5, 0.26, 0.0, 1e-30]]), np.array([[1, 7, 3, 0]])
+    w = np.maximum(sw.pack_pow_frq(pow_a, frq_a), sw.pack_pow_frq(pow_b, frq_b))
+    p, f = sw.unpack_pow_frq(w)
+    assert np.array_equal(f, [[1, 7, 0, 0]]) and np.array_equal(p, np.array([[0.5, 0.26, 0.0, 1e-30]]).astype(np.float32).astype(np.float64))
+    assert [list(b) for b in sw.foe_blocks(7, 2)] == [[0, 1, 2, 3], [4, 5, 6]] and [len(b) for b in sw.foe_blocks(3, 8)].count(0) == 5
+    assert np.array_equal(np.concatenate(sw.foe_blocks(37, 8)), np.arange(37))
+
+
+def test_foe_split_two_ranks_equal_single_rank(tmp_path):
+    """Collapsed (pow, frq) after the packed all-reduce are bit-identical to the single-rank arrays, the duplicate
+    hypothesis (index 3 == index 2) never wins, and the decoded cells come back in the single-rank order."""
+    one = _run(1, tmp_path, FOE_WORKER, "29543", use_gpu=False)
+    two = _run(2, tmp_path, FOE_WORKER, "29543", use_gpu=False)
+    assert one == two
+    assert one["n_dup_wins"] == 0 and [c[0] for c in one["cells"]] == [277, 271] and [c[2] for c in one["cells"]] == [74, 22]
+
+
+@pytest.mark.gpu
+def test_foe_split_two_ranks_real_searcher(tmp_path):
+    one = _run(1, tmp_path, FOE_WORKER, "29545", use_gpu=True)
+    two = _run(2, tmp_path, FOE_WORKER, "29545", use_gpu=True)
+    assert one == two and [c[0] for c in one["cells"]] == [277, 271]
+
+
+@pytest.mark.gpu
+def test_two_rank_sweep_real_searcher_shared_gpu(tmp_path):
+    """tools/sweep_cellsearch.py with two ranks sharing GPU 0 (gloo) against one rank: same table, real Searcher."""
+    import json
+    tool = os.path.join(ROOT, "tools", "sweep_cellsearch.py")
+    args = ["-s", "738e6", "-e", "740.3e6", "--occupied-every", "5", "--json"]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", GPU_MAX_HW_QUEUES="8")
+    a = subprocess.run([sys.executable, tool] + args, env=env, capture_output=True, text=True, timeout=600)
+    assert a.returncode == 0, a.stderr[-2000:]
+    b = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29547", tool] + args + ["--share-gpu0", "--dist-backend", "gloo"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert b.returncode == 0, b.stderr[-2000:]
+    ja = json.loads([l for l in a.stdout.splitlines() if l.startswith("{")][-1])
+    jb = json.loads([l for l in b.stdout.splitlines() if l.startswith("{")][-1])
+    assert ja["cells"] == jb["cells"] and ja["carriers"] == jb["carriers"] == 24 and len(ja["cells"]) >= 3

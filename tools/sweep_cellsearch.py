@@ -11,7 +11,10 @@ sharded block-cyclically over the ranks (lte-cell-scanner_amd/sweep.py); every r
 carriers through the device-resident batch API in batches that fit HBM, and the detected-cell records
 are all-gathered ONCE at the end (RCCL).  Capture buffers come from --load DIR (capbuf_NNNN.it files
 as written by `CellSearch --record`) or are synthesised (most carriers empty, every `--occupied-every`-th
-carries 1-2 cells), since a GPU node has no SDR.
+carries 1-2 cells), since a GPU node has no SDR.  Every rank's buffers are made RESIDENT IN HBM before the clock
+starts (noise-only carriers are drawn on the device, occupied ones come from the numpy generator), so the reported
+time is the search, not the signal generator; --write-it DIR dumps the same sweep as capbuf_NNNN.it files for the
+C++ CLI (host/CellSearch -l -d DIR).
 """
 from __future__ import annotations
 
@@ -53,6 +56,7 @@ def main():
     ap.add_argument("--dist-backend", default="nccl")
     ap.add_argument("--share-gpu0", action="store_true", help="testing only: every rank uses GPU 0")
     ap.add_argument("--json", action="store_true", help="print a JSON summary line instead of the table")
+    ap.add_argument("--write-it", default=None, help="also write every carrier's buffer as capbuf_NNNN.it into this directory")
     args = ap.parse_args()
 
     import torch
@@ -79,35 +83,49 @@ def main():
     f_set = pkg.f_search_set_for(fs_, args.ppm)
     fs_prog = FS * args.correction
 
-    if args.load:
-        def get_capbufs(idx):
-            out = np.empty((len(idx), 2 * N_CAP), np.uint8)
-            for j, ci in enumerate(idx):
-                cap = np.asarray(pkg.itfile.read_it(os.path.join(args.load, f"capbuf_{ci:04d}.it"))["capbuf"]).ravel()
-                iq = np.empty(2 * N_CAP)
-                iq[0::2], iq[1::2] = cap.real[:N_CAP], cap.imag[:N_CAP]
-                out[j] = np.clip(np.rint(iq * 128.0 + 127.0), 0, 255).astype(np.uint8)
-            return out
-    else:
-        def get_capbufs(idx):       # a carrier's buffer depends on its index only: the same band whatever the sharding
-            out = np.empty((len(idx), 2 * N_CAP), np.uint8)
-            for j, ci in enumerate(idx):
-                rng = np.random.default_rng(args.seed + int(ci))
-                if ci % args.occupied_every == 0:
-                    cells = [dict(n_id_1=int(rng.integers(0, 168)), n_id_2=int(rng.integers(0, 3)), cp_normal=bool(rng.integers(0, 8) != 0),
-                                  n_ports=int((1, 2, 2, 4)[rng.integers(0, 4)]), n_rb_dl=int((6, 15, 25, 50, 75, 100)[rng.integers(0, 6)]),
-                                  f_off=float(rng.uniform(-60e3, 60e3)), gain_db=-3.0 * k) for k in range(1 + int(rng.integers(0, 2)))]
-                    out[j] = pkg.synth.make_capbuf(args.seed + int(ci), float(fcs[ci]), cells, snr_db=float(rng.uniform(0, 10)))[0]
-                else:
-                    out[j] = np.clip(np.rint(rng.normal(127.0, 12.0, 2 * N_CAP)), 0, 255).astype(np.uint8)
-            return out
+    mine = sw.shard(len(fcs), rank, world)
+    t_gen = time.perf_counter()
+    resident = torch.empty((len(mine), 2 * N_CAP), dtype=torch.uint8, device=dev)      # this rank's carriers, in HBM
+    truth = {}
+    for j, ci in enumerate(mine):
+        ci = int(ci)
+        if args.load:
+            cap = np.asarray(pkg.itfile.read_it(os.path.join(args.load, f"capbuf_{ci:04d}.it"))["capbuf"]).ravel()
+            iq = np.empty(2 * N_CAP)
+            iq[0::2], iq[1::2] = cap.real[:N_CAP], cap.imag[:N_CAP]
+            resident[j] = torch.from_numpy(np.clip(np.rint(iq * 128.0 + 127.0), 0, 255).astype(np.uint8)).to(dev)
+        elif ci % args.occupied_every == 0:     # a carrier's buffer depends on its index only: the same band whatever the sharding
+            rng = np.random.default_rng(args.seed + ci)
+            cells = [dict(n_id_1=int(rng.integers(0, 168)), n_id_2=int(rng.integers(0, 3)), cp_normal=bool(rng.integers(0, 8) != 0),
+                          n_ports=int((1, 2, 2, 4)[rng.integers(0, 4)]), n_rb_dl=int((6, 15, 25, 50, 75, 100)[rng.integers(0, 6)]),
+                          f_off=float(rng.uniform(-60e3, 60e3)), gain_db=-3.0 * k) for k in range(1 + int(rng.integers(0, 2)))]
+            resident[j] = torch.from_numpy(pkg.synth.make_capbuf(args.seed + ci, float(fcs[ci]), cells, snr_db=float(rng.uniform(0, 10)))[0]).to(dev)
+            truth[ci] = [c["n_id_2"] + 3 * c["n_id_1"] for c in cells]
+        else:                                   # receiver noise only, drawn on the device (seeded by the carrier index)
+            gen = torch.Generator(device=dev)
+            gen.manual_seed(args.seed + ci)
+            resident[j] = torch.clamp(torch.round(torch.randn(2 * N_CAP, device=dev, generator=gen) * 12.0 + 127.0), 0, 255).to(torch.uint8)
+    torch.cuda.synchronize()
+    t_gen = time.perf_counter() - t_gen
+    if args.write_it:
+        os.makedirs(args.write_it, exist_ok=True)
+        for j, ci in enumerate(mine):
+            iq = resident[j].cpu().numpy().astype(np.float64)
+            pkg.itfile.write_it(os.path.join(args.write_it, f"capbuf_{int(ci):04d}.it"),
+                                {"capbuf": ((iq[0::2] - 127.0) / 128.0) + 1j * ((iq[1::2] - 127.0) / 128.0), "fc": np.array([int(fcs[ci])], np.int32)})
+    pos = {int(ci): j for j, ci in enumerate(mine)}
+
+    def get_capbufs(idx):          # a contiguous run of this rank's resident buffers (run_sweep walks `mine` in order)
+        return resident[pos[int(idx[0])]: pos[int(idx[0])] + len(idx)]
 
     S = pkg.Searcher(local)
 
     def search_fn(bufs, fc):
-        d = torch.from_numpy(np.ascontiguousarray(bufs)).to(dev)
-        return S.search_batch(d.data_ptr(), pkg.FMT_IQ_U8, len(bufs), N_CAP, f_set, fc, fc, fs_prog, pkg.STAGE_FULL)
+        S.batch_enqueue(bufs.data_ptr(), pkg.FMT_IQ_U8, len(fc), N_CAP, f_set, fc, fc, fs_prog, pkg.STAGE_FULL)
+        return S.batch_collect_raw(len(fc), sw.MAXC)
 
+    if len(mine):      # warm-up: workspace allocation, first launches
+        search_fn(get_capbufs(mine[:min(len(mine), args.batch)]), fcs[mine[:min(len(mine), args.batch)]])
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -118,8 +136,9 @@ def main():
     dt = time.perf_counter() - t0
     if rank == 0:
         if args.json:
-            print(json.dumps({"carriers": int(len(fcs)), "n_f": int(len(f_set)), "n_gpus": world, "seconds": dt,
-                              "carriers_per_s_incl_generation": len(fcs) / dt,
+            print(json.dumps({"carriers": int(len(fcs)), "n_f": int(len(f_set)), "n_gpus": world, "seconds_search": dt,
+                              "carriers_per_s": len(fcs) / dt, "seconds_making_buffers_resident_rank0": t_gen,
+                              "planted": {str(k): v for k, v in sorted(truth.items())} if world == 1 else None,
                               "cells": [(c["n_id_cell"], c["fc_requested"], c["n_rb_dl"], c["n_ports"]) for c in final]}))
         elif not final:
             print("No LTE cells were found...")
