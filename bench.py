@@ -173,6 +173,89 @@ def stream_bench(pkg, args, rank, world, local_rank, dist):
         dist.destroy_process_group()
 
 
+def track_bench(pkg, args, rank, world, local_rank, dist):
+    """LTE-Tracker's per-symbol pipeline.  A step = one block of 980 OFDM symbols (7 frames, 70 ms of air
+    time) for --batch tracked cells, time-domain symbols resident in HBM; replicas only (cells are independent)."""
+    import torch
+    dev_i = local_rank if world > 1 else 0
+    g = np.load(os.path.join(ROOT, "tests", "golden", "capbuf_0000.npz"))
+    iq = g["iq_u8"].astype(np.float64)
+    cap = ((iq[0::2] - 127.0) / 128.0) + 1j * ((iq[1::2] - 127.0) / 128.0)
+    fc = float(g["fc"][0])
+    S = pkg.Searcher(dev_i)
+    found, _ = S.search_capbuf(cap, np.array([30e3, 35e3, 40e3]), fc, fc, FS)        # the cells to track: 277 and 271
+    n_sym, C = 980, args.batch
+    per = []
+    for c in found:
+        kf = (fc - c.freq_superfine) / fc
+        per.append(pkg.tracker.cut_symbols(cap, c.frame_start * (30.72e6 / 16) / (FS * kf), c.cp_type, c.freq_superfine, fc, fc, FS, n_sym))
+    cells = [found[i % len(found)] for i in range(C)]
+    td = np.stack([per[i % len(found)][0] for i in range(C)])
+    late = np.stack([per[i % len(found)][1] for i in range(C)])
+    ftv = np.stack([per[i % len(found)][2] for i in range(C)])
+    fov = np.stack([per[i % len(found)][3] for i in range(C)])
+    d_td = torch.from_numpy(td).to(torch.device("cuda", dev_i))
+    gpu_ms, locks = [], 0
+
+    def step():
+        nonlocal locks
+        r = S.track_block(cells, None, fov, ftv, late, fc, fc, FS, want_syms=False, want_ce=False, td_device_ptr=d_td.data_ptr(), n_sym=n_sym)
+        gpu_ms.append(r["gpu_ms"])
+        locks = int(np.count_nonzero(r["mib_ok"] == 3))
+        return r
+
+    for _ in range(max(1, args.warmup)):
+        step()
+    gpu_ms.clear()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        value = world * C * n_sym * args.steps / dt
+        out = {"metric": "OFDM symbols/s, LTE-Tracker per-symbol pipeline (get_fd + CRS channel estimate + FOE/TOE + MIB re-decode)",
+               "value": value, "unit": "OFDM-symbols/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+               "data": "symbols cut from tests/golden/capbuf_0000 (cells 277, 271), tiled over the tracked cells",
+               "config": {"workload": f"SURVEY 8 f4: {C} tracked cells x {n_sym} OFDM symbols (70 ms) per step, time-domain symbols resident in HBM",
+                          "tracked_cells": C, "symbols_per_block": n_sym, "gpu_ms_per_block": float(np.mean(gpu_ms)),
+                          "mib_locks_per_block": locks, "cells_in_real_time": value / world / 14000.0,
+                          "parallelism": "replicas" if world > 1 else "single GPU"}}
+        if not args.no_cpu_baseline:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import oracle as O
+            t1 = time.perf_counter()
+            n_done = 0
+            for i in range(min(4, C)):
+                c = O.Cell()
+                for fld in ("n_id_1", "n_id_2", "cp_type", "n_ports", "n_rb_dl", "phich_duration", "phich_resource"):
+                    setattr(c, fld, int(getattr(cells[i], fld)))
+                sy, _, _ = O.trk_get_fd(c, td[i], 0, 0, fov[i], late[i], fc, fc, FS)
+                r = O.trk_chan_est(c, sy, 0, 0, fov[i], ftv[i], fc, fc, FS)
+                for o in range(4):
+                    ii = [(o + fr) * 140 + 7 + s_ for fr in range(4) for s_ in range(4)]
+                    if ii[-1] < min(r["ce_upto"][:c.n_ports]):
+                        O.trk_mib(c, sy[ii], r["ce"][:c.n_ports][:, ii], r["ce_pw"][:c.n_ports][:, ii, 3])
+                n_done += n_sym
+            dtc = time.perf_counter() - t1
+            out["cpu_baseline"] = {"value": n_done / dtc, "unit": "OFDM-symbols/s", "cores": 1, "kind": "port",
+                                   "sample": f"{n_done} symbols (4 cells x one block) through the C oracle's restatement of the same pipeline, {dtc:.2f} s"}
+        print(json.dumps(out))
+    S.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def kernel_source_sha():
     """sha256 over the sources of the dominant kernel: roofline.traffic is only reported when the committed PMC
     summary was collected from exactly this code."""
@@ -197,10 +280,11 @@ def main():
     ap.add_argument("--batches-per-step", type=int, default=32, help="enqueues per step: a step is batch x this many buffers per GPU")
     ap.add_argument("--distinct", type=int, default=4, help="distinct resident batches the enqueues cycle through")
     ap.add_argument("--ppm", type=float, default=100.0)
-    ap.add_argument("--stage", choices=["pss", "full", "stream"], default="full",
+    ap.add_argument("--stage", choices=["pss", "full", "stream", "track"], default="full",
                     help="full = BASELINE configs[2], the whole CellSearch chain (default); pss = configs[1], xcorr_pss + "
                          "peak_search only; stream = configs[4], one host buffer at a time through the hipGraph-captured "
-                         "single-hypothesis chain (separate, shorter report)")
+                         "single-hypothesis chain (separate, shorter report); track = SURVEY 8 f4, LTE-Tracker's per-symbol "
+                         "pipeline on blocks of OFDM symbols of --batch tracked cells")
     ap.add_argument("--input", choices=["u8", "c64"], default="u8",
                     help="resident input format: raw RTL-SDR u8 I/Q (int8 MFMA correlation kernel, default) or complex<float> "
                          "(fp32 MFMA correlation kernel)")
@@ -238,6 +322,8 @@ def main():
 
     if args.stage == "stream":
         return stream_bench(pkg, args, rank, world, local_rank, dist)
+    if args.stage == "track":
+        return track_bench(pkg, args, rank, world, local_rank, dist)
     f = pkg.f_search_set_for(FC, args.ppm)
     stage_mask = pkg.STAGE_FULL if args.stage == "full" else pkg.STAGE_PSS
     B, K, D = args.batch, args.batches_per_step, max(1, args.distinct)

@@ -220,6 +220,38 @@ int lcs_stream_push(lcs_ctx *ctx, const void *samples, double f_off, const int16
 int lcs_stream_collect(lcs_ctx *ctx, lcs_cell *cells, int max_cells, int *n_cells, int *n_redetected, float *gpu_ms);
 int lcs_stream_close(lcs_ctx *ctx);
 
+/* ---- LTE-Tracker's per-symbol pipeline on blocks of OFDM symbols (src/tracker_thread.cpp:823-1068) ------------
+ * The reference tracks every detected cell with a thread that takes one OFDM symbol at a time: get_fd (:91-174), the
+ * cell-specific reference symbols, filter_ce (:176-201) with its power measurements (:906-931), the frequency and
+ * timing measurements of do_foe (:203-243) and do_toe_v2 (:245-288), interp2d (:383-477) and the MIB re-decode
+ * (pbch_extract_rt :494-529, do_mib_decode :531-749).  lcs_track_block does that work for a BLOCK of n_sym
+ * consecutive symbols (starting at slot 0 symbol 0 of a frame) of n_cells tracked cells at once.
+ *   td            [n_cells][n_sym][128] complex<double>: the samples the producer thread queues per symbol
+ *                 (src/producer_thread.cpp:196-246), in host memory or (td_on_device != 0) already in HBM
+ *   freq_off, frame_timing, late [n_cells][n_sym]: the capture metadata queued with every symbol (host)
+ *   cells         identity of each tracked cell; bulk_phase_offset is get_fd's running phase, in before / out after
+ * Outputs (host; NULL = not wanted):
+ *   syms          [n_cells][n_sym][72] complex: get_fd's output
+ *   ce, ce_pw     [n_cells][4][n_sym][72] complex channel estimate and [n_cells][4][n_sym][4] (tp, sp, sp_raw, np) after
+ *                 interp2d, valid for symbols < ce_upto[cell][port]
+ *   meas          [n_cells][4][max_rs][LCS_TRK_MEAS]: per filtered reference symbol: symbol index, np, tp, sp_raw, sp,
+ *                 frequency_offset + residual_f, residual_f_np (what do_foe feeds its recurrence, :235-242),
+ *                 rs_curr.frame_timing + delay, delay_np (do_toe_v2, :283-287); n_meas [n_cells][4] rows filled
+ *   mib_ok        [n_cells][max_off]: one decode attempt per frame offset o (frames o..o+3 of the block): bit 0 = CRC
+ *                 matches, bit 1 = bandwidth / PHICH fields equal the tracked cell's (lock test of :689-694 = both), -1 = not
+ *                 attempted (no channel estimate that far into the block); mib_bits: the 40 decoded bits, bit i = c_est(i)
+ * The scalar recurrences those results feed (global frequency offset, frame timing, the mib_decode_failures counter)
+ * stay with the caller (lte-cell-scanner_amd/tracker.py). */
+typedef struct lcs_track_cell {
+  int32_t n_id_1, n_id_2, cp_type, n_ports, n_rb_dl, phich_duration, phich_resource, reserved;
+  double bulk_phase_offset;
+} lcs_track_cell;
+#define LCS_TRK_MEAS 9
+int lcs_track_block(lcs_ctx *ctx, lcs_track_cell *cells, int n_cells, int n_sym, const void *td, int td_on_device,
+                    const double *freq_off, const double *frame_timing, const double *late, double fc_requested,
+                    double fc_programmed, double fs_programmed, double *syms, double *ce, double *ce_pw, int32_t *ce_upto,
+                    double *meas, int max_rs, int32_t *n_meas, int32_t *mib_ok, uint64_t *mib_bits, int max_off, float *gpu_ms);
+
 /* Stream the context launches on (hipStream_t as void*), for external event timing. */
 void *lcs_stream(lcs_ctx *ctx);
 int lcs_sync(lcs_ctx *ctx);

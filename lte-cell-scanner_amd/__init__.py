@@ -19,7 +19,8 @@ from . import capi
 from . import synth
 from . import sweep
 from . import itfile
-from .capi import LcsCell, FMT_C64, FMT_IQ_U8, STAGE_PSS, STAGE_FULL
+from . import tracker
+from .capi import LcsCell, LcsTrackCell, FMT_C64, FMT_IQ_U8, STAGE_PSS, STAGE_FULL
 
 FS_LTE = 30720000.0        # include/constants.h:32
 DS_COMB_ARM = 2            # src/CellSearch.cpp:484
@@ -247,6 +248,44 @@ class Searcher:
                      fs_programmed: float, stage_mask: int = STAGE_FULL, max_cells_per_buf: int = 16):
         self.batch_enqueue(d_ptr, fmt, n_buf, n_cap, f_search_set, fc_requested, fc_programmed, fs_programmed, stage_mask)
         return self.batch_collect(n_buf, max_cells_per_buf)
+
+    # ---- LTE-Tracker's per-symbol pipeline on a block of symbols (src/tracker_thread.cpp:823-1068) ----
+    def track_block(self, cells, td, freq_off, frame_timing, late, fc_requested, fc_programmed, fs_programmed,
+                    want_syms=True, want_ce=True, td_device_ptr=None, n_sym=None):
+        """cells: list of searcher records (LcsCell with n_id_1/2, cp_type, n_ports, n_rb_dl, PHICH fields) or LcsTrackCell;
+        td [n_cells][n_sym][128] complex128 (or a device pointer via td_device_ptr + n_sym); the metadata arrays are
+        [n_cells][n_sym].  Returns a dict (see lcs_track_block in include/lcs.h); 'bpo' = bulk phase after the block."""
+        n_cells = len(cells)
+        tc = (capi.LcsTrackCell * n_cells)()
+        for i, c in enumerate(cells):
+            for f in ("n_id_1", "n_id_2", "cp_type", "n_ports", "n_rb_dl", "phich_duration", "phich_resource"):
+                setattr(tc[i], f, int(getattr(c, f)))
+            tc[i].bulk_phase_offset = float(getattr(c, "bulk_phase_offset", 0.0))
+        fo = np.ascontiguousarray(freq_off, np.float64).reshape(n_cells, -1)
+        n_sym = fo.shape[1] if n_sym is None else n_sym
+        ft = np.ascontiguousarray(frame_timing, np.float64).reshape(n_cells, n_sym)
+        lt = np.ascontiguousarray(late, np.float64).reshape(n_cells, n_sym)
+        if td_device_ptr is None:
+            tdh = np.ascontiguousarray(td, np.complex128).reshape(n_cells, n_sym, 128)
+            tdp, on_dev = tdh.ctypes.data_as(C.c_void_p), 0
+        else:
+            tdp, on_dev = C.c_void_p(td_device_ptr), 1
+        max_rs, max_off = n_sym // 3 + 4, max(1, n_sym // 120 - 3)
+        out = dict(syms=np.empty((n_cells, n_sym, 72), np.complex128) if want_syms else None,
+                   ce=np.full((n_cells, 4, n_sym, 72), np.nan + 0j, np.complex128) if want_ce else None,
+                   ce_pw=np.full((n_cells, 4, n_sym, 4), np.nan) if want_ce else None,
+                   ce_upto=np.zeros((n_cells, 4), np.int32), meas=np.full((n_cells, 4, max_rs, 9), np.nan),
+                   n_meas=np.zeros((n_cells, 4), np.int32), mib_ok=np.full((n_cells, max_off), -1, np.int32),
+                   mib_bits=np.zeros((n_cells, max_off), np.uint64))
+        ms = C.c_float(0)
+        rc = self._lib.lcs_track_block(self._h, tc, n_cells, n_sym, tdp, on_dev, _dp(fo), _dp(ft), _dp(lt), fc_requested, fc_programmed,
+                                       fs_programmed, _dp(out["syms"]), _dp(out["ce"]), _dp(out["ce_pw"]), _ip(out["ce_upto"]),
+                                       _dp(out["meas"]), max_rs, _ip(out["n_meas"]), _ip(out["mib_ok"]),
+                                       out["mib_bits"].ctypes.data_as(C.POINTER(C.c_uint64)), max_off, C.byref(ms))
+        self._chk(rc, "lcs_track_block")
+        out["bpo"] = np.array([tc[i].bulk_phase_offset for i in range(n_cells)])
+        out["gpu_ms"] = ms.value
+        return out
 
     # ---- streaming mode (LTE-Tracker's searcher thread, src/searcher_thread.cpp:83-246) ----
     def stream_open(self, fmt: int, n_cap: int, fc_requested: float, fc_programmed: float, fs_programmed: float):

@@ -190,6 +190,12 @@ struct lcs_ctx {
   hipGraph_t st_graph = nullptr;
   hipGraphExec_t st_exec = nullptr;
   hipEvent_t st_ev0 = nullptr, st_ev1 = nullptr;
+  // tracker block pipeline (tracker.hip): workspace laid out for one (n_cells, n_sym) block shape
+  double2 *trk_td = nullptr, *trk_syms = nullptr, *trk_raw = nullptr, *trk_ce = nullptr;
+  double *trk_meta = nullptr, *trk_rs = nullptr, *trk_fmeta = nullptr, *trk_pw = nullptr;
+  int *trk_idx = nullptr, *trk_small = nullptr;
+  lcs_track_cell *trk_cells = nullptr;
+  int trk_cells_cap = 0, trk_sym_cap = 0;
   // host staging
   SlotParams h_params{};             // source of asynchronous parameter uploads of the single-buffer entry points
   void *h_pinned = nullptr;

@@ -1,0 +1,178 @@
+// lte_device.h -- device-side LTE helpers shared by the per-cell kernels (tfg_mib.hip) and the tracker kernels
+// (tracker.hip): complex fp64 arithmetic, the soft demodulator, and the tail of the PBCH decoder.
+#pragma once
+#include "lcs_internal.h"
+
+struct cd2 { double re, im; };
+__device__ __forceinline__ cd2 mk(double a, double b) { cd2 r; r.re = a; r.im = b; return r; }
+__device__ __forceinline__ cd2 cadd(cd2 a, cd2 b) { return mk(a.re + b.re, a.im + b.im); }
+__device__ __forceinline__ cd2 csub(cd2 a, cd2 b) { return mk(a.re - b.re, a.im - b.im); }
+__device__ __forceinline__ cd2 cmul(cd2 a, cd2 b) { return mk(a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re); }
+__device__ __forceinline__ cd2 cconj(cd2 a) { return mk(a.re, -a.im); }
+__device__ __forceinline__ cd2 cscale(cd2 a, double s) { return mk(a.re * s, a.im * s); }
+__device__ __forceinline__ cd2 cdivr(cd2 a, double s) { return mk(a.re / s, a.im / s); }
+__device__ __forceinline__ double cabs2(cd2 a) { return a.re * a.re + a.im * a.im; }
+__device__ __forceinline__ cd2 ld(const double2 *p) { const double2 v = *p; return mk(v.x, v.y); }
+__device__ __forceinline__ void st(double2 *p, cd2 v) { *p = make_double2(v.re, v.im); }
+// std::complex division for finite operands (libgcc __divdc3 main path)
+__device__ __forceinline__ cd2 cdiv(cd2 x, cd2 y) {
+  const double a = x.re, b = x.im, c = y.re, d = y.im;
+  if (fabs(c) < fabs(d)) {
+    const double ratio = c / d, denom = (c * ratio) + d;
+    return mk(((a * ratio) + b) / denom, ((b * ratio) - a) / denom);
+  }
+  const double ratio = d / c, denom = (d * ratio) + c;
+  return mk(((b * ratio) + a) / denom, (b - (a * ratio)) / denom);
+}
+__device__ __forceinline__ int d_round_i(double x) { return (int)rint(x); }
+__device__ __forceinline__ int d_imod(int k, int n) { int r = k % n; return r < 0 ? r + n : r; }
+__device__ __forceinline__ int cell_n_symb(const lcs_cell &c) { return c.cp_type == LCS_CP_NORMAL ? 7 : (c.cp_type == LCS_CP_EXTENDED ? 6 : -1); }
+__device__ __forceinline__ int cell_id(const lcs_cell &c) { return (c.n_id_1 >= 0 && c.n_id_2 >= 0) ? c.n_id_2 + 3 * c.n_id_1 : -1; }
+__device__ __forceinline__ int cn_of(int i) { return (i < 36) ? (i - 36) : (i - 35); }
+
+// ---- one row of RS_DL (ref src/lte_lib.cpp:305-383): the cell-specific reference symbols of the 6 centre resource
+// blocks in OFDM symbol `sym` of slot `slot` (t = 0, 1, 2 -> sym 0, 1, n_symb - 3) as 12 (re, im) pairs, and the per-port
+// frequency shifts of that symbol (entries of ports without RS there are left untouched: callers pre-fill -1).
+// pn_jump: Gold-sequence jump-ahead table (lcs_tables::pn_jump_table(1600 + 2 * (110 - 6)))
+__device__ __forceinline__ void rs_dl_row(int slot, int t, int id, int cp_type, int n_symb, const uint32_t *__restrict__ pn_jump,
+                                          double *rs_row /*[12][2]*/, double *shift4) {
+  const int sym = (t == 2) ? (n_symb - 3) : t;
+  const uint32_t n_cp = (cp_type == LCS_CP_NORMAL);
+  const uint32_t c_init = (1u << 10) * (7 * (slot + 1) + sym + 1) * (2 * id + 1) + 2 * id + n_cp;
+  // registers after Nc + 2 * (N_RB_MAXDL - 6) clocks (bit index of c(2m) for m = 104), by jump-ahead
+  uint32_t x1 = pn_jump[31], x2 = 0;
+  for (int b = 0; b < 31; ++b) if ((c_init >> b) & 1u) x2 ^= pn_jump[b];
+  uint32_t bits = 0;                                // c(208..231)
+  for (int i = 0; i < 24; ++i) {
+    bits |= ((x1 ^ x2) & 1u) << i;
+    const uint32_t n1 = ((x1 >> 3) ^ x1) & 1u;
+    const uint32_t n2 = ((x2 >> 3) ^ (x2 >> 2) ^ (x2 >> 1) ^ x2) & 1u;
+    x1 = (x1 >> 1) | (n1 << 30);
+    x2 = (x2 >> 1) | (n2 << 30);
+  }
+  const double isq = 1 / pow(2.0, 0.5);
+  for (int k = 0; k < 12; ++k) {
+    rs_row[2 * k] = isq * (1 - 2 * (int)((bits >> (2 * k)) & 1u));
+    rs_row[2 * k + 1] = isq * (1 - 2 * (int)((bits >> (2 * k + 1)) & 1u));
+  }
+  for (int port = 0; port < 4; ++port) {
+    int v = -1;
+    if (port == 0 && sym == 0) v = 0;
+    else if (port == 0 && sym == n_symb - 3) v = 3;
+    else if (port == 1 && sym == 0) v = 3;
+    else if (port == 1 && sym == n_symb - 3) v = 0;
+    else if (port == 2 && sym == 1) v = 3 * (slot & 1);
+    else if (port == 3 && sym == 1) v = 3 + 3 * (slot & 1);
+    const bool want = (t == 0 || t == 2) ? (port <= 1) : (port >= 2);
+    if (want && v >= 0) shift4[port] = (double)((v + id) % 6);
+  }
+}
+
+// ---- soft demodulation of one QPSK symbol: exact log-MAP as itpp::Modulator::demodulate_soft_bits (LOGMAP) with
+// rx = sym/sqrt(np), channel = 1/sqrt(np), N0 = 1 (ref src/lte_lib.cpp:612-634)
+__device__ __forceinline__ double trunc_log(double x) {     // itpp::trunc_log
+  if (x == INFINITY) return log(1.79769313486231570815e+308);
+  if (x <= 0) return log(2.22507385850720138309e-308);
+  return log(x);
+}
+__device__ __forceinline__ void qpsk_llr(cd2 sym, double np, double &l0, double &l1) {
+  const double a = 1 / sqrt(2.0);
+  const cd2 gain = cdiv(mk(1.0, 0), mk(sqrt(np), 0));
+  const cd2 rx = cmul(sym, gain);
+  double metric[4];
+  for (int j = 0; j < 4; ++j) {
+    const cd2 S = mk((j & 2) ? -a : a, (j & 1) ? -a : a);
+    metric[j] = exp(-cabs2(csub(rx, cmul(gain, S))) / 1);
+  }
+  l0 = trunc_log(metric[0] + metric[1]) - trunc_log(metric[2] + metric[3]);
+  l1 = trunc_log(metric[0] + metric[2]) - trunc_log(metric[1] + metric[3]);
+}
+
+// ---- PBCH decode from the descrambled LLRs e_est[m_bit] (LDS) to the 40 decoded bits: de-ratematch, tail-biting
+// Viterbi, CRC-16 with the antenna-port mask (ref src/lte_lib.cpp:469-518, 538-551, 637-663; src/searcher.cpp:1617-1636).
+// Called by all PB_WAVES * 64 threads of the workgroup; ok / bits40 are valid on thread 0 afterwards.
+template <int PB_WAVES>
+__device__ __forceinline__ void pbch_decode_tail(const double *e_est, double (*d_est)[40], unsigned long long (*best_surv)[40],
+                                                 double *w_best, int *w_best_ss, unsigned char *c_est,
+                                                 const int16_t *__restrict__ derm_inv, int m_bit, int n_ports, int tid, int &ok,
+                                                 unsigned long long &bits40) {
+    // de-ratematch: average all observations of each coded bit (ref src/lte_lib.cpp:497-509)
+    if (tid < 120) {
+      const int16_t *lst = derm_inv + ((m_bit == 1920) ? 0 : 120 * 16) + tid * 16;   // ascending bit positions
+      double s = 0; int cnt = 0;
+      for (int q = 0; q < 16; ++q) { const int t = lst[q]; if (t < 0) break; s += e_est[t]; ++cnt; }
+      if (cnt > 1) s = s / cnt;
+      d_est[tid / 40][tid % 40] = s;
+    }
+    __syncthreads();
+    // tail-biting Viterbi, K=7, G=(133,171,165)o: one trellis per start state with the end state
+    // forced equal; lane = trellis state, each of the 16 waves takes 4 start states.
+    {
+      // each wave runs its 64 / PB_WAVES start states TOGETHER: the trellises are independent, so
+      // their shuffle -> add -> compare chains overlap instead of running back to back.  Lane t
+      // keeps the survivor word of step t for every trellis of the wave in registers.
+      const int wave = tid >> 6, s = tid & 63;
+      constexpr int NQ = 64 / PB_WAVES;
+      const int b = s >> 5, p0 = (s << 1) & 63, p1 = p0 | 1;       // new state s <- predecessors p0, p1 with input bit b
+      const int reg0 = (b << 6) | p0, reg1 = (b << 6) | p1;
+      const bool a00 = __popc(reg0 & 0133) & 1, a01 = __popc(reg0 & 0171) & 1, a02 = __popc(reg0 & 0165) & 1;
+      const bool a10 = __popc(reg1 & 0133) & 1, a11 = __popc(reg1 & 0171) & 1, a12 = __popc(reg1 & 0165) & 1;
+      double pm[NQ];
+      unsigned long long my_surv[NQ];
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) { pm[q] = (s == wave * NQ + q) ? 0.0 : INFINITY; my_surv[q] = 0ull; }
+      for (int t = 0; t < 40; ++t) {
+        const double rr0 = d_est[0][t], rr1 = d_est[1][t], rr2 = d_est[2][t];
+        const double c00 = a00 ? rr0 : -rr0, c01 = a01 ? rr1 : -rr1, c02 = a02 ? rr2 : -rr2;
+        const double c10 = a10 ? rr0 : -rr0, c11 = a11 ? rr1 : -rr1, c12 = a12 ? rr2 : -rr2;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          double m0 = __shfl(pm[q], p0), m1 = __shfl(pm[q], p1);
+          m0 += c00; m0 += c01; m0 += c02;
+          m1 += c10; m1 += c11; m1 += c12;
+          const bool take1 = m1 < m0;          // ties keep the lower-numbered predecessor
+          pm[q] = take1 ? m1 : m0;
+          const unsigned long long bal = __ballot(take1);
+          if (s == t) my_surv[q] = bal;
+        }
+      }
+      double wbest = INFINITY; int wbest_ss = -1;
+      unsigned long long keep = 0ull;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {         // start states in ascending order, strict < : first best wins
+        const int ss = wave * NQ + q;
+        const double fin = __shfl(pm[q], ss);
+        if (fin < wbest) { wbest = fin; wbest_ss = ss; keep = my_surv[q]; }
+      }
+      if (s < 40) best_surv[wave][s] = keep;
+      if (s == 0) { w_best[wave] = wbest; w_best_ss[wave] = wbest_ss; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int bw = 0;
+      for (int w = 1; w < PB_WAVES; ++w) if (w_best[w] < w_best[bw]) bw = w;
+      ok = 0;
+      if (w_best_ss[bw] >= 0) {
+        int s = w_best_ss[bw];
+        for (int t = 39; t >= 0; --t) {
+          c_est[t] = (unsigned char)((s >> 5) & 1);
+          const int dec = (int)((best_surv[bw][t] >> s) & 1ull);
+          s = ((s << 1) & 63) | dec;
+        }
+        // CRC-16 (x^16+x^12+x^5+1, zero init) over the 24 payload bits, antenna-port mask
+        unsigned char buf[40];
+        for (int i = 0; i < 40; ++i) buf[i] = (i < 24) ? c_est[i] : 0;
+        const unsigned char poly[17] = {1, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+        for (int i = 0; i < 24; ++i) if (buf[i]) for (int j = 0; j < 17; ++j) buf[i + j] ^= poly[j];
+        ok = 1;
+        for (int t = 0; t < 16; ++t) {
+          int crc = buf[24 + t];
+          if (n_ports == 2) crc = 1 - crc;
+          else if (n_ports == 4 && (t & 1)) crc = 1 - crc;
+          if (crc != c_est[24 + t]) ok = 0;
+        }
+        for (int i = 0; i < 40; ++i) bits40 |= (unsigned long long)c_est[i] << i;
+      }
+    }
+  __syncthreads();
+}

@@ -37,32 +37,7 @@ extern "C" int lcs_debug_phase_ts(unsigned long long *out) { return (int)hipMemc
 #define CS_RS 1024       // [140][12] complex
 #define CS_SIZE LCS_CELL_SCRATCH
 
-struct cd2 { double re, im; };
-__device__ __forceinline__ cd2 mk(double a, double b) { cd2 r; r.re = a; r.im = b; return r; }
-__device__ __forceinline__ cd2 cadd(cd2 a, cd2 b) { return mk(a.re + b.re, a.im + b.im); }
-__device__ __forceinline__ cd2 csub(cd2 a, cd2 b) { return mk(a.re - b.re, a.im - b.im); }
-__device__ __forceinline__ cd2 cmul(cd2 a, cd2 b) { return mk(a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re); }
-__device__ __forceinline__ cd2 cconj(cd2 a) { return mk(a.re, -a.im); }
-__device__ __forceinline__ cd2 cscale(cd2 a, double s) { return mk(a.re * s, a.im * s); }
-__device__ __forceinline__ cd2 cdivr(cd2 a, double s) { return mk(a.re / s, a.im / s); }
-__device__ __forceinline__ double cabs2(cd2 a) { return a.re * a.re + a.im * a.im; }
-__device__ __forceinline__ cd2 ld(const double2 *p) { const double2 v = *p; return mk(v.x, v.y); }
-__device__ __forceinline__ void st(double2 *p, cd2 v) { *p = make_double2(v.re, v.im); }
-// std::complex division for finite operands (libgcc __divdc3 main path)
-__device__ __forceinline__ cd2 cdiv(cd2 x, cd2 y) {
-  const double a = x.re, b = x.im, c = y.re, d = y.im;
-  if (fabs(c) < fabs(d)) {
-    const double ratio = c / d, denom = (c * ratio) + d;
-    return mk(((a * ratio) + b) / denom, ((b * ratio) - a) / denom);
-  }
-  const double ratio = d / c, denom = (d * ratio) + c;
-  return mk(((b * ratio) + a) / denom, (b - (a * ratio)) / denom);
-}
-__device__ __forceinline__ int d_round_i(double x) { return (int)rint(x); }
-__device__ __forceinline__ int d_imod(int k, int n) { int r = k % n; return r < 0 ? r + n : r; }
-__device__ __forceinline__ int cell_n_symb(const lcs_cell &c) { return c.cp_type == LCS_CP_NORMAL ? 7 : (c.cp_type == LCS_CP_EXTENDED ? 6 : -1); }
-__device__ __forceinline__ int cell_id(const lcs_cell &c) { return (c.n_id_1 >= 0 && c.n_id_2 >= 0) ? c.n_id_2 + 3 * c.n_id_1 : -1; }
-__device__ __forceinline__ int cn_of(int i) { return (i < 36) ? (i - 36) : (i - 35); }
+#include "lte_device.h"
 
 // block-wide sum of a complex value (any order; the reference sums sequentially, the
 // difference is at the 1e-16 relative level)
@@ -180,39 +155,10 @@ __global__ __launch_bounds__(128) void k_cell_prep(const lcs_cell *__restrict__ 
     if (n_symb < 0 || id < 0) continue;
     if (tid < 64) for (int e = tid; e < 140 * 4; e += 64) sc[CS_SHIFT + e] = -1.0;
     __syncthreads();
-    if (tid < 60) {
+    if (tid < 60) {      // one (slot, RS symbol) per lane
       const int slot = tid / 3, t = tid % 3;
-      const int sym = (t == 2) ? (n_symb - 3) : t;
-      const uint32_t n_cp = (c.cp_type == LCS_CP_NORMAL);
-      const uint32_t c_init = (1u << 10) * (7 * (slot + 1) + sym + 1) * (2 * id + 1) + 2 * id + n_cp;
-      // registers after Nc + 2 * (N_RB_MAXDL - 6) clocks (bit index of c(2m) for m = 104), by jump-ahead
-      uint32_t x1 = pn_jump[31], x2 = 0;
-      for (int b = 0; b < 31; ++b) if ((c_init >> b) & 1u) x2 ^= pn_jump[b];
-      uint32_t bits = 0;                                // c(208..231)
-      for (int i = 0; i < 24; ++i) {
-        bits |= ((x1 ^ x2) & 1u) << i;
-        const uint32_t n1 = ((x1 >> 3) ^ x1) & 1u;
-        const uint32_t n2 = ((x2 >> 3) ^ (x2 >> 2) ^ (x2 >> 1) ^ x2) & 1u;
-        x1 = (x1 >> 1) | (n1 << 30);
-        x2 = (x2 >> 1) | (n2 << 30);
-      }
-      const double isq = 1 / pow(2.0, 0.5);
-      const int row = slot * n_symb + sym;
-      for (int k = 0; k < 12; ++k) {
-        sc[CS_RS + (row * 12 + k) * 2] = isq * (1 - 2 * (int)((bits >> (2 * k)) & 1u));
-        sc[CS_RS + (row * 12 + k) * 2 + 1] = isq * (1 - 2 * (int)((bits >> (2 * k + 1)) & 1u));
-      }
-      for (int port = 0; port < 4; ++port) {
-        int v = -1;
-        if (port == 0 && sym == 0) v = 0;
-        else if (port == 0 && sym == n_symb - 3) v = 3;
-        else if (port == 1 && sym == 0) v = 3;
-        else if (port == 1 && sym == n_symb - 3) v = 0;
-        else if (port == 2 && sym == 1) v = 3 * (slot & 1);
-        else if (port == 3 && sym == 1) v = 3 + 3 * (slot & 1);
-        const bool want = (t == 0 || t == 2) ? (port <= 1) : (port >= 2);
-        if (want && v >= 0) sc[CS_SHIFT + row * 4 + port] = (double)((v + id) % 6);
-      }
+      const int sym = (t == 2) ? (n_symb - 3) : t, row = slot * n_symb + sym;
+      rs_dl_row(slot, t, id, c.cp_type, n_symb, pn_jump, &sc[CS_RS + row * 24], &sc[CS_SHIFT + row * 4]);
     }
     __syncthreads();
   }
@@ -769,11 +715,6 @@ __device__ __forceinline__ double np_from_partials(const double *sc, int port) {
 // pairs go straight through the soft demodulator), only the 1920 LLRs go through LDS.
 #define PB_THREADS 256
 #define PB_WAVES (PB_THREADS / 64)
-__device__ __forceinline__ double trunc_log(double x) {     // itpp::trunc_log
-  if (x == INFINITY) return log(1.79769313486231570815e+308);
-  if (x <= 0) return log(2.22507385850720138309e-308);
-  return log(x);
-}
 __global__ __launch_bounds__(PB_THREADS) __attribute__((amdgpu_waves_per_eu(3, 8))) void k_pbch(const lcs_cell *__restrict__ cells, const int *__restrict__ n_work,
                                                       const double2 *__restrict__ tfg_comp, const double2 *__restrict__ ce,
                                                       double *__restrict__ scratch, const uint8_t *__restrict__ pbch_scr,
@@ -840,109 +781,25 @@ __global__ __launch_bounds__(PB_THREADS) __attribute__((amdgpu_waves_per_eu(3, 8
         syms[0] = cscale(s0, s2); syms[1] = cscale(s1, s2);
         npv[0] = npp; npv[1] = npp;
       }
-      // soft demodulation: exact log-MAP as itpp::Modulator::demodulate_soft_bits (LOGMAP) with
-      // rx = sym/sqrt(np), channel = 1/sqrt(np), N0 = 1 (ref src/lte_lib.cpp:628-631); descramble
+      // soft demodulation (exact log-MAP, lte_device.h) and descrambling
+      const uint8_t *scr = pbch_scr + (size_t)id * 1920;
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
-      const int l = t + q;
-      const double a = 1 / sqrt(2.0);
-      const cd2 gain = cdiv(mk(1.0, 0), mk(sqrt(npv[q]), 0));
-      const cd2 rx = cmul(syms[q], gain);
-      double metric[4];
-      for (int j = 0; j < 4; ++j) {
-        const cd2 S = mk((j & 2) ? -a : a, (j & 1) ? -a : a);
-        metric[j] = exp(-cabs2(csub(rx, cmul(gain, S))) / 1);
-      }
-      double l0 = trunc_log(metric[0] + metric[1]) - trunc_log(metric[2] + metric[3]);
-      double l1 = trunc_log(metric[0] + metric[2]) - trunc_log(metric[1] + metric[3]);
-      const uint8_t *scr = pbch_scr + (size_t)id * 1920;
-      if (scr[2 * l]) l0 = -l0;
-      if (scr[2 * l + 1]) l1 = -l1;
-      e_est[2 * l] = l0; e_est[2 * l + 1] = l1;
+        const int l = t + q;
+        double l0, l1;
+        qpsk_llr(syms[q], npv[q], l0, l1);
+        if (scr[2 * l]) l0 = -l0;
+        if (scr[2 * l + 1]) l1 = -l1;
+        e_est[2 * l] = l0; e_est[2 * l + 1] = l1;
       }
     }
     __syncthreads();
     PH(1);
-    // de-ratematch: average all observations of each coded bit (ref src/lte_lib.cpp:497-509)
-    if (tid < 120) {
-      const int16_t *lst = derm_inv + ((m_bit == 1920) ? 0 : 120 * 16) + tid * 16;   // ascending bit positions
-      double s = 0; int cnt = 0;
-      for (int q = 0; q < 16; ++q) { const int t = lst[q]; if (t < 0) break; s += e_est[t]; ++cnt; }
-      if (cnt > 1) s = s / cnt;
-      d_est[tid / 40][tid % 40] = s;
-    }
-    __syncthreads();
-    PH(2);
-    // tail-biting Viterbi, K=7, G=(133,171,165)o: one trellis per start state with the end state
-    // forced equal; lane = trellis state, each of the 16 waves takes 4 start states.
-    {
-      // each wave runs its 64 / PB_WAVES start states TOGETHER: the trellises are independent, so
-      // their shuffle -> add -> compare chains overlap instead of running back to back.  Lane t
-      // keeps the survivor word of step t for every trellis of the wave in registers.
-      const int wave = tid >> 6, s = tid & 63;
-      constexpr int NQ = 64 / PB_WAVES;
-      const int b = s >> 5, p0 = (s << 1) & 63, p1 = p0 | 1;       // new state s <- predecessors p0, p1 with input bit b
-      const int reg0 = (b << 6) | p0, reg1 = (b << 6) | p1;
-      const bool a00 = __popc(reg0 & 0133) & 1, a01 = __popc(reg0 & 0171) & 1, a02 = __popc(reg0 & 0165) & 1;
-      const bool a10 = __popc(reg1 & 0133) & 1, a11 = __popc(reg1 & 0171) & 1, a12 = __popc(reg1 & 0165) & 1;
-      double pm[NQ];
-      unsigned long long my_surv[NQ];
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) { pm[q] = (s == wave * NQ + q) ? 0.0 : INFINITY; my_surv[q] = 0ull; }
-      for (int t = 0; t < 40; ++t) {
-        const double rr0 = d_est[0][t], rr1 = d_est[1][t], rr2 = d_est[2][t];
-        const double c00 = a00 ? rr0 : -rr0, c01 = a01 ? rr1 : -rr1, c02 = a02 ? rr2 : -rr2;
-        const double c10 = a10 ? rr0 : -rr0, c11 = a11 ? rr1 : -rr1, c12 = a12 ? rr2 : -rr2;
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-          double m0 = __shfl(pm[q], p0), m1 = __shfl(pm[q], p1);
-          m0 += c00; m0 += c01; m0 += c02;
-          m1 += c10; m1 += c11; m1 += c12;
-          const bool take1 = m1 < m0;          // ties keep the lower-numbered predecessor
-          pm[q] = take1 ? m1 : m0;
-          const unsigned long long bal = __ballot(take1);
-          if (s == t) my_surv[q] = bal;
-        }
-      }
-      double wbest = INFINITY; int wbest_ss = -1;
-      unsigned long long keep = 0ull;
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) {         // start states in ascending order, strict < : first best wins
-        const int ss = wave * NQ + q;
-        const double fin = __shfl(pm[q], ss);
-        if (fin < wbest) { wbest = fin; wbest_ss = ss; keep = my_surv[q]; }
-      }
-      if (s < 40) best_surv[wave][s] = keep;
-      if (s == 0) { w_best[wave] = wbest; w_best_ss[wave] = wbest_ss; }
-    }
-    __syncthreads();
-    PH(3);
+    int ok = 0;
+    unsigned long long bits40 = 0;
+    pbch_decode_tail<PB_WAVES>(e_est, d_est, best_surv, w_best, w_best_ss, c_est, derm_inv, m_bit, n_ports, tid, ok, bits40);
     if (tid == 0) {
-      int bw = 0;
-      for (int w = 1; w < PB_WAVES; ++w) if (w_best[w] < w_best[bw]) bw = w;
-      int ok = 0;
-      unsigned bits24 = 0;
-      if (w_best_ss[bw] >= 0) {
-        int s = w_best_ss[bw];
-        for (int t = 39; t >= 0; --t) {
-          c_est[t] = (unsigned char)((s >> 5) & 1);
-          const int dec = (int)((best_surv[bw][t] >> s) & 1ull);
-          s = ((s << 1) & 63) | dec;
-        }
-        // CRC-16 (x^16+x^12+x^5+1, zero init) over the 24 payload bits, antenna-port mask
-        unsigned char buf[40];
-        for (int i = 0; i < 40; ++i) buf[i] = (i < 24) ? c_est[i] : 0;
-        const unsigned char poly[17] = {1, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
-        for (int i = 0; i < 24; ++i) if (buf[i]) for (int j = 0; j < 17; ++j) buf[i + j] ^= poly[j];
-        ok = 1;
-        for (int t = 0; t < 16; ++t) {
-          int crc = buf[24 + t];
-          if (n_ports == 2) crc = 1 - crc;
-          else if (n_ports == 4 && (t & 1)) crc = 1 - crc;
-          if (crc != c_est[24 + t]) ok = 0;
-        }
-        for (int i = 0; i < 24; ++i) bits24 |= (unsigned)c_est[i] << i;
-      }
+      const unsigned bits24 = (unsigned)(bits40 & 0xffffffull);
       sc[CS_CAND + cand * 4 + 0] = (double)ok;
       sc[CS_CAND + cand * 4 + 1] = (double)bits24;
     }

@@ -1,0 +1,460 @@
+// tracker.hip -- LTE-Tracker's per-symbol pipeline for blocks of OFDM symbols of many tracked
+// cells at once.
+//
+// The reference gives every tracked cell a thread that consumes one OFDM symbol at a time (src/tracker_thread.cpp:
+// 823-1068): get_fd (:91-174: frequency correction, 128-point DFT, the 72 occupied subcarriers, timing / bulk phase
+// compensation), the cell-specific reference symbols (:868-890), filter_ce (:176-201) with the power measurements
+// (:906-931), the frequency and timing measurements of do_foe (:203-243) and do_toe_v2 (:245-288), interp2d (:383-477)
+// and, on the PBCH symbols of four frames, pbch_extract_rt + the decoder of do_mib_decode (:494-529, 555-705).  None
+// of that depends on other symbols beyond a window of three reference symbols, so a block of symbols (whole frames,
+// starting at slot 0 symbol 0) of n_cells cells is processed as four launches over (cell, symbol), (cell, port) and
+// (cell, frame offset).  What stays sequential -- the running bulk phase, a 600-step scalar recurrence per cell --
+// is walked by one lane per cell in the preparation kernel; the slow feedback loops that consume the measurements
+// (global frequency offset, frame timing, MIB lock counter) are scalar and live on the host (tracker.py).
+// All arithmetic is fp64 like the reference.
+#include "lte_device.h"
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#define FS_LTE 30720000.0
+#define TRK_MEAS 9
+
+__device__ __forceinline__ double trk_wrap(double x, double sm, double lg) {     // WRAP, include/macros.h
+  const double k = x - sm, n = lg - sm;
+  return ((n == 0) ? k : (k - n * (double)(int)floor(k / n))) + sm;
+}
+__device__ __forceinline__ int trk_n_symb(const lcs_track_cell &c) { return c.cp_type == LCS_CP_NORMAL ? 7 : 6; }
+__device__ __forceinline__ double trk_sym_len(int cp_type, int sym) {            // samples from the previous DFT to this one's
+  return (cp_type == LCS_CP_EXTENDED) ? 128 + 32 : ((sym == 0) ? 128 + 10 : 128 + 9);
+}
+
+// Per cell: RS_DL, the running bulk phase of get_fd at every symbol (:151-153), and per port the list of symbols that
+// carry its reference symbols.  128 threads: lanes 0..59 one RS row each, thread 64 the phase walk, threads 65..68
+// the per-port lists.
+__global__ __launch_bounds__(128) void k_trk_prep(lcs_track_cell *__restrict__ cells, int n_sym, const double *__restrict__ freq_off,
+                                                 const uint32_t *__restrict__ pn_jump, double *__restrict__ rs /*[c][140][24]*/,
+                                                 double *__restrict__ shift /*[c][140][4]*/, double *__restrict__ bpo /*[c][n_sym]*/,
+                                                 int *__restrict__ rs_idx /*[c][4][max_rs]*/, int *__restrict__ n_rs /*[c][4]*/, int max_rs) {
+  const int cell = blockIdx.x, tid = threadIdx.x;
+  const lcs_track_cell c = cells[cell];
+  const int n_symb = trk_n_symb(c), id = c.n_id_2 + 3 * c.n_id_1;
+  double *sh = shift + (size_t)cell * 140 * 4;
+  for (int e = tid; e < 140 * 4; e += 128) sh[e] = -1.0;
+  __syncthreads();
+  if (tid < 60) {
+    const int slot = tid / 3, t = tid % 3;
+    const int sym = (t == 2) ? (n_symb - 3) : t, row = slot * n_symb + sym;
+    rs_dl_row(slot, t, id, c.cp_type, n_symb, pn_jump, rs + ((size_t)cell * 140 + row) * 24, sh + row * 4);
+  }
+  if (tid == 64) {
+    double b = c.bulk_phase_offset;
+    int sym = 0;
+    for (int i = 0; i < n_sym; ++i) {
+      b = trk_wrap(b + 2 * M_PI * trk_sym_len(c.cp_type, sym) * (1 / (FS_LTE / 16)) * -freq_off[(size_t)cell * n_sym + i], -M_PI, M_PI);
+      bpo[(size_t)cell * n_sym + i] = b;
+      sym = (sym + 1 == n_symb) ? 0 : sym + 1;
+    }
+    cells[cell].bulk_phase_offset = b;
+  }
+  __syncthreads();
+  if (tid >= 65 && tid < 69) {
+    const int port = tid - 65;
+    int m = 0;
+    if (port < c.n_ports)
+      for (int i = 0; i < n_sym; ++i) {
+        const int row = i % (20 * n_symb);
+        if (sh[row * 4 + port] >= 0.0 && m < max_rs) rs_idx[((size_t)cell * 4 + port) * max_rs + m++] = i;
+      }
+    n_rs[cell * 4 + port] = m;
+  }
+}
+
+// get_fd: one wave per OFDM symbol, 4 symbols per workgroup.
+#define TRK_FD_SYM 4
+__global__ __launch_bounds__(64 * TRK_FD_SYM) void k_trk_fd(const lcs_track_cell *__restrict__ cells, int n_sym, const double2 *__restrict__ td,
+                                                            const double *__restrict__ freq_off, const double *__restrict__ late,
+                                                            const double *__restrict__ bpo, double fc_req, double fc_prog, double fs_prog,
+                                                            double2 *__restrict__ syms) {
+  __shared__ cd2 W[64];
+  __shared__ cd2 win[TRK_FD_SYM][128];
+  const int cell = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int i = blockIdx.x * TRK_FD_SYM + wv;
+  const bool live = i < n_sym;
+  if (tid < 64) { double s, c; sincospi((double)tid / 64.0, &s, &c); W[tid] = mk(c, -s); }
+  if (live) {
+    const double f_off = freq_off[(size_t)cell * n_sym + i];
+    const double k_factor = (fc_req - f_off) / fc_prog;
+    const double k = M_PI * (-f_off) / ((fs_prog * k_factor) / 2);                  // fshift_inplace, include/dsp.h:58-69
+    const double2 *src = td + ((size_t)cell * n_sym + i) * 128;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int t = lane + 64 * h;
+      const double2 x = src[t];
+      const cd2 v = cmul(mk(x.x, x.y), mk(cos(k * t), sin(k * t)));
+      win[wv][(t + 126) & 127] = v;                                                 // remove the 2 sample delay (:128-134)
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int stg = 0; stg < 7; ++stg) {     // 128-point decimation-in-frequency FFT, bit-reversed order out
+    const int half = 64 >> stg;
+    const int pos = lane & (half - 1);
+    const int i0 = ((lane >> (6 - stg)) << (7 - stg)) + pos, i1 = i0 + half;
+    const cd2 tw = W[pos << stg];
+    cd2 *x = win[wv];
+    const cd2 a = x[i0], b = x[i1];
+    x[i0] = cadd(a, b);
+    x[i1] = cmul(csub(a, b), tw);
+    __syncthreads();
+  }
+  if (!live) return;
+  const lcs_track_cell c = cells[cell];
+  (void)c;
+  const double kl = 2 * M_PI * late[(size_t)cell * n_sym + i] / 128;
+  const double b = bpo[(size_t)cell * n_sym + i];
+  const cd2 bpo_coeff = mk(cos(b), sin(b));
+  for (int j = lane; j < 72; j += 64) {
+    const int bin = (j < 36) ? 92 + j : j - 35;                                     // :138-141
+    cd2 a = cdivr(win[wv][__brev((unsigned)bin) >> 25], sqrt(128.0));
+    const int t = (j >= 36) ? j - 35 : 36 - j;
+    const double phase = -kl * t;
+    cd2 coeff = mk(cos(phase), sin(phase));
+    if (j < 36) coeff.im = -coeff.im;
+    a = cmul(a, cmul(bpo_coeff, coeff));                                            // :158-165
+    st(&syms[((size_t)cell * n_sym + i) * 72 + j], a);
+  }
+}
+
+// interp72 (:383-400) evaluated at subcarrier t: the segment the reference's running pointers have reached there
+__device__ __forceinline__ cd2 trk_interp72(const double2 *__restrict__ filt, int shift, int t) {
+  int a = (t - shift - 1 >= 0) ? (t - shift - 1) / 6 : 0;
+  if (a > 10) a = 10;
+  const cd2 l_y = ld(&filt[a]), r_y = ld(&filt[a + 1]);
+  return cadd(cscale(cdivr(csub(r_y, l_y), 6.0), (double)(t - (shift + 6 * a))), l_y);
+}
+
+// One workgroup per (port, cell): raw channel estimates on the reference symbols, filter_ce + powers + FOE/TOE
+// measurements for every reference symbol that has both neighbours, then the 2-D interpolation onto every symbol.
+#define TRK_CE_THREADS 256
+__global__ __launch_bounds__(TRK_CE_THREADS) void k_trk_ce(const lcs_track_cell *__restrict__ cells, int n_sym, const double2 *__restrict__ syms,
+                                                          const double *__restrict__ freq_off, const double *__restrict__ frame_timing,
+                                                          const double *__restrict__ rs, const double *__restrict__ shift,
+                                                          const int *__restrict__ rs_idx, const int *__restrict__ n_rs, int max_rs,
+                                                          double fc_req, double fc_prog, double fs_prog, double2 *__restrict__ raw,
+                                                          double2 *__restrict__ filt, double *__restrict__ fmeta /*[..][max_rs][4]: tp, sp, sp_raw, np*/,
+                                                          double *__restrict__ meas, int *__restrict__ n_meas, double2 *__restrict__ ce,
+                                                          double *__restrict__ ce_pw, int *__restrict__ ce_upto) {
+  const int port = blockIdx.x, cell = blockIdx.y, tid = threadIdx.x;
+  const lcs_track_cell c = cells[cell];
+  const size_t cp = (size_t)cell * 4 + port;
+  if (port >= c.n_ports) { if (tid == 0) { n_meas[cp] = 0; ce_upto[cp] = 0; } return; }
+  const int n_symb = trk_n_symb(c), per_frame = 20 * n_symb;
+  const int m = n_rs[cp];
+  const int *idx = rs_idx + cp * max_rs;
+  const double *sh = shift + (size_t)cell * 140 * 4;
+  const double *fo = freq_off + (size_t)cell * n_sym, *ft = frame_timing + (size_t)cell * n_sym;
+  double2 *raw_p = raw + cp * max_rs * 12, *filt_p = filt + cp * max_rs * 12;
+  double *fm = fmeta + cp * max_rs * 4, *ms = meas + cp * max_rs * TRK_MEAS;
+  // raw channel estimates (:874-880)
+  for (int e = tid; e < m * 12; e += TRK_CE_THREADS) {
+    const int r = e / 12, k = e % 12, i = idx[r], row = i % per_frame;
+    const int s = d_round_i(sh[row * 4 + port]);
+    const cd2 ref = mk(rs[((size_t)cell * 140 + row) * 24 + 2 * k], rs[((size_t)cell * 140 + row) * 24 + 2 * k + 1]);
+    st(&raw_p[e], cmul(ld(&syms[((size_t)cell * n_sym + i) * 72 + s + 6 * k]), cconj(ref)));
+  }
+  __syncthreads();
+  const int nf = (m >= 3) ? m - 2 : 0;
+  for (int f = tid; f < nf; f += TRK_CE_THREADS) {
+    const int r = f + 1;
+    const int ip = idx[r - 1], ic = idx[r], in = idx[r + 1];
+    const double sh_p = sh[(ip % per_frame) * 4 + port], sh_c = sh[(ic % per_frame) * 4 + port];
+    cd2 P[12], Cq[12], N[12], F[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) { P[k] = ld(&raw_p[(r - 1) * 12 + k]); Cq[k] = ld(&raw_p[r * 12 + k]); N[k] = ld(&raw_p[(r + 1) * 12 + k]); }
+    const bool up = sh_p < sh_c;
+#pragma unroll
+    for (int t = 0; t < 12; ++t) {                                // filter_ce :176-201
+      cd2 total = mk(0, 0);
+      int n_total = 0;
+#pragma unroll
+      for (int k = t - 1; k <= t + 1; ++k) if (k >= 0 && k <= 11) { total = cadd(total, Cq[k]); ++n_total; }
+      const int lo = up ? t : t - 1;
+      cd2 sp_ = mk(0, 0), sn_ = mk(0, 0);
+      int n_ind = 0;
+#pragma unroll
+      for (int k = lo; k <= lo + 1; ++k) if (k >= 0 && k <= 11) { sp_ = cadd(sp_, P[k]); sn_ = cadd(sn_, N[k]); ++n_ind; }
+      total = cadd(total, sp_);
+      total = cadd(total, sn_);
+      n_total += 2 * n_ind;
+      F[t] = cdivr(total, (double)n_total);
+    }
+    double d2 = 0, f2s = 0;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) { const cd2 d = csub(Cq[k], F[k]); d2 += pow(d.re, 2) + pow(d.im, 2); }
+#pragma unroll
+    for (int k = 0; k < 12; ++k) f2s += pow(F[k].re, 2) + pow(F[k].im, 2);
+    const double np = (d2 / 12) * 7 / 6, tp = f2s / 12;           // :908-912
+    const double sp_raw = tp - np / 7, sp = (.00001 > sp_raw) ? .00001 : sp_raw;
+    // do_foe :203-243
+    cd2 foe_comb = mk(0, 0);
+    double foe_comb_np = 0, wsum = 0;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+      const cd2 foe = cmul(cconj(P[k]), N[k]);
+      const double f2 = cabs2(F[k]);
+      const double foe_np = np * np + 2 * np * f2;
+      const double weight = f2 / foe_np;
+      foe_comb = cadd(foe_comb, cscale(foe, weight));
+      foe_comb_np += foe_np * weight * weight;
+      wsum += f2 * weight;
+    }
+    const double scale = 1 / wsum;
+    foe_comb = cscale(foe_comb, scale);
+    foe_comb_np = foe_comb_np * scale * scale;
+    const double frequency_offset = fo[ip];
+    const double k_factor = (fc_req - frequency_offset) / fc_prog;
+    const double residual_f = atan2(foe_comb.im, foe_comb.re) / (2 * M_PI) /
+                              (0.0005 + trk_wrap(ft[in] - ft[ip], -19200.0 / 2, 19200.0 / 2) * (1 / (fs_prog * k_factor)));
+    const double residual_f_np = (foe_comb_np / 2 > .001) ? foe_comb_np / 2 : .001;
+    // do_toe_v2 :245-288
+    cd2 toe1 = mk(0, 0), s1 = mk(0, 0), s2 = mk(0, 0);
+    const cd2 *A = up ? P : Cq, *B = up ? Cq : P;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) toe1 = cadd(toe1, cmul(cconj(A[k]), B[k]));
+    toe1 = cdivr(toe1, 12);
+#pragma unroll
+    for (int k = 0; k <= 4; ++k) s1 = cadd(s1, cmul(cconj(B[k]), A[k + 1]));
+#pragma unroll
+    for (int k = 6; k <= 10; ++k) s2 = cadd(s2, cmul(cconj(B[k]), A[k + 1]));
+    cd2 toe2 = cdivr(cadd(s1, s2), 10);
+    toe1 = cdivr(toe1, sqrt(sp));
+    toe2 = cdivr(toe2, sqrt(sp));
+    const double delay = -(atan2(toe1.im, toe1.re) + atan2(toe2.im, toe2.re)) / 2 / 3 / (2 * M_PI / 128);
+    const double delay_np = (np / sp / 2 / 12 > .001) ? np / sp / 2 / 12 : .001;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) st(&filt_p[f * 12 + k], F[k]);
+    fm[f * 4] = tp; fm[f * 4 + 1] = sp; fm[f * 4 + 2] = sp_raw; fm[f * 4 + 3] = np;
+    double *mrow = ms + (size_t)f * TRK_MEAS;
+    mrow[0] = ic; mrow[1] = np; mrow[2] = tp; mrow[3] = sp_raw; mrow[4] = sp;
+    mrow[5] = frequency_offset + residual_f; mrow[6] = residual_f_np; mrow[7] = ft[ic] + delay; mrow[8] = delay_np;
+  }
+  __syncthreads();
+  // interp2d :402-477: symbol i lies between filtered reference symbols j and j + 1 (idx[j + 1] <= i < idx[j + 2]);
+  // symbols in front of the first one repeat its estimate; nothing is produced from the last one on
+  const int upto = (nf >= 2) ? idx[nf] : 0;
+  if (tid == 0) { n_meas[cp] = nf; ce_upto[cp] = upto; }
+  double2 *ce_p = ce + cp * n_sym * 72;
+  double *pw_p = ce_pw + cp * n_sym * 4;
+  for (int e = tid; e < upto * 72; e += TRK_CE_THREADS) {
+    const int i = e / 72, t = e % 72;
+    int lo = 0, hi = nf - 2;                                      // largest j <= nf - 2 with idx[j + 1] <= i (0 when i is in front of all)
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (idx[mid + 1] <= i) lo = mid; else hi = mid - 1; }
+    const int j = lo;
+    const int i_prev = idx[j + 1], i_cur = idx[j + 2];
+    const int sym_prev = i_prev % n_symb;
+    double time_diff;
+    if (port > 2) time_diff = 0.0005;                             // the reference's `port_num>2`
+    else if (c.cp_type == LCS_CP_EXTENDED) time_diff = 3 * (128 + 32) * (1 / (FS_LTE / 16));
+    else if (sym_prev == 0) time_diff = 4 * (128 + 9) * (1 / (FS_LTE / 16));
+    else time_diff = (2 * (128 + 9) + (128 + 10)) * (1 / (FS_LTE / 16));
+    double time_offset = 0;
+    for (int q = i_prev; q < i; ++q) {                            // the reference's running sum, same order
+      const int sy = q % n_symb;
+      if (c.cp_type == LCS_CP_EXTENDED) time_offset += (128 + 32) * (1 / (FS_LTE / 16));
+      else if (sy == 6) time_offset += (128 + 10) * (1 / (FS_LTE / 16));
+      else time_offset += (128 + 9) * (1 / (FS_LTE / 16));
+    }
+    (void)i_cur;
+    const double w = time_offset / time_diff;
+    const int sh_a = (int)sh[(i_prev % per_frame) * 4 + port], sh_b = (int)sh[(idx[j + 2] % per_frame) * 4 + port];
+    const cd2 a = trk_interp72(filt_p + j * 12, sh_a, t), b = trk_interp72(filt_p + (j + 1) * 12, sh_b, t);
+    st(&ce_p[e], cadd(a, cscale(csub(b, a), w)));
+    if (t < 4) pw_p[i * 4 + t] = fm[j * 4 + t] + (fm[(j + 1) * 4 + t] - fm[j * 4 + t]) * w;
+  }
+}
+
+// One MIB attempt per (frame offset, cell): pbch_extract_rt (:494-529) + the decoder of do_mib_decode (:555-705).
+#define TRK_PB_THREADS 256
+#define TRK_PB_WAVES (TRK_PB_THREADS / 64)
+__global__ __launch_bounds__(TRK_PB_THREADS) void k_trk_mib(const lcs_track_cell *__restrict__ cells, int n_sym, int n_off,
+                                                           const double2 *__restrict__ syms, const double2 *__restrict__ ce,
+                                                           const double *__restrict__ ce_pw, const int *__restrict__ ce_upto,
+                                                           const uint8_t *__restrict__ pbch_scr, const int16_t *__restrict__ derm_inv,
+                                                           int *__restrict__ mib_ok, unsigned long long *__restrict__ mib_bits) {
+  __shared__ double e_est[1920];
+  __shared__ double d_est[3][40];
+  __shared__ unsigned long long best_surv[TRK_PB_WAVES][40];
+  __shared__ double w_best[TRK_PB_WAVES];
+  __shared__ int w_best_ss[TRK_PB_WAVES];
+  __shared__ unsigned char c_est[40];
+  const int off = blockIdx.x, cell = blockIdx.y, tid = threadIdx.x;
+  const lcs_track_cell c = cells[cell];
+  const int n_symb = trk_n_symb(c), per_frame = 20 * n_symb, id = c.n_id_2 + 3 * c.n_id_1;
+  const int last = (off + 3) * per_frame + n_symb + 3;            // last PBCH symbol of the attempt
+  int upto = n_sym;
+  for (int p = 0; p < c.n_ports; ++p) upto = min(upto, ce_upto[cell * 4 + p]);
+  if (last >= upto || (c.n_ports != 1 && c.n_ports != 2 && c.n_ports != 4)) {
+    if (tid == 0) { mib_ok[(size_t)cell * n_off + off] = -1; mib_bits[(size_t)cell * n_off + off] = 0ull; }
+    return;
+  }
+  const int m_bit = (c.cp_type == LCS_CP_NORMAL) ? 1920 : 1728;
+  const int n_syms = m_bit / 2, per_fr = n_syms / 4;
+  const int v3 = d_imod(id, 3);
+  const int r0 = (v3 == 0) ? 1 : 0, r1 = (v3 == 2) ? 1 : 2;       // the two residues != v3, ascending
+  const uint8_t *scr = pbch_scr + (size_t)id * 1920;
+  for (int pr = tid; pr < n_syms / 2; pr += TRK_PB_THREADS) {
+    cd2 x[2], h[4][2], sy[2];
+    double npp[4], npv[2];
+    const int t = 2 * pr;
+    for (int q = 0; q < 2; ++q) {
+      const int ix = t + q, fr = ix / per_fr;
+      int rem = ix % per_fr, symn;
+      if (rem < 48) symn = 0; else if (rem < 96) { symn = 1; rem -= 48; } else if (rem < 168) { symn = 2; rem -= 96; } else { symn = 3; rem -= 168; }
+      const bool has_rs = (symn == 0) || (symn == 1) || (symn == 3 && n_symb == 6);
+      const int scx = has_rs ? (3 * (rem / 2) + ((rem & 1) ? r1 : r0)) : rem;
+      const int i = (off + fr) * per_frame + n_symb + symn;
+      x[q] = ld(&syms[((size_t)cell * n_sym + i) * 72 + scx]);
+      for (int p = 0; p < c.n_ports; ++p) {
+        h[p][q] = ld(&ce[(((size_t)cell * 4 + p) * n_sym + i) * 72 + scx]);
+        if (q == 0) npp[p] = ce_pw[(((size_t)cell * 4 + p) * n_sym + i) * 4 + 3];       // np_pre(port, t): the symbol pair shares an OFDM symbol
+      }
+    }
+    if (c.n_ports == 1) {
+      for (int q = 0; q < 2; ++q) {
+        const cd2 gain = cconj(cdiv(h[0][q], mk(cabs2(h[0][q]), 0)));
+        sy[q] = cmul(x[q], gain);
+        npv[q] = npp[0] * cabs2(gain);
+      }
+    } else {
+      cd2 h1, h2;
+      double np_temp;
+      if (c.n_ports == 2) { h1 = cdivr(cadd(h[0][0], h[0][1]), 2); h2 = cdivr(cadd(h[1][0], h[1][1]), 2); np_temp = (npp[0] + npp[1]) / 2; }
+      else if ((t & 3) == 0) { h1 = cdivr(cadd(h[0][0], h[0][1]), 2); h2 = cdivr(cadd(h[2][0], h[2][1]), 2); np_temp = (npp[0] + npp[2]) / 2; }
+      else { h1 = cdivr(cadd(h[1][0], h[1][1]), 2); h2 = cdivr(cadd(h[3][0], h[3][1]), 2); np_temp = (npp[1] + npp[3]) / 2; }
+      const double scale = pow(h1.re, 2) + pow(h1.im, 2) + pow(h2.re, 2) + pow(h2.im, 2);
+      const cd2 s0 = cdivr(cadd(cmul(cconj(h1), x[0]), cmul(h2, cconj(x[1]))), scale);
+      const cd2 s1 = cconj(cdivr(cadd(cmul(mk(-h2.re, h2.im), x[0]), cmul(h1, cconj(x[1]))), scale));
+      const double a1 = hypot(h1.re, h1.im) / scale, a2 = hypot(h2.re, h2.im) / scale;
+      const double s2 = pow(2.0, 0.5);
+      sy[0] = cscale(s0, s2); sy[1] = cscale(s1, s2);
+      npv[0] = npv[1] = (a1 * a1 + a2 * a2) * np_temp;
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int l = t + q;
+      double l0, l1;
+      qpsk_llr(sy[q], npv[q], l0, l1);
+      if (scr[2 * l]) l0 = -l0;
+      if (scr[2 * l + 1]) l1 = -l1;
+      e_est[2 * l] = l0; e_est[2 * l + 1] = l1;
+    }
+  }
+  __syncthreads();
+  int ok = 0;
+  unsigned long long bits40 = 0;
+  pbch_decode_tail<TRK_PB_WAVES>(e_est, d_est, best_surv, w_best, w_best_ss, c_est, derm_inv, m_bit, c.n_ports, tid, ok, bits40);
+  if (tid == 0) {
+    const int bw[8] = {6, 15, 25, 50, 75, 100, 0, 0};
+    const int b0 = (int)(bits40 & 1), b1 = (int)((bits40 >> 1) & 1), b2 = (int)((bits40 >> 2) & 1);
+    const int n_rb = bw[b0 * 4 + b1 * 2 + b2];
+    const int dur = ((bits40 >> 3) & 1) ? 2 : 1, res = 1 + (int)((bits40 >> 4) & 1) * 2 + (int)((bits40 >> 5) & 1);
+    const int fields = (n_rb == c.n_rb_dl) && (dur == c.phich_duration) && (res == c.phich_resource);
+    mib_ok[(size_t)cell * n_off + off] = (ok ? 1 : 0) | (fields ? 2 : 0);
+    mib_bits[(size_t)cell * n_off + off] = bits40;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------ host
+namespace {
+template <typename T>
+int trk_alloc(lcs_ctx *c, T **p, size_t n) {
+  if (*p) { (void)hipFree(*p); *p = nullptr; }
+  HIPCHK(c, hipMalloc((void **)p, n * sizeof(T)));
+  return LCS_OK;
+}
+}  // namespace
+
+extern "C" int lcs_track_block(lcs_ctx *c, lcs_track_cell *cells, int n_cells, int n_sym, const void *td, int td_on_device,
+                               const double *freq_off, const double *frame_timing, const double *late, double fc_requested,
+                               double fc_programmed, double fs_programmed, double *syms, double *ce, double *ce_pw,
+                               int32_t *ce_upto, double *meas, int max_rs, int32_t *n_meas, int32_t *mib_ok, uint64_t *mib_bits,
+                               int max_off, float *gpu_ms) {
+  if (!c) return LCS_ERR_BAD_ARG;
+  if (!cells || !td || !freq_off || !frame_timing || !late || n_cells < 1 || n_sym < 1 || max_rs < 0 || max_off < 0) { c->err = "bad argument"; return LCS_ERR_BAD_ARG; }
+  for (int i = 0; i < n_cells; ++i) {
+    const lcs_track_cell &t = cells[i];
+    if (t.n_id_1 < 0 || t.n_id_1 > 167 || t.n_id_2 < 0 || t.n_id_2 > 2 || (t.cp_type != LCS_CP_NORMAL && t.cp_type != LCS_CP_EXTENDED) ||
+        t.n_ports < 1 || t.n_ports > 4) { c->err = "tracked cell needs n_id_1, n_id_2, a known cp_type and 1..4 ports"; return LCS_ERR_BAD_ARG; }
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  const int rs_cap = n_sym / 3 + 4;                       // reference symbols of one port in the block: at most 2 per slot of >= 6 symbols
+  const int n_off = std::max(0, n_sym / 120 - 3);         // frame offsets that could hold four frames (120 = extended-CP frame)
+  int rc;
+  if (n_cells != c->trk_cells_cap || n_sym != c->trk_sym_cap) {      // workspace laid out for one block shape
+    const size_t N = (size_t)n_cells * n_sym, C4 = (size_t)n_cells * 4;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if ((rc = trk_alloc(c, &c->trk_td, N * 128)) || (rc = trk_alloc(c, &c->trk_meta, N * 4)) || (rc = trk_alloc(c, &c->trk_cells, (size_t)n_cells)) ||
+        (rc = trk_alloc(c, &c->trk_syms, N * 72)) || (rc = trk_alloc(c, &c->trk_rs, (size_t)n_cells * 140 * 28)) ||
+        (rc = trk_alloc(c, &c->trk_idx, C4 * (rs_cap + 1))) || (rc = trk_alloc(c, &c->trk_raw, C4 * rs_cap * 24)) ||
+        (rc = trk_alloc(c, &c->trk_fmeta, C4 * rs_cap * (4 + TRK_MEAS))) || (rc = trk_alloc(c, &c->trk_ce, C4 * n_sym * 72)) ||
+        (rc = trk_alloc(c, &c->trk_pw, C4 * n_sym * 4)) || (rc = trk_alloc(c, &c->trk_small, C4 * 2 + (size_t)n_cells * (n_off + 1) * 3)))
+      return rc;
+    c->trk_cells_cap = n_cells; c->trk_sym_cap = n_sym;
+  }
+  const size_t N = (size_t)n_cells * n_sym, C4 = (size_t)n_cells * 4;
+  double *d_fo = c->trk_meta, *d_ft = d_fo + N, *d_late = d_ft + N, *d_bpo = d_late + N;
+  double *d_rs = c->trk_rs, *d_shift = d_rs + (size_t)n_cells * 140 * 24;
+  int *d_idx = c->trk_idx, *d_nrs = d_idx + C4 * rs_cap;
+  double2 *d_raw = c->trk_raw, *d_filt = d_raw + C4 * rs_cap * 12;
+  double *d_fm = c->trk_fmeta, *d_meas = d_fm + C4 * rs_cap * 4;
+  int *d_nmeas = c->trk_small, *d_upto = d_nmeas + C4, *d_mibok = d_upto + C4;
+  unsigned long long *d_mibbits = reinterpret_cast<unsigned long long *>(d_mibok + (((size_t)n_cells * n_off + 1) & ~(size_t)1));
+  const double2 *d_td = td_on_device ? (const double2 *)td : c->trk_td;
+  if (!td_on_device) HIPCHK(c, hipMemcpyAsync(c->trk_td, td, sizeof(double2) * N * 128, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d_fo, freq_off, sizeof(double) * N, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d_ft, frame_timing, sizeof(double) * N, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d_late, late, sizeof(double) * N, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->trk_cells, cells, sizeof(lcs_track_cell) * n_cells, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipEventRecord(c->ev_xc0, c->stream));
+  hipLaunchKernelGGL(k_trk_prep, dim3(n_cells), dim3(128), 0, c->stream, c->trk_cells, n_sym, d_fo, c->d_pn_jump, d_rs, d_shift, d_bpo, d_idx,
+                     d_nrs, rs_cap);
+  hipLaunchKernelGGL(k_trk_fd, dim3((n_sym + TRK_FD_SYM - 1) / TRK_FD_SYM, n_cells), dim3(64 * TRK_FD_SYM), 0, c->stream, c->trk_cells, n_sym,
+                     d_td, d_fo, d_late, d_bpo, fc_requested, fc_programmed, fs_programmed, c->trk_syms);
+  hipLaunchKernelGGL(k_trk_ce, dim3(4, n_cells), dim3(TRK_CE_THREADS), 0, c->stream, c->trk_cells, n_sym, c->trk_syms, d_fo, d_ft, d_rs, d_shift,
+                     d_idx, d_nrs, rs_cap, fc_requested, fc_programmed, fs_programmed, d_raw, d_filt, d_fm, d_meas, d_nmeas, c->trk_ce,
+                     c->trk_pw, d_upto);
+  if (n_off > 0)
+    hipLaunchKernelGGL(k_trk_mib, dim3(n_off, n_cells), dim3(TRK_PB_THREADS), 0, c->stream, c->trk_cells, n_sym, n_off, c->trk_syms, c->trk_ce,
+                       c->trk_pw, d_upto, c->d_pbch_scr, c->d_derm_inv, d_mibok, d_mibbits);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipEventRecord(c->ev_xc1, c->stream));
+  // results
+  HIPCHK(c, hipMemcpyAsync(cells, c->trk_cells, sizeof(lcs_track_cell) * n_cells, hipMemcpyDeviceToHost, c->stream));
+  if (syms) HIPCHK(c, hipMemcpyAsync(syms, c->trk_syms, sizeof(double2) * N * 72, hipMemcpyDeviceToHost, c->stream));
+  if (ce) HIPCHK(c, hipMemcpyAsync(ce, c->trk_ce, sizeof(double2) * C4 * n_sym * 72, hipMemcpyDeviceToHost, c->stream));
+  if (ce_pw) HIPCHK(c, hipMemcpyAsync(ce_pw, c->trk_pw, sizeof(double) * C4 * n_sym * 4, hipMemcpyDeviceToHost, c->stream));
+  std::vector<double> h_meas(C4 * rs_cap * TRK_MEAS);
+  std::vector<int> h_small(C4 * 2 + (size_t)n_cells * n_off);
+  std::vector<unsigned long long> h_bits((size_t)n_cells * n_off + 1);
+  HIPCHK(c, hipMemcpyAsync(h_meas.data(), d_meas, sizeof(double) * h_meas.size(), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(h_small.data(), c->trk_small, sizeof(int) * h_small.size(), hipMemcpyDeviceToHost, c->stream));
+  if (n_off > 0) HIPCHK(c, hipMemcpyAsync(h_bits.data(), d_mibbits, sizeof(unsigned long long) * n_cells * n_off, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (gpu_ms) HIPCHK(c, hipEventElapsedTime(gpu_ms, c->ev_xc0, c->ev_xc1));
+  rc = LCS_OK;
+  for (size_t q = 0; q < C4; ++q) {
+    int nm = h_small[q];
+    if (n_meas) n_meas[q] = std::min(nm, max_rs);
+    if (nm > max_rs) rc = LCS_ERR_OVERFLOW;
+    if (ce_upto) ce_upto[q] = h_small[C4 + q];
+    if (meas) for (int r = 0; r < std::min(nm, max_rs); ++r) std::memcpy(meas + (q * max_rs + r) * TRK_MEAS, &h_meas[(q * rs_cap + r) * TRK_MEAS], sizeof(double) * TRK_MEAS);
+  }
+  for (int i = 0; i < n_cells; ++i)
+    for (int o = 0; o < max_off; ++o) {
+      if (mib_ok) mib_ok[(size_t)i * max_off + o] = (o < n_off) ? h_small[C4 * 2 + (size_t)i * n_off + o] : -1;
+      if (mib_bits) mib_bits[(size_t)i * max_off + o] = (o < n_off) ? h_bits[(size_t)i * n_off + o] : 0ull;
+    }
+  if (rc) c->err = "more reference symbols per port than max_rs rows";
+  return rc;
+}

@@ -1,0 +1,101 @@
+"""LTE-Tracker's per-symbol pipeline on blocks of OFDM symbols.
+
+The reference tracks every detected cell with one thread that consumes one OFDM symbol at a time
+(src/tracker_thread.cpp:823-1068): 128 time-domain samples cut by the producer thread (src/producer_thread.cpp:
+196-246) -> get_fd (:91-174) -> cell-specific reference symbols -> filter_ce (:176-201) -> frequency / timing
+measurements (do_foe :203-243, do_toe_v2 :245-288) -> 2-D interpolation of the channel estimate (:383-477) -> MIB
+re-decoding from the PBCH symbols of four frames (:494-529, 531-749).  Here the same work is done for a BLOCK of
+symbols of MANY tracked cells at once (`Searcher.track_block`, csrc/tracker.hip); this module holds the host side:
+the producer's symbol cutter, and the scalar feedback recurrences that consume the per-symbol measurements.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+FS_LTE = 30720000.0
+
+
+def wrap(x, lo, hi):
+    """WRAP of include/macros.h:45-53: x folded into [lo, hi)."""
+    return (x - lo) - (hi - lo) * np.floor((x - lo) / (hi - lo)) + lo
+
+
+def n_symb_dl(cp_type: int) -> int:
+    return 7 if cp_type == 1 else 6
+
+
+def cut_symbols(capbuf, frame_timing: float, cp_type: int, frequency_offset: float, fc_requested: float, fc_programmed: float,
+                fs_programmed: float, n_sym: int):
+    """What the producer thread queues for one tracked cell (src/producer_thread.cpp:96-131, 196-246), for a capture
+    buffer whose first sample has timestamp 0: up to n_sym OFDM symbols starting at slot 0 symbol 0 of the first
+    frame boundary in the buffer.  Returns (td [n][128] complex128, late [n], frame_timing [n], frequency_offset [n])."""
+    cap = np.asarray(capbuf, np.complex128)
+    k_factor = (fc_requested - frequency_offset) / fc_programmed
+    step = (FS_LTE / 16) / (fs_programmed * k_factor)
+    ts = wrap(np.arange(cap.size) * step, 0.0, 19200.0)     # timestamp of sample n on the cell-independent 1.92 MHz time base
+    td, late = [], []
+    target = 10.0 if cp_type == 1 else 32.0
+    sym, pos = 0, 0
+    nsd = n_symb_dl(cp_type)
+    while len(td) < n_sym:
+        # first sample at or after `pos` whose timestamp is within half a sample of the target (or just past it)
+        hit = -1
+        limit = min(cap.size - 128, pos + 25000)
+        n = pos
+        while n <= limit:
+            blk = ts[n:min(n + 4096, limit + 1)]
+            tdiff = wrap(blk - (frame_timing + target), -9600.0, 9600.0)
+            ok = np.flatnonzero((np.abs(tdiff) < 0.5) | ((tdiff > 0) & (tdiff < 3)))
+            if ok.size:
+                hit = n + int(ok[0])
+                late.append(float(tdiff[ok[0]]))
+                break
+            n += blk.size
+        if hit < 0:
+            break
+        td.append(cap[hit:hit + 128])
+        pos = hit + 128
+        target = (target + (160.0 if cp_type != 1 else (138.0 if sym == 6 else 137.0))) % 19200.0
+        sym = (sym + 1) % nsd
+    n = len(td)
+    return (np.array(td, np.complex128).reshape(n, 128), np.array(late), np.full(n, float(frame_timing)),
+            np.full(n, float(frequency_offset)))
+
+
+def fold_frequency_offset(f0: float, meas: np.ndarray) -> float:
+    """The global frequency-offset recurrence of do_foe (src/tracker_thread.cpp:235-242) over the rows of a block's
+    measurement table (columns 5, 6 = frequency_offset + residual_f, residual_f_np), in symbol order."""
+    f = f0
+    for row in meas[np.argsort(meas[:, 0], kind="stable")]:
+        f = (f * (1 / .000001) + row[5] * (1 / row[6])) / (1 / .000001 + 1 / row[6])
+    return f
+
+
+def fold_frame_timing(t0: float, meas: np.ndarray) -> float:
+    """The frame-timing recurrence of do_toe_v2 (src/tracker_thread.cpp:283-287); columns 7, 8 = rs_curr.frame_timing
+    + delay, delay_np."""
+    t = t0
+    for row in meas[np.argsort(meas[:, 0], kind="stable")]:
+        diff = wrap(row[7] - t, -19200.0 / 2, 19200.0 / 2)
+        diff = (0 * (1 / .0001) + diff * (1 / row[8])) / (1 / .0001 + 1 / row[8])
+        t = (t + diff) - 19200.0 * np.floor((t + diff) / 19200.0)
+    return t
+
+
+def mib_lock_walk(ok_by_frame_offset, failures: float = 0.0, synchronized: bool = False, drop_threshold: float = 400.0):      # CELL_DROP_THRESHOLD, include/constants.h:35
+    """do_mib_decode's fifo walk (src/tracker_thread.cpp:552-745) over a block in which every frame offset has been
+    tried in parallel: an attempt is made whenever 16 PBCH symbols are queued; success or a synchronised failure
+    consumes four frames, an unsynchronised failure one.  Returns (failures, synchronized, attempts made, dropped)."""
+    o, attempts = 0, 0
+    n = len(ok_by_frame_offset)
+    while o < n:
+        attempts += 1
+        if ok_by_frame_offset[o]:
+            synchronized, failures, o = True, 0.0, o + 4
+        elif synchronized:
+            failures, o = failures + 1.0, o + 4
+        else:
+            failures, o = failures + 0.25, o + 1
+        if failures >= drop_threshold:
+            return failures, synchronized, attempts, True
+    return failures, synchronized, attempts, False

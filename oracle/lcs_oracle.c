@@ -1295,3 +1295,301 @@ int orc_search_capbuf(const double *capbuf_re_im, uint32_t n_cap, const double *
   free(pow_); free(frq); free(single); free(pk); free(tfg); free(tfgc);
   return 0;
 }
+
+/* ==================================================================================================
+ * LTE-Tracker per-symbol pipeline (reference src/tracker_thread.cpp), restated for a BLOCK of
+ * n_sym consecutive OFDM symbols of one tracked cell: symbol i of the block is (slot, sym) = (slot0, sym0) advanced
+ * i times by slot_sym_inc (include/LTE-Tracker.h:255-263), with the 128 time-domain samples and the capture metadata
+ * (frequency_offset, frame_timing, late) the producer thread queues with every symbol (src/producer_thread.cpp:
+ * 196-246).  The reference walks the symbols one at a time through small fifos; the functions below produce the same
+ * per-symbol results as arrays.  The slow feedback recurrences those results feed (global frequency offset,
+ * src/tracker_thread.cpp:235-242; frame timing, :283-287; the mib_decode_failures state machine, :706-745) are
+ * scalar and stay with the caller.
+ */
+static void slot_sym_inc(int n_symb_dl, int *slot, int *sym) { /* ref: include/LTE-Tracker.h:255-263 */
+  *sym = imod(*sym + 1, n_symb_dl);
+  if (*sym == 0) *slot = imod(*slot + 1, 20);
+}
+
+/* ref: src/tracker_thread.cpp:91-174 get_fd.  td: [n_sym][128] complex; out syms: [n_sym][72]; *bpo is the running
+ * bulk_phase_offset (in: value before the block, out: after it); bpo_trace (nullable): its value at every symbol. */
+int orc_trk_get_fd(const orc_cell *cell, const double *td_re_im, int n_sym, int slot0, int sym0, const double *freq_off,
+                   const double *late, double fc_requested, double fc_programmed, double fs_programmed, double *bpo,
+                   double *syms_re_im, double *bpo_trace) {
+  const int n_symb_dl = cell_n_symb_dl(cell);
+  if (n_symb_dl < 0) return -1;
+  const cd *td = (const cd *)td_re_im;
+  cd *out = (cd *)syms_re_im;
+  int slot = slot0, sym = sym0;
+  double bulk_phase_offset = *bpo;
+  for (int i = 0; i < n_sym; i++) {
+    const double frequency_offset = freq_off[i];
+    const double k_factor = (fc_requested - frequency_offset) / fc_programmed;
+    cd data[128], dft_in[128], dft_out[128], syms[72];
+    fshift(td + (size_t)i * 128, 128, -frequency_offset, fs_programmed * k_factor, data);      /* :126 */
+    for (int t = 0; t < 126; t++) dft_in[t] = data[t + 2];                                      /* :129-134 */
+    dft_in[126] = data[0];
+    dft_in[127] = data[1];
+    dft128(dft_in, dft_out);                                                                    /* :135 */
+    for (int t = 0; t < 36; t++) { syms[t + 36] = dft_out[t + 1]; syms[t] = dft_out[92 + t]; }  /* :138-141 */
+    int n_samp_elapsed;
+    if (cell->cp_type == ORC_CP_EXTENDED) n_samp_elapsed = 128 + 32;                            /* :146-150 */
+    else n_samp_elapsed = (sym == 0) ? 128 + 10 : 128 + 9;
+    const double k = 2 * PI * late[i] / 128;
+    bulk_phase_offset = WRAP(bulk_phase_offset + 2 * PI * n_samp_elapsed * (1 / (FS_LTE / 16)) * -frequency_offset, -PI, PI);
+    const cd bpo_coeff = c_(cos(bulk_phase_offset), sin(bulk_phase_offset));
+    for (int t = 1; t <= 36; t++) {                                                             /* :158-165 */
+      const double phase = -k * t;
+      cd coeff = c_(cos(phase), sin(phase));
+      syms[35 + t] = cmul(syms[35 + t], cmul(bpo_coeff, coeff));
+      coeff.im = -coeff.im;
+      syms[36 - t] = cmul(syms[36 - t], cmul(bpo_coeff, coeff));
+    }
+    memcpy(out + (size_t)i * 72, syms, sizeof(syms));
+    if (bpo_trace) bpo_trace[i] = bulk_phase_offset;
+    slot_sym_inc(n_symb_dl, &slot, &sym);
+  }
+  *bpo = bulk_phase_offset;
+  return 0;
+}
+
+typedef struct { double shift; int slot, sym, idx; double frequency_offset, frame_timing; cd ce[12]; } trk_raw_t;
+typedef struct { double shift; int slot, sym, idx; double tp, sp, sp_raw, np; cd ce_filt[12]; } trk_filt_t;
+
+/* ref: src/tracker_thread.cpp:176-201 filter_ce (matlab_range + del_oob = the index ranges clipped to 0..11) */
+static void trk_filter_ce(const trk_raw_t *prev, const trk_raw_t *curr, const trk_raw_t *next, cd *ce_filt) {
+  for (int t = 0; t < 12; t++) {
+    cd total = c_(0, 0);
+    int n_total = 0;
+    for (int k = t - 1; k <= t + 1; k++) if (k >= 0 && k <= 11) { total = cadd(total, curr->ce[k]); n_total++; }
+    const int lo = (prev->shift < curr->shift) ? t : t - 1, hi = lo + 1;
+    cd sp_ = c_(0, 0), sn_ = c_(0, 0);
+    int n_ind = 0;
+    for (int k = lo; k <= hi; k++) if (k >= 0 && k <= 11) { sp_ = cadd(sp_, prev->ce[k]); sn_ = cadd(sn_, next->ce[k]); n_ind++; }
+    total = cadd(total, sp_);
+    total = cadd(total, sn_);
+    n_total += 2 * n_ind;
+    ce_filt[t] = cdivr(total, (double)n_total);
+  }
+}
+
+/* ref: src/tracker_thread.cpp:383-400 interp72 */
+static void trk_interp72(const trk_filt_t *rs, cd *interp) {
+  int l_x = (int)rs->shift;
+  cd l_y = rs->ce_filt[0];
+  int r_x = (int)rs->shift + 6;
+  cd r_y = rs->ce_filt[1];
+  int ptr = 1;
+  for (int t = 0; t < 72; t++) {
+    if ((t > r_x) && (ptr < 11)) { l_x = r_x; l_y = r_y; r_x += 6; ptr++; r_y = rs->ce_filt[ptr]; }
+    interp[t] = cadd(cscale(cdivr(csub(r_y, l_y), (double)(r_x - l_x)), (double)(t - l_x)), l_y);
+  }
+}
+
+/* RS extraction (ref :868-890), filtering + power measurements (:906-931), the FOE and TOE measurements (do_foe
+ * :203-243, do_toe_v2 :245-288, up to the value each one feeds into its recurrence) and the 2-D interpolation
+ * (interp2d :402-477) for every port of a block.
+ *   meas    [4][max_rs][9]: symbol index, np, tp, sp_raw, sp, frequency_offset + residual_f, residual_f_np,
+ *                           rs_curr.frame_timing + delay, delay_np -- one row per filtered RS symbol
+ *   n_meas  [4]            rows filled per port
+ *   ce      [4][n_sym][72] complex, ce_pw [4][n_sym][4] (tp, sp, sp_raw, np), valid for symbols < ce_upto[port]
+ */
+int orc_trk_chan_est(const orc_cell *cell, const double *syms_re_im, int n_sym, int slot0, int sym0, const double *freq_off,
+                     const double *frame_timing, double fc_requested, double fc_programmed, double fs_programmed,
+                     double *meas, int max_rs, int *n_meas, double *ce_re_im, double *ce_pw, int *ce_upto) {
+  const int n_symb_dl = cell_n_symb_dl(cell);
+  if (n_symb_dl < 0 || cell->n_ports < 1 || cell->n_ports > 4) return -1;
+  const cd *syms = (const cd *)syms_re_im;
+  rs_dl_t *R = (rs_dl_t *)malloc(sizeof(rs_dl_t));
+  rs_dl_build(cell_n_id_cell(cell), cell->cp_type, R);
+  trk_raw_t *raw = (trk_raw_t *)malloc(sizeof(trk_raw_t) * (n_sym + 1));
+  trk_filt_t *fl = (trk_filt_t *)malloc(sizeof(trk_filt_t) * (n_sym + 1));
+  for (int port = 0; port < 4; port++) { n_meas[port] = 0; ce_upto[port] = 0; }
+  for (int port = 0; port < cell->n_ports; port++) {
+    int m = 0, slot = slot0, sym = sym0;
+    for (int i = 0; i < n_sym; i++) {                                 /* :868-890 */
+      const double shift = rs_get_shift(R, slot, sym, port);
+      if (!isnan(shift)) {
+        trk_raw_t *r = &raw[m++];
+        r->shift = shift; r->slot = slot; r->sym = sym; r->idx = i;
+        r->frequency_offset = freq_off[i]; r->frame_timing = frame_timing[i];
+        const cd *rs = rs_get_rs(R, slot, sym);
+        for (int k = 0; k < 12; k++) r->ce[k] = cmul(syms[(size_t)i * 72 + round_i(shift) + 6 * k], cconj(rs[k]));
+      }
+      slot_sym_inc(n_symb_dl, &slot, &sym);
+    }
+    int nf = 0;
+    for (int r = 1; r + 1 < m; r++) {
+      const trk_raw_t *prev = &raw[r - 1], *curr = &raw[r], *next = &raw[r + 1];
+      trk_filt_t *F = &fl[nf];
+      trk_filter_ce(prev, curr, next, F->ce_filt);                    /* :906 */
+      cd diff[12];
+      for (int k = 0; k < 12; k++) diff[k] = csub(curr->ce[k], F->ce_filt[k]);
+      const double np = sigpower(diff, 12) * 7 / 6;                   /* :908 */
+      const double tp = sigpower(F->ce_filt, 12);
+      const double sp_raw = tp - np / 7;
+      const double sp = (.00001 > sp_raw) ? .00001 : sp_raw;          /* MAX(.00001, sp_raw) */
+      F->shift = curr->shift; F->slot = curr->slot; F->sym = curr->sym; F->idx = curr->idx;
+      F->tp = tp; F->sp = sp; F->sp_raw = sp_raw; F->np = np;
+      /* do_foe :203-243 */
+      cd foe_comb = c_(0, 0);
+      double foe_comb_np = 0, wsum = 0;
+      for (int k = 0; k < 12; k++) {
+        const cd foe = cmul(cconj(prev->ce[k]), next->ce[k]);
+        const double f2 = cabs2(F->ce_filt[k]);
+        const double foe_np = np * np + 2 * np * f2;
+        const double weight = f2 / foe_np;
+        foe_comb = cadd(foe_comb, cscale(foe, weight));
+        foe_comb_np += foe_np * weight * weight;
+        wsum += f2 * weight;
+      }
+      const double scale = 1 / wsum;
+      foe_comb = cscale(foe_comb, scale);
+      foe_comb_np = foe_comb_np * scale * scale;
+      const double frequency_offset = prev->frequency_offset;
+      const double k_factor = (fc_requested - frequency_offset) / fc_programmed;
+      const double residual_f = carg_(foe_comb) / (2 * PI) /
+                                (0.0005 + WRAP(next->frame_timing - prev->frame_timing, -19200.0 / 2, 19200.0 / 2) * (1 / (fs_programmed * k_factor)));
+      const double residual_f_np = (foe_comb_np / 2 > .001) ? foe_comb_np / 2 : .001;
+      /* do_toe_v2 :245-288 */
+      cd toe1 = c_(0, 0), toe2 = c_(0, 0);
+      const trk_raw_t *A = (prev->shift < curr->shift) ? prev : curr, *B = (prev->shift < curr->shift) ? curr : prev;
+      for (int k = 0; k < 12; k++) toe1 = cadd(toe1, cmul(cconj(A->ce[k]), B->ce[k]));
+      toe1 = cdivr(toe1, 12);
+      {
+        cd s1 = c_(0, 0), s2 = c_(0, 0);
+        for (int k = 0; k <= 4; k++) s1 = cadd(s1, cmul(cconj(B->ce[k]), A->ce[k + 1]));
+        for (int k = 6; k <= 10; k++) s2 = cadd(s2, cmul(cconj(B->ce[k]), A->ce[k + 1]));
+        toe2 = cdivr(cadd(s1, s2), 10);
+      }
+      toe1 = cdivr(toe1, sqrt(sp));
+      toe2 = cdivr(toe2, sqrt(sp));
+      const double delay = -(carg_(toe1) + carg_(toe2)) / 2 / 3 / (2 * PI / 128);
+      const double delay_np = (np / sp / 2 / 12 > .001) ? np / sp / 2 / 12 : .001;
+      if (nf < max_rs) {
+        double *mrow = meas + ((size_t)port * max_rs + nf) * 9;
+        mrow[0] = curr->idx; mrow[1] = np; mrow[2] = tp; mrow[3] = sp_raw; mrow[4] = sp;
+        mrow[5] = frequency_offset + residual_f; mrow[6] = residual_f_np;
+        mrow[7] = curr->frame_timing + delay; mrow[8] = delay_np;
+      }
+      nf++;
+    }
+    n_meas[port] = nf < max_rs ? nf : max_rs;
+    /* interp2d :402-477 over consecutive filtered RS symbols */
+    cd *ce = (cd *)ce_re_im + (size_t)port * n_sym * 72;
+    double *pw = ce_pw + (size_t)port * n_sym * 4;
+    int initialized = 0;
+    for (int j = 0; j + 1 < nf; j++) {
+      const trk_filt_t *rp = &fl[j], *rc = &fl[j + 1];
+      cd ip[72], ic[72];
+      trk_interp72(rp, ip);
+      trk_interp72(rc, ic);
+      double time_diff;
+      if (port > 2) time_diff = 0.0005;                               /* quirk kept: ports 0..2 take the symbol-based spacing */
+      else if (cell->cp_type == ORC_CP_EXTENDED) time_diff = 3 * (128 + 32) * (1 / (FS_LTE / 16));
+      else if (rp->sym == 0) time_diff = 4 * (128 + 9) * (1 / (FS_LTE / 16));
+      else time_diff = (2 * (128 + 9) + (128 + 10)) * (1 / (FS_LTE / 16));
+      double time_offset = 0;
+      int sl = rp->slot, sy = rp->sym, i = rp->idx;
+      while ((sl != rc->slot) || (sy != rc->sym)) {
+        cd mid[72];
+        const double q = time_offset / time_diff;
+        for (int t = 0; t < 72; t++) mid[t] = cadd(ip[t], cscale(csub(ic[t], ip[t]), q));
+        const double m_tp = rp->tp + (rc->tp - rp->tp) * q, m_sp = rp->sp + (rc->sp - rp->sp) * q;
+        const double m_spr = rp->sp_raw + (rc->sp_raw - rp->sp_raw) * q, m_np = rp->np + (rc->np - rp->np) * q;
+        if (!initialized) {                                           /* :449-462: the first estimate also covers the symbols before it */
+          initialized = 1;
+          for (int b = 0; b < i; b++) { memcpy(ce + (size_t)b * 72, mid, sizeof(mid)); pw[b * 4] = m_tp; pw[b * 4 + 1] = m_sp; pw[b * 4 + 2] = m_spr; pw[b * 4 + 3] = m_np; }
+        }
+        memcpy(ce + (size_t)i * 72, mid, sizeof(mid));
+        pw[i * 4] = m_tp; pw[i * 4 + 1] = m_sp; pw[i * 4 + 2] = m_spr; pw[i * 4 + 3] = m_np;
+        if (cell->cp_type == ORC_CP_EXTENDED) time_offset += (128 + 32) * (1 / (FS_LTE / 16));
+        else if (sy == 6) time_offset += (128 + 10) * (1 / (FS_LTE / 16));
+        else time_offset += (128 + 9) * (1 / (FS_LTE / 16));
+        slot_sym_inc(n_symb_dl, &sl, &sy);
+        i++;
+      }
+      ce_upto[port] = i;
+    }
+  }
+  free(R); free(raw); free(fl);
+  return 0;
+}
+
+/* One MIB attempt of the tracker: pbch_extract_rt (ref src/tracker_thread.cpp:494-529) + the decode part of
+ * do_mib_decode (:555-705) on 16 PBCH symbols (slot 1, symbols 0..3 of four consecutive frames).
+ * syms16 [16][72]; ce16 [n_ports][16][72]; np16 [n_ports][16].  c_est: the 40 decoded bits; *crc_ok: CRC (with the
+ * port mask) matches; *fields_ok: bandwidth / PHICH fields equal the tracked cell's (the lock test of :689-694 is
+ * crc_ok && fields_ok). */
+int orc_trk_mib(const orc_cell *cell, const double *syms16, const double *ce16, const double *np16, uint8_t *c_est,
+                int *crc_ok, int *fields_ok) {
+  const int n_ports = cell->n_ports;
+  if (n_ports != 1 && n_ports != 2 && n_ports != 4) return -1;
+  const int m_bit = (cell->cp_type == ORC_CP_NORMAL) ? 1920 : 1728, n_syms = m_bit / 2;
+  const int v_shift_m3 = imod(cell_n_id_cell(cell), 3);
+  const cd *S = (const cd *)syms16, *CE = (const cd *)ce16;
+  cd *pbch_sym = (cd *)malloc(sizeof(cd) * n_syms), *pbch_ce = (cd *)malloc(sizeof(cd) * 4 * n_syms);
+  double *np_pre = (double *)malloc(sizeof(double) * 4 * n_syms);
+  cd *syms_mib = (cd *)malloc(sizeof(cd) * n_syms);
+  double *np_mib = (double *)malloc(sizeof(double) * n_syms), *e_est = (double *)malloc(sizeof(double) * m_bit);
+  uint8_t *scr = (uint8_t *)malloc(m_bit);
+  int idx = 0;
+  for (int fr = 0; fr < 4; fr++) for (int symn = 0; symn < 4; symn++) for (int sc = 0; sc < 72; sc++) {
+    if ((imod(sc, 3) == v_shift_m3) && ((symn == 0) || (symn == 1) || ((symn == 3) && (cell->cp_type == ORC_CP_EXTENDED)))) continue;
+    pbch_sym[idx] = S[(fr * 4 + symn) * 72 + sc];
+    for (int p = 0; p < n_ports; p++) { pbch_ce[p * n_syms + idx] = CE[((size_t)p * 16 + fr * 4 + symn) * 72 + sc]; np_pre[p * n_syms + idx] = np16[p * 16 + fr * 4 + symn]; }
+    idx++;
+  }
+  if (n_ports == 1) {                                                  /* :572-576 */
+    for (int t = 0; t < n_syms; t++) {
+      const cd h = pbch_ce[t];
+      const cd gain = cconj(cdiv(h, c_(cabs2(h), 0)));
+      syms_mib[t] = cmul(pbch_sym[t], gain);
+      np_mib[t] = np_pre[t] * cabs2(gain);
+    }
+  } else {                                                             /* :584-625 */
+    for (int t = 0; t < n_syms; t += 2) {
+      cd h1, h2; double np_temp;
+      if (n_ports == 2) {
+        h1 = cdivr(cadd(pbch_ce[t], pbch_ce[t + 1]), 2);
+        h2 = cdivr(cadd(pbch_ce[n_syms + t], pbch_ce[n_syms + t + 1]), 2);
+        np_temp = (np_pre[t] + np_pre[n_syms + t]) / 2;
+      } else if (imod(t, 4) == 0) {
+        h1 = cdivr(cadd(pbch_ce[t], pbch_ce[t + 1]), 2);
+        h2 = cdivr(cadd(pbch_ce[2 * n_syms + t], pbch_ce[2 * n_syms + t + 1]), 2);
+        np_temp = (np_pre[t] + np_pre[2 * n_syms + t]) / 2;
+      } else {
+        h1 = cdivr(cadd(pbch_ce[n_syms + t], pbch_ce[n_syms + t + 1]), 2);
+        h2 = cdivr(cadd(pbch_ce[3 * n_syms + t], pbch_ce[3 * n_syms + t + 1]), 2);
+        np_temp = (np_pre[n_syms + t] + np_pre[3 * n_syms + t]) / 2;
+      }
+      const cd x1 = pbch_sym[t], x2 = pbch_sym[t + 1];
+      const double scale = pow(h1.re, 2) + pow(h1.im, 2) + pow(h2.re, 2) + pow(h2.im, 2);
+      syms_mib[t] = cdivr(cadd(cmul(cconj(h1), x1), cmul(h2, cconj(x2))), scale);
+      syms_mib[t + 1] = cconj(cdivr(cadd(cmul(c_(-h2.re, h2.im), x1), cmul(h1, cconj(x2))), scale));
+      np_mib[t] = (pow(hypot(h1.re, h1.im) / scale, 2) + pow(hypot(h2.re, h2.im) / scale, 2)) * np_temp;
+      np_mib[t + 1] = np_mib[t];
+    }
+    const double s2 = pow(2, 0.5);
+    for (int t = 0; t < n_syms; t++) syms_mib[t] = cscale(syms_mib[t], s2);
+  }
+  lte_demodulate_qpsk(syms_mib, np_mib, n_syms, e_est);               /* :634 */
+  orc_lte_pn((uint32_t)cell_n_id_cell(cell), (uint32_t)m_bit, scr);
+  for (int t = 0; t < m_bit; t++) if (scr[t]) e_est[t] = -e_est[t];
+  double d_est[3 * 40];
+  lte_conv_deratematch(e_est, m_bit, 40, d_est);
+  uint8_t crc_est[16];
+  conv_decode_tailbite(d_est, 40, c_est);
+  crc16_bits(c_est, 24, crc_est);
+  if (n_ports == 2) for (int t = 0; t < 16; t++) crc_est[t] = 1 - crc_est[t];
+  else if (n_ports == 4) for (int t = 1; t < 16; t += 2) crc_est[t] = 1 - crc_est[t];
+  *crc_ok = memcmp(crc_est, c_est + 24, 16) == 0;
+  const int bw_packed = c_est[0] * 4 + c_est[1] * 2 + c_est[2];
+  static const int bw[8] = {6, 15, 25, 50, 75, 100, 0, 0};
+  const int n_rb_dl_est = bw[bw_packed];
+  const int phich_duration_est = c_est[3] ? 2 : 1;
+  const int phich_resource_est = 1 + c_est[4] * 2 + c_est[5];
+  *fields_ok = (n_rb_dl_est == cell->n_rb_dl) && (phich_duration_est == cell->phich_duration) && (phich_resource_est == cell->phich_resource);
+  free(pbch_sym); free(pbch_ce); free(np_pre); free(syms_mib); free(np_mib); free(e_est); free(scr);
+  return 0;
+}

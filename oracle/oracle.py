@@ -289,3 +289,47 @@ def search_capbuf(capbuf, f_search_set, fc_requested, fc_programmed, fs_programm
     if rc:
         raise RuntimeError(f"orc_search_capbuf rc={rc}")
     return [_copy(cells[i]) for i in range(min(n.value, max_cells))], [_copy(peaks[i]) for i in range(min(npk.value, 256))]
+
+
+# ---- LTE-Tracker per-symbol pipeline on a block of OFDM symbols (src/tracker_thread.cpp) ----
+def trk_get_fd(cell, td, slot0, sym0, freq_off, late, fc_requested, fc_programmed, fs_programmed, bpo=0.0):
+    """-> (syms [n_sym][72], bulk_phase_offset after the block, its value at every symbol)"""
+    td = np.ascontiguousarray(td, np.complex128)
+    n = td.shape[0]
+    fo, lt = np.ascontiguousarray(freq_off, np.float64), np.ascontiguousarray(late, np.float64)
+    syms, trace = np.empty((n, 72), np.complex128), np.empty(n)
+    b = C.c_double(bpo)
+    rc = lib().orc_trk_get_fd(C.byref(cell), _dp(td), n, slot0, sym0, _dp(fo), _dp(lt), C.c_double(fc_requested),
+                              C.c_double(fc_programmed), C.c_double(fs_programmed), C.byref(b), _dp(syms), _dp(trace))
+    if rc:
+        raise RuntimeError(f"orc_trk_get_fd rc={rc}")
+    return syms, b.value, trace
+
+
+def trk_chan_est(cell, syms, slot0, sym0, freq_off, frame_timing, fc_requested, fc_programmed, fs_programmed, max_rs=None):
+    """-> dict(meas [4][max_rs][9], n_meas [4], ce [4][n_sym][72], ce_pw [4][n_sym][4], ce_upto [4])"""
+    syms = np.ascontiguousarray(syms, np.complex128)
+    n = syms.shape[0]
+    max_rs = max_rs or n
+    fo, ft = np.ascontiguousarray(freq_off, np.float64), np.ascontiguousarray(frame_timing, np.float64)
+    out = dict(meas=np.full((4, max_rs, 9), np.nan), n_meas=np.zeros(4, np.int32), ce=np.full((4, n, 72), np.nan + 0j, np.complex128),
+               ce_pw=np.full((4, n, 4), np.nan), ce_upto=np.zeros(4, np.int32))
+    rc = lib().orc_trk_chan_est(C.byref(cell), _dp(syms), n, slot0, sym0, _dp(fo), _dp(ft), C.c_double(fc_requested),
+                                C.c_double(fc_programmed), C.c_double(fs_programmed), _dp(out["meas"]), max_rs, _ip(out["n_meas"]),
+                                _dp(out["ce"]), _dp(out["ce_pw"]), _ip(out["ce_upto"]))
+    if rc:
+        raise RuntimeError(f"orc_trk_chan_est rc={rc}")
+    return out
+
+
+def trk_mib(cell, syms16, ce16, np16):
+    """-> (c_est [40] uint8, crc_ok, fields_ok)"""
+    s = np.ascontiguousarray(syms16, np.complex128)
+    ce = np.ascontiguousarray(ce16, np.complex128)
+    npw = np.ascontiguousarray(np16, np.float64)
+    bits = np.zeros(40, np.uint8)
+    a, b = C.c_int(0), C.c_int(0)
+    rc = lib().orc_trk_mib(C.byref(cell), _dp(s), _dp(ce), _dp(npw), bits.ctypes.data_as(C.POINTER(C.c_uint8)), C.byref(a), C.byref(b))
+    if rc:
+        raise RuntimeError(f"orc_trk_mib rc={rc}")
+    return bits, bool(a.value), bool(b.value)

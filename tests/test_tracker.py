@@ -1,0 +1,137 @@
+"""LTE-Tracker's per-symbol pipeline on blocks of OFDM symbols.
+
+CPU: the oracle's restatement of src/tracker_thread.cpp (get_fd, filter_ce, do_foe, do_toe_v2, interp2d,
+pbch_extract_rt + do_mib_decode) is pinned to the reference's golden capture: symbols cut from test/capbuf_0000.it the
+way the producer thread cuts them must re-decode the MIBs the searcher decodes there (cells 277 and 271, 50 RB, two
+ports, PHICH normal/one -- src/CMakeLists.txt:34-35, doc/CellSearch.html:75-82), and the frequency / timing measurements
+must agree with the searcher's estimates.  GPU: lcs_track_block against that oracle, array by array."""
+import numpy as np
+import pytest
+
+import oracle as O
+from conftest import golden, iq_u8_to_capbuf, load_pkg
+
+FS, FC = 1.92e6, 739e6
+
+
+@pytest.fixture(scope="module")
+def tracked():
+    """(capbuf, [(searcher record, td, late, frame_timing, freq_off)] for cells 277 and 271 of capbuf_0000)."""
+    pkg = load_pkg()
+    O.set_legacy(False)
+    O.set_threads(8)
+    cap = iq_u8_to_capbuf(golden("capbuf_0000")["iq_u8"])
+    cells, _ = O.search_capbuf(cap, np.array([30e3, 35e3, 40e3]), FC, FC, FS)
+    out = []
+    for c in cells:
+        k_factor = (FC - c.freq_superfine) / FC
+        ft = c.frame_start * (30.72e6 / 16) / (FS * k_factor)          # src/searcher_thread.cpp:224 with capbuf_sync.late = 0
+        td, late, ftv, fov = pkg.tracker.cut_symbols(cap, ft, c.cp_type, c.freq_superfine, FC, FC, FS, 7 * 140)
+        out.append((c, td, late, ftv, fov))
+    return cap, out
+
+
+def _oracle_block(c, td, late, ftv, fov):
+    syms, bpo, trace = O.trk_get_fd(c, td, 0, 0, fov, late, FC, FC, FS)
+    r = O.trk_chan_est(c, syms, 0, 0, fov, ftv, FC, FC, FS)
+    r.update(syms=syms, bpo=bpo)
+    n_fr = td.shape[0] // 140
+    upto = int(min(r["ce_upto"][:c.n_ports]))
+    mib = []
+    for o in range(n_fr - 3):
+        ii = [(o + fr) * 140 + 7 + s for fr in range(4) for s in range(4)]
+        if ii[-1] >= upto:
+            mib.append(None)
+            continue
+        mib.append(O.trk_mib(c, syms[ii], r["ce"][:c.n_ports][:, ii], r["ce_pw"][:c.n_ports][:, ii, 3]))
+    r["mib"] = mib
+    return r
+
+
+def test_producer_cut_is_symbol_aligned(tracked):
+    _, cells = tracked
+    pkg = load_pkg()
+    for c, td, late, ftv, fov in cells:
+        assert td.shape == (980, 128) and np.all(np.abs(late) < 0.5)
+        # the cutter advances 137/138 LTE samples per symbol: 19200 per frame
+        assert abs((late[140] - late[0])) < 0.2
+    assert pkg.tracker.mib_lock_walk([False, False, True, False, False, False, True]) == (0.0, True, 4, False)
+    assert pkg.tracker.mib_lock_walk([False] * 5)[0] == 1.25
+
+
+def test_oracle_tracker_redecodes_the_golden_cells(tracked):
+    _, cells = tracked
+    pkg = load_pkg()
+    assert [c.n_id_2 + 3 * c.n_id_1 for c, *_ in cells] == [277, 271]
+    for c, td, late, ftv, fov in cells:
+        r = _oracle_block(c, td, late, ftv, fov)
+        assert list(r["n_meas"][:2]) == [278, 278] and r["n_meas"][2] == 0      # 2 reference symbols per slot and port, minus the two ends
+        locked = [o for o, m in enumerate(r["mib"]) if m and m[1] and m[2]]
+        assert len(locked) == 1                                                  # exactly one 40 ms alignment in a 70 ms block
+        bits = r["mib"][locked[0]][0]
+        sfn8 = int("".join(str(b) for b in bits[6:14]), 2)
+        assert list(bits[:6]) == [0, 1, 1, 0, 1, 0]                              # 50 RB, PHICH normal / one
+        assert (sfn8 * 4 - locked[0]) % 1024 == c.sfn                            # the searcher's SFN for the buffer's first frame
+        others = [m for o, m in enumerate(r["mib"]) if m and o != locked[0]]
+        assert others and not any(m[1] for m in others)
+        # FOE / TOE measurements scatter around the searcher's estimates; folded through the reference's recurrences
+        # they stay put (the 1e-6 prior weight of do_foe makes a 50 ms block move the offset by well under 1 Hz)
+        m0 = r["meas"][0, :r["n_meas"][0]]
+        assert abs(np.median(m0[:, 5]) - c.freq_superfine) < 40 and abs(np.median(m0[:, 7]) - ftv[0]) < 1.0
+        assert abs(pkg.tracker.fold_frequency_offset(c.freq_superfine, m0) - c.freq_superfine) < 1.0
+        # channel estimates: |ce| on the strong cell is stable across the block, phase continuous
+        ce = r["ce"][0, :r["ce_upto"][0]]
+        assert np.isfinite(ce).all() and 0.2 < np.abs(ce).mean() / np.sqrt(r["meas"][0, 5, 2]) < 2.0
+
+
+@pytest.mark.gpu
+def test_gpu_track_block_matches_oracle(tracked):
+    """Both cells in one call (two tracked cells, 980 symbols each), every output array against the oracle."""
+    pkg = load_pkg()
+    _, cells = tracked
+    recs = [c for c, *_ in cells]
+    td = np.stack([x[1] for x in cells]); late = np.stack([x[2] for x in cells])
+    ftv = np.stack([x[3] for x in cells]); fov = np.stack([x[4] for x in cells])
+    with pkg.Searcher(0) as S:
+        g = S.track_block(recs, td, fov, ftv, late, FC, FC, FS)
+        g2 = S.track_block(recs, td, fov, ftv, late, FC, FC, FS)
+    assert np.array_equal(g["syms"], g2["syms"]) and np.array_equal(g["mib_bits"], g2["mib_bits"])
+    for i, (c, td_i, late_i, ft_i, fo_i) in enumerate(cells):
+        r = _oracle_block(c, td_i, late_i, ft_i, fo_i)
+        scale = np.abs(r["syms"]).max()
+        assert np.abs(g["syms"][i] - r["syms"]).max() < 1e-11 * scale
+        assert abs(g["bpo"][i] - r["bpo"]) < 1e-9
+        assert np.array_equal(g["n_meas"][i], r["n_meas"]) and np.array_equal(g["ce_upto"][i], r["ce_upto"])
+        for p in range(c.n_ports):
+            n = r["n_meas"][p]
+            gm, om = g["meas"][i, p, :n], r["meas"][p, :n]
+            assert np.array_equal(gm[:, 0], om[:, 0])
+            assert np.abs(gm[:, 1:5] - om[:, 1:5]).max() < 1e-11 * om[:, 2].max()
+            assert np.abs(gm[:, 5] - om[:, 5]).max() < 1e-6 and np.abs(gm[:, 7] - om[:, 7]).max() < 1e-8      # Hz, samples
+            assert np.abs(gm[:, 6] / om[:, 6] - 1).max() < 1e-9 and np.abs(gm[:, 8] / om[:, 8] - 1).max() < 1e-9
+            u = r["ce_upto"][p]
+            assert np.abs(g["ce"][i, p, :u] - r["ce"][p, :u]).max() < 1e-11 * np.abs(r["ce"][p, :u]).max()
+            assert np.abs(g["ce_pw"][i, p, :u] - r["ce_pw"][p, :u]).max() < 1e-11 * np.abs(r["ce_pw"][p, :u]).max()
+        for o, m in enumerate(r["mib"]):
+            if m is None:
+                assert g["mib_ok"][i, o] == -1
+                continue
+            bits, crc, fields = m
+            assert g["mib_ok"][i, o] == (1 if crc else 0) | (2 if fields else 0), (i, o)
+            assert [(int(g["mib_bits"][i, o]) >> k) & 1 for k in range(40)] == list(bits), (i, o)
+        assert 3 in list(g["mib_ok"][i])
+
+
+@pytest.mark.gpu
+def test_gpu_track_block_shapes_and_errors(tracked):
+    """One cell / a block too short for any MIB attempt / bad identities."""
+    pkg = load_pkg()
+    _, cells = tracked
+    c, td, late, ftv, fov = cells[0]
+    with pkg.Searcher(0) as S:
+        g = S.track_block([c], td[:280], fov[:280], ftv[:280], late[:280], FC, FC, FS)
+        r = O.trk_chan_est(c, O.trk_get_fd(c, td[:280], 0, 0, fov[:280], late[:280], FC, FC, FS)[0], 0, 0, fov[:280], ftv[:280], FC, FC, FS)
+        assert np.array_equal(g["ce_upto"][0], r["ce_upto"]) and (g["mib_ok"] == -1).all()
+        bad = pkg.new_cell(n_id_1=-1, n_id_2=1, cp_type=1, n_ports=2, n_rb_dl=50, phich_duration=1, phich_resource=3)
+        with pytest.raises(pkg.SearcherError):
+            S.track_block([bad], td[:280], fov[:280], ftv[:280], late[:280], FC, FC, FS)
