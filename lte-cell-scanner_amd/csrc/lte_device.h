@@ -93,7 +93,7 @@ __device__ __forceinline__ void qpsk_llr(cd2 sym, double np, double &l0, double 
 // Called by all PB_WAVES * 64 threads of the workgroup; ok / bits40 are valid on thread 0 afterwards.
 template <int PB_WAVES>
 __device__ __forceinline__ void pbch_decode_tail(const double *e_est, double (*d_est)[40], unsigned long long (*best_surv)[40],
-                                                 double *w_best, int *w_best_ss, unsigned char *c_est,
+                                                 double *w_best, int *w_best_ss,
                                                  const int16_t *__restrict__ derm_inv, int m_bit, int n_ports, int tid, int &ok,
                                                  unsigned long long &bits40) {
     // de-ratematch: average all observations of each coded bit (ref src/lte_lib.cpp:497-509)
@@ -112,7 +112,7 @@ __device__ __forceinline__ void pbch_decode_tail(const double *e_est, double (*d
       // their shuffle -> add -> compare chains overlap instead of running back to back.  Lane t
       // keeps the survivor word of step t for every trellis of the wave in registers.
       const int wave = tid >> 6, s = tid & 63;
-      constexpr int NQ = 64 / PB_WAVES;
+      constexpr int NQ = 64 / PB_WAVES, HQ = (NQ < 8) ? NQ : 8;
       const int b = s >> 5, p0 = (s << 1) & 63, p1 = p0 | 1;       // new state s <- predecessors p0, p1 with input bit b
       const int reg0 = (b << 6) | p0, reg1 = (b << 6) | p1;
       const bool a00 = __popc(reg0 & 0133) & 1, a01 = __popc(reg0 & 0171) & 1, a02 = __popc(reg0 & 0165) & 1;
@@ -125,15 +125,32 @@ __device__ __forceinline__ void pbch_decode_tail(const double *e_est, double (*d
         const double rr0 = d_est[0][t], rr1 = d_est[1][t], rr2 = d_est[2][t];
         const double c00 = a00 ? rr0 : -rr0, c01 = a01 ? rr1 : -rr1, c02 = a02 ? rr2 : -rr2;
         const double c10 = a10 ? rr0 : -rr0, c11 = a11 ? rr1 : -rr1, c12 = a12 ? rr2 : -rr2;
+        // the predecessor metrics of ALL trellises of a half-batch are fetched first (ds_bpermute on the two halves of
+        // each double), then the add-compare-select chains run: issued one trellis at a time, every chain would
+        // sit out the full cross-lane latency on its own (measured: 76 of k_pbch's 120 us)
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-          double m0 = __shfl(pm[q], p0), m1 = __shfl(pm[q], p1);
-          m0 += c00; m0 += c01; m0 += c02;
-          m1 += c10; m1 += c11; m1 += c12;
-          const bool take1 = m1 < m0;          // ties keep the lower-numbered predecessor
-          pm[q] = take1 ? m1 : m0;
-          const unsigned long long bal = __ballot(take1);
-          if (s == t) my_surv[q] = bal;
+        for (int h = 0; h < NQ; h += HQ) {
+          int f0l[HQ], f0h[HQ], f1l[HQ], f1h[HQ];
+#pragma unroll
+          for (int q = 0; q < HQ; ++q) {
+            const long long b = __double_as_longlong(pm[h + q]);
+            const int lo = (int)(b & 0xffffffffll), hi = (int)(b >> 32);
+            f0l[q] = __builtin_amdgcn_ds_bpermute(p0 << 2, lo); f0h[q] = __builtin_amdgcn_ds_bpermute(p0 << 2, hi);
+            f1l[q] = __builtin_amdgcn_ds_bpermute(p1 << 2, lo); f1h[q] = __builtin_amdgcn_ds_bpermute(p1 << 2, hi);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int q = 0; q < HQ; ++q) {
+            double m0 = __longlong_as_double(((long long)f0h[q] << 32) | (unsigned)f0l[q]);
+            double m1 = __longlong_as_double(((long long)f1h[q] << 32) | (unsigned)f1l[q]);
+            m0 += c00; m0 += c01; m0 += c02;
+            m1 += c10; m1 += c11; m1 += c12;
+            const bool take1 = m1 < m0;          // ties keep the lower-numbered predecessor
+            pm[h + q] = take1 ? m1 : m0;
+            const unsigned long long bal = __ballot(take1);
+            if (s == t) my_surv[h + q] = bal;
+          }
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
       double wbest = INFINITY; int wbest_ss = -1;
@@ -154,24 +171,26 @@ __device__ __forceinline__ void pbch_decode_tail(const double *e_est, double (*d
       ok = 0;
       if (w_best_ss[bw] >= 0) {
         int s = w_best_ss[bw];
+        unsigned long long bits = 0ull;                    // bit t = decoded bit c_est(t)
         for (int t = 39; t >= 0; --t) {
-          c_est[t] = (unsigned char)((s >> 5) & 1);
+          bits |= (unsigned long long)((s >> 5) & 1) << t;
           const int dec = (int)((best_surv[bw][t] >> s) & 1ull);
           s = ((s << 1) & 63) | dec;
         }
-        // CRC-16 (x^16+x^12+x^5+1, zero init) over the 24 payload bits, antenna-port mask
-        unsigned char buf[40];
-        for (int i = 0; i < 40; ++i) buf[i] = (i < 24) ? c_est[i] : 0;
-        const unsigned char poly[17] = {1, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
-        for (int i = 0; i < 24; ++i) if (buf[i]) for (int j = 0; j < 17; ++j) buf[i + j] ^= poly[j];
-        ok = 1;
-        for (int t = 0; t < 16; ++t) {
-          int crc = buf[24 + t];
-          if (n_ports == 2) crc = 1 - crc;
-          else if (n_ports == 4 && (t & 1)) crc = 1 - crc;
-          if (crc != c_est[24 + t]) ok = 0;
+        // CRC-16 (x^16+x^12+x^5+1, zero init) over the 24 payload bits as a shift register -- the remainder of the
+        // reference's long division (src/lte_lib.cpp:637-663), kept in one register instead of a byte array
+        unsigned crc = 0;
+        for (int i = 0; i < 24; ++i) {
+          const unsigned msb = ((crc >> 15) & 1u) ^ (unsigned)((bits >> i) & 1ull);
+          crc = (crc << 1) & 0xffffu;
+          if (msb) crc ^= 0x1021u;
         }
-        for (int i = 0; i < 40; ++i) bits40 |= (unsigned long long)c_est[i] << i;
+        unsigned rx = 0;                                   // received CRC, bit 15 - t = c_est(24 + t)
+        for (int t = 0; t < 16; ++t) rx |= (unsigned)((bits >> (24 + t)) & 1ull) << (15 - t);
+        if (n_ports == 2) crc ^= 0xffffu;                  // antenna-port masks (ref src/searcher.cpp:1628-1636)
+        else if (n_ports == 4) crc ^= 0x5555u;             // every second bit, t = 1, 3, ... <-> register bits 14, 12, ...
+        ok = (crc == rx) ? 1 : 0;
+        bits40 = bits;
       }
     }
   __syncthreads();

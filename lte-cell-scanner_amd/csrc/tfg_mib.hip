@@ -725,7 +725,6 @@ __global__ __launch_bounds__(PB_THREADS) __attribute__((amdgpu_waves_per_eu(3, 8
   __shared__ unsigned long long best_surv[PB_WAVES][40];
   __shared__ double w_best[PB_WAVES];
   __shared__ int w_best_ss[PB_WAVES];
-  __shared__ unsigned char c_est[40];
   const int tid = threadIdx.x, cand = blockIdx.y;
   const int guess = cand / 3, n_ports = (cand % 3 == 2) ? 4 : (cand % 3) + 1;
   for (int it = blockIdx.x; it < *n_work; it += gridDim.x) {
@@ -797,7 +796,7 @@ __global__ __launch_bounds__(PB_THREADS) __attribute__((amdgpu_waves_per_eu(3, 8
     PH(1);
     int ok = 0;
     unsigned long long bits40 = 0;
-    pbch_decode_tail<PB_WAVES>(e_est, d_est, best_surv, w_best, w_best_ss, c_est, derm_inv, m_bit, n_ports, tid, ok, bits40);
+    pbch_decode_tail<PB_WAVES>(e_est, d_est, best_surv, w_best, w_best_ss, derm_inv, m_bit, n_ports, tid, ok, bits40);
     if (tid == 0) {
       const unsigned bits24 = (unsigned)(bits40 & 0xffffffull);
       sc[CS_CAND + cand * 4 + 0] = (double)ok;

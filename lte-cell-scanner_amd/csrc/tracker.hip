@@ -287,7 +287,6 @@ __global__ __launch_bounds__(TRK_PB_THREADS) void k_trk_mib(const lcs_track_cell
   __shared__ unsigned long long best_surv[TRK_PB_WAVES][40];
   __shared__ double w_best[TRK_PB_WAVES];
   __shared__ int w_best_ss[TRK_PB_WAVES];
-  __shared__ unsigned char c_est[40];
   const int off = blockIdx.x, cell = blockIdx.y, tid = threadIdx.x;
   const lcs_track_cell c = cells[cell];
   const int n_symb = trk_n_symb(c), per_frame = 20 * n_symb, id = c.n_id_2 + 3 * c.n_id_1;
@@ -353,7 +352,7 @@ __global__ __launch_bounds__(TRK_PB_THREADS) void k_trk_mib(const lcs_track_cell
   __syncthreads();
   int ok = 0;
   unsigned long long bits40 = 0;
-  pbch_decode_tail<TRK_PB_WAVES>(e_est, d_est, best_surv, w_best, w_best_ss, c_est, derm_inv, m_bit, c.n_ports, tid, ok, bits40);
+  pbch_decode_tail<TRK_PB_WAVES>(e_est, d_est, best_surv, w_best, w_best_ss, derm_inv, m_bit, c.n_ports, tid, ok, bits40);
   if (tid == 0) {
     const int bw[8] = {6, 15, 25, 50, 75, 100, 0, 0};
     const int b0 = (int)(bits40 & 1), b1 = (int)((bits40 >> 1) & 1), b2 = (int)((bits40 >> 2) & 1);
