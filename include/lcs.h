@@ -146,6 +146,12 @@ int lcs_tfoec(lcs_ctx *ctx, const lcs_cell *cell, const double *tfg_re_im,
 int lcs_decode_mib(lcs_ctx *ctx, const lcs_cell *cell, const double *tfg_re_im, int n_ofdm,
                    lcs_cell *cell_out);
 
+/* chan_est (src/searcher.cpp:1369-1477 with ce_interp_hex :1223-1362), the first half of decode_mib, as a stage of its
+ * own: channel estimate of antenna port `port` on the whole compensated grid and the port's noise power.  Internal to the
+ * reference's searcher.cpp (not in searcher.h); exported so that it can be tested directly. */
+int lcs_chan_est(lcs_ctx *ctx, const lcs_cell *cell, const double *tfg_re_im, int n_ofdm, int port,
+                 double *ce_tfg_re_im /*[n_ofdm][72]*/, double *np);
+
 /* ---- fused chain ------------------------------------------------------------------- */
 
 /* One capture buffer through the whole chain of the reference's main loop

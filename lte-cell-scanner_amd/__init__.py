@@ -183,6 +183,14 @@ class Searcher:
         self._chk(rc, "lcs_decode_mib")
         return out
 
+    # ---- searcher.cpp:1369-1477 (internal to decode_mib; exported for direct testing) ------
+    def chan_est(self, cell, tfg, port: int):
+        tfg = np.ascontiguousarray(tfg, np.complex128)
+        ce = np.empty_like(tfg)
+        npw = C.c_double(0)
+        self._chk(self._lib.lcs_chan_est(self._h, C.byref(cell), _dp(tfg), tfg.shape[0], int(port), _dp(ce), C.byref(npw)), "lcs_chan_est")
+        return ce, npw.value
+
     # ---- CellSearch.cpp:484-558, one buffer -----------------------------------------
     def search_capbuf(self, capbuf, f_search_set, fc_requested, fc_programmed, fs_programmed, max_cells=64):
         cap = np.ascontiguousarray(capbuf, np.complex128)

@@ -63,7 +63,7 @@ class LcsTrackCell(C.Structure):
 EXPORTS = [
     "lcs_create", "lcs_destroy", "lcs_last_error", "lcs_version", "lcs_cell_init", "lcs_set_max_cells_in_flight",
     "lcs_xcorr_pss", "lcs_peak_search", "lcs_sss_detect", "lcs_pss_sss_foe", "lcs_extract_tfg", "lcs_tfoec",
-    "lcs_decode_mib", "lcs_search_capbuf", "lcs_search_batch_dev", "lcs_search_batch_host", "lcs_batch_enqueue",
+    "lcs_decode_mib", "lcs_chan_est", "lcs_search_capbuf", "lcs_search_batch_dev", "lcs_search_batch_host", "lcs_batch_enqueue",
     "lcs_batch_collect", "lcs_batch_readback",
     "lcs_track_block", "lcs_stream_open", "lcs_stream_push", "lcs_stream_collect", "lcs_stream_close",
     "lcs_last_xcorr_ms", "lcs_last_xcorr_info", "lcs_stream", "lcs_sync", "lcs_table_pss_td", "lcs_table_pss_fd", "lcs_table_sss_fd",
@@ -110,6 +110,7 @@ def load() -> C.CDLL:
     L.lcs_extract_tfg.argtypes = [vp, cp, dp, C.c_uint32, C.c_double, C.c_double, C.c_double, dp, dp, C.POINTER(C.c_int)]
     L.lcs_tfoec.argtypes = [vp, cp, dp, dp, C.c_int, C.c_double, C.c_double, dp, dp, cp]
     L.lcs_decode_mib.argtypes = [vp, cp, dp, C.c_int, cp]
+    L.lcs_chan_est.argtypes = [vp, cp, dp, C.c_int, C.c_int, dp, dp]
     L.lcs_search_capbuf.argtypes = [vp, dp, C.c_uint32, dp, C.c_uint16, C.c_double, C.c_double, C.c_double,
                                     cp, C.c_int, C.POINTER(C.c_int), cp, C.c_int, C.POINTER(C.c_int)]
     L.lcs_search_batch_dev.argtypes = [vp, vp, C.c_int, C.c_int, C.c_uint32, dp, C.c_uint16, dp, dp, C.c_double,

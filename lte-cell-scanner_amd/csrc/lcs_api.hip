@@ -624,6 +624,35 @@ int lcs_decode_mib(lcs_ctx *c, const lcs_cell *cell, const double *tfg, int n_of
   return LCS_OK;
 }
 
+// chan_est of decode_mib as a stage of its own (ref src/searcher.cpp:1369-1477, ce_interp_hex :1223-1362): the channel
+// estimate of one antenna port on the whole grid and its noise power -- an internal function of the reference, exported
+// so that the tests can pin it to the oracle directly rather than through the decoded MIB.
+int lcs_chan_est(lcs_ctx *c, const lcs_cell *cell, const double *tfg, int n_ofdm, int port, double *ce_tfg, double *np_out) {
+  if (!c || !cell || !tfg || !ce_tfg || !np_out) return LCS_ERR_BAD_ARG;
+  const int need = n_ofdm_for(cell);
+  if (need < 0 || n_ofdm != need || cell->n_id_1 < 0 || cell->n_id_2 < 0 || port < 0 || port > 3) {
+    c->err = "chan_est needs a detected cell, its full 854/732-symbol grid and a port 0..3";
+    return LCS_ERR_BAD_ARG;
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc;
+  if ((rc = put_single_work_item(c, cell, n_ofdm))) return rc;
+  HIPCHK(c, hipMemcpyAsync(c->tfg_comp, tfg, sizeof(double2) * n_ofdm * LCS_TFG_NSC, hipMemcpyHostToDevice, c->stream));
+  if ((rc = lcs_launch_rs_build(c))) return rc;
+  c->needed_rows_only = false;
+  if ((rc = lcs_launch_chan_est(c))) return rc;
+  int first, per_port, n_rs_at;
+  lcs_chan_est_np_layout(&first, &per_port, &n_rs_at);
+  std::vector<double> sc(LCS_CELL_SCRATCH);
+  HIPCHK(c, hipMemcpyAsync(ce_tfg, c->ce + (size_t)port * LCS_TFG_ROWS * LCS_TFG_NSC, sizeof(double2) * n_ofdm * LCS_TFG_NSC, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(sc.data(), c->cell_scratch, sizeof(double) * LCS_CELL_SCRATCH, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  double s = 0;
+  for (int q = 0; q < per_port; ++q) s += sc[first + port * per_port + q];      // chunk partials, in chunk order (tfg_mib.hip np_from_partials)
+  *np_out = s / (sc[n_rs_at + port] * 12);
+  return LCS_OK;
+}
+
 // One host buffer through the whole chain (ref src/CellSearch.cpp:484-558).
 int lcs_search_capbuf(lcs_ctx *c, const double *capbuf, uint32_t n_cap, const double *f_search_set, uint16_t n_f,
                       double fc_req, double fc_prog, double fs_prog, lcs_cell *cells, int max_cells, int *n_cells,

@@ -260,3 +260,5 @@ int lcs_launch_rs_build(lcs_ctx *c);
 int lcs_launch_tfg(lcs_ctx *c, uint32_t n_cap, bool with_rs /* also build RS_DL (the fused chain) */);
 int lcs_launch_tfoec(lcs_ctx *c, int n_items);
 int lcs_launch_mib(lcs_ctx *c, int n_items);
+int lcs_launch_chan_est(lcs_ctx *c);
+void lcs_chan_est_np_layout(int *first, int *per_port, int *n_rs_first);   // where k_chan_est leaves its noise-power partial sums in cell_scratch

@@ -235,7 +235,7 @@ __global__ __launch_bounds__(TFG_THREADS) void k_tfg(const lcs_cell *__restrict_
           double sn, cs;
           sincospi(kk * (double)src, &sn, &cs);
           v = cmul(mk(x.x, x.y), mk(cs, sn));
-        } else if (n == 0) sc[CS_OOB] = 1.0;   // the reference would read out of bounds here
+        } else sc[CS_OOB] = 1.0;               // any sample of a DFT window outside the buffer: the reference would read out of bounds
       }
       win[s][n] = v;
     }
@@ -871,6 +871,13 @@ int lcs_launch_tfoec(lcs_ctx *c, int n_items) {
   HIPCHK(c, hipGetLastError());
   return LCS_OK;
 }
+int lcs_launch_chan_est(lcs_ctx *c) {
+  hipLaunchKernelGGL(k_chan_est, dim3(GRID_ITEMS, 4, CE_NCHUNK), dim3(CE_THREADS), 0, c->stream, c->cells_out, c->n_work,
+                     c->tfg_comp, c->cell_scratch, c->ce, c->needed_rows_only ? 1 : 0);
+  HIPCHK(c, hipGetLastError());
+  return LCS_OK;
+}
+void lcs_chan_est_np_layout(int *first, int *per_port, int *n_rs_first) { *first = CS_NPP; *per_port = 8; *n_rs_first = CS_NRS; }
 int lcs_launch_mib(lcs_ctx *c, int n_items) {
   (void)n_items;
   hipLaunchKernelGGL(k_chan_est, dim3(GRID_ITEMS, 4, CE_NCHUNK), dim3(CE_THREADS), 0, c->stream, c->cells_out, c->n_work,

@@ -1593,3 +1593,16 @@ int orc_trk_mib(const orc_cell *cell, const double *syms16, const double *ce16, 
   free(pbch_sym); free(pbch_ce); free(np_pre); free(syms_mib); free(np_mib); free(e_est); free(scr);
   return 0;
 }
+
+/* ---- thin exports of two third-party-arithmetic restatements, so that the tests can pin them to independent
+ * implementations (numpy.linalg.solve; the closed form of the QPSK log-MAP LLR) ---- */
+void orc_solve3(const double *M_re_im /*[3][3]*/, const double *V_re_im /*[3]*/, double *out_re_im /*[3]*/) {
+  cd M[3][3], V[3], o[3];
+  memcpy(M, M_re_im, sizeof(M));
+  memcpy(V, V_re_im, sizeof(V));
+  solve3(M, V, o);
+  memcpy(out_re_im, o, sizeof(o));
+}
+void orc_qpsk_llr(const double *syms_re_im, const double *np, int n, double *llr /*[2n]*/) {
+  lte_demodulate_qpsk((const cd *)syms_re_im, np, n, llr);
+}

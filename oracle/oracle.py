@@ -333,3 +333,17 @@ def trk_mib(cell, syms16, ce16, np16):
     if rc:
         raise RuntimeError(f"orc_trk_mib rc={rc}")
     return bits, bool(a.value), bool(b.value)
+
+
+def solve3(M, V):
+    M = np.ascontiguousarray(M, np.complex128); V = np.ascontiguousarray(V, np.complex128)
+    o = np.empty(3, np.complex128)
+    lib().orc_solve3(_dp(M), _dp(V), _dp(o))
+    return o
+
+
+def qpsk_llr(syms, np_):
+    s = np.ascontiguousarray(syms, np.complex128); n = np.ascontiguousarray(np_, np.float64)
+    out = np.empty(2 * s.size)
+    lib().orc_qpsk_llr(_dp(s), _dp(n), s.size, _dp(out))
+    return out

@@ -85,6 +85,14 @@ def test_tfg_tfoec_mib_on_golden_cell(S, pkg):
     assert abs(c2g.freq_superfine - c2o.freq_superfine) < 1e-7
     assert _close(tsc_g, tsc_o, 1e-13)
     assert _close(tfgc_g, tfgc_o, 1e-9), np.abs(tfgc_g - tfgc_o).max()
+    # chan_est + ce_interp_hex (src/searcher.cpp:1369-1477, 1223-1362) directly: all four antenna ports, the whole 854 x 72
+    # estimate and the noise power (the GPU forms each triangle's plane in closed form where the reference -- and the
+    # oracle -- solve the 3x3 system: same plane, rounding differs at the 1e-13 level)
+    for port in range(4):
+        ce_o, np_o = O.chan_est(c2o, tfgc_o, port)
+        ce_g, np_g = S.chan_est(c2g, tfgc_o, port)
+        assert abs(np_g - np_o) <= 1e-11 * np_o, port
+        assert np.abs(ce_g - ce_o).max() <= 1e-9 * np.abs(ce_o).max(), (port, np.abs(ce_g - ce_o).max())
     c3o = O.decode_mib(c2o, tfgc_o)
     c3g = S.decode_mib(c2g, tfgc_o)
     assert c3g.n_rb_dl == 50 == int(g["expected_n_rb_dl"][0])

@@ -263,3 +263,54 @@ def test_short_capbuf_135360():
     cells, _ = O.search_capbuf(cap, g["f_search_set"], fc, fc, FS)
     assert [c.n_id_cell() for c in cells][:1] == [277]
     assert (cells[0].n_ports, cells[0].n_rb_dl) == (2, 50)
+
+
+# ---- third-party arithmetic the reference delegates to IT++ / LAPACK, pinned to independent implementations ----------
+def test_solve3_matches_numpy_linalg():
+    """ce_interp_hex solves a 3x3 complex system per triangle with itpp::inv (LAPACK), src/searcher.cpp:1309; the oracle's
+    LU restatement against numpy.linalg.solve on random and on badly scaled systems."""
+    rng = np.random.default_rng(42)
+    for k in range(300):
+        M = rng.normal(size=(3, 3)) + 1j * rng.normal(size=(3, 3))
+        if k % 3 == 0:      # the shape the searcher builds: rows (x, y, 1) with integer coordinates
+            M = np.array([[rng.integers(0, 72), rng.integers(0, 854), 1], [rng.integers(0, 72), rng.integers(0, 854), 1],
+                          [rng.integers(0, 72), rng.integers(0, 854), 1]], np.complex128)
+            if abs(np.linalg.det(M)) < 1:
+                continue
+        V = rng.normal(size=3) + 1j * rng.normal(size=3)
+        ref = np.linalg.solve(M, V)
+        got = O.solve3(M, V)
+        assert np.abs(got - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max()) * np.linalg.cond(M), k
+
+
+def test_qpsk_llr_matches_closed_form_log_map():
+    """lte_demodulate(QAM) = IT++ exact log-MAP with rx = sym/sqrt(np), channel 1/sqrt(np), N0 = 1 (src/lte_lib.cpp:628-631).
+    For Gray-mapped QPSK the sums factor: LLR(b0) = 2 sqrt(2) Re(sym) / np, LLR(b1) = 2 sqrt(2) Im(sym) / np, as long as no
+    exponential underflows; where they do, IT++'s trunc_log clips at log(DBL_MIN) and the LLR saturates -- checked too."""
+    rng = np.random.default_rng(7)
+    syms = (rng.normal(size=4000) + 1j * rng.normal(size=4000)) * 0.8
+    npw = 10 ** rng.uniform(-1.2, 1.0, 4000)
+    llr = O.qpsk_llr(syms, npw)
+    exact = np.empty(8000)
+    exact[0::2] = 2 * np.sqrt(2) * syms.real / npw
+    exact[1::2] = 2 * np.sqrt(2) * syms.imag / npw
+    # independent evaluation of the same log-MAP expression in extended precision (no underflow, no clipping)
+    a = 1 / np.sqrt(2)
+    g = (1 / np.sqrt(npw)).astype(np.longdouble)
+    rx = syms.astype(np.clongdouble) * g
+    S = np.array([a + 1j * a, a - 1j * a, -a + 1j * a, -a - 1j * a])
+    m = np.stack([np.exp(-np.abs(rx - g * s) ** 2) for s in S])
+    lm0, lm1 = np.log(m[0] + m[1]) - np.log(m[2] + m[3]), np.log(m[0] + m[2]) - np.log(m[1] + m[3])
+    ok = np.isfinite(lm0) & np.isfinite(lm1)
+    assert ok.mean() > 0.9
+    assert np.abs(llr[0::2][ok] - np.asarray(lm0[ok], np.float64)).max() < 1e-9 * (1 + np.abs(exact).max())
+    assert np.abs(llr[1::2][ok] - np.asarray(lm1[ok], np.float64)).max() < 1e-9 * (1 + np.abs(exact).max())
+    small = np.abs(exact) < 300                      # well inside the range of exp(): closed form holds
+    assert np.abs(llr[small] - exact[small]).max() < 1e-9 * 300
+    # strong symbols: the exponentials of the far hypotheses underflow, trunc_log(0) = log(DBL_MIN) = -708.4 clips the LLR
+    # below its closed-form value (2545 here) ...
+    mid = O.qpsk_llr(np.array([0.9 + 0.9j]), np.array([1e-3]))
+    assert 500 < mid[0] < 708.4 and 500 < mid[1] < 708.4
+    # ... and when all four underflow the difference of two clipped logs is exactly 0: an erasure
+    big = O.qpsk_llr(np.array([40 + 0.01j, -40 - 40j]), np.array([1e-3, 1e-3]))
+    assert np.all(big == 0.0)
