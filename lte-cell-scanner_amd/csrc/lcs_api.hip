@@ -30,20 +30,22 @@ int pinned(lcs_ctx *c, size_t bytes) {
   return LCS_OK;
 }
 
-XcGeom make_geo(uint32_t n_cap, int n_f, int ds) {
+XcGeom make_geo(uint32_t n_cap, int n_f, int ds, int cpg = LCS_TG) {
   XcGeom g;
   g.n_cap = n_cap;
   g.n_f = n_f;
   g.n_tmpl = 3 * n_f;
-  g.G = (g.n_tmpl + LCS_TG - 1) / LCS_TG;
+  g.cpg = cpg;
+  g.G = (g.n_tmpl + cpg - 1) / cpg;
   g.n_comb = (int)((n_cap - 136 - 100) / 9600);   // ref src/searcher.cpp:276
   g.ds = ds;
   return g;
 }
 
 // Grow the workspace so that n_slots buffers of n_cap samples with n_f hypotheses fit.
-int ensure_ws(lcs_ctx *c, int n_slots, uint32_t n_cap, int n_f, bool debug) {
-  if (n_slots <= c->cap_slots && n_cap <= c->cap_n_cap && n_f <= c->cap_n_f && (!debug || c->cap_debug)) return LCS_OK;
+int ensure_ws(lcs_ctx *c, int n_slots, uint32_t n_cap, int n_f, bool debug, int G_need = 0) {
+  if (G_need <= 0) G_need = (3 * n_f + LCS_TG - 1) / LCS_TG;           // dense packing
+  if (n_slots <= c->cap_slots && n_cap <= c->cap_n_cap && n_f <= c->cap_n_f && G_need <= c->cap_G && (!debug || c->cap_debug)) return LCS_OK;
   if (c->st_open) {     // the captured graph of the streaming mode holds the current buffers' addresses
     c->err = "this call needs a larger workspace than the open stream was captured with: lcs_stream_close first";
     return LCS_ERR_BAD_ARG;
@@ -54,7 +56,7 @@ int ensure_ws(lcs_ctx *c, int n_slots, uint32_t n_cap, int n_f, bool debug) {
   debug = debug || c->cap_debug;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   const size_t S = n_slots, NE = 3 * LCS_N_IDX;
-  const int G = (3 * n_f + LCS_TG - 1) / LCS_TG;
+  const int G = std::max(std::max(G_need, c->cap_G), (3 * n_f + LCS_TG - 1) / LCS_TG);
   int rc;
 #define A(p, n) if ((rc = dev_alloc(c, &c->p, (n))) != LCS_OK) return rc
   A(cap32, S * n_cap);
@@ -89,6 +91,7 @@ int ensure_ws(lcs_ctx *c, int n_slots, uint32_t n_cap, int n_f, bool debug) {
   c->cap_slots = n_slots;
   c->cap_n_cap = n_cap;
   c->cap_n_f = n_f;
+  c->cap_G = G;
   c->cap_debug = debug;
   return LCS_OK;
 }
@@ -98,7 +101,7 @@ int ensure_i8(lcs_ctx *c) {
   if (c->i8_ready) return LCS_OK;
   if (c->st_open) { c->err = "int8 buffers cannot be (re)allocated while a stream is open: lcs_stream_close first"; return LCS_ERR_BAD_ARG; }
   const size_t S = (size_t)c->cap_slots;
-  const int G = (3 * c->cap_n_f + LCS_TG - 1) / LCS_TG;
+  const int G = c->cap_G;
   int rc;
   const size_t n8 = S * lcs_cap8_stride(c->cap_n_cap);
   if ((rc = dev_alloc(c, &c->cap8, n8)) || (rc = dev_alloc(c, &c->cap8s, n8))) return rc;
@@ -130,27 +133,43 @@ int ensure_percell(lcs_ctx *c) {
   return LCS_OK;
 }
 
-// Host-side check that the frequency grid fits the fused combining (see k_prep_tables).
-int validate_grid(lcs_ctx *c, const XcGeom &geo, const double *fset, double fc_req, double fc_prog, double fs_prog) {
-  for (int w = 0; w < geo.n_comb; ++w) {
+// Largest tap count (137 + the spread of the window starts inside one template group, see k_prep_tables) of a frequency
+// grid packed `cpg` template columns per group.
+int grid_taps(const XcGeom &geo, const double *fset, double fc_req, double fc_prog, double fs_prog) {
+  int worst = 137;
+  for (int w = 0; w < geo.n_comb; ++w)
     for (int g = 0; g < geo.G; ++g) {
-      const int c_hi = std::min(g * LCS_TG + LCS_TG - 1, geo.n_tmpl - 1);
-      const int f_lo = (g * LCS_TG) / 3, f_hi = c_hi / 3;
+      const int c_hi = std::min(g * geo.cpg + geo.cpg - 1, geo.n_tmpl - 1);
+      const int f_lo = (g * geo.cpg) / 3, f_hi = c_hi / 3;
       int mn = 0, mx = 0;
       for (int f = f_lo; f <= f_hi; ++f) {
         const double kf = (fc_req - fset[f]) / fc_prog;
         const int s = (int)std::rint((((double)w * .005) * kf) * fs_prog);
         if (f == f_lo) { mn = mx = s; } else { mn = std::min(mn, s); mx = std::max(mx, s); }
       }
-      c->grid_max_k2 = std::max(c->grid_max_k2, (137 + (mx - mn) + 1) / 2);
-      if ((137 + (mx - mn) + 1) / 2 > LCS_KP2_MAX - LCS_KP2_UNROLL) {
-        c->err = "f_search_set too sparse: window-start spread inside one 16-template group exceeds the fused kernel's limit";
-        return LCS_ERR_BAD_ARG;
-      }
+      worst = std::max(worst, 137 + (mx - mn));
     }
-  }
-  return LCS_OK;
+  return worst;
 }
+
+// Choose how the 3 n_f templates are packed into 16-column groups: densely when the window starts of a group's
+// hypotheses stay within `max_taps` - 137 samples of each other over the whole buffer (every grid the CLI builds), else
+// with fewer whole hypotheses per group -- one per group always fits (its three templates share a window start).
+XcGeom pack_grid(uint32_t n_cap, int n_f, int ds, const double *fset, const double *fc_req, const double *fc_prog, int n_buf,
+                 double fs_prog, int max_taps) {
+  static const int packings[] = {LCS_TG, 15, 12, 9, 6, 3};
+  for (int cpg : packings) {
+    const XcGeom geo = make_geo(n_cap, n_f, ds, cpg);
+    bool fits = true;
+    for (int i = 0; i < n_buf && fits; ++i)
+      if (i == 0 || fc_req[i] != fc_req[i - 1] || fc_prog[i] != fc_prog[i - 1])
+        fits = grid_taps(geo, fset, fc_req[i], fc_prog[i], fs_prog) <= max_taps;
+    if (fits || cpg == 3) return geo;
+  }
+  return make_geo(n_cap, n_f, ds, 3);
+}
+constexpr int kMaxTapsI8 = 32 * LCS_I8_KB;                               // int8 kernel: 5 blocks of 32 taps
+constexpr int kMaxTapsF32 = 2 * (LCS_KP2_MAX - LCS_KP2_UNROLL);          // fp32 kernel: 124 tap pairs
 
 int check_common(lcs_ctx *c, uint32_t n_cap, int n_f) {
   if (!c) return LCS_ERR_BAD_ARG;
@@ -285,9 +304,8 @@ int lcs_xcorr_pss(lcs_ctx *c, const double *capbuf, uint32_t n_cap, const double
   if (ds_comb_arm > 8) { c->err = "ds_comb_arm > 8 is not supported (the reference uses 2)"; return LCS_ERR_BAD_ARG; }
   HIPCHK(c, hipSetDevice(c->device));
   const bool debug = incoh != nullptr;
-  if ((rc = ensure_ws(c, 1, n_cap, n_f, debug))) return rc;
-  const XcGeom geo = make_geo(n_cap, n_f, ds_comb_arm);
-  if ((rc = validate_grid(c, geo, f_search_set, fc_req, fc_prog, fs_prog))) return rc;
+  const XcGeom geo = pack_grid(n_cap, n_f, ds_comb_arm, f_search_set, &fc_req, &fc_prog, 1, fs_prog, kMaxTapsF32);
+  if ((rc = ensure_ws(c, 1, n_cap, n_f, debug, geo.G))) return rc;
   SlotParams p{fc_req, fc_prog, fs_prog};
   HIPCHK(c, hipMemcpyAsync(c->cap64, capbuf, sizeof(double2) * n_cap, hipMemcpyHostToDevice, c->stream));
   c->cap64_valid = true;
@@ -359,24 +377,21 @@ int lcs_batch_enqueue(lcs_ctx *c, const void *d_capbufs, int fmt, int n_buf, uin
   if (!d_capbufs || !f_search_set || !fc_requested || !fc_programmed || n_buf < 1) { c->err = "bad argument"; return LCS_ERR_BAD_ARG; }
   if (fmt != LCS_FMT_C64 && fmt != LCS_FMT_IQ_U8) { c->err = "unknown capture format"; return LCS_ERR_BAD_ARG; }
   HIPCHK(c, hipSetDevice(c->device));
-  if ((rc = ensure_ws(c, n_buf, n_cap, n_f, false))) return rc;
-  const XcGeom geo = make_geo(n_cap, n_f, 2 /* DS_COMB_ARM, ref src/CellSearch.cpp:484 */);
+  // u8 I/Q is exact in int8: the int8 three-digit kernel (pss_xcorr_i8.hip), 137 taps + window-start spread <= 160 inside
+  // every template group; every other source takes the fp32 kernel (spread <= 111); pack_grid thins the groups of a grid
+  // that is too sparse for that
+  const XcGeom geo = pack_grid(n_cap, n_f, 2 /* DS_COMB_ARM, ref src/CellSearch.cpp:484 */, f_search_set, fc_requested, fc_programmed,
+                               n_buf, fs_programmed, fmt == LCS_FMT_IQ_U8 ? kMaxTapsI8 : kMaxTapsF32);
+  if ((rc = ensure_ws(c, n_buf, n_cap, n_f, false, geo.G))) return rc;
   if ((rc = pinned(c, sizeof(SlotParams) * n_buf + sizeof(double) * LCS_NF_MAX))) return rc;
   SlotParams *hp = (SlotParams *)c->h_pinned;
   double *hf = (double *)(hp + n_buf);
-  c->grid_max_k2 = 0;
-  for (int i = 0; i < n_buf; ++i) {
-    hp[i] = SlotParams{fc_requested[i], fc_programmed[i], fs_programmed};
-    if (i == 0 || fc_requested[i] != fc_requested[i - 1] || fc_programmed[i] != fc_programmed[i - 1])
-      if ((rc = validate_grid(c, geo, f_search_set, fc_requested[i], fc_programmed[i], fs_programmed))) return rc;
-  }
+  for (int i = 0; i < n_buf; ++i) hp[i] = SlotParams{fc_requested[i], fc_programmed[i], fs_programmed};
   std::memcpy(hf, f_search_set, sizeof(double) * n_f);
   HIPCHK(c, hipMemcpyAsync(c->params, hp, sizeof(SlotParams) * n_buf, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->fset, hf, sizeof(double) * n_f, hipMemcpyHostToDevice, c->stream));
   c->cap64_valid = false;
-  // u8 I/Q is exact in int8: the int8 three-digit kernel (pss_xcorr_i8.hip); it needs 137 taps + window-start
-  // spread <= 160 inside every 16-template group, sparser grids (and every other source) take the fp32 kernel
-  c->use_i8 = fmt == LCS_FMT_IQ_U8 && 2 * c->grid_max_k2 <= 32 * LCS_I8_KB;
+  c->use_i8 = fmt == LCS_FMT_IQ_U8;
   if (fmt == LCS_FMT_IQ_U8 && (rc = ensure_i8(c))) return rc;      // int8 copies: every u8 source (the fp64 stages read them)
   if ((rc = lcs_launch_ingest(c, d_capbufs, fmt, n_buf, n_cap))) return rc;
   if ((rc = lcs_launch_xcorr(c, n_buf, geo, false, true))) return rc;
@@ -661,10 +676,9 @@ int lcs_search_capbuf(lcs_ctx *c, const double *capbuf, uint32_t n_cap, const do
   if (rc) return rc;
   if (!capbuf || !f_search_set || !n_cells || (max_cells > 0 && !cells)) { c->err = "null argument"; return LCS_ERR_BAD_ARG; }
   HIPCHK(c, hipSetDevice(c->device));
-  if ((rc = ensure_ws(c, 1, n_cap, n_f, false))) return rc;
+  const XcGeom geo = pack_grid(n_cap, n_f, 2, f_search_set, &fc_req, &fc_prog, 1, fs_prog, kMaxTapsF32);
+  if ((rc = ensure_ws(c, 1, n_cap, n_f, false, geo.G))) return rc;
   if ((rc = ensure_percell(c))) return rc;
-  const XcGeom geo = make_geo(n_cap, n_f, 2);
-  if ((rc = validate_grid(c, geo, f_search_set, fc_req, fc_prog, fs_prog))) return rc;
   SlotParams p{fc_req, fc_prog, fs_prog};
   HIPCHK(c, hipMemcpyAsync(c->cap64, capbuf, sizeof(double2) * n_cap, hipMemcpyHostToDevice, c->stream));
   c->cap64_valid = true;

@@ -36,7 +36,7 @@
 #define LCS_GRID_CAP (1 << 20)
 #endif
 #define LCS_TG 16            // templates per MFMA column group
-#define LCS_G_MAX ((3 * LCS_NF_MAX + LCS_TG - 1) / LCS_TG)
+#define LCS_G_MAX LCS_NF_MAX   // template groups per buffer: ceil(3 n_f / 16) when packed densely, up to n_f when one hypothesis takes a group
 #define LCS_KP2_MAX 128      // tap pairs per (window, group): 137 taps + up to 119 samples of spread
 #define LCS_KP2_UNROLL 4
 #define LCS_LAG_TILE 64      // lags per wave
@@ -55,7 +55,8 @@ struct XcGeom {
   uint32_t n_cap;
   int n_f;
   int n_tmpl;   // 3*n_f
-  int G;        // ceil(n_tmpl/16)
+  int cpg;      // template columns in use per 16-column group: 16 = dense packing, 15/12/9/6/3 = whole hypotheses per group
+  int G;        // ceil(n_tmpl / cpg)
   int n_comb;   // n_comb_xc
   int ds;       // ds_comb_arm
 };
@@ -64,6 +65,15 @@ struct XcGeom {
 // aligned) with LCS_I8_PAD zero samples behind the data -- the correlation kernel's LDS-DMA reads run past n_cap
 #define LCS_I8_PAD 1024
 __host__ __device__ static inline size_t lcs_cap8_stride(uint32_t n_cap) { return (((size_t)n_cap + 7) & ~(size_t)7) + LCS_I8_PAD; }
+
+// Template (foi * 3 + pss) held by column j of group g, or -1.  With the dense packing (cpg 16) consecutive templates fill
+// the columns and a hypothesis may straddle two groups; a frequency grid too sparse for that (the window starts of the
+// hypotheses in one group drift apart by more samples than the correlation kernels' tap blocks hold) is packed with
+// fewer, whole hypotheses per group -- down to one (cpg 3), whose three templates share one window start.
+__host__ __device__ static inline int lcs_col_tmpl(const XcGeom &geo, int g, int j) {
+  const int c = g * geo.cpg + j;
+  return (j < geo.cpg && c < geo.n_tmpl) ? c : -1;
+}
 
 // The capture buffers as the fp64 stages see them (exactly one pointer is set): the fp64 copy when a host entry
 // point handed over complex<double>; the int8 pairs 127 - u8 of an RTL-SDR source ((u8-127)/128 = -a/128, exact);
@@ -126,6 +136,7 @@ struct lcs_ctx {
   int cap_slots = 0;
   uint32_t cap_n_cap = 0;
   int cap_n_f = 0;
+  int cap_G = 0;                     // template groups per buffer the tables are sized for
   bool cap_debug = false;
 
   // device buffers
@@ -137,7 +148,6 @@ struct lcs_ctx {
   float *tsc = nullptr;              // per template: 1 / (128 q)
   bool i8_ready = false, use_i8 = false;
   bool src_u8 = false;               // the resident buffers came from a u8 source: the fp64 stages read cap8
-  int grid_max_k2 = 0;               // largest tap-pair count (137 taps + window-start spread) seen by validate_grid
   double2 *cap64 = nullptr;          // slot 0 only: fp64 copy for the host (complex<double>) entry points
   bool cap64_valid = false;
   SlotParams *params = nullptr;

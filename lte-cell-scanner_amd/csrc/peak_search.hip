@@ -85,7 +85,7 @@ __global__ __launch_bounds__(PS_THREADS) void k_peak_search(const double *__rest
           for (int t = peak_ind - ds; t <= peak_ind + ds; ++t) {
             const int tw = t % LCS_N_IDX;
             const int cc = fi * 3 + peak_n_id_2;
-            const float v = sg[((size_t)(cc / LCS_TG) * LCS_N_IDX + tw) * LCS_TG + (cc % LCS_TG)];
+            const float v = sg[((size_t)(cc / geo.cpg) * LCS_N_IDX + tw) * LCS_TG + (cc % geo.cpg)];
             if ((double)v > best_pow) { best_pow = v; best_ind = tw; }
           }
         }
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(PSR_THREADS) __attribute__((amdgpu_waves_per_eu(3, 
           for (int t = peak_ind - ds; t <= peak_ind + ds; ++t) {
             const int tw = t % LCS_N_IDX;
             const int cc = fi * 3 + peak_n_id_2;
-            const float sv = sg[((size_t)(cc / LCS_TG) * LCS_N_IDX + tw) * LCS_TG + (cc % LCS_TG)];
+            const float sv = sg[((size_t)(cc / geo.cpg) * LCS_N_IDX + tw) * LCS_TG + (cc % geo.cpg)];
             if ((double)sv > best_pow) { best_pow = sv; best_ind = tw; }
           }
         }

@@ -127,8 +127,8 @@ __global__ __launch_bounds__(256) void k_prep_tables(const SlotParams *__restric
   __syncthreads();
   for (int i = threadIdx.x; i < geo.n_comb * geo.G; i += blockDim.x) {
     const int w = i / geo.G, g = i % geo.G;
-    const int c_hi = min(g * LCS_TG + LCS_TG - 1, geo.n_tmpl - 1);
-    const int f_lo = (g * LCS_TG) / 3, f_hi = c_hi / 3;
+    const int c_hi = min(g * geo.cpg + geo.cpg - 1, geo.n_tmpl - 1);
+    const int f_lo = (g * geo.cpg) / 3, f_hi = c_hi / 3;
     int mn = s_start[w][f_lo], mx = mn;
     for (int f = f_lo + 1; f <= f_hi; ++f) { mn = min(mn, s_start[w][f]); mx = max(mx, s_start[w][f]); }
     int k2 = (137 + (mx - mn) + 1) / 2;
@@ -166,9 +166,9 @@ __global__ __launch_bounds__(256) void k_fill_btab(const float2 *__restrict__ tm
   float *out = btab + (((size_t)slot * geo.n_comb + w) * geo.G + g) * (size_t)(LCS_KP2_MAX * 64);
   for (int e = threadIdx.x; e < k2 * 64; e += blockDim.x) {
     const int kk = e >> 6, l = e & 63;
-    const int c = g * LCS_TG + (l & 15);
+    const int c = lcs_col_tmpl(geo, g, l & 15);
     float v = 0.f;
-    if (c < geo.n_tmpl) {
+    if (c >= 0) {
       const int foi = c / 3, t = c % 3;
       const int delta = start[((size_t)slot * NW + w) * NFM + foi] - s0;
       const int tap = 2 * kk + (l >> 5) - delta;
@@ -453,8 +453,8 @@ __global__ __launch_bounds__(128) void k_collapse(const float *__restrict__ sg, 
       }
 #pragma unroll
       for (int j = 0; j < LCS_TG; ++j) {
-        const int c = g * LCS_TG + j;
-        if (c < geo.n_tmpl) {
+        const int c = lcs_col_tmpl(geo, g, j);
+        if (c >= 0) {
           const int foi = c / 3, t = c % 3;
           const float x = __fdiv_rn(v[j], dsn);
           if (incoh) incoh[((((size_t)slot * 3 + t) * LCS_N_IDX) + idx) * geo.n_f + foi] = x;
@@ -484,8 +484,8 @@ __global__ __launch_bounds__(256) void k_single_to_ref(const float *__restrict__
     const int j = (int)(e % LCS_TG);
     const int idx = (int)((e / LCS_TG) % LCS_N_IDX);
     const int g = (int)(e / ((size_t)LCS_TG * LCS_N_IDX));
-    const int c = g * LCS_TG + j;
-    if (c >= geo.n_tmpl) { if (!to_ref) ((float *)sg)[(size_t)slot * n + e] = 0.f; continue; }
+    const int c = lcs_col_tmpl(geo, g, j);
+    if (c < 0) { if (!to_ref) ((float *)sg)[(size_t)slot * n + e] = 0.f; continue; }
     const int foi = c / 3, t = c % 3;
     const size_t r = ((((size_t)slot * 3 + t) * LCS_N_IDX) + idx) * geo.n_f + foi;
     if (to_ref) ref[r] = sg[(size_t)slot * n + e]; else ((float *)sg)[(size_t)slot * n + e] = ref[r];

@@ -58,14 +58,15 @@ __global__ __launch_bounds__(256) void k_i8_scales(const float2 *__restrict__ tm
   const int slot = blockIdx.x;
   __shared__ float part[LCS_G_MAX * LCS_TG][4];
   for (int e = threadIdx.x; e < geo.G * LCS_TG * 4; e += 256) {      // 4 threads per template, 35 taps each
-    const int c = e >> 2, qd = e & 3;
+    const int col = e >> 2, qd = e & 3;            // column index: group col / 16, column col % 16
+    const int c = lcs_col_tmpl(geo, col >> 4, col & 15);
     float mx = 0.f;
-    if (c < geo.n_tmpl) {
+    if (c >= 0) {
       const int foi = c / 3, t = c % 3;
       const float2 *T = tmpl + (((size_t)slot * NFM + foi) * 3 + t) * 137;
       for (int m = qd * 35; m < min(137, qd * 35 + 35); ++m) mx = fmaxf(mx, fmaxf(fabsf(T[m].x), fabsf(T[m].y)));
     }
-    part[c][qd] = mx;
+    part[col][qd] = mx;
   }
   __syncthreads();
   for (int c = threadIdx.x; c < geo.G * LCS_TG; c += 256) {
@@ -97,14 +98,14 @@ __global__ __launch_bounds__(256) void k_fill_btab_i8(const float2 *__restrict__
   uint4 *out = bt8 + (((size_t)slot * geo.n_comb + w) * geo.G + g) * (size_t)(3 * I8_NKB * 2 * 64);
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < I8_NKB * 64; e += gridDim.x * blockDim.x) {
     const int kb = e >> 6, lane = e & 63;
-    const int c = g * LCS_TG + (lane & 15), kg = lane >> 4;
+    const int c = lcs_col_tmpl(geo, g, lane & 15), kg = lane >> 4;
     int vre[16], vim[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) { vre[j] = 0; vim[j] = 0; }
-    if (c < geo.n_tmpl) {
+    if (c >= 0) {
       const int foi = c / 3, t = c % 3;
       const int delta = start[((size_t)slot * NW + w) * NFM + foi] - s0;
-      const double q = tq[(size_t)slot * GM * LCS_TG + c];
+      const double q = tq[(size_t)slot * GM * LCS_TG + g * LCS_TG + (lane & 15)];      // scales are stored per column
 #pragma unroll
       for (int m = 0; m < 8; ++m) {
         const int tap = 32 * kb + 8 * kg + m - delta;

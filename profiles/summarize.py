@@ -10,12 +10,12 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(root, "gpurun_out", tag), os.path.join(root, "profiles", tag)
 os.makedirs(dst, exist_ok=True)
 
-for name in ("bench_full_n1.json", "bench_pss_n1.json"):
+for name in ("bench_full_n1.json", "bench_pss_n1.json", "bench_stream_n1.json", "bench_track_n1.json", "bench_full_n1_c64_fp32_kernel.json", "pytest_gpu.log"):
     p = os.path.join(src, name)
     if os.path.exists(p):
-        lines = [l for l in open(p).read().splitlines() if l.startswith("{")]
+        lines = [l for l in open(p).read().splitlines() if l.startswith("{")] if name.endswith(".json") else open(p).read().splitlines()[-6:]
         if lines:
-            open(os.path.join(dst, name), "w").write(lines[-1] + "\n")
+            open(os.path.join(dst, name), "w").write((lines[-1] if name.endswith(".json") else "\n".join(lines)) + "\n")
 
 for d, out in (("stats_full_p1", "kernel_stats_full_chain_b64_nf31_pipeline1.csv"),
                ("stats_full_default", "kernel_stats_full_chain_b64_nf31_default.csv")):
@@ -39,14 +39,22 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
             acc[(k, r["Counter_Name"])][r["Dispatch_Id"]] += float(r["Counter_Value"])
         for (k, c), per in acc.items():
             kern.setdefault(k, {})[c] = sum(per.values()) / len(per)
-dom = next((k for k in kern if k.startswith("k_xcorr_i8x3")), None) or next((k for k in kern if k.startswith("k_xcorr_bf16x3")), None) or next((k for k in kern if k.startswith("k_xcorr_mfma_blk")), None)
+dom = next((k for k in kern if k.startswith("k_xcorr_i8x3")), None) or next((k for k in kern if k.startswith("k_xcorr_mfma_blk")), None)
+sys.path.insert(0, root)
+import hashlib
+def kernel_source_sha():          # the same digest bench.py computes: traffic is only reported for exactly these sources
+    h = hashlib.sha256()
+    for name in ("pss_xcorr_i8.hip", "pss_xcorr.hip", "lcs_internal.h"):
+        h.update(open(os.path.join(root, "lte-cell-scanner_amd", "csrc", name), "rb").read())
+    return h.hexdigest()[:16]
 summary = {
-    "source": "profiles/collect.sh: rocprofv3 --pmc <group> --kernel-trace --output-format csv -- python bench.py --steps 3 "
-              "--warmup 1 --pipeline 1 --no-cpu-baseline, one pass per counter group; values are per-launch averages "
-              "(64 buffers per launch, n_f = 31)",
+    "source": "profiles/collect.sh: rocprofv3 --pmc <group> --kernel-trace --output-format csv -- python bench.py --steps 1 "
+              "--warmup 0 --batches-per-step 4 --pipeline 1 --no-cpu-baseline, one pass per counter group; values are per-launch averages "
+              "(64 buffers per launch, n_f = 31); kernel_source_sha = sha256 of the correlation kernel sources the counters were taken from",
     "corrections": "FETCH_SIZE is reported in KiB and, on gfx950, as half of the bytes fetched; WRITE_SIZE in KiB is exact "
                    "(MI355X_MICROARCH.md, HBM / rocprofv3 section).  hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024",
     "kernels": kern,
+    "kernel_source_sha": kernel_source_sha(),
 }
 if dom:
     k = kern[dom]

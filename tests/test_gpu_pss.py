@@ -125,7 +125,7 @@ def test_batched_kernels_full_arrays_vs_oracle_short_buffer_and_odd_grids(S, pkg
     """The 135360-sample Matlab/test_xcorr_pss.mat buffer (14 combining windows) on its own 3-entry grid, on a
     single hypothesis (one template group with 3 of 16 columns in use) and on a 10 kHz grid whose window starts
     spread over many samples inside a group (int8 kernel with 5 full tap blocks), plus a 40 kHz grid that is too
-    sparse for the int8 kernel (the u8 source then takes the fp32 kernel)."""
+    sparse for 16 templates per group (the groups are then packed with fewer hypotheses each)."""
     g = golden("test_xcorr_pss")
     fc = float(g["fc"][0])
     n = g["iq_u8"].size // 2
@@ -256,5 +256,16 @@ def test_bad_arguments_fail_loudly(S, pkg, capbuf_0000):
         S.xcorr_pss(cap, np.array([]), 2, fc, fc, FS)
     with pytest.raises(pkg.SearcherError):
         S.xcorr_pss(cap[:5000], np.array([0.0]), 2, fc, fc, FS)
-    with pytest.raises(pkg.SearcherError):          # 6 adjacent hypotheses spanning 30 MHz: too sparse to fuse
-        S.xcorr_pss(cap, np.arange(6) * 6e6, 2, fc, fc, FS)
+
+
+def test_sparse_frequency_grids_are_repacked(S, pkg, capbuf_0000):
+    """Grids whose hypotheses drift apart by more samples than a tap block holds -- 40 kHz, 1 MHz and 6 MHz steps: window
+    starts up to 1100 samples apart -- are packed with fewer hypotheses per template group (down to one) instead of being
+    rejected; host entry point (fp32 kernel) and u8 batch (int8 kernel), full arrays against the oracle."""
+    cap, fc = capbuf_0000
+    g = golden("capbuf_0000")
+    for f in (np.arange(-4, 5) * 40e3, np.array([-2e6, -1e6, 0.0, 35e3, 1e6]), np.arange(6) * 6e6):
+        ro = O.xcorr_pss(cap, f, 2, fc, fc, FS)
+        r = S.xcorr_pss(cap, f, 2, fc, fc, FS)
+        _check_xcorr(r, ro, f"sparse grid step {f[1] - f[0]}")
+        _batch_arrays_vs_oracle(S, pkg, [g["iq_u8"]], f, np.array([fc]), 153600, f"sparse grid step {f[1] - f[0]}")
