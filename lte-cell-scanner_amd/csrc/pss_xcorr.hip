@@ -114,6 +114,21 @@ __global__ __launch_bounds__(256) void k_prep_tables(const SlotParams *__restric
   const int slot = blockIdx.x;
   const SlotParams p = params[slot];
   __shared__ int s_start[NW][NFM];
+  // the templates (3 x 137 sincos per hypothesis, the long part) are spread over gridDim.y workgroups; the window
+  // starts and per-group offsets are few: workgroup y = 0 does them
+  for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < geo.n_f * 3 * 137; i += gridDim.y * blockDim.x) {
+    const int m = i % 137, t = (i / 137) % 3, foi = i / (137 * 3);
+    const double f_off = fset[foi];
+    const double kf = (p.fc_req - f_off) / p.fc_prog;
+    const double fs = p.fs_prog * kf;
+    const double k = M_PI * f_off / (fs / 2);
+    const double ang = k * (double)m;
+    const double cs = cos(ang), sn = sin(ang);
+    const double2 s = pss_td[t * 137 + m];
+    const double rr = s.x * cs - s.y * sn, ri = s.x * sn + s.y * cs;   // seq*coeff
+    tmpl[(((size_t)slot * NFM + foi) * 3 + t) * 137 + m] = make_float2((float)(rr / 137), (float)(-ri / 137));
+  }
+  if (blockIdx.y != 0) return;
   for (int foi = threadIdx.x; foi < geo.n_f; foi += blockDim.x) {
     const double kf = (p.fc_req - fset[foi]) / p.fc_prog;
     for (int w = 0; w < geo.n_comb; ++w) {
@@ -135,18 +150,6 @@ __global__ __launch_bounds__(256) void k_prep_tables(const SlotParams *__restric
     if (k2 > LCS_KP2_MAX - LCS_KP2_UNROLL) k2 = LCS_KP2_MAX - LCS_KP2_UNROLL;   // rejected on the host before launch (lcs_api.hip)
     smin[((size_t)slot * NW + w) * GM + g] = mn;
     kp2[((size_t)slot * NW + w) * GM + g] = k2;
-  }
-  for (int i = threadIdx.x; i < geo.n_f * 3 * 137; i += blockDim.x) {
-    const int m = i % 137, t = (i / 137) % 3, foi = i / (137 * 3);
-    const double f_off = fset[foi];
-    const double kf = (p.fc_req - f_off) / p.fc_prog;
-    const double fs = p.fs_prog * kf;
-    const double k = M_PI * f_off / (fs / 2);
-    const double ang = k * (double)m;
-    const double cs = cos(ang), sn = sin(ang);
-    const double2 s = pss_td[t * 137 + m];
-    const double rr = s.x * cs - s.y * sn, ri = s.x * sn + s.y * cs;   // seq*coeff
-    tmpl[(((size_t)slot * NFM + foi) * 3 + t) * 137 + m] = make_float2((float)(rr / 137), (float)(-ri / 137));
   }
 }
 
@@ -408,6 +411,68 @@ __global__ __launch_bounds__(256) void k_sp_fold(const double *__restrict__ sp_a
   }
 }
 
+// The same for RTL-SDR sources, in integers.  A sample is (127 - u8) / -128, so 16384 |x|^2 is an integer <= 32768 and
+// every 274-sample window sum an exact int32: one workgroup owns SPI_TILE positions of one buffer, walks the windows m =
+// 0 .. n_comb_sp - 1, forms the prefix sums of the 16384 |x|^2 of SPI_TILE + 274 samples with a block scan and takes
+// sp[m][i] = (C[i + 274] - C[i]) / 16384 / 274 -- the same doubles k_sp_sums produces (its fp64 sums of these values
+// are exact too) -- accumulated in window order and folded like k_sp_fold.  No per-window array ever reaches HBM.
+#define SPI_TILE 960
+#define SPI_N (SPI_TILE + 274)
+#define SPI_PER ((SPI_N + 255) / 256)
+__global__ __launch_bounds__(256) void k_sp_i8(const uint16_t *__restrict__ cap8, uint32_t n_cap, double *__restrict__ spinc,
+                                               double *__restrict__ zth, SpArgs a) {
+  LCS_TAIL_PRIO();
+  __shared__ int C[SPI_N + 1];           // C[k] = sum of the first k powers of the window
+  __shared__ int wsum[4];
+  const int slot = blockIdx.y, i0 = blockIdx.x * SPI_TILE, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const uint16_t *cap = cap8 + (size_t)slot * lcs_cap8_stride(n_cap);
+  double acc[4] = {0, 0, 0, 0};
+  for (int m = 0; m < a.n_comb_sp; ++m) {
+    const uint32_t base = (uint32_t)m * 9600u + i0;
+    // thread t owns elements t * SPI_PER .. + SPI_PER - 1 (consecutive: a serial prefix, then a scan over the threads)
+    int v[SPI_PER], run = 0;
+#pragma unroll
+    for (int j = 0; j < SPI_PER; ++j) {
+      const int k = tid * SPI_PER + j;
+      int pw = 0;
+      if (k < SPI_N && base + k < n_cap) {
+        const uint32_t s = cap[base + k];
+        const int re = (int)(int8_t)(s & 255u), im = (int)(int8_t)(s >> 8);
+        pw = re * re + im * im;
+      }
+      run += pw;
+      v[j] = run;
+    }
+    int incl = run;                          // inclusive scan of the per-thread totals: wave, then the 4 waves
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int up = __shfl_up(incl, off); if (lane >= off) incl += up; }
+    __syncthreads();                         // previous window's readers of C / wsum are done
+    if (lane == 63) wsum[wv] = incl;
+    __syncthreads();
+    int before = incl - run;
+    for (int q = 0; q < wv; ++q) before += wsum[q];
+    if (tid == 0) C[0] = 0;
+#pragma unroll
+    for (int j = 0; j < SPI_PER; ++j) { const int k = tid * SPI_PER + j; if (k < SPI_N) C[k + 1] = before + v[j]; }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = tid + 256 * r;
+      if (i < SPI_TILE) acc[r] += ((double)(C[i + 274] - C[i]) / 16384.0) / 274;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = i0 + tid + 256 * r;
+    if (tid + 256 * r < SPI_TILE && i < 9600) {
+      const double vv = acc[r] / a.n_comb_sp;
+      const int o = (i + 137) % 9600;
+      spinc[(size_t)slot * 9600 + o] = vv;
+      zth[(size_t)slot * 9600 + o] = a.R_th1 * vv / a.rx_cutoff / 137 / 2 / a.n_comb_xc / (2 * a.ds + 1);
+    }
+  }
+}
+
 // ------------------------------------------------- K3: delay spread + max over frequency
 // ref :312-347 (float adds in the reference's order, circular in idx) and :353-383 (first max).
 // One thread per output position: it reads the 2*ds+1 neighbouring 64-byte rows of every group
@@ -557,7 +622,7 @@ static std::mutex g_xc_mutex;
 static hipEvent_t g_xc_done[64] = {};
 
 int lcs_launch_xcorr(lcs_ctx *c, int n_buf, const XcGeom &geo, bool want_incoh, bool time_it) {
-  hipLaunchKernelGGL(k_prep_tables, dim3(n_buf), dim3(256), 0, c->stream, c->params, c->fset, c->d_pss_td, c->tmpl,
+  hipLaunchKernelGGL(k_prep_tables, dim3(n_buf, 4), dim3(256), 0, c->stream, c->params, c->fset, c->d_pss_td, c->tmpl,
                      c->start, c->smin, c->kp2, geo);
   if (c->use_i8) {
     int rc_ = lcs_launch_fill_btab_i8(c, n_buf, geo);
@@ -572,10 +637,14 @@ int lcs_launch_xcorr(lcs_ctx *c, int n_buf, const XcGeom &geo, bool want_incoh, 
   a.ds = geo.ds;
   a.R_th1 = lcs_tables::chi2cdf_inv(1 - pow(10.0, -12), 2.0 * geo.n_comb * (2 * geo.ds + 1));
   a.rx_cutoff = (6 * 12 * 15e3 / 2 + 4 * 15e3) / (30720000.0 / 16 / 2);
+  if (c->src_u8 && !c->cap64_valid)
+    hipLaunchKernelGGL(k_sp_i8, dim3(LCS_N_IDX / SPI_TILE, n_buf), dim3(256), 0, c->stream, c->cap8, geo.n_cap, c->spinc, c->zth, a);
+  else {
   hipLaunchKernelGGL(k_sp_sums, dim3(std::min(((LCS_N_IDX + SP_TILE - 1) / SP_TILE) * a.n_comb_sp * n_buf, 4 * LCS_GRID_CAP)), dim3(64), 0,
                      c->stream, lcs_cap_src(c, geo.n_cap), c->sp, geo.n_cap, a.n_comb_sp, n_buf);       // one-wave workgroups
   hipLaunchKernelGGL(k_sp_fold, dim3(std::min((n_buf * LCS_N_IDX + 255) / 256, LCS_GRID_CAP)), dim3(256), 0, c->stream, c->sp, c->spinc,
                      c->zth, a, n_buf);
+  }
 
   // slots [0, n8) with the XCD-aware mapping, the remainder with the plain one
   const int n8 = (n_buf >= 8) ? (n_buf & ~7) : 0;
