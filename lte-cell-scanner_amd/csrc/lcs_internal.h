@@ -26,15 +26,6 @@
 // shares CUs with the next batch's correlation waves.  Raising the wave priority lets the SIMD
 // arbiter issue these few waves ahead of the MFMA stream instead of round-robin behind 4-5 of them.
 #define LCS_TAIL_PRIO() __builtin_amdgcn_s_setprio(3)
-// The wide, memory-bound kernels of the chain loop over their jobs with at most LCS_GRID_CAP workgroups per launch.
-// A correlation grid keeps two workgroups resident on every CU; a small kernel's workgroup can only start where one
-// of them retires, and the high-priority queue wins every freed slot: a kernel with thousands of short workgroups
-// takes the chip over for its duration.  Measured (tools/microbench notes in DESIGN.md): capping the grids lowers the
-// correlation's slowdown under load but stretches the chain more than it gains (caps of 64/128/256 workgroups:
-// 28.3 k / 37.0 k / 39.9 k buffers/s against 40.6 k uncapped), so the cap is set where it never binds.
-#ifndef LCS_GRID_CAP
-#define LCS_GRID_CAP (1 << 20)
-#endif
 #define LCS_TG 16            // templates per MFMA column group
 #define LCS_G_MAX LCS_NF_MAX   // template groups per buffer: ceil(3 n_f / 16) when packed densely, up to n_f when one hypothesis takes a group
 #define LCS_KP2_MAX 128      // tap pairs per (window, group): 137 taps + up to 119 samples of spread

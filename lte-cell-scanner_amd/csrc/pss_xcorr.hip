@@ -56,10 +56,9 @@ __global__ void k_ingest(const void *__restrict__ src, int fmt, uint32_t n_cap, 
 // every sample, cap8s the same sequence shifted down by one sample (the correlation kernel's LDS-DMA copies dwords,
 // i.e. sample PAIRS: with both phases in memory every window start is dword aligned), both zero-padded behind
 // n_cap up to the slot stride.  Nothing wider is stored: the int8 kernel multiplies these bytes, the fp64 stages
-// widen them on the fly (cap_at()), and when the frequency grid is too sparse for the int8 kernel the fp32 copy
-// cap32 is written as well.  One thread = 8 samples = one 16-byte load and two 16-byte stores.
+// widen them on the fly (cap_at()).  One thread = 8 samples = one 16-byte load and two 16-byte stores.
 __global__ __launch_bounds__(256) void k_ingest_u8(const uint8_t *__restrict__ src, uint32_t n_cap, uint16_t *__restrict__ cap8,
-                                                   uint16_t *__restrict__ cap8s, float2 *__restrict__ cap32) {
+                                                   uint16_t *__restrict__ cap8s) {
   LCS_TAIL_PRIO();
   const int slot = blockIdx.y;
   const size_t stride = lcs_cap8_stride(n_cap);
@@ -93,12 +92,6 @@ __global__ __launch_bounds__(256) void k_ingest_u8(const uint8_t *__restrict__ s
     b.x = v[1] | (v[2] << 16); b.y = v[3] | (v[4] << 16); b.z = v[5] | (v[6] << 16); b.w = v[7] | (v[8] << 16);
     *reinterpret_cast<uint4 *>(cap8 + (size_t)slot * stride + i0) = a;
     *reinterpret_cast<uint4 *>(cap8s + (size_t)slot * stride + i0) = b;
-    if (cap32) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j)
-        if (i0 + j < n_cap)
-          cap32[(size_t)slot * n_cap + i0 + j] = make_float2(-(float)(int)(int8_t)(v[j] & 255u) / 128.f, -(float)(int)(int8_t)(v[j] >> 8) / 128.f);
-    }
   }
 }
 
@@ -601,12 +594,10 @@ CapSrc lcs_cap_src(const lcs_ctx *c, uint32_t n_cap) {
 int lcs_launch_ingest(lcs_ctx *c, const void *d_src, int fmt, int n_buf, uint32_t n_cap) {
   c->src_u8 = fmt == LCS_FMT_IQ_U8;
   if (fmt == LCS_FMT_IQ_U8) {
-    const unsigned nb = std::max(1u, std::min((unsigned)((lcs_cap8_stride(n_cap) / 8 + 255) / 256), (unsigned)(LCS_GRID_CAP / n_buf)));
-    hipLaunchKernelGGL(k_ingest_u8, dim3(nb, n_buf), dim3(256), 0, c->stream, (const uint8_t *)d_src, n_cap, c->cap8, c->cap8s,
-                       c->use_i8 ? nullptr : c->cap32);
+    const unsigned nb = (unsigned)((lcs_cap8_stride(n_cap) / 8 + 255) / 256);
+    hipLaunchKernelGGL(k_ingest_u8, dim3(nb, n_buf), dim3(256), 0, c->stream, (const uint8_t *)d_src, n_cap, c->cap8, c->cap8s);
   } else {
-    hipLaunchKernelGGL(k_ingest, dim3(std::max(1, std::min(128, LCS_GRID_CAP / n_buf)), n_buf), dim3(256), 0, c->stream, d_src, fmt,
-                       n_cap, c->cap32, c->cap64);
+    hipLaunchKernelGGL(k_ingest, dim3(128, n_buf), dim3(256), 0, c->stream, d_src, fmt, n_cap, c->cap32, c->cap64);
   }
   HIPCHK(c, hipGetLastError());
   return LCS_OK;
@@ -628,7 +619,7 @@ int lcs_launch_xcorr(lcs_ctx *c, int n_buf, const XcGeom &geo, bool want_incoh, 
     int rc_ = lcs_launch_fill_btab_i8(c, n_buf, geo);
     if (rc_) return rc_;
   } else
-    hipLaunchKernelGGL(k_fill_btab, dim3(std::min(geo.n_comb * geo.G * n_buf, LCS_GRID_CAP)), dim3(256), 0, c->stream, c->tmpl,
+    hipLaunchKernelGGL(k_fill_btab, dim3(geo.n_comb * geo.G * n_buf), dim3(256), 0, c->stream, c->tmpl,
                        c->start, c->smin, c->kp2, c->btab, geo, n_buf);
   // signal-power estimate and threshold do not depend on the correlation: enqueue them first
   SpArgs a;
@@ -640,9 +631,9 @@ int lcs_launch_xcorr(lcs_ctx *c, int n_buf, const XcGeom &geo, bool want_incoh, 
   if (c->src_u8 && !c->cap64_valid)
     hipLaunchKernelGGL(k_sp_i8, dim3(LCS_N_IDX / SPI_TILE, n_buf), dim3(256), 0, c->stream, c->cap8, geo.n_cap, c->spinc, c->zth, a);
   else {
-  hipLaunchKernelGGL(k_sp_sums, dim3(std::min(((LCS_N_IDX + SP_TILE - 1) / SP_TILE) * a.n_comb_sp * n_buf, 4 * LCS_GRID_CAP)), dim3(64), 0,
+  hipLaunchKernelGGL(k_sp_sums, dim3(((LCS_N_IDX + SP_TILE - 1) / SP_TILE) * a.n_comb_sp * n_buf), dim3(64), 0,
                      c->stream, lcs_cap_src(c, geo.n_cap), c->sp, geo.n_cap, a.n_comb_sp, n_buf);       // one-wave workgroups
-  hipLaunchKernelGGL(k_sp_fold, dim3(std::min((n_buf * LCS_N_IDX + 255) / 256, LCS_GRID_CAP)), dim3(256), 0, c->stream, c->sp, c->spinc,
+  hipLaunchKernelGGL(k_sp_fold, dim3((n_buf * LCS_N_IDX + 255) / 256), dim3(256), 0, c->stream, c->sp, c->spinc,
                      c->zth, a, n_buf);
   }
 
@@ -686,7 +677,7 @@ int lcs_launch_xcorr(lcs_ctx *c, int n_buf, const XcGeom &geo, bool want_incoh, 
     HIPCHK(c, hipEventRecord(c->ev_post, sxc));
     HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_post, 0));
   }
-  hipLaunchKernelGGL(k_collapse, dim3(std::min(((LCS_N_IDX + 127) / 128) * n_buf, 2 * LCS_GRID_CAP)), dim3(128), 0, c->stream, c->single,
+  hipLaunchKernelGGL(k_collapse, dim3(((LCS_N_IDX + 127) / 128) * n_buf), dim3(128), 0, c->stream, c->single,
                      want_incoh ? c->incoh : nullptr, c->pow_, reinterpret_cast<float *>(c->work), c->frq, geo, n_buf);
   HIPCHK(c, hipGetLastError());
   return LCS_OK;

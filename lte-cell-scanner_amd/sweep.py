@@ -103,6 +103,9 @@ def run_sweep(search_fn: Callable, get_capbufs: Callable[[np.ndarray], object], 
             r, c = res
             rec[a:a + len(idx)] = r[:, :MAXC]
             cnt[a:a + len(idx)] = np.minimum(c, MAXC)
+            if np.any(np.asarray(c) > MAXC):
+                import warnings
+                warnings.warn(f"run_sweep: a carrier reported more than {MAXC} cells; the list was truncated", RuntimeWarning)
         else:
             for j, cells in enumerate(res):
                 cnt[a + j] = min(len(cells), MAXC)

@@ -19,19 +19,19 @@ for name in ("bench_full_n1.json", "bench_pss_n1.json", "bench_stream_n1.json", 
 
 for d, out in (("stats_full_p1", "kernel_stats_full_chain_b64_nf31_pipeline1.csv"),
                ("stats_full_default", "kernel_stats_full_chain_b64_nf31_default.csv")):
-    f = glob.glob(os.path.join(src, d, "*", "*_kernel_stats.csv"))
+    f = sorted(glob.glob(os.path.join(src, d, "*", "*_kernel_stats.csv")), key=os.path.getmtime)     # newest collection wins
     if f:
-        shutil.copy(f[0], os.path.join(dst, out))
-f = glob.glob(os.path.join(src, "stats_full_p1", "*", "*_agent_info.csv"))
+        shutil.copy(f[-1], os.path.join(dst, out))
+f = sorted(glob.glob(os.path.join(src, "stats_full_p1", "*", "*_agent_info.csv")), key=os.path.getmtime)
 if f:
-    shutil.copy(f[0], os.path.join(dst, "agent_info.csv"))
+    shutil.copy(f[-1], os.path.join(dst, "agent_info.csv"))
 
 # PMC: average every counter per kernel over its dispatches
 kern = {}
 for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
     if not os.path.isdir(d):
         continue
-    for f in glob.glob(os.path.join(d, "*", "*_counter_collection.csv")):
+    for f in sorted(glob.glob(os.path.join(d, "*", "*_counter_collection.csv")), key=os.path.getmtime)[-1:]:
         acc = {}
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"].split("(")[0].replace("void ", "")
