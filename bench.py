@@ -292,6 +292,9 @@ def main():
                     help="contexts (streams + workspaces) used round-robin: the latency-bound per-cell "
                          "stages of batch i overlap the PSS correlation of batch i+1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-xc-timing", action="store_true", help="developer A/B runs with builds that record no kernel events")
+    ap.add_argument("--synth-cache", default=None, help="developer A/B runs: directory caching the synthetic host batch between runs")
+    ap.add_argument("--lib", default=None, help="developer A/B runs: load this build of liblcs_amd.so instead of the in-tree one")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (testing the multi-rank path on one GPU)")
     ap.add_argument("--share-gpu0", action="store_true", help="testing only: every rank uses GPU 0")
     args = ap.parse_args()
@@ -299,6 +302,8 @@ def main():
     import torch
     import __graft_entry__ as ge
     pkg = ge.load_package()
+    if args.lib:
+        pkg.capi.LIB_PATH = args.lib if os.path.isabs(args.lib) or os.path.exists(args.lib) else os.path.join(ROOT, args.lib)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -330,7 +335,14 @@ def main():
     fmt = pkg.FMT_IQ_U8 if args.input == "u8" else pkg.FMT_C64
     # rank r searches carriers FC + 100 kHz * (r*B + b): the sweep's carrier axis is the shard axis
     fcs = FC + 100e3 * (np.arange(B) + rank * B)
-    host = synth_batch(pkg, B, 1234 + rank, fcs)
+    cache = os.path.join(args.synth_cache, f"batch_{B}_{1234 + rank}.npy") if args.synth_cache else None
+    if cache and os.path.exists(cache):
+        host = np.load(cache)
+    else:
+        host = synth_batch(pkg, B, 1234 + rank, fcs)
+        if cache:
+            os.makedirs(args.synth_cache, exist_ok=True)
+            np.save(cache, host)
     base = torch.from_numpy(host).to(dev)
     # D distinct resident batches: the synthetic base batch and copies rotated in time by whole samples on the device
     # (cells move, frame timing changes, every correlation value changes).  Inputs are in HBM before timing starts.
@@ -398,7 +410,7 @@ def main():
             if j >= 0:
                 last = collect(j)
                 recs.append(last)
-                if xc_ms is not None:
+                if xc_ms is not None and not args.no_xc_timing:
                     xc_ms.append(ctxs[j % depth].last_xcorr_ms()[0])
                 if (j + 1) % K == 0:
                     if world > 1 and gather:
@@ -447,7 +459,7 @@ def main():
     for d in range(D):
         ctxs[0].batch_enqueue(d_caps[d].data_ptr(), fmt, B, N_CAP, f, fcs, fcs, FS, stage_mask)
         rec, cnt = ctxs[0].batch_collect_raw(B, MAXC)
-        iso_ms.append(ctxs[0].last_xcorr_ms()[0])       # the dominant kernel alone on the GPU (nothing overlaps it here)
+        iso_ms.append(float('nan') if args.no_xc_timing else ctxs[0].last_xcorr_ms()[0])       # the dominant kernel alone on the GPU (nothing overlaps it here)
         n_cells_per_batch.append(int(cnt.sum()))
         seq_ok = seq_ok and (seen.get(d) == digest(rec, cnt))
         if d == 0:
@@ -465,7 +477,7 @@ def main():
         # 15 x 9600 lags xc_combine reads.
         flops_per_buf = 8.0 * 137 * 3 * (N_CAP - 136) * n_f
         flops_consumed = 8.0 * 137 * 3 * 9600 * 15 * n_f
-        k_ms = float(np.mean(xc_ms))
+        k_ms = float(np.mean(xc_ms)) if xc_ms else float('nan')
         k_iso = float(np.mean(iso_ms))
         i8 = kname.startswith("k_xcorr_i8")
         peak = PEAK_I8_TOPS if i8 else PEAK_FP32_TFLOPS

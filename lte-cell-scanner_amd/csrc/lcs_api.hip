@@ -369,6 +369,15 @@ int lcs_peak_search(lcs_ctx *c, const double *pow_, const int32_t *frq, const do
 }
 
 // ------------------------------------------------------------------- batched chain
+static int percell_round(lcs_ctx *c, int n_buf, uint32_t n_cap, int r) {
+  int rc;
+  if ((rc = lcs_launch_gather_work(c, n_buf, r * c->max_work))) return rc;
+  if ((rc = lcs_launch_tfg(c, n_cap, true))) return rc;
+  if ((rc = lcs_launch_tfoec(c, 0))) return rc;
+  if ((rc = lcs_launch_mib(c, 0))) return rc;
+  return lcs_launch_scatter_back(c);
+}
+
 int lcs_batch_enqueue(lcs_ctx *c, const void *d_capbufs, int fmt, int n_buf, uint32_t n_cap, const double *f_search_set,
                       uint16_t n_f, const double *fc_requested, const double *fc_programmed, double fs_programmed,
                       int stage_mask) {
@@ -399,17 +408,14 @@ int lcs_batch_enqueue(lcs_ctx *c, const void *d_capbufs, int fmt, int n_buf, uin
   if (stage_mask & 2) {
     if ((rc = ensure_percell(c))) return rc;
     if ((rc = lcs_launch_sss_foe(c, n_buf, n_cap, 3.0 /* THRESH2_N_SIGMA, ref src/CellSearch.cpp:528 */, nullptr))) return rc;
-    // The per-cell stages hold LCS_MAX_WORK cells at a time; rounds are sized for 8 cells per buffer
-    // on average (lcs_batch_collect reports LCS_ERR_OVERFLOW if a batch had more than that).
+    // The per-cell stages hold max_work cells at a time.  The rounds enqueued here cover one detected cell per
+    // buffer on average (a band scan finds far fewer); lcs_batch_collect launches further rounds if the device-side
+    // count says the batch had more, so no batch overflows and sparse batches pay for no empty rounds.
     c->needed_rows_only = true;
-    const int rounds = (n_buf * 8 + c->max_work - 1) / c->max_work;
-    for (int r = 0; r < rounds; ++r) {
-      if ((rc = lcs_launch_gather_work(c, n_buf, r * c->max_work))) return rc;
-      if ((rc = lcs_launch_tfg(c, n_cap, true))) return rc;
-      if ((rc = lcs_launch_tfoec(c, 0))) return rc;
-      if ((rc = lcs_launch_mib(c, 0))) return rc;
-      if ((rc = lcs_launch_scatter_back(c))) return rc;
-    }
+    c->grid_items = std::min(c->max_work, std::max(64, n_buf / 2));
+    const int rounds = (n_buf + c->max_work - 1) / c->max_work;
+    for (int r = 0; r < rounds; ++r)
+      if ((rc = percell_round(c, n_buf, n_cap, r))) return rc;
     c->last_cell_rounds = rounds;
   }
   c->last_n_buf = n_buf;
@@ -430,7 +436,15 @@ int lcs_batch_collect(lcs_ctx *c, lcs_cell *cells, int max_cells_per_buf, int *n
   if (full) HIPCHK(c, hipMemcpyAsync(work_cnt, c->n_work, sizeof(work_cnt), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   int rc = LCS_OK;
-  if (full && work_cnt[1] > c->last_cell_rounds * c->max_work) rc = LCS_ERR_OVERFLOW;   // cells beyond the rounds were not decoded
+  if (full && work_cnt[1] > c->last_cell_rounds * c->max_work) {
+    // more cells passed SSS than the enqueued rounds decode: run the remaining rounds now (rare: dense batches)
+    const int rounds = (work_cnt[1] + c->max_work - 1) / c->max_work;
+    for (int r = c->last_cell_rounds; r < rounds; ++r)
+      if ((rc = percell_round(c, nb, c->last_geo.n_cap, r))) return rc;
+    c->last_cell_rounds = rounds;
+    HIPCHK(c, hipMemcpyAsync(tmp.data(), c->peaks, sizeof(lcs_cell) * tmp.size(), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
   for (int b = 0; b < nb; ++b) {
     const int np = std::min(cnt[b], (int)LCS_MAXP);
     if (cnt[b] > LCS_MAXP) rc = LCS_ERR_OVERFLOW;

@@ -35,6 +35,18 @@
 #define LCS_MAXP 64          // peaks kept per capture buffer
 #define LCS_I8_KB 5          // 32-tap blocks of the int8 correlation kernel: taps + window-start spread <= 160
 #define LCS_MAX_WORK 512     // cells carried into the TFG/MIB stages per batch
+// grid sizes of the work-list kernels (every one loops over its list, so these only trade latency for workgroups)
+#ifdef LCS_EXP_GRIDCAP     // A/B builds only
+#define LCS_WIN_GRID LCS_EXP_GRIDCAP
+#define LCS_ITEM_GRID LCS_EXP_GRIDCAP
+#define LCS_TFG_GRID LCS_EXP_GRIDCAP
+#define LCS_TFA_GRID LCS_EXP_GRIDCAP
+#else
+#define LCS_WIN_GRID 4096
+#define LCS_ITEM_GRID 1024
+#define LCS_TFG_GRID 4096
+#define LCS_TFA_GRID 2048
+#endif
 #define LCS_TFG_ROWS 854
 #define LCS_CELL_SCRATCH 4608 // doubles of per-cell scratch (RS table, shifts, noise powers, PBCH candidates)
 
@@ -209,7 +221,8 @@ struct lcs_ctx {
   int last_stage_mask = 0;
   bool needed_rows_only = false;     // fused chains: compute only the grid rows later stages read (tfg_mib.hip)
   int max_work = LCS_MAX_WORK;       // cells per per-cell round (lcs_set_max_cells_in_flight)
-  int last_cell_rounds = 0;          // per-cell rounds launched for the last batch (LCS_MAX_WORK cells each)
+  int last_cell_rounds = 0;          // per-cell rounds launched for the last batch (max_work cells each)
+  int grid_items = 64;               // workgroups per work-list axis of the per-cell kernels (they loop over the list)
   XcGeom last_geo{};
   hipEvent_t ev_xc0 = nullptr, ev_xc1 = nullptr;
   int last_xc_launches = 0;

@@ -88,6 +88,82 @@ __device__ __forceinline__ void qpsk_llr(cd2 sym, double np, double &l0, double 
   l1 = trunc_log(metric[0] + metric[2]) - trunc_log(metric[1] + metric[3]);
 }
 
+// ---- tail-biting Viterbi of the PBCH decoder, one trellis per LANE (K = 7, G = (133,171,165)o, 40 steps; ref
+// src/lte_lib.cpp:538-551 -> itpp decode_tailbite: one trellis pass per start state, end state forced equal).
+// Lane ss runs the trellis that starts in state ss and keeps all 64 path metrics in registers, so a step is 32
+// butterflies of plain fp64 adds with no cross-lane traffic (the lane-per-state form moves every metric through
+// ds_bpermute: measured LDS-pipe bound, ~100 us of a whole CU per candidate).  Butterfly j reads old states 2j,
+// 2j+1 and writes new states j, j+32 INTO THE SAME TWO REGISTERS, so after k steps state s lives in slot
+// rotl6(s, k); the slot pattern repeats every 6 steps, which is the unroll depth.  Branch metrics are added one
+// generator at a time in the order of the oracle (m += +-r0; m += +-r1; m += +-r2), ties keep predecessor 2j.
+#define VIT_ROTL6(s, k) ((((s) << (k)) | ((s) >> (6 - (k)))) & 63)
+template <int K>
+__host__ __device__ __forceinline__ void vit_step(double (&pm)[64], double r0, double r1, double r2, unsigned &lo, unsigned &hi) {
+  lo = 0u; hi = 0u;
+#pragma unroll
+  for (int j = 0; j < 32; ++j) {
+    const int p0 = 2 * j, p1 = 2 * j + 1;
+    const int sa = VIT_ROTL6(p0, K), sb = VIT_ROTL6(p1, K);
+    const double o0 = pm[sa], o1 = pm[sb];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {                      // new state j + 32 b <- (input bit b, predecessor p0 / p1)
+      const int g0 = (b << 6) | p0, g1 = (b << 6) | p1;
+      double m0 = o0, m1 = o1;
+      m0 += (__builtin_parity(g0 & 0133) ? r0 : -r0); m0 += (__builtin_parity(g0 & 0171) ? r1 : -r1); m0 += (__builtin_parity(g0 & 0165) ? r2 : -r2);
+      m1 += (__builtin_parity(g1 & 0133) ? r0 : -r0); m1 += (__builtin_parity(g1 & 0171) ? r1 : -r1); m1 += (__builtin_parity(g1 & 0165) ? r2 : -r2);
+      const bool take1 = m1 < m0;                      // ties keep the lower-numbered predecessor
+      pm[b ? sb : sa] = take1 ? m1 : m0;
+      if (b) hi |= take1 ? (1u << j) : 0u; else lo |= take1 ? (1u << j) : 0u;
+    }
+  }
+}
+// all 40 steps of the trellis that starts in state ss; surv[t * stride]: bit n = decision of new state n at step t.
+// Returns the metric of the forced end state ss.
+__host__ __device__ __forceinline__ double vit_trellis(const double *d0, const double *d1, const double *d2, int ss,
+                                                       unsigned long long *surv, int stride) {
+  double pm[64];
+#pragma unroll
+  for (int s = 0; s < 64; ++s) pm[s] = (s == ss) ? 0.0 : INFINITY;
+  unsigned lo, hi;
+#define VIT_S(K, T) do { vit_step<K>(pm, d0[T], d1[T], d2[T], lo, hi); surv[(size_t)(T) * stride] = ((unsigned long long)hi << 32) | lo; } while (0)
+  for (int t6 = 0; t6 < 42; t6 += 6) {
+    VIT_S(0, t6); VIT_S(1, t6 + 1); VIT_S(2, t6 + 2); VIT_S(3, t6 + 3);
+    if (t6 + 4 < 40) { VIT_S(4, t6 + 4); VIT_S(5, t6 + 5); }
+  }
+#undef VIT_S
+  // 40 = 6 * 6 + 4 steps: state s sits in slot rotl6(s, 4)
+  double fin = INFINITY;
+#pragma unroll
+  for (int s = 0; s < 64; ++s) fin = (s == ss) ? pm[VIT_ROTL6(s, 4)] : fin;
+  return fin;
+}
+// decoded bits of the trellis whose survivor words are surv[t * stride] and whose start = end state is ss
+__host__ __device__ __forceinline__ unsigned long long vit_traceback(const unsigned long long *surv, int stride, int ss) {
+  int s = ss;
+  unsigned long long bits = 0ull;                      // bit t = decoded bit c_est(t)
+  for (int t = 39; t >= 0; --t) {
+    bits |= (unsigned long long)((s >> 5) & 1) << t;
+    const int dec = (int)((surv[(size_t)t * stride] >> s) & 1ull);
+    s = ((s << 1) & 63) | dec;
+  }
+  return bits;
+}
+// CRC-16 (x^16+x^12+x^5+1, zero init) of the 24 payload bits against the received 16, with the antenna-port mask
+// (ref src/lte_lib.cpp:637-663, src/searcher.cpp:1628-1636)
+__host__ __device__ __forceinline__ int pbch_crc_ok(unsigned long long bits, int n_ports) {
+  unsigned crc = 0;
+  for (int i = 0; i < 24; ++i) {
+    const unsigned msb = ((crc >> 15) & 1u) ^ (unsigned)((bits >> i) & 1ull);
+    crc = (crc << 1) & 0xffffu;
+    if (msb) crc ^= 0x1021u;
+  }
+  unsigned rx = 0;                                     // received CRC, bit 15 - t = c_est(24 + t)
+  for (int t = 0; t < 16; ++t) rx |= (unsigned)((bits >> (24 + t)) & 1ull) << (15 - t);
+  if (n_ports == 2) crc ^= 0xffffu;
+  else if (n_ports == 4) crc ^= 0x5555u;               // every second bit, t = 1, 3, ... <-> register bits 14, 12, ...
+  return (crc == rx) ? 1 : 0;
+}
+
 // ---- PBCH decode from the descrambled LLRs e_est[m_bit] (LDS) to the 40 decoded bits: de-ratematch, tail-biting
 // Viterbi, CRC-16 with the antenna-port mask (ref src/lte_lib.cpp:469-518, 538-551, 637-663; src/searcher.cpp:1617-1636).
 // Called by all PB_WAVES * 64 threads of the workgroup; ok / bits40 are valid on thread 0 afterwards.

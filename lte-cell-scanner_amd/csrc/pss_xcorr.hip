@@ -595,7 +595,9 @@ int lcs_launch_ingest(lcs_ctx *c, const void *d_src, int fmt, int n_buf, uint32_
   c->src_u8 = fmt == LCS_FMT_IQ_U8;
   if (fmt == LCS_FMT_IQ_U8) {
     const unsigned nb = (unsigned)((lcs_cap8_stride(n_cap) / 8 + 255) / 256);
+#ifndef LCS_EXP_SKIP_INGEST
     hipLaunchKernelGGL(k_ingest_u8, dim3(nb, n_buf), dim3(256), 0, c->stream, (const uint8_t *)d_src, n_cap, c->cap8, c->cap8s);
+#endif
   } else {
     hipLaunchKernelGGL(k_ingest, dim3(128, n_buf), dim3(256), 0, c->stream, d_src, fmt, n_cap, c->cap32, c->cap64);
   }
@@ -613,8 +615,10 @@ static std::mutex g_xc_mutex;
 static hipEvent_t g_xc_done[64] = {};
 
 int lcs_launch_xcorr(lcs_ctx *c, int n_buf, const XcGeom &geo, bool want_incoh, bool time_it) {
+#ifndef LCS_EXP_SKIP_PREP
   hipLaunchKernelGGL(k_prep_tables, dim3(n_buf, 4), dim3(256), 0, c->stream, c->params, c->fset, c->d_pss_td, c->tmpl,
                      c->start, c->smin, c->kp2, geo);
+#endif
   if (c->use_i8) {
     int rc_ = lcs_launch_fill_btab_i8(c, n_buf, geo);
     if (rc_) return rc_;
@@ -628,9 +632,11 @@ int lcs_launch_xcorr(lcs_ctx *c, int n_buf, const XcGeom &geo, bool want_incoh, 
   a.ds = geo.ds;
   a.R_th1 = lcs_tables::chi2cdf_inv(1 - pow(10.0, -12), 2.0 * geo.n_comb * (2 * geo.ds + 1));
   a.rx_cutoff = (6 * 12 * 15e3 / 2 + 4 * 15e3) / (30720000.0 / 16 / 2);
-  if (c->src_u8 && !c->cap64_valid)
+  if (c->src_u8 && !c->cap64_valid) {
+#ifndef LCS_EXP_SKIP_SP
     hipLaunchKernelGGL(k_sp_i8, dim3(LCS_N_IDX / SPI_TILE, n_buf), dim3(256), 0, c->stream, c->cap8, geo.n_cap, c->spinc, c->zth, a);
-  else {
+#endif
+  } else {
   hipLaunchKernelGGL(k_sp_sums, dim3(((LCS_N_IDX + SP_TILE - 1) / SP_TILE) * a.n_comb_sp * n_buf), dim3(64), 0,
                      c->stream, lcs_cap_src(c, geo.n_cap), c->sp, geo.n_cap, a.n_comb_sp, n_buf);       // one-wave workgroups
   hipLaunchKernelGGL(k_sp_fold, dim3((n_buf * LCS_N_IDX + 255) / 256), dim3(256), 0, c->stream, c->sp, c->spinc,
@@ -677,8 +683,10 @@ int lcs_launch_xcorr(lcs_ctx *c, int n_buf, const XcGeom &geo, bool want_incoh, 
     HIPCHK(c, hipEventRecord(c->ev_post, sxc));
     HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_post, 0));
   }
+#ifndef LCS_EXP_SKIP_COLLAPSE
   hipLaunchKernelGGL(k_collapse, dim3(((LCS_N_IDX + 127) / 128) * n_buf), dim3(128), 0, c->stream, c->single,
                      want_incoh ? c->incoh : nullptr, c->pow_, reinterpret_cast<float *>(c->work), c->frq, geo, n_buf);
+#endif
   HIPCHK(c, hipGetLastError());
   return LCS_OK;
 }

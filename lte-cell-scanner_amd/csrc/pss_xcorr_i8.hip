@@ -314,9 +314,13 @@ __global__ __launch_bounds__(256, 2) void k_xcorr_i8x3(const uint16_t *__restric
 }
 
 int lcs_launch_fill_btab_i8(lcs_ctx *c, int n_buf, const XcGeom &geo) {
+#ifndef LCS_EXP_SKIP_PREP
   hipLaunchKernelGGL(k_i8_scales, dim3(n_buf), dim3(256), 0, c->stream, c->tmpl, c->tq, c->tsc, geo);
+#endif
+#ifndef LCS_EXP_SKIP_FILL
   hipLaunchKernelGGL(k_fill_btab_i8, dim3(2, geo.n_comb * geo.G, n_buf), dim3(256), 0, c->stream, c->tmpl, c->start, c->smin,
                      c->tq, c->bt8, geo);
+#endif
   HIPCHK(c, hipGetLastError());
   return LCS_OK;
 }

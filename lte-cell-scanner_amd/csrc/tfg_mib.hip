@@ -709,22 +709,23 @@ __device__ __forceinline__ double np_from_partials(const double *sc, int port) {
 }
 
 // ------------------------------------------------------------------------ PBCH decode
-// One workgroup per (cell, candidate): candidate = frame_timing_guess*3 + {1,2,4 ports}.
-// 256 threads (one wave per SIMD, < 288 VGPRs) and ~19 KB of LDS so the workgroup can be placed
-// beside the correlation kernel's resident workgroups: equalised symbols stay in registers (symbol
-// pairs go straight through the soft demodulator), only the 1920 LLRs go through LDS.
-#define PB_THREADS 256
-#define PB_WAVES (PB_THREADS / 64)
-__global__ __launch_bounds__(PB_THREADS) __attribute__((amdgpu_waves_per_eu(3, 8))) void k_pbch(const lcs_cell *__restrict__ cells, const int *__restrict__ n_work,
+// One WAVE per (cell, candidate): candidate = frame_timing_guess*3 + {1,2,4 ports}.  The equalised symbols stay in
+// registers (symbol pairs go straight through the soft demodulator), the 1920 LLRs go through LDS, and the 64
+// tail-biting trellises run one per lane with their path metrics in registers (lte_device.h).  64 threads, < 284
+// VGPRs, 21 KB of LDS: four of these fit where one resident correlation workgroup has retired.
+#define PB_THREADS 64
+// out of line: the trellis pass takes ~240 registers of its own; inlined, the values that live across it spill
+__device__ __noinline__ double pbch_trellis_pass(const double (*d_est)[40], int ss, unsigned long long *surv) {
+  return vit_trellis(d_est[0], d_est[1], d_est[2], ss, surv, 64);
+}
+__global__ __launch_bounds__(PB_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_pbch(const lcs_cell *__restrict__ cells, const int *__restrict__ n_work,
                                                       const double2 *__restrict__ tfg_comp, const double2 *__restrict__ ce,
                                                       double *__restrict__ scratch, const uint8_t *__restrict__ pbch_scr,
                                                       const int16_t *__restrict__ derm_inv /*[2][120][16]*/) {
   LCS_TAIL_PRIO();
-  __shared__ double e_est[1920];
+  __shared__ unsigned long long surv[40 * 64];      // survivor words [step][trellis]; holds the LLRs until they are de-ratematched
   __shared__ double d_est[3][40];
-  __shared__ unsigned long long best_surv[PB_WAVES][40];
-  __shared__ double w_best[PB_WAVES];
-  __shared__ int w_best_ss[PB_WAVES];
+  double *e_est = reinterpret_cast<double *>(surv);  // 1920 doubles = 15 KB of the 20 KB
   const int tid = threadIdx.x, cand = blockIdx.y;
   const int guess = cand / 3, n_ports = (cand % 3 == 2) ? 4 : (cand % 3) + 1;
   for (int it = blockIdx.x; it < *n_work; it += gridDim.x) {
@@ -741,7 +742,7 @@ __global__ __launch_bounds__(PB_THREADS) __attribute__((amdgpu_waves_per_eu(3, 8
     const int start = guess * 10 * 2 * n_symb;
     __syncthreads();
     PH(0);
-    // pbch_extract (ref :1503-1520) + equalisation (ref :1571-1612), one symbol pair per thread
+    // pbch_extract (ref :1503-1520) + equalisation (ref :1571-1612), one symbol pair per thread and round
     for (int pr = tid; pr < n_sym / 2; pr += PB_THREADS) {
       cd2 x[2], h[4][2], syms[2];
       double npv[2];
@@ -749,10 +750,8 @@ __global__ __launch_bounds__(PB_THREADS) __attribute__((amdgpu_waves_per_eu(3, 8
         const int idx = 2 * pr + q;
         const int fr = idx / per_frame;
         int rem = idx % per_frame, sym;
-        const int n3 = (n_symb == 6) ? 48 : 72;
         if (rem < 48) sym = 0; else if (rem < 96) { sym = 1; rem -= 48; } else if (rem < 168) { sym = 2; rem -= 96; } else { sym = 3; rem -= 168; }
         const bool has_rs = (sym == 0) || (sym == 1) || (sym == 3 && n_symb == 6);
-        (void)n3;
         const int scx = has_rs ? (3 * (rem / 2) + ((rem & 1) ? r1 : r0)) : rem;
         const int row = start + fr * 10 * 2 * n_symb + n_symb + sym;
         x[q] = ld(&g[(size_t)row * NSC + scx]);
@@ -794,9 +793,43 @@ __global__ __launch_bounds__(PB_THREADS) __attribute__((amdgpu_waves_per_eu(3, 8
     }
     __syncthreads();
     PH(1);
+    // de-ratematch: average all observations of each coded bit (ref src/lte_lib.cpp:497-509); the sums wait in
+    // registers until every lane has read its LLRs, because the survivor words reuse that LDS
+    double dsum[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int bit = tid + 64 * q;
+      double s = 0; int cnt = 0;
+      if (bit < 120) {
+        const int16_t *lst = derm_inv + ((m_bit == 1920) ? 0 : 120 * 16) + bit * 16;   // ascending bit positions
+        for (int k = 0; k < 16; ++k) { const int t = lst[k]; if (t < 0) break; s += e_est[t]; ++cnt; }
+        if (cnt > 1) s = s / cnt;
+      }
+      dsum[q] = s;
+    }
+    __syncthreads();
+    d_est[tid / 40][tid % 40] = dsum[0];
+    if (tid + 64 < 120) d_est[(tid + 64) / 40][(tid + 64) % 40] = dsum[1];
+    __syncthreads();
+    PH(2);
+    // 64 tail-biting trellises, lane = start state; the best end metric wins, the lowest start state among equals
+    const double fin = pbch_trellis_pass(d_est, tid, surv + tid);
+    double best = (fin < INFINITY) ? fin : INFINITY;     // NaN / unreachable never win (strict < against +inf in the reference)
+    int best_ss = tid;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const double ov = __shfl_xor(best, off);
+      const int oi = __shfl_xor(best_ss, off);
+      if (ov < best || (ov == best && oi < best_ss)) { best = ov; best_ss = oi; }
+    }
+    __syncthreads();
+    PH(3);
     int ok = 0;
-    unsigned long long bits40 = 0;
-    pbch_decode_tail<PB_WAVES>(e_est, d_est, best_surv, w_best, w_best_ss, derm_inv, m_bit, n_ports, tid, ok, bits40);
+    unsigned long long bits40 = 0ull;
+    if (best < INFINITY) {
+      bits40 = vit_traceback(surv + best_ss, 64, best_ss);
+      ok = pbch_crc_ok(bits40, n_ports);
+    }
     if (tid == 0) {
       const unsigned bits24 = (unsigned)(bits40 & 0xffffffull);
       sc[CS_CAND + cand * 4 + 0] = (double)ok;
@@ -834,7 +867,7 @@ __global__ void k_mib_select(lcs_cell *__restrict__ cells, const int *__restrict
 }
 
 // ------------------------------------------------------------------------------ launch
-#define GRID_ITEMS 64       // workgroups loop over the work list: enough for a typical batch in one round
+// workgroups loop over the work list; c->grid_items of them per list axis (64: a typical 64-buffer batch in one round)
 int lcs_launch_gather_work(lcs_ctx *c, int n_buf, int skip) {
   hipLaunchKernelGGL(k_gather_work, dim3(1), dim3(64), 0, c->stream, c->peaks, c->npeaks, n_buf, skip, c->max_work,
                      c->st_open ? c->st_dtracked : nullptr, c->st_dntracked, c->work_items, c->n_work,
@@ -849,30 +882,36 @@ int lcs_launch_scatter_back(lcs_ctx *c) {
   return LCS_OK;
 }
 int lcs_launch_tfg(lcs_ctx *c, uint32_t n_cap, bool with_rs) {
-  hipLaunchKernelGGL(k_cell_prep, dim3(GRID_ITEMS), dim3(128), 0, c->stream, c->cells_out, c->work_items, c->n_work, c->params,
+  hipLaunchKernelGGL(k_cell_prep, dim3(c->grid_items), dim3(128), 0, c->stream, c->cells_out, c->work_items, c->n_work, c->params,
                      c->d_pn_jump, c->tfg_ts, c->cell_scratch, with_rs ? 3 : 1);
-  hipLaunchKernelGGL(k_tfg, dim3(4096), dim3(TFG_THREADS), 0, c->stream, c->cells_out, c->work_items, c->n_work, c->params,
+#ifndef LCS_EXP_SKIP_TFG
+  hipLaunchKernelGGL(k_tfg, dim3(LCS_TFG_GRID), dim3(TFG_THREADS), 0, c->stream, c->cells_out, c->work_items, c->n_work, c->params,
                      lcs_cap_src(c, n_cap), n_cap, c->tfg_ts, c->cell_scratch, c->tfg, c->needed_rows_only ? 1 : 0);
+#endif
   HIPCHK(c, hipGetLastError());
   return LCS_OK;
 }
 int lcs_launch_rs_build(lcs_ctx *c) {
-  hipLaunchKernelGGL(k_cell_prep, dim3(GRID_ITEMS), dim3(128), 0, c->stream, c->cells_out, c->work_items, c->n_work, c->params,
+  hipLaunchKernelGGL(k_cell_prep, dim3(c->grid_items), dim3(128), 0, c->stream, c->cells_out, c->work_items, c->n_work, c->params,
                      c->d_pn_jump, c->tfg_ts, c->cell_scratch, 2);
   HIPCHK(c, hipGetLastError());
   return LCS_OK;
 }
 int lcs_launch_tfoec(lcs_ctx *c, int n_items) {
   (void)n_items;
-  hipLaunchKernelGGL(k_tfoec_est, dim3(GRID_ITEMS, TF_PARTS), dim3(TF_THREADS), 0, c->stream, c->cells_out, c->work_items, c->n_work,
+#ifndef LCS_EXP_SKIP_TFOEC
+  hipLaunchKernelGGL(k_tfoec_est, dim3(c->grid_items, TF_PARTS), dim3(TF_THREADS), 0, c->stream, c->cells_out, c->work_items, c->n_work,
                      c->params, c->tfg, c->tfg_ts, c->cell_scratch, c->tfg_ts_comp);
-  hipLaunchKernelGGL(k_tfoec_apply, dim3(2048), dim3(TFA_THREADS), 0, c->stream, c->n_work, c->tfg, c->tfg_ts, c->cell_scratch,
+#endif
+#ifndef LCS_EXP_SKIP_TFOEC
+  hipLaunchKernelGGL(k_tfoec_apply, dim3(LCS_TFA_GRID), dim3(TFA_THREADS), 0, c->stream, c->n_work, c->tfg, c->tfg_ts, c->cell_scratch,
                      c->cells_out, c->tfg_comp, c->needed_rows_only ? 1 : 0);
+#endif
   HIPCHK(c, hipGetLastError());
   return LCS_OK;
 }
 int lcs_launch_chan_est(lcs_ctx *c) {
-  hipLaunchKernelGGL(k_chan_est, dim3(GRID_ITEMS, 4, CE_NCHUNK), dim3(CE_THREADS), 0, c->stream, c->cells_out, c->n_work,
+  hipLaunchKernelGGL(k_chan_est, dim3(c->grid_items, 4, CE_NCHUNK), dim3(CE_THREADS), 0, c->stream, c->cells_out, c->n_work,
                      c->tfg_comp, c->cell_scratch, c->ce, c->needed_rows_only ? 1 : 0);
   HIPCHK(c, hipGetLastError());
   return LCS_OK;
@@ -880,10 +919,14 @@ int lcs_launch_chan_est(lcs_ctx *c) {
 void lcs_chan_est_np_layout(int *first, int *per_port, int *n_rs_first) { *first = CS_NPP; *per_port = 8; *n_rs_first = CS_NRS; }
 int lcs_launch_mib(lcs_ctx *c, int n_items) {
   (void)n_items;
-  hipLaunchKernelGGL(k_chan_est, dim3(GRID_ITEMS, 4, CE_NCHUNK), dim3(CE_THREADS), 0, c->stream, c->cells_out, c->n_work,
+#ifndef LCS_EXP_SKIP_CHANEST
+  hipLaunchKernelGGL(k_chan_est, dim3(c->grid_items, 4, CE_NCHUNK), dim3(CE_THREADS), 0, c->stream, c->cells_out, c->n_work,
                      c->tfg_comp, c->cell_scratch, c->ce, c->needed_rows_only ? 1 : 0);
-  hipLaunchKernelGGL(k_pbch, dim3(GRID_ITEMS, 12), dim3(PB_THREADS), 0, c->stream, c->cells_out, c->n_work, c->tfg_comp,
+#endif
+#ifndef LCS_EXP_SKIP_PBCH
+  hipLaunchKernelGGL(k_pbch, dim3(c->grid_items, 12), dim3(PB_THREADS), 0, c->stream, c->cells_out, c->n_work, c->tfg_comp,
                      c->ce, c->cell_scratch, c->d_pbch_scr, c->d_derm_inv);
+#endif
   hipLaunchKernelGGL(k_mib_select, dim3((LCS_MAX_WORK + 63) / 64), dim3(64), 0, c->stream, c->cells_out, c->n_work,
                      c->cell_scratch);
   HIPCHK(c, hipGetLastError());

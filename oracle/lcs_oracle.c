@@ -1160,6 +1160,16 @@ static void lte_demodulate_qpsk(const cd *syms, const double *np, int n, double 
   }
 }
 
+void orc_conv_decode_tailbite(const double *d_est, int n, uint8_t *c_est) { conv_decode_tailbite(d_est, n, c_est); }
+/* ref: src/searcher.cpp:1617-1636: CRC-16 of the 24 payload bits, antenna-port mask, compare with bits 24..39 */
+int orc_pbch_crc_ok(const uint8_t *c_est, int n_ports) {
+  uint8_t crc_est[16];
+  crc16_bits(c_est, 24, crc_est);
+  if (n_ports == 2) for (int t = 0; t < 16; t++) crc_est[t] = 1 - crc_est[t];
+  else if (n_ports == 4) for (int t = 1; t < 16; t += 2) crc_est[t] = 1 - crc_est[t];
+  return memcmp(crc_est, c_est + 24, 16) == 0;
+}
+
 /* ref: src/searcher.cpp:1482-1522 pbch_extract, :1526-1692 decode_mib */
 int orc_decode_mib(const orc_cell *cell, const double *tfg_re_im, int n_ofdm, orc_cell *cell_out) {
   const cd *tfg = (const cd *)tfg_re_im;

@@ -1,0 +1,20 @@
+// Host-side harness for the lane-per-trellis Viterbi of lte_device.h (the same __host__ __device__ code the GPU
+// runs, with the 64 lanes walked sequentially): tests/test_viterbi_host.py compares it with the oracle's
+// exhaustive tail-biting decoder on random, quantised (tie-prone) and saturated inputs.  Test infrastructure.
+#include "../../lte-cell-scanner_amd/csrc/lte_device.h"
+#include <vector>
+
+extern "C" int vit_host_decode(const double *d_est /*[3][40]*/, unsigned long long *bits40, int *best_ss, double *best_metric) {
+  std::vector<unsigned long long> surv((size_t)40 * 64);
+  double best = INFINITY;
+  int bss = -1;
+  for (int ss = 0; ss < 64; ++ss) {
+    const double fin = vit_trellis(d_est, d_est + 40, d_est + 80, ss, surv.data() + ss, 64);
+    if (fin < best) { best = fin; bss = ss; }
+  }
+  *best_ss = bss;
+  *best_metric = best;
+  *bits40 = (bss >= 0) ? vit_traceback(surv.data() + bss, 64, bss) : 0ull;
+  return bss >= 0;
+}
+extern "C" int vit_host_crc_ok(unsigned long long bits, int n_ports) { return pbch_crc_ok(bits, n_ports); }

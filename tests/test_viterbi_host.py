@@ -1,0 +1,102 @@
+"""The GPU's tail-biting Viterbi (lte_device.h: one trellis per lane, 64 path metrics in registers, slot rotation
+instead of a metric shuffle) compiled for the HOST and compared with the oracle's exhaustive decoder
+(oracle/lcs_oracle.c conv_decode_tailbite <- src/lte_lib.cpp:538-551 -> itpp decode_tailbite): decoded bits and
+winning start state on random LLRs, coarsely quantised LLRs (exact metric ties between paths), saturated LLRs and
+encoded codewords with noise; CRC check incl. the antenna-port masks (src/searcher.cpp:1617-1636)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "tests", "host", "vit_host.cpp")
+LIB = os.path.join(ROOT, "tests", "host", "libvit_host.so")
+
+
+@pytest.fixture(scope="module")
+def libs():
+    dep = [SRC, os.path.join(ROOT, "lte-cell-scanner_amd", "csrc", "lte_device.h")]
+    if not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in dep):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC",
+                               "-shared", "-I" + os.path.join(ROOT, "include"), "-o", LIB, SRC])
+    H = C.CDLL(LIB)
+    H.vit_host_decode.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_int), C.POINTER(C.c_double)]
+    H.vit_host_crc_ok.argtypes = [C.c_uint64, C.c_int]
+    O = C.CDLL(os.path.join(ROOT, "oracle", "liblcs_oracle.so"))
+    O.orc_conv_decode_tailbite.argtypes = [C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_uint8)]
+    O.orc_conv_decode_tailbite.restype = None
+    O.orc_pbch_crc_ok.argtypes = [C.POINTER(C.c_uint8), C.c_int]
+    return H, O
+
+
+def both(libs, d):
+    H, O = libs
+    d = np.ascontiguousarray(d, np.float64).reshape(3, 40)
+    bits, ss, met = C.c_uint64(), C.c_int(), C.c_double()
+    H.vit_host_decode(d.ctypes.data_as(C.POINTER(C.c_double)), C.byref(bits), C.byref(ss), C.byref(met))
+    got = np.array([(bits.value >> t) & 1 for t in range(40)], np.uint8)
+    ref = np.zeros(40, np.uint8)
+    O.orc_conv_decode_tailbite(d.ctypes.data_as(C.POINTER(C.c_double)), 40, ref.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return got, ref, bits.value
+
+
+def encode(bits):
+    """Tail-biting K=7 (133,171,165)o encoder; LLR sign convention of the decoder: out bit 1 <-> negative metric term."""
+    G = (0o133, 0o171, 0o165)
+    state = 0
+    for b in bits[-6:]:
+        state = (state >> 1) | (int(b) << 5)
+    out = np.zeros((3, 40))
+    for t, b in enumerate(bits):
+        reg = (int(b) << 6) | state
+        for j in range(3):
+            out[j, t] = 1.0 if bin(reg & G[j]).count("1") & 1 else -1.0
+        state = reg >> 1
+    return out
+
+
+def test_matches_oracle_on_random_and_tied_inputs(libs):
+    rng = np.random.default_rng(5)
+    n_tie_cases = 0
+    for k in range(120):
+        if k < 40:
+            d = rng.normal(0, 3, (3, 40))
+        elif k < 80:                       # coarse grid: many exactly equal path metrics
+            d = rng.integers(-2, 3, (3, 40)).astype(np.float64)
+            n_tie_cases += 1
+        elif k < 100:                      # saturated LLRs as at high SNR (trunc_log clipping), some exactly 0
+            d = rng.choice([-708.396418532264, 708.396418532264, 0.0, 12.5], (3, 40))
+        else:                              # a codeword in noise
+            msg = rng.integers(0, 2, 40)
+            d = -encode(msg) * 4.0 + rng.normal(0, 2.0, (3, 40))
+        got, ref, _ = both(libs, d)
+        assert np.array_equal(got, ref), f"case {k}"
+    assert n_tie_cases == 40
+
+
+def test_decodes_clean_codewords_and_crc(libs):
+    H, O = libs
+    rng = np.random.default_rng(6)
+    for k in range(20):
+        msg = rng.integers(0, 2, 40).astype(np.uint8)
+        got, ref, word = both(libs, -encode(msg) * 5.0)
+        assert np.array_equal(got, msg) and np.array_equal(ref, msg)
+        for n_ports in (1, 2, 4):
+            assert H.vit_host_crc_ok(word, n_ports) == O.orc_pbch_crc_ok(msg.ctypes.data_as(C.POINTER(C.c_uint8)), n_ports)
+    # a word with a valid CRC for exactly one port count
+    payload = rng.integers(0, 2, 24).astype(np.uint8)
+    for n_ports, mask in ((1, 0x0000), (2, 0xFFFF), (4, 0x5555)):
+        crc = 0
+        for b in payload:
+            msb = ((crc >> 15) & 1) ^ int(b)
+            crc = (crc << 1) & 0xFFFF
+            if msb:
+                crc ^= 0x1021
+        crc ^= mask
+        c_est = np.concatenate([payload, [(crc >> (15 - t)) & 1 for t in range(16)]]).astype(np.uint8)
+        word = sum(int(b) << t for t, b in enumerate(c_est))
+        for p in (1, 2, 4):
+            want = int(p == n_ports)
+            assert H.vit_host_crc_ok(word, p) == want == O.orc_pbch_crc_ok(c_est.ctypes.data_as(C.POINTER(C.c_uint8)), p)
