@@ -36,17 +36,10 @@
 #define LCS_I8_KB 5          // 32-tap blocks of the int8 correlation kernel: taps + window-start spread <= 160
 #define LCS_MAX_WORK 512     // cells carried into the TFG/MIB stages per batch
 // grid sizes of the work-list kernels (every one loops over its list, so these only trade latency for workgroups)
-#ifdef LCS_EXP_GRIDCAP     // A/B builds only
-#define LCS_WIN_GRID LCS_EXP_GRIDCAP
-#define LCS_ITEM_GRID LCS_EXP_GRIDCAP
-#define LCS_TFG_GRID LCS_EXP_GRIDCAP
-#define LCS_TFA_GRID LCS_EXP_GRIDCAP
-#else
 #define LCS_WIN_GRID 4096
 #define LCS_ITEM_GRID 1024
 #define LCS_TFG_GRID 4096
 #define LCS_TFA_GRID 2048
-#endif
 #define LCS_TFG_ROWS 854
 #define LCS_CELL_SCRATCH 4608 // doubles of per-cell scratch (RS table, shifts, noise powers, PBCH candidates)
 

@@ -164,110 +164,51 @@ __host__ __device__ __forceinline__ int pbch_crc_ok(unsigned long long bits, int
   return (crc == rx) ? 1 : 0;
 }
 
-// ---- PBCH decode from the descrambled LLRs e_est[m_bit] (LDS) to the 40 decoded bits: de-ratematch, tail-biting
-// Viterbi, CRC-16 with the antenna-port mask (ref src/lte_lib.cpp:469-518, 538-551, 637-663; src/searcher.cpp:1617-1636).
-// Called by all PB_WAVES * 64 threads of the workgroup; ok / bits40 are valid on thread 0 afterwards.
-template <int PB_WAVES>
-__device__ __forceinline__ void pbch_decode_tail(const double *e_est, double (*d_est)[40], unsigned long long (*best_surv)[40],
-                                                 double *w_best, int *w_best_ss,
-                                                 const int16_t *__restrict__ derm_inv, int m_bit, int n_ports, int tid, int &ok,
-                                                 unsigned long long &bits40) {
-    // de-ratematch: average all observations of each coded bit (ref src/lte_lib.cpp:497-509)
-    if (tid < 120) {
-      const int16_t *lst = derm_inv + ((m_bit == 1920) ? 0 : 120 * 16) + tid * 16;   // ascending bit positions
-      double s = 0; int cnt = 0;
-      for (int q = 0; q < 16; ++q) { const int t = lst[q]; if (t < 0) break; s += e_est[t]; ++cnt; }
+// ---- PBCH decode by ONE wave from the descrambled LLRs (LDS) to the 40 decoded bits: de-ratematch, the 64 tail-biting
+// trellises one per lane, CRC-16 with the antenna-port mask (ref src/lte_lib.cpp:469-518, 538-551, 637-663;
+// src/searcher.cpp:1617-1636).  `surv` is 40 x 64 survivor words of LDS whose first m_bit doubles hold the LLRs on
+// entry (they are dead once de-ratematched); called by all 64 lanes after a barrier behind the LLR writes; ok / bits40
+// are valid on every lane afterwards.
+// The trellis pass stays out of line: it takes ~240 registers of its own; inlined, whatever lives across it spills.
+static __device__ __noinline__ double pbch_trellis_pass(const double (*d_est)[40], int ss, unsigned long long *surv) {
+  return vit_trellis(d_est[0], d_est[1], d_est[2], ss, surv, 64);
+}
+__device__ __forceinline__ void pbch_decode_wave(unsigned long long *surv, double (*d_est)[40], const int16_t *__restrict__ derm_inv,
+                                                 int m_bit, int n_ports, int lane, int &ok, unsigned long long &bits40) {
+  const double *e_est = reinterpret_cast<const double *>(surv);
+  // de-ratematch: average all observations of each coded bit (ref src/lte_lib.cpp:497-509); the sums wait in registers
+  // until every lane has read its LLRs, because the survivor words reuse that LDS
+  double dsum[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int bit = lane + 64 * q;
+    double s = 0; int cnt = 0;
+    if (bit < 120) {
+      const int16_t *lst = derm_inv + ((m_bit == 1920) ? 0 : 120 * 16) + bit * 16;   // ascending bit positions
+      for (int k = 0; k < 16; ++k) { const int t = lst[k]; if (t < 0) break; s += e_est[t]; ++cnt; }
       if (cnt > 1) s = s / cnt;
-      d_est[tid / 40][tid % 40] = s;
     }
-    __syncthreads();
-    // tail-biting Viterbi, K=7, G=(133,171,165)o: one trellis per start state with the end state
-    // forced equal; lane = trellis state, each of the 16 waves takes 4 start states.
-    {
-      // each wave runs its 64 / PB_WAVES start states TOGETHER: the trellises are independent, so
-      // their shuffle -> add -> compare chains overlap instead of running back to back.  Lane t
-      // keeps the survivor word of step t for every trellis of the wave in registers.
-      const int wave = tid >> 6, s = tid & 63;
-      constexpr int NQ = 64 / PB_WAVES, HQ = (NQ < 8) ? NQ : 8;
-      const int b = s >> 5, p0 = (s << 1) & 63, p1 = p0 | 1;       // new state s <- predecessors p0, p1 with input bit b
-      const int reg0 = (b << 6) | p0, reg1 = (b << 6) | p1;
-      const bool a00 = __popc(reg0 & 0133) & 1, a01 = __popc(reg0 & 0171) & 1, a02 = __popc(reg0 & 0165) & 1;
-      const bool a10 = __popc(reg1 & 0133) & 1, a11 = __popc(reg1 & 0171) & 1, a12 = __popc(reg1 & 0165) & 1;
-      double pm[NQ];
-      unsigned long long my_surv[NQ];
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) { pm[q] = (s == wave * NQ + q) ? 0.0 : INFINITY; my_surv[q] = 0ull; }
-      for (int t = 0; t < 40; ++t) {
-        const double rr0 = d_est[0][t], rr1 = d_est[1][t], rr2 = d_est[2][t];
-        const double c00 = a00 ? rr0 : -rr0, c01 = a01 ? rr1 : -rr1, c02 = a02 ? rr2 : -rr2;
-        const double c10 = a10 ? rr0 : -rr0, c11 = a11 ? rr1 : -rr1, c12 = a12 ? rr2 : -rr2;
-        // the predecessor metrics of ALL trellises of a half-batch are fetched first (ds_bpermute on the two halves of
-        // each double), then the add-compare-select chains run: issued one trellis at a time, every chain would
-        // sit out the full cross-lane latency on its own (measured: 76 of k_pbch's 120 us)
-#pragma unroll
-        for (int h = 0; h < NQ; h += HQ) {
-          int f0l[HQ], f0h[HQ], f1l[HQ], f1h[HQ];
-#pragma unroll
-          for (int q = 0; q < HQ; ++q) {
-            const long long b = __double_as_longlong(pm[h + q]);
-            const int lo = (int)(b & 0xffffffffll), hi = (int)(b >> 32);
-            f0l[q] = __builtin_amdgcn_ds_bpermute(p0 << 2, lo); f0h[q] = __builtin_amdgcn_ds_bpermute(p0 << 2, hi);
-            f1l[q] = __builtin_amdgcn_ds_bpermute(p1 << 2, lo); f1h[q] = __builtin_amdgcn_ds_bpermute(p1 << 2, hi);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int q = 0; q < HQ; ++q) {
-            double m0 = __longlong_as_double(((long long)f0h[q] << 32) | (unsigned)f0l[q]);
-            double m1 = __longlong_as_double(((long long)f1h[q] << 32) | (unsigned)f1l[q]);
-            m0 += c00; m0 += c01; m0 += c02;
-            m1 += c10; m1 += c11; m1 += c12;
-            const bool take1 = m1 < m0;          // ties keep the lower-numbered predecessor
-            pm[h + q] = take1 ? m1 : m0;
-            const unsigned long long bal = __ballot(take1);
-            if (s == t) my_surv[h + q] = bal;
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-      double wbest = INFINITY; int wbest_ss = -1;
-      unsigned long long keep = 0ull;
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) {         // start states in ascending order, strict < : first best wins
-        const int ss = wave * NQ + q;
-        const double fin = __shfl(pm[q], ss);
-        if (fin < wbest) { wbest = fin; wbest_ss = ss; keep = my_surv[q]; }
-      }
-      if (s < 40) best_surv[wave][s] = keep;
-      if (s == 0) { w_best[wave] = wbest; w_best_ss[wave] = wbest_ss; }
-    }
-    __syncthreads();
-    if (tid == 0) {
-      int bw = 0;
-      for (int w = 1; w < PB_WAVES; ++w) if (w_best[w] < w_best[bw]) bw = w;
-      ok = 0;
-      if (w_best_ss[bw] >= 0) {
-        int s = w_best_ss[bw];
-        unsigned long long bits = 0ull;                    // bit t = decoded bit c_est(t)
-        for (int t = 39; t >= 0; --t) {
-          bits |= (unsigned long long)((s >> 5) & 1) << t;
-          const int dec = (int)((best_surv[bw][t] >> s) & 1ull);
-          s = ((s << 1) & 63) | dec;
-        }
-        // CRC-16 (x^16+x^12+x^5+1, zero init) over the 24 payload bits as a shift register -- the remainder of the
-        // reference's long division (src/lte_lib.cpp:637-663), kept in one register instead of a byte array
-        unsigned crc = 0;
-        for (int i = 0; i < 24; ++i) {
-          const unsigned msb = ((crc >> 15) & 1u) ^ (unsigned)((bits >> i) & 1ull);
-          crc = (crc << 1) & 0xffffu;
-          if (msb) crc ^= 0x1021u;
-        }
-        unsigned rx = 0;                                   // received CRC, bit 15 - t = c_est(24 + t)
-        for (int t = 0; t < 16; ++t) rx |= (unsigned)((bits >> (24 + t)) & 1ull) << (15 - t);
-        if (n_ports == 2) crc ^= 0xffffu;                  // antenna-port masks (ref src/searcher.cpp:1628-1636)
-        else if (n_ports == 4) crc ^= 0x5555u;             // every second bit, t = 1, 3, ... <-> register bits 14, 12, ...
-        ok = (crc == rx) ? 1 : 0;
-        bits40 = bits;
-      }
-    }
+    dsum[q] = s;
+  }
   __syncthreads();
+  d_est[lane / 40][lane % 40] = dsum[0];
+  if (lane + 64 < 120) d_est[(lane + 64) / 40][(lane + 64) % 40] = dsum[1];
+  __syncthreads();
+  // lane = start state; the best end metric wins, the lowest start state among equals (ascending, strict < in the reference)
+  const double fin = pbch_trellis_pass(d_est, lane, surv + lane);
+  double best = (fin < INFINITY) ? fin : INFINITY;       // NaN / unreachable never win
+  int best_ss = lane;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const double ov = __shfl_xor(best, off);
+    const int oi = __shfl_xor(best_ss, off);
+    if (ov < best || (ov == best && oi < best_ss)) { best = ov; best_ss = oi; }
+  }
+  __syncthreads();
+  ok = 0;
+  bits40 = 0ull;
+  if (best < INFINITY) {
+    bits40 = vit_traceback(surv + best_ss, 64, best_ss);
+    ok = pbch_crc_ok(bits40, n_ports);
+  }
 }

@@ -237,10 +237,8 @@ __global__ __launch_bounds__(PSR_THREADS) __attribute__((amdgpu_waves_per_eu(3, 
 
 int lcs_launch_peak_search(lcs_ctx *c, int n_buf, const XcGeom &geo, double udb10_m12, bool fp32_exact) {
   if (fp32_exact) {
-#ifndef LCS_EXP_SKIP_PEAK
     hipLaunchKernelGGL(k_peak_search_reg, dim3(n_buf), dim3(PSR_THREADS), 0, c->stream, reinterpret_cast<const float *>(c->work), c->frq, c->zth, c->single,
                        c->fset, c->params, c->peaks, c->npeaks, geo, udb10_m12);
-#endif
   } else
     hipLaunchKernelGGL(k_peak_search, dim3(n_buf), dim3(PS_THREADS), 0, c->stream, c->pow_, c->frq, c->zth, c->single,
                        c->fset, c->params, c->work, c->peaks, c->npeaks, geo, udb10_m12);

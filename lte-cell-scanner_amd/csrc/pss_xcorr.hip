@@ -500,23 +500,30 @@ __global__ __launch_bounds__(128) void k_collapse(const float *__restrict__ sg, 
     }
     __syncthreads();
     if (idx < LCS_N_IDX) {
-      float v[LCS_TG];
+      // four columns at a time keep the kernel at 39 VGPRs: its workgroups fit beside two resident correlation
+      // workgroups (see k_fill_btab_i8)
       const float *me = tile + (tid + ds) * (LCS_TG + 1);
+#pragma unroll 1
+      for (int j0 = 0; j0 < LCS_TG; j0 += 4) {
+        float v[4];
 #pragma unroll
-      for (int j = 0; j < LCS_TG; ++j) v[j] = me[j];
-      for (int d = 1; d <= ds; ++d) {
-        const float *pa = me - d * (LCS_TG + 1), *pb = me + d * (LCS_TG + 1);
+        for (int j = 0; j < 4; ++j) v[j] = me[j0 + j];
+        for (int d = 1; d <= ds; ++d) {
+          const float *pa = me - d * (LCS_TG + 1) + j0, *pb = me + d * (LCS_TG + 1) + j0;
 #pragma unroll
-        for (int j = 0; j < LCS_TG; ++j) v[j] = v[j] + (pa[j] + pb[j]);
-      }
+          for (int j = 0; j < 4; ++j) v[j] = v[j] + (pa[j] + pb[j]);
+        }
 #pragma unroll
-      for (int j = 0; j < LCS_TG; ++j) {
-        const int c = lcs_col_tmpl(geo, g, j);
-        if (c >= 0) {
-          const int foi = c / 3, t = c % 3;
-          const float x = __fdiv_rn(v[j], dsn);
-          if (incoh) incoh[((((size_t)slot * 3 + t) * LCS_N_IDX) + idx) * geo.n_f + foi] = x;
-          if (foi == 0 || x > best[t]) { best[t] = x; bi[t] = foi; }
+        for (int j = 0; j < 4; ++j) {
+          const int c = lcs_col_tmpl(geo, g, j0 + j);
+          if (c >= 0) {
+            const int foi = c / 3, t = c % 3;
+            const float x = __fdiv_rn(v[j], dsn);
+            if (incoh) incoh[((((size_t)slot * 3 + t) * LCS_N_IDX) + idx) * geo.n_f + foi] = x;
+            if (t == 0) { if (foi == 0 || x > best[0]) { best[0] = x; bi[0] = foi; } }
+            else if (t == 1) { if (foi == 0 || x > best[1]) { best[1] = x; bi[1] = foi; } }
+            else { if (foi == 0 || x > best[2]) { best[2] = x; bi[2] = foi; } }
+          }
         }
       }
     }
@@ -595,9 +602,7 @@ int lcs_launch_ingest(lcs_ctx *c, const void *d_src, int fmt, int n_buf, uint32_
   c->src_u8 = fmt == LCS_FMT_IQ_U8;
   if (fmt == LCS_FMT_IQ_U8) {
     const unsigned nb = (unsigned)((lcs_cap8_stride(n_cap) / 8 + 255) / 256);
-#ifndef LCS_EXP_SKIP_INGEST
     hipLaunchKernelGGL(k_ingest_u8, dim3(nb, n_buf), dim3(256), 0, c->stream, (const uint8_t *)d_src, n_cap, c->cap8, c->cap8s);
-#endif
   } else {
     hipLaunchKernelGGL(k_ingest, dim3(128, n_buf), dim3(256), 0, c->stream, d_src, fmt, n_cap, c->cap32, c->cap64);
   }
@@ -615,10 +620,8 @@ static std::mutex g_xc_mutex;
 static hipEvent_t g_xc_done[64] = {};
 
 int lcs_launch_xcorr(lcs_ctx *c, int n_buf, const XcGeom &geo, bool want_incoh, bool time_it) {
-#ifndef LCS_EXP_SKIP_PREP
   hipLaunchKernelGGL(k_prep_tables, dim3(n_buf, 4), dim3(256), 0, c->stream, c->params, c->fset, c->d_pss_td, c->tmpl,
                      c->start, c->smin, c->kp2, geo);
-#endif
   if (c->use_i8) {
     int rc_ = lcs_launch_fill_btab_i8(c, n_buf, geo);
     if (rc_) return rc_;
@@ -633,9 +636,7 @@ int lcs_launch_xcorr(lcs_ctx *c, int n_buf, const XcGeom &geo, bool want_incoh, 
   a.R_th1 = lcs_tables::chi2cdf_inv(1 - pow(10.0, -12), 2.0 * geo.n_comb * (2 * geo.ds + 1));
   a.rx_cutoff = (6 * 12 * 15e3 / 2 + 4 * 15e3) / (30720000.0 / 16 / 2);
   if (c->src_u8 && !c->cap64_valid) {
-#ifndef LCS_EXP_SKIP_SP
     hipLaunchKernelGGL(k_sp_i8, dim3(LCS_N_IDX / SPI_TILE, n_buf), dim3(256), 0, c->stream, c->cap8, geo.n_cap, c->spinc, c->zth, a);
-#endif
   } else {
   hipLaunchKernelGGL(k_sp_sums, dim3(((LCS_N_IDX + SP_TILE - 1) / SP_TILE) * a.n_comb_sp * n_buf), dim3(64), 0,
                      c->stream, lcs_cap_src(c, geo.n_cap), c->sp, geo.n_cap, a.n_comb_sp, n_buf);       // one-wave workgroups
@@ -683,10 +684,8 @@ int lcs_launch_xcorr(lcs_ctx *c, int n_buf, const XcGeom &geo, bool want_incoh, 
     HIPCHK(c, hipEventRecord(c->ev_post, sxc));
     HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_post, 0));
   }
-#ifndef LCS_EXP_SKIP_COLLAPSE
   hipLaunchKernelGGL(k_collapse, dim3(((LCS_N_IDX + 127) / 128) * n_buf), dim3(128), 0, c->stream, c->single,
                      want_incoh ? c->incoh : nullptr, c->pow_, reinterpret_cast<float *>(c->work), c->frq, geo, n_buf);
-#endif
   HIPCHK(c, hipGetLastError());
   return LCS_OK;
 }

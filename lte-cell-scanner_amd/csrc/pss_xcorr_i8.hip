@@ -96,51 +96,53 @@ __global__ __launch_bounds__(256) void k_fill_btab_i8(const float2 *__restrict__
   const int w = wg / geo.G, g = wg % geo.G;
   const int s0 = smin[((size_t)slot * NW + w) * GM + g];
   uint4 *out = bt8 + (((size_t)slot * geo.n_comb + w) * geo.G + g) * (size_t)(3 * I8_NKB * 2 * 64);
-  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < I8_NKB * 64; e += gridDim.x * blockDim.x) {
-    const int kb = e >> 6, lane = e & 63;
+  // one thread per (tap block, lane, half of the lane's 8 taps): 4 taps = 8 operand bytes per digit and output.
+  // 30 VGPRs: under the 48 that two resident correlation workgroups leave free on a SIMD (512 - 2 x 232), so these
+  // workgroups start beside them instead of waiting for one to retire; the table is stored with non-temporal
+  // stores (it is read ~1.5 ms later by another kernel; allocating 173 MB of it in L2 only evicts the running
+  // correlation's operands).  Together -1 % step time in the pipelined chain -- what this kernel costs there is its
+  // memory traffic (skip-kernel ablation: 45 us per batch before, ~35 after).
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < I8_NKB * 64 * 2; e += gridDim.x * blockDim.x) {
+    const int hf = e & 1, lane = (e >> 1) & 63, kb = e >> 7;
     const int c = lcs_col_tmpl(geo, g, lane & 15), kg = lane >> 4;
-    int vre[16], vim[16];
+    int tr[4], ti[4];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) { vre[j] = 0; vim[j] = 0; }
+    for (int m = 0; m < 4; ++m) { tr[m] = 0; ti[m] = 0; }
     if (c >= 0) {
       const int foi = c / 3, t = c % 3;
       const int delta = start[((size_t)slot * NW + w) * NFM + foi] - s0;
       const double q = tq[(size_t)slot * GM * LCS_TG + g * LCS_TG + (lane & 15)];      // scales are stored per column
+      const float2 *T = tmpl + (((size_t)slot * NFM + foi) * 3 + t) * 137;
 #pragma unroll
-      for (int m = 0; m < 8; ++m) {
-        const int tap = 32 * kb + 8 * kg + m - delta;
-        if (tap >= 0 && tap < 137) {
-          const float2 T = tmpl[(((size_t)slot * NFM + foi) * 3 + t) * 137 + tap];
-          const int tr = (int)rint((double)T.x * q), ti = (int)rint((double)T.y * q);
-          vre[2 * m] = tr; vre[2 * m + 1] = -ti;
-          vim[2 * m] = ti; vim[2 * m + 1] = tr;
-        }
+      for (int m = 0; m < 4; ++m) {
+        const int tap = 32 * kb + 8 * kg + 4 * hf + m - delta;
+        if (tap >= 0 && tap < 137) { tr[m] = (int)rint((double)T[tap].x * q); ti[m] = (int)rint((double)T[tap].y * q); }
       }
     }
-    uint32_t pk[3][2][4];
 #pragma unroll
-    for (int d = 0; d < 3; ++d)
+    for (int op = 0; op < 2; ++op) {                  // op 0: pairs (tr, -ti), op 1: pairs (ti, tr)
+      uint32_t pk[3][2];
 #pragma unroll
-      for (int op = 0; op < 2; ++op)
+      for (int d = 0; d < 3; ++d) { pk[d][0] = 0u; pk[d][1] = 0u; }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) pk[d][op][r] = 0u;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-#pragma unroll
-      for (int op = 0; op < 2; ++op) {
+      for (int j = 0; j < 8; ++j) {
+        const int m = j >> 1;
+        const int v = op ? ((j & 1) ? tr[m] : ti[m]) : ((j & 1) ? -ti[m] : tr[m]);
         int d0, d1, d2;
-        digits3(op ? vim[j] : vre[j], d0, d1, d2);
+        digits3(v, d0, d1, d2);
         const int sh = 8 * (j & 3);
-        pk[0][op][j >> 2] |= (uint32_t)(d0 & 255) << sh;
-        pk[1][op][j >> 2] |= (uint32_t)(d1 & 255) << sh;
-        pk[2][op][j >> 2] |= (uint32_t)(d2 & 255) << sh;
+        pk[0][j >> 2] |= (uint32_t)(d0 & 255) << sh;
+        pk[1][j >> 2] |= (uint32_t)(d1 & 255) << sh;
+        pk[2][j >> 2] |= (uint32_t)(d2 & 255) << sh;
+      }
+#pragma unroll
+      for (int d = 0; d < 3; ++d)
+      {
+        typedef unsigned u2v __attribute__((ext_vector_type(2)));
+        u2v val = {pk[d][0], pk[d][1]};
+        __builtin_nontemporal_store(val, reinterpret_cast<u2v *>(out + (((size_t)d * I8_NKB + kb) * 2 + op) * 64 + lane) + hf);
       }
     }
-#pragma unroll
-    for (int d = 0; d < 3; ++d)
-#pragma unroll
-      for (int op = 0; op < 2; ++op)
-        out[(((size_t)d * I8_NKB + kb) * 2 + op) * 64 + lane] = make_uint4(pk[d][op][0], pk[d][op][1], pk[d][op][2], pk[d][op][3]);
   }
 }
 
@@ -314,13 +316,9 @@ __global__ __launch_bounds__(256, 2) void k_xcorr_i8x3(const uint16_t *__restric
 }
 
 int lcs_launch_fill_btab_i8(lcs_ctx *c, int n_buf, const XcGeom &geo) {
-#ifndef LCS_EXP_SKIP_PREP
   hipLaunchKernelGGL(k_i8_scales, dim3(n_buf), dim3(256), 0, c->stream, c->tmpl, c->tq, c->tsc, geo);
-#endif
-#ifndef LCS_EXP_SKIP_FILL
-  hipLaunchKernelGGL(k_fill_btab_i8, dim3(2, geo.n_comb * geo.G, n_buf), dim3(256), 0, c->stream, c->tmpl, c->start, c->smin,
+  hipLaunchKernelGGL(k_fill_btab_i8, dim3((I8_NKB * 128 + 255) / 256, geo.n_comb * geo.G, n_buf), dim3(256), 0, c->stream, c->tmpl, c->start, c->smin,
                      c->tq, c->bt8, geo);
-#endif
   HIPCHK(c, hipGetLastError());
   return LCS_OK;
 }

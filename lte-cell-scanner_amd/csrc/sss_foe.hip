@@ -426,7 +426,6 @@ static int run_sss_foe(lcs_ctx *c, int n_buf, uint32_t n_cap, double thresh2, in
   const int win_grid = (int)std::min<size_t>(cap_items * MAX_HF, LCS_WIN_GRID);
   const int item_grid = (int)std::min<size_t>(cap_items, LCS_ITEM_GRID);
   hipLaunchKernelGGL(k_peak_list, dim3(1), dim3(64), 0, c->stream, c->npeaks, n_buf, c->pk_items, c->n_pk);
-#ifndef LCS_EXP_SKIP_SSSFOE
   if (mode & 1) {
     hipLaunchKernelGGL(k_sss_win, dim3(win_grid), dim3(SW_THREADS), 0, c->stream, c->peaks, c->pk_items, c->n_pk, src,
                        n_cap, c->params, c->d_pss_fd, c->sss_ws);
@@ -439,7 +438,6 @@ static int run_sss_foe(lcs_ctx *c, int n_buf, uint32_t n_cap, double thresh2, in
     hipLaunchKernelGGL(k_foe_fin, dim3((unsigned)((cap_items + 63) / 64)), dim3(64), 0, c->stream, c->peaks, c->pk_items,
                        c->n_pk, n_cap, c->params, c->sss_ws);
   }
-#endif
   HIPCHK(c, hipGetLastError());
   return LCS_OK;
 }

@@ -714,10 +714,6 @@ __device__ __forceinline__ double np_from_partials(const double *sc, int port) {
 // tail-biting trellises run one per lane with their path metrics in registers (lte_device.h).  64 threads, < 284
 // VGPRs, 21 KB of LDS: four of these fit where one resident correlation workgroup has retired.
 #define PB_THREADS 64
-// out of line: the trellis pass takes ~240 registers of its own; inlined, the values that live across it spill
-__device__ __noinline__ double pbch_trellis_pass(const double (*d_est)[40], int ss, unsigned long long *surv) {
-  return vit_trellis(d_est[0], d_est[1], d_est[2], ss, surv, 64);
-}
 __global__ __launch_bounds__(PB_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_pbch(const lcs_cell *__restrict__ cells, const int *__restrict__ n_work,
                                                       const double2 *__restrict__ tfg_comp, const double2 *__restrict__ ce,
                                                       double *__restrict__ scratch, const uint8_t *__restrict__ pbch_scr,
@@ -793,43 +789,9 @@ __global__ __launch_bounds__(PB_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     }
     __syncthreads();
     PH(1);
-    // de-ratematch: average all observations of each coded bit (ref src/lte_lib.cpp:497-509); the sums wait in
-    // registers until every lane has read its LLRs, because the survivor words reuse that LDS
-    double dsum[2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int bit = tid + 64 * q;
-      double s = 0; int cnt = 0;
-      if (bit < 120) {
-        const int16_t *lst = derm_inv + ((m_bit == 1920) ? 0 : 120 * 16) + bit * 16;   // ascending bit positions
-        for (int k = 0; k < 16; ++k) { const int t = lst[k]; if (t < 0) break; s += e_est[t]; ++cnt; }
-        if (cnt > 1) s = s / cnt;
-      }
-      dsum[q] = s;
-    }
-    __syncthreads();
-    d_est[tid / 40][tid % 40] = dsum[0];
-    if (tid + 64 < 120) d_est[(tid + 64) / 40][(tid + 64) % 40] = dsum[1];
-    __syncthreads();
-    PH(2);
-    // 64 tail-biting trellises, lane = start state; the best end metric wins, the lowest start state among equals
-    const double fin = pbch_trellis_pass(d_est, tid, surv + tid);
-    double best = (fin < INFINITY) ? fin : INFINITY;     // NaN / unreachable never win (strict < against +inf in the reference)
-    int best_ss = tid;
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-      const double ov = __shfl_xor(best, off);
-      const int oi = __shfl_xor(best_ss, off);
-      if (ov < best || (ov == best && oi < best_ss)) { best = ov; best_ss = oi; }
-    }
-    __syncthreads();
-    PH(3);
     int ok = 0;
     unsigned long long bits40 = 0ull;
-    if (best < INFINITY) {
-      bits40 = vit_traceback(surv + best_ss, 64, best_ss);
-      ok = pbch_crc_ok(bits40, n_ports);
-    }
+    pbch_decode_wave(surv, d_est, derm_inv, m_bit, n_ports, tid, ok, bits40);
     if (tid == 0) {
       const unsigned bits24 = (unsigned)(bits40 & 0xffffffull);
       sc[CS_CAND + cand * 4 + 0] = (double)ok;
@@ -884,10 +846,8 @@ int lcs_launch_scatter_back(lcs_ctx *c) {
 int lcs_launch_tfg(lcs_ctx *c, uint32_t n_cap, bool with_rs) {
   hipLaunchKernelGGL(k_cell_prep, dim3(c->grid_items), dim3(128), 0, c->stream, c->cells_out, c->work_items, c->n_work, c->params,
                      c->d_pn_jump, c->tfg_ts, c->cell_scratch, with_rs ? 3 : 1);
-#ifndef LCS_EXP_SKIP_TFG
   hipLaunchKernelGGL(k_tfg, dim3(LCS_TFG_GRID), dim3(TFG_THREADS), 0, c->stream, c->cells_out, c->work_items, c->n_work, c->params,
                      lcs_cap_src(c, n_cap), n_cap, c->tfg_ts, c->cell_scratch, c->tfg, c->needed_rows_only ? 1 : 0);
-#endif
   HIPCHK(c, hipGetLastError());
   return LCS_OK;
 }
@@ -899,14 +859,10 @@ int lcs_launch_rs_build(lcs_ctx *c) {
 }
 int lcs_launch_tfoec(lcs_ctx *c, int n_items) {
   (void)n_items;
-#ifndef LCS_EXP_SKIP_TFOEC
   hipLaunchKernelGGL(k_tfoec_est, dim3(c->grid_items, TF_PARTS), dim3(TF_THREADS), 0, c->stream, c->cells_out, c->work_items, c->n_work,
                      c->params, c->tfg, c->tfg_ts, c->cell_scratch, c->tfg_ts_comp);
-#endif
-#ifndef LCS_EXP_SKIP_TFOEC
   hipLaunchKernelGGL(k_tfoec_apply, dim3(LCS_TFA_GRID), dim3(TFA_THREADS), 0, c->stream, c->n_work, c->tfg, c->tfg_ts, c->cell_scratch,
                      c->cells_out, c->tfg_comp, c->needed_rows_only ? 1 : 0);
-#endif
   HIPCHK(c, hipGetLastError());
   return LCS_OK;
 }
@@ -919,14 +875,10 @@ int lcs_launch_chan_est(lcs_ctx *c) {
 void lcs_chan_est_np_layout(int *first, int *per_port, int *n_rs_first) { *first = CS_NPP; *per_port = 8; *n_rs_first = CS_NRS; }
 int lcs_launch_mib(lcs_ctx *c, int n_items) {
   (void)n_items;
-#ifndef LCS_EXP_SKIP_CHANEST
   hipLaunchKernelGGL(k_chan_est, dim3(c->grid_items, 4, CE_NCHUNK), dim3(CE_THREADS), 0, c->stream, c->cells_out, c->n_work,
                      c->tfg_comp, c->cell_scratch, c->ce, c->needed_rows_only ? 1 : 0);
-#endif
-#ifndef LCS_EXP_SKIP_PBCH
   hipLaunchKernelGGL(k_pbch, dim3(c->grid_items, 12), dim3(PB_THREADS), 0, c->stream, c->cells_out, c->n_work, c->tfg_comp,
                      c->ce, c->cell_scratch, c->d_pbch_scr, c->d_derm_inv);
-#endif
   hipLaunchKernelGGL(k_mib_select, dim3((LCS_MAX_WORK + 63) / 64), dim3(64), 0, c->stream, c->cells_out, c->n_work,
                      c->cell_scratch);
   HIPCHK(c, hipGetLastError());

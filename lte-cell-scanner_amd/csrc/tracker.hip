@@ -275,18 +275,15 @@ __global__ __launch_bounds__(TRK_CE_THREADS) void k_trk_ce(const lcs_track_cell 
 }
 
 // One MIB attempt per (frame offset, cell): pbch_extract_rt (:494-529) + the decoder of do_mib_decode (:555-705).
-#define TRK_PB_THREADS 256
-#define TRK_PB_WAVES (TRK_PB_THREADS / 64)
-__global__ __launch_bounds__(TRK_PB_THREADS) void k_trk_mib(const lcs_track_cell *__restrict__ cells, int n_sym, int n_off,
+#define TRK_PB_THREADS 64       // one wave: LLRs through LDS, then the 64 trellises one per lane (lte_device.h)
+__global__ __launch_bounds__(TRK_PB_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_trk_mib(const lcs_track_cell *__restrict__ cells, int n_sym, int n_off,
                                                            const double2 *__restrict__ syms, const double2 *__restrict__ ce,
                                                            const double *__restrict__ ce_pw, const int *__restrict__ ce_upto,
                                                            const uint8_t *__restrict__ pbch_scr, const int16_t *__restrict__ derm_inv,
                                                            int *__restrict__ mib_ok, unsigned long long *__restrict__ mib_bits) {
-  __shared__ double e_est[1920];
+  __shared__ unsigned long long surv[40 * 64];      // survivor words [step][trellis]; holds the LLRs until they are de-ratematched
   __shared__ double d_est[3][40];
-  __shared__ unsigned long long best_surv[TRK_PB_WAVES][40];
-  __shared__ double w_best[TRK_PB_WAVES];
-  __shared__ int w_best_ss[TRK_PB_WAVES];
+  double *e_est = reinterpret_cast<double *>(surv);
   const int off = blockIdx.x, cell = blockIdx.y, tid = threadIdx.x;
   const lcs_track_cell c = cells[cell];
   const int n_symb = trk_n_symb(c), per_frame = 20 * n_symb, id = c.n_id_2 + 3 * c.n_id_1;
@@ -352,7 +349,7 @@ __global__ __launch_bounds__(TRK_PB_THREADS) void k_trk_mib(const lcs_track_cell
   __syncthreads();
   int ok = 0;
   unsigned long long bits40 = 0;
-  pbch_decode_tail<TRK_PB_WAVES>(e_est, d_est, best_surv, w_best, w_best_ss, derm_inv, m_bit, c.n_ports, tid, ok, bits40);
+  pbch_decode_wave(surv, d_est, derm_inv, m_bit, c.n_ports, tid, ok, bits40);
   if (tid == 0) {
     const int bw[8] = {6, 15, 25, 50, 75, 100, 0, 0};
     const int b0 = (int)(bits40 & 1), b1 = (int)((bits40 >> 1) & 1), b2 = (int)((bits40 >> 2) & 1);
