@@ -86,7 +86,9 @@ const char *lcs_version(void);
 void lcs_cell_init(lcs_cell *c);                      /* src/common.cpp:36-56 */
 /* Memory-footprint limit: the per-cell stages (time-frequency grid, channel estimate, PBCH) hold at most n
  * detected cells at a time (default and maximum 512, ~6 MB each); a batch with more cells is processed in
- * rounds.  Results do not depend on it. */
+ * rounds: lcs_batch_enqueue launches the rounds a typical batch needs (one detected cell per buffer on average),
+ * lcs_batch_collect launches the rest if the device-side count says the batch had more.  Results do not depend
+ * on it and no batch is truncated. */
 int lcs_set_max_cells_in_flight(lcs_ctx *ctx, int n);
 
 /* ---- stage entry points (host buffers in / out) ------------------------------------ */

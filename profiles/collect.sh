@@ -13,11 +13,6 @@ mkdir -p "$OUT"
 (cd "$REPO" && timeout 300 python -m pytest tests -m gpu -x -q 2>&1 | tail -6) > "$OUT/pytest_gpu.log"
 cd /tmp; export TMPDIR=/tmp
 B="python $REPO/bench.py"
-timeout 300 $B > "$OUT/bench_full_n1.json" 2> "$OUT/bench_full_n1.err"
-timeout 120 $B --stage pss --no-cpu-baseline > "$OUT/bench_pss_n1.json" 2> "$OUT/bench_pss_n1.err"
-timeout 120 $B --stage stream --steps 100 --warmup 10 > "$OUT/bench_stream_n1.json" 2> "$OUT/bench_stream_n1.err"
-timeout 120 $B --stage track > "$OUT/bench_track_n1.json" 2> "$OUT/bench_track_n1.err"
-timeout 120 $B --input c64 --no-cpu-baseline > "$OUT/bench_full_n1_c64_fp32_kernel.json" 2> "$OUT/bench_c64.err"
 SHORT="--steps 2 --warmup 1 --batches-per-step 8 --no-cpu-baseline"
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_full_p1" -- $B $SHORT --pipeline 1 > "$OUT/stats_full_p1.log" 2>&1
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_full_default" -- $B $SHORT > "$OUT/stats_full_default.log" 2>&1
@@ -27,4 +22,11 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFL
   i=$((i+1))
   timeout 200 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d "$OUT/pmc_$i" -- $B --steps 1 --warmup 0 --batches-per-step 4 --pipeline 1 --no-cpu-baseline > "$OUT/pmc_$i.log" 2>&1
 done
+# the bench lines last: bench.py reports roofline.traffic only from a PMC summary taken from the running kernel sources
+(cd "$REPO" && python profiles/summarize.py "$TAG" > /dev/null 2>&1)
+timeout 300 $B > "$OUT/bench_full_n1.json" 2> "$OUT/bench_full_n1.err"
+timeout 120 $B --stage pss --no-cpu-baseline > "$OUT/bench_pss_n1.json" 2> "$OUT/bench_pss_n1.err"
+timeout 120 $B --stage stream --steps 100 --warmup 10 > "$OUT/bench_stream_n1.json" 2> "$OUT/bench_stream_n1.err"
+timeout 120 $B --stage track > "$OUT/bench_track_n1.json" 2> "$OUT/bench_track_n1.err"
+timeout 120 $B --input c64 --no-cpu-baseline > "$OUT/bench_full_n1_c64_fp32_kernel.json" 2> "$OUT/bench_c64.err"
 echo collected > "$OUT/done"

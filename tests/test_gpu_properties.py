@@ -101,8 +101,9 @@ def test_u8_and_complex_float_sources_agree(S, pkg, synth_buf):
 
 def test_per_cell_rounds_and_overflow(S, pkg, synth_buf):
     """The per-cell stages hold lcs_set_max_cells_in_flight cells per round.  With the round size forced down to 3
-    cells, a 19-buffer batch (38 cells past SSS) is decoded in 13 non-empty rounds (plus empty ones)
-    and must return exactly what one big round returns."""
+    cells, a 19-buffer batch (38 cells past SSS) is decoded in 13 rounds -- 7 launched by the enqueue (one cell per
+    buffer on average), 6 more by the collect once the device-side count is known -- and must return exactly what
+    one big round returns."""
     import torch
     f = f_search_set_for(FC, 100)
     g = golden("capbuf_0000")["iq_u8"]
