@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """bench.py -- capture-buffers/s of the searcher hot path on MI355X (driver contract).
 
-A "step" is one pass of the chain over --batches-per-step (32) batches of --batch (64) synthetic
+A "step" is one pass of the chain over --batches-per-step (40) batches of --batch (64) synthetic
 153600-sample, 1.92 Msps capture buffers that are ALREADY RESIDENT IN HBM when the timed region
-starts (2048 buffers per step: the default 20 steps time ~1 s of GPU work).  N=1 workload =
+starts (2560 buffers per step: the default 20 steps time ~1.2 s of GPU work).  N=1 workload =
 BASELINE.json configs[2], the metric's "full CellSearch": PSS correlation over the full +-100 ppm
 grid at 739 MHz (n_f = 31), peak_search and every per-cell stage down to the decoded MIB
 (--stage pss stops after peak_search = configs[1]).  With --gpus N (launched
@@ -277,7 +277,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="capture buffers per enqueue (one correlation launch) per GPU")
-    ap.add_argument("--batches-per-step", type=int, default=32, help="enqueues per step: a step is batch x this many buffers per GPU")
+    ap.add_argument("--batches-per-step", type=int, default=40, help="enqueues per step: a step is batch x this many buffers per GPU")
     ap.add_argument("--distinct", type=int, default=4, help="distinct resident batches the enqueues cycle through")
     ap.add_argument("--ppm", type=float, default=100.0)
     ap.add_argument("--stage", choices=["pss", "full", "stream", "track"], default="full",
