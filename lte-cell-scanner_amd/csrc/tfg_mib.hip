@@ -507,7 +507,9 @@ __device__ __forceinline__ void ext_vertex(const cd2 *row, int s, int i, int &x,
   } else { v = row[j]; x = s + 6 * j; }
 }
 
-#define CE_THREADS 256
+// one wave per workgroup: the long pole is the per-row triangle walk (a handful of active lanes per chunk), the
+// parallel phases are small -- four-wave workgroups only held three idle waves' registers (A/B: -0.4 % step time)
+#define CE_THREADS 64
 // RS row list of one port (ref :1383-1392) in closed form: ports 0/1 carry RS in symbols 0 and
 // n_symb-3 of every slot (the sorted union alternates between the two), ports 2/3 in symbol 1.
 __device__ __forceinline__ int ce_rs_row(int port, int n_symb, int t) {
@@ -594,11 +596,11 @@ __global__ __launch_bounds__(CE_THREADS) void k_chan_est(const lcs_cell *__restr
     if (tid == 0) { sc[CS_NPP + port * 8 + chunk] = tot.re; if (chunk == 0) sc[CS_NRS + port] = (double)n_rs; }
     // piecewise-planar interpolation between consecutive RS rows (ref :1237-1351): one thread
     // walks the triangle strip of one row pair exactly as the reference does
-    if (chunk == 0 && tid < NSC) {   // first RS row: plain 1-D interpolation (ref :1250-1252)
+    if (chunk == 0) for (int xs = tid; xs < NSC; xs += CE_THREADS) {   // first RS row: plain 1-D interpolation (ref :1250-1252)
       // interp1 (ref dsp.h:151-185: bisection with round_i midpoint, linear, extrapolating) over the
       // edge-extended row, vertices fetched through ext_vertex instead of materialised arrays
       const int n = ext_len(sh0);
-      const double x = (double)tid;
+      const double x = (double)xs;
       unsigned l = 0, r = (unsigned)n - 1;
       int xm; cd2 vm;
       while (r - l > 1) {
@@ -610,7 +612,7 @@ __global__ __launch_bounds__(CE_THREADS) void k_chan_est(const lcs_cell *__restr
       ext_vertex(ce_filt, sh0, (int)l, xl, vl);
       ext_vertex(ce_filt, sh0, (int)r, xr, vr);
       const cd2 d = csub(vr, vl);
-      st(&out[(size_t)rs_set(0) * NSC + tid], cadd(vl, cdivr(cscale(d, (x - (double)xl)), ((double)xr - (double)xl))));
+      st(&out[(size_t)rs_set(0) * NSC + xs], cadd(vl, cdivr(cscale(d, (x - (double)xl)), ((double)xr - (double)xl))));
     }
     PH(23);
     // One thread per OUTPUT ROW between the chunk's first and last RS row: it replays the triangle
