@@ -371,7 +371,7 @@ int lcs_peak_search(lcs_ctx *c, const double *pow_, const int32_t *frq, const do
 // ------------------------------------------------------------------- batched chain
 static int percell_round(lcs_ctx *c, int n_buf, uint32_t n_cap, int r) {
   int rc;
-  if ((rc = lcs_launch_gather_work(c, n_buf, r * c->max_work))) return rc;
+  if ((rc = lcs_launch_gather_work(c, n_buf, r * c->round_cells, c->round_cells))) return rc;
   if ((rc = lcs_launch_tfg(c, n_cap, true))) return rc;
   if ((rc = lcs_launch_tfoec(c, 0))) return rc;
   if ((rc = lcs_launch_mib(c, 0))) return rc;
@@ -412,8 +412,9 @@ int lcs_batch_enqueue(lcs_ctx *c, const void *d_capbufs, int fmt, int n_buf, uin
     // buffer on average (a band scan finds far fewer); lcs_batch_collect launches further rounds if the device-side
     // count says the batch had more, so no batch overflows and sparse batches pay for no empty rounds.
     c->needed_rows_only = true;
-    c->grid_items = std::min(c->max_work, std::max(64, n_buf / 2));
-    const int rounds = (n_buf + c->max_work - 1) / c->max_work;
+    c->round_cells = c->max_work;          // fixed for this batch: lcs_set_max_cells_in_flight applies from the next one
+    c->grid_items = std::min(c->round_cells, std::max(64, n_buf / 2));
+    const int rounds = (n_buf + c->round_cells - 1) / c->round_cells;
     for (int r = 0; r < rounds; ++r)
       if ((rc = percell_round(c, n_buf, n_cap, r))) return rc;
     c->last_cell_rounds = rounds;
@@ -436,9 +437,9 @@ int lcs_batch_collect(lcs_ctx *c, lcs_cell *cells, int max_cells_per_buf, int *n
   if (full) HIPCHK(c, hipMemcpyAsync(work_cnt, c->n_work, sizeof(work_cnt), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   int rc = LCS_OK;
-  if (full && work_cnt[1] > c->last_cell_rounds * c->max_work) {
+  if (full && work_cnt[1] > c->last_cell_rounds * c->round_cells) {
     // more cells passed SSS than the enqueued rounds decode: run the remaining rounds now (rare: dense batches)
-    const int rounds = (work_cnt[1] + c->max_work - 1) / c->max_work;
+    const int rounds = (work_cnt[1] + c->round_cells - 1) / c->round_cells;
     for (int r = c->last_cell_rounds; r < rounds; ++r)
       if ((rc = percell_round(c, nb, c->last_geo.n_cap, r))) return rc;
     c->last_cell_rounds = rounds;

@@ -214,7 +214,8 @@ struct lcs_ctx {
   int last_stage_mask = 0;
   bool needed_rows_only = false;     // fused chains: compute only the grid rows later stages read (tfg_mib.hip)
   int max_work = LCS_MAX_WORK;       // cells per per-cell round (lcs_set_max_cells_in_flight)
-  int last_cell_rounds = 0;          // per-cell rounds launched for the last batch (max_work cells each)
+  int last_cell_rounds = 0;          // per-cell rounds launched for the last batch (round_cells cells each)
+  int round_cells = LCS_MAX_WORK;    // max_work as it was when the last batch was enqueued
   int grid_items = 64;               // workgroups per work-list axis of the per-cell kernels (they loop over the list)
   XcGeom last_geo{};
   hipEvent_t ev_xc0 = nullptr, ev_xc1 = nullptr;
@@ -261,7 +262,8 @@ int lcs_launch_sss_foe(lcs_ctx *c, int n_buf, uint32_t n_cap, double thresh2_n_s
 int lcs_launch_sss_only(lcs_ctx *c, uint32_t n_cap, double thresh2_n_sigma, double *dbg);
 int lcs_launch_foe_only(lcs_ctx *c, uint32_t n_cap);
 // tfg_mib.hip
-int lcs_launch_gather_work(lcs_ctx *c, int n_buf, int skip /* cells already handled by earlier rounds */);
+int lcs_launch_gather_work(lcs_ctx *c, int n_buf, int skip /* cells already handled by earlier rounds */,
+                           int limit = 0 /* cells of this round; 0: max_work */);
 int lcs_launch_scatter_back(lcs_ctx *c);
 int lcs_launch_rs_build(lcs_ctx *c);
 int lcs_launch_tfg(lcs_ctx *c, uint32_t n_cap, bool with_rs /* also build RS_DL (the fused chain) */);

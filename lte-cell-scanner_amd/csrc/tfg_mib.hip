@@ -832,8 +832,8 @@ __global__ void k_mib_select(lcs_cell *__restrict__ cells, const int *__restrict
 
 // ------------------------------------------------------------------------------ launch
 // workgroups loop over the work list; c->grid_items of them per list axis (64: a typical 64-buffer batch in one round)
-int lcs_launch_gather_work(lcs_ctx *c, int n_buf, int skip) {
-  hipLaunchKernelGGL(k_gather_work, dim3(1), dim3(64), 0, c->stream, c->peaks, c->npeaks, n_buf, skip, c->max_work,
+int lcs_launch_gather_work(lcs_ctx *c, int n_buf, int skip, int limit) {
+  hipLaunchKernelGGL(k_gather_work, dim3(1), dim3(64), 0, c->stream, c->peaks, c->npeaks, n_buf, skip, limit > 0 ? limit : c->max_work,
                      c->st_open ? c->st_dtracked : nullptr, c->st_dntracked, c->work_items, c->n_work,
                      c->cells_out);
   HIPCHK(c, hipGetLastError());
