@@ -262,6 +262,20 @@ int lcs_track_block(lcs_ctx *ctx, lcs_track_cell *cells, int n_cells, int n_sym,
                     double fc_programmed, double fs_programmed, double *syms, double *ce, double *ce_pw, int32_t *ce_upto,
                     double *meas, int max_rs, int32_t *n_meas, int32_t *mib_ok, uint64_t *mib_bits, int max_off, float *gpu_ms);
 
+/* Display statistics of the tracker thread for the block the LAST lcs_track_block call on this context processed (same
+ * n_cells, n_sym; its symbols and raw reference-signal estimates are read from the workspace, nothing is recomputed):
+ *   ac_fd   [n_cells][4][max_rs][12] complex: do_ac_fd (src/tracker_thread.cpp:318-341): autocorrelation over the 12 raw
+ *           estimates of reference symbol row + 1 of the port (row = row of `meas`), divided by its signal power -- the
+ *           value the reference then folds into tracked_cell.ac_fd with weight 1 / ac_fd_np (:335-338)
+ *   ac_td   [n_cells][4][max_rs][72] complex: do_ac_td (:343-371): this_xc of the row against the 71 reference symbols
+ *           before it, from row 71 on (NaN before: the reference's 72-deep history is not full)
+ *   sync    [n_cells][max_hf][4] = (tp, sp, np, np_blank), sync_ce [n_cells][max_hf][72] complex: do_pss_sss_sigpower_ce
+ *           (:754-820) of the k-th PSS/SSS pair of the block; n_hf [n_cells] pairs found
+ * The running averages (ac_fd, ac_td, sync_*_av) are scalar recurrences and stay with the caller (tracker.py).
+ * NULL = not wanted. */
+int lcs_track_stats(lcs_ctx *ctx, int n_cells, int n_sym, double *ac_fd, double *ac_td, int max_rs, double *sync, double *sync_ce,
+                    int max_hf, int32_t *n_hf);
+
 /* Stream the context launches on (hipStream_t as void*), for external event timing. */
 void *lcs_stream(lcs_ctx *ctx);
 int lcs_sync(lcs_ctx *ctx);

@@ -295,6 +295,20 @@ class Searcher:
         out["gpu_ms"] = ms.value
         return out
 
+    def track_stats(self, n_cells, n_sym, want_ac_td=True):
+        """Display statistics (do_ac_fd, do_ac_td, do_pss_sss_sigpower_ce) of the block the last track_block call
+        processed; see lcs_track_stats in include/lcs.h.  -> dict(ac_fd [c][4][max_rs][12], ac_td [c][4][max_rs][72],
+        sync [c][max_hf][4] = (tp, sp, np, np_blank), sync_ce [c][max_hf][72], n_hf [c])."""
+        max_rs, max_hf = n_sym // 3 + 4, n_sym // 60 + 2
+        out = dict(ac_fd=np.full((n_cells, 4, max_rs, 12), np.nan + 0j, np.complex128),
+                   ac_td=np.full((n_cells, 4, max_rs, 72), np.nan + 0j, np.complex128) if want_ac_td else None,
+                   sync=np.full((n_cells, max_hf, 4), np.nan), sync_ce=np.full((n_cells, max_hf, 72), np.nan + 0j, np.complex128),
+                   n_hf=np.zeros(n_cells, np.int32))
+        rc = self._lib.lcs_track_stats(self._h, n_cells, n_sym, _dp(out["ac_fd"]), _dp(out["ac_td"]), max_rs, _dp(out["sync"]),
+                                       _dp(out["sync_ce"]), max_hf, _ip(out["n_hf"]))
+        self._chk(rc, "lcs_track_stats")
+        return out
+
     # ---- streaming mode (LTE-Tracker's searcher thread, src/searcher_thread.cpp:83-246) ----
     def stream_open(self, fmt: int, n_cap: int, fc_requested: float, fc_programmed: float, fs_programmed: float):
         """Capture the one-buffer, single-hypothesis chain as a hipGraph (see include/lcs.h)."""

@@ -265,7 +265,8 @@ void lcs_destroy(lcs_ctx *c) {
                   c->work_items, c->n_work, c->tfg, c->tfg_comp, c->ce, c->tfg_ts, c->tfg_ts_comp, c->cell_scratch,
                   c->cells_out, c->d_pss_td, c->d_pss_fd, c->d_sss_fd, c->d_pbch_scr, c->d_derm_inv, c->d_dbg, c->pk_items, c->n_pk,
                   c->sss_ws, c->d_pn_jump, c->cap8, c->cap8s, c->bt8, c->tq, c->tsc, c->h2d, c->trk_td, c->trk_syms, c->trk_raw, c->trk_ce,
-                  c->trk_meta, c->trk_rs, c->trk_fmeta, c->trk_pw, c->trk_idx, c->trk_small, c->trk_cells};
+                  c->trk_meta, c->trk_rs, c->trk_fmeta, c->trk_pw, c->trk_idx, c->trk_small, c->trk_cells, c->trk_acfd, c->trk_actd,
+                  c->trk_syncce, c->trk_sync};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   if (c->h_pinned) (void)hipHostFree(c->h_pinned);
   if (c->ev_xc0) (void)hipEventDestroy(c->ev_xc0);

@@ -202,6 +202,9 @@ struct lcs_ctx {
   int *trk_idx = nullptr, *trk_small = nullptr;
   lcs_track_cell *trk_cells = nullptr;
   int trk_cells_cap = 0, trk_sym_cap = 0;
+  double2 *trk_acfd = nullptr, *trk_actd = nullptr, *trk_syncce = nullptr;   // lcs_track_stats outputs
+  double *trk_sync = nullptr;
+  int trk_stat_cells = 0, trk_stat_sym = 0;
   // host staging
   SlotParams h_params{};             // source of asynchronous parameter uploads of the single-buffer entry points
   void *h_pinned = nullptr;

@@ -361,6 +361,80 @@ __global__ __launch_bounds__(TRK_PB_THREADS) __attribute__((amdgpu_waves_per_eu(
   }
 }
 
+// ---- display statistics of the tracker thread (do_ac_fd :318-341, do_ac_td :343-371, do_pss_sss_sigpower_ce :754-820)
+// from what lcs_track_block left in the workspace: the raw reference-signal estimates, the per-symbol powers and the
+// frequency-domain symbols.  The running averages these values feed are scalar recurrences and stay with the caller.
+// One workgroup per (port, cell): row f = filtered reference symbol f + 1 of the port (rs_curr of the reference's loop).
+__global__ __launch_bounds__(256) void k_trk_acf(const lcs_track_cell *__restrict__ cells, const int *__restrict__ n_meas, int max_rs,
+                                                const double2 *__restrict__ raw, const double *__restrict__ meas,
+                                                double2 *__restrict__ ac_fd /*[c][4][max_rs][12]*/, double2 *__restrict__ ac_td /*[c][4][max_rs][72]*/) {
+  const int port = blockIdx.x, cell = blockIdx.y, tid = threadIdx.x;
+  const size_t cp = (size_t)cell * 4 + port;
+  if (port >= cells[cell].n_ports) return;
+  const int nf = n_meas[cp];
+  const double2 *raw_p = raw + cp * max_rs * 12;
+  const double *ms = meas + cp * max_rs * TRK_MEAS;
+  if (ac_fd)
+    for (int e = tid; e < nf * 12; e += 256) {
+      const int f = e / 12, d = e % 12;
+      const double2 *cur = raw_p + (size_t)(f + 1) * 12;
+      cd2 a = mk(0, 0);
+      for (int t = 0; t < 12 - d; ++t) a = cadd(a, cmul(cconj(ld(&cur[t])), ld(&cur[t + d])));
+      a = cdivr(a, (double)(12 - d));
+      st(&ac_fd[(cp * max_rs + f) * 12 + d], cdivr(a, ms[(size_t)f * TRK_MEAS + 4]));
+    }
+  if (ac_td)
+    for (int e = tid; e < nf * 72; e += 256) {
+      const int f = e / 72, t = e % 72;
+      cd2 o = mk(NAN, NAN);                                       // the 72-deep history is not full before row 71
+      if (f >= 71) {
+        const double2 *cur = raw_p + (size_t)(f + 1) * 12, *old = raw_p + (size_t)(f + 1 - t) * 12;
+        cd2 a = mk(0, 0);
+        for (int k = 0; k < 12; ++k) a = cadd(a, cmul(cconj(ld(&cur[k])), ld(&old[k])));
+        o = cdivr(cdivr(a, 12.0), ms[(size_t)f * TRK_MEAS + 4]);
+      }
+      st(&ac_td[(cp * max_rs + f) * 72 + t], o);
+    }
+}
+// One thread per (cell, PSS/SSS pair): the sums run in the reference's order (62-element vectors: nothing to spread).
+__global__ __launch_bounds__(64) void k_trk_sync(const lcs_track_cell *__restrict__ cells, int n_cells, int n_sym, int max_hf,
+                                                const double2 *__restrict__ syms, const double2 *__restrict__ pss_fd,
+                                                const int8_t *__restrict__ sss_fd, double *__restrict__ sync /*[c][max_hf][4]*/,
+                                                double2 *__restrict__ sync_ce /*[c][max_hf][72]*/) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_cells * max_hf) return;
+  const int cell = e / max_hf, k = e % max_hf;
+  const lcs_track_cell c = cells[cell];
+  const int n_symb = trk_n_symb(c), slot = (k & 1) * 10;
+  const int i_sss = (k >> 1) * 20 * n_symb + slot * n_symb + n_symb - 2;
+  if (i_sss + 1 >= n_sym) return;
+  const double2 *sss = syms + ((size_t)cell * n_sym + i_sss) * 72, *pss = sss + 72;
+  auto pw5 = [](const double2 *v) { double r = 0; for (int t = 0; t < 5; ++t) r += pow(v[t].x, 2) + pow(v[t].y, 2); return r / 5; };
+  const double np_blank = (pw5(sss) + pw5(sss + 67) + pw5(pss) + pw5(pss + 67)) / 4;
+  const int8_t *sf = sss_fd + (((size_t)c.n_id_1 * 3 + c.n_id_2) * 2 + (slot ? 1 : 0)) * 62;
+  const double2 *pf = pss_fd + c.n_id_2 * 62;
+  auto ce_sss = [&](int t) { return cmul(ld(&sss[5 + t]), mk((double)sf[t], 0)); };
+  auto ce_pss = [&](int t) { return cmul(ld(&pss[5 + t]), cconj(ld(&pf[t]))); };
+  double d1 = 0, d2 = 0, tp = 0;
+  double2 *oc = sync_ce ? sync_ce + ((size_t)cell * max_hf + k) * 72 : nullptr;
+  for (int t = 0; t < 62; ++t) {
+    const int lt = (t - 6 > 0) ? t - 6 : 0, rt = (t + 6 < 61) ? t + 6 : 61;
+    cd2 a = mk(0, 0), b = mk(0, 0);
+    for (int q = lt; q <= rt; ++q) a = cadd(a, ce_sss(q));
+    for (int q = lt; q <= rt; ++q) b = cadd(b, ce_pss(q));
+    const cd2 sm = cdivr(cadd(a, b), (double)(2 * (rt - lt + 1)));
+    const cd2 e1 = csub(sm, ce_sss(t)), e2 = csub(sm, ce_pss(t));
+    d1 += pow(e1.re, 2) + pow(e1.im, 2);
+    d2 += pow(e2.re, 2) + pow(e2.im, 2);
+    tp += pow(sm.re, 2) + pow(sm.im, 2);
+    if (oc) st(&oc[5 + t], sm);
+  }
+  if (oc) for (int t = 0; t < 5; ++t) { st(&oc[t], mk(0, 0)); st(&oc[67 + t], mk(0, 0)); }
+  const double np = ((d1 / 62) * 13 / 12 + (d2 / 62) * 13 / 12) / 2;
+  tp = tp / 62;
+  if (sync) { double *o = sync + ((size_t)cell * max_hf + k) * 4; o[0] = tp; o[1] = tp - np / 13; o[2] = np; o[3] = np_blank; }
+}
+
 // ------------------------------------------------------------------------------------------------------------ host
 namespace {
 template <typename T>
@@ -452,5 +526,65 @@ extern "C" int lcs_track_block(lcs_ctx *c, lcs_track_cell *cells, int n_cells, i
       if (mib_bits) mib_bits[(size_t)i * max_off + o] = (o < n_off) ? h_bits[(size_t)i * n_off + o] : 0ull;
     }
   if (rc) c->err = "more reference symbols per port than max_rs rows";
+  return rc;
+}
+
+// Statistics of the block the last lcs_track_block call on this context processed (its workspace is read, not recomputed).
+extern "C" int lcs_track_stats(lcs_ctx *c, int n_cells, int n_sym, double *ac_fd, double *ac_td, int max_rs, double *sync, double *sync_ce,
+                               int max_hf, int32_t *n_hf) {
+  if (!c) return LCS_ERR_BAD_ARG;
+  if (n_cells < 1 || n_cells != c->trk_cells_cap || n_sym != c->trk_sym_cap || max_rs < 0 || max_hf < 0) {
+    c->err = "lcs_track_stats describes the block of the last lcs_track_block call on this context (same n_cells, n_sym)";
+    return LCS_ERR_BAD_ARG;
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  const int rs_cap = n_sym / 3 + 4;
+  const size_t C4 = (size_t)n_cells * 4;
+  const int hf_cap = n_sym / 60 + 2;                       // PSS/SSS pairs of the block: two per frame of >= 120 symbols
+  int rc;
+  if (c->trk_stat_cells != n_cells || c->trk_stat_sym != n_sym) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if ((rc = trk_alloc(c, &c->trk_acfd, C4 * rs_cap * 12)) || (rc = trk_alloc(c, &c->trk_actd, C4 * rs_cap * 72)) ||
+        (rc = trk_alloc(c, &c->trk_sync, (size_t)n_cells * hf_cap * 4)) || (rc = trk_alloc(c, &c->trk_syncce, (size_t)n_cells * hf_cap * 72)))
+      return rc;
+    c->trk_stat_cells = n_cells; c->trk_stat_sym = n_sym;
+  }
+  const double2 *d_raw = c->trk_raw;
+  const double *d_meas = c->trk_fmeta + C4 * rs_cap * 4;
+  const int *d_nmeas = c->trk_small;
+  std::vector<int> h_nmeas(C4);
+  std::vector<lcs_track_cell> h_cells(n_cells);
+  if (ac_fd || ac_td)
+    hipLaunchKernelGGL(k_trk_acf, dim3(4, n_cells), dim3(256), 0, c->stream, c->trk_cells, d_nmeas, rs_cap, d_raw, d_meas,
+                       ac_fd ? c->trk_acfd : nullptr, ac_td ? c->trk_actd : nullptr);
+  hipLaunchKernelGGL(k_trk_sync, dim3((n_cells * hf_cap + 63) / 64), dim3(64), 0, c->stream, c->trk_cells, n_cells, n_sym, hf_cap, c->trk_syms,
+                     c->d_pss_fd, c->d_sss_fd, c->trk_sync, c->trk_syncce);
+  HIPCHK(c, hipGetLastError());
+  std::vector<double> h_fd, h_td, h_sync((size_t)n_cells * hf_cap * 4), h_ce;
+  if (ac_fd) { h_fd.resize(C4 * rs_cap * 24); HIPCHK(c, hipMemcpyAsync(h_fd.data(), c->trk_acfd, sizeof(double) * h_fd.size(), hipMemcpyDeviceToHost, c->stream)); }
+  if (ac_td) { h_td.resize(C4 * rs_cap * 144); HIPCHK(c, hipMemcpyAsync(h_td.data(), c->trk_actd, sizeof(double) * h_td.size(), hipMemcpyDeviceToHost, c->stream)); }
+  if (sync_ce) { h_ce.resize((size_t)n_cells * hf_cap * 144); HIPCHK(c, hipMemcpyAsync(h_ce.data(), c->trk_syncce, sizeof(double) * h_ce.size(), hipMemcpyDeviceToHost, c->stream)); }
+  HIPCHK(c, hipMemcpyAsync(h_sync.data(), c->trk_sync, sizeof(double) * h_sync.size(), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(h_nmeas.data(), d_nmeas, sizeof(int) * C4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(h_cells.data(), c->trk_cells, sizeof(lcs_track_cell) * n_cells, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  rc = LCS_OK;
+  for (size_t q = 0; q < C4; ++q) {
+    const int rows = std::min(h_nmeas[q], max_rs);
+    if (h_nmeas[q] > max_rs) rc = LCS_ERR_OVERFLOW;
+    if (ac_fd) std::memcpy(ac_fd + q * max_rs * 24, &h_fd[q * rs_cap * 24], sizeof(double) * 24 * rows);
+    if (ac_td) std::memcpy(ac_td + q * max_rs * 144, &h_td[q * rs_cap * 144], sizeof(double) * 144 * rows);
+  }
+  for (int i = 0; i < n_cells; ++i) {
+    const int n_symb = (h_cells[i].cp_type == LCS_CP_NORMAL) ? 7 : 6;
+    int hf = 0;
+    while (((hf >> 1) * 20 + (hf & 1) * 10) * n_symb + n_symb - 1 < n_sym) ++hf;
+    if (n_hf) n_hf[i] = std::min(hf, max_hf);
+    if (hf > max_hf) rc = LCS_ERR_OVERFLOW;
+    const int rows = std::min(hf, max_hf);
+    if (sync) std::memcpy(sync + (size_t)i * max_hf * 4, &h_sync[(size_t)i * hf_cap * 4], sizeof(double) * 4 * rows);
+    if (sync_ce) std::memcpy(sync_ce + (size_t)i * max_hf * 144, &h_ce[(size_t)i * hf_cap * 144], sizeof(double) * 144 * rows);
+  }
+  if (rc) c->err = "more rows than the output arrays hold";
   return rc;
 }

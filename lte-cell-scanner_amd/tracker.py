@@ -82,6 +82,37 @@ def fold_frame_timing(t0: float, meas: np.ndarray) -> float:
     return t
 
 
+def fold_ac_fd(ac0: np.ndarray, ac_fd_rows: np.ndarray, meas_rows: np.ndarray) -> np.ndarray:
+    """tracked_cell.ac_fd's update (src/tracker_thread.cpp:335-338) over the rows of one port of a block, in row order:
+    ac_fd_np = (np^2/sp^2 + 2 np/sp) / (12, 11, ..., 1); ac = (ac / 1e-5 + ac_fd / ac_fd_np) / (1 / 1e-5 + 1 / ac_fd_np).
+    ac_fd_rows [n][12] from lcs_track_stats, meas_rows [n][9] (columns 1 = np, 4 = sp)."""
+    ac = np.array(ac0, np.complex128)
+    div = np.arange(12.0, 0.0, -1.0)
+    for row, m in zip(ac_fd_rows, meas_rows):
+        w = 1.0 / ((m[1] * m[1] / (m[4] * m[4]) + 2 * m[1] / m[4]) / div)
+        ac = (ac * (1 / .00001) + row * w) / (1 / .00001 + w)
+    return ac
+
+
+def fold_ac_td(ac0: np.ndarray, ac_td_rows: np.ndarray) -> np.ndarray:
+    """tracked_cell.ac_td's update (src/tracker_thread.cpp:367-368) over the rows that have a full history (not NaN)."""
+    ac = np.array(ac0, np.complex128)
+    for row in ac_td_rows:
+        if np.isnan(row[0]):
+            continue
+        ac = (ac * (1 / .00001) + row * 1 / 1) / (1 / .00001 + 1)
+    return ac
+
+
+def fold_sync_power(av, sync_rows: np.ndarray):
+    """The sync_{tp,sp,np,np_blank}_av recurrences of do_pss_sss_sigpower_ce (src/tracker_thread.cpp:808-818): the first
+    PSS/SSS pair initialises the averages (av = None or NaN), every later one moves them by 0.001."""
+    av = None if av is None or np.isnan(np.asarray(av, np.float64)[1]) else np.array(av, np.float64)
+    for row in sync_rows:
+        av = np.array(row, np.float64) if av is None else 0.999 * av + .001 * row
+    return av
+
+
 def mib_lock_walk(ok_by_frame_offset, failures: float = 0.0, synchronized: bool = False, drop_threshold: float = 400.0):      # CELL_DROP_THRESHOLD, include/constants.h:35
     """do_mib_decode's fifo walk (src/tracker_thread.cpp:552-745) over a block in which every frame offset has been
     tried in parallel: an attempt is made whenever 16 PBCH symbols are queued; success or a synchronised failure

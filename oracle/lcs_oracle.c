@@ -1526,6 +1526,108 @@ int orc_trk_chan_est(const orc_cell *cell, const double *syms_re_im, int n_sym, 
   return 0;
 }
 
+/* ref: src/tracker_thread.cpp:318-341 do_ac_fd, :343-371 do_ac_td, :754-820 do_pss_sss_sigpower_ce -- the display
+ * statistics the tracker thread derives from the same per-symbol data: the frequency-domain autocorrelation of the
+ * raw reference-signal estimates of the current RS symbol (normalised by its signal power), the time-domain
+ * autocorrelation against the 71 RS symbols before it, and signal / noise power + a smoothed channel estimate from
+ * every PSS/SSS pair.  Here WITHOUT the running averages they feed (tracked_cell.ac_fd / ac_td / sync_*_av: scalar
+ * recurrences, kept by the caller like the other feedback loops).  `meas` / `n_meas` are orc_trk_chan_est's outputs
+ * of the same block (row f = filtered RS symbol f + 1 of the port; column 4 = rs_curr_sp).
+ *   ac_fd   [4][max_rs][12] complex: row f = do_ac_fd's ac_fd before the weighting (:324-334)
+ *   ac_td   [4][max_rs][72] complex: row f = do_ac_td's this_xc (:361-364), defined for f >= 71 (NaN before)
+ *   sync    [max_hf][4] = tp, sp, np, np_blank of the k-th PSS/SSS pair of the block; sync_ce [max_hf][72] complex */
+int orc_trk_stats(const orc_cell *cell, const double *syms_re_im, int n_sym, int slot0, int sym0, const double *meas, int max_rs,
+                  const int *n_meas, double *ac_fd, double *ac_td, double *sync, double *sync_ce, int max_hf, int *n_hf) {
+  const int n_symb_dl = cell_n_symb_dl(cell);
+  if (n_symb_dl < 0 || cell->n_ports < 1 || cell->n_ports > 4) return -1;
+  const cd *syms = (const cd *)syms_re_im;
+  rs_dl_t *R = (rs_dl_t *)malloc(sizeof(rs_dl_t));
+  rs_dl_build(cell_n_id_cell(cell), cell->cp_type, R);
+  cd (*raw)[12] = (cd (*)[12])malloc(sizeof(cd) * 12 * (n_sym + 1));
+  for (int port = 0; port < cell->n_ports; port++) {
+    int m = 0, slot = slot0, sym = sym0;
+    for (int i = 0; i < n_sym; i++) {                                 /* rs_curr.ce as in the main loop, :868-890 */
+      const double shift = rs_get_shift(R, slot, sym, port);
+      if (!isnan(shift)) {
+        const cd *rs = rs_get_rs(R, slot, sym);
+        for (int k = 0; k < 12; k++) raw[m][k] = cmul(syms[(size_t)i * 72 + round_i(shift) + 6 * k], cconj(rs[k]));
+        m++;
+      }
+      slot_sym_inc(n_symb_dl, &slot, &sym);
+    }
+    const int nf = (n_meas[port] < max_rs) ? n_meas[port] : max_rs;
+    for (int f = 0; f < nf; f++) {
+      const cd *cur = raw[f + 1];
+      const double sp = meas[((size_t)port * max_rs + f) * 9 + 4];
+      if (ac_fd) {
+        cd *o = (cd *)ac_fd + ((size_t)port * max_rs + f) * 12;
+        for (int d = 0; d < 12; d++) {                                /* :325-334 */
+          cd a = c_(0, 0);
+          for (int t = 0; t < 12 - d; t++) a = cadd(a, cmul(cconj(cur[t]), cur[t + d]));
+          a = cdivr(a, 12 - d);
+          o[d] = cdivr(a, sp);
+        }
+      }
+      if (ac_td) {
+        cd *o = (cd *)ac_td + ((size_t)port * max_rs + f) * 72;
+        for (int t = 0; t < 72; t++) {
+          if (f < 71) { o[t] = c_(NAN, NAN); continue; }              /* the 72-deep history is not full yet, :358 */
+          const cd *old = raw[f + 1 - t];
+          cd a = c_(0, 0);
+          for (int k = 0; k < 12; k++) a = cadd(a, cmul(cconj(cur[k]), old[k]));     /* elem_mult_sum(conj(h[71]), h[71-t]) */
+          o[t] = cdivr(cdivr(a, 12), sp);
+        }
+      }
+    }
+  }
+  /* do_pss_sss_sigpower_ce, :754-820 */
+  int hf = 0;
+  {
+    static cd pss_fd_tab[3][62]; static int ready = 0;
+#pragma omp critical(orc_trk_stats_tab)
+    if (!ready) { for (int t = 0; t < 3; t++) pss_fd_calc(t, pss_fd_tab[t]); ready = 1; }
+    const cd *sss_sym = NULL;
+    int slot = slot0, sym = sym0;
+    for (int i = 0; i < n_sym; i++) {
+      if ((slot == 0 || slot == 10) && sym == n_symb_dl - 2) sss_sym = syms + (size_t)i * 72;
+      else if ((slot == 0 || slot == 10) && sym == n_symb_dl - 1 && sss_sym) {
+        const cd *pss_sym = syms + (size_t)i * 72;
+        const double np_blank = (sigpower(sss_sym, 5) + sigpower(sss_sym + 67, 5) + sigpower(pss_sym, 5) + sigpower(pss_sym + 67, 5)) / 4;
+        int32_t sfd[62];
+        sss_fd_calc(cell->n_id_1, cell->n_id_2, (slot == 0) ? 0 : 10, sfd);
+        cd ce_sss[62], ce_pss[62], sm[62], d1[62], d2[62];
+        for (int t = 0; t < 62; t++) {
+          ce_sss[t] = cmul(sss_sym[5 + t], c_((double)sfd[t], 0));
+          ce_pss[t] = cmul(pss_sym[5 + t], cconj(pss_fd_tab[cell->n_id_2][t]));
+        }
+        for (int t = 0; t < 62; t++) {
+          const int lt = (t - 6 > 0) ? t - 6 : 0, rt = (t + 6 < 61) ? t + 6 : 61;
+          cd a = c_(0, 0), b = c_(0, 0);
+          for (int q = lt; q <= rt; q++) a = cadd(a, ce_sss[q]);
+          for (int q = lt; q <= rt; q++) b = cadd(b, ce_pss[q]);
+          sm[t] = cdivr(cadd(a, b), 2 * (rt - lt + 1));
+        }
+        for (int t = 0; t < 62; t++) { d1[t] = csub(sm[t], ce_sss[t]); d2[t] = csub(sm[t], ce_pss[t]); }
+        const double np = (sigpower(d1, 62) * 13 / 12 + sigpower(d2, 62) * 13 / 12) / 2;
+        const double tp = sigpower(sm, 62);
+        const double sp = tp - np / 13;
+        if (hf < max_hf) {
+          if (sync) { double *o = sync + (size_t)hf * 4; o[0] = tp; o[1] = sp; o[2] = np; o[3] = np_blank; }
+          if (sync_ce) {
+            cd *o = (cd *)sync_ce + (size_t)hf * 72;
+            for (int t = 0; t < 72; t++) o[t] = (t >= 5 && t < 67) ? sm[t - 5] : c_(0, 0);
+          }
+        }
+        hf++;
+      }
+      slot_sym_inc(n_symb_dl, &slot, &sym);
+    }
+  }
+  if (n_hf) *n_hf = hf;
+  free(raw); free(R);
+  return 0;
+}
+
 /* One MIB attempt of the tracker: pbch_extract_rt (ref src/tracker_thread.cpp:494-529) + the decode part of
  * do_mib_decode (:555-705) on 16 PBCH symbols (slot 1, symbols 0..3 of four consecutive frames).
  * syms16 [16][72]; ce16 [n_ports][16][72]; np16 [n_ports][16].  c_est: the 40 decoded bits; *crc_ok: CRC (with the

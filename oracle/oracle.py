@@ -322,6 +322,29 @@ def trk_chan_est(cell, syms, slot0, sym0, freq_off, frame_timing, fc_requested, 
     return out
 
 
+def trk_stats(cell, syms, slot0, sym0, meas, n_meas):
+    """do_ac_fd / do_ac_td / do_pss_sss_sigpower_ce without their running averages (see orc_trk_stats).
+    -> dict(ac_fd [4][max_rs][12], ac_td [4][max_rs][72], sync [max_hf][4], sync_ce [max_hf][72], n_hf)"""
+    syms = np.ascontiguousarray(syms, np.complex128)
+    n = syms.shape[0]
+    meas = np.ascontiguousarray(meas, np.float64)
+    max_rs, max_hf = meas.shape[1], n // 60 + 2
+    nm = np.ascontiguousarray(n_meas, np.int32)
+    out = dict(ac_fd=np.full((4, max_rs, 12), np.nan + 0j, np.complex128), ac_td=np.full((4, max_rs, 72), np.nan + 0j, np.complex128),
+               sync=np.full((max_hf, 4), np.nan), sync_ce=np.full((max_hf, 72), np.nan + 0j, np.complex128))
+    nh = C.c_int(0)
+    L = lib()
+    L.orc_trk_stats.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_int,
+                                C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int)]
+    rc = L.orc_trk_stats(C.byref(cell), _dp(syms), n, slot0, sym0, _dp(meas), max_rs, _ip(nm), _dp(out["ac_fd"]), _dp(out["ac_td"]),
+                         _dp(out["sync"]), _dp(out["sync_ce"]), max_hf, C.byref(nh))
+    if rc:
+        raise RuntimeError(f"orc_trk_stats rc={rc}")
+    out["n_hf"] = nh.value
+    return out
+
+
 def trk_mib(cell, syms16, ce16, np16):
     """-> (c_est [40] uint8, crc_ok, fields_ok)"""
     s = np.ascontiguousarray(syms16, np.complex128)

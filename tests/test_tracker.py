@@ -122,6 +122,64 @@ def test_gpu_track_block_matches_oracle(tracked):
         assert 3 in list(g["mib_ok"][i])
 
 
+def test_oracle_tracker_statistics_on_the_golden_cells(tracked):
+    """do_ac_fd / do_ac_td / do_pss_sss_sigpower_ce (src/tracker_thread.cpp:318-371, 754-820) on the golden capture: the
+    PSS/SSS signal-to-noise measurement agrees with the searcher's picture of the two cells (277 strong, 271 weaker),
+    the autocorrelations are Hermitian-consistent and normalised like the reference's."""
+    _, cells = tracked
+    pkg = load_pkg()
+    snr = []
+    for c, td, late, ftv, fov in cells:
+        r = _oracle_block(c, td, late, ftv, fov)
+        st = O.trk_stats(c, r["syms"], 0, 0, r["meas"], r["n_meas"])
+        assert st["n_hf"] == 14                                           # 7 frames: two PSS/SSS pairs each
+        sy = st["sync"][:14]
+        assert np.isfinite(sy).all() and (sy[:, 0] > 0).all() and (sy[:, 2] > 0).all()
+        assert np.allclose(sy[:, 1], sy[:, 0] - sy[:, 2] / 13, rtol=0, atol=1e-15)          # sp = tp - np/13
+        assert np.all(st["sync_ce"][:14, :5] == 0) and np.all(st["sync_ce"][:14, 67:] == 0)
+        assert np.allclose(np.mean(np.abs(st["sync_ce"][:14, 5:67]) ** 2, axis=1), sy[:, 0])
+        snr.append(10 * np.log10(np.median(sy[:, 1] / sy[:, 2])))
+        n = r["n_meas"][0]
+        fd, tdc = st["ac_fd"][0, :n], st["ac_td"][0, :n]
+        # lag 0 of both autocorrelations is the raw power of the current reference symbol over its signal power: real, >= ~1
+        assert np.abs(fd[:, 0].imag).max() < 1e-12 and np.abs(tdc[71:, 0].imag).max() < 1e-12
+        assert np.allclose(fd[71:, 0].real, tdc[71:, 0].real, rtol=1e-12)
+        assert np.isnan(tdc[:71].real).all() and np.isfinite(tdc[71:]).all()
+        assert 0.8 < np.median(fd[:, 0].real) < 3.0
+        # the running averages, folded as the reference does: coherent across frequency on a line-of-sight capture
+        ac = pkg.tracker.fold_ac_fd(np.zeros(12), fd, r["meas"][0, :n])
+        assert abs(ac[1]) > 0.5 * abs(ac[0]) > 0
+        av = pkg.tracker.fold_sync_power(None, sy)
+        assert av.shape == (4,) and abs(av[0] - sy[0, 0]) < 0.02 * sy[0, 0]
+    assert snr[0] > snr[1] and snr[0] > 5.0                                # cell 277 is the strong one (doc/CellSearch.html:75-82)
+
+
+@pytest.mark.gpu
+def test_gpu_track_stats_match_oracle(tracked):
+    pkg = load_pkg()
+    _, cells = tracked
+    recs = [c for c, *_ in cells]
+    td = np.stack([x[1] for x in cells]); late = np.stack([x[2] for x in cells])
+    ftv = np.stack([x[3] for x in cells]); fov = np.stack([x[4] for x in cells])
+    with pkg.Searcher(0) as S:
+        S.track_block(recs, td, fov, ftv, late, FC, FC, FS, want_syms=False, want_ce=False)
+        g = S.track_stats(len(recs), td.shape[1])
+        with pytest.raises(pkg.SearcherError):
+            S.track_stats(len(recs), td.shape[1] - 140)                    # not the block that was processed
+    for i, (c, td_i, late_i, ft_i, fo_i) in enumerate(cells):
+        r = _oracle_block(c, td_i, late_i, ft_i, fo_i)
+        st = O.trk_stats(c, r["syms"], 0, 0, r["meas"], r["n_meas"])
+        assert g["n_hf"][i] == st["n_hf"] == 14
+        assert np.abs(g["sync"][i, :14] - st["sync"][:14]).max() < 1e-11 * st["sync"][:14].max()
+        assert np.abs(g["sync_ce"][i, :14] - st["sync_ce"][:14]).max() < 1e-11 * np.abs(st["sync_ce"][:14]).max()
+        for p in range(c.n_ports):
+            n = r["n_meas"][p]
+            assert np.abs(g["ac_fd"][i, p, :n] - st["ac_fd"][p, :n]).max() < 1e-10 * np.abs(st["ac_fd"][p, :n]).max()
+            assert np.isnan(g["ac_td"][i, p, :71].real).all()
+            assert np.abs(g["ac_td"][i, p, 71:n] - st["ac_td"][p, 71:n]).max() < 1e-10 * np.abs(st["ac_td"][p, 71:n]).max()
+        assert np.isnan(g["ac_fd"][i, c.n_ports:].real).all()
+
+
 @pytest.mark.gpu
 def test_gpu_track_block_shapes_and_errors(tracked):
     """One cell / a block too short for any MIB attempt / bad identities."""
