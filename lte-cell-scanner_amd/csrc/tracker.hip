@@ -437,6 +437,27 @@ __global__ __launch_bounds__(64) void k_trk_sync(const lcs_track_cell *__restric
 
 // ------------------------------------------------------------------------------------------------------------ host
 namespace {
+// Where lcs_track_block leaves its intermediate results in the block workspace (lcs_track_stats reads them back)
+struct TrkLayout {
+  int rs_cap, n_off;
+  size_t N, C4;
+  double *d_fo, *d_ft, *d_late, *d_bpo, *d_rs, *d_shift, *d_fm, *d_meas;
+  int *d_idx, *d_nrs, *d_nmeas, *d_upto, *d_mibok;
+  double2 *d_raw, *d_filt;
+  unsigned long long *d_mibbits;
+  TrkLayout(const lcs_ctx *c, int n_cells, int n_sym) {
+    rs_cap = n_sym / 3 + 4;                               // reference symbols of one port in the block: at most 2 per slot of >= 6 symbols
+    n_off = std::max(0, n_sym / 120 - 3);                 // frame offsets that could hold four frames (120 = extended-CP frame)
+    N = (size_t)n_cells * n_sym; C4 = (size_t)n_cells * 4;
+    d_fo = c->trk_meta; d_ft = d_fo + N; d_late = d_ft + N; d_bpo = d_late + N;
+    d_rs = c->trk_rs; d_shift = d_rs + (size_t)n_cells * 140 * 24;
+    d_idx = c->trk_idx; d_nrs = d_idx + C4 * rs_cap;
+    d_raw = c->trk_raw; d_filt = d_raw + C4 * rs_cap * 12;
+    d_fm = c->trk_fmeta; d_meas = d_fm + C4 * rs_cap * 4;
+    d_nmeas = c->trk_small; d_upto = d_nmeas + C4; d_mibok = d_upto + C4;
+    d_mibbits = reinterpret_cast<unsigned long long *>(d_mibok + (((size_t)n_cells * n_off + 1) & ~(size_t)1));
+  }
+};
 template <typename T>
 int trk_alloc(lcs_ctx *c, T **p, size_t n) {
   if (*p) { (void)hipFree(*p); *p = nullptr; }
@@ -458,8 +479,7 @@ extern "C" int lcs_track_block(lcs_ctx *c, lcs_track_cell *cells, int n_cells, i
         t.n_ports < 1 || t.n_ports > 4) { c->err = "tracked cell needs n_id_1, n_id_2, a known cp_type and 1..4 ports"; return LCS_ERR_BAD_ARG; }
   }
   HIPCHK(c, hipSetDevice(c->device));
-  const int rs_cap = n_sym / 3 + 4;                       // reference symbols of one port in the block: at most 2 per slot of >= 6 symbols
-  const int n_off = std::max(0, n_sym / 120 - 3);         // frame offsets that could hold four frames (120 = extended-CP frame)
+  const int rs_cap = n_sym / 3 + 4, n_off = std::max(0, n_sym / 120 - 3);     // as TrkLayout
   int rc;
   if (n_cells != c->trk_cells_cap || n_sym != c->trk_sym_cap) {      // workspace laid out for one block shape
     const size_t N = (size_t)n_cells * n_sym, C4 = (size_t)n_cells * 4;
@@ -472,14 +492,13 @@ extern "C" int lcs_track_block(lcs_ctx *c, lcs_track_cell *cells, int n_cells, i
       return rc;
     c->trk_cells_cap = n_cells; c->trk_sym_cap = n_sym;
   }
-  const size_t N = (size_t)n_cells * n_sym, C4 = (size_t)n_cells * 4;
-  double *d_fo = c->trk_meta, *d_ft = d_fo + N, *d_late = d_ft + N, *d_bpo = d_late + N;
-  double *d_rs = c->trk_rs, *d_shift = d_rs + (size_t)n_cells * 140 * 24;
-  int *d_idx = c->trk_idx, *d_nrs = d_idx + C4 * rs_cap;
-  double2 *d_raw = c->trk_raw, *d_filt = d_raw + C4 * rs_cap * 12;
-  double *d_fm = c->trk_fmeta, *d_meas = d_fm + C4 * rs_cap * 4;
-  int *d_nmeas = c->trk_small, *d_upto = d_nmeas + C4, *d_mibok = d_upto + C4;
-  unsigned long long *d_mibbits = reinterpret_cast<unsigned long long *>(d_mibok + (((size_t)n_cells * n_off + 1) & ~(size_t)1));
+  const TrkLayout L(c, n_cells, n_sym);
+  const size_t N = L.N, C4 = L.C4;
+  double *d_fo = L.d_fo, *d_ft = L.d_ft, *d_late = L.d_late, *d_bpo = L.d_bpo, *d_rs = L.d_rs, *d_shift = L.d_shift;
+  int *d_idx = L.d_idx, *d_nrs = L.d_nrs, *d_nmeas = L.d_nmeas, *d_upto = L.d_upto, *d_mibok = L.d_mibok;
+  double2 *d_raw = L.d_raw, *d_filt = L.d_filt;
+  double *d_fm = L.d_fm, *d_meas = L.d_meas;
+  unsigned long long *d_mibbits = L.d_mibbits;
   const double2 *d_td = td_on_device ? (const double2 *)td : c->trk_td;
   if (!td_on_device) HIPCHK(c, hipMemcpyAsync(c->trk_td, td, sizeof(double2) * N * 128, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(d_fo, freq_off, sizeof(double) * N, hipMemcpyHostToDevice, c->stream));
@@ -538,8 +557,9 @@ extern "C" int lcs_track_stats(lcs_ctx *c, int n_cells, int n_sym, double *ac_fd
     return LCS_ERR_BAD_ARG;
   }
   HIPCHK(c, hipSetDevice(c->device));
-  const int rs_cap = n_sym / 3 + 4;
-  const size_t C4 = (size_t)n_cells * 4;
+  const TrkLayout L(c, n_cells, n_sym);
+  const int rs_cap = L.rs_cap;
+  const size_t C4 = L.C4;
   const int hf_cap = n_sym / 60 + 2;                       // PSS/SSS pairs of the block: two per frame of >= 120 symbols
   int rc;
   if (c->trk_stat_cells != n_cells || c->trk_stat_sym != n_sym) {
@@ -549,9 +569,9 @@ extern "C" int lcs_track_stats(lcs_ctx *c, int n_cells, int n_sym, double *ac_fd
       return rc;
     c->trk_stat_cells = n_cells; c->trk_stat_sym = n_sym;
   }
-  const double2 *d_raw = c->trk_raw;
-  const double *d_meas = c->trk_fmeta + C4 * rs_cap * 4;
-  const int *d_nmeas = c->trk_small;
+  const double2 *d_raw = L.d_raw;
+  const double *d_meas = L.d_meas;
+  const int *d_nmeas = L.d_nmeas;
   std::vector<int> h_nmeas(C4);
   std::vector<lcs_track_cell> h_cells(n_cells);
   if (ac_fd || ac_td)
