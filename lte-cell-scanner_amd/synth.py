@@ -227,8 +227,12 @@ def frac_resample(x, u, half=24, beta=9.0):
     return out
 
 
-def make_capbuf(seed, fc, cells=(), snr_db=10.0, n_cap=N_CAP, rms=0.15, quantise=True):
+def make_capbuf(seed, fc, cells=(), snr_db=10.0, n_cap=N_CAP, rms=0.15, quantise=True, fc_programmed=None, fs_programmed=FS):
     """One capture buffer as the receiver would record it.
+
+    fc is the frequency the caller asked for (fc_requested); fc_programmed / fs_programmed are what the dongle reports
+    it was actually set to (ref src/CellSearch.cpp:380-390): the crystal error then is k_factor = (fc - f_off) /
+    fc_programmed and the true sample rate fs_programmed * k_factor (src/searcher.cpp:147).
 
     cells: dicts with n_id_1, n_id_2 and optionally cp_normal, n_ports, n_rb_dl, phich_duration_ext,
     phich_res, sfn0, load, f_off (Hz, the dongle's LO error: +f_off means the cell appears f_off
@@ -240,15 +244,16 @@ def make_capbuf(seed, fc, cells=(), snr_db=10.0, n_cap=N_CAP, rms=0.15, quantise
     ref_pow = None
     for cd in cells:
         f_off = float(cd.get("f_off", 0.0))
-        k_factor = (fc - f_off) / fc
+        k_factor = (fc - f_off) / (fc if fc_programmed is None else fc_programmed)
+        rate = k_factor if fs_programmed == FS else fs_programmed * k_factor / FS      # receiver samples per nominal 1.92 MHz transmitter sample
         t0 = float(cd.get("t0", rng.uniform(0, 19200)))
-        n_frames = int(np.ceil((n_cap / k_factor + t0) / 19200)) + 1
+        n_frames = int(np.ceil((n_cap / rate + t0) / 19200)) + 1
         w = cell_waveform(n_frames, cd["n_id_1"], cd["n_id_2"], cd.get("cp_normal", True), cd.get("n_ports", 2),
                           cd.get("n_rb_dl", 50), cd.get("phich_duration_ext", 0), cd.get("phich_res", 2),
                           cd.get("sfn0", int(rng.integers(0, 1024))), cd.get("load", 0.5), rng, cd.get("port_gains"))
-        # receiver sample n is taken at transmitter time (t0 + n/k_factor) nominal samples
-        y = frac_resample(w, t0 + n / k_factor)
-        y = y * np.exp(2j * np.pi * f_off * n / (FS * k_factor))
+        # receiver sample n is taken at transmitter time (t0 + n / rate) nominal samples
+        y = frac_resample(w, t0 + n / rate)
+        y = y * np.exp(2j * np.pi * f_off * n / (fs_programmed * k_factor))
         g = 10 ** (cd.get("gain_db", 0.0) / 20)
         sig += g * y
         if ref_pow is None:

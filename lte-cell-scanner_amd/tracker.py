@@ -113,15 +113,26 @@ def fold_sync_power(av, sync_rows: np.ndarray):
     return av
 
 
-def mib_lock_walk(ok_by_frame_offset, failures: float = 0.0, synchronized: bool = False, drop_threshold: float = 400.0):      # CELL_DROP_THRESHOLD, include/constants.h:35
+def mib_lock_walk(mib_ok, failures: float = 0.0, synchronized: bool = False, drop_threshold: float = 400.0):      # CELL_DROP_THRESHOLD, include/constants.h:35
     """do_mib_decode's fifo walk (src/tracker_thread.cpp:552-745) over a block in which every frame offset has been
     tried in parallel: an attempt is made whenever 16 PBCH symbols are queued; success or a synchronised failure
-    consumes four frames, an unsynchronised failure one.  Returns (failures, synchronized, attempts made, dropped)."""
+    consumes four frames, an unsynchronised failure one.  `mib_ok` is a row of track_block's 'mib_ok' codes as they
+    come (bit 0 = CRC, bit 1 = bandwidth / PHICH fields equal the tracked cell's, -1 = not attempted): only code 3 is a
+    lock (:689-694 needs both) and the walk ends at the first offset that was never attempted (the reference would be
+    waiting for more symbols there).  A boolean sequence (True = locked) is accepted too.
+    Returns (failures, synchronized, attempts made, dropped)."""
+    a = np.asarray(mib_ok)
+    if a.dtype == np.bool_:
+        codes = np.where(a, 3, 0)
+    elif np.issubdtype(a.dtype, np.integer):
+        codes = a
+    else:
+        raise ValueError("mib_lock_walk takes track_block's integer mib_ok codes or booleans")
     o, attempts = 0, 0
-    n = len(ok_by_frame_offset)
-    while o < n:
+    n = len(codes)
+    while o < n and codes[o] != -1:
         attempts += 1
-        if ok_by_frame_offset[o]:
+        if codes[o] == 3:
             synchronized, failures, o = True, 0.0, o + 4
         elif synchronized:
             failures, o = failures + 1.0, o + 4

@@ -980,7 +980,9 @@ static void ce_interp_hex(const cd *ce_filt /*[n_rs][12]*/, const int *shift, in
 static int cmp_int(const void *a, const void *b) { return (*(const int *)a > *(const int *)b) - (*(const int *)a < *(const int *)b); }
 
 /* ref: src/searcher.cpp:1369-1477  chan_est */
-static int chan_est(const orc_cell *cell, const rs_dl_t *R, const cd *tfg, int n_ofdm, int port, cd *ce_tfg, double *np) {
+typedef struct { cd *raw, *filt; int *rows, *n_rs; } ce_dbg_t;   /* test hook: chan_est's internal estimates */
+static int chan_est_x(const orc_cell *cell, const rs_dl_t *R, const cd *tfg, int n_ofdm, int port, cd *ce_tfg, double *np,
+                      const ce_dbg_t *dbg) {
   const int n_symb_dl = cell_n_symb_dl(cell);
   int rs_set[512]; int n_rs_ofdm = 0;
   if (port <= 1) {
@@ -1035,9 +1037,31 @@ static int chan_est(const orc_cell *cell, const rs_dl_t *R, const cd *tfg, int n
     }
     *np = r / (n_rs_ofdm * 12);
   }
-  ce_interp_hex(ce_filt, shift, n_ofdm, n_rs_ofdm, rs_set, ce_tfg);
+  if (dbg) {
+    memcpy(dbg->raw, ce_raw, sizeof(cd) * n_rs_ofdm * 12);
+    memcpy(dbg->filt, ce_filt, sizeof(cd) * n_rs_ofdm * 12);
+    memcpy(dbg->rows, rs_set, sizeof(int) * n_rs_ofdm);
+    *dbg->n_rs = n_rs_ofdm;
+  }
+  if (ce_tfg) ce_interp_hex(ce_filt, shift, n_ofdm, n_rs_ofdm, rs_set, ce_tfg);
   free(ce_raw); free(ce_filt);
   return 0;
+}
+static int chan_est(const orc_cell *cell, const rs_dl_t *R, const cd *tfg, int n_ofdm, int port, cd *ce_tfg, double *np) {
+  return chan_est_x(cell, R, tfg, n_ofdm, port, ce_tfg, np, NULL);
+}
+/* chan_est's raw (ref src/searcher.cpp:1404-1419) and hexagonally filtered (:1431-1467) reference-signal estimates,
+ * [n_rs][12] each, and the grid rows they were taken from (<= 244 rows) -- exported so that the tests can pin the
+ * tracker restatement below to them. */
+int orc_chan_est_dbg(const orc_cell *cell, const double *tfg_re_im, int n_ofdm, int port, double *raw_re_im, double *filt_re_im,
+                     int *rows, int *n_rs) {
+  rs_dl_t *R = (rs_dl_t *)malloc(sizeof(rs_dl_t));
+  rs_dl_build(cell_n_id_cell(cell), cell->cp_type, R);
+  ce_dbg_t d = {(cd *)raw_re_im, (cd *)filt_re_im, rows, n_rs};
+  double np;
+  const int rc = chan_est_x(cell, R, (const cd *)tfg_re_im, n_ofdm, port, NULL, &np, &d);
+  free(R);
+  return rc;
 }
 int orc_chan_est(const orc_cell *cell, const double *tfg_re_im, int n_ofdm, int port, double *ce_re_im, double *np) {
   rs_dl_t *R = (rs_dl_t *)malloc(sizeof(rs_dl_t));
@@ -1404,9 +1428,10 @@ static void trk_interp72(const trk_filt_t *rs, cd *interp) {
  *   n_meas  [4]            rows filled per port
  *   ce      [4][n_sym][72] complex, ce_pw [4][n_sym][4] (tp, sp, sp_raw, np), valid for symbols < ce_upto[port]
  */
-int orc_trk_chan_est(const orc_cell *cell, const double *syms_re_im, int n_sym, int slot0, int sym0, const double *freq_off,
+typedef struct { int port; cd *raw, *filt; int *raw_idx, *filt_idx, *n_raw, *n_filt; } trk_dbg_t;   /* test hook */
+static int trk_chan_est_x(const orc_cell *cell, const double *syms_re_im, int n_sym, int slot0, int sym0, const double *freq_off,
                      const double *frame_timing, double fc_requested, double fc_programmed, double fs_programmed,
-                     double *meas, int max_rs, int *n_meas, double *ce_re_im, double *ce_pw, int *ce_upto) {
+                     double *meas, int max_rs, int *n_meas, double *ce_re_im, double *ce_pw, int *ce_upto, const trk_dbg_t *dbg) {
   const int n_symb_dl = cell_n_symb_dl(cell);
   if (n_symb_dl < 0 || cell->n_ports < 1 || cell->n_ports > 4) return -1;
   const cd *syms = (const cd *)syms_re_im;
@@ -1485,6 +1510,11 @@ int orc_trk_chan_est(const orc_cell *cell, const double *syms_re_im, int n_sym, 
       nf++;
     }
     n_meas[port] = nf < max_rs ? nf : max_rs;
+    if (dbg && dbg->port == port) {
+      for (int r = 0; r < m; r++) { memcpy(dbg->raw + (size_t)r * 12, raw[r].ce, sizeof(cd) * 12); dbg->raw_idx[r] = raw[r].idx; }
+      for (int r = 0; r < nf; r++) { memcpy(dbg->filt + (size_t)r * 12, fl[r].ce_filt, sizeof(cd) * 12); dbg->filt_idx[r] = fl[r].idx; }
+      *dbg->n_raw = m; *dbg->n_filt = nf;
+    }
     /* interp2d :402-477 over consecutive filtered RS symbols */
     cd *ce = (cd *)ce_re_im + (size_t)port * n_sym * 72;
     double *pw = ce_pw + (size_t)port * n_sym * 4;
@@ -1524,6 +1554,28 @@ int orc_trk_chan_est(const orc_cell *cell, const double *syms_re_im, int n_sym, 
   }
   free(R); free(raw); free(fl);
   return 0;
+}
+int orc_trk_chan_est(const orc_cell *cell, const double *syms_re_im, int n_sym, int slot0, int sym0, const double *freq_off,
+                     const double *frame_timing, double fc_requested, double fc_programmed, double fs_programmed,
+                     double *meas, int max_rs, int *n_meas, double *ce_re_im, double *ce_pw, int *ce_upto) {
+  return trk_chan_est_x(cell, syms_re_im, n_sym, slot0, sym0, freq_off, frame_timing, fc_requested, fc_programmed, fs_programmed,
+                        meas, max_rs, n_meas, ce_re_im, ce_pw, ce_upto, NULL);
+}
+/* The tracker's raw reference-signal estimates (ref src/tracker_thread.cpp:868-890) and filter_ce outputs (:176-201) of one
+ * port, [n][12] each with the symbol index of every row -- exported so that the tests can pin them to the searcher's
+ * chan_est (orc_chan_est_dbg) on the same grid. */
+int orc_trk_raw_filt(const orc_cell *cell, const double *syms_re_im, int n_sym, int slot0, int sym0, int port,
+                     double *raw_re_im, int *raw_idx, int *n_raw, double *filt_re_im, int *filt_idx, int *n_filt) {
+  double *meas = (double *)malloc(sizeof(double) * 4 * (size_t)n_sym * 9), *fo = (double *)calloc(n_sym, sizeof(double));
+  cd *ce = (cd *)malloc(sizeof(cd) * 4 * (size_t)n_sym * 72);
+  double *pw = (double *)malloc(sizeof(double) * 4 * (size_t)n_sym * 4);
+  int nm[4], upto[4];
+  trk_dbg_t d = {port, (cd *)raw_re_im, (cd *)filt_re_im, raw_idx, filt_idx, n_raw, n_filt};
+  *n_raw = *n_filt = 0;
+  const int rc = trk_chan_est_x(cell, syms_re_im, n_sym, slot0, sym0, fo, fo, 739e6, 739e6, 1.92e6, meas, n_sym, nm, (double *)ce, pw,
+                                upto, &d);
+  free(meas); free(fo); free(ce); free(pw);
+  return rc;
 }
 
 /* ref: src/tracker_thread.cpp:318-341 do_ac_fd, :343-371 do_ac_td, :754-820 do_pss_sss_sigpower_ce -- the display

@@ -270,6 +270,36 @@ def chan_est(cell, tfg, port):
     return ce, np_.value
 
 
+def chan_est_dbg(cell, tfg, port):
+    """chan_est's internal estimates -> (raw [n_rs][12], filtered [n_rs][12], grid rows [n_rs])"""
+    tfg = np.ascontiguousarray(tfg, np.complex128)
+    raw, filt = np.empty((512, 12), np.complex128), np.empty((512, 12), np.complex128)
+    rows, n = np.empty(512, np.int32), C.c_int(0)
+    L = lib()
+    L.orc_chan_est_dbg.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                   C.POINTER(C.c_int32), C.POINTER(C.c_int)]
+    rc = L.orc_chan_est_dbg(C.byref(cell), _dp(tfg), tfg.shape[0], port, _dp(raw), _dp(filt), _ip(rows), C.byref(n))
+    if rc:
+        raise RuntimeError(f"orc_chan_est_dbg rc={rc}")
+    return raw[:n.value].copy(), filt[:n.value].copy(), rows[:n.value].copy()
+
+
+def trk_raw_filt(cell, syms, slot0, sym0, port):
+    """The tracker's raw / filter_ce estimates of one port -> (raw [n][12], their symbol indices, filt [m][12], indices)"""
+    syms = np.ascontiguousarray(syms, np.complex128)
+    n = syms.shape[0]
+    raw, filt = np.empty((n, 12), np.complex128), np.empty((n, 12), np.complex128)
+    ri, fi = np.empty(n, np.int32), np.empty(n, np.int32)
+    nr, nf = C.c_int(0), C.c_int(0)
+    L = lib()
+    L.orc_trk_raw_filt.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double),
+                                   C.POINTER(C.c_int32), C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int)]
+    rc = L.orc_trk_raw_filt(C.byref(cell), _dp(syms), n, slot0, sym0, port, _dp(raw), _ip(ri), C.byref(nr), _dp(filt), _ip(fi), C.byref(nf))
+    if rc:
+        raise RuntimeError(f"orc_trk_raw_filt rc={rc}")
+    return raw[:nr.value].copy(), ri[:nr.value].copy(), filt[:nf.value].copy(), fi[:nf.value].copy()
+
+
 def decode_mib(cell, tfg) -> Cell:
     tfg = np.ascontiguousarray(tfg, np.complex128)
     out = Cell()
