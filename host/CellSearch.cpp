@@ -12,17 +12,22 @@
 // fc_requested and fs_programmed = 1.92e6 * correction (the convention of src/LTE-Tracker.cpp:609, 791).
 // A recorded capture holds exactly (u8-127)/128 per component (src/capbuf.cpp:172-181): such buffers go to the GPU
 // as raw bytes, 64 carriers per batch, and take the int8 correlation kernel; anything else (synthetic complex
-// data) is searched one buffer at a time as complex<double>.  Extra option: -g/--gpu N selects the device.
+// data) is searched one buffer at a time as complex<double>.  Extra option: -g/--gpu N selects the device, -g all
+// shards the carrier sweep over every visible GPU (one thread and two batches in flight per device).
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <condition_variable>
 #include <iostream>
 #include <list>
 #include <map>
+#include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../include/searcher_amd.h"
@@ -51,6 +56,8 @@ struct Options {
   bool record = false, load = false, help = false;
   std::string data_dir = ".";
   long device_index = -1, gpu = -1;
+  bool gpu_all = false;          // -g all: shard the carriers over every visible GPU
+  long batch = 64;               // carriers per GPU batch (one correlation launch)
   int verbosity = 1;
 };
 
@@ -67,7 +74,8 @@ const OptSpec kSpecs[] = {
     {'v', "verbose", FLAG, 0, {"increase status messages from program", 0}},
     {'b', "brief", FLAG, 0, {"reduce status messages from program", 0}},
     {'i', "device-index", INDEX, "device index", {"(accepted for compatibility; there is no RTLSDR dongle on a GPU node)", 0}},
-    {'g', "gpu", INDEX, "gpu index", {"GPU to run the searcher on (default: current device)", 0}},
+    {'g', "gpu", INDEX, "gpu index", {"GPU to run the searcher on (default: current device); 'all' shards the carriers over every GPU", 0}},
+    {'B', "batch", INDEX, "batch size", {"carriers searched per GPU batch (default 64)", 0}},
     {'s', "freq-start", REAL, "start frequency", {"frequency where cell search should start", 0}},
     {'e', "freq-end", REAL, "end frequency", {"frequency where cell search should end", 0}},
     {'p', "ppm", REAL, "ppm value", {"crystal remaining PPM error", 0}},
@@ -82,7 +90,7 @@ void usage() {
   std::cout << "LTE CellSearch v" << VERSION_STRING << " (MI355X) help screen\n\n"
             << "CellSearch -s start_frequency [optional_parameters]\n";
   const struct { const char *title; const char *letters; } sections[] = {
-      {"Basic options", "hvbig"}, {"Frequency search options:", "se"}, {"Dongle LO correction options:", "pc"},
+      {"Basic options", "hvbigB"}, {"Frequency search options:", "se"}, {"Dongle LO correction options:", "pc"},
       {"Capture buffer save/ load options:", "rld"}};
   for (const auto &sec : sections) {
     std::cout << "  " << sec.title << "\n";
@@ -119,9 +127,11 @@ void store(Options &o, const OptSpec &s, const char *value) {
       return;
     }
     case INDEX: {
+      if (s.letter == 'g' && std::strcmp(value, "all") == 0) { o.gpu_all = true; return; }
       const long v = std::strtol(value, &end, 10);
       if (end == value || *end) die(std::string("could not parse ") + s.what);
-      if (v < 0) die(s.letter == 'i' ? "device index cannot be negative" : "could not parse gpu index");
+      if (v < 0) die(s.letter == 'i' ? "device index cannot be negative" : s.letter == 'g' ? "could not parse gpu index" : "could not parse batch size");
+      if (s.letter == 'B') { if (v < 1 || v > 512) die("batch size must be 1..512"); o.batch = v; return; }
       (s.letter == 'i' ? o.device_index : o.gpu) = v;
       return;
     }
@@ -263,89 +273,188 @@ void announce(const std::list<Cell> &cells) {
               << " dB\n    residual frequency offset: " << num(c.freq_superfine) << " Hz" << std::endl;
 }
 
+// ---- the sweep -------------------------------------------------------------------------------------------------------
+// The carrier loop of src/CellSearch.cpp:471-569, sharded: carriers are cut into batches of 64 (one correlation launch),
+// batch b belongs to GPU b mod n_gpus (block-cyclic), every GPU has one thread that keeps TWO batches in flight -- it
+// reads and enqueues batch k + 1 (page-locked staging buffer, asynchronous copy) while the device works on batch k -- and
+// the main thread prints the per-carrier report in carrier order as batches complete.  No collective is needed: the
+// results meet in host memory of this one process.
+struct Sweep {
+  Options opt;
+  lcsc::vec f_search_set;
+  double fs_programmed;
+  int n_fc, n_batches;
+  std::vector<std::list<Cell> > detected;
+  std::vector<char> fc_matches, batched;
+  std::vector<char> batch_done;
+  std::string failure;
+  std::mutex m;
+  std::condition_variable cv;
+  int kBatch = 64;                     // carriers per batch (-B)
+
+  void finish(int b) {
+    std::lock_guard<std::mutex> lk(m);
+    batch_done[b] = 1;
+    cv.notify_all();
+  }
+  void fail(const std::string &what) {
+    std::lock_guard<std::mutex> lk(m);
+    if (failure.empty()) failure = what;
+    cv.notify_all();
+  }
+};
+
+struct InFlight {
+  int batch = -1;
+  std::vector<int> carriers;           // carriers of the batch that went to the GPU as bytes, in buffer order
+  std::vector<Capture> singles;        // the others: searched one by one as complex<double>
+  std::vector<int> single_carriers;
+};
+
+void device_thread(Sweep *sw, int device, int first_batch, int stride) {
+  try {
+    lcs::Searcher ctx[2] = {lcs::Searcher(device), lcs::Searcher(device)};
+    std::unique_ptr<lcs::Searcher> one;                     // for captures that are not raw dongle bytes
+    unsigned char *pinned[2] = {0, 0};
+    size_t pinned_bytes[2] = {0, 0};
+    InFlight fl[2];
+    auto collect = [&](int slot) {
+      InFlight &f = fl[slot];
+      if (f.batch < 0) return;
+      if (!f.carriers.empty()) {
+        std::vector<std::list<Cell> > found;
+        ctx[slot].collect_batch(found);
+        if (ctx[slot].last_batch_overflowed()) std::cerr << "Warning: more cells than the result arrays hold; list truncated" << std::endl;
+        for (size_t j = 0; j < f.carriers.size(); ++j) sw->detected[f.carriers[j]].swap(found[j]);
+      }
+      for (size_t j = 0; j < f.singles.size(); ++j) {
+        if (!one) one.reset(new lcs::Searcher(device));
+        const double fc = sw->opt.freq_start + 100e3 * f.single_carriers[j];
+        lcsc::cvec capbuf((int)f.singles[j].samples.size());
+        std::memcpy(capbuf._data(), f.singles[j].samples.data(), f.singles[j].samples.size() * sizeof(std::complex<double>));
+        one->search_capbuf(capbuf, sw->f_search_set, fc, fc, sw->fs_programmed, sw->detected[f.single_carriers[j]]);
+      }
+      sw->finish(f.batch);
+      f = InFlight();
+    };
+    int slot = 0;
+    for (int b = first_batch; b < sw->n_batches; b += stride, slot ^= 1) {
+      collect(slot);                                        // the batch this slot carried two rounds ago
+      const int first = b * sw->kBatch, n = std::min<int>(sw->kBatch, sw->n_fc - first);
+      InFlight &f = fl[slot];
+      f.batch = b;
+      std::vector<Capture> caps(n);
+      for (int k = 0; k < n; ++k) {
+        const std::string path = sw->opt.data_dir + fmt("/capbuf_%04d.it", first + k);
+        if (sw->opt.verbosity >= 2) { std::lock_guard<std::mutex> lk(sw->m); std::cout << "Reading captured data from file: " << path << std::endl; }
+        caps[k] = read_capture(path, sw->opt.freq_start + 100e3 * (first + k));
+        sw->fc_matches[first + k] = caps[k].fc_matches;
+      }
+      // raw-byte captures of one length go through the int8 path together; the rest one by one
+      size_t n_cap = 0;
+      for (int k = 0; k < n && !n_cap; ++k) if (!caps[k].iq_u8.empty()) n_cap = caps[k].samples.size();
+      for (int k = 0; k < n; ++k) {
+        const bool bytes = n_cap && !caps[k].iq_u8.empty() && caps[k].samples.size() == n_cap;
+        sw->batched[first + k] = bytes;
+        if (bytes) f.carriers.push_back(first + k);
+        else { f.single_carriers.push_back(first + k); f.singles.push_back(Capture()); f.singles.back().samples.swap(caps[k].samples); }
+      }
+      if (!f.carriers.empty()) {
+        const size_t need = f.carriers.size() * 2 * n_cap;
+        if (need > pinned_bytes[slot]) {
+          if (pinned[slot]) ctx[slot].host_free(pinned[slot]);
+          pinned[slot] = (unsigned char *)ctx[slot].host_alloc(need);
+          pinned_bytes[slot] = need;
+        }
+        std::vector<double> fcs(f.carriers.size());
+        for (size_t j = 0; j < f.carriers.size(); ++j) {
+          std::memcpy(pinned[slot] + j * 2 * n_cap, caps[f.carriers[j] - first].iq_u8.data(), 2 * n_cap);
+          fcs[j] = sw->opt.freq_start + 100e3 * f.carriers[j];
+        }
+        ctx[slot].enqueue_batch_host(pinned[slot], LCS_FMT_IQ_U8, (int)f.carriers.size(), (uint32_t)n_cap, sw->f_search_set, fcs, fcs,
+                                     sw->fs_programmed);
+      }
+    }
+    collect(slot);
+    collect(slot ^ 1);
+    for (int k = 0; k < 2; ++k) if (pinned[k]) ctx[k].host_free(pinned[k]);
+  } catch (const std::exception &e) {
+    sw->fail(e.what());
+  }
+}
+
 }  // namespace
 
 int main(int argc, char *const argv[]) {
-  Options opt = scan_args(argc, argv);
+  Sweep sw;
+  sw.opt = scan_args(argc, argv);
+  Options &opt = sw.opt;
   validate(opt);
   if (!opt.load) {
     std::cerr << "Error: this build has no RTL-SDR support (GPU node); use --load with capbuf_XXXX.it files" << std::endl;
     return 1;
   }
-  const double fs_programmed = 1.92e6 * opt.correction;   // recorded-data convention, src/LTE-Tracker.cpp:791
+  sw.fs_programmed = 1.92e6 * opt.correction;   // recorded-data convention, src/LTE-Tracker.cpp:791
 
   // frequency-offset hypotheses and carrier raster (src/CellSearch.cpp:463-465; n_extra uses freq_start only)
   const int n_extra = (int)std::floor((opt.freq_start * opt.ppm / 1e6 + 2.5e3) / 5e3);
-  lcsc::vec f_search_set(2 * n_extra + 1);
-  for (int i = 0; i <= 2 * n_extra; ++i) f_search_set(i) = 5000.0 * (i - n_extra);
-  const int n_fc = (int)std::floor((opt.freq_end - opt.freq_start) / 100e3) + 1;
+  sw.f_search_set.set_size(2 * n_extra + 1);
+  for (int i = 0; i <= 2 * n_extra; ++i) sw.f_search_set(i) = 5000.0 * (i - n_extra);
+  sw.n_fc = (int)std::floor((opt.freq_end - opt.freq_start) / 100e3) + 1;
+  sw.kBatch = (int)opt.batch;
+  sw.n_batches = (sw.n_fc + sw.kBatch - 1) / sw.kBatch;
+  sw.detected.resize(sw.n_fc);
+  sw.fc_matches.assign(sw.n_fc, 1);
+  sw.batched.assign(sw.n_fc, 0);
+  sw.batch_done.assign(sw.n_batches, 0);
 
-  try {
-    lcs::Searcher searcher((int)opt.gpu);
-    std::vector<std::list<Cell> > detected(n_fc);
-    const int kBatch = 64;                                   // carriers per GPU batch (one correlation launch)
-    for (int first = 0; first < n_fc; first += kBatch) {
-      const int n = std::min(kBatch, n_fc - first);
-      // read the batch's captures
-      std::vector<Capture> caps(n);
-      for (int k = 0; k < n; ++k) {
-        const std::string path = opt.data_dir + fmt("/capbuf_%04d.it", first + k);
-        if (opt.verbosity >= 2) std::cout << "Reading captured data from file: " << path << std::endl;
-        caps[k] = read_capture(path, opt.freq_start + 100e3 * (first + k));
-      }
-      // raw-byte captures of one length go through the int8 path together; the rest one by one as complex<double>
-      std::vector<int> bytes_idx;
-      for (int k = 0; k < n; ++k)
-        if (!caps[k].iq_u8.empty() && caps[k].samples.size() == caps[0].samples.size()) bytes_idx.push_back(k);
-      if (!bytes_idx.empty()) {
-        const size_t n_cap = caps[bytes_idx[0]].samples.size();
-        std::vector<unsigned char> host(bytes_idx.size() * 2 * n_cap);
-        std::vector<double> fcs(bytes_idx.size());
-        for (size_t j = 0; j < bytes_idx.size(); ++j) {
-          std::memcpy(&host[j * 2 * n_cap], caps[bytes_idx[j]].iq_u8.data(), 2 * n_cap);
-          fcs[j] = opt.freq_start + 100e3 * (first + bytes_idx[j]);
-        }
-        std::vector<std::list<Cell> > found;
-        searcher.search_batch_host(host.data(), LCS_FMT_IQ_U8, (int)bytes_idx.size(), (uint32_t)n_cap, f_search_set, fcs, fcs,
-                                   fs_programmed, found);
-        if (searcher.last_batch_overflowed()) std::cerr << "Warning: more cells than the result arrays hold; list truncated" << std::endl;
-        for (size_t j = 0; j < bytes_idx.size(); ++j) detected[first + bytes_idx[j]].swap(found[j]);
-      }
-      for (int k = 0; k < n; ++k) {
-        const double fc_requested = opt.freq_start + 100e3 * (first + k);
-        const bool batched = std::find(bytes_idx.begin(), bytes_idx.end(), k) != bytes_idx.end();
-        if (!batched) {
-          lcsc::cvec capbuf((int)caps[k].samples.size());
-          std::memcpy(capbuf._data(), caps[k].samples.data(), caps[k].samples.size() * sizeof(std::complex<double>));
-          searcher.search_capbuf(capbuf, f_search_set, fc_requested, fc_requested, fs_programmed, detected[first + k]);
-        }
-        // the reference's per-carrier report, in carrier order
-        if (opt.verbosity >= 1) std::cout << "Examining center frequency " << num(fc_requested / 1e6) << " MHz ..." << std::endl;
-        if (!caps[k].fc_matches)
-          std::cout << "Warning: while reading capture buffer " << first + k << ", the read\n"
-                    << "center frequency did not match the expected center frequency." << std::endl;
-        if (opt.verbosity >= 2) std::cout << "  PSS correlation, peak search, SSS, FOE, TFG and MIB decoding ran on the GPU ("
-                                          << (batched ? "int8 batch" : "fp32 single buffer") << ")" << std::endl;
-        if (opt.verbosity >= 1) announce(detected[first + k]);
-      }
-    }
+  std::vector<int> devices;
+  if (opt.gpu_all) {
+    const int n = lcs::Searcher::device_count();
+    if (n < 1) { std::cerr << "Error: lcs_create failed (an MI355X is required; there is no CPU fallback)" << std::endl; return 2; }
+    for (int d = 0; d < std::min(n, sw.n_batches); ++d) devices.push_back(d);
+  } else {
+    devices.push_back((int)opt.gpu);
+  }
+  std::vector<std::thread> workers;
+  for (size_t d = 0; d < devices.size(); ++d) workers.push_back(std::thread(device_thread, &sw, devices[d], (int)d, (int)devices.size()));
 
-    const std::vector<Cell> cells = merge_duplicates(detected);
-    if (cells.empty()) {
-      std::cout << "No LTE cells were found..." << std::endl;
-    } else {
-      std::cout << "Detected the following cells:\n"
-                << "A: #antenna ports C: CP type ; P: PHICH duration ; PR: PHICH resource type\n"
-                << "CID A      fc   foff RXPWR C nRB P  PR CrystalCorrectionFactor\n";
-      for (const Cell &c : cells) std::cout << table_row(c, opt.correction) << "\n";
-      std::cout.flush();
+  // the reference's per-carrier report, in carrier order, as the batches complete
+  bool failed = false;
+  for (int b = 0; b < sw.n_batches && !failed; ++b) {
+    {
+      std::unique_lock<std::mutex> lk(sw.m);
+      sw.cv.wait(lk, [&] { return sw.batch_done[b] || !sw.failure.empty(); });
+      failed = !sw.failure.empty();
     }
-  } catch (const lcs::error &e) {
-    std::cerr << "Error: " << e.what() << std::endl;
+    if (failed) break;
+    std::lock_guard<std::mutex> lk(sw.m);                     // keeps the -v file messages of the workers out of a report
+    for (int fci = b * sw.kBatch; fci < std::min(sw.n_fc, (b + 1) * sw.kBatch); ++fci) {
+      const double fc_requested = opt.freq_start + 100e3 * fci;
+      if (opt.verbosity >= 1) std::cout << "Examining center frequency " << num(fc_requested / 1e6) << " MHz ..." << std::endl;
+      if (!sw.fc_matches[fci])
+        std::cout << "Warning: while reading capture buffer " << fci << ", the read\n"
+                  << "center frequency did not match the expected center frequency." << std::endl;
+      if (opt.verbosity >= 2) std::cout << "  PSS correlation, peak search, SSS, FOE, TFG and MIB decoding ran on the GPU ("
+                                        << (sw.batched[fci] ? "int8 batch" : "single buffer") << ")" << std::endl;
+      if (opt.verbosity >= 1) announce(sw.detected[fci]);
+    }
+  }
+  for (std::thread &t : workers) t.join();
+  if (!sw.failure.empty()) {
+    std::cerr << "Error: " << sw.failure << std::endl;
     return 2;
-  } catch (const std::exception &e) {
-    std::cerr << "Error: " << e.what() << std::endl;
-    return 3;
+  }
+
+  const std::vector<Cell> cells = merge_duplicates(sw.detected);
+  if (cells.empty()) {
+    std::cout << "No LTE cells were found..." << std::endl;
+  } else {
+    std::cout << "Detected the following cells:\n"
+              << "A: #antenna ports C: CP type ; P: PHICH duration ; PR: PHICH resource type\n"
+              << "CID A      fc   foff RXPWR C nRB P  PR CrystalCorrectionFactor\n";
+    for (const Cell &c : cells) std::cout << table_row(c, opt.correction) << "\n";
+    std::cout.flush();
   }
   return 0;
 }

@@ -7,16 +7,21 @@
 // from the main thread and from the searcher thread; a context serialises its own calls.
 #include "searcher_shim.h"
 
+#include <atomic>
+#include <memory>
+
 #define LCS_CONTAINER_NS itpp
 #include "../include/searcher_amd.h"
 
 namespace {
 
-int g_device = -1;
+std::atomic<int> g_device(-1);
 
 lcs::Searcher &gpu() {
-  static thread_local lcs::Searcher *s = 0;
-  if (!s) s = new lcs::Searcher(g_device);      // lives as long as the thread; lcs::error propagates to the caller
+  // lives as long as the thread and is destroyed (streams, events, workspace) when the thread exits; a failing
+  // lcs_create throws lcs::error to the caller and is tried again by the next call
+  static thread_local std::unique_ptr<lcs::Searcher> s;
+  if (!s) s.reset(new lcs::Searcher(g_device.load()));
   return *s;
 }
 
@@ -47,7 +52,9 @@ Cell from_lcs(const lcs_cell &c) {
 
 }  // namespace
 
-void lcs_shim_set_device(int device) { g_device = device; }
+// Applies to contexts created AFTER the call: set it before a thread's first searcher call (a thread that already has
+// its context keeps its device).
+void lcs_shim_set_device(int device) { g_device.store(device); }
 
 void xcorr_pss(const itpp::cvec &capbuf, const itpp::vec &f_search_set, const uint8 &ds_comb_arm,
                const double &fc_requested, const double &fc_programmed, const double &fs_programmed,

@@ -32,6 +32,7 @@
 #ifndef LCS_H
 #define LCS_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -187,11 +188,23 @@ int lcs_search_batch_dev(lcs_ctx *ctx, const void *d_capbufs, int fmt, int n_buf
 /* The same for buffers in HOST memory (copied to the device by the call): what a caller holding recorded
  * capbuf_NNNN.it files or dongle bytes uses.  RTL-SDR captures are exactly (u8-127)/128 (src/capbuf.cpp:172-181):
  * handing them over as LCS_FMT_IQ_U8 moves 8x fewer bytes than complex<double> and takes the int8 correlation
- * kernel. */
+ * kernel.  lcs_batch_enqueue_host returns as soon as the copy and the kernels are queued (results: lcs_batch_collect);
+ * used round-robin over two or three contexts the PCIe transfer of batch i + 1 runs under the kernels of batch i.
+ * The copy is a DMA straight from the caller's memory when that memory is page-locked (lcs_host_alloc); any other
+ * pointer is staged through pinned slots inside the call (correct, but bounded by a CPU memcpy). */
 int lcs_search_batch_host(lcs_ctx *ctx, const void *h_capbufs, int fmt, int n_buf, uint32_t n_cap,
                           const double *f_search_set, uint16_t n_f, const double *fc_requested,
                           const double *fc_programmed, double fs_programmed, int stage_mask,
                           lcs_cell *cells, int max_cells_per_buf, int *n_cells);
+int lcs_batch_enqueue_host(lcs_ctx *ctx, const void *h_capbufs, int fmt, int n_buf, uint32_t n_cap,
+                           const double *f_search_set, uint16_t n_f, const double *fc_requested,
+                           const double *fc_programmed, double fs_programmed, int stage_mask);
+/* Page-locked host memory for capture buffers (freed with lcs_host_free before the context is destroyed). */
+int lcs_host_alloc(lcs_ctx *ctx, size_t bytes, void **out);
+int lcs_host_free(lcs_ctx *ctx, void *p);
+/* Number of usable GPUs (0 without one): a sweep driver creates one context per device and shards the carriers
+ * (host/CellSearch.cpp -g all; src/CellSearch.cpp:471-569 is the loop being sharded). */
+int lcs_device_count(void);
 
 /* Enqueue-only variant for timing: same work, results stay on the device until
  * lcs_batch_collect.  Between enqueue and collect nothing synchronises with the host. */

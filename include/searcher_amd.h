@@ -211,6 +211,31 @@ class Searcher {
   }
   bool last_batch_overflowed() const { return overflowed_; }     // more cells than the arrays hold: results truncated
 
+  // The same in two halves, for drivers that keep several batches in flight (one Searcher per batch in flight, used
+  // round-robin): enqueue_batch_host returns once the copy and the kernels are queued, collect_batch waits for them.
+  // Buffers from host_alloc are page-locked and DMA'd in place (lcs_host_alloc); any other memory is staged.
+  void enqueue_batch_host(const void *h_capbufs, int fmt, int n_buf, uint32_t n_cap, const cn::vec &f_search_set,
+                          const std::vector<double> &fc_requested, const std::vector<double> &fc_programmed, double fs_programmed) {
+    check(lcs_batch_enqueue_host(h_, h_capbufs, fmt, n_buf, n_cap, f_search_set._data(), (uint16_t)f_search_set.length(),
+                                 &fc_requested[0], &fc_programmed[0], fs_programmed, LCS_STAGE_FULL));
+    pending_ = n_buf;
+  }
+  void collect_batch(std::vector<std::list<Cell> > &cells, int max_cells_per_buf = 16) {
+    const int n_buf = pending_;
+    std::vector<lcs_cell> out((size_t)n_buf * max_cells_per_buf);
+    std::vector<int> cnt(n_buf);
+    const int rc = lcs_batch_collect(h_, out.data(), max_cells_per_buf, cnt.data());
+    if (rc != LCS_OK && rc != LCS_ERR_OVERFLOW) check(rc);
+    overflowed_ = rc == LCS_ERR_OVERFLOW;
+    cells.assign(n_buf, std::list<Cell>());
+    for (int b = 0; b < n_buf; ++b)
+      for (int i = 0; i < cnt[b] && i < max_cells_per_buf; ++i) cells[b].push_back(Cell(out[(size_t)b * max_cells_per_buf + i]));
+    pending_ = 0;
+  }
+  void *host_alloc(size_t bytes) { void *p = 0; check(lcs_host_alloc(h_, bytes, &p)); return p; }
+  void host_free(void *p) { check(lcs_host_free(h_, p)); }
+  static int device_count() { return lcs_device_count(); }
+
   // LO calibration step of LTE-Tracker (src/LTE-Tracker.cpp:565-741) on one recorded buffer: search the
   // +-ppm grid shifted by the current correction (:586), keep the strongest decoded cell (:712-722) and
   // return its residual frequency offset; *correction_residual gets the factor of :724-731.  Returns
@@ -275,6 +300,7 @@ class Searcher {
   }
   lcs_ctx *h_;
   bool overflowed_ = false;
+  int pending_ = 0;
 };
 
 }  // namespace lcs

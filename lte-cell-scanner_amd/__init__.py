@@ -252,6 +252,34 @@ class Searcher:
         return [[cells[b * max_cells_per_buf + i].copy() for i in range(min(cnt[b], max_cells_per_buf))]
                 for b in range(n_buf)]
 
+    def host_alloc(self, n_bytes: int) -> np.ndarray:
+        """Page-locked host memory as a uint8 array (lcs_host_alloc): batch_enqueue_host DMAs from it without staging.
+        Keep the Searcher alive while the array is in use; host_free() releases it."""
+        p = C.c_void_p()
+        self._chk(self._lib.lcs_host_alloc(self._h, n_bytes, C.byref(p)), "lcs_host_alloc")
+        a = np.ctypeslib.as_array((C.c_uint8 * n_bytes).from_address(p.value))
+        self._pinned = getattr(self, "_pinned", {})
+        self._pinned[a.ctypes.data] = p
+        return a
+
+    def host_free(self, a: np.ndarray):
+        p = self._pinned.pop(a.ctypes.data)
+        self._chk(self._lib.lcs_host_free(self._h, p), "lcs_host_free")
+
+    def batch_enqueue_host(self, h_capbufs, fmt: int, n_buf: int, n_cap: int, f_search_set, fc_requested, fc_programmed,
+                           fs_programmed: float, stage_mask: int = STAGE_FULL):
+        """Asynchronous host-fed batch (lcs_batch_enqueue_host): returns once the copy and the kernels are queued;
+        results come from batch_collect / batch_collect_raw.  The array must stay untouched until then."""
+        a = h_capbufs if (isinstance(h_capbufs, np.ndarray) and h_capbufs.flags.c_contiguous) else np.ascontiguousarray(h_capbufs)
+        assert a.nbytes == n_buf * n_cap * (2 if fmt == FMT_IQ_U8 else 8)
+        f = np.ascontiguousarray(f_search_set, np.float64)
+        fr = np.ascontiguousarray(np.broadcast_to(np.asarray(fc_requested, np.float64), (n_buf,)))
+        fp_ = np.ascontiguousarray(np.broadcast_to(np.asarray(fc_programmed, np.float64), (n_buf,)))
+        self._keep = a
+        rc = self._lib.lcs_batch_enqueue_host(self._h, a.ctypes.data_as(C.c_void_p), fmt, n_buf, n_cap, _dp(f), f.size, _dp(fr),
+                                              _dp(fp_), fs_programmed, stage_mask)
+        self._chk(rc, "lcs_batch_enqueue_host")
+
     def search_batch(self, d_ptr: int, fmt: int, n_buf: int, n_cap: int, f_search_set, fc_requested, fc_programmed,
                      fs_programmed: float, stage_mask: int = STAGE_FULL, max_cells_per_buf: int = 16):
         self.batch_enqueue(d_ptr, fmt, n_buf, n_cap, f_search_set, fc_requested, fc_programmed, fs_programmed, stage_mask)
@@ -357,6 +385,11 @@ class Searcher:
 
     def sync(self):
         self._chk(self._lib.lcs_sync(self._h), "lcs_sync")
+
+
+def device_count() -> int:
+    """GPUs the library can use (lcs_device_count)."""
+    return capi.load().lcs_device_count()
 
 
 def kalibrate(searcher: "Searcher", capbuf, fc_requested: float, fc_programmed: float, fs_programmed: float,

@@ -64,7 +64,7 @@ EXPORTS = [
     "lcs_create", "lcs_destroy", "lcs_last_error", "lcs_version", "lcs_cell_init", "lcs_set_max_cells_in_flight",
     "lcs_xcorr_pss", "lcs_peak_search", "lcs_sss_detect", "lcs_pss_sss_foe", "lcs_extract_tfg", "lcs_tfoec",
     "lcs_decode_mib", "lcs_chan_est", "lcs_search_capbuf", "lcs_search_batch_dev", "lcs_search_batch_host", "lcs_batch_enqueue",
-    "lcs_batch_collect", "lcs_batch_readback",
+    "lcs_batch_collect", "lcs_batch_readback", "lcs_batch_enqueue_host", "lcs_host_alloc", "lcs_host_free", "lcs_device_count",
     "lcs_track_block", "lcs_track_stats", "lcs_stream_open", "lcs_stream_push", "lcs_stream_collect", "lcs_stream_close",
     "lcs_last_xcorr_ms", "lcs_last_xcorr_info", "lcs_stream", "lcs_sync", "lcs_table_pss_td", "lcs_table_pss_fd", "lcs_table_sss_fd",
     "lcs_table_lte_pn", "lcs_chi2cdf_inv",
@@ -118,6 +118,10 @@ def load() -> C.CDLL:
     L.lcs_search_batch_host.argtypes = L.lcs_search_batch_dev.argtypes
     L.lcs_batch_readback.argtypes = [vp, C.c_int, fp, dp, ip, dp, dp]
     L.lcs_batch_enqueue.argtypes = [vp, vp, C.c_int, C.c_int, C.c_uint32, dp, C.c_uint16, dp, dp, C.c_double, C.c_int]
+    L.lcs_batch_enqueue_host.argtypes = L.lcs_batch_enqueue.argtypes
+    L.lcs_host_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
+    L.lcs_host_free.argtypes = [vp, vp]
+    L.lcs_device_count.argtypes = []
     L.lcs_batch_collect.argtypes = [vp, cp, C.c_int, C.POINTER(C.c_int)]
     L.lcs_track_block.argtypes = [vp, C.POINTER(LcsTrackCell), C.c_int, C.c_int, vp, C.c_int, dp, dp, dp, C.c_double, C.c_double, C.c_double,
                                   dp, dp, dp, ip, dp, C.c_int, ip, ip, C.POINTER(C.c_uint64), C.c_int, C.POINTER(C.c_float)]

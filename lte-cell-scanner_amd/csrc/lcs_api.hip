@@ -171,6 +171,31 @@ XcGeom pack_grid(uint32_t n_cap, int n_f, int ds, const double *fset, const doub
 constexpr int kMaxTapsI8 = 32 * LCS_I8_KB;                               // int8 kernel: 5 blocks of 32 taps
 constexpr int kMaxTapsF32 = 2 * (LCS_KP2_MAX - LCS_KP2_UNROLL);          // fp32 kernel: 124 tap pairs
 
+// complex<double> host buffer -> device (cap64, slot 0) and the choice of the correlation kernel: a buffer whose every
+// component is exactly (u8 - 127) / 128 -- any dongle capture -- takes the int8 kernel, anything else the fp32 one.
+// Returns the geometry to correlate with; c->use_i8 is set accordingly.
+int upload_host_capbuf(lcs_ctx *c, const double *capbuf, uint32_t n_cap, const double *f_search_set, int n_f, int ds, double fc_req,
+                       double fc_prog, double fs_prog, bool debug, XcGeom *geo_out) {
+  const XcGeom geo32 = pack_grid(n_cap, n_f, ds, f_search_set, &fc_req, &fc_prog, 1, fs_prog, kMaxTapsF32);
+  const XcGeom geo8 = pack_grid(n_cap, n_f, ds, f_search_set, &fc_req, &fc_prog, 1, fs_prog, kMaxTapsI8);
+  int rc;
+  if ((rc = ensure_ws(c, 1, n_cap, n_f, debug, std::max(geo32.G, geo8.G)))) return rc;
+  // the int8 copies cannot be (re)allocated under an open stream's graph: such a context keeps the fp32 kernel
+  const bool can_i8 = c->i8_ready || !c->st_open;
+  if (can_i8 && (rc = ensure_i8(c))) return rc;
+  c->h_params = SlotParams{fc_req, fc_prog, fs_prog};
+  HIPCHK(c, hipMemcpyAsync(c->cap64, capbuf, sizeof(double2) * n_cap, hipMemcpyHostToDevice, c->stream));
+  c->cap64_valid = true;
+  HIPCHK(c, hipMemcpyAsync(c->fset, f_search_set, sizeof(double) * n_f, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->params, &c->h_params, sizeof(SlotParams), hipMemcpyHostToDevice, c->stream));
+  bool exact = false;
+  if (can_i8) { if ((rc = lcs_launch_ingest_c128(c, n_cap, &exact))) return rc; }
+  else if ((rc = lcs_launch_ingest(c, nullptr, 2, 1, n_cap))) return rc;
+  c->use_i8 = exact;
+  *geo_out = exact ? geo8 : geo32;
+  return LCS_OK;
+}
+
 int check_common(lcs_ctx *c, uint32_t n_cap, int n_f) {
   if (!c) return LCS_ERR_BAD_ARG;
   if (n_f < 1 || n_f > LCS_NF_MAX) { c->err = "n_f out of range (1..128)"; return LCS_ERR_BAD_ARG; }
@@ -238,6 +263,7 @@ int lcs_create(int device, lcs_ctx **out) {
   uint32_t pn_jump[32];
   lcs_tables::pn_jump_table(1600 + 2 * (110 - 6), pn_jump);
   bool ok = hipMalloc((void **)&c->d_pss_td, td.size() * sizeof(double)) == hipSuccess &&
+            hipMalloc((void **)&c->d_flag, sizeof(int)) == hipSuccess &&
             hipMalloc((void **)&c->d_pn_jump, sizeof(pn_jump)) == hipSuccess &&
             hipMemcpy(c->d_pn_jump, pn_jump, sizeof(pn_jump), hipMemcpyHostToDevice) == hipSuccess &&
             hipMalloc((void **)&c->d_pss_fd, fd.size() * sizeof(double)) == hipSuccess &&
@@ -266,9 +292,13 @@ void lcs_destroy(lcs_ctx *c) {
                   c->cells_out, c->d_pss_td, c->d_pss_fd, c->d_sss_fd, c->d_pbch_scr, c->d_derm_inv, c->d_dbg, c->pk_items, c->n_pk,
                   c->sss_ws, c->d_pn_jump, c->cap8, c->cap8s, c->bt8, c->tq, c->tsc, c->h2d, c->trk_td, c->trk_syms, c->trk_raw, c->trk_ce,
                   c->trk_meta, c->trk_rs, c->trk_fmeta, c->trk_pw, c->trk_idx, c->trk_small, c->trk_cells, c->trk_acfd, c->trk_actd,
-                  c->trk_syncce, c->trk_sync};
+                  c->trk_syncce, c->trk_sync, c->d_flag};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+  for (int k = 0; k < 2; ++k) {
+    if (c->h_stage[k]) (void)hipHostFree(c->h_stage[k]);
+    if (c->ev_stage[k]) (void)hipEventDestroy(c->ev_stage[k]);
+  }
   if (c->ev_xc0) (void)hipEventDestroy(c->ev_xc0);
   if (c->ev_xc1) (void)hipEventDestroy(c->ev_xc1);
   if (c->ev_pre) (void)hipEventDestroy(c->ev_pre);
@@ -305,15 +335,8 @@ int lcs_xcorr_pss(lcs_ctx *c, const double *capbuf, uint32_t n_cap, const double
   if (ds_comb_arm > 8) { c->err = "ds_comb_arm > 8 is not supported (the reference uses 2)"; return LCS_ERR_BAD_ARG; }
   HIPCHK(c, hipSetDevice(c->device));
   const bool debug = incoh != nullptr;
-  const XcGeom geo = pack_grid(n_cap, n_f, ds_comb_arm, f_search_set, &fc_req, &fc_prog, 1, fs_prog, kMaxTapsF32);
-  if ((rc = ensure_ws(c, 1, n_cap, n_f, debug, geo.G))) return rc;
-  SlotParams p{fc_req, fc_prog, fs_prog};
-  HIPCHK(c, hipMemcpyAsync(c->cap64, capbuf, sizeof(double2) * n_cap, hipMemcpyHostToDevice, c->stream));
-  c->cap64_valid = true;
-  c->use_i8 = false;        // complex<double> input: fp32 correlation
-  HIPCHK(c, hipMemcpyAsync(c->fset, f_search_set, sizeof(double) * n_f, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->params, &p, sizeof(p), hipMemcpyHostToDevice, c->stream));
-  if ((rc = lcs_launch_ingest(c, nullptr, 2, 1, n_cap))) return rc;
+  XcGeom geo;
+  if ((rc = upload_host_capbuf(c, capbuf, n_cap, f_search_set, n_f, ds_comb_arm, fc_req, fc_prog, fs_prog, debug, &geo))) return rc;
   if ((rc = lcs_launch_xcorr(c, 1, geo, incoh != nullptr, false))) return rc;
   if ((rc = lcs_launch_single_layout(c, geo, 0, c->sref, 1))) return rc;
   const size_t NE = 3 * LCS_N_IDX;
@@ -473,11 +496,35 @@ int lcs_search_batch_dev(lcs_ctx *c, const void *d_capbufs, int fmt, int n_buf, 
   return lcs_batch_collect(c, cells, max_cells_per_buf, n_cells);
 }
 
-// Host-buffer form of lcs_search_batch_dev: the buffers are copied into a device staging area owned by the
-// context (u8 I/Q: 307 KB per buffer instead of the 2.46 MB of complex<double>) and then take the same path.
-int lcs_search_batch_host(lcs_ctx *c, const void *h_capbufs, int fmt, int n_buf, uint32_t n_cap, const double *f_search_set,
-                          uint16_t n_f, const double *fc_requested, const double *fc_programmed, double fs_programmed,
-                          int stage_mask, lcs_cell *cells, int max_cells_per_buf, int *n_cells) {
+// ---- host-fed batches ---------------------------------------------------------------------------------------------
+// What a caller holding recorded capbuf_NNNN.it files or dongle bytes uses (the carrier loop of src/CellSearch.cpp:471-569
+// with the captures in host memory).  The H2D copy is asynchronous on the context's stream: with two or three contexts
+// used round-robin (enqueue batch i + 1, then collect batch i) the PCIe transfer of one batch runs under the kernels of
+// the previous one.  That needs page-locked source memory: buffers from lcs_host_alloc are DMA'd in place; any other
+// pointer is staged through two pinned 4 MB slots owned by the context (CPU memcpy of chunk k + 1 under the DMA of
+// chunk k -- correct for every pointer, but then the CPU copy, ~10 GB/s, is what bounds the transfer).
+int lcs_device_count(void) {
+  int n = 0;
+  return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+
+int lcs_host_alloc(lcs_ctx *c, size_t bytes, void **out) {
+  if (!c || !out) return LCS_ERR_BAD_ARG;
+  *out = nullptr;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+  return LCS_OK;
+}
+
+int lcs_host_free(lcs_ctx *c, void *p) {
+  if (!c) return LCS_ERR_BAD_ARG;
+  if (p) HIPCHK(c, hipHostFree(p));
+  return LCS_OK;
+}
+
+int lcs_batch_enqueue_host(lcs_ctx *c, const void *h_capbufs, int fmt, int n_buf, uint32_t n_cap, const double *f_search_set,
+                           uint16_t n_f, const double *fc_requested, const double *fc_programmed, double fs_programmed,
+                           int stage_mask) {
   if (!c) return LCS_ERR_BAD_ARG;
   if (!h_capbufs || n_buf < 1 || (fmt != LCS_FMT_C64 && fmt != LCS_FMT_IQ_U8)) { c->err = "bad argument"; return LCS_ERR_BAD_ARG; }
   HIPCHK(c, hipSetDevice(c->device));
@@ -490,9 +537,38 @@ int lcs_search_batch_host(lcs_ctx *c, const void *h_capbufs, int fmt, int n_buf,
     HIPCHK(c, hipMalloc(&c->h2d, bytes));
     c->h2d_bytes = bytes;
   }
-  HIPCHK(c, hipMemcpyAsync(c->h2d, h_capbufs, bytes, hipMemcpyHostToDevice, c->stream));
-  return lcs_search_batch_dev(c, c->h2d, fmt, n_buf, n_cap, f_search_set, n_f, fc_requested, fc_programmed, fs_programmed,
-                              stage_mask, cells, max_cells_per_buf, n_cells);
+  hipPointerAttribute_t at;
+  const bool locked = hipPointerGetAttributes(&at, h_capbufs) == hipSuccess && at.type == hipMemoryTypeHost;
+  (void)hipGetLastError();        // an ordinary malloc'ed pointer makes the query fail: not an error here
+  if (locked) {
+    HIPCHK(c, hipMemcpyAsync(c->h2d, h_capbufs, bytes, hipMemcpyHostToDevice, c->stream));
+  } else {
+    constexpr size_t CH = (size_t)4 << 20;
+    for (int k = 0; k < 2; ++k)
+      if (!c->h_stage[k]) {
+        HIPCHK(c, hipHostMalloc(&c->h_stage[k], CH, hipHostMallocDefault));
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_stage[k], hipEventDisableTiming));
+        HIPCHK(c, hipEventRecord(c->ev_stage[k], c->stream));
+      }
+    int k = 0;
+    for (size_t off = 0; off < bytes; off += CH, k ^= 1) {
+      const size_t n = std::min(CH, bytes - off);
+      HIPCHK(c, hipEventSynchronize(c->ev_stage[k]));          // the DMA that last read this slot is done
+      std::memcpy(c->h_stage[k], (const char *)h_capbufs + off, n);
+      HIPCHK(c, hipMemcpyAsync((char *)c->h2d + off, c->h_stage[k], n, hipMemcpyHostToDevice, c->stream));
+      HIPCHK(c, hipEventRecord(c->ev_stage[k], c->stream));
+    }
+  }
+  return lcs_batch_enqueue(c, c->h2d, fmt, n_buf, n_cap, f_search_set, n_f, fc_requested, fc_programmed, fs_programmed, stage_mask);
+}
+
+int lcs_search_batch_host(lcs_ctx *c, const void *h_capbufs, int fmt, int n_buf, uint32_t n_cap, const double *f_search_set,
+                          uint16_t n_f, const double *fc_requested, const double *fc_programmed, double fs_programmed,
+                          int stage_mask, lcs_cell *cells, int max_cells_per_buf, int *n_cells) {
+  const int rc = lcs_batch_enqueue_host(c, h_capbufs, fmt, n_buf, n_cap, f_search_set, n_f, fc_requested, fc_programmed,
+                                        fs_programmed, stage_mask);
+  if (rc) return rc;
+  return lcs_batch_collect(c, cells, max_cells_per_buf, n_cells);
 }
 
 // Debug readback: the xcorr_pss outputs of buffer `buf` of the last batch, in the reference's layouts.
@@ -692,16 +768,9 @@ int lcs_search_capbuf(lcs_ctx *c, const double *capbuf, uint32_t n_cap, const do
   if (rc) return rc;
   if (!capbuf || !f_search_set || !n_cells || (max_cells > 0 && !cells)) { c->err = "null argument"; return LCS_ERR_BAD_ARG; }
   HIPCHK(c, hipSetDevice(c->device));
-  const XcGeom geo = pack_grid(n_cap, n_f, 2, f_search_set, &fc_req, &fc_prog, 1, fs_prog, kMaxTapsF32);
-  if ((rc = ensure_ws(c, 1, n_cap, n_f, false, geo.G))) return rc;
+  XcGeom geo;
+  if ((rc = upload_host_capbuf(c, capbuf, n_cap, f_search_set, n_f, 2, fc_req, fc_prog, fs_prog, false, &geo))) return rc;
   if ((rc = ensure_percell(c))) return rc;
-  SlotParams p{fc_req, fc_prog, fs_prog};
-  HIPCHK(c, hipMemcpyAsync(c->cap64, capbuf, sizeof(double2) * n_cap, hipMemcpyHostToDevice, c->stream));
-  c->cap64_valid = true;
-  c->use_i8 = false;        // complex<double> input: fp32 correlation
-  HIPCHK(c, hipMemcpyAsync(c->fset, f_search_set, sizeof(double) * n_f, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->params, &p, sizeof(p), hipMemcpyHostToDevice, c->stream));
-  if ((rc = lcs_launch_ingest(c, nullptr, 2, 1, n_cap))) return rc;
   if ((rc = lcs_launch_xcorr(c, 1, geo, false, false))) return rc;
   if ((rc = lcs_launch_peak_search(c, 1, geo, std::pow(10.0, -12.0 / 10.0), true))) return rc;
   if ((rc = lcs_launch_sss_foe(c, 1, n_cap, 3.0, nullptr))) return rc;

@@ -181,6 +181,7 @@ struct lcs_ctx {
   uint32_t *d_pn_jump = nullptr;    // [32]: Gold-sequence jump-ahead by 1600 + 208 clocks (lcs_tables::pn_jump_table)
   int16_t *d_derm_inv = nullptr;    // [2][120][16]: for every coded bit (stream*40+col) the rate-matched PBCH bit positions carrying it (ascending, -1 padded)
   double *d_dbg = nullptr;          // debug outputs of the single-cell stage entry points
+  int *d_flag = nullptr;            // exactness verdict of k_ingest_c128
   bool percell_ready = false;
   // streaming mode (lcs_stream_*): the one-buffer, n_f = 1 chain captured once as a hipGraph; every
   // per-push input reaches the device through fixed pinned buffers, so the graph never changes
@@ -209,7 +210,9 @@ struct lcs_ctx {
   SlotParams h_params{};             // source of asynchronous parameter uploads of the single-buffer entry points
   void *h_pinned = nullptr;
   size_t h_pinned_bytes = 0;
-  void *h2d = nullptr;               // device staging of lcs_search_batch_host
+  void *h2d = nullptr;               // device staging of lcs_batch_enqueue_host
+  void *h_stage[2] = {nullptr, nullptr};        // pinned slots for host sources that are not page-locked
+  hipEvent_t ev_stage[2] = {nullptr, nullptr};
   size_t h2d_bytes = 0;
 
   // last batch bookkeeping
@@ -251,6 +254,7 @@ void pbch_deratematch_map(int n_e, uint8_t *out /*n_e*/);   // ref src/lte_lib.c
 // pss_xcorr.hip
 CapSrc lcs_cap_src(const lcs_ctx *c, uint32_t n_cap);   // which copy of the capture buffers the fp64 stages read
 int lcs_launch_ingest(lcs_ctx *c, const void *d_src, int fmt, int n_buf, uint32_t n_cap);
+int lcs_launch_ingest_c128(lcs_ctx *c, uint32_t n_cap, bool *exact);   // cap64 -> cap32 + int8 copies; exact: every component is (u8 - 127) / 128
 int lcs_launch_xcorr(lcs_ctx *c, int n_buf, const XcGeom &geo, bool want_incoh, bool time_it);
 int lcs_launch_single_layout(lcs_ctx *c, const XcGeom &geo, int slot, float *ref_layout, int to_ref);   // group-major <-> [t][idx][foi]
 // pss_xcorr_i8.hip

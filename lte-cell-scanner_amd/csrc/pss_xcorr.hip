@@ -95,6 +95,41 @@ __global__ __launch_bounds__(256) void k_ingest_u8(const uint8_t *__restrict__ s
   }
 }
 
+// fmt 2 with an exactness probe: a complex<double> buffer handed over by a host entry point (already in cap64).  A dongle
+// capture holds exactly (u8 - 127) / 128 per component (ref src/capbuf.cpp:172-181; src/LTE-Tracker.cpp:844-845): when
+// EVERY component of the buffer is k / 128 with an integer k in [-127, 128], the int8 pairs written here are the ones
+// k_ingest_u8 makes from the bytes and the buffer takes the int8 correlation kernel -- which is how the reference's own
+// call shape (searcher.h: cvec capbuf) reaches it.  Any other value raises *inexact and the caller correlates the fp32
+// copy written in the same pass.  One thread = 8 samples, as k_ingest_u8.
+__global__ __launch_bounds__(256) void k_ingest_c128(const double2 *__restrict__ cap64, uint32_t n_cap, float2 *__restrict__ cap32,
+                                                     uint16_t *__restrict__ cap8, uint16_t *__restrict__ cap8s, int *__restrict__ inexact) {
+  LCS_TAIL_PRIO();
+  const size_t stride = lcs_cap8_stride(n_cap);
+  bool bad = false;
+  for (size_t i0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 8; i0 < stride; i0 += (size_t)gridDim.x * blockDim.x * 8) {
+    uint32_t v[9];      // packed int8 pairs (127 - u8 = -k) of samples i0 .. i0 + 8
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+      uint32_t x = 0;
+      if (i0 + j < n_cap) {
+        const double2 s = cap64[i0 + j];
+        if (j < 8) cap32[i0 + j] = make_float2((float)s.x, (float)s.y);
+        const double kr = s.x * 128.0, ki = s.y * 128.0;          // exact: a power of two
+        const bool ok = kr == rint(kr) && ki == rint(ki) && kr >= -127.0 && kr <= 128.0 && ki >= -127.0 && ki <= 128.0;
+        if (ok) x = ((uint32_t)(-(int)kr) & 255u) | (((uint32_t)(-(int)ki) & 255u) << 8);
+        else bad = true;
+      }
+      v[j] = x;
+    }
+    uint4 a, b;
+    a.x = v[0] | (v[1] << 16); a.y = v[2] | (v[3] << 16); a.z = v[4] | (v[5] << 16); a.w = v[6] | (v[7] << 16);
+    b.x = v[1] | (v[2] << 16); b.y = v[3] | (v[4] << 16); b.z = v[5] | (v[6] << 16); b.w = v[7] | (v[8] << 16);
+    *reinterpret_cast<uint4 *>(cap8 + i0) = a;
+    *reinterpret_cast<uint4 *>(cap8s + i0) = b;
+  }
+  if (bad) atomicOr(inexact, 1);
+}
+
 // ------------------------------------------------------------------------- K0a: tables
 // Per slot: window start indices (ref :298), per-(window,group) first offset / tap-pair count,
 // and the frequency-shifted conjugated templates (ref :146-151, dsp.h:40-53).
@@ -596,6 +631,21 @@ CapSrc lcs_cap_src(const lcs_ctx *c, uint32_t n_cap) {
   else if (c->src_u8) s.c8 = c->cap8;
   else s.c32 = c->cap32;
   return s;
+}
+
+// complex<double> in cap64 (slot 0): fp32 copy + int8 copies + exactness verdict (one small readback: the caller picks
+// the correlation kernel from it).  Needs the int8 buffers (ensure_i8 in lcs_api.hip).
+int lcs_launch_ingest_c128(lcs_ctx *c, uint32_t n_cap, bool *exact) {
+  c->src_u8 = false;
+  HIPCHK(c, hipMemsetAsync(c->d_flag, 0, sizeof(int), c->stream));
+  const unsigned nb = (unsigned)((lcs_cap8_stride(n_cap) / 8 + 255) / 256);
+  hipLaunchKernelGGL(k_ingest_c128, dim3(nb), dim3(256), 0, c->stream, c->cap64, n_cap, c->cap32, c->cap8, c->cap8s, c->d_flag);
+  HIPCHK(c, hipGetLastError());
+  int flag = 1;
+  HIPCHK(c, hipMemcpyAsync(&flag, c->d_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  *exact = flag == 0;
+  return LCS_OK;
 }
 
 int lcs_launch_ingest(lcs_ctx *c, const void *d_src, int fmt, int n_buf, uint32_t n_cap) {

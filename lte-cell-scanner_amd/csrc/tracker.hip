@@ -484,6 +484,10 @@ extern "C" int lcs_track_block(lcs_ctx *c, lcs_track_cell *cells, int n_cells, i
   if (n_cells != c->trk_cells_cap || n_sym != c->trk_sym_cap) {      // workspace laid out for one block shape
     const size_t N = (size_t)n_cells * n_sym, C4 = (size_t)n_cells * 4;
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    // the caps describe a complete workspace or nothing: if an allocation below fails, later calls (and
+    // lcs_track_stats, which trusts them) must not take the half-replaced buffers for the old shape
+    c->trk_cells_cap = c->trk_sym_cap = 0;
+    c->trk_stat_cells = c->trk_stat_sym = 0;
     if ((rc = trk_alloc(c, &c->trk_td, N * 128)) || (rc = trk_alloc(c, &c->trk_meta, N * 4)) || (rc = trk_alloc(c, &c->trk_cells, (size_t)n_cells)) ||
         (rc = trk_alloc(c, &c->trk_syms, N * 72)) || (rc = trk_alloc(c, &c->trk_rs, (size_t)n_cells * 140 * 28)) ||
         (rc = trk_alloc(c, &c->trk_idx, C4 * (rs_cap + 1))) || (rc = trk_alloc(c, &c->trk_raw, C4 * rs_cap * 24)) ||
@@ -564,6 +568,7 @@ extern "C" int lcs_track_stats(lcs_ctx *c, int n_cells, int n_sym, double *ac_fd
   int rc;
   if (c->trk_stat_cells != n_cells || c->trk_stat_sym != n_sym) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->trk_stat_cells = c->trk_stat_sym = 0;
     if ((rc = trk_alloc(c, &c->trk_acfd, C4 * rs_cap * 12)) || (rc = trk_alloc(c, &c->trk_actd, C4 * rs_cap * 72)) ||
         (rc = trk_alloc(c, &c->trk_sync, (size_t)n_cells * hf_cap * 4)) || (rc = trk_alloc(c, &c->trk_syncce, (size_t)n_cells * hf_cap * 72)))
       return rc;

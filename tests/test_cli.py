@@ -142,3 +142,29 @@ def test_sweep_mixes_byte_exact_and_arbitrary_captures(tmp_path):
     # the same two cells are seen on carriers 0 and 2 (200 kHz apart: within the 1 MHz merge window); the stronger copy (carrier 0) stays
     table = r.stdout.split("CrystalCorrectionFactor\n")[1].splitlines()
     assert len(table) == 2 and all(re.match(r"^(277|271) 2  738\.9M", l) for l in table), table
+
+
+@pytest.mark.gpu
+def test_sharded_sweep_gives_the_same_report(tmp_path):
+    """`-g all` (one thread + two batches in flight per visible GPU, carriers block-cyclic in batches of -B) must print
+    exactly what the single-device, single-batch run prints: five carriers, batches of two -> three batches, the
+    recorded cells on carriers 0 and 3, a non-byte-exact capture in the middle, noise elsewhere."""
+    pkg = load_pkg()
+    g = golden("capbuf_0000")
+    it = __import__("importlib").import_module("lte_cell_scanner_amd.itfile")
+    cap = iq_u8_to_capbuf(g["iq_u8"])
+    rng = np.random.default_rng(6)
+    noise_u8 = np.clip(np.rint(rng.normal(127.0, 12.0, g["iq_u8"].size)), 0, 255).astype(np.uint8)
+    bufs = [cap, iq_u8_to_capbuf(noise_u8), 0.05 * (rng.normal(size=153600) + 1j * rng.normal(size=153600)),
+            np.roll(cap, 4000), iq_u8_to_capbuf(noise_u8[::-1].copy())]
+    for k, b in enumerate(bufs):
+        it.write_it(str(tmp_path / f"capbuf_{k:04d}.it"), {"capbuf": b, "fc": np.array([739000000 + 2000000 * k], np.int32)})
+    base = ["-s", "739.0e6", "-e", "739.4e6", "-l", "-d", str(tmp_path)]
+    one = _run(base)
+    assert one.returncode == 0, one.stderr
+    for extra in (["-g", "all", "-B", "2"], ["-g", "0", "-B", "1"], ["--gpu=all", "--batch", "3"]):
+        r = _run(base + extra)
+        assert r.returncode == 0, r.stderr
+        assert r.stdout == one.stdout, (extra, r.stdout, one.stdout)
+    assert one.stdout.count("Detected a cell!") == 4 and one.stdout.count("center frequency did not match") == 4
+    assert "could not parse gpu index" in _run(base + ["-g", "some"]).stderr
