@@ -30,15 +30,24 @@ def synth_buf(pkg):
 
 def test_power_of_two_scaling_is_exact(S, pkg, synth_buf):
     """xcorr is quadratic in the buffer: scaling the input by 2 scales every correlation power by
-    exactly 4 (power-of-two scaling commutes with fp32/fp64 rounding) and moves no decision."""
+    exactly 4 (power-of-two scaling commutes with fp32/fp64 rounding) and moves no decision.  Holds within one
+    correlation kernel: the halved and quartered captures are not (u8 - 127) / 128 any more, so both take the fp32
+    kernel (the byte-exact capture itself would take the int8 kernel, whose results agree to ~1e-7, not bit for bit)."""
     f = f_search_set_for(FC, 100)
     cap = pkg.synth.iq_u8_to_complex(synth_buf)
-    a = S.xcorr_pss(cap, f, 2, FC, FC, FS)
-    b = S.xcorr_pss(2.0 * cap, f, 2, FC, FC, FS)
+    a = S.xcorr_pss(0.25 * cap, f, 2, FC, FC, FS)
+    assert S.last_xcorr_info()[0].startswith("k_xcorr_mfma_blk")
+    b = S.xcorr_pss(0.5 * cap, f, 2, FC, FC, FS)
+    assert S.last_xcorr_info()[0].startswith("k_xcorr_mfma_blk")
     assert np.array_equal(b["single"], 4.0 * a["single"])
     assert np.array_equal(b["incoherent"], 4.0 * a["incoherent"])
     assert np.array_equal(b["pow"], 4.0 * a["pow"]) and np.array_equal(b["frq"], a["frq"])
     assert np.array_equal(b["sp_incoherent"], 4.0 * a["sp_incoherent"])
+    # and across the two kernels: the byte-exact capture (int8 kernel) against 16 x the quartered one (fp32 kernel)
+    c = S.xcorr_pss(cap, f, 2, FC, FC, FS)
+    assert S.last_xcorr_info()[0] == "k_xcorr_i8x3"
+    assert (np.abs(c["single"] - 16.0 * a["single"]) / c["single"]).max() < 2e-5
+    assert np.array_equal(c["sp_incoherent"], 16.0 * a["sp_incoherent"])
 
 
 def test_full_grid_is_repeatable(S, pkg, synth_buf):
