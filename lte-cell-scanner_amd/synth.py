@@ -280,15 +280,16 @@ def iq_u8_to_complex(iq):
     return ((f[0::2] - 127.0) / 128.0) + 1j * ((f[1::2] - 127.0) / 128.0)
 
 
-def make_batch_u8(n_buf, seed, fc_list, occupied_every=4, n_distinct=8):
+def make_batch_u8(n_buf, seed, fc_list, occupied_every=4, n_distinct=8, cells_cycle=(1, 2)):
     """Synthetic sweep: every `occupied_every`-th carrier holds 1-2 cells (SNR 0..10 dB, LO error within
     +-60 kHz), the others are noise only -- like a band scan where most raster points are empty.
     To keep host-side generation quick, `n_distinct` different occupied buffers are generated and
-    re-used cyclically with an independent circular time shift."""
+    re-used cyclically with an independent circular time shift.  cells_cycle: cells planted in the i-th distinct
+    occupied buffer, cyclically."""
     rng = np.random.default_rng(seed)
     occ = []
     for i in range(min(n_distinct, max(1, n_buf // occupied_every + 1))):
-        n_cells = 1 + (i % 2)
+        n_cells = int(cells_cycle[i % len(cells_cycle)])
         cells = [dict(n_id_1=int(rng.integers(0, 168)), n_id_2=int(rng.integers(0, 3)), cp_normal=bool(i % 5 != 4),
                       n_ports=int((1, 2, 2, 4)[i % 4]), n_rb_dl=int((6, 15, 25, 50, 75, 100)[i % 6]),
                       f_off=float(rng.uniform(-60e3, 60e3)), gain_db=-3.0 * j) for j in range(n_cells)]

@@ -159,3 +159,36 @@ def test_two_rank_sweep_real_searcher_shared_gpu(tmp_path):
     ja = json.loads([l for l in a.stdout.splitlines() if l.startswith("{")][-1])
     jb = json.loads([l for l in b.stdout.splitlines() if l.startswith("{")][-1])
     assert ja["cells"] == jb["cells"] and ja["carriers"] == jb["carriers"] == 24 and len(ja["cells"]) >= 3
+
+
+def test_bench_gpus_flag_must_match_the_launcher():
+    """bench.py --gpus N is the number of ranks: a launcher that started a different number is an error, not a silent
+    single-GPU run (`--gpus 8` used to time one GPU and print n_gpus 1).  No GPU needed: it exits first."""
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "the two must agree" in r.stderr
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_starts_two_ranks_itself():
+    """`python bench.py --gpus 2` with no launcher: bench.py re-executes itself through torch.distributed.run with two ranks
+    (here sharing GPU 0 over gloo, the only way two ranks fit a one-GPU box) and prints ONE line that says n_gpus 2, carries
+    both ranks' rates, and whose value is their sum over the slower rank's time."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu0", "--dist-backend", "gloo", "--steps", "2",
+                        "--warmup", "1", "--batch", "8", "--batches-per-step", "3", "--no-cpu-baseline", "--no-dense"], env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["verified"] is True and len(j["config"]["per_rank_buffers_per_s"]) == 2
+    assert j["config"]["buffers_timed"] == 2 * 8 * 3 * 2 and len(j["config"]["devices"]) == 2
+    assert j["value"] <= sum(j["config"]["per_rank_buffers_per_s"]) * 1.001
+    # without --share-gpu0 two ranks on a one-GPU box are refused (each rank must own a GPU)
+    import torch
+    if torch.cuda.device_count() == 1:
+        r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "8",
+                             "--batches-per-step", "2", "--no-cpu-baseline", "--no-dense"], env=env, capture_output=True, text=True, timeout=600)
+        assert r2.returncode != 0 and "GPU(s) visible" in (r2.stderr + r2.stdout)
