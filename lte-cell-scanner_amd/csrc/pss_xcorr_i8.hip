@@ -17,7 +17,7 @@
 // are 2 bytes, lanes start at any sample: LDS holds the window twice, the second copy shifted by one sample,
 // so that every lane reads 4 aligned dwords from the copy matching its parity.
 //
-// Tiling as in pss_xcorr_bf16.hip: 256-thread workgroup = 512 output positions x one 16-template group, 8
+// Tiling: 256-thread workgroup = 512 output positions x one 16-template group, 8
 // sub-tiles per wave; per window 3 digit passes x 5 tap blocks, fully unrolled; the window's B operands
 // (30 KB) sit in LDS next to the capture samples.  Digit 2 has its own int32 accumulator; digits 1
 // and 0 share one (shifted left by 8 between the passes), so int -> float conversion happens twice per

@@ -1,7 +1,8 @@
 """Streaming mode (BASELINE configs[4] / SURVEY 8f-2: LTE-Tracker's searcher thread,
 ref src/searcher_thread.cpp:83-246): the hipGraph-captured one-buffer chain must return exactly what
 the eager single-buffer entry point returns for the same buffer and the same single hypothesis, push
-after push, and must leave already-tracked cells undecoded."""
+after push, and must leave already-tracked cells undecoded.  (Graph vs the CPU oracle:
+tests/test_gpu_configs.py::test_stream_graph_against_oracle.)"""
 import numpy as np
 import pytest
 
@@ -17,7 +18,7 @@ def pkg():
     return load_pkg()
 
 
-def _key(c):     # u8 streams run the bf16 correlation kernel, the host entry point the fp32 one: pss_pow agrees to ~1e-7
+def _key(c):     # both sides run the int8 correlation kernel on these byte-exact buffers; pss_pow is left out of the key anyway
     return tuple(v for k, v in c.as_dict().items() if k != "pss_pow")
 
 
