@@ -13,7 +13,8 @@ for spec in sys.argv[2:]:
         j = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
         c, r = j["config"], j.get("roofline", {})
         line += (f"value {j['value']:9.0f}  ms/batch64 {1e3 * 64 / j['value']:.4f}  ms_per_batch {c.get('ms_per_batch', 0):.3f}  xc_in {r.get('kernel_ms', 0):.3f} "
-                 f"xc_iso {r.get('kernel_ms_isolated', 0):.3f}  verified {j.get('verified')}  step_ms {c.get('step_ms')}")
+                 f"xc_iso {r.get('kernel_ms_isolated', 0):.3f}  verified {j.get('verified')}  dense {(c.get('dense_band') or {}).get('ms_per_batch', 0):.3f}  "
+                 f"step_ms {'/'.join('%.1f' % v for v in (c.get('step_ms') or {}).values())}")
     except Exception as e:
         line += f"FAILED rc={p.returncode} {e!r} :: {p.stderr[-400:]!r}"
     line += f"  [{time.time() - t0:.0f}s]"
