@@ -289,6 +289,31 @@ int lcs_track_block(lcs_ctx *ctx, lcs_track_cell *cells, int n_cells, int n_sym,
 int lcs_track_stats(lcs_ctx *ctx, int n_cells, int n_sym, double *ac_fd, double *ac_td, int max_rs, double *sync, double *sync_ce,
                     int max_hf, int32_t *n_hf);
 
+/* Continuous form of lcs_track_block for callers that deliver a tracked cell's symbols block after block, as the reference's
+ * producer thread does (src/producer_thread.cpp:196-246 -> the per-cell fifo read at src/tracker_thread.cpp:823-1068).  The
+ * first call of a stream starts at slot 0 symbol 0 of a frame; every later call continues where the previous one ended
+ * (any n_sym >= 1, the same cells in the same order).  Nothing is lost at the cut: the three-symbol window of filter_ce
+ * (:176-201), the interpolation between filtered reference symbols (:383-477), the 72-deep history of do_ac_td (:343-371)
+ * and the four-frame PBCH fifo (:552-745) all see the previous blocks' symbols, because the context carries the inputs of the
+ * last 3-4 frames and processes them again in front of the new symbols (same kernels, so every row is bit-identical to
+ * what ONE lcs_track_block call over the whole stream returns).  Every output row is handed out exactly once, by the first
+ * call that can compute it, under its index in the whole stream:
+ *   syms      [n_cells][n_sym][72]: get_fd of the symbols of this call
+ *   meas, ac_fd, ac_td [n_cells][4][max_rs][9 | 12 | 72 complex]: the filtered reference symbols that became available (a
+ *             reference symbol's filter needs the NEXT one, so the last one of a block arrives with the next call); n_meas
+ *             [n_cells][4] rows; meas[.][0] is the symbol index counted from the start of the stream
+ *   ce, ce_pw [n_cells][4][ce_cap][72 complex | 4]: row r = symbol ce_from[cell][port] + r of the stream, ce_n rows
+ *   mib_ok, mib_bits [n_cells][max_off]: entry k = frame offset mib_from[cell] + k of the stream (frames o..o+3), n_mib entries
+ * cells[].bulk_phase_offset: in at the first call, out after every call.  Host td only.  lcs_track_stream_reset forgets the
+ * stream (the next call starts a new one).  The PSS/SSS statistics (do_pss_sss_sigpower_ce) have no state across symbols
+ * and stay with lcs_track_stats. */
+int lcs_track_stream_block(lcs_ctx *ctx, lcs_track_cell *cells, int n_cells, int n_sym, const void *td, const double *freq_off,
+                           const double *frame_timing, const double *late, double fc_requested, double fc_programmed,
+                           double fs_programmed, double *syms, double *ce, double *ce_pw, int ce_cap, int64_t *ce_from, int32_t *ce_n,
+                           double *meas, double *ac_fd, double *ac_td, int max_rs, int32_t *n_meas, int32_t *mib_ok,
+                           uint64_t *mib_bits, int max_off, int64_t *mib_from, int32_t *n_mib);
+int lcs_track_stream_reset(lcs_ctx *ctx);
+
 /* Stream the context launches on (hipStream_t as void*), for external event timing. */
 void *lcs_stream(lcs_ctx *ctx);
 int lcs_sync(lcs_ctx *ctx);

@@ -303,5 +303,55 @@ class Searcher {
   int pending_ = 0;
 };
 
+// ---- LTE-Tracker's scalar feedback recurrences (src/tracker_thread.cpp) -----------------------------------------------------
+// lcs_track_block / lcs_track_stream_block return, per filtered reference symbol, what the reference's tracker thread feeds
+// into its three slow loops; the loops themselves are a handful of flops per symbol and stay on the host.  `meas` rows are
+// LCS_TRK_MEAS doubles as lcs.h documents them (0 symbol index, 1 np, 2 tp, 3 sp_raw, 4 sp, 5 frequency_offset +
+// residual_f, 6 residual_f_np, 7 frame_timing + delay, 8 delay_np), walked in row order = symbol order of one port.
+namespace track {
+inline double wrap(double x, double lo, double hi) { return (x - lo) - (hi - lo) * std::floor((x - lo) / (hi - lo)) + lo; }   // include/macros.h:45-53
+
+// do_foe's update of the global frequency offset (:235-242)
+inline double fold_frequency_offset(double f, const double *meas, int n_rows) {
+  for (int r = 0; r < n_rows; ++r) {
+    const double *m = meas + (size_t)r * LCS_TRK_MEAS;
+    f = (f * (1 / .000001) + m[5] * (1 / m[6])) / (1 / .000001 + 1 / m[6]);
+  }
+  return f;
+}
+
+// do_toe_v2's update of the frame timing (:283-287)
+inline double fold_frame_timing(double t, const double *meas, int n_rows) {
+  for (int r = 0; r < n_rows; ++r) {
+    const double *m = meas + (size_t)r * LCS_TRK_MEAS;
+    double diff = wrap(m[7] - t, -19200.0 / 2, 19200.0 / 2);
+    diff = (0 * (1 / .0001) + diff * (1 / m[8])) / (1 / .0001 + 1 / m[8]);
+    t = (t + diff) - 19200.0 * std::floor((t + diff) / 19200.0);
+  }
+  return t;
+}
+
+// do_mib_decode's walk over the PBCH fifo (:552-745) when every frame offset has been tried in parallel: mib_ok codes as
+// lcs_track_block returns them (3 = CRC and fields match = lock, -1 = not attempted: the walk stops there).  A lock or a
+// synchronised failure consumes four frames, an unsynchronised failure one.
+struct MibLock {
+  double failures;
+  bool synchronized;
+  int attempts;
+  bool dropped;
+};
+inline MibLock mib_lock_walk(const int32_t *mib_ok, int n, double failures = 0.0, bool synchronized = false, double drop_threshold = 400.0) {
+  MibLock s = {failures, synchronized, 0, false};
+  for (int o = 0; o < n && mib_ok[o] != -1;) {
+    ++s.attempts;
+    if (mib_ok[o] == 3) { s.synchronized = true; s.failures = 0.0; o += 4; }
+    else if (s.synchronized) { s.failures += 1.0; o += 4; }
+    else { s.failures += 0.25; o += 1; }
+    if (s.failures >= drop_threshold) { s.dropped = true; break; }
+  }
+  return s;
+}
+}  // namespace track
+
 }  // namespace lcs
 #endif

@@ -323,6 +323,48 @@ class Searcher:
         out["gpu_ms"] = ms.value
         return out
 
+    def track_stream_block(self, cells, td, freq_off, frame_timing, late, fc_requested, fc_programmed, fs_programmed, want_stats=False):
+        """Continuous tracking (lcs_track_stream_block): the next block of a symbol stream.  `cells` as in track_block; the
+        objects' bulk_phase_offset attribute (if any) seeds the first call.  Returns a dict whose rows carry their index in
+        the whole stream: syms [c][n_sym][72]; meas [c][4][n_meas][9] (+ ac_fd, ac_td with want_stats); ce / ce_pw lists per
+        (cell, port) with ce_from; mib_ok / mib_bits lists per cell with mib_from."""
+        n_cells = len(cells)
+        if not hasattr(self, "_trk_stream_cells"):
+            tc = (capi.LcsTrackCell * n_cells)()
+            for i, c in enumerate(cells):
+                for f in ("n_id_1", "n_id_2", "cp_type", "n_ports", "n_rb_dl", "phich_duration", "phich_resource"):
+                    setattr(tc[i], f, int(getattr(c, f)))
+                tc[i].bulk_phase_offset = float(getattr(c, "bulk_phase_offset", 0.0))
+            self._trk_stream_cells = tc
+        tc = self._trk_stream_cells
+        fo = np.ascontiguousarray(freq_off, np.float64).reshape(n_cells, -1)
+        n_sym = fo.shape[1]
+        ft = np.ascontiguousarray(frame_timing, np.float64).reshape(n_cells, n_sym)
+        lt = np.ascontiguousarray(late, np.float64).reshape(n_cells, n_sym)
+        tdh = np.ascontiguousarray(td, np.complex128).reshape(n_cells, n_sym, 128)
+        max_rs, ce_cap, max_off = n_sym // 3 + 8, n_sym + 64, n_sym // 120 + 4
+        o = dict(syms=np.empty((n_cells, n_sym, 72), np.complex128), ce=np.full((n_cells, 4, ce_cap, 72), np.nan + 0j, np.complex128),
+                 ce_pw=np.full((n_cells, 4, ce_cap, 4), np.nan), ce_from=np.zeros((n_cells, 4), np.int64), ce_n=np.zeros((n_cells, 4), np.int32),
+                 meas=np.full((n_cells, 4, max_rs, 9), np.nan), n_meas=np.zeros((n_cells, 4), np.int32),
+                 ac_fd=np.full((n_cells, 4, max_rs, 12), np.nan + 0j, np.complex128) if want_stats else None,
+                 ac_td=np.full((n_cells, 4, max_rs, 72), np.nan + 0j, np.complex128) if want_stats else None,
+                 mib_ok=np.full((n_cells, max_off), -1, np.int32), mib_bits=np.zeros((n_cells, max_off), np.uint64),
+                 mib_from=np.zeros(n_cells, np.int64), n_mib=np.zeros(n_cells, np.int32))
+        i64 = lambda a: a.ctypes.data_as(C.POINTER(C.c_int64))
+        rc = self._lib.lcs_track_stream_block(self._h, tc, n_cells, n_sym, tdh.ctypes.data_as(C.c_void_p), _dp(fo), _dp(ft), _dp(lt),
+                                              fc_requested, fc_programmed, fs_programmed, _dp(o["syms"]), _dp(o["ce"]), _dp(o["ce_pw"]), ce_cap,
+                                              i64(o["ce_from"]), _ip(o["ce_n"]), _dp(o["meas"]), _dp(o["ac_fd"]), _dp(o["ac_td"]), max_rs,
+                                              _ip(o["n_meas"]), _ip(o["mib_ok"]), o["mib_bits"].ctypes.data_as(C.POINTER(C.c_uint64)), max_off,
+                                              i64(o["mib_from"]), _ip(o["n_mib"]))
+        self._chk(rc, "lcs_track_stream_block")
+        o["bpo"] = np.array([tc[i].bulk_phase_offset for i in range(n_cells)])
+        return o
+
+    def track_stream_reset(self):
+        self._chk(self._lib.lcs_track_stream_reset(self._h), "lcs_track_stream_reset")
+        if hasattr(self, "_trk_stream_cells"):
+            del self._trk_stream_cells
+
     def track_stats(self, n_cells, n_sym, want_ac_td=True):
         """Display statistics (do_ac_fd, do_ac_td, do_pss_sss_sigpower_ce) of the block the last track_block call
         processed; see lcs_track_stats in include/lcs.h.  -> dict(ac_fd [c][4][max_rs][12], ac_td [c][4][max_rs][72],

@@ -284,6 +284,7 @@ void lcs_destroy(lcs_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->st_open) (void)lcs_stream_close(c);
+  lcs_track_stream_free(c);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->stream_xc) (void)hipStreamSynchronize(c->stream_xc);
   void *ptrs[] = {c->cap32, c->cap64, c->params, c->fset, c->tmpl, c->start, c->smin, c->kp2, c->btab, c->single,

@@ -206,6 +206,7 @@ struct lcs_ctx {
   double2 *trk_acfd = nullptr, *trk_actd = nullptr, *trk_syncce = nullptr;   // lcs_track_stats outputs
   double *trk_sync = nullptr;
   int trk_stat_cells = 0, trk_stat_sym = 0;
+  void *trk_stream = nullptr;        // carried state of lcs_track_stream_block (tracker.hip)
   // host staging
   SlotParams h_params{};             // source of asynchronous parameter uploads of the single-buffer entry points
   void *h_pinned = nullptr;
@@ -249,6 +250,8 @@ void pn_jump_table(uint32_t steps, uint32_t out[32]);
 double chi2cdf_inv(double p, double k);
 void pbch_deratematch_map(int n_e, uint8_t *out /*n_e*/);   // ref src/lte_lib.cpp:409-463 via :473-478
 }  // namespace lcs_tables
+
+void lcs_track_stream_free(lcs_ctx *c);   // tracker.hip
 
 // ---- kernel launchers (one per .hip file) -------------------------------------------
 // pss_xcorr.hip

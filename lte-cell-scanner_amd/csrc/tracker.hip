@@ -613,3 +613,196 @@ extern "C" int lcs_track_stats(lcs_ctx *c, int n_cells, int n_sym, double *ac_fd
   if (rc) c->err = "more rows than the output arrays hold";
   return rc;
 }
+
+// ------------------------------------------------------------------------------------------ continuous tracking
+// The reference's tracker thread never stops: the three-symbol window of filter_ce (ref src/tracker_thread.cpp:176-201),
+// the interpolation between consecutive filtered reference symbols (:383-477), the 72-deep history of do_ac_td (:343-371)
+// and the four-frame fifo of do_mib_decode (:552-745) all reach across any boundary one could cut the symbol stream at.
+// lcs_track_block cuts it: each call starts from nothing.  lcs_track_stream_block removes the cut for a caller that
+// delivers a cell's symbols block after block: the context keeps the INPUTS (time-domain symbols and their metadata) of
+// the last three-to-four frames of every stream and the bulk phase at their first symbol, and every call processes
+// [carried frames ++ new symbols] as one block that starts at a frame boundary, with the same kernels -- so each output
+// row is computed exactly as a single call over the whole stream would compute it (nothing in the pipeline reaches back
+// further than the carried frames) -- and hands out only the rows no earlier call could: every filtered reference symbol,
+// channel-estimate row, autocorrelation row and MIB attempt exactly once, under its index in the whole stream.
+// The price is recomputing the carried frames (3-4 frames per call: x1.4 for 7-frame blocks).
+namespace {
+struct TrkStreamCell {
+  std::vector<double> td;                    // carried symbols [n_tail][128][2]
+  std::vector<double> fo, ft, late;          // their metadata
+  double bpo_before_tail = 0;                // bulk phase before the first carried symbol
+  long long tail_start = 0;                  // stream index of the first carried symbol (a frame boundary)
+  long long n_seen = 0;                      // symbols delivered so far
+  long long next_raw[4] = {1, 1, 1, 1};      // per port: reference-symbol row (counted from the stream start) whose filter is emitted next
+  long long ce_upto[4] = {0, 0, 0, 0};       // per port: channel estimates emitted for symbols below this
+  long long mib_next = 0;                    // first frame offset not attempted yet
+  int cp_type = 0, n_id_1 = -1, n_id_2 = -1, n_ports = 0;
+};
+struct TrkStream { std::vector<TrkStreamCell> cells; };
+}  // namespace
+
+void lcs_track_stream_free(lcs_ctx *c) {
+  delete static_cast<TrkStream *>(c->trk_stream);
+  c->trk_stream = nullptr;
+}
+
+extern "C" int lcs_track_stream_reset(lcs_ctx *c) {
+  if (!c) return LCS_ERR_BAD_ARG;
+  lcs_track_stream_free(c);
+  return LCS_OK;
+}
+
+extern "C" int lcs_track_stream_block(lcs_ctx *c, lcs_track_cell *cells, int n_cells, int n_sym, const void *td,
+                                      const double *freq_off, const double *frame_timing, const double *late, double fc_requested,
+                                      double fc_programmed, double fs_programmed, double *syms, double *ce, double *ce_pw, int ce_cap,
+                                      int64_t *ce_from, int32_t *ce_n, double *meas, double *ac_fd, double *ac_td, int max_rs,
+                                      int32_t *n_meas, int32_t *mib_ok, uint64_t *mib_bits, int max_off, int64_t *mib_from, int32_t *n_mib) {
+  if (!c) return LCS_ERR_BAD_ARG;
+  if (!cells || !td || !freq_off || !frame_timing || !late || n_cells < 1 || n_sym < 1 || max_rs < 0 || max_off < 0 || ce_cap < 0 ||
+      ((ce || ce_pw) && (!ce_from || !ce_n)) || ((meas || ac_fd || ac_td) && !n_meas) || ((mib_ok || mib_bits) && (!mib_from || !n_mib))) {
+    c->err = "bad argument";
+    return LCS_ERR_BAD_ARG;
+  }
+  TrkStream *st = static_cast<TrkStream *>(c->trk_stream);
+  if (!st) { st = new TrkStream(); c->trk_stream = st; }
+  if (st->cells.empty()) {
+    st->cells.resize(n_cells);
+    for (int i = 0; i < n_cells; ++i) {
+      TrkStreamCell &sc = st->cells[i];
+      sc.cp_type = cells[i].cp_type; sc.n_id_1 = cells[i].n_id_1; sc.n_id_2 = cells[i].n_id_2; sc.n_ports = cells[i].n_ports;
+      sc.bpo_before_tail = cells[i].bulk_phase_offset;
+    }
+  }
+  if ((int)st->cells.size() != n_cells) { c->err = "the stream was started with a different number of cells: lcs_track_stream_reset first"; return LCS_ERR_BAD_ARG; }
+  for (int i = 0; i < n_cells; ++i) {
+    const TrkStreamCell &sc = st->cells[i];
+    if (sc.cp_type != cells[i].cp_type || sc.n_id_1 != cells[i].n_id_1 || sc.n_id_2 != cells[i].n_id_2 || sc.n_ports != cells[i].n_ports) {
+      c->err = "a tracked cell changed identity inside a stream: lcs_track_stream_reset first";
+      return LCS_ERR_BAD_ARG;
+    }
+  }
+  const double *tdv = static_cast<const double *>(td);
+  int rc_all = LCS_OK;
+  // cells of one CP type carry the same number of frames: one extended block per CP type
+  for (int cp = LCS_CP_NORMAL; cp <= LCS_CP_EXTENDED; ++cp) {
+    std::vector<int> idx;
+    for (int i = 0; i < n_cells; ++i) if (cells[i].cp_type == cp) idx.push_back(i);
+    if (idx.empty()) continue;
+    const int G = (int)idx.size(), F = (cp == LCS_CP_NORMAL) ? 140 : 120, n_symb = F / 20;
+    const int n_tail = (int)(st->cells[idx[0]].n_seen - st->cells[idx[0]].tail_start);
+    const int L = n_tail + n_sym;
+    const long long T = st->cells[idx[0]].tail_start;
+    for (int g = 0; g < G; ++g)
+      if (st->cells[idx[g]].n_seen - st->cells[idx[g]].tail_start != n_tail || st->cells[idx[g]].tail_start != T) { c->err = "streams out of step"; return LCS_ERR_BAD_ARG; }
+    std::vector<lcs_track_cell> gc(G);
+    std::vector<double> x_td((size_t)G * L * 256), x_fo((size_t)G * L), x_ft((size_t)G * L), x_late((size_t)G * L);
+    for (int g = 0; g < G; ++g) {
+      const TrkStreamCell &sc = st->cells[idx[g]];
+      gc[g] = cells[idx[g]];
+      gc[g].bulk_phase_offset = sc.bpo_before_tail;
+      std::copy(sc.td.begin(), sc.td.end(), x_td.begin() + (size_t)g * L * 256);
+      std::copy(tdv + (size_t)idx[g] * n_sym * 256, tdv + (size_t)(idx[g] + 1) * n_sym * 256, x_td.begin() + ((size_t)g * L + n_tail) * 256);
+      auto join = [&](const std::vector<double> &tail, const double *fresh, std::vector<double> &out) {
+        std::copy(tail.begin(), tail.end(), out.begin() + (size_t)g * L);
+        std::copy(fresh + (size_t)idx[g] * n_sym, fresh + (size_t)(idx[g] + 1) * n_sym, out.begin() + (size_t)g * L + n_tail);
+      };
+      join(sc.fo, freq_off, x_fo); join(sc.ft, frame_timing, x_ft); join(sc.late, late, x_late);
+    }
+    const int rs_cap = L / 3 + 4, n_off = std::max(0, L / 120 - 3);
+    std::vector<double> o_syms(syms ? (size_t)G * L * 144 : 0), o_ce((ce || mib_ok) ? (size_t)G * 4 * L * 144 : 0), o_pw((ce_pw || ce) ? (size_t)G * 4 * L * 4 : 0);
+    std::vector<double> o_meas((size_t)G * 4 * rs_cap * LCS_TRK_MEAS);
+    std::vector<int32_t> o_upto((size_t)G * 4), o_nmeas((size_t)G * 4), o_ok((size_t)G * std::max(1, n_off));
+    std::vector<uint64_t> o_bits((size_t)G * std::max(1, n_off));
+    int rc = lcs_track_block(c, gc.data(), G, L, x_td.data(), 0, x_fo.data(), x_ft.data(), x_late.data(), fc_requested, fc_programmed, fs_programmed,
+                             syms ? o_syms.data() : nullptr, ce ? o_ce.data() : nullptr, (ce || ce_pw) ? o_pw.data() : nullptr, o_upto.data(),
+                             o_meas.data(), rs_cap, o_nmeas.data(), o_ok.data(), o_bits.data(), std::max(1, n_off), nullptr);
+    if (rc != LCS_OK) return rc;
+    std::vector<double> o_fd, o_tdc;
+    if (ac_fd || ac_td) {
+      if (ac_fd) o_fd.resize((size_t)G * 4 * rs_cap * 24);
+      if (ac_td) o_tdc.resize((size_t)G * 4 * rs_cap * 144);
+      rc = lcs_track_stats(c, G, L, ac_fd ? o_fd.data() : nullptr, ac_td ? o_tdc.data() : nullptr, rs_cap, nullptr, nullptr, 0, nullptr);
+      if (rc != LCS_OK && rc != LCS_ERR_OVERFLOW) return rc;      // no PSS/SSS rows were asked for: their overflow is of no concern
+    }
+    // the bulk phase before the first symbol of the NEXT carried tail = the value used at the symbol before it
+    const long long n_after = st->cells[idx[0]].n_seen + n_sym;
+    const long long T_next = std::max<long long>(0, (n_after - 3 * F) / F * F);
+    std::vector<double> bpo_at(G, 0.0);
+    if (T_next > T) {
+      const TrkLayout Lay(c, G, L);
+      for (int g = 0; g < G; ++g)
+        HIPCHK(c, hipMemcpy(&bpo_at[g], Lay.d_bpo + (size_t)g * L + (size_t)(T_next - T - 1), sizeof(double), hipMemcpyDeviceToHost));
+    }
+    for (int g = 0; g < G; ++g) {
+      const int i = idx[g];
+      TrkStreamCell &sc = st->cells[i];
+      cells[i].bulk_phase_offset = gc[g].bulk_phase_offset;
+      if (syms) std::memcpy(syms + (size_t)i * n_sym * 144, &o_syms[((size_t)g * L + n_tail) * 144], sizeof(double) * n_sym * 144);
+      for (int p = 0; p < 4; ++p) {
+        const size_t q = (size_t)g * 4 + p, Q = (size_t)i * 4 + p;
+        // filtered reference symbols: row r of the block is raw row r + 1 of the block = raw row (rows before T) + r + 1 of the stream
+        const long long rows_before = (T / F) * (p < 2 ? 40 : 20);
+        int emitted = 0;
+        for (int r = 0; r < o_nmeas[q]; ++r) {
+          const long long raw = rows_before + r + 1;
+          if (raw < sc.next_raw[p]) continue;
+          if (emitted < max_rs) {
+            if (meas) {
+              double *m = meas + (Q * max_rs + emitted) * LCS_TRK_MEAS;
+              std::memcpy(m, &o_meas[(q * rs_cap + r) * LCS_TRK_MEAS], sizeof(double) * LCS_TRK_MEAS);
+              m[0] += (double)T;                               // symbol index in the stream
+            }
+            if (ac_fd) std::memcpy(ac_fd + (Q * max_rs + emitted) * 24, &o_fd[(q * rs_cap + r) * 24], sizeof(double) * 24);
+            if (ac_td) std::memcpy(ac_td + (Q * max_rs + emitted) * 144, &o_tdc[(q * rs_cap + r) * 144], sizeof(double) * 144);
+          } else rc_all = LCS_ERR_OVERFLOW;
+          ++emitted;
+          sc.next_raw[p] = raw + 1;
+        }
+        if (n_meas) n_meas[Q] = std::min(emitted, max_rs);
+        // channel estimates: symbols [ce_upto, T + upto) are new
+        const long long upto = (o_upto[q] > 0) ? T + o_upto[q] : sc.ce_upto[p];
+        const long long from = sc.ce_upto[p];
+        const int n_new = (int)std::max<long long>(0, upto - from);
+        if (ce_from) ce_from[Q] = from;
+        if (ce_n) ce_n[Q] = std::min(n_new, ce_cap);
+        if (n_new > ce_cap && (ce || ce_pw)) rc_all = LCS_ERR_OVERFLOW;
+        for (int r = 0; r < std::min(n_new, ce_cap); ++r) {
+          const size_t src = q * L + (size_t)(from - T) + r;
+          if (ce) std::memcpy(ce + (Q * ce_cap + r) * 144, &o_ce[src * 144], sizeof(double) * 144);
+          if (ce_pw) std::memcpy(ce_pw + (Q * ce_cap + r) * 4, &o_pw[src * 4], sizeof(double) * 4);
+        }
+        if (upto > sc.ce_upto[p]) sc.ce_upto[p] = upto;
+      }
+      // MIB attempts: frame offset o of the block is offset T / F + o of the stream; an offset stays pending until it has been tried
+      int em = 0;
+      if (mib_from) mib_from[i] = sc.mib_next;
+      for (int o = 0; o < n_off; ++o) {
+        const long long og = T / F + o;
+        if (og < sc.mib_next) continue;
+        if (og > sc.mib_next || o_ok[(size_t)g * std::max(1, n_off) + o] == -1) break;
+        if (em < max_off) {
+          if (mib_ok) mib_ok[(size_t)i * max_off + em] = o_ok[(size_t)g * std::max(1, n_off) + o];
+          if (mib_bits) mib_bits[(size_t)i * max_off + em] = o_bits[(size_t)g * std::max(1, n_off) + o];
+        } else rc_all = LCS_ERR_OVERFLOW;
+        ++em;
+        sc.mib_next = og + 1;
+      }
+      if (n_mib) n_mib[i] = std::min(em, max_off);
+      // carry: whole frames from T_next on
+      sc.n_seen = n_after;
+      const size_t keep_from = (size_t)(T_next - T);
+      const size_t n_keep = (size_t)(n_after - T_next);
+      std::vector<double> ntd(n_keep * 256), nfo(n_keep), nft(n_keep), nlate(n_keep);
+      std::copy(x_td.begin() + ((size_t)g * L + keep_from) * 256, x_td.begin() + ((size_t)g * L + keep_from + n_keep) * 256, ntd.begin());
+      std::copy(x_fo.begin() + (size_t)g * L + keep_from, x_fo.begin() + (size_t)g * L + keep_from + n_keep, nfo.begin());
+      std::copy(x_ft.begin() + (size_t)g * L + keep_from, x_ft.begin() + (size_t)g * L + keep_from + n_keep, nft.begin());
+      std::copy(x_late.begin() + (size_t)g * L + keep_from, x_late.begin() + (size_t)g * L + keep_from + n_keep, nlate.begin());
+      sc.td.swap(ntd); sc.fo.swap(nfo); sc.ft.swap(nft); sc.late.swap(nlate);
+      if (T_next > T) sc.bpo_before_tail = bpo_at[g];
+      sc.tail_start = T_next;
+      (void)n_symb;
+    }
+  }
+  if (rc_all) c->err = "more rows than the output arrays hold (rows beyond the capacity were dropped)";
+  return rc_all;
+}

@@ -193,3 +193,54 @@ def test_gpu_track_block_shapes_and_errors(tracked):
         bad = pkg.new_cell(n_id_1=-1, n_id_2=1, cp_type=1, n_ports=2, n_rb_dl=50, phich_duration=1, phich_resource=3)
         with pytest.raises(pkg.SearcherError):
             S.track_block([bad], td[:280], fov[:280], ftv[:280], late[:280], FC, FC, FS)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cuts", [(490, 490), (300, 301, 379), (140, 840), (977, 3)])
+def test_gpu_track_stream_blocks_equal_one_block(tracked, cuts):
+    """lcs_track_stream_block: the 980 symbols of both golden cells delivered in pieces (cut anywhere, also in the middle
+    of a frame) must give, row for row and BIT FOR BIT, what one lcs_track_block call over all 980 symbols gives: the
+    filter window, the channel-estimate interpolation, the 72-deep ac_td history and the four-frame MIB fifo all reach
+    across the cuts (ref src/tracker_thread.cpp:176-201, 343-371, 383-477, 552-745)."""
+    pkg = load_pkg()
+    _, cells = tracked
+    recs = [c for c, *_ in cells]
+    td = np.stack([x[1] for x in cells]); late = np.stack([x[2] for x in cells])
+    ftv = np.stack([x[3] for x in cells]); fov = np.stack([x[4] for x in cells])
+    assert sum(cuts) == 980
+    with pkg.Searcher(0) as S:
+        one = S.track_block(recs, td, fov, ftv, late, FC, FC, FS)
+        st = S.track_stats(2, 980)
+        parts, a = [], 0
+        for n in cuts:
+            parts.append(S.track_stream_block(recs, td[:, a:a + n], fov[:, a:a + n], ftv[:, a:a + n], late[:, a:a + n], FC, FC, FS, want_stats=True))
+            a += n
+        # a second stream on the same context starts from scratch after a reset
+        S.track_stream_reset()
+        again = S.track_stream_block(recs, td[:, :cuts[0]], fov[:, :cuts[0]], ftv[:, :cuts[0]], late[:, :cuts[0]], FC, FC, FS)
+        assert np.array_equal(again["syms"], parts[0]["syms"])
+    assert np.array_equal(np.concatenate([p["syms"] for p in parts], axis=1), one["syms"])
+    assert np.array_equal(parts[-1]["bpo"], one["bpo"])
+    for i, c in enumerate(recs):
+        for p in range(4):
+            rows = np.concatenate([q["meas"][i, p, :q["n_meas"][i, p]] for q in parts])
+            n = one["n_meas"][i, p]
+            assert rows.shape[0] == n and np.array_equal(rows, one["meas"][i, p, :n]), (i, p)
+            if n:
+                fd = np.concatenate([q["ac_fd"][i, p, :q["n_meas"][i, p]] for q in parts])
+                tdc = np.concatenate([q["ac_td"][i, p, :q["n_meas"][i, p]] for q in parts])
+                assert np.array_equal(fd, st["ac_fd"][i, p, :n])
+                assert np.array_equal(tdc[71:], st["ac_td"][i, p, 71:n]) and np.isnan(tdc[:71].real).all()
+            # channel estimates: every symbol below ce_upto exactly once, in order
+            pos = 0
+            for q in parts:
+                assert q["ce_from"][i, p] == pos
+                k = q["ce_n"][i, p]
+                assert np.array_equal(q["ce"][i, p, :k], one["ce"][i, p, pos:pos + k]) and np.array_equal(q["ce_pw"][i, p, :k], one["ce_pw"][i, p, pos:pos + k])
+                pos += k
+            assert pos == one["ce_upto"][i, p]
+        ok = np.concatenate([q["mib_ok"][i, :q["n_mib"][i]] for q in parts])
+        bits = np.concatenate([q["mib_bits"][i, :q["n_mib"][i]] for q in parts])
+        tried = one["mib_ok"][i] != -1
+        assert np.array_equal(ok, one["mib_ok"][i][tried]) and np.array_equal(bits, one["mib_bits"][i][tried]) and 3 in list(ok)
+        assert [q["mib_from"][i] for q in parts] == list(np.cumsum([0] + [q["n_mib"][i] for q in parts[:-1]]))

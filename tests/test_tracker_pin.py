@@ -106,3 +106,36 @@ def test_mib_lock_walk_accepts_raw_codes():
     assert walk([False, False, True, False, False, False, True]) == (0.0, True, 4, False)    # booleans still work
     with pytest.raises(ValueError):
         walk(np.array([0.5, 1.0]))
+
+
+def test_cpp_tracker_recurrences_equal_the_python_ones(tmp_path):
+    """include/searcher_amd.h (lcs::track): fold_frequency_offset / fold_frame_timing / mib_lock_walk in C++, for a
+    reference-side caller that links the C ABI (ref src/tracker_thread.cpp:235-242, 283-287, 552-745) -- bit-identical to
+    lte-cell-scanner_amd/tracker.py on random measurement tables (no GPU: stub library symbols are never called)."""
+    import subprocess
+    from conftest import ROOT
+    import os
+    pkg = load_pkg()
+    exe = tmp_path / "track_host"
+    subprocess.check_call(["g++", "-O2", "-std=c++11", "-ffp-contract=off", "-o", str(exe), os.path.join(ROOT, "tests", "host", "track_host.cpp"),
+                           "-L" + os.path.join(ROOT, "lte-cell-scanner_amd"), "-llcs_amd", "-Wl,-rpath," + os.path.join(ROOT, "lte-cell-scanner_amd"),
+                           "-Wl,-rpath,/opt/rocm/lib"])
+    rng = np.random.default_rng(3)
+    for trial in range(4):
+        n = int(rng.integers(1, 300))
+        meas = np.zeros((n, 9))
+        meas[:, 0] = np.arange(n) * 3.5
+        meas[:, 5] = 35e3 + rng.normal(0, 30, n)
+        meas[:, 6] = rng.uniform(1e-3, 5.0, n)
+        meas[:, 7] = (15000.0 + rng.normal(0, 0.4, n) + (19190.0 if trial == 3 else 0.0)) % 19200.0
+        meas[:, 8] = rng.uniform(1e-3, 0.5, n)
+        codes = rng.choice(np.array([-1, 0, 1, 2, 3], np.int32), size=int(rng.integers(1, 40)), p=[0.03, 0.5, 0.1, 0.1, 0.27])
+        f0, t0 = 35010.0, 14999.5
+        inp = f"{f0!r} {t0!r} {n}\n" + " ".join(repr(float(v)) for v in meas.reshape(-1)) + f"\n{codes.size}\n" + " ".join(str(int(v)) for v in codes) + "\n"
+        out = subprocess.run([str(exe)], input=inp, capture_output=True, text=True, timeout=60)
+        assert out.returncode == 0, out.stderr
+        got = out.stdout.split()
+        assert float(got[0]) == pkg.tracker.fold_frequency_offset(f0, meas)
+        assert float(got[1]) == pkg.tracker.fold_frame_timing(t0, meas)
+        fl, sy, at, dr = pkg.tracker.mib_lock_walk(codes)
+        assert (float(got[2]), bool(int(got[3])), int(got[4]), bool(int(got[5]))) == (fl, sy, at, dr)
