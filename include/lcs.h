@@ -225,13 +225,33 @@ int lcs_last_xcorr_ms(lcs_ctx *ctx, float *ms, int *n_launches);
  * padding included) those launches executed -- 0 when the kernel does not count them.  For bench.py's
  * roofline.frac_executed. */
 int lcs_last_xcorr_info(lcs_ctx *ctx, double *executed_ops, const char **kernel);
+/* ---- one capture buffer, frequency hypotheses split over GPUs ("latency mode") ----------------------------
+ * a1 / a3 / a4 (src/searcher.cpp:113-347) are independent per hypothesis; the hypotheses meet only where xc_peak_freq takes
+ * the maximum over the frequency axis (:369-382).  Every rank calls lcs_foe_partial with the whole f_search_set and its
+ * contiguous share [f_first, f_first + f_count) (f_count may be 0); d_words (DEVICE memory of the caller, 3 x 9600 int64)
+ * receives, per position, (bits(pow as float) << 32) | (0xFFFFFFFF - global hypothesis index): non-negative floats order
+ * like their bit patterns and the complemented index makes the LOWEST hypothesis win a tie, as the reference's strict > does
+ * (:374).  d_meta (DEVICE, 9601 doubles) receives sp_incoherent and n_comb_xc.  The caller all-reduces d_words with MAX
+ * (RCCL: ncclMax on int64) and broadcasts rank 0's d_meta, both in place on the device, then every rank calls
+ * lcs_foe_finish with the reduced buffers: peak_search runs identically everywhere; sss_detect .. decode_mib run for the
+ * peaks whose winning hypothesis the rank owns (only it holds the xc_incoherent_single slice the refinement of `ind`
+ * reads, :457-465).  cells / order: the rank's decoded cells and their positions in the peak list -- the caller gathers
+ * them and sorts by `order` to get the reference's list.  peaks (nullable): the whole peak list; entries won by another
+ * rank have ind = -1 and reserved = 1. */
+int lcs_foe_partial(lcs_ctx *ctx, const double *capbuf_re_im, uint32_t n_cap, const double *f_search_set, uint16_t n_f,
+                    int f_first, int f_count, double fc_requested, double fc_programmed, double fs_programmed,
+                    void *d_words /*device int64[3][9600]*/, double *d_meta /*device double[9601]*/);
+int lcs_foe_finish(lcs_ctx *ctx, const void *d_words, const double *d_meta, const double *f_search_set, uint16_t n_f,
+                   lcs_cell *cells, int32_t *order, int max_cells, int *n_cells, lcs_cell *peaks, int max_peaks, int *n_peaks);
+
 /* ---- streaming mode: LTE-Tracker's searcher thread (src/searcher_thread.cpp:83-246) ----------
  * One 80 ms capture buffer at a time, a single frequency hypothesis (the tracked frequency offset,
  * :97-98), cells whose identity is already tracked are reported as re-detected and not decoded again
- * (:157-177).  lcs_stream_open captures the whole chain once as a hipGraph; lcs_stream_push copies
- * the HOST buffer (fmt LCS_FMT_C64: n_cap complex<float>, LCS_FMT_IQ_U8: 2*n_cap bytes) into pinned
- * memory and replays the graph asynchronously; lcs_stream_collect waits for it and returns the NEW
- * cells (SSS and MIB decoded), the number of tracked cells seen again and the GPU time of the pass.
+ * (:157-177).  lcs_stream_open captures the whole chain as a hipGraph (twice: one graph per pinned input slot);
+ * lcs_stream_push copies the HOST buffer (fmt LCS_FMT_C64: n_cap complex<float>, LCS_FMT_IQ_U8: 2*n_cap bytes) into
+ * pinned memory and replays the graph asynchronously -- up to TWO buffers may be in flight, so the host fills and
+ * launches buffer i + 1 while buffer i is on the GPU; lcs_stream_collect waits for the OLDEST buffer in flight and
+ * returns its NEW cells (SSS and MIB decoded), the number of tracked cells seen again and the GPU time of the pass.
  * frame_start is in samples of the pushed buffer; the tracker's 1.92 MHz time base is
  * frame_start*(FS_LTE/16)/(fs_programmed*k_factor) + capture latency (:224).
  * While a stream is open the captured graph holds the context's workspace addresses: any other call on the

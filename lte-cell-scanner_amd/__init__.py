@@ -202,6 +202,25 @@ class Searcher:
         self._chk(rc, "lcs_search_capbuf")
         return [cells[i].copy() for i in range(min(n.value, max_cells))], [peaks[i].copy() for i in range(min(npk.value, 64))]
 
+    # ---- one buffer, hypotheses split over GPUs (lcs_foe_*; driver: sweep.search_capbuf_foe_split_dev) ----
+    def foe_partial(self, capbuf, f_search_set, f_first: int, f_count: int, fc_requested, fc_programmed, fs_programmed,
+                    d_words_ptr: int, d_meta_ptr: int):
+        cap = np.ascontiguousarray(capbuf, np.complex128)
+        f = np.ascontiguousarray(f_search_set, np.float64)
+        self._chk(self._lib.lcs_foe_partial(self._h, _dp(cap), cap.size, _dp(f), f.size, int(f_first), int(f_count), fc_requested,
+                                            fc_programmed, fs_programmed, C.c_void_p(d_words_ptr), C.c_void_p(d_meta_ptr)), "lcs_foe_partial")
+
+    def foe_finish(self, d_words_ptr: int, d_meta_ptr: int, f_search_set, max_cells: int = 64):
+        """-> (cells this rank decoded, their positions in the peak list, the whole peak list)"""
+        f = np.ascontiguousarray(f_search_set, np.float64)
+        cells, peaks = (LcsCell * max_cells)(), (LcsCell * 64)()
+        order = np.zeros(max_cells, np.int32)
+        n, npk = C.c_int(0), C.c_int(0)
+        rc = self._lib.lcs_foe_finish(self._h, C.c_void_p(d_words_ptr), C.c_void_p(d_meta_ptr), _dp(f), f.size, cells, _ip(order), max_cells,
+                                      C.byref(n), peaks, 64, C.byref(npk))
+        self._chk(rc, "lcs_foe_finish")
+        return [cells[i].copy() for i in range(n.value)], order[:n.value].copy(), [peaks[i].copy() for i in range(min(npk.value, 64))]
+
     # ---- batched, device-resident ---------------------------------------------------
     def batch_enqueue(self, d_ptr: int, fmt: int, n_buf: int, n_cap: int, f_search_set, fc_requested, fc_programmed,
                       fs_programmed: float, stage_mask: int = STAGE_FULL):

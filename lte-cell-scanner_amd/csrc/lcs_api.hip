@@ -39,6 +39,7 @@ XcGeom make_geo(uint32_t n_cap, int n_f, int ds, int cpg = LCS_TG) {
   g.G = (g.n_tmpl + cpg - 1) / cpg;
   g.n_comb = (int)((n_cap - 136 - 100) / 9600);   // ref src/searcher.cpp:276
   g.ds = ds;
+  g.foi0 = 0;
   return g;
 }
 
@@ -807,6 +808,87 @@ int lcs_search_capbuf(lcs_ctx *c, const double *capbuf, uint32_t n_cap, const do
   return rc;
 }
 
+// ------------------------------------------------------------------- one buffer, hypotheses split over GPUs
+// SURVEY 8e "latency mode": every rank correlates its contiguous share of f_search_set; the shares meet where the
+// reference takes the maximum over the frequency axis (src/searcher.cpp:369-382).  RCCL has no arg-max: the collapsed
+// power (a non-negative float: ordered like its bit pattern) and the complemented GLOBAL hypothesis index are packed
+// into one 64-bit word, (bits(pow) << 32) | (0xFFFFFFFF - foi), and an ordinary MAX all-reduce then reproduces the
+// reference's first-maximum rule (strict >: the lowest index wins a tie, :374).  The words never leave the GPUs:
+// lcs_foe_partial leaves them in a device buffer of the caller (a torch tensor handed to torch.distributed), the caller
+// all-reduces in place, lcs_foe_finish reads them back in, runs peak_search (identical on every rank) and the per-peak
+// stages, and reports the cells whose winning hypothesis this rank owns (it alone holds the xc_incoherent_single slice
+// the refinement of `ind` reads, :457-465).
+int lcs_foe_partial(lcs_ctx *c, const double *capbuf, uint32_t n_cap, const double *f_search_set, uint16_t n_f, int f_first, int f_count,
+                    double fc_req, double fc_prog, double fs_prog, void *d_words, double *d_meta) {
+  int rc = check_common(c, n_cap, n_f);
+  if (rc) return rc;
+  if (!capbuf || !f_search_set || !d_words || !d_meta || f_first < 0 || f_count < 0 || f_first + f_count > n_f) { c->err = "bad argument"; return LCS_ERR_BAD_ARG; }
+  HIPCHK(c, hipSetDevice(c->device));
+  c->foe_ready = false;
+  // a rank without hypotheses still takes part: it correlates one (the first) so that its buffer, tables and power
+  // estimate exist, and contributes words that never win
+  const int cnt = std::max(1, f_count), first = f_count ? f_first : 0;
+  XcGeom geo;
+  if ((rc = upload_host_capbuf(c, capbuf, n_cap, f_search_set + first, cnt, 2, fc_req, fc_prog, fs_prog, false, &geo))) return rc;
+  if ((rc = ensure_percell(c))) return rc;
+  if ((rc = lcs_launch_xcorr(c, 1, geo, false, false))) return rc;
+  geo.foi0 = f_count ? f_first : -1;            // -1: owns nothing
+  if ((rc = lcs_launch_foe_pack(c, geo, static_cast<long long *>(d_words), d_meta))) return rc;
+  HIPCHK(c, hipStreamSynchronize(c->stream));    // the caller's collective runs on another stream
+  c->foe_geo = geo;
+  c->foe_n_cap = n_cap;
+  c->foe_ready = true;
+  return LCS_OK;
+}
+
+int lcs_foe_finish(lcs_ctx *c, const void *d_words, const double *d_meta, const double *f_search_set, uint16_t n_f, lcs_cell *cells,
+                   int32_t *order, int max_cells, int *n_cells, lcs_cell *peaks, int max_peaks, int *n_peaks) {
+  if (!c) return LCS_ERR_BAD_ARG;
+  if (!c->foe_ready) { c->err = "lcs_foe_finish needs the lcs_foe_partial call of the same buffer first"; return LCS_ERR_BAD_ARG; }
+  if (!d_words || !d_meta || !f_search_set || !n_cells || (max_cells > 0 && (!cells || !order)) || n_f < 1 || n_f > LCS_NF_MAX) { c->err = "bad argument"; return LCS_ERR_BAD_ARG; }
+  HIPCHK(c, hipSetDevice(c->device));
+  c->foe_ready = false;
+  const XcGeom geo = c->foe_geo;
+  const uint32_t n_cap = c->foe_n_cap;
+  int rc;
+  // peak_search names the winning hypothesis by its GLOBAL index: the whole grid now, not this rank's share
+  HIPCHK(c, hipMemcpyAsync(c->fset, f_search_set, sizeof(double) * n_f, hipMemcpyHostToDevice, c->stream));
+  if ((rc = lcs_launch_foe_unpack(c, geo, static_cast<const long long *>(d_words), d_meta))) return rc;
+  if ((rc = lcs_launch_peak_search(c, 1, geo, std::pow(10.0, -12.0 / 10.0), true))) return rc;
+  if ((rc = lcs_launch_sss_foe(c, 1, n_cap, 3.0, nullptr))) return rc;
+  c->needed_rows_only = true;
+  if ((rc = lcs_launch_gather_work(c, 1, 0))) return rc;
+  if ((rc = lcs_launch_tfg(c, n_cap, true))) return rc;
+  if ((rc = lcs_launch_tfoec(c, 0))) return rc;
+  if ((rc = lcs_launch_mib(c, 0))) return rc;
+  if ((rc = lcs_launch_scatter_back(c))) return rc;
+  std::vector<lcs_cell> tmp(LCS_MAXP);
+  int np = 0;
+  HIPCHK(c, hipMemcpyAsync(tmp.data(), c->peaks, sizeof(lcs_cell) * LCS_MAXP, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(&np, c->npeaks, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  rc = LCS_OK;
+  if (np > LCS_MAXP) { np = LCS_MAXP; rc = LCS_ERR_OVERFLOW; }
+  int n = 0;
+  for (int i = 0; i < np; ++i) {
+    const bool mine = tmp[i].reserved == 0;                   // the fused peak search marks peaks won by another rank's hypothesis
+    if (peaks && i < max_peaks) {
+      lcs_cell pk;
+      lcs_cell_init(&pk);
+      pk.fc_requested = tmp[i].fc_requested; pk.fc_programmed = tmp[i].fc_programmed; pk.pss_pow = tmp[i].pss_pow;
+      pk.ind = mine ? tmp[i].ind : -1; pk.freq = tmp[i].freq; pk.n_id_2 = tmp[i].n_id_2; pk.reserved = tmp[i].reserved;
+      peaks[i] = pk;
+    }
+    if (!mine || tmp[i].n_id_1 == -1 || tmp[i].n_rb_dl == -1) continue;
+    if (n < max_cells) { cells[n] = tmp[i]; order[n] = i; } else rc = LCS_ERR_OVERFLOW;
+    ++n;
+  }
+  if (n_peaks) *n_peaks = np;
+  *n_cells = n;
+  if (rc) c->err = "more results than the output arrays hold";
+  return rc;
+}
+
 // ---------------------------------------------------------------------------- streaming mode
 // LTE-Tracker's searcher thread (ref src/searcher_thread.cpp:83-246) runs the whole chain on every
 // 80 ms capture buffer with a single frequency hypothesis (the tracked frequency offset, :97-98) and
@@ -815,12 +897,13 @@ int lcs_search_capbuf(lcs_ctx *c, const double *capbuf, uint32_t n_cap, const do
 // pushes (samples, frequency offset, tracked identities) travels through fixed pinned host buffers
 // that the graph's copy nodes read at execution time.
 namespace {
-int stream_chain(lcs_ctx *c) {
-  StreamHost *h = c->st_host;
+// the chain as slot k sees it: its own pinned input buffer and parameter / result block, the shared device workspace
+int stream_chain(lcs_ctx *c, int k) {
+  StreamHost *h = c->st_host[k];
   const XcGeom geo = make_geo(c->st_n_cap, 1, 2);
   int rc;
   c->use_i8 = c->st_fmt == LCS_FMT_IQ_U8;      // one hypothesis: no window-start spread, the int8 kernel always fits
-  HIPCHK(c, hipMemcpyAsync(c->st_din, c->st_hin, c->st_in_bytes, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->st_din, c->st_hin[k], c->st_in_bytes, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->params, &h->p, sizeof(SlotParams), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->fset, &h->f, sizeof(double), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->st_dntracked, &h->n_tracked, sizeof(int), hipMemcpyHostToDevice, c->stream));
@@ -846,22 +929,28 @@ int lcs_stream_close(lcs_ctx *c) {
   if (!c) return LCS_ERR_BAD_ARG;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  if (c->st_exec) (void)hipGraphExecDestroy(c->st_exec);
-  if (c->st_graph) (void)hipGraphDestroy(c->st_graph);
-  if (c->st_hin) (void)hipHostFree(c->st_hin);
-  if (c->st_host) (void)hipHostFree(c->st_host);
+  for (int k = 0; k < 2; ++k) {
+    if (c->st_exec[k]) (void)hipGraphExecDestroy(c->st_exec[k]);
+    if (c->st_graph[k]) (void)hipGraphDestroy(c->st_graph[k]);
+    if (c->st_hin[k]) (void)hipHostFree(c->st_hin[k]);
+    if (c->st_host[k]) (void)hipHostFree(c->st_host[k]);
+    if (c->st_ev0[k]) (void)hipEventDestroy(c->st_ev0[k]);
+    if (c->st_ev1[k]) (void)hipEventDestroy(c->st_ev1[k]);
+    c->st_exec[k] = nullptr; c->st_graph[k] = nullptr; c->st_hin[k] = nullptr; c->st_host[k] = nullptr; c->st_ev0[k] = c->st_ev1[k] = nullptr;
+  }
   if (c->st_din) (void)hipFree(c->st_din);
   if (c->st_dtracked) (void)hipFree(c->st_dtracked);
   if (c->st_dntracked) (void)hipFree(c->st_dntracked);
-  if (c->st_ev0) (void)hipEventDestroy(c->st_ev0);
-  if (c->st_ev1) (void)hipEventDestroy(c->st_ev1);
-  c->st_exec = nullptr; c->st_graph = nullptr; c->st_hin = nullptr; c->st_host = nullptr; c->st_din = nullptr;
-  c->st_dtracked = nullptr; c->st_dntracked = nullptr; c->st_ev0 = c->st_ev1 = nullptr;
-  c->st_open = c->st_pending = false;
+  c->st_din = nullptr; c->st_dtracked = nullptr; c->st_dntracked = nullptr;
+  c->st_open = false;
+  c->st_head = c->st_count = 0;
   c->single_stream = false;
   return LCS_OK;
 }
 
+// Two slots: the chain is captured twice, once per pinned input buffer + parameter / result block, so that the host may
+// fill and launch buffer i + 1 while the graph of buffer i is still running (the launches themselves serialise on the
+// context's stream and share the device workspace).
 int lcs_stream_open(lcs_ctx *c, int fmt, uint32_t n_cap, double fc_requested, double fc_programmed, double fs_programmed) {
   int rc = check_common(c, n_cap, 1);
   if (rc) return rc;
@@ -874,59 +963,68 @@ int lcs_stream_open(lcs_ctx *c, int fmt, uint32_t n_cap, double fc_requested, do
   c->st_fmt = fmt;
   c->st_n_cap = n_cap;
   c->st_in_bytes = (size_t)n_cap * (fmt == LCS_FMT_IQ_U8 ? 2 : sizeof(float2));
-  HIPCHK(c, hipHostMalloc(&c->st_hin, c->st_in_bytes, hipHostMallocDefault));
-  HIPCHK(c, hipHostMalloc((void **)&c->st_host, sizeof(StreamHost), hipHostMallocDefault));
   HIPCHK(c, hipMalloc(&c->st_din, c->st_in_bytes));
-  HIPCHK(c, hipMalloc((void **)&c->st_dtracked, sizeof(c->st_host->tracked)));
+  HIPCHK(c, hipMalloc((void **)&c->st_dtracked, sizeof(c->st_host[0]->tracked)));
   HIPCHK(c, hipMalloc((void **)&c->st_dntracked, sizeof(int)));
-  HIPCHK(c, hipEventCreate(&c->st_ev0));
-  HIPCHK(c, hipEventCreate(&c->st_ev1));
-  std::memset(c->st_hin, fmt == LCS_FMT_IQ_U8 ? 127 : 0, c->st_in_bytes);
-  std::memset(c->st_host, 0, sizeof(StreamHost));
-  c->st_host->p = SlotParams{fc_requested, fc_programmed, fs_programmed};
+  for (int k = 0; k < 2; ++k) {
+    HIPCHK(c, hipHostMalloc(&c->st_hin[k], c->st_in_bytes, hipHostMallocDefault));
+    HIPCHK(c, hipHostMalloc((void **)&c->st_host[k], sizeof(StreamHost), hipHostMallocDefault));
+    HIPCHK(c, hipEventCreate(&c->st_ev0[k]));
+    HIPCHK(c, hipEventCreate(&c->st_ev1[k]));
+    std::memset(c->st_hin[k], fmt == LCS_FMT_IQ_U8 ? 127 : 0, c->st_in_bytes);
+    std::memset(c->st_host[k], 0, sizeof(StreamHost));
+    c->st_host[k]->p = SlotParams{fc_requested, fc_programmed, fs_programmed};
+  }
   c->cap64_valid = false;
   c->single_stream = true;
   c->st_open = true;
-  // one eager pass (lazy allocations, function attributes), then the same call sequence under capture
-  if ((rc = stream_chain(c))) { lcs_stream_close(c); return rc; }
+  c->st_head = c->st_count = 0;
+  // one eager pass (lazy allocations, function attributes), then the same call sequence under capture, per slot
+  if ((rc = stream_chain(c, 0))) { lcs_stream_close(c); return rc; }
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-  rc = stream_chain(c);
-  hipGraph_t g = nullptr;
-  const hipError_t e = hipStreamEndCapture(c->stream, &g);
-  if (rc || e != hipSuccess || !g) {
-    if (!rc) { c->err = std::string("hipStreamEndCapture: ") + hipGetErrorString(e); rc = LCS_ERR_HIP; }
-    lcs_stream_close(c);
-    return rc;
+  for (int k = 0; k < 2; ++k) {
+    HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+    rc = stream_chain(c, k);
+    hipGraph_t g = nullptr;
+    const hipError_t e = hipStreamEndCapture(c->stream, &g);
+    if (rc || e != hipSuccess || !g) {
+      if (!rc) { c->err = std::string("hipStreamEndCapture: ") + hipGetErrorString(e); rc = LCS_ERR_HIP; }
+      lcs_stream_close(c);
+      return rc;
+    }
+    c->st_graph[k] = g;
+    HIPCHK(c, hipGraphInstantiate(&c->st_exec[k], c->st_graph[k], nullptr, nullptr, 0));
   }
-  c->st_graph = g;
-  HIPCHK(c, hipGraphInstantiate(&c->st_exec, c->st_graph, nullptr, nullptr, 0));
   return LCS_OK;
 }
 
 int lcs_stream_push(lcs_ctx *c, const void *samples, double f_off, const int16_t *tracked_ids, int n_tracked) {
   if (!c || !c->st_open || !samples) { if (c) c->err = "stream not open"; return LCS_ERR_BAD_ARG; }
-  if (c->st_pending) { c->err = "previous buffer not collected"; return LCS_ERR_BAD_ARG; }
+  if (c->st_count >= 2) { c->err = "two buffers are in flight already: lcs_stream_collect first"; return LCS_ERR_BAD_ARG; }
   if (n_tracked < 0 || n_tracked > 504 || (n_tracked > 0 && !tracked_ids)) { c->err = "bad tracked list"; return LCS_ERR_BAD_ARG; }
   HIPCHK(c, hipSetDevice(c->device));
-  std::memcpy(c->st_hin, samples, c->st_in_bytes);
-  c->st_host->f = f_off;
-  c->st_host->n_tracked = n_tracked;
-  for (int i = 0; i < n_tracked; ++i) c->st_host->tracked[i] = tracked_ids[i];
-  HIPCHK(c, hipEventRecord(c->st_ev0, c->stream));
-  HIPCHK(c, hipGraphLaunch(c->st_exec, c->stream));
-  HIPCHK(c, hipEventRecord(c->st_ev1, c->stream));
-  c->st_pending = true;
+  const int k = (c->st_head + c->st_count) & 1;
+  std::memcpy(c->st_hin[k], samples, c->st_in_bytes);
+  c->st_host[k]->f = f_off;
+  c->st_host[k]->n_tracked = n_tracked;
+  for (int i = 0; i < n_tracked; ++i) c->st_host[k]->tracked[i] = tracked_ids[i];
+  HIPCHK(c, hipEventRecord(c->st_ev0[k], c->stream));
+  HIPCHK(c, hipGraphLaunch(c->st_exec[k], c->stream));
+  HIPCHK(c, hipEventRecord(c->st_ev1[k], c->stream));
+  ++c->st_count;
   return LCS_OK;
 }
 
+// Results of the OLDEST buffer in flight.
 int lcs_stream_collect(lcs_ctx *c, lcs_cell *cells, int max_cells, int *n_cells, int *n_redetected, float *gpu_ms) {
-  if (!c || !c->st_open || !c->st_pending || !n_cells || (max_cells > 0 && !cells)) { if (c) c->err = "nothing to collect"; return LCS_ERR_BAD_ARG; }
+  if (!c || !c->st_open || c->st_count < 1 || !n_cells || (max_cells > 0 && !cells)) { if (c) c->err = "nothing to collect"; return LCS_ERR_BAD_ARG; }
   HIPCHK(c, hipSetDevice(c->device));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  c->st_pending = false;
-  if (gpu_ms) HIPCHK(c, hipEventElapsedTime(gpu_ms, c->st_ev0, c->st_ev1));
-  const StreamHost *h = c->st_host;
+  const int k = c->st_head;
+  HIPCHK(c, hipEventSynchronize(c->st_ev1[k]));
+  c->st_head ^= 1;
+  --c->st_count;
+  if (gpu_ms) HIPCHK(c, hipEventElapsedTime(gpu_ms, c->st_ev0[k], c->st_ev1[k]));
+  const StreamHost *h = c->st_host[k];
   int rc = LCS_OK, n = 0;
   const int np = std::min(h->n_peaks, (int)LCS_MAXP);
   if (h->n_peaks > LCS_MAXP || h->n_work[1] > c->max_work) rc = LCS_ERR_OVERFLOW;

@@ -55,6 +55,7 @@ struct XcGeom {
   int G;        // ceil(n_tmpl / cpg)
   int n_comb;   // n_comb_xc
   int ds;       // ds_comb_arm
+  int foi0;     // hypothesis split over GPUs (lcs_foe_*): global index of this rank's first hypothesis; frq then holds GLOBAL indices
 };
 
 // int8 copies of a u8 capture buffer: slot stride in samples (a multiple of 8, so that every slot starts 16-byte
@@ -186,17 +187,19 @@ struct lcs_ctx {
   // streaming mode (lcs_stream_*): the one-buffer, n_f = 1 chain captured once as a hipGraph; every
   // per-push input reaches the device through fixed pinned buffers, so the graph never changes
   bool single_stream = false;        // launch everything on `stream`, no cross-stream events
-  bool st_open = false, st_pending = false;
+  bool st_open = false;
+  int st_head = 0, st_count = 0;                  // two slots: oldest buffer in flight, number in flight
   int st_fmt = 0;
   uint32_t st_n_cap = 0;
-  void *st_hin = nullptr, *st_din = nullptr;      // pinned / device copy of the pushed buffer
+  void *st_hin[2] = {nullptr, nullptr};           // pinned copies of the pushed buffers
+  void *st_din = nullptr;                         // device copy (shared: the graph launches serialise)
   size_t st_in_bytes = 0;
-  struct StreamHost *st_host = nullptr;           // pinned parameter + result block
+  struct StreamHost *st_host[2] = {nullptr, nullptr};   // pinned parameter + result blocks
   int16_t *st_dtracked = nullptr;
   int *st_dntracked = nullptr;
-  hipGraph_t st_graph = nullptr;
-  hipGraphExec_t st_exec = nullptr;
-  hipEvent_t st_ev0 = nullptr, st_ev1 = nullptr;
+  hipGraph_t st_graph[2] = {nullptr, nullptr};
+  hipGraphExec_t st_exec[2] = {nullptr, nullptr};
+  hipEvent_t st_ev0[2] = {nullptr, nullptr}, st_ev1[2] = {nullptr, nullptr};
   // tracker block pipeline (tracker.hip): workspace laid out for one (n_cells, n_sym) block shape
   double2 *trk_td = nullptr, *trk_syms = nullptr, *trk_raw = nullptr, *trk_ce = nullptr;
   double *trk_meta = nullptr, *trk_rs = nullptr, *trk_fmeta = nullptr, *trk_pw = nullptr;
@@ -225,6 +228,9 @@ struct lcs_ctx {
   int round_cells = LCS_MAX_WORK;    // max_work as it was when the last batch was enqueued
   int grid_items = 64;               // workgroups per work-list axis of the per-cell kernels (they loop over the list)
   XcGeom last_geo{};
+  XcGeom foe_geo{};                  // lcs_foe_partial -> lcs_foe_finish: this rank's share of the hypotheses
+  bool foe_ready = false;
+  uint32_t foe_n_cap = 0;
   hipEvent_t ev_xc0 = nullptr, ev_xc1 = nullptr;
   int last_xc_launches = 0;
   double last_xc_ops = 0;            // matrix-core operations (2 x MACs) the correlation launches of the last batch executed
@@ -267,6 +273,8 @@ int lcs_launch_xcorr_i8(lcs_ctx *c, hipStream_t sxc, const XcGeom &geo, int slot
 int lcs_launch_xc_debug(lcs_ctx *c, const XcGeom &geo);   // raw xc for slot 0 (debug output only)
 // peak_search.hip
 int lcs_launch_peak_search(lcs_ctx *c, int n_buf, const XcGeom &geo, double udb10_m12, bool fp32_exact);
+int lcs_launch_foe_pack(lcs_ctx *c, const XcGeom &geo, long long *d_words, double *d_meta);      // collapsed (pow, frq) -> packed words
+int lcs_launch_foe_unpack(lcs_ctx *c, const XcGeom &geo, const long long *d_words, const double *d_meta);
 // sss_foe.hip
 int lcs_launch_sss_foe(lcs_ctx *c, int n_buf, uint32_t n_cap, double thresh2_n_sigma, double *dbg /*device, nullable*/);
 int lcs_launch_sss_only(lcs_ctx *c, uint32_t n_cap, double thresh2_n_sigma, double *dbg);

@@ -192,10 +192,15 @@ __global__ __launch_bounds__(PSR_THREADS) __attribute__((amdgpu_waves_per_eu(3, 
         double best_pow = -INFINITY;
         int best_ind = -1;
         const int ds = geo.ds;
-        if (peak_ind - ds >= 0) {   // uint16 wrap of the reference loop variable, quirk Q2
+        // hypotheses split over GPUs (lcs_foe_*): fq holds global indices, this rank's xc_incoherent_single only its
+        // own share [foi0, foi0 + n_f): a peak won elsewhere is listed (the greedy loop must be the same everywhere)
+        // but not refined here
+        const int fl = fi - geo.foi0;
+        const bool mine = geo.foi0 >= 0 && fl >= 0 && fl < geo.n_f;
+        if (mine && peak_ind - ds >= 0) {   // uint16 wrap of the reference loop variable, quirk Q2
           for (int t = peak_ind - ds; t <= peak_ind + ds; ++t) {
             const int tw = t % LCS_N_IDX;
-            const int cc = fi * 3 + peak_n_id_2;
+            const int cc = fl * 3 + peak_n_id_2;
             const float sv = sg[((size_t)(cc / geo.cpg) * LCS_N_IDX + tw) * LCS_TG + (cc % geo.cpg)];
             if ((double)sv > best_pow) { best_pow = sv; best_ind = tw; }
           }
@@ -209,6 +214,7 @@ __global__ __launch_bounds__(PSR_THREADS) __attribute__((amdgpu_waves_per_eu(3, 
           c.ind = best_ind;
           c.freq = fset[fi];
           c.n_id_2 = peak_n_id_2;
+          c.reserved = mine ? 0 : 1;
           out[n] = c;
         }
       }
@@ -242,6 +248,53 @@ int lcs_launch_peak_search(lcs_ctx *c, int n_buf, const XcGeom &geo, double udb1
   } else
     hipLaunchKernelGGL(k_peak_search, dim3(n_buf), dim3(PS_THREADS), 0, c->stream, c->pow_, c->frq, c->zth, c->single,
                        c->fset, c->params, c->work, c->peaks, c->npeaks, geo, udb10_m12);
+  HIPCHK(c, hipGetLastError());
+  return LCS_OK;
+}
+
+
+// ------------------------------------------------------------ hypotheses split over GPUs: packed (pow, frq) words
+// word = (bits(pow as float) << 32) | (0xFFFFFFFF - global foi): a MAX all-reduce over ranks is the reference's
+// first-maximum rule over the whole frequency axis (lcs_api.hip: lcs_foe_partial).  meta = sp_incoherent[9600], n_comb_xc.
+__global__ __launch_bounds__(256) void k_foe_pack(const float *__restrict__ pow32, const int *__restrict__ frq, const double *__restrict__ spinc,
+                                                  long long *__restrict__ words, double *__restrict__ meta, XcGeom geo) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 3 * LCS_N_IDX) {
+    long long w = -1;                                    // below every real word (pow >= 0 packs non-negative)
+    if (geo.foi0 >= 0) w = ((long long)__float_as_uint(pow32[i]) << 32) | (long long)(0xFFFFFFFFu - (unsigned)(frq[i] + geo.foi0));
+    words[i] = w;
+  }
+  if (i < LCS_N_IDX) meta[i] = spinc[i];
+  if (i == LCS_N_IDX) meta[i] = (double)geo.n_comb;
+}
+__global__ __launch_bounds__(256) void k_foe_unpack(const long long *__restrict__ words, const double *__restrict__ meta, double *__restrict__ pow_,
+                                                    float *__restrict__ pow32, int *__restrict__ frq, double *__restrict__ spinc, double *__restrict__ zth,
+                                                    double R_th1, double rx_cutoff, int ds) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 3 * LCS_N_IDX) {
+    const long long w = words[i];
+    const float p = __uint_as_float((unsigned)(w >> 32));
+    pow32[i] = p;
+    pow_[i] = (double)p;
+    frq[i] = (int)(0xFFFFFFFFu - (unsigned)(w & 0xFFFFFFFFll));
+  }
+  if (i < LCS_N_IDX) {
+    const double v = meta[i];
+    spinc[i] = v;
+    zth[i] = R_th1 * v / rx_cutoff / 137 / 2 / (int)meta[LCS_N_IDX] / (2 * ds + 1);      // src/CellSearch.cpp:500-503, as k_sp_fold
+  }
+}
+int lcs_launch_foe_pack(lcs_ctx *c, const XcGeom &geo, long long *d_words, double *d_meta) {
+  hipLaunchKernelGGL(k_foe_pack, dim3((3 * LCS_N_IDX + 255) / 256), dim3(256), 0, c->stream, reinterpret_cast<const float *>(c->work), c->frq, c->spinc,
+                     d_words, d_meta, geo);
+  HIPCHK(c, hipGetLastError());
+  return LCS_OK;
+}
+int lcs_launch_foe_unpack(lcs_ctx *c, const XcGeom &geo, const long long *d_words, const double *d_meta) {
+  const double R_th1 = lcs_tables::chi2cdf_inv(1 - pow(10.0, -12), 2.0 * geo.n_comb * (2 * geo.ds + 1));
+  const double rx_cutoff = (6 * 12 * 15e3 / 2 + 4 * 15e3) / (30720000.0 / 16 / 2);
+  hipLaunchKernelGGL(k_foe_unpack, dim3((3 * LCS_N_IDX + 255) / 256), dim3(256), 0, c->stream, d_words, d_meta, c->pow_, reinterpret_cast<float *>(c->work),
+                     c->frq, c->spinc, c->zth, R_th1, rx_cutoff, geo.ds);
   HIPCHK(c, hipGetLastError());
   return LCS_OK;
 }

@@ -222,3 +222,42 @@ def search_capbuf_foe_split(stages, capbuf, f_search_set, fc_requested, fc_progr
         allc = [(int(order[k]), record_to_dict(rec[k])) for k in range(MAXC) if order[k] >= 0]
     allc.sort(key=lambda x: x[0])
     return [c for _, c in allc], dict(pow=pow_, frq=frq, sp_incoherent=sp_inc, n_comb_xc=n_comb_xc)
+
+
+def search_capbuf_foe_split_dev(searcher, capbuf, f_search_set, fc_requested, fc_programmed, fs_programmed, rank=0, world=1,
+                                dist=None, device=None):
+    """The same split with everything between the correlation and the peak search staying on the GPUs: `searcher`
+    (a Searcher on this rank's GPU) leaves the packed (pow, ~foi) words and the power estimate in two torch tensors on
+    `device` (lcs_foe_partial), torch.distributed reduces / broadcasts them in place (RCCL: one 230 KB MAX all-reduce, one
+    77 KB broadcast -- no host copy of any array), lcs_foe_finish takes them back.  Only the decoded cell records (a few
+    hundred bytes) travel through the host, in one all-gather.  Returns (cells in peak order, peak list)."""
+    import torch
+    f = np.asarray(f_search_set, np.float64)
+    own = foe_blocks(f.size, world)[rank]
+    dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+    words = torch.empty(3 * 9600, dtype=torch.int64, device=dev)
+    meta = torch.empty(9601, dtype=torch.float64, device=dev)
+    searcher.foe_partial(capbuf, f, int(own[0]) if own.size else 0, int(own.size), fc_requested, fc_programmed, fs_programmed,
+                         words.data_ptr(), meta.data_ptr())
+    if world > 1:
+        dist.all_reduce(words, op=dist.ReduceOp.MAX)
+        dist.broadcast(meta, src=0)
+        torch.cuda.synchronize(dev)
+    cells, order, peaks = searcher.foe_finish(words.data_ptr(), meta.data_ptr(), f)
+    rec = np.zeros(MAXC, cell_dtype())
+    ordv = np.full(MAXC, -1, np.int32)
+    n = min(len(cells), MAXC)
+    if n:
+        rec[:n] = cells_to_records(cells[:n])
+        ordv[:n] = order[:n]
+    if world > 1:
+        gdev = dev if dist.get_backend() == "nccl" else None        # the record gather of a gloo test run goes through host tensors
+        blobs = _all_gather_bytes(np.concatenate([ordv.view(np.uint8), rec.view(np.uint8)]), dist, gdev, world)
+    else:
+        blobs = [np.concatenate([ordv.view(np.uint8), rec.view(np.uint8)])]
+    allc = []
+    for b in blobs:
+        o, rr = b[:ordv.nbytes].view(np.int32), b[ordv.nbytes:].view(cell_dtype())
+        allc += [(int(o[k]), record_to_dict(rr[k])) for k in range(MAXC) if o[k] >= 0]
+    allc.sort(key=lambda x: x[0])
+    return [c for _, c in allc], peaks

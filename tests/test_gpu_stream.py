@@ -56,10 +56,42 @@ def test_stream_complex64_input_and_misuse(pkg):
             S._chk(S._lib.lcs_stream_push(S._h, None, 0.0, None, 0), "push before open")
         S.stream_open(pkg.FMT_C64, 153600, FC, FC, FS)
         S.stream_push(cap, 35e3)
+        S.stream_push(cap, 30e3)                  # a second buffer may be in flight ...
         with pytest.raises(RuntimeError):
-            S.stream_push(cap, 35e3)              # previous buffer not collected
-        cells, _, _ = S.stream_collect()
+            S.stream_push(cap, 35e3)              # ... a third may not
+        cells, _, _ = S.stream_collect()          # oldest first
         assert [c.n_id_cell() for c in cells] == [277, 271]
+        cells, _, _ = S.stream_collect()
+        assert [round(c.freq) for c in cells] == [30000] * len(cells)
+        with pytest.raises(RuntimeError):
+            S.stream_collect()                    # nothing in flight
+
+
+def test_stream_two_buffers_in_flight_keep_their_order(pkg):
+    """Double-buffered pushes (lcs_stream_push while the previous graph launch is still running): results come back in
+    push order, each with its own hypothesis and tracked list, identical to one-at-a-time pushes."""
+    g = golden("capbuf_0000")["iq_u8"]
+    rng = np.random.default_rng(9)
+    noise = np.clip(np.rint(rng.normal(127.0, 15.0, g.size)), 0, 255).astype(np.uint8)
+    seq = [(g, 35e3, ()), (noise, 35e3, ()), (g, 35e3, (277,)), (np.roll(g, 2 * 700), 35e3, ()), (g, 30e3, ()), (noise, 0.0, (5,)), (g, 35e3, (271, 277))]
+    with pkg.Searcher(0) as S:
+        S.stream_open(pkg.FMT_IQ_U8, 153600, FC, FC, FS)
+        ref = []
+        for buf, f_off, tr in seq:
+            S.stream_push(buf, f_off, tracked=tr)
+            cells, dup, _ = S.stream_collect()
+            ref.append(([_key(c) for c in cells], dup))
+        got = []
+        for i, (buf, f_off, tr) in enumerate(seq):
+            S.stream_push(buf, f_off, tracked=tr)
+            if i >= 1:
+                cells, dup, ms = S.stream_collect()
+                got.append(([_key(c) for c in cells], dup))
+                assert 0.0 < ms < 50.0
+        cells, dup, _ = S.stream_collect()
+        got.append(([_key(c) for c in cells], dup))
+        assert got == ref
+        assert [len(x[0]) for x in ref] == [2, 0, 1, 2, 2, 0, 0] and [x[1] for x in ref] == [0, 0, 1, 0, 0, 0, 2]
 
 
 def test_sweep_tool_single_gpu(tmp_path):

@@ -78,7 +78,12 @@ FOE_WORKER = textwrap.dedent("""
         stages = O
     cap = iq_u8_to_capbuf(golden("capbuf_0000")["iq_u8"])
     f = np.array([25e3, 30e3, 35e3, 35e3, 40e3, 45e3, 50e3])        # duplicate hypothesis: the tie must go to the lower index
-    cells, arr = pkg.sweep.search_capbuf_foe_split(stages, cap, f, 739e6, 739e6, 1.92e6, rank, world, dist if world > 1 else None)
+    if {dev!r}:      # everything between correlation and peak search stays on the GPU (lcs_foe_partial / lcs_foe_finish)
+        torch.cuda.set_device(0)
+        cells, peaks = pkg.sweep.search_capbuf_foe_split_dev(S, cap, f, 739e6, 739e6, 1.92e6, rank, world, dist if world > 1 else None, torch.device("cuda", 0))
+        arr = dict(pow=np.array([p.pss_pow for p in peaks]), frq=np.array([p.freq for p in peaks]))
+    else:
+        cells, arr = pkg.sweep.search_capbuf_foe_split(stages, cap, f, 739e6, 739e6, 1.92e6, rank, world, dist if world > 1 else None)
     if rank == 0:
         print("RESULT " + json.dumps(dict(cells=[(c["n_id_cell"], c["n_rb_dl"], c["sfn"], c["ind"], c["freq"], repr(c["pss_pow"]), repr(c["freq_superfine"])) for c in cells],
                                           pow=hashlib.sha256(arr["pow"].tobytes()).hexdigest(), frq=hashlib.sha256(arr["frq"].tobytes()).hexdigest(),
@@ -89,6 +94,8 @@ FOE_WORKER = textwrap.dedent("""
 
 
 def _run(world, tmp_path, worker=None, port="29541", **fmt):
+    if worker is FOE_WORKER:
+        fmt.setdefault("dev", False)
     script = tmp_path / "worker.py"
     script.write_text((worker or WORKER).format(root=ROOT, **fmt))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, OMP_NUM_THREADS="2", GPU_MAX_HW_QUEUES="8")
@@ -141,6 +148,61 @@ def test_foe_split_two_ranks_real_searcher(tmp_path):
     one = _run(1, tmp_path, FOE_WORKER, "29545", use_gpu=True)
     two = _run(2, tmp_path, FOE_WORKER, "29545", use_gpu=True)
     assert one == two and [c[0] for c in one["cells"]] == [277, 271]
+
+
+@pytest.mark.gpu
+def test_foe_split_device_resident(tmp_path):
+    """lcs_foe_partial / lcs_foe_finish: the packed words and the power estimate stay in device tensors, torch.distributed
+    reduces them in place (gloo on CUDA tensors here, two ranks sharing GPU 0; RCCL on a real node), and the result is
+    the single-rank result -- which in turn is what the ordinary fused chain finds."""
+    one = _run(1, tmp_path, FOE_WORKER, "29549", use_gpu=True, dev=True)
+    two = _run(2, tmp_path, FOE_WORKER, "29549", use_gpu=True, dev=True)
+    host = _run(1, tmp_path, FOE_WORKER, "29549", use_gpu=True)
+    assert one == two and [c[0] for c in one["cells"]] == [277, 271] and [c[2] for c in one["cells"]] == [74, 22]
+    for a, b in zip(one["cells"], host["cells"]):
+        assert a[:5] == b[:5] and abs(float(a[5]) / float(b[5]) - 1) < 1e-5 and abs(float(a[6]) - float(b[6])) < 1e-2
+
+
+@pytest.mark.gpu
+def test_foe_split_two_contexts_emulate_two_ranks():
+    """The same without processes: two contexts take one share of the hypotheses each, the MAX of their word tensors
+    stands in for the all-reduce; every peak is refined by exactly one of them and the union is the fused chain's list.
+    Includes a rank with NO hypotheses (world > n_f)."""
+    import torch
+    import oracle as O
+    from conftest import golden, iq_u8_to_capbuf, f_search_set_for
+    pkg = load_pkg()
+    cap = iq_u8_to_capbuf(golden("capbuf_0000")["iq_u8"])
+    fc, fs = 739e6, 1.92e6
+    f = f_search_set_for(fc, 100)
+    O.set_threads(8)
+    exp, exp_peaks = O.search_capbuf(cap, f, fc, fc, fs)
+    shares = [(0, 16), (16, 15), (0, 0)]
+    with pkg.Searcher(0) as A, pkg.Searcher(0) as B, pkg.Searcher(0) as Z:
+        ctxs = [A, B, Z]
+        words = [torch.empty(3 * 9600, dtype=torch.int64, device="cuda") for _ in ctxs]
+        meta = [torch.empty(9601, dtype=torch.float64, device="cuda") for _ in ctxs]
+        for S, (a, n), w, m in zip(ctxs, shares, words, meta):
+            S.foe_partial(cap, f, a, n, fc, fc, fs, w.data_ptr(), m.data_ptr())
+        assert int(words[2].max()) == -1                       # the empty share never wins
+        red = torch.maximum(torch.maximum(words[0], words[1]), words[2])
+        got, seen = [], []
+        for S in ctxs:
+            cells, order, peaks = S.foe_finish(red.data_ptr(), meta[0].data_ptr(), f)
+            got += list(zip(order.tolist(), cells))
+            seen.append([(p.n_id_2, p.freq, p.reserved) for p in peaks])
+            assert [(p.n_id_2, p.freq) for p in peaks] == [(p.n_id_2, p.freq) for p in exp_peaks]
+        # each peak is owned (reserved == 0) by exactly one context; nobody owns anything on the empty rank
+        for k in range(len(exp_peaks)):
+            assert sum(1 for s in seen if s[k][2] == 0) == 1
+        assert all(x[2] == 1 for x in seen[2])
+        got.sort(key=lambda x: x[0])
+        assert [c.n_id_cell() for _, c in got] == [c.n_id_cell() for c in exp] == [277, 271]
+        for (_, a), b in zip(got, exp):
+            assert (a.ind, a.n_id_1, a.n_ports, a.n_rb_dl, a.sfn) == (b.ind, b.n_id_1, b.n_ports, b.n_rb_dl, b.sfn)
+            assert abs(a.pss_pow - b.pss_pow) < 1e-5 * b.pss_pow and abs(a.freq_superfine - b.freq_superfine) < 1e-3
+        with pytest.raises(pkg.SearcherError):
+            A.foe_finish(red.data_ptr(), meta[0].data_ptr(), f)          # no partial call pending
 
 
 @pytest.mark.gpu
