@@ -125,6 +125,13 @@ def stream_bench(pkg, args, rank, world, local_rank, dist):
             cells, _, ms = S.stream_collect()
             gpu_ms.append(ms)
             n_cells = max(n_cells, len(cells))
+    # pre-conditioning (untimed, like the warm-up): a fresh process runs its first ~100 ms of pushes at 0.5 ms each before it
+    # settles at the GPU time of the graph (0.35 ms); keep the stream busy for 0.6 s first, as the batch bench does
+    t_pre, i = time.perf_counter(), 0
+    while time.perf_counter() - t_pre < 0.6:
+        step(i, last=False)
+        i += 1
+    S.stream_collect()
     for i in range(args.warmup):
         step(i, last=(i == args.warmup - 1))
     gpu_ms.clear()
