@@ -168,3 +168,30 @@ def test_sharded_sweep_gives_the_same_report(tmp_path):
         assert r.stdout == one.stdout, (extra, r.stdout, one.stdout)
     assert one.stdout.count("Detected a cell!") == 4 and one.stdout.count("center frequency did not match") == 4
     assert "could not parse gpu index" in _run(base + ["-g", "some"]).stderr
+
+
+@pytest.mark.gpu
+def test_stream_search_consumer_loop(tmp_path):
+    """host/StreamSearch.cpp: the searcher thread's consumer loop (ref src/searcher_thread.cpp:83-246) in C++ over
+    lcs_stream_*: cells found in one buffer are tracked from the next PUSH on (two buffers are in flight, so the buffer
+    already launched still reports them once more), noise adds nothing."""
+    pkg = load_pkg()
+    g = golden("capbuf_0000")
+    it = __import__("importlib").import_module("lte_cell_scanner_amd.itfile")
+    cap = iq_u8_to_capbuf(g["iq_u8"])
+    rng = np.random.default_rng(4)
+    noise = iq_u8_to_capbuf(np.clip(np.rint(rng.normal(127.0, 12.0, g["iq_u8"].size)), 0, 255).astype(np.uint8))
+    it.write_it(str(tmp_path / "capbuf_0000.it"), {"capbuf": cap, "fc": g["fc"].astype(np.int32)})
+    it.write_it(str(tmp_path / "capbuf_0001.it"), {"capbuf": noise, "fc": g["fc"].astype(np.int32)})
+    exe = os.path.join(ROOT, "host", "StreamSearch")
+    r = subprocess.run([exe, "-f", "35000", "-n", "3", str(tmp_path / "capbuf_0000.it"), str(tmp_path / "capbuf_0001.it")],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("buffer ")]
+    assert len(lines) == 6
+    assert lines[0].startswith("buffer 0: 2 new, 0 tracked") and "[cell 277 ports 2 nRB 50" in lines[0] and "[cell 271 " in lines[0]
+    assert lines[1].startswith("buffer 1: 0 new, 0 tracked")
+    assert lines[2].startswith("buffer 2: 0 new, 2 tracked")          # pushed after buffer 0 was collected: both cells tracked
+    assert lines[4].startswith("buffer 4: 0 new, 2 tracked") and lines[5].startswith("buffer 5: 0 new, 0 tracked")
+    assert "tracked: 277 271" in r.stdout
+    assert subprocess.run([exe], capture_output=True, text=True).returncode == 2
