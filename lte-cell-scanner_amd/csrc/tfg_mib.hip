@@ -713,18 +713,25 @@ __device__ __forceinline__ double np_from_partials(const double *sc, int port) {
 // ------------------------------------------------------------------------ PBCH decode
 // One WAVE per (cell, candidate): candidate = frame_timing_guess*3 + {1,2,4 ports}.  The equalised symbols stay in
 // registers (symbol pairs go straight through the soft demodulator), the 1920 LLRs go through LDS, and the 64
-// tail-biting trellises run one per lane with their path metrics in registers (lte_device.h).  64 threads, < 284
-// VGPRs, 21 KB of LDS: four of these fit where one resident correlation workgroup has retired.
-#define PB_THREADS 64
-__global__ __launch_bounds__(PB_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_pbch(const lcs_cell *__restrict__ cells, const int *__restrict__ n_work,
+// tail-biting trellises run one per lane with their path metrics in registers (lte_device.h).  < 256 VGPRs and 21 KB of
+// LDS per wave.  FOUR candidates share a workgroup, one wave (= one SIMD) each: in the pipelined chain a workgroup of
+// this kernel can only start where a resident correlation workgroup (4 waves x 228 VGPRs, 68 KB) has retired, and keeps
+// the next one out for its whole ~160 us -- as 264 one-wave workgroups spread over the chip that emptied up to 264
+// correlation slots, as 66 four-wave workgroups it empties 66 (profiles/r03/experiments: the chain's cost is the slots
+// it keeps empty, not slower workgroups).
+#define PB_THREADS 64                 // lanes of one candidate
+#define PB_CANDS 4                    // candidates (waves) per workgroup
+__global__ __launch_bounds__(PB_THREADS * PB_CANDS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_pbch(const lcs_cell *__restrict__ cells, const int *__restrict__ n_work,
                                                       const double2 *__restrict__ tfg_comp, const double2 *__restrict__ ce,
                                                       double *__restrict__ scratch, const uint8_t *__restrict__ pbch_scr,
                                                       const int16_t *__restrict__ derm_inv /*[2][120][16]*/) {
   LCS_TAIL_PRIO();
-  __shared__ unsigned long long surv[40 * 64];      // survivor words [step][trellis]; holds the LLRs until they are de-ratematched
-  __shared__ double d_est[3][40];
+  __shared__ unsigned long long surv_all[PB_CANDS][40 * 64];      // per wave: survivor words [step][trellis]; holds the LLRs until they are de-ratematched
+  __shared__ double d_est_all[PB_CANDS][3][40];
+  const int wv = threadIdx.x >> 6, tid = threadIdx.x & 63, cand = blockIdx.y * PB_CANDS + wv;
+  unsigned long long *surv = surv_all[wv];
+  double (*d_est)[40] = d_est_all[wv];
   double *e_est = reinterpret_cast<double *>(surv);  // 1920 doubles = 15 KB of the 20 KB
-  const int tid = threadIdx.x, cand = blockIdx.y;
   const int guess = cand / 3, n_ports = (cand % 3 == 2) ? 4 : (cand % 3) + 1;
   for (int it = blockIdx.x; it < *n_work; it += gridDim.x) {
     const lcs_cell c = cells[it];
@@ -879,7 +886,7 @@ int lcs_launch_mib(lcs_ctx *c, int n_items) {
   (void)n_items;
   hipLaunchKernelGGL(k_chan_est, dim3(c->grid_items, 4, CE_NCHUNK), dim3(CE_THREADS), 0, c->stream, c->cells_out, c->n_work,
                      c->tfg_comp, c->cell_scratch, c->ce, c->needed_rows_only ? 1 : 0);
-  hipLaunchKernelGGL(k_pbch, dim3(c->grid_items, 12), dim3(PB_THREADS), 0, c->stream, c->cells_out, c->n_work, c->tfg_comp,
+  hipLaunchKernelGGL(k_pbch, dim3(c->grid_items, 12 / PB_CANDS), dim3(PB_THREADS * PB_CANDS), 0, c->stream, c->cells_out, c->n_work, c->tfg_comp,
                      c->ce, c->cell_scratch, c->d_pbch_scr, c->d_derm_inv);
   hipLaunchKernelGGL(k_mib_select, dim3((LCS_MAX_WORK + 63) / 64), dim3(64), 0, c->stream, c->cells_out, c->n_work,
                      c->cell_scratch);
