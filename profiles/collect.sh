@@ -1,32 +1,34 @@
 #!/bin/bash
 # Collect a round's profiling artifacts on a GPU box (run from the repository root through gpurun):
-#   bash profiles/collect.sh r02
+#   bash profiles/collect.sh r03
 # GPU tests first, then the bench lines, the kernel-trace statistics (one context = isolated kernel times, default
 # pipeline = under load) and the PMC counters -- kernel-trace statistics and counters in SEPARATE rocprofv3 runs, one
 # counter group per pass, as MI355X_MICROARCH.md prescribes.  Outputs land in gpurun_out/<tag>/; profiles/summarize.py
 # reduces them to the small files kept under profiles/<tag>/.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 REPO=$PWD
 OUT=$REPO/gpurun_out/$TAG
 mkdir -p "$OUT"
 (cd "$REPO" && timeout 300 python -m pytest tests -m gpu -x -q 2>&1 | tail -6) > "$OUT/pytest_gpu.log"
 cd /tmp; export TMPDIR=/tmp
 B="python $REPO/bench.py"
-SHORT="--steps 2 --warmup 1 --batches-per-step 8 --no-cpu-baseline"
+SHORT="--steps 2 --warmup 1 --batches-per-step 8 --no-cpu-baseline --no-dense"
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_full_p1" -- $B $SHORT --pipeline 1 > "$OUT/stats_full_p1.log" 2>&1
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_full_default" -- $B $SHORT > "$OUT/stats_full_default.log" 2>&1
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS" \
            "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
-  timeout 200 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d "$OUT/pmc_$i" -- $B --steps 1 --warmup 0 --batches-per-step 4 --pipeline 1 --no-cpu-baseline > "$OUT/pmc_$i.log" 2>&1
+  timeout 200 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d "$OUT/pmc_$i" -- $B --steps 1 --warmup 0 --batches-per-step 4 --pipeline 1 --no-cpu-baseline --no-dense > "$OUT/pmc_$i.log" 2>&1
 done
 # the bench lines last: bench.py reports roofline.traffic only from a PMC summary taken from the running kernel sources
 (cd "$REPO" && python profiles/summarize.py "$TAG" > /dev/null 2>&1)
-timeout 300 $B > "$OUT/bench_full_n1.json" 2> "$OUT/bench_full_n1.err"
+timeout 300 $B --steps 20 --warmup 5 > "$OUT/bench_full_n1.json" 2> "$OUT/bench_full_n1.err"
+timeout 200 $B --steps 20 --warmup 5 --input-host --no-cpu-baseline --no-dense > "$OUT/bench_full_n1_input_host.json" 2> "$OUT/bench_host.err"
 timeout 120 $B --stage pss --no-cpu-baseline > "$OUT/bench_pss_n1.json" 2> "$OUT/bench_pss_n1.err"
-timeout 120 $B --stage stream --steps 100 --warmup 10 > "$OUT/bench_stream_n1.json" 2> "$OUT/bench_stream_n1.err"
+timeout 120 $B --stage single --steps 200 --warmup 20 > "$OUT/bench_single_n1.json" 2> "$OUT/bench_single_n1.err"
+timeout 120 $B --stage stream --steps 400 --warmup 20 > "$OUT/bench_stream_n1.json" 2> "$OUT/bench_stream_n1.err"
 timeout 120 $B --stage track > "$OUT/bench_track_n1.json" 2> "$OUT/bench_track_n1.err"
-timeout 120 $B --input c64 --no-cpu-baseline > "$OUT/bench_full_n1_c64_fp32_kernel.json" 2> "$OUT/bench_c64.err"
+timeout 200 $B --steps 10 --warmup 2 --batches-per-step 40 --input c64 --no-cpu-baseline > "$OUT/bench_full_n1_c64_fp32_kernel.json" 2> "$OUT/bench_c64.err"
 echo collected > "$OUT/done"

@@ -5,12 +5,12 @@
 """
 import csv, glob, json, os, shutil, sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(root, "gpurun_out", tag), os.path.join(root, "profiles", tag)
 os.makedirs(dst, exist_ok=True)
 
-for name in ("bench_full_n1.json", "bench_pss_n1.json", "bench_stream_n1.json", "bench_track_n1.json", "bench_full_n1_c64_fp32_kernel.json", "pytest_gpu.log"):
+for name in ("bench_full_n1.json", "bench_full_n1_input_host.json", "bench_single_n1.json", "bench_pss_n1.json", "bench_stream_n1.json", "bench_track_n1.json", "bench_full_n1_c64_fp32_kernel.json", "pytest_gpu.log"):
     p = os.path.join(src, name)
     if os.path.exists(p):
         lines = [l for l in open(p).read().splitlines() if l.startswith("{")] if name.endswith(".json") else open(p).read().splitlines()[-6:]
@@ -49,7 +49,7 @@ def kernel_source_sha():          # the same digest bench.py computes: traffic i
     return h.hexdigest()[:16]
 summary = {
     "source": "profiles/collect.sh: rocprofv3 --pmc <group> --kernel-trace --output-format csv -- python bench.py --steps 1 "
-              "--warmup 0 --batches-per-step 4 --pipeline 1 --no-cpu-baseline, one pass per counter group; values are per-launch averages "
+              "--warmup 0 --batches-per-step 4 --pipeline 1 --no-cpu-baseline --no-dense, one pass per counter group; values are per-launch averages "
               "(64 buffers per launch, n_f = 31); kernel_source_sha = sha256 of the correlation kernel sources the counters were taken from",
     "corrections": "FETCH_SIZE is reported in KiB and, on gfx950, as half of the bytes fetched; WRITE_SIZE in KiB is exact "
                    "(MI355X_MICROARCH.md, HBM / rocprofv3 section).  hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024",
