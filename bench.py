@@ -205,6 +205,10 @@ def single_bench(pkg, args, rank, world, local_rank, dist):
         cells, _ = S.search_capbuf(caps[i % 8], f, fc, fc, FS)
         lat.append(1e3 * (time.perf_counter() - t))
         n_cells += len(cells)
+    t_pre, i = time.perf_counter(), 0
+    while time.perf_counter() - t_pre < 0.6:      # pre-conditioning (untimed): clocks and queues settle, as in the batch bench
+        step(i)
+        i += 1
     for i in range(max(2, args.warmup)):
         step(i)
     lat.clear(); n_cells = 0
