@@ -18,12 +18,14 @@
  *  - every function returns LCS_OK (0) or a negative error; "not found" stays in-band in
  *    lcs_cell (n_id_1 == -1 / n_rb_dl == -1) exactly as in the reference
  *    (src/CellSearch.cpp:530, 554).
- *  - correlation kernel: raw RTL-SDR u8 I/Q (LCS_FMT_IQ_U8) is exact in int8 and runs on the int8 matrix cores
- *    (templates as 24-bit integers in three int8 digits, exact int32 accumulation); every other source takes the
- *    fp32 MFMA kernel.  Both agree with the reference to ~1e-7 relative.  Templates are processed 16 to a group;
- *    any f_search_set is accepted: a grid whose hypotheses' window starts drift apart by more samples than a
- *    group's tap blocks hold (> 23 samples for int8, > 111 for fp32 -- far sparser than the 5 kHz grids of the
- *    CLI) is packed with fewer whole hypotheses per group, down to one, at proportionally more work.
+ *  - correlation kernel: the DATA decides.  Dongle samples are exactly (u8 - 127) / 128 (src/capbuf.cpp:172-181) and exact
+ *    in int8: handed over as raw bytes (LCS_FMT_IQ_U8) or as complex<double> through the reference's call shape (the host
+ *    entry points check every component on the device), they run on the int8 matrix cores (templates as 24-bit integers
+ *    in three int8 digits, exact int32 accumulation); every other buffer takes the fp32 MFMA kernel.  Both agree with the
+ *    reference to ~1e-7 relative.  Templates are processed 16 to a group; any f_search_set is accepted: a grid whose
+ *    hypotheses' window starts drift apart by more samples than a group's tap blocks hold (> 23 samples for int8, > 111
+ *    for fp32 -- far sparser than the 5 kHz grids of the CLI) is packed with fewer whole hypotheses per group, down to
+ *    one, at proportionally more work.
  *  - a context owns one HIP device + stream + workspace; calls on one context are
  *    serialised by the caller, different contexts are independent (the reference's
  *    functions are re-entrant).

@@ -286,3 +286,40 @@ def test_saturated_full_scale_buffers(S, pkg):
     runs = np.repeat(np.where(rng.random((n // 24 + 1, 2)) < 0.5, 0, 255), 12, axis=0).reshape(-1)[:n].astype(np.uint8)
     f = f_search_set_for(FC, 100)
     _batch_arrays_vs_oracle(S, pkg, [sat, runs], f, np.array([FC, FC]), 153600, "saturated buffers")
+
+
+def test_track_stream_mixed_cp_types_and_dongle_parameters(pkg, mixed):
+    """lcs_track_stream_block with a normal-CP and an extended-CP cell in ONE stream (frames of 140 and 120 symbols: the two
+    carry different amounts of history and are processed as two groups inside the call), cut in the middle of frames, under
+    fc_programmed / fs_programmed off nominal: row for row what lcs_track_block returns for each cell's whole stream."""
+    _, cap, _ = mixed
+    cells, _ = O.search_capbuf(cap, f_search_set_for(FC, 100), FC, FCP, FSP)
+    assert sorted(c.cp_type for c in cells) == [1, 2]
+    n_sym = 840                                    # 6 normal-CP frames / 7 extended-CP frames
+    per = []
+    for c in cells:
+        k_factor = (FC - c.freq_superfine) / FCP
+        ft = c.frame_start * (30.72e6 / 16) / (FSP * k_factor)
+        per.append(pkg.tracker.cut_symbols(cap, ft, c.cp_type, c.freq_superfine, FC, FCP, FSP, n_sym))
+        assert per[-1][0].shape[0] == n_sym
+    td = np.stack([p[0] for p in per]); late = np.stack([p[1] for p in per])
+    ftv = np.stack([p[2] for p in per]); fov = np.stack([p[3] for p in per])
+    with pkg.Searcher(0) as S:
+        ones = [S.track_block([c], td[i:i + 1], fov[i:i + 1], ftv[i:i + 1], late[i:i + 1], FC, FCP, FSP) for i, c in enumerate(cells)]
+        parts, a = [], 0
+        for n in (333, 200, 307):
+            parts.append(S.track_stream_block(cells, td[:, a:a + n], fov[:, a:a + n], ftv[:, a:a + n], late[:, a:a + n], FC, FCP, FSP))
+            a += n
+    for i, c in enumerate(cells):
+        one = ones[i]
+        assert np.array_equal(np.concatenate([q["syms"][i] for q in parts]), one["syms"][0])
+        assert parts[-1]["bpo"][i] == one["bpo"][0]
+        for p in range(4):
+            rows = np.concatenate([q["meas"][i, p, :q["n_meas"][i, p]] for q in parts])
+            assert np.array_equal(rows, one["meas"][0, p, :one["n_meas"][0, p]]), (c.n_id_cell(), p)
+            ce = np.concatenate([q["ce"][i, p, :q["ce_n"][i, p]] for q in parts])
+            assert ce.shape[0] == one["ce_upto"][0, p] and np.array_equal(ce, one["ce"][0, p, :one["ce_upto"][0, p]])
+        ok = np.concatenate([q["mib_ok"][i, :q["n_mib"][i]] for q in parts])
+        tried = one["mib_ok"][0] != -1
+        assert np.array_equal(ok, one["mib_ok"][0][tried]) and np.array_equal(
+            np.concatenate([q["mib_bits"][i, :q["n_mib"][i]] for q in parts]), one["mib_bits"][0][tried])
