@@ -507,9 +507,9 @@ __device__ __forceinline__ void ext_vertex(const cd2 *row, int s, int i, int &x,
   } else { v = row[j]; x = s + 6 * j; }
 }
 
-// one wave per workgroup: the long pole is the per-row triangle walk (a handful of active lanes per chunk), the
-// parallel phases are small -- four-wave workgroups only held three idle waves' registers (A/B: -0.4 % step time)
-#define CE_THREADS 64
+// four waves per workgroup: the filter phases use all of them, the interpolation gives every output row a wave (one
+// lane per triangle of its strip)
+#define CE_THREADS 256
 // RS row list of one port (ref :1383-1392) in closed form: ports 0/1 carry RS in symbols 0 and
 // n_symb-3 of every slot (the sorted union alternates between the two), ports 2/3 in symbol 1.
 __device__ __forceinline__ int ce_rs_row(int port, int n_symb, int t) {
@@ -615,12 +615,20 @@ __global__ __launch_bounds__(CE_THREADS) void k_chan_est(const lcs_cell *__restr
       st(&out[(size_t)rs_set(0) * NSC + xs], cadd(vl, cdivr(cscale(d, (x - (double)xl)), ((double)xr - (double)xl))));
     }
     PH(23);
-    // One thread per OUTPUT ROW between the chunk's first and last RS row: it replays the triangle
-    // strip of its row pair exactly as the reference does (same vertex order, same boundary test)
-    // but only emits its own row.  The reference's early exit looks at rows 1 and `spacing` of the
-    // pair; their column counters are advanced too (closed form of the same while loop).
+    // One WAVE per output row between the chunk's first and last RS row, one LANE per triangle of the row pair's strip
+    // (round 3; before: one thread walked the whole strip of its row, ~25 triangles x 72 columns in sequence, and the
+    // kernel was the longest of the per-cell chain).  The reference walks the strip triangle by triangle (ref :1262-1351):
+    // triangle l = vertices (S_l, S_l+1, S_l+2) of the sequence S that alternates between the two edge-extended RS rows
+    // (starting with the row whose second vertex lies further left), its right boundary is the line through S_l+1 and
+    // S_l+2, and a column counter x runs on: triangle l emits the columns from where the earlier triangles stopped up to
+    // its boundary at this row.  As a scan: stop_l = max over j <= l of (floor(boundary_j(row)) + 1); triangle l emits
+    // [stop_(l-1), floor(boundary_l(row))].  The walk ends after the first triangle at which the two tracked rows of the
+    // pair (row 1 and the last one) both stand at column 72 exactly (ref :1337-1339), or when either row runs out of
+    // vertices.  Every value is the plane through the same three vertices evaluated with the same expressions, so the
+    // result is bit-identical to the sequential walk.
     const int y_first = rs_set(c0), y_last = rs_set(min(c1, n_rs - 1));
-    for (int yy = y_first + 1 + tid; yy <= y_last; yy += CE_THREADS) {
+    const int lane = tid & 63, wv = tid >> 6;
+    for (int yy = y_first + 1 + wv; yy <= y_last; yy += CE_THREADS / 64) {
       // the fused chain only ever reads the channel estimate on PBCH rows (`pbch_only`); the last RS row
       // is kept as the source of the edge copy below
       if (pbch_only && !pbch_row(yy, n_symb) && yy != rs_set(n_rs - 1)) continue;
@@ -633,56 +641,60 @@ __global__ __launch_bounds__(CE_THREADS) void k_chan_est(const lcs_cell *__restr
       const cd2 *top = ce_filt + (t - c0) * 12, *bot = ce_filt + (t + 1 - c0) * 12;
       const int n_top = ext_len(s_top), n_bot = ext_len(s_bot);
       const int y_top = rs_set(t), y_bot = rs_set(t + 1);
-      int tx[3], ty[3]; cd2 tv[3];
-      int top_last, bot_last, x1t, x1b; cd2 dummy;
+      const int spacing = y_bot - y_top;
+      int x1t, x1b; cd2 dummy;
       ext_vertex(top, s_top, 1, x1t, dummy);
       ext_vertex(bot, s_bot, 1, x1b, dummy);
-      if (x1t < x1b) {
-        ext_vertex(top, s_top, 0, tx[0], tv[0]); ty[0] = y_top;
-        ext_vertex(bot, s_bot, 0, tx[1], tv[1]); ty[1] = y_bot;
-        ext_vertex(top, s_top, 1, tx[2], tv[2]); ty[2] = y_top;
-        top_last = 1; bot_last = 0;
+      const bool top_first = x1t < x1b;
+      // S_k: even k from the first row, odd k from the other; the strip ends where either row has no vertex left
+      const int n_a = top_first ? n_top : n_bot, n_b = top_first ? n_bot : n_top;      // counts of the first / second row
+      const int n_seq = (n_a <= n_b) ? 2 * n_a : 2 * n_b + 1;                          // entries of S: a0 b0 a1 b1 ... while both exist
+      const int n_tri = min(n_seq - 2, 64);
+      int tx[3], ty[3]; cd2 tv[3];
+      const bool have = lane < n_tri;
+      if (have) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          const int k = lane + q;
+          const bool from_top = ((k & 1) == 0) == top_first;
+          if (from_top) { ext_vertex(top, s_top, k >> 1, tx[q], tv[q]); ty[q] = y_top; }
+          else { ext_vertex(bot, s_bot, k >> 1, tx[q], tv[q]); ty[q] = y_bot; }
+        }
       } else {
-        ext_vertex(bot, s_bot, 0, tx[0], tv[0]); ty[0] = y_bot;
-        ext_vertex(top, s_top, 0, tx[1], tv[1]); ty[1] = y_top;
-        ext_vertex(bot, s_bot, 1, tx[2], tv[2]); ty[2] = y_bot;
-        top_last = 0; bot_last = 1;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { tx[q] = 0; ty[q] = q; tv[q] = mk(0, 0); }
       }
-      const int spacing = y_bot - y_top;
-      int x_mine = 0, x_r1 = 0, x_rs = 0;
-      for (int guard = 0; guard < 64; ++guard) {
-        const double x1 = tx[1], x2 = tx[2], y1 = ty[1], y2 = ty[2];
-        const double a_l = (x1 - x2) / (y1 - y2);
-        const double b_l = (y1 * x2 - y2 * x1) / (y1 - y2);
-        if ((double)x_mine <= a_l * yy + b_l) {
-          // plane through the three vertices (the reference solves the 3x3 system with a LAPACK
-          // inverse, ref :1293-1312; same plane, rounding differs at the 1e-14 level)
-          const double dx1 = tx[1] - tx[0], dy1 = ty[1] - ty[0], dx2 = tx[2] - tx[0], dy2 = ty[2] - ty[0];
-          const double det = dx1 * dy2 - dx2 * dy1;
-          const cd2 d1 = csub(tv[1], tv[0]), d2 = csub(tv[2], tv[0]);
-          const cd2 a_p = cdivr(csub(cscale(d1, dy2), cscale(d2, dy1)), det);
-          const cd2 b_p = cdivr(csub(cscale(d2, dx1), cscale(d1, dx2)), det);
-          while ((double)x_mine <= a_l * yy + b_l) {
-            const cd2 v = cadd(cadd(tv[0], cscale(a_p, (double)(x_mine - tx[0]))), cscale(b_p, (double)(yy - ty[0])));
-            if (x_mine <= 71) st(&out[(size_t)yy * NSC + x_mine], v);
-            ++x_mine;
-          }
-        }
-        {   // while ((double)x <= bound) ++x  ==  x = max(x, floor(bound) + 1)
-          const double bd1 = a_l * (y_top + 1) + b_l, bds = a_l * (y_top + spacing) + b_l;
-          if ((double)x_r1 <= bd1) x_r1 = (int)floor(bd1) + 1;
-          if ((double)x_rs <= bds) x_rs = (int)floor(bds) + 1;
-        }
-        if (x_r1 == 72 && x_rs == 72) break;
-        tx[0] = tx[1]; ty[0] = ty[1]; tv[0] = tv[1]; tx[1] = tx[2]; ty[1] = ty[2]; tv[1] = tv[2];
-        if (ty[1] == y_top) {
-          ++bot_last;
-          if (bot_last >= n_bot) break;
-          ext_vertex(bot, s_bot, bot_last, tx[2], tv[2]); ty[2] = y_bot;
-        } else {
-          ++top_last;
-          if (top_last >= n_top) break;
-          ext_vertex(top, s_top, top_last, tx[2], tv[2]); ty[2] = y_top;
+      const double x1 = tx[1], x2 = tx[2], y1 = ty[1], y2 = ty[2];
+      const double a_l = (x1 - x2) / (y1 - y2);
+      const double b_l = (y1 * x2 - y2 * x1) / (y1 - y2);
+      const double bd = a_l * yy + b_l, bd1 = a_l * (y_top + 1) + b_l, bds = a_l * (y_top + spacing) + b_l;
+      // where the three column counters stand after this triangle if nothing stood further right before: counter =
+      // max(counter, floor(bound) + 1) whenever counter <= bound; inclusive prefix max over the triangles
+      int m_mine = have ? (int)floor(bd) + 1 : 0, m_r1 = have ? (int)floor(bd1) + 1 : 0, m_rs = have ? (int)floor(bds) + 1 : 0;
+      if (m_mine < 0) m_mine = 0;
+      if (m_r1 < 0) m_r1 = 0;
+      if (m_rs < 0) m_rs = 0;
+#pragma unroll
+      for (int off = 1; off < 32; off <<= 1) {
+        const int o0 = __shfl_up(m_mine, off), o1 = __shfl_up(m_r1, off), o2 = __shfl_up(m_rs, off);
+        if (lane >= off) { m_mine = max(m_mine, o0); m_r1 = max(m_r1, o1); m_rs = max(m_rs, o2); }
+      }
+      int x_from = __shfl_up(m_mine, 1);
+      if (lane == 0) x_from = 0;
+      // the walk stops after the first triangle that leaves both tracked rows at column 72
+      const unsigned long long done = __ballot(have && m_r1 == 72 && m_rs == 72);
+      const int l_end = done ? (int)__builtin_ctzll(done) : 63;
+      if (have && lane <= l_end && (double)x_from <= bd) {
+        // plane through the three vertices (the reference solves the 3x3 system with a LAPACK
+        // inverse, ref :1293-1312; same plane, rounding differs at the 1e-14 level)
+        const double dx1 = tx[1] - tx[0], dy1 = ty[1] - ty[0], dx2 = tx[2] - tx[0], dy2 = ty[2] - ty[0];
+        const double det = dx1 * dy2 - dx2 * dy1;
+        const cd2 d1 = csub(tv[1], tv[0]), d2 = csub(tv[2], tv[0]);
+        const cd2 a_p = cdivr(csub(cscale(d1, dy2), cscale(d2, dy1)), det);
+        const cd2 b_p = cdivr(csub(cscale(d2, dx1), cscale(d1, dx2)), det);
+        for (int x = x_from; (double)x <= bd && x <= 71; ++x) {
+          const cd2 v = cadd(cadd(tv[0], cscale(a_p, (double)(x - tx[0]))), cscale(b_p, (double)(yy - ty[0])));
+          st(&out[(size_t)yy * NSC + x], v);
         }
       }
     }
