@@ -75,10 +75,25 @@ __device__ __forceinline__ double trunc_log(double x) {     // itpp::trunc_log
   if (x <= 0) return log(2.22507385850720138309e-308);
   return log(x);
 }
+// The four likelihoods factor over the two bits, e^{-|rx - g s|^2} = e^{-(rx.re -+ g a)^2} e^{-(rx.im -+ g a)^2}, so as long as no
+// exponential underflows the log-MAP value is exactly linear, l0 = 4 rx.re g a and l1 = 4 rx.im g a: what the four exps and
+// four logs below compute up to their rounding (~1e-13 absolute on values of order 1-1000, the same size as the difference
+// between this device's exp / log and the host libm the oracle uses).  What makes the reference's output differ from the
+// linear form is underflow (the far hypotheses' exponentials flush to zero: the LLR saturates below its closed-form value,
+// and when all four underflow it is exactly 0, ref trunc_log): every symbol whose farthest hypothesis is within range of
+// that (|.|^2 >= 600; exp underflows to subnormals at 708, to zero at 745) takes the reference's arithmetic unchanged.
 __device__ __forceinline__ void qpsk_llr(cd2 sym, double np, double &l0, double &l1) {
   const double a = 1 / sqrt(2.0);
   const cd2 gain = cdiv(mk(1.0, 0), mk(sqrt(np), 0));
   const cd2 rx = cmul(sym, gain);
+  {
+    const double ga = gain.re * a, fr = fabs(rx.re) + ga, fi = fabs(rx.im) + ga;
+    if (fr * fr + fi * fi < 600.0) {       // false for NaN / inf as well: those take the reference's path
+      l0 = 4.0 * rx.re * ga;
+      l1 = 4.0 * rx.im * ga;
+      return;
+    }
+  }
   double metric[4];
   for (int j = 0; j < 4; ++j) {
     const cd2 S = mk((j & 2) ? -a : a, (j & 1) ? -a : a);
