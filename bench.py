@@ -236,6 +236,23 @@ def single_bench(pkg, args, rank, world, local_rank, dist):
         S.search_batch(d_one[i % 8].data_ptr(), pkg.FMT_IQ_U8, 1, N_CAP, f, fc, fc, FS, pkg.STAGE_FULL)
     res_ms = 1e3 * (time.perf_counter() - t1) / 20
     xc_ms = S.last_xcorr_ms()[0]
+    # the hypothesis-split form of the same search (lcs_foe_partial + lcs_foe_finish, SURVEY 8e latency mode) on this one GPU:
+    # what the split costs before any second GPU helps (the packed words make a round trip through a device buffer, the
+    # peak search runs on the unpacked arrays); at world 2 each rank would correlate half the hypotheses between the two calls
+    words = torch.empty(3 * 9600, dtype=torch.int64, device=torch.device("cuda", dev_i))
+    meta = torch.empty(9601, dtype=torch.float64, device=torch.device("cuda", dev_i))
+    for i in range(23):
+        if i == 3:
+            t1 = time.perf_counter()
+        S.foe_partial(caps[i % 8], f, 0, f.size, fc, fc, FS, words.data_ptr(), meta.data_ptr())
+        S.foe_finish(words.data_ptr(), meta.data_ptr(), f)
+    foe_ms = 1e3 * (time.perf_counter() - t1) / 20
+    half = []
+    for i in range(23):
+        if i == 3:
+            t1 = time.perf_counter()
+        S.foe_partial(caps[i % 8], f, 0, (f.size + 1) // 2, fc, fc, FS, words.data_ptr(), meta.data_ptr())
+    foe_half_ms = 1e3 * (time.perf_counter() - t1) / 20
     if rank == 0:
         value = world * args.steps / dt
         flops = 8.0 * 137 * 3 * (N_CAP - 136) * f.size
@@ -251,6 +268,10 @@ def single_bench(pkg, args, rank, world, local_rank, dist):
                        "n_f": int(f.size), "latency_ms": {"min": float(la.min()), "median": float(np.median(la)), "max": float(la.max())},
                        "xcorr_kernel": kname, "cells_per_buffer": n_cells / max(1, args.steps),
                        "ms_per_buffer_resident_u8_input": res_ms, "xcorr_kernel_ms_one_buffer": xc_ms,
+                       "foe_split": {"world1_partial_plus_finish_ms": foe_ms, "partial_with_half_the_hypotheses_ms": foe_half_ms,
+                                     "note": "lcs_foe_partial + lcs_foe_finish on one GPU with all hypotheses (no collective), and the "
+                                             "partial call alone with half of them (a rank's share at world 2; RCCL's 230 KB all-reduce and "
+                                             "77 KB broadcast come on top)"},
                        "parallelism": "replicas" if world > 1 else "single GPU"},
             "roofline": {"bound": "launch/latency", "achieved": flops / (xc_ms * 1e-3) / 1e12, "peak": PEAK_I8_TOPS, "unit": "TOP/s",
                          "frac": flops / (xc_ms * 1e-3) / 1e12 / PEAK_I8_TOPS, "traffic": None,
