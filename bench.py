@@ -390,15 +390,12 @@ def self_launch(n):
 
 
 def device_identity(torch, index):
-    """Something that tells two GPUs of one node apart (uuid or PCI address), for the distinct-devices check."""
+    """(host, device index) tells the GPUs of one node apart; uuid / PCI address ride along for the record (some ROCm
+    builds report an all-zero uuid, so they are not what the distinct-devices check compares)."""
     import socket
     pr = torch.cuda.get_device_properties(index)
-    for attr in ("uuid", "pci_bus_id"):
-        v = getattr(pr, attr, None)
-        if v not in (None, ""):
-            extra = (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_device_id", 0)) if attr == "pci_bus_id" else ()
-            return f"{socket.gethostname()}/{attr}={v}{extra}"
-    return f"{socket.gethostname()}/index={index}"
+    extra = ",".join(f"{a}={getattr(pr, a)}" for a in ("uuid", "pci_bus_id", "pci_device_id") if getattr(pr, a, None) not in (None, ""))
+    return f"{socket.gethostname()}/cuda:{index}" + (f" ({extra})" if extra else "")
 
 
 def kernel_source_sha():
@@ -482,7 +479,7 @@ def main():
         # every rank must own a different GPU
         devices = [None] * world
         dist.all_gather_object(devices, device_identity(torch, local_rank))
-        if len(set(devices)) != world and not args.share_gpu0:
+        if len({d.split(" ")[0] for d in devices}) != world and not args.share_gpu0:
             sys.exit(f"bench.py: the {world} ranks do not sit on {world} distinct GPUs: {devices}")
     else:
         torch.cuda.set_device(0)
