@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <atomic>
 #include <condition_variable>
 #include <iostream>
 #include <list>
@@ -343,12 +344,31 @@ void device_thread(Sweep *sw, int device, int first_batch, int stride) {
       const int first = b * sw->kBatch, n = std::min<int>(sw->kBatch, sw->n_fc - first);
       InFlight &f = fl[slot];
       f.batch = b;
+      // a batch's files are read and converted by a few threads at once: parsing 64 x 2.46 MB of complex<double> is what a
+      // sweep over recorded captures spends its time on (the GPU needs ~1.5 ms for the batch)
       std::vector<Capture> caps(n);
-      for (int k = 0; k < n; ++k) {
-        const std::string path = sw->opt.data_dir + fmt("/capbuf_%04d.it", first + k);
-        if (sw->opt.verbosity >= 2) { std::lock_guard<std::mutex> lk(sw->m); std::cout << "Reading captured data from file: " << path << std::endl; }
-        caps[k] = read_capture(path, sw->opt.freq_start + 100e3 * (first + k));
-        sw->fc_matches[first + k] = caps[k].fc_matches;
+      {
+        std::atomic<int> next(0);
+        std::string read_error;
+        auto reader = [&]() {
+          for (int k = next.fetch_add(1); k < n; k = next.fetch_add(1)) {
+            const std::string path = sw->opt.data_dir + fmt("/capbuf_%04d.it", first + k);
+            if (sw->opt.verbosity >= 2) { std::lock_guard<std::mutex> lk(sw->m); std::cout << "Reading captured data from file: " << path << std::endl; }
+            try {
+              caps[k] = read_capture(path, sw->opt.freq_start + 100e3 * (first + k));
+              sw->fc_matches[first + k] = caps[k].fc_matches;
+            } catch (const std::exception &e) {
+              std::lock_guard<std::mutex> lk(sw->m);
+              if (read_error.empty()) read_error = e.what();
+            }
+          }
+        };
+        const int n_readers = std::max(1, std::min(std::min(n, 8), (int)std::thread::hardware_concurrency()));
+        std::vector<std::thread> pool;
+        for (int r = 1; r < n_readers; ++r) pool.push_back(std::thread(reader));
+        reader();
+        for (std::thread &t : pool) t.join();
+        if (!read_error.empty()) throw std::runtime_error(read_error);
       }
       // raw-byte captures of one length go through the int8 path together; the rest one by one
       size_t n_cap = 0;
