@@ -314,7 +314,8 @@ struct InFlight {
 
 void device_thread(Sweep *sw, int device, int first_batch, int stride) {
   try {
-    lcs::Searcher ctx[2] = {lcs::Searcher(device), lcs::Searcher(device)};
+    std::unique_ptr<lcs::Searcher> ctx[2];
+    for (int k = 0; k < 2; ++k) ctx[k].reset(new lcs::Searcher(device));
     std::unique_ptr<lcs::Searcher> one;                     // for captures that are not raw dongle bytes
     unsigned char *pinned[2] = {0, 0};
     size_t pinned_bytes[2] = {0, 0};
@@ -324,8 +325,8 @@ void device_thread(Sweep *sw, int device, int first_batch, int stride) {
       if (f.batch < 0) return;
       if (!f.carriers.empty()) {
         std::vector<std::list<Cell> > found;
-        ctx[slot].collect_batch(found);
-        if (ctx[slot].last_batch_overflowed()) std::cerr << "Warning: more cells than the result arrays hold; list truncated" << std::endl;
+        ctx[slot]->collect_batch(found);
+        if (ctx[slot]->last_batch_overflowed()) std::cerr << "Warning: more cells than the result arrays hold; list truncated" << std::endl;
         for (size_t j = 0; j < f.carriers.size(); ++j) sw->detected[f.carriers[j]].swap(found[j]);
       }
       for (size_t j = 0; j < f.singles.size(); ++j) {
@@ -382,8 +383,8 @@ void device_thread(Sweep *sw, int device, int first_batch, int stride) {
       if (!f.carriers.empty()) {
         const size_t need = f.carriers.size() * 2 * n_cap;
         if (need > pinned_bytes[slot]) {
-          if (pinned[slot]) ctx[slot].host_free(pinned[slot]);
-          pinned[slot] = (unsigned char *)ctx[slot].host_alloc(need);
+          if (pinned[slot]) ctx[slot]->host_free(pinned[slot]);
+          pinned[slot] = (unsigned char *)ctx[slot]->host_alloc(need);
           pinned_bytes[slot] = need;
         }
         std::vector<double> fcs(f.carriers.size());
@@ -391,13 +392,13 @@ void device_thread(Sweep *sw, int device, int first_batch, int stride) {
           std::memcpy(pinned[slot] + j * 2 * n_cap, caps[f.carriers[j] - first].iq_u8.data(), 2 * n_cap);
           fcs[j] = sw->opt.freq_start + 100e3 * f.carriers[j];
         }
-        ctx[slot].enqueue_batch_host(pinned[slot], LCS_FMT_IQ_U8, (int)f.carriers.size(), (uint32_t)n_cap, sw->f_search_set, fcs, fcs,
+        ctx[slot]->enqueue_batch_host(pinned[slot], LCS_FMT_IQ_U8, (int)f.carriers.size(), (uint32_t)n_cap, sw->f_search_set, fcs, fcs,
                                      sw->fs_programmed);
       }
     }
     collect(slot);
     collect(slot ^ 1);
-    for (int k = 0; k < 2; ++k) if (pinned[k]) ctx[k].host_free(pinned[k]);
+    for (int k = 0; k < 2; ++k) if (pinned[k]) ctx[k]->host_free(pinned[k]);
   } catch (const std::exception &e) {
     sw->fail(e.what());
   }

@@ -55,6 +55,8 @@ class Searcher {
     if (rc != LCS_OK) throw error("lcs_create failed (an MI355X is required; there is no CPU fallback)");
   }
   ~Searcher() { lcs_destroy(h_); }
+  Searcher(const Searcher &) = delete;               // a context has one owner
+  Searcher &operator=(const Searcher &) = delete;
   lcs_ctx *handle() { return h_; }
 
   // include/searcher.h:22-41
