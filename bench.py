@@ -430,7 +430,7 @@ def main():
                          "pipeline on blocks of OFDM symbols of --batch tracked cells")
     ap.add_argument("--input", choices=["u8", "c64"], default="u8",
                     help="resident input format: raw RTL-SDR u8 I/Q (int8 MFMA correlation kernel, default) or complex<float> "
-                         "(fp32 MFMA correlation kernel)")
+                         "(fp16 three-product MFMA correlation kernel)")
     ap.add_argument("--pipeline", type=int, default=3,
                     help="contexts (streams + workspaces) used round-robin: the latency-bound per-cell "
                          "stages of batch i overlap the PSS correlation of batch i+1")
@@ -694,7 +694,8 @@ def main():
         k_ms = float(np.mean(xc_ms)) if xc_ms else float('nan')
         k_iso = float(np.mean(iso_ms))
         i8 = kname.startswith("k_xcorr_i8")
-        peak = PEAK_I8_TOPS if i8 else PEAK_FP32_TFLOPS
+        f16 = kname.startswith("k_xcorr_f16")
+        peak = PEAK_I8_TOPS if i8 else (PEAK_BF16_TFLOPS if f16 else PEAK_FP32_TFLOPS)
         # HBM traffic of the dominant kernel from the PMC counters (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 passes,
         # corrected as MI355X_MICROARCH.md prescribes), taken from the committed summary ONLY if it was collected from
         # exactly the kernel sources that are running now.
@@ -717,7 +718,8 @@ def main():
             "value": value, "unit": "capture-buffers/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": value / PUBLISHED_BUFFERS_PER_S,
-            "dtype": ("i8 x 3 base-256 digits of 24-bit integer templates, i32 accumulate (exact)" if i8 else "f32"),
+            "dtype": ("i8 x 3 base-256 digits of 24-bit integer templates, i32 accumulate (exact)" if i8 else
+                      "f16 hi + lo parts of fp32 samples and templates (22 bits each), 3 products, f32 accumulate" if f16 else "f32"),
             "data": "synthetic", "verified": bool(seq_ok and state["mismatch"] == 0),
             "iq_samples_per_s": value * N_CAP,
             "config": {"workload": ("configs[2]: full searcher chain (PSS+SSS+FOE+TFG+MIB)" if args.stage == "full" else
@@ -728,7 +730,8 @@ def main():
                        "buffers_timed": n_buffers, "timed_region_s": dt, "stage": args.stage,
                        "ingest": ("u8 I/Q in page-locked host memory, PCIe copy of every batch inside the timed region" if args.input_host else
                                   "u8 I/Q resident in HBM") if fmt == pkg.FMT_IQ_U8 else "complex<float> resident in HBM",
-                       "xcorr_kernel": "mfma_i32_16x16x64_i8, three int8 digits per 24-bit integer template tap" if i8 else "mfma_f32_16x16x4_f32",
+                       "xcorr_kernel": "mfma_i32_16x16x64_i8, three int8 digits per 24-bit integer template tap" if i8 else
+                                       ("mfma_f32_16x16x32_f16, hi / lo fp16 split of samples and templates, three products" if f16 else "mfma_f32_16x16x4_f32"),
                        "pipeline_depth": len(ctxs),
                        "parallelism": f"carrier-sweep shard x{world}, one async RCCL all-gather of the cell records per step" if world > 1 else "single GPU",
                        "baseline_note": "vs_baseline = value / (1 buffer per ~6 s), doc/CellSearch.html:52-54 (dual-core i7-2640, ppm 100; BASELINE.md section 1)",
@@ -750,6 +753,8 @@ def main():
                                   "figure of MI355X_MICROARCH.md (16x16x64 issues every ~18 cycles, 32x32x32 every 32: both measure 4.3-4.4 POP/s at the "
                                   "sustained clock, tools/microbench/mfma_rate.hip).  frac_algorithmic counts only the 15 x 9600 lags that are consumed; "
                                   "frac_executed counts the MFMA work issued (x3 digits, 160 of 137 taps, 96 of 93 columns)." % B) if i8 else
+                                 ("achieved = SURVEY 8(d) algorithmic flops of one launch / the kernel's mean duration in the timed region, against the dense "
+                                  "fp16 MFMA peak (2.5 PFLOP/s); frac_executed counts the MFMA work issued (x3 products, 160 of 137 taps, 96 of 93 columns)") if f16 else
                                  "achieved = SURVEY 8(d) algorithmic flops / kernel time, against the fp32 MFMA peak",
                          "kernel": kname, "kernel_ms": k_ms, "kernel_ms_isolated": k_iso,
                          "frac_isolated": flops_per_buf * B / (k_iso * 1e-3) / 1e12 / peak,

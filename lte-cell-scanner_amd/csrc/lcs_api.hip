@@ -89,6 +89,9 @@ int ensure_ws(lcs_ctx *c, int n_slots, uint32_t n_cap, int n_f, bool debug, int 
   if (c->tq) { (void)hipFree(c->tq); c->tq = nullptr; }
   if (c->tsc) { (void)hipFree(c->tsc); c->tsc = nullptr; }
   c->i8_ready = false;
+  for (void **q : {(void **)&c->cap16h, (void **)&c->cap16l, (void **)&c->bt16, (void **)&c->texp16, (void **)&c->tsc16, (void **)&c->xmax16})
+    if (*q) { (void)hipFree(*q); *q = nullptr; }
+  c->f16_ready = false;
   c->cap_slots = n_slots;
   c->cap_n_cap = n_cap;
   c->cap_n_f = n_f;
@@ -110,6 +113,21 @@ int ensure_i8(lcs_ctx *c) {
   if ((rc = dev_alloc(c, &c->tq, S * LCS_G_MAX * LCS_TG))) return rc;
   if ((rc = dev_alloc(c, &c->tsc, S * LCS_G_MAX * LCS_TG))) return rc;
   c->i8_ready = true;
+  return LCS_OK;
+}
+
+// Buffers of the fp16 three-product correlation path (complex<float> sources of the batch entry points).
+int ensure_f16(lcs_ctx *c) {
+  if (c->f16_ready) return LCS_OK;
+  if (c->st_open) { c->err = "fp16 buffers cannot be (re)allocated while a stream is open: lcs_stream_close first"; return LCS_ERR_BAD_ARG; }
+  const size_t S = (size_t)c->cap_slots;
+  int rc;
+  const size_t n16 = S * lcs_cap8_stride(c->cap_n_cap);
+  if ((rc = dev_alloc(c, &c->cap16h, n16)) || (rc = dev_alloc(c, &c->cap16l, n16))) return rc;
+  if ((rc = dev_alloc(c, &c->bt16, S * LCS_NW_MAX * c->cap_G * lcs_bt16_elems_per_wg()))) return rc;
+  if ((rc = dev_alloc(c, &c->texp16, S * LCS_G_MAX * LCS_TG)) || (rc = dev_alloc(c, &c->tsc16, S * LCS_G_MAX * LCS_TG))) return rc;
+  if ((rc = dev_alloc(c, &c->xmax16, S))) return rc;
+  c->f16_ready = true;
   return LCS_OK;
 }
 
@@ -193,6 +211,7 @@ int upload_host_capbuf(lcs_ctx *c, const double *capbuf, uint32_t n_cap, const d
   if (can_i8) { if ((rc = lcs_launch_ingest_c128(c, n_cap, &exact))) return rc; }
   else if ((rc = lcs_launch_ingest(c, nullptr, 2, 1, n_cap))) return rc;
   c->use_i8 = exact;
+  c->use_f16 = false;
   *geo_out = exact ? geo8 : geo32;
   return LCS_OK;
 }
@@ -292,7 +311,7 @@ void lcs_destroy(lcs_ctx *c) {
                   c->incoh, c->sref, c->pow_, c->work, c->spinc, c->zth, c->sp, c->frq, c->peaks, c->npeaks, c->xc,
                   c->work_items, c->n_work, c->tfg, c->tfg_comp, c->ce, c->tfg_ts, c->tfg_ts_comp, c->cell_scratch,
                   c->cells_out, c->d_pss_td, c->d_pss_fd, c->d_sss_fd, c->d_pbch_scr, c->d_derm_inv, c->d_dbg, c->pk_items, c->n_pk,
-                  c->sss_ws, c->d_pn_jump, c->cap8, c->cap8s, c->bt8, c->tq, c->tsc, c->h2d, c->trk_td, c->trk_syms, c->trk_raw, c->trk_ce,
+                  c->sss_ws, c->d_pn_jump, c->cap8, c->cap8s, c->bt8, c->tq, c->tsc, c->cap16h, c->cap16l, c->bt16, c->texp16, c->tsc16, c->xmax16, c->h2d, c->trk_td, c->trk_syms, c->trk_raw, c->trk_ce,
                   c->trk_meta, c->trk_rs, c->trk_fmeta, c->trk_pw, c->trk_idx, c->trk_small, c->trk_cells, c->trk_acfd, c->trk_actd,
                   c->trk_syncce, c->trk_sync, c->d_flag};
   for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -416,7 +435,7 @@ int lcs_batch_enqueue(lcs_ctx *c, const void *d_capbufs, int fmt, int n_buf, uin
   // every template group; every other source takes the fp32 kernel (spread <= 111); pack_grid thins the groups of a grid
   // that is too sparse for that
   const XcGeom geo = pack_grid(n_cap, n_f, 2 /* DS_COMB_ARM, ref src/CellSearch.cpp:484 */, f_search_set, fc_requested, fc_programmed,
-                               n_buf, fs_programmed, fmt == LCS_FMT_IQ_U8 ? kMaxTapsI8 : kMaxTapsF32);
+                               n_buf, fs_programmed, kMaxTapsI8);      // the int8 and the fp16 kernel both hold 160 taps per group
   if ((rc = ensure_ws(c, n_buf, n_cap, n_f, false, geo.G))) return rc;
   if ((rc = pinned(c, sizeof(SlotParams) * n_buf + sizeof(double) * LCS_NF_MAX))) return rc;
   SlotParams *hp = (SlotParams *)c->h_pinned;
@@ -427,8 +446,11 @@ int lcs_batch_enqueue(lcs_ctx *c, const void *d_capbufs, int fmt, int n_buf, uin
   HIPCHK(c, hipMemcpyAsync(c->fset, hf, sizeof(double) * n_f, hipMemcpyHostToDevice, c->stream));
   c->cap64_valid = false;
   c->use_i8 = fmt == LCS_FMT_IQ_U8;
+  c->use_f16 = fmt == LCS_FMT_C64;            // complex<float> sources: fp16 hi / lo operands, three products (pss_xcorr_f16.hip)
   if (fmt == LCS_FMT_IQ_U8 && (rc = ensure_i8(c))) return rc;      // int8 copies: every u8 source (the fp64 stages read them)
+  if (fmt == LCS_FMT_C64 && (rc = ensure_f16(c))) return rc;
   if ((rc = lcs_launch_ingest(c, d_capbufs, fmt, n_buf, n_cap))) return rc;
+  if (c->use_f16 && (rc = lcs_launch_ingest_f16(c, n_buf, n_cap))) return rc;
   if ((rc = lcs_launch_xcorr(c, n_buf, geo, false, true))) return rc;
   if ((rc = lcs_launch_peak_search(c, n_buf, geo, std::pow(10.0, -12.0 / 10.0), true))) return rc;
   if (stage_mask & 2) {
@@ -903,6 +925,7 @@ int stream_chain(lcs_ctx *c, int k) {
   const XcGeom geo = make_geo(c->st_n_cap, 1, 2);
   int rc;
   c->use_i8 = c->st_fmt == LCS_FMT_IQ_U8;      // one hypothesis: no window-start spread, the int8 kernel always fits
+  c->use_f16 = false;
   HIPCHK(c, hipMemcpyAsync(c->st_din, c->st_hin[k], c->st_in_bytes, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->params, &h->p, sizeof(SlotParams), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->fset, &h->f, sizeof(double), hipMemcpyHostToDevice, c->stream));

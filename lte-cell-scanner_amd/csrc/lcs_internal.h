@@ -144,6 +144,13 @@ struct lcs_ctx {
   double *tq = nullptr;              // per template: integer scale q
   float *tsc = nullptr;              // per template: 1 / (128 q)
   bool i8_ready = false, use_i8 = false;
+  // fp16 three-product path (pss_xcorr_f16.hip): complex<float> sources of the batched device entry points
+  uint32_t *cap16h = nullptr, *cap16l = nullptr;   // (re, im) fp16 pairs, hi and lo parts, slot stride lcs_cap8_stride
+  uint4 *bt16 = nullptr;             // template operands, hi and lo terms
+  int *texp16 = nullptr;             // per template column: power-of-two scale exponent
+  float *tsc16 = nullptr;            // per template column: 2^-(k_x + k_t)
+  unsigned *xmax16 = nullptr;        // per slot: bits of the largest |component|
+  bool f16_ready = false, use_f16 = false;
   bool src_u8 = false;               // the resident buffers came from a u8 source: the fp64 stages read cap8
   double2 *cap64 = nullptr;          // slot 0 only: fp64 copy for the host (complex<double>) entry points
   bool cap64_valid = false;
@@ -269,6 +276,11 @@ int lcs_launch_single_layout(lcs_ctx *c, const XcGeom &geo, int slot, float *ref
 // pss_xcorr_i8.hip
 int lcs_launch_fill_btab_i8(lcs_ctx *c, int n_buf, const XcGeom &geo);
 int lcs_launch_xcorr_i8(lcs_ctx *c, hipStream_t sxc, const XcGeom &geo, int slot0, int n_slots, int xcd_map);
+// pss_xcorr_f16.hip
+int lcs_launch_ingest_f16(lcs_ctx *c, int n_buf, uint32_t n_cap);          // cap32 -> fp16 hi / lo pairs + per-buffer scale
+int lcs_launch_fill_btab_f16(lcs_ctx *c, int n_buf, const XcGeom &geo);
+int lcs_launch_xcorr_f16(lcs_ctx *c, hipStream_t sxc, const XcGeom &geo, int slot0, int n_slots, int xcd_map);
+size_t lcs_bt16_elems_per_wg(void);
 
 int lcs_launch_xc_debug(lcs_ctx *c, const XcGeom &geo);   // raw xc for slot 0 (debug output only)
 // peak_search.hip

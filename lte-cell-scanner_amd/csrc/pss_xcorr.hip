@@ -675,6 +675,9 @@ int lcs_launch_xcorr(lcs_ctx *c, int n_buf, const XcGeom &geo, bool want_incoh, 
   if (c->use_i8) {
     int rc_ = lcs_launch_fill_btab_i8(c, n_buf, geo);
     if (rc_) return rc_;
+  } else if (c->use_f16) {
+    int rc_ = lcs_launch_fill_btab_f16(c, n_buf, geo);
+    if (rc_) return rc_;
   } else
     hipLaunchKernelGGL(k_fill_btab, dim3(geo.n_comb * geo.G * n_buf), dim3(256), 0, c->stream, c->tmpl,
                        c->start, c->smin, c->kp2, c->btab, geo, n_buf);
@@ -717,6 +720,9 @@ int lcs_launch_xcorr(lcs_ctx *c, int n_buf, const XcGeom &geo, bool want_incoh, 
     if (ns <= 0) continue;
     if (c->use_i8) {                                                            // u8 sources: int8 three-digit kernel
       int rc_ = lcs_launch_xcorr_i8(c, sxc, geo, s0, ns, part ? 0 : 1);
+      if (rc_) return rc_;
+    } else if (c->use_f16) {                                                    // complex<float> batches: fp16 three-product kernel
+      int rc_ = lcs_launch_xcorr_f16(c, sxc, geo, s0, ns, part ? 0 : 1);
       if (rc_) return rc_;
     } else {                                                                    // fp32: 4-wave workgroups, B through LDS
       constexpr int NWV = 4;

@@ -1,0 +1,295 @@
+// pss_xcorr_f16.hip -- the PSS correlation for capture buffers that are NOT dongle bytes (complex<float> sources already
+// resident in HBM), on the fp16 matrix cores at fp32 accuracy.
+//
+// A float sample has 24 significant bits, an fp16 operand 11.  Scaled by a power of two per buffer (so that the largest
+// component lies in [512, 1024): exact), every sample component x splits into xh = fp16(x) and xl = fp16(x - xh): xh + xl
+// carries 22 bits (relative error 2^-22 = 2.4e-7, the two roundings of an fp32 product chain).  The templates split the
+// same way (per-template power-of-two scale).  Then  x t = xh th + xh tl + xl th + xl tl  with the last term below 2^-22 of
+// the first: three v_mfma_f32_16x16x32_f16 per operand pair, every product exact in the fp32 accumulator, summed in
+// fp32 by the matrix pipe.  That is 3 x the dense fp16 rate (2.5 PFLOP/s) against the fp32 MFMA rate (157 TFLOP/s) of
+// k_xcorr_mfma_blk: ~5 x less matrix-pipe time for the same 1e-6 agreement with the reference.
+//
+// Formulation as pss_xcorr_i8.hip: real GEMM with K = 2 taps, the capture buffer in natural (re, im) order = the A operand
+// (one fp16 pair = one dword per sample, so a window starts at any sample without the shifted copies the 2-byte int8
+// pairs need), B_re = (tr, -ti), B_im = (ti, tr), the window-start spread of a template group folded into the B table as
+// delays.  v_mfma_f32_16x16x32_f16 takes K = 32 = 16 taps: lane (i, kg) of an A operand holds samples lag_i + 16 kb +
+// 4 kg .. + 3 (16 bytes, read from LDS at 4-byte alignment), the operand of (sub-tile mt, tap block kb) depends on mt + kb
+// only and slides by one operand per block.  256-thread workgroup = 512 lags x one 16-template group, 8 sub-tiles per
+// wave; a window is 10 tap blocks (160 taps) in two chunks of 5: the B operands of a chunk (hi and lo terms, both
+// outputs: 20 KB) are double-buffered in LDS by LDS-DMA one chunk ahead, the samples (hi and lo, 5.6 KB) one window
+// ahead.  52 KB of LDS, 64 fp32 accumulators + 32 power sums per lane: no digit recombination, the epilogue is two FMAs
+// per output and window.
+#include "lcs_internal.h"
+#include <algorithm>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+
+#define NW LCS_NW_MAX
+#define NFM LCS_NF_MAX
+#define GM LCS_G_MAX
+
+#define F16_MT 8
+#define F16_LAGS (4 * F16_MT * 16)
+#define F16_TILES ((LCS_N_IDX + F16_LAGS - 1) / F16_LAGS)
+#define F16_NKB 10                                        // 16-tap blocks per window: 137 taps + spread <= 160
+#define F16_CH 5                                          // tap blocks per B chunk
+#define F16_AW (F16_LAGS + 16 * F16_NKB + 16)             // staged samples per window
+#define F16_ADW (((F16_AW + 63) / 64) * 64)               // dwords (= samples) per staged array: whole 64-dword LDS-DMA pieces
+#define F16_CHUNK (2 * F16_CH * 2 * 64)                   // uint4 per B chunk: [term hi / lo][kb][op][lane]
+#define F16_TARGET_EXP 9                                  // operands are scaled into [2^9, 2^10)
+
+__device__ __forceinline__ uint32_t f16_bits(_Float16 h) { return (uint32_t)__builtin_bit_cast(unsigned short, h); }
+__device__ __forceinline__ void f16_split(float v, _Float16 &hi, _Float16 &lo) {
+  hi = (_Float16)v;
+  lo = (_Float16)(v - (float)hi);
+}
+
+// ---- per buffer: the power of two that brings the largest sample component into [512, 1024)
+__global__ __launch_bounds__(256) void k_f16_max(const float2 *__restrict__ cap32, uint32_t n_cap, unsigned *__restrict__ xmax_bits) {
+  LCS_TAIL_PRIO();
+  const int slot = blockIdx.y;
+  const float2 *c = cap32 + (size_t)slot * n_cap;
+  float m = 0.f;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_cap; i += gridDim.x * blockDim.x) {
+    const float2 v = c[i];
+    m = fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y)));
+  }
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_down(m, off));
+  if ((threadIdx.x & 63) == 0 && m > 0.f && m < INFINITY) atomicMax(xmax_bits + slot, __float_as_uint(m));     // non-negative floats order like their bits
+}
+__device__ __forceinline__ int f16_scale_exp(float mx) { return (mx > 0.f) ? F16_TARGET_EXP - ilogbf(mx) : 0; }
+
+// cap32 -> (re, im) fp16 pairs, hi and lo parts, zero-padded behind n_cap like the int8 copies (the LDS-DMA of the
+// correlation reads past the end)
+__global__ __launch_bounds__(256) void k_f16_ingest(const float2 *__restrict__ cap32, uint32_t n_cap, const unsigned *__restrict__ xmax_bits,
+                                                    uint32_t *__restrict__ cap16h, uint32_t *__restrict__ cap16l) {
+  LCS_TAIL_PRIO();
+  const int slot = blockIdx.y;
+  const size_t stride = lcs_cap8_stride(n_cap);
+  const int k = f16_scale_exp(__uint_as_float(xmax_bits[slot]));
+  const float2 *c = cap32 + (size_t)slot * n_cap;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < stride; i += (size_t)gridDim.x * blockDim.x) {
+    uint32_t h = 0, l = 0;
+    if (i < n_cap) {
+      const float2 v = c[i];
+      _Float16 rh, rl, ih, il;
+      f16_split(ldexpf(v.x, k), rh, rl);
+      f16_split(ldexpf(v.y, k), ih, il);
+      h = f16_bits(rh) | (f16_bits(ih) << 16);
+      l = f16_bits(rl) | (f16_bits(il) << 16);
+    }
+    cap16h[(size_t)slot * stride + i] = h;
+    cap16l[(size_t)slot * stride + i] = l;
+  }
+}
+
+// per template column: power-of-two scale exponent of the template (largest tap into [512, 1024)) and the factor that
+// takes the scaled correlation back to the reference's units, 2^-(k_x + k_t)
+__global__ __launch_bounds__(256) void k_f16_scales(const float2 *__restrict__ tmpl, const unsigned *__restrict__ xmax_bits, int *__restrict__ texp,
+                                                    float *__restrict__ sc, XcGeom geo) {
+  LCS_TAIL_PRIO();
+  const int slot = blockIdx.x;
+  const int kx = f16_scale_exp(__uint_as_float(xmax_bits[slot]));
+  for (int col = threadIdx.x; col < geo.G * LCS_TG; col += blockDim.x) {
+    const int c = lcs_col_tmpl(geo, col >> 4, col & 15);
+    float mx = 0.f;
+    if (c >= 0) {
+      const float2 *T = tmpl + (((size_t)slot * NFM + c / 3) * 3 + c % 3) * 137;
+      for (int m = 0; m < 137; ++m) mx = fmaxf(mx, fmaxf(fabsf(T[m].x), fabsf(T[m].y)));
+    }
+    const int kt = f16_scale_exp(mx);
+    texp[(size_t)slot * GM * LCS_TG + col] = kt;
+    sc[(size_t)slot * GM * LCS_TG + col] = (c >= 0) ? ldexpf(1.f, -(kx + kt)) : 0.f;
+  }
+}
+
+// bt16[slot][w][g][chunk][term][kbc][op][lane] (uint4 = 8 fp16): lane (n, kg) holds taps 16 kb + 4 kg .. + 3 (kb = 5 chunk +
+// kbc) of template column 16 g + n delayed by start[w][foi] - smin[w][g] (zero outside its 137 taps) as the pairs (tr, -ti)
+// (op 0, real output) or (ti, tr) (op 1, imaginary output); term 0 = fp16(value), term 1 = fp16(value - term 0).
+__global__ __launch_bounds__(256) void k_fill_btab_f16(const float2 *__restrict__ tmpl, const int *__restrict__ start, const int *__restrict__ smin,
+                                                       const int *__restrict__ texp, uint4 *__restrict__ bt16, XcGeom geo) {
+  LCS_TAIL_PRIO();
+  const int slot = blockIdx.z, wg = blockIdx.y, w = wg / geo.G, g = wg % geo.G;
+  const int s0 = smin[((size_t)slot * NW + w) * GM + g];
+  uint4 *out = bt16 + (((size_t)slot * geo.n_comb + w) * geo.G + g) * (size_t)(2 * F16_CHUNK);
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < F16_NKB * 64; e += gridDim.x * blockDim.x) {
+    const int lane = e & 63, kb = e >> 6;
+    const int c = lcs_col_tmpl(geo, g, lane & 15), kg = lane >> 4;
+    float tr[4] = {0.f, 0.f, 0.f, 0.f}, ti[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c >= 0) {
+      const int foi = c / 3, t = c % 3;
+      const int delta = start[((size_t)slot * NW + w) * NFM + foi] - s0;
+      const int kt = texp[(size_t)slot * GM * LCS_TG + g * LCS_TG + (lane & 15)];
+      const float2 *T = tmpl + (((size_t)slot * NFM + foi) * 3 + t) * 137;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int tap = 16 * kb + 4 * kg + m - delta;
+        if (tap >= 0 && tap < 137) { tr[m] = ldexpf(T[tap].x, kt); ti[m] = ldexpf(T[tap].y, kt); }
+      }
+    }
+#pragma unroll
+    for (int op = 0; op < 2; ++op) {
+      uint32_t hi[4], lo[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const float a = op ? ti[m] : tr[m], b = op ? tr[m] : -ti[m];       // (tr, -ti) or (ti, tr)
+        _Float16 ah, al, bh, bl;
+        f16_split(a, ah, al);
+        f16_split(b, bh, bl);
+        hi[m] = f16_bits(ah) | (f16_bits(bh) << 16);
+        lo[m] = f16_bits(al) | (f16_bits(bl) << 16);
+      }
+      const int chunk = kb / F16_CH, kbc = kb % F16_CH;
+      uint4 *o = out + (size_t)chunk * F16_CHUNK;
+      typedef unsigned u4v __attribute__((ext_vector_type(4)));
+      const u4v vh = {hi[0], hi[1], hi[2], hi[3]}, vl = {lo[0], lo[1], lo[2], lo[3]};
+      __builtin_nontemporal_store(vh, reinterpret_cast<u4v *>(o + ((0 * F16_CH + kbc) * 2 + op) * 64 + lane));
+      __builtin_nontemporal_store(vl, reinterpret_cast<u4v *>(o + ((1 * F16_CH + kbc) * 2 + op) * 64 + lane));
+    }
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void k_xcorr_f16x3(const uint32_t *__restrict__ cap16h, const uint32_t *__restrict__ cap16l,
+                                                        const int *__restrict__ smin, const uint4 *__restrict__ bt16,
+                                                        const float *__restrict__ sc, float *__restrict__ sg, XcGeom geo, int slot0,
+                                                        int n_slots, int xcd_map) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int per_slot = F16_TILES * geo.G;
+  int q, sidx;
+  if (xcd_map) { sidx = blockIdx.x & 7; q = blockIdx.x >> 3; sidx += 8 * (q / per_slot); q = q % per_slot; }
+  else { sidx = blockIdx.x / per_slot; q = blockIdx.x % per_slot; }
+  if (sidx >= n_slots) return;
+  const int slot = slot0 + sidx, g = q / F16_TILES, idx0 = (q % F16_TILES) * F16_LAGS;
+  const int widx0 = idx0 + wave * (F16_MT * 16);
+
+  __shared__ uint32_t ldsA[2][2][F16_ADW];       // [window & 1][hi, lo][sample]
+  __shared__ uint4 ldsB[2][F16_CHUNK];           // [chunk counter & 1]
+  constexpr int NCB = F16_CHUNK / 64;            // 1 KiB pieces of a B chunk
+  constexpr int NCA = 2 * (F16_ADW / 64);        // 256-byte pieces of the two sample arrays
+  const size_t cstride = lcs_cap8_stride(geo.n_cap);
+  const uint32_t *caph = cap16h + (size_t)slot * cstride + lane, *capl = cap16l + (size_t)slot * cstride + lane;
+  const int *smin_s = smin + (size_t)slot * NW * GM + g;
+  const uint4 *bt_s = bt16 + ((size_t)slot * geo.n_comb * geo.G + g) * (size_t)(2 * F16_CHUNK) + lane;
+  const size_t bt_wstride = (size_t)geo.G * (2 * F16_CHUNK);
+  const float my_sc = sc[(size_t)slot * GM * LCS_TG + g * LCS_TG + (lane & 15)];
+  const int p0 = wave * (F16_MT * 16) + (lane & 15) + 4 * (lane >> 4);     // first sample of this lane's operand 0 in the staged window
+
+  f32x4 P[F16_MT];
+#pragma unroll
+  for (int mt = 0; mt < F16_MT; ++mt) P[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#define F16_DMA_A(W)                                                                                         \
+  {                                                                                                          \
+    const int L0_ = idx0 + smin_s[(W) * GM];                                                                 \
+    _Pragma("unroll") for (int c_ = 0; c_ < (NCA + 3) / 4; ++c_) {                                           \
+      const int ca_ = wave + 4 * c_;                                                                         \
+      if (ca_ < NCA) {                                                                                       \
+        const int hl_ = ca_ / (F16_ADW / 64), k_ = ca_ % (F16_ADW / 64);                                     \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)((hl_ ? capl : caph) + L0_ + 64 * k_), \
+                                         (__attribute__((address_space(3))) void *)(ldsA[(W) & 1][hl_] + 64 * k_), 4, 0, 0); \
+      }                                                                                                      \
+    }                                                                                                        \
+  }
+#define F16_DMA_B(W, C, CC)                                                                                  \
+  {                                                                                                          \
+    uint4 *dst_ = ldsB[(CC) & 1];                                                                            \
+    const uint4 *src_ = bt_s + (size_t)(W) * bt_wstride + (size_t)(C) * F16_CHUNK;                           \
+    _Pragma("unroll") for (int c_ = 0; c_ < (NCB + 3) / 4; ++c_) {                                           \
+      const int ch_ = wave + 4 * c_;                                                                         \
+      if (ch_ < NCB)                                                                                         \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src_ + ch_ * 64),  \
+                                         (__attribute__((address_space(3))) void *)(dst_ + ch_ * 64), 16, 0, 0); \
+    }                                                                                                        \
+  }
+  // 16 bytes = 4 samples from a 4-byte aligned LDS address (the window starts at any sample)
+  typedef uint4 __attribute__((aligned(4))) uint4_a4;
+#define F16_RD_A(U) { const uint4 th_ = *reinterpret_cast<const uint4_a4 *>(bufAh + 16 * (U)); const uint4 tl_ = *reinterpret_cast<const uint4_a4 *>(bufAl + 16 * (U)); \
+                      Ah[(U) % (F16_MT + 1)] = __builtin_bit_cast(h8, th_); Al[(U) % (F16_MT + 1)] = __builtin_bit_cast(h8, tl_); }
+
+  F16_DMA_A(0);
+  F16_DMA_B(0, 0, 0);
+  int cc = 0;                                 // chunk counter: the B buffer in use is cc & 1
+  for (int w = 0; w < geo.n_comb; ++w) {
+    f32x4 aR[F16_MT], aI[F16_MT];
+    h8 Ah[F16_MT + 1], Al[F16_MT + 1];        // operands u = kb .. kb + 7 of the current block, one slot ahead for the next
+    const uint32_t *bufAh = ldsA[w & 1][0] + p0, *bufAl = ldsA[w & 1][1] + p0;
+#pragma unroll
+    for (int c = 0; c < 2; ++c, ++cc) {
+      __syncthreads();                        // this chunk's operands (and, at c == 0, the window's samples) have landed; the other buffers are free
+      if (c == 0) { F16_DMA_B(w, 1, cc + 1); }
+      else if (w + 1 < geo.n_comb) { F16_DMA_A(w + 1); F16_DMA_B(w + 1, 0, cc + 1); }
+      const uint4 *bl = ldsB[cc & 1] + lane;
+      if (c == 0) {
+#pragma unroll
+        for (int u = 0; u < F16_MT; ++u) F16_RD_A(u);
+      }
+#pragma unroll
+      for (int kbc = 0; kbc < F16_CH; ++kbc) {
+        const int kb = F16_CH * c + kbc;
+        h8 B[2][2];                           // [term][op]
+#pragma unroll
+        for (int term = 0; term < 2; ++term)
+#pragma unroll
+          for (int op = 0; op < 2; ++op) B[term][op] = __builtin_bit_cast(h8, bl[((term * F16_CH + kbc) * 2 + op) * 64]);
+        if (kb + 1 < F16_NKB) F16_RD_A(kb + F16_MT);          // the operand the next block adds
+        // three products per output: xh th, xh tl, xl th; sixteen independent accumulators between two uses of one
+#pragma unroll
+        for (int pr = 0; pr < 3; ++pr) {
+#pragma unroll
+          for (int mt = 0; mt < F16_MT; ++mt) {
+            const h8 a = (pr == 2) ? Al[(kb + mt) % (F16_MT + 1)] : Ah[(kb + mt) % (F16_MT + 1)];
+            const int term = (pr == 1) ? 1 : 0;
+            const f32x4 cr = (kb == 0 && pr == 0) ? (f32x4){0.f, 0.f, 0.f, 0.f} : aR[mt];
+            const f32x4 ci = (kb == 0 && pr == 0) ? (f32x4){0.f, 0.f, 0.f, 0.f} : aI[mt];
+            aR[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, B[term][0], cr, 0, 0, 0);
+            aI[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, B[term][1], ci, 0, 0, 0);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int mt = 0; mt < F16_MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) P[mt][r] = fmaf(aI[mt][r], aI[mt][r], fmaf(aR[mt][r], aR[mt][r], P[mt][r]));
+  }
+#undef F16_DMA_A
+#undef F16_DMA_B
+#undef F16_RD_A
+  const float ncomb = (float)geo.n_comb;
+  float *o = sg + (((size_t)slot * geo.G + g) * LCS_N_IDX) * LCS_TG + (lane & 15);
+#pragma unroll
+  for (int mt = 0; mt < F16_MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int idx = widx0 + mt * 16 + 4 * (lane >> 4) + r;
+      if (idx < LCS_N_IDX) o[(size_t)idx * LCS_TG] = __fdiv_rn((P[mt][r] * my_sc) * my_sc, ncomb);      // powers of two: exact, in two steps against underflow
+    }
+}
+
+// ---- launchers -----------------------------------------------------------------------------------------------------
+int lcs_launch_ingest_f16(lcs_ctx *c, int n_buf, uint32_t n_cap) {
+  HIPCHK(c, hipMemsetAsync(c->xmax16, 0, sizeof(unsigned) * n_buf, c->stream));
+  hipLaunchKernelGGL(k_f16_max, dim3(32, n_buf), dim3(256), 0, c->stream, c->cap32, n_cap, c->xmax16);
+  hipLaunchKernelGGL(k_f16_ingest, dim3(64, n_buf), dim3(256), 0, c->stream, c->cap32, n_cap, c->xmax16, c->cap16h, c->cap16l);
+  HIPCHK(c, hipGetLastError());
+  return LCS_OK;
+}
+int lcs_launch_fill_btab_f16(lcs_ctx *c, int n_buf, const XcGeom &geo) {
+  hipLaunchKernelGGL(k_f16_scales, dim3(n_buf), dim3(256), 0, c->stream, c->tmpl, c->xmax16, c->texp16, c->tsc16, geo);
+  hipLaunchKernelGGL(k_fill_btab_f16, dim3((F16_NKB * 64 + 255) / 256, geo.n_comb * geo.G, n_buf), dim3(256), 0, c->stream, c->tmpl, c->start,
+                     c->smin, c->texp16, c->bt16, geo);
+  HIPCHK(c, hipGetLastError());
+  return LCS_OK;
+}
+int lcs_launch_xcorr_f16(lcs_ctx *c, hipStream_t sxc, const XcGeom &geo, int slot0, int n_slots, int xcd_map) {
+  const unsigned grid = (unsigned)(F16_TILES * geo.G * n_slots);
+  hipLaunchKernelGGL(k_xcorr_f16x3, dim3(grid), dim3(256), 0, sxc, c->cap16h, c->cap16l, c->smin, c->bt16, c->tsc16, c->single, geo, slot0, n_slots,
+                     xcd_map);
+  HIPCHK(c, hipGetLastError());
+  // executed work: per wave and window 3 products x F16_NKB tap blocks x F16_MT sub-tiles x (re, im) MFMAs of 16x16x32 MACs
+  c->last_xc_ops += (double)grid * 4 * geo.n_comb * (3.0 * F16_NKB * F16_MT * 2) * (2.0 * 16 * 16 * 32);
+  c->last_xc_kernel = "k_xcorr_f16x3";
+  return LCS_OK;
+}
+size_t lcs_bt16_elems_per_wg(void) { return (size_t)(2 * F16_CHUNK); }

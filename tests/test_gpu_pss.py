@@ -76,7 +76,7 @@ def _check_frq(frq, ro, tag, tie=5e-7):
 
 def _batch_arrays_vs_oracle(S, pkg, bufs_u8, f, fcs, n_cap, what):
     """Run `bufs_u8` through the device-resident batch entry point as raw u8 I/Q (int8 MFMA kernel when the grid
-    fits it) and as complex<float> (fp32 MFMA kernel), read back EVERY element of xc_incoherent_single / collapsed
+    fits it) and as complex<float> (fp16 three-product MFMA kernel), read back EVERY element of xc_incoherent_single / collapsed
     pow / frq / sp_incoherent / Z_th1 of every buffer and compare with the oracle (reference semantics:
     src/searcher.cpp:263-308, 353-383; tolerance as test/test_xcorr_pss.cpp:104-109 and the 1e-5 of north_star)."""
     import torch
@@ -88,8 +88,9 @@ def _batch_arrays_vs_oracle(S, pkg, bufs_u8, f, fcs, n_cap, what):
         ro = O.xcorr_pss(iq_u8_to_capbuf(bufs_u8[b]), f, 2, fcs[b], fcs[b], FS)
         ro["z_th1"] = O.z_th1(ro["sp_incoherent"], ro["n_comb_xc"])
         oracle.append(ro)
-    for fmt, dptr, name in ((pkg.FMT_IQ_U8, d8.data_ptr(), "u8/int8"), (pkg.FMT_C64, d32.data_ptr(), "c64/fp32")):
+    for fmt, dptr, name, kernel in ((pkg.FMT_IQ_U8, d8.data_ptr(), "u8/int8", "k_xcorr_i8x3"), (pkg.FMT_C64, d32.data_ptr(), "c64/fp16x3", "k_xcorr_f16x3")):
         S.search_batch(dptr, fmt, n_buf, n_cap, f, fcs, fcs, FS, pkg.STAGE_PSS, max_cells_per_buf=64)
+        assert S.last_xcorr_info()[0] == kernel
         for b in range(n_buf):
             r, ro = S.batch_readback(b, f.size), oracle[b]
             tag = f"{what} [{name}] buffer {b}"
@@ -334,3 +335,39 @@ def test_sparse_frequency_grids_are_repacked(S, pkg, capbuf_0000):
         r = S.xcorr_pss(cap, f, 2, fc, fc, FS)
         _check_xcorr(r, ro, f"sparse grid step {f[1] - f[0]}")
         _batch_arrays_vs_oracle(S, pkg, [g["iq_u8"]], f, np.array([fc]), 153600, f"sparse grid step {f[1] - f[0]}")
+
+
+def test_fp16_kernel_on_unquantised_float_sources(S, pkg):
+    """complex<float> batches whose samples are NOT dongle values take the fp16 three-product kernel (samples and templates
+    as fp16 hi + lo parts, 22 bits each): genuinely 24-bit float data of very different scales in one batch (each buffer
+    gets its own power-of-two scale), every element against the oracle run on the same float values."""
+    import torch
+    fc = 739e6
+    f = f_search_set_for(fc, 100)
+    rng = np.random.default_rng(41)
+    a, _ = pkg.synth.make_capbuf(7001, fc, [dict(n_id_1=60, n_id_2=1, f_off=12e3), dict(n_id_1=9, n_id_2=0, f_off=-48e3, gain_db=-3)], 6.0, quantise=False)
+    b, _ = pkg.synth.make_capbuf(7002, fc, [dict(n_id_1=130, n_id_2=2, f_off=30e3, cp_normal=False)], 0.0, quantise=False)
+    noise = 0.1 * (rng.normal(size=153600) + 1j * rng.normal(size=153600))
+    bufs = [a.astype(np.complex64), (b * 3.7e-4).astype(np.complex64), (noise * 250.0).astype(np.complex64), np.zeros(153600, np.complex64)]
+    bufs[3][1000:1137] = 1e-3 * O.pss_td(1).astype(np.complex64)          # an all-zero buffer but for one PSS: extreme dynamic range
+    d = torch.from_numpy(np.stack(bufs)).cuda()
+    fcs = np.full(4, fc)
+    res = S.search_batch(d.data_ptr(), pkg.FMT_C64, 4, 153600, f, fcs, fcs, FS, pkg.STAGE_FULL, max_cells_per_buf=16)
+    assert S.last_xcorr_info()[0] == "k_xcorr_f16x3"
+    worst = 0.0
+    for k in range(3):
+        ro = O.xcorr_pss(bufs[k].astype(np.complex128), f, 2, fc, fc, FS)
+        r = S.batch_readback(k, f.size)
+        err = np.abs(r["single"].astype(np.float64) - ro["single"]) / ro["single"]
+        worst = max(worst, float(err.max()))
+        assert err.max() < RTOL, (k, err.max())
+        _check_frq(r["frq"], ro, f"float buffer {k}")
+        assert (np.abs(r["pow"] - ro["pow"]) / ro["pow"]).max() < RTOL
+        co, _ = O.search_capbuf(bufs[k].astype(np.complex128), f, fc, fc, FS)
+        assert [(c.n_id_cell(), c.ind, c.sfn) for c in res[k]] == [(c.n_id_cell(), c.ind, c.sfn) for c in co], k
+    assert [c.n_id_cell() for c in res[0]] == [181, 27] or len(res[0]) >= 1
+    # the nearly empty buffer: absolute agreement (most positions correlate to exactly zero in both)
+    ro = O.xcorr_pss(bufs[3].astype(np.complex128), f, 2, fc, fc, FS)
+    r = S.batch_readback(3, f.size)
+    assert np.abs(r["single"].astype(np.float64) - ro["single"]).max() < 1e-6 * ro["single"].max()
+    print(f"fp16 three-product kernel: worst relative deviation of xc_incoherent_single from the oracle {worst:.2e}")

@@ -7,4 +7,4 @@ NAME=$1; shift
 mkdir -p build_exp
 C=lte-cell-scanner_amd/csrc
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -Wall -Wno-unused-function "$@" \
-  -o build_exp/liblcs_$NAME.so $C/pss_xcorr.hip $C/pss_xcorr_i8.hip $C/peak_search.hip $C/sss_foe.hip $C/tfg_mib.hip $C/tracker.hip $C/lcs_api.hip $C/lte_tables.cpp
+  -o build_exp/liblcs_$NAME.so $C/pss_xcorr.hip $C/pss_xcorr_i8.hip $C/pss_xcorr_f16.hip $C/peak_search.hip $C/sss_foe.hip $C/tfg_mib.hip $C/tracker.hip $C/lcs_api.hip $C/lte_tables.cpp
