@@ -21,8 +21,9 @@
  *  - correlation kernel: the DATA decides.  Dongle samples are exactly (u8 - 127) / 128 (src/capbuf.cpp:172-181) and exact
  *    in int8: handed over as raw bytes (LCS_FMT_IQ_U8) or as complex<double> through the reference's call shape (the host
  *    entry points check every component on the device), they run on the int8 matrix cores (templates as 24-bit integers
- *    in three int8 digits, exact int32 accumulation); every other buffer takes the fp32 MFMA kernel.  Both agree with the
- *    reference to ~1e-7 relative.  Templates are processed 16 to a group; any f_search_set is accepted: a grid whose
+ *    in three int8 digits, exact int32 accumulation); batches of complex<float> buffers (LCS_FMT_C64) run on the fp16
+ *    matrix cores (fp16 hi + lo parts of samples and templates, three products, fp32 accumulation), any other single
+ *    buffer on the fp32 MFMA kernel.  All agree with the reference to ~1e-6 relative or better.  Templates are processed 16 to a group; any f_search_set is accepted: a grid whose
  *    hypotheses' window starts drift apart by more samples than a group's tap blocks hold (> 23 samples for int8, > 111
  *    for fp32 -- far sparser than the 5 kHz grids of the CLI) is packed with fewer whole hypotheses per group, down to
  *    one, at proportionally more work.
