@@ -418,9 +418,8 @@ static int percell_round(lcs_ctx *c, int n_buf, uint32_t n_cap, int r) {
   int rc;
   if ((rc = lcs_launch_gather_work(c, n_buf, r * c->round_cells, c->round_cells))) return rc;
   if ((rc = lcs_launch_tfg(c, n_cap, true))) return rc;
-  if ((rc = lcs_launch_tfoec(c, 0))) return rc;
-  if ((rc = lcs_launch_mib(c, 0))) return rc;
-  return lcs_launch_scatter_back(c);
+  if ((rc = lcs_launch_tfoec(c, false))) return rc;
+  return lcs_launch_mib(c, true);
 }
 
 int lcs_batch_enqueue(lcs_ctx *c, const void *d_capbufs, int fmt, int n_buf, uint32_t n_cap, const double *f_search_set,
@@ -728,7 +727,7 @@ int lcs_tfoec(lcs_ctx *c, const lcs_cell *cell, const double *tfg, const double 
   HIPCHK(c, hipMemcpyAsync(c->tfg_ts, tfg_timestamp, sizeof(double) * n_ofdm, hipMemcpyHostToDevice, c->stream));
   if ((rc = lcs_launch_rs_build(c))) return rc;
   c->needed_rows_only = false;
-  if ((rc = lcs_launch_tfoec(c, 1))) return rc;
+  if ((rc = lcs_launch_tfoec(c, true))) return rc;
   HIPCHK(c, hipMemcpyAsync(tfg_comp, c->tfg_comp, sizeof(double2) * n_ofdm * LCS_TFG_NSC, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(tfg_comp_timestamp, c->tfg_ts_comp, sizeof(double) * n_ofdm, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(cell_out, c->cells_out, sizeof(lcs_cell), hipMemcpyDeviceToHost, c->stream));
@@ -749,7 +748,7 @@ int lcs_decode_mib(lcs_ctx *c, const lcs_cell *cell, const double *tfg, int n_of
   HIPCHK(c, hipMemcpyAsync(c->tfg_comp, tfg, sizeof(double2) * n_ofdm * LCS_TFG_NSC, hipMemcpyHostToDevice, c->stream));
   if ((rc = lcs_launch_rs_build(c))) return rc;
   c->needed_rows_only = true;      // decode_mib reads the channel estimate on PBCH rows only
-  if ((rc = lcs_launch_mib(c, 1))) return rc;
+  if ((rc = lcs_launch_mib(c, false))) return rc;
   HIPCHK(c, hipMemcpyAsync(cell_out, c->cells_out, sizeof(lcs_cell), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return LCS_OK;
@@ -801,9 +800,8 @@ int lcs_search_capbuf(lcs_ctx *c, const double *capbuf, uint32_t n_cap, const do
   c->needed_rows_only = true;
   if ((rc = lcs_launch_gather_work(c, 1, 0))) return rc;
   if ((rc = lcs_launch_tfg(c, n_cap, true))) return rc;
-  if ((rc = lcs_launch_tfoec(c, 0))) return rc;
-  if ((rc = lcs_launch_mib(c, 0))) return rc;
-  if ((rc = lcs_launch_scatter_back(c))) return rc;
+  if ((rc = lcs_launch_tfoec(c, false))) return rc;
+  if ((rc = lcs_launch_mib(c, true))) return rc;
   std::vector<lcs_cell> tmp(LCS_MAXP);
   int np = 0;
   HIPCHK(c, hipMemcpyAsync(tmp.data(), c->peaks, sizeof(lcs_cell) * LCS_MAXP, hipMemcpyDeviceToHost, c->stream));
@@ -881,9 +879,8 @@ int lcs_foe_finish(lcs_ctx *c, const void *d_words, const double *d_meta, const 
   c->needed_rows_only = true;
   if ((rc = lcs_launch_gather_work(c, 1, 0))) return rc;
   if ((rc = lcs_launch_tfg(c, n_cap, true))) return rc;
-  if ((rc = lcs_launch_tfoec(c, 0))) return rc;
-  if ((rc = lcs_launch_mib(c, 0))) return rc;
-  if ((rc = lcs_launch_scatter_back(c))) return rc;
+  if ((rc = lcs_launch_tfoec(c, false))) return rc;
+  if ((rc = lcs_launch_mib(c, true))) return rc;
   std::vector<lcs_cell> tmp(LCS_MAXP);
   int np = 0;
   HIPCHK(c, hipMemcpyAsync(tmp.data(), c->peaks, sizeof(lcs_cell) * LCS_MAXP, hipMemcpyDeviceToHost, c->stream));
@@ -938,9 +935,8 @@ int stream_chain(lcs_ctx *c, int k) {
   c->needed_rows_only = true;
   if ((rc = lcs_launch_gather_work(c, 1, 0))) return rc;
   if ((rc = lcs_launch_tfg(c, c->st_n_cap, true))) return rc;
-  if ((rc = lcs_launch_tfoec(c, 0))) return rc;
-  if ((rc = lcs_launch_mib(c, 0))) return rc;
-  if ((rc = lcs_launch_scatter_back(c))) return rc;
+  if ((rc = lcs_launch_tfoec(c, false))) return rc;
+  if ((rc = lcs_launch_mib(c, true))) return rc;
   HIPCHK(c, hipMemcpyAsync(h->res, c->peaks, sizeof(h->res), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(&h->n_peaks, c->npeaks, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(h->n_work, c->n_work, sizeof(h->n_work), hipMemcpyDeviceToHost, c->stream));

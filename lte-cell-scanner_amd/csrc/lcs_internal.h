@@ -294,10 +294,9 @@ int lcs_launch_foe_only(lcs_ctx *c, uint32_t n_cap);
 // tfg_mib.hip
 int lcs_launch_gather_work(lcs_ctx *c, int n_buf, int skip /* cells already handled by earlier rounds */,
                            int limit = 0 /* cells of this round; 0: max_work */);
-int lcs_launch_scatter_back(lcs_ctx *c);
 int lcs_launch_rs_build(lcs_ctx *c);
 int lcs_launch_tfg(lcs_ctx *c, uint32_t n_cap, bool with_rs /* also build RS_DL (the fused chain) */);
-int lcs_launch_tfoec(lcs_ctx *c, int n_items);
-int lcs_launch_mib(lcs_ctx *c, int n_items);
+int lcs_launch_tfoec(lcs_ctx *c, bool apply_grid);
+int lcs_launch_mib(lcs_ctx *c, bool fused);   // chan_est + PBCH candidates + selection (+ record back into the peak table)
 int lcs_launch_chan_est(lcs_ctx *c);
 void lcs_chan_est_np_layout(int *first, int *per_port, int *n_rs_first);   // where k_chan_est leaves its noise-power partial sums in cell_scratch

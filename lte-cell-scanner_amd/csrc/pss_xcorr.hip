@@ -503,74 +503,104 @@ __global__ __launch_bounds__(256) void k_sp_i8(const uint16_t *__restrict__ cap8
 
 // ------------------------------------------------- K3: delay spread + max over frequency
 // ref :312-347 (float adds in the reference's order, circular in idx) and :353-383 (first max).
-// One thread per output position: it reads the 2*ds+1 neighbouring 64-byte rows of every group
-// (consecutive lanes read consecutive rows: fully coalesced), then scans the templates in
-// ascending (foi, pss) order keeping the first maximum per PSS.
-__global__ __launch_bounds__(128) void k_collapse(const float *__restrict__ sg, float *__restrict__ incoh,
+// Four lanes per output position, one per quad of a group's 16 columns: a lane reads its 16 bytes of the 2*ds+1
+// neighbouring 64-byte rows straight from global memory (a wave instruction covers 16 consecutive rows = 1 KB; the
+// rows shared with the neighbouring positions come back from L1), sums them in the reference's order and keeps the
+// first maximum per PSS over its own columns (ascending in foi); the four lanes of a position then merge their
+// candidates -- larger value, on equal values the lower foi: what a single scan in ascending (foi, pss) order with a
+// strict comparison keeps.  No LDS, no barrier (round 2 staged the rows in LDS with a 17-float stride whose dword
+// writes collided four ways; 85 us alone for 229 MB), 32 VGPRs: the workgroups fit beside two resident correlation
+// workgroups (see k_fill_btab_i8).  DS = the arm as a compile-time constant (2: every caller of the reference), or
+// -1 = read it from geo.
+struct CollapseBest { float v; int foi; };
+__device__ __forceinline__ void collapse_merge(CollapseBest &b, int lane_xor) {
+  const float ov = __shfl_xor(b.v, lane_xor);
+  const int of = __shfl_xor(b.foi, lane_xor);
+  const bool tk = ov > b.v || (ov == b.v && of < b.foi);
+  b.v = tk ? ov : b.v;
+  b.foi = tk ? of : b.foi;
+}
+typedef const __attribute__((address_space(1))) char *collapse_gptr;
+typedef float collapse_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 collapse_row(collapse_gptr base, unsigned byte_off) {   // uniform base + 32-bit lane offset
+  const collapse_f4 r = *reinterpret_cast<const __attribute__((address_space(1))) collapse_f4 *>(base + byte_off);
+  return make_float4(r.x, r.y, r.z, r.w);
+}
+template <int DS, bool INCOH>
+__global__ __launch_bounds__(256) void k_collapse(const float *__restrict__ sg, float *__restrict__ incoh,
                                                    double *__restrict__ pow_, float *__restrict__ pow32,
                                                    int *__restrict__ frq, XcGeom geo, int n_buf) {
   LCS_TAIL_PRIO();
-  // the 128 + 2*ds rows (64 bytes each) a workgroup needs from one group are loaded once, coalesced, into LDS
-  constexpr int CT = 128, CH = 8;                  // positions per workgroup, halo rows each side (ds <= 8)
-  __shared__ float tile[(CT + 2 * CH) * (LCS_TG + 1)];
-  const int tid = threadIdx.x;
-  const int ds = min(geo.ds, CH);
+  constexpr int CT = 64;                           // positions per workgroup
+  static_assert(LCS_N_IDX % CT == 0 && LCS_TG == 16, "k_collapse tiles 9600 positions x 16 columns");
+  constexpr int NT = LCS_N_IDX / CT;
+  constexpr int NA = DS > 0 ? DS : 1;
+  const int tid = threadIdx.x, q = tid & 3;
+  const int ds = (DS >= 0) ? DS : min(geo.ds, 8);
   const float dsn = (float)(2 * geo.ds + 1);
-  constexpr int NT = (LCS_N_IDX + CT - 1) / CT;
   for (int vb = blockIdx.x; vb < NT * n_buf; vb += gridDim.x) {       // (position tile, slot), tile fastest
-  const int slot = vb / NT;
-  const int idx0 = (vb % NT) * CT;
-  const int idx = idx0 + tid;
-  float best[3] = {0.f, 0.f, 0.f};
-  int bi[3] = {0, 0, 0};
-  for (int g = 0; g < geo.G; ++g) {
-    const float4 *rows = (const float4 *)(sg + (((size_t)slot * geo.G + g) * LCS_N_IDX) * LCS_TG);
-    __syncthreads();
-    for (int e = tid; e < (CT + 2 * ds) * 4; e += CT) {
-      const int r = e >> 2, q = e & 3;
-      const int src = ((idx0 - ds + r) % LCS_N_IDX + LCS_N_IDX) % LCS_N_IDX;      // circular in idx (ref :336)
-      const float4 x = rows[(size_t)src * 4 + q];
-      float *t = tile + r * (LCS_TG + 1) + 4 * q;
-      t[0] = x.x; t[1] = x.y; t[2] = x.z; t[3] = x.w;
+    const int slot = vb / NT;
+    const int idx = (vb % NT) * CT + (tid >> 2);
+    // byte offsets of this lane's 16 bytes of the rows idx, idx -+ d (circular in idx, ref :336) within one group
+    const unsigned o0 = ((unsigned)idx * 4u + q) * 16u;
+    unsigned om[NA], op[NA];
+#pragma unroll
+    for (int d = 1; d <= DS; ++d) {
+      om[d - 1] = ((unsigned)((idx - d < 0) ? idx - d + LCS_N_IDX : idx - d) * 4u + q) * 16u;
+      op[d - 1] = ((unsigned)((idx + d >= LCS_N_IDX) ? idx + d - LCS_N_IDX : idx + d) * 4u + q) * 16u;
     }
-    __syncthreads();
-    if (idx < LCS_N_IDX) {
-      // four columns at a time keep the kernel at 39 VGPRs: its workgroups fit beside two resident correlation
-      // workgroups (see k_fill_btab_i8)
-      const float *me = tile + (tid + ds) * (LCS_TG + 1);
+    CollapseBest b0 = {-INFINITY, 0}, b1 = {-INFINITY, 0}, b2 = {-INFINITY, 0};  // any value beats it: foi 0 is always taken
 #pragma unroll 1
-      for (int j0 = 0; j0 < LCS_TG; j0 += 4) {
-        float v[4];
+    for (int g = 0; g < geo.G; ++g) {
+      // the group's rows: a wave-uniform base kept in scalar registers (the loads then take base + 32-bit lane offset)
+      const uintptr_t gb = reinterpret_cast<uintptr_t>(sg + (((size_t)slot * geo.G + g) * LCS_N_IDX) * LCS_TG);
+      const unsigned gb_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(gb >> 32)), gb_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)gb);
+      const collapse_gptr rows = reinterpret_cast<collapse_gptr>(((uintptr_t)gb_hi << 32) | (uintptr_t)gb_lo);   // (readfirstlane returns int)
+      float4 v = collapse_row(rows, o0);
+      if (DS >= 0) {
+        float4 a[NA], b[NA];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = me[j0 + j];
-        for (int d = 1; d <= ds; ++d) {
-          const float *pa = me - d * (LCS_TG + 1) + j0, *pb = me + d * (LCS_TG + 1) + j0;
+        for (int d = 1; d <= DS; ++d) { a[d - 1] = collapse_row(rows, om[d - 1]); b[d - 1] = collapse_row(rows, op[d - 1]); }
 #pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = v[j] + (pa[j] + pb[j]);
+        for (int d = 1; d <= DS; ++d) {
+          v.x = v.x + (a[d - 1].x + b[d - 1].x); v.y = v.y + (a[d - 1].y + b[d - 1].y);
+          v.z = v.z + (a[d - 1].z + b[d - 1].z); v.w = v.w + (a[d - 1].w + b[d - 1].w);
         }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int c = lcs_col_tmpl(geo, g, j0 + j);
-          if (c >= 0) {
-            const int foi = c / 3, t = c % 3;
-            const float x = __fdiv_rn(v[j], dsn);
-            if (incoh) incoh[((((size_t)slot * 3 + t) * LCS_N_IDX) + idx) * geo.n_f + foi] = x;
-            if (t == 0) { if (foi == 0 || x > best[0]) { best[0] = x; bi[0] = foi; } }
-            else if (t == 1) { if (foi == 0 || x > best[1]) { best[1] = x; bi[1] = foi; } }
-            else { if (foi == 0 || x > best[2]) { best[2] = x; bi[2] = foi; } }
-          }
+      } else {
+        for (int d = 1; d <= ds; ++d) {
+          const int im = (idx - d < 0) ? idx - d + LCS_N_IDX : idx - d, ip = (idx + d >= LCS_N_IDX) ? idx + d - LCS_N_IDX : idx + d;
+          const float4 a = collapse_row(rows, ((unsigned)im * 4u + q) * 16u), b = collapse_row(rows, ((unsigned)ip * 4u + q) * 16u);
+          v.x = v.x + (a.x + b.x); v.y = v.y + (a.y + b.y); v.z = v.z + (a.z + b.z); v.w = v.w + (a.w + b.w);
         }
       }
-    }
-  }
-  if (idx < LCS_N_IDX) {
+      // this lane's columns 4q .. 4q+3 of group g are the templates cq .. cq+3 = (foi, pss) in ascending order
+      const int cq = g * geo.cpg + 4 * q;
+      const int f0 = cq / 3, t0 = cq - 3 * f0;
+      float vv[4] = {__fdiv_rn(v.x, dsn), __fdiv_rn(v.y, dsn), __fdiv_rn(v.z, dsn), __fdiv_rn(v.w, dsn)};
+      asm volatile("" : "+v"(vv[0]), "+v"(vv[1]), "+v"(vv[2]), "+v"(vv[3]));    // all four, here: no per-column branches
 #pragma unroll
-    for (int t = 0; t < 3; ++t) {
-      pow_[((size_t)slot * 3 + t) * LCS_N_IDX + idx] = (double)best[t];
-      pow32[((size_t)slot * 3 + t) * LCS_N_IDX + idx] = best[t];   // what the fused peak search loads
-      frq[((size_t)slot * 3 + t) * LCS_N_IDX + idx] = bi[t];
+      for (int j = 0; j < 4; ++j) {
+        const int tj = t0 + j;
+        const int t = (tj >= 3) ? tj - 3 : tj, foi = f0 + (tj >= 3 ? 1 : 0);
+        const bool valid = (4 * q + j < geo.cpg) && (cq + j < geo.n_tmpl);       // lcs_col_tmpl(geo, g, 4q + j) >= 0
+        const float x = vv[j];
+        if (INCOH) { if (valid) incoh[((((size_t)slot * 3 + t) * LCS_N_IDX) + idx) * geo.n_f + foi] = x; }
+        const bool k0 = valid && t == 0 && x > b0.v, k1 = valid && t == 1 && x > b1.v, k2 = valid && t == 2 && x > b2.v;
+        b0.v = k0 ? x : b0.v; b0.foi = k0 ? foi : b0.foi;
+        b1.v = k1 ? x : b1.v; b1.foi = k1 ? foi : b1.foi;
+        b2.v = k2 ? x : b2.v; b2.foi = k2 ? foi : b2.foi;
+      }
     }
-  }
+    collapse_merge(b0, 1); collapse_merge(b0, 2);
+    collapse_merge(b1, 1); collapse_merge(b1, 2);
+    collapse_merge(b2, 1); collapse_merge(b2, 2);
+    if (q < 3) {                                                       // lane q of the position writes PSS q
+      const CollapseBest r = (q == 0) ? b0 : (q == 1 ? b1 : b2);
+      const size_t o = ((size_t)slot * 3 + q) * LCS_N_IDX + idx;
+      pow_[o] = (double)r.v;
+      pow32[o] = r.v;                                                  // what the fused peak search loads
+      frq[o] = r.foi;
+    }
   }
 }
 
@@ -740,8 +770,13 @@ int lcs_launch_xcorr(lcs_ctx *c, int n_buf, const XcGeom &geo, bool want_incoh, 
     HIPCHK(c, hipEventRecord(c->ev_post, sxc));
     HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_post, 0));
   }
-  hipLaunchKernelGGL(k_collapse, dim3(((LCS_N_IDX + 127) / 128) * n_buf), dim3(128), 0, c->stream, c->single,
-                     want_incoh ? c->incoh : nullptr, c->pow_, reinterpret_cast<float *>(c->work), c->frq, geo, n_buf);
+  {
+    const dim3 grid((LCS_N_IDX / 64) * n_buf), block(256);
+    float *incoh = want_incoh ? c->incoh : nullptr;
+    float *pow32 = reinterpret_cast<float *>(c->work);
+    if (geo.ds == 2 && !incoh) hipLaunchKernelGGL((k_collapse<2, false>), grid, block, 0, c->stream, c->single, incoh, c->pow_, pow32, c->frq, geo, n_buf);
+    else hipLaunchKernelGGL((k_collapse<-1, true>), grid, block, 0, c->stream, c->single, incoh, c->pow_, pow32, c->frq, geo, n_buf);
+  }
   HIPCHK(c, hipGetLastError());
   return LCS_OK;
 }

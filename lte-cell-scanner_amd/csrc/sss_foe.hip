@@ -92,21 +92,57 @@ __device__ __forceinline__ double noise_power(const cd2 *h_sm, const cd2 *h_raw)
 }
 
 // ------------------------------------------------------------------ work list of peaks
-__global__ __launch_bounds__(64) void k_peak_list(const int *__restrict__ npeaks, int n_buf, WorkItem *__restrict__ items,
-                                                  int *__restrict__ n_items) {
-  LCS_TAIL_PRIO();
-  const int lane = threadIdx.x;
+// The peaks of a batch, numbered in (buffer, peak) order.  One wave: lane = capture buffer, 64 at a time.
+__device__ __forceinline__ int peak_count(const int *__restrict__ npeaks, int n_buf, int s) {
+  return (s < n_buf) ? min(max(npeaks[s], 0), LCS_MAXP) : 0;
+}
+__device__ __forceinline__ int wave_incl_scan(int v, int lane) {
+  for (int off = 1; off < 64; off <<= 1) { const int u = __shfl_up(v, off); if (lane >= off) v += u; }
+  return v;
+}
+__device__ void peak_list_write(const int *__restrict__ npeaks, int n_buf, WorkItem *__restrict__ items, int *__restrict__ n_items, int lane) {
   int base = 0;
   for (int s0 = 0; s0 < n_buf; s0 += 64) {
     const int s = s0 + lane;
-    const int cnt = (s < n_buf) ? min(max(npeaks[s], 0), LCS_MAXP) : 0;
-    int incl = cnt;
-    for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(incl, off); if (lane >= off) incl += v; }
+    const int cnt = peak_count(npeaks, n_buf, s);
+    const int incl = wave_incl_scan(cnt, lane);
     const int at = base + incl - cnt;
     for (int p = 0; p < cnt; ++p) { items[at + p].slot = s; items[at + p].peak = p; }
     base += __shfl(incl, 63);
   }
   if (lane == 0) *n_items = base;
+}
+// the stage entry point of pss_sss_foe alone (no k_sss_win in front of it)
+__global__ __launch_bounds__(64) void k_peak_list(const int *__restrict__ npeaks, int n_buf, WorkItem *__restrict__ items,
+                                                  int *__restrict__ n_items) {
+  LCS_TAIL_PRIO();
+  peak_list_write(npeaks, n_buf, items, n_items, threadIdx.x);
+}
+// The same numbering without a list, for the kernel that runs right behind the peak search (round 2: a one-wave
+// kernel in between): every wave calls these with all 64 lanes; results are wave-uniform.
+__device__ __forceinline__ int peak_total(const int *__restrict__ npeaks, int n_buf, int lane) {
+  int base = 0;
+  for (int s0 = 0; s0 < n_buf; s0 += 64) base += __shfl(wave_incl_scan(peak_count(npeaks, n_buf, s0 + lane), lane), 63);
+  return base;
+}
+__device__ __forceinline__ WorkItem peak_lookup(const int *__restrict__ npeaks, int n_buf, int it, int lane) {
+  WorkItem w;
+  w.slot = 0; w.peak = 0;
+  int base = 0;
+  for (int s0 = 0; s0 < n_buf; s0 += 64) {
+    const int cnt = peak_count(npeaks, n_buf, s0 + lane);
+    const int incl = wave_incl_scan(cnt, lane);
+    const int total = __shfl(incl, 63);
+    if (it < base + total) {                                            // wave-uniform
+      const unsigned long long m = __ballot(it < base + incl);          // first lane whose range reaches past `it`
+      const int src = __ffsll((long long)m) - 1;
+      w.slot = s0 + src;
+      w.peak = it - base - __shfl(incl - cnt, src);
+      return w;
+    }
+    base += total;
+  }
+  return w;
 }
 
 // ------------------------------------------------------------------ sss_detect geometry
@@ -124,8 +160,8 @@ __device__ __forceinline__ SssGeo sss_geometry(const lcs_cell &cell, const SlotP
 }
 
 #define SW_THREADS 192
-__global__ __launch_bounds__(SW_THREADS) void k_sss_win(const lcs_cell *__restrict__ peaks, const WorkItem *__restrict__ items,
-                                                        const int *__restrict__ n_items,
+__global__ __launch_bounds__(SW_THREADS) void k_sss_win(const lcs_cell *__restrict__ peaks, const int *__restrict__ npeaks, int n_buf,
+                                                        WorkItem *__restrict__ items, int *__restrict__ n_items,
                                                         const CapSrc src,
                                                         uint32_t n_cap, const SlotParams *__restrict__ params,
                                                         const double2 *__restrict__ pss_fd, double *__restrict__ ws) {
@@ -135,11 +171,14 @@ __global__ __launch_bounds__(SW_THREADS) void k_sss_win(const lcs_cell *__restri
   __shared__ cd2 h_raw[62], h_sm[62];
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
   fill_twiddles(W, tid);
-  const int n_jobs = *n_items * MAX_HF;
+  // the work list: numbered here from the per-buffer counts; workgroup 0 also writes it out for the kernels that follow
+  if (blockIdx.x == 0 && w == 0) peak_list_write(npeaks, n_buf, items, n_items, lane);
+  const int n_jobs = peak_total(npeaks, n_buf, lane) * MAX_HF;
   for (int job = blockIdx.x; job < n_jobs; job += gridDim.x) {
     const int it = job / MAX_HF, k = job % MAX_HF;
-    const int slot = items[it].slot;
-    const lcs_cell cell = peaks[(size_t)slot * LCS_MAXP + items[it].peak];
+    const WorkItem wi = peak_lookup(npeaks, n_buf, it, lane);
+    const int slot = wi.slot;
+    const lcs_cell cell = peaks[(size_t)slot * LCS_MAXP + wi.peak];
     const SlotParams p = params[slot];
     const SssGeo g = sss_geometry(cell, p, n_cap);
     if (k >= g.n_pss) continue;
@@ -425,9 +464,9 @@ static int run_sss_foe(lcs_ctx *c, int n_buf, uint32_t n_cap, double thresh2, in
   // kernels loop over the work list, so larger batches only take more rounds
   const int win_grid = (int)std::min<size_t>(cap_items * MAX_HF, LCS_WIN_GRID);
   const int item_grid = (int)std::min<size_t>(cap_items, LCS_ITEM_GRID);
-  hipLaunchKernelGGL(k_peak_list, dim3(1), dim3(64), 0, c->stream, c->npeaks, n_buf, c->pk_items, c->n_pk);
+  if (!(mode & 1)) hipLaunchKernelGGL(k_peak_list, dim3(1), dim3(64), 0, c->stream, c->npeaks, n_buf, c->pk_items, c->n_pk);
   if (mode & 1) {
-    hipLaunchKernelGGL(k_sss_win, dim3(win_grid), dim3(SW_THREADS), 0, c->stream, c->peaks, c->pk_items, c->n_pk, src,
+    hipLaunchKernelGGL(k_sss_win, dim3(win_grid), dim3(SW_THREADS), 0, c->stream, c->peaks, c->npeaks, n_buf, c->pk_items, c->n_pk, src,
                        n_cap, c->params, c->d_pss_fd, c->sss_ws);
     hipLaunchKernelGGL(k_sss_ml, dim3(item_grid), dim3(SF_THREADS), 0, c->stream, c->peaks, c->pk_items, c->n_pk, n_cap,
                        c->params, thresh2, c->d_sss_fd, c->sss_ws, dbg);

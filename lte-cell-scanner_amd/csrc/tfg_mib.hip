@@ -97,13 +97,6 @@ __global__ __launch_bounds__(64) void k_gather_work(const lcs_cell *__restrict__
   for (int off = 32; off > 0; off >>= 1) dup += __shfl_down(dup, off);
   if (lane == 0) { n_work[0] = min(max(base - skip, 0), limit); n_work[1] = base; n_work[2] = dup; }
 }
-__global__ void k_scatter_back(lcs_cell *__restrict__ peaks, const WorkItem *__restrict__ items,
-                               const int *__restrict__ n_work, const lcs_cell *__restrict__ cells) {
-  LCS_TAIL_PRIO();
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < *n_work) peaks[(size_t)items[i].slot * LCS_MAXP + items[i].peak] = cells[i];
-}
-
 // ------------------------------------------------------------ extract_tfg: timestamps
 // ref :875-889 and the running dft_location of :903-920 (kept sequential: each timestamp is a
 // floating-point running sum).  One thread per cell.
@@ -395,6 +388,25 @@ __global__ __launch_bounds__(TF_THREADS) void k_tfoec_est(lcs_cell *__restrict__
   }
 }
 
+// the pieces of the correction that k_tfoec_est leaves in the cell's scratch, as every consumer forms them
+struct TfoecCorr { double residual_f, k_res, delay; };
+__device__ __forceinline__ TfoecCorr tfoec_corr(const double *sc) {
+  TfoecCorr r;
+  r.residual_f = sc[CS_TF_RES];
+  r.k_res = sc[CS_TF_KRES];
+  cd2 toe = mk(0, 0);
+  for (int q = 0; q < TF_PARTS; ++q) toe = cadd(toe, mk(sc[CS_TF_TOE + 2 * q], sc[CS_TF_TOE + 2 * q + 1]));
+  r.delay = -atan2(toe.im, toe.re) / 3 / (2 * M_PI / 128);          // ref :1058
+  return r;
+}
+// per-subcarrier rotation of the timing correction (ref :1061-1064)
+__device__ __forceinline__ cd2 toc_subcarrier_rot(double delay, int i) {
+  double k_im = 1.0;
+  k_im = k_im * 2; k_im = k_im * M_PI; k_im = k_im / 128; k_im = k_im * delay;
+  const double ph = k_im * (double)cn_of(i);
+  return mk(cos(ph), sin(ph));
+}
+
 #define TFA_ROWS 8
 #define TFA_THREADS 192
 __global__ __launch_bounds__(TFA_THREADS) void k_tfoec_apply(const int *__restrict__ n_work, const double2 *__restrict__ tfg,
@@ -411,22 +423,15 @@ __global__ __launch_bounds__(TFA_THREADS) void k_tfoec_apply(const int *__restri
     const int it = job / tiles, t0 = (job % tiles) * TFA_ROWS;
     const double *sc = scratch + (size_t)it * CS_SIZE;
     const int n_ofdm = (int)sc[CS_N_OFDM];
-    const double residual_f = sc[CS_TF_RES], k_res = sc[CS_TF_KRES];
-    cd2 toe = mk(0, 0);
-    for (int q = 0; q < TF_PARTS; ++q) toe = cadd(toe, mk(sc[CS_TF_TOE + 2 * q], sc[CS_TF_TOE + 2 * q + 1]));
-    const double delay = -atan2(toe.im, toe.re) / 3 / (2 * M_PI / 128);          // ref :1058
+    const TfoecCorr corr = tfoec_corr(sc);
+    const double residual_f = corr.residual_f, k_res = corr.k_res, delay = corr.delay;
     const double2 *g = tfg + (size_t)it * ROWS * NSC;
     double2 *gc = tfg_comp + (size_t)it * ROWS * NSC;
     const double *tsi = ts + (size_t)it * ROWS;
     const int n_symb = cell_n_symb(cells[it]);
     if (it != comp_it) {     // per-subcarrier rotation of the timing correction (ref :1061-1064)
       __syncthreads();
-      if (tid < NSC) {
-        double k_im = 1.0;
-        k_im = k_im * 2; k_im = k_im * M_PI; k_im = k_im / 128; k_im = k_im * delay;
-        const double ph = k_im * (double)cn_of(tid);
-        comp[tid] = mk(cos(ph), sin(ph));
-      }
+      if (tid < NSC) comp[tid] = toc_subcarrier_rot(delay, tid);
       __syncthreads();
       comp_it = it;
     }
@@ -522,13 +527,21 @@ __device__ __forceinline__ int ce_rs_count(int port, int n_symb, int n_ofdm) {
 #define CE_MAX_RS 256
 #define CE_CH 48                                      // RS rows per workgroup: 19 KB of LDS
 #define CE_NCHUNK ((CE_MAX_RS + CE_CH - 1) / CE_CH)   // 6 (scratch holds 8 partials per port)
+// In the fused chain (tfg_raw != nullptr) the grid has NOT been through k_tfoec_apply: the frequency and timing corrections
+// (ref :992-1005, :1061-1064) are applied here, with k_tfoec_apply's expressions, to the values this kernel reads -- the
+// reference symbols of the port, 12 of a row's 72 subcarriers -- and the port-0 workgroups write the corrected PBCH rows
+// (4 per frame: all that k_pbch reads of the grid) into tfg_comp.  Round 2 corrected 390 rows x 72 subcarriers per cell in
+// a kernel of its own, three sincos pairs per element, to have 11 k of the 28 k values read back here.
 __global__ __launch_bounds__(CE_THREADS) void k_chan_est(const lcs_cell *__restrict__ cells, const int *__restrict__ n_work,
-                                                          const double2 *__restrict__ tfg_comp,
+                                                          double2 *__restrict__ tfg_comp, const double2 *__restrict__ tfg_raw,
+                                                          const double *__restrict__ ts,
                                                           double *__restrict__ scratch, double2 *__restrict__ ce, int pbch_only) {
   LCS_TAIL_PRIO();
   __shared__ cd2 ce_raw[(CE_CH + 3) * 12];     // RS rows r0 .. r1 of this chunk (one halo row each side)
   __shared__ cd2 ce_filt[(CE_CH + 1) * 12];    // RS rows c0 .. f1
   __shared__ cd2 red[CE_THREADS / 64];
+  __shared__ cd2 toc_rot[NSC];                 // fused chain: per-subcarrier rotation of the timing correction
+  __shared__ cd2 foc_rot[CE_CH + 3];           // fused chain: per-row rotation of the frequency correction, rows r0 .. r1
   const int tid = threadIdx.x, port = blockIdx.y, chunk = blockIdx.z;
   for (int it = blockIdx.x; it < *n_work; it += gridDim.x) {
     const lcs_cell c = cells[it];
@@ -536,8 +549,25 @@ __global__ __launch_bounds__(CE_THREADS) void k_chan_est(const lcs_cell *__restr
     const int n_symb = cell_n_symb(c);
     const int n_ofdm = (int)sc[CS_N_OFDM];
     const double2 *g = tfg_comp + (size_t)it * ROWS * NSC;
+    const double2 *graw = tfg_raw ? tfg_raw + (size_t)it * ROWS * NSC : nullptr;
+    const double *tsi = tfg_raw ? ts + (size_t)it * ROWS : nullptr;
+    TfoecCorr corr = {0.0, 0.0, 0.0};
     double2 *out = ce + (((size_t)it * 4 + port) * ROWS) * NSC;
     __syncthreads();
+    if (graw) {
+      corr = tfoec_corr(sc);
+      if (tid < NSC) toc_rot[tid] = toc_subcarrier_rot(corr.delay, tid);
+      __syncthreads();
+      if (port == 0) {          // the PBCH rows of frame f (slot 20 f + 1, symbols 0..3), frames dealt round-robin to the chunks
+        double2 *gw = tfg_comp + (size_t)it * ROWS * NSC;
+        for (int f = chunk; (20 * f + 1) * n_symb < n_ofdm; f += CE_NCHUNK)
+          for (int e = tid; e < 4 * NSC; e += CE_THREADS) {
+            const int t = (20 * f + 1) * n_symb + e / NSC, i = e % NSC;
+            if (t < n_ofdm)
+              st(&gw[(size_t)t * NSC + i], cmul(foc_value(graw, t, i, tsi[t], corr.k_res, foc_row_rot(tsi[t], corr.k_res, corr.residual_f)), toc_rot[i]));
+          }
+      }
+    }
 #define rs_set(t) ce_rs_row(port, n_symb, (t))
     const int n_rs = min(ce_rs_count(port, n_symb, n_ofdm), CE_MAX_RS);
     // slot_num advances every 2nd RS row for ports 0/1, every row for ports 2/3 (quirk Q9)
@@ -552,12 +582,19 @@ __global__ __launch_bounds__(CE_THREADS) void k_chan_est(const lcs_cell *__restr
     }
     const int f1 = min(c1, n_rs - 1);                          // last filtered row needed (inclusive)
     const int r0 = max(c0 - 1, 0), r1 = min(f1 + 1, n_rs - 1);  // raw rows needed (inclusive)
+    if (graw) {
+      for (int t = r0 + tid; t <= r1; t += CE_THREADS) foc_rot[t - r0] = foc_row_rot(tsi[rs_set(t)], corr.k_res, corr.residual_f);
+      __syncthreads();
+    }
     for (int e = tid; e < (r1 - r0 + 1) * 12; e += CE_THREADS) {
       const int t = r0 + e / 12, i = e % 12;
       const int slot = (port >= 2) ? (t % 20) : ((t >> 1) % 20);
       const int sym = d_imod(rs_set(t), n_symb);
       const int sh = rs_shift(sc, n_symb, slot, sym, port);
-      ce_raw[e] = cmul(ld(&g[(size_t)rs_set(t) * NSC + sh + 6 * i]), cconj(rs_val(sc, n_symb, slot, sym, i)));
+      const int row = rs_set(t), col = sh + 6 * i;
+      const cd2 v = graw ? cmul(foc_value(graw, row, col, tsi[row], corr.k_res, foc_rot[t - r0]), toc_rot[col])
+                         : ld(&g[(size_t)row * NSC + col]);
+      ce_raw[e] = cmul(v, cconj(rs_val(sc, n_symb, slot, sym, i)));
     }
     __syncthreads();
     PH(21);
@@ -823,30 +860,34 @@ __global__ __launch_bounds__(PB_THREADS * PB_CANDS) __attribute__((amdgpu_waves_
   }
 }
 
-// first passing candidate in the reference's loop order wins (ref :1547, :1567, :1638-1686)
-__global__ void k_mib_select(lcs_cell *__restrict__ cells, const int *__restrict__ n_work, const double *__restrict__ scratch) {
+// first passing candidate in the reference's loop order wins (ref :1547, :1567, :1638-1686); in the fused chain the
+// finished record also goes back to its (buffer, peak) place in the peak table (round 2: a kernel of its own)
+__global__ __launch_bounds__(64) void k_mib_select(lcs_cell *__restrict__ cells, const int *__restrict__ n_work, const double *__restrict__ scratch,
+                                                   lcs_cell *__restrict__ peaks, const WorkItem *__restrict__ items) {
   LCS_TAIL_PRIO();
   const int it = blockIdx.x * blockDim.x + threadIdx.x;
   if (it >= *n_work) return;
   const double *sc = scratch + (size_t)it * CS_SIZE;
-  if (sc[CS_OOB] != 0.0) return;
-  for (int cand = 0; cand < 12; ++cand) {
-    if (sc[CS_CAND + cand * 4] == 0.0) continue;
-    const unsigned bits = (unsigned)sc[CS_CAND + cand * 4 + 1];
-    const int guess = cand / 3, n_ports = (cand % 3 == 2) ? 4 : (cand % 3) + 1;
-    lcs_cell c = cells[it];
-    auto bit = [&](int i) { return (int)((bits >> i) & 1u); };
-    c.n_ports = n_ports;
-    const int bw = bit(0) * 4 + bit(1) * 2 + bit(2);
-    const int bwt[6] = {6, 15, 25, 50, 75, 100};
-    if (bw < 6) c.n_rb_dl = bwt[bw];
-    c.phich_duration = bit(3) ? 2 : 1;
-    c.phich_resource = 1 + bit(4) * 2 + bit(5);
-    const signed char sfn_temp = (signed char)(128 * bit(6) + 64 * bit(7) + 32 * bit(8) + 16 * bit(9) + 8 * bit(10) + 4 * bit(11) + 2 * bit(12) + bit(13));   // quirk Q10
-    c.sfn = d_imod((int)sfn_temp * 4 - guess, 1024);
-    cells[it] = c;
-    return;
+  if (sc[CS_OOB] == 0.0) {
+    for (int cand = 0; cand < 12; ++cand) {
+      if (sc[CS_CAND + cand * 4] == 0.0) continue;
+      const unsigned bits = (unsigned)sc[CS_CAND + cand * 4 + 1];
+      const int guess = cand / 3, n_ports = (cand % 3 == 2) ? 4 : (cand % 3) + 1;
+      lcs_cell c = cells[it];
+      auto bit = [&](int i) { return (int)((bits >> i) & 1u); };
+      c.n_ports = n_ports;
+      const int bw = bit(0) * 4 + bit(1) * 2 + bit(2);
+      const int bwt[6] = {6, 15, 25, 50, 75, 100};
+      if (bw < 6) c.n_rb_dl = bwt[bw];
+      c.phich_duration = bit(3) ? 2 : 1;
+      c.phich_resource = 1 + bit(4) * 2 + bit(5);
+      const signed char sfn_temp = (signed char)(128 * bit(6) + 64 * bit(7) + 32 * bit(8) + 16 * bit(9) + 8 * bit(10) + 4 * bit(11) + 2 * bit(12) + bit(13));   // quirk Q10
+      c.sfn = d_imod((int)sfn_temp * 4 - guess, 1024);
+      cells[it] = c;
+      break;
+    }
   }
+  if (peaks) peaks[(size_t)items[it].slot * LCS_MAXP + items[it].peak] = cells[it];
 }
 
 // ------------------------------------------------------------------------------ launch
@@ -855,12 +896,6 @@ int lcs_launch_gather_work(lcs_ctx *c, int n_buf, int skip, int limit) {
   hipLaunchKernelGGL(k_gather_work, dim3(1), dim3(64), 0, c->stream, c->peaks, c->npeaks, n_buf, skip, limit > 0 ? limit : c->max_work,
                      c->st_open ? c->st_dtracked : nullptr, c->st_dntracked, c->work_items, c->n_work,
                      c->cells_out);
-  HIPCHK(c, hipGetLastError());
-  return LCS_OK;
-}
-int lcs_launch_scatter_back(lcs_ctx *c) {
-  hipLaunchKernelGGL(k_scatter_back, dim3((LCS_MAX_WORK + 255) / 256), dim3(256), 0, c->stream, c->peaks, c->work_items,
-                     c->n_work, c->cells_out);
   HIPCHK(c, hipGetLastError());
   return LCS_OK;
 }
@@ -878,30 +913,33 @@ int lcs_launch_rs_build(lcs_ctx *c) {
   HIPCHK(c, hipGetLastError());
   return LCS_OK;
 }
-int lcs_launch_tfoec(lcs_ctx *c, int n_items) {
-  (void)n_items;
+// apply_grid: also write the corrected grid (the stage entry point); the fused chain leaves the correction to k_chan_est
+int lcs_launch_tfoec(lcs_ctx *c, bool apply_grid) {
   hipLaunchKernelGGL(k_tfoec_est, dim3(c->grid_items, TF_PARTS), dim3(TF_THREADS), 0, c->stream, c->cells_out, c->work_items, c->n_work,
                      c->params, c->tfg, c->tfg_ts, c->cell_scratch, c->tfg_ts_comp);
-  hipLaunchKernelGGL(k_tfoec_apply, dim3(LCS_TFA_GRID), dim3(TFA_THREADS), 0, c->stream, c->n_work, c->tfg, c->tfg_ts, c->cell_scratch,
+  if (apply_grid) hipLaunchKernelGGL(k_tfoec_apply, dim3(LCS_TFA_GRID), dim3(TFA_THREADS), 0, c->stream, c->n_work, c->tfg, c->tfg_ts, c->cell_scratch,
                      c->cells_out, c->tfg_comp, c->needed_rows_only ? 1 : 0);
   HIPCHK(c, hipGetLastError());
   return LCS_OK;
 }
 int lcs_launch_chan_est(lcs_ctx *c) {
   hipLaunchKernelGGL(k_chan_est, dim3(c->grid_items, 4, CE_NCHUNK), dim3(CE_THREADS), 0, c->stream, c->cells_out, c->n_work,
-                     c->tfg_comp, c->cell_scratch, c->ce, c->needed_rows_only ? 1 : 0);
+                     c->tfg_comp, (const double2 *)nullptr, (const double *)nullptr, c->cell_scratch, c->ce, c->needed_rows_only ? 1 : 0);
   HIPCHK(c, hipGetLastError());
   return LCS_OK;
 }
 void lcs_chan_est_np_layout(int *first, int *per_port, int *n_rs_first) { *first = CS_NPP; *per_port = 8; *n_rs_first = CS_NRS; }
-int lcs_launch_mib(lcs_ctx *c, int n_items) {
-  (void)n_items;
+// fused: the chain's form -- the grid comes uncorrected from k_tfg (k_chan_est applies k_tfoec_est's corrections to what it
+// and k_pbch read), and the finished records go back into the peak table
+int lcs_launch_mib(lcs_ctx *c, bool fused) {
+  const bool scatter_back = fused;
   hipLaunchKernelGGL(k_chan_est, dim3(c->grid_items, 4, CE_NCHUNK), dim3(CE_THREADS), 0, c->stream, c->cells_out, c->n_work,
-                     c->tfg_comp, c->cell_scratch, c->ce, c->needed_rows_only ? 1 : 0);
+                     c->tfg_comp, fused ? (const double2 *)c->tfg : (const double2 *)nullptr, (const double *)c->tfg_ts, c->cell_scratch,
+                     c->ce, c->needed_rows_only ? 1 : 0);
   hipLaunchKernelGGL(k_pbch, dim3(c->grid_items, 12 / PB_CANDS), dim3(PB_THREADS * PB_CANDS), 0, c->stream, c->cells_out, c->n_work, c->tfg_comp,
                      c->ce, c->cell_scratch, c->d_pbch_scr, c->d_derm_inv);
   hipLaunchKernelGGL(k_mib_select, dim3((LCS_MAX_WORK + 63) / 64), dim3(64), 0, c->stream, c->cells_out, c->n_work,
-                     c->cell_scratch);
+                     c->cell_scratch, scatter_back ? c->peaks : nullptr, c->work_items);
   HIPCHK(c, hipGetLastError());
   return LCS_OK;
 }

@@ -10,7 +10,7 @@ TAG=${1:-r03}
 REPO=$PWD
 OUT=$REPO/gpurun_out/$TAG
 mkdir -p "$OUT"
-(cd "$REPO" && timeout 300 python -m pytest tests -m gpu -x -q 2>&1 | tail -6) > "$OUT/pytest_gpu.log"
+(cd "$REPO" && timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -6) > "$OUT/pytest_gpu.log"
 cd /tmp; export TMPDIR=/tmp
 B="python $REPO/bench.py"
 SHORT="--steps 2 --warmup 1 --batches-per-step 8 --no-cpu-baseline --no-dense"
@@ -30,5 +30,5 @@ timeout 120 $B --stage pss --no-cpu-baseline > "$OUT/bench_pss_n1.json" 2> "$OUT
 timeout 120 $B --stage single --steps 200 --warmup 20 > "$OUT/bench_single_n1.json" 2> "$OUT/bench_single_n1.err"
 timeout 120 $B --stage stream --steps 400 --warmup 20 > "$OUT/bench_stream_n1.json" 2> "$OUT/bench_stream_n1.err"
 timeout 120 $B --stage track > "$OUT/bench_track_n1.json" 2> "$OUT/bench_track_n1.err"
-timeout 200 $B --steps 10 --warmup 2 --batches-per-step 40 --input c64 --no-cpu-baseline > "$OUT/bench_full_n1_c64_fp32_kernel.json" 2> "$OUT/bench_c64.err"
+timeout 200 $B --steps 10 --warmup 2 --batches-per-step 40 --input c64 --no-cpu-baseline > "$OUT/bench_full_n1_c64_f16_kernel.json" 2> "$OUT/bench_c64.err"
 echo collected > "$OUT/done"

@@ -10,7 +10,7 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(root, "gpurun_out", tag), os.path.join(root, "profiles", tag)
 os.makedirs(dst, exist_ok=True)
 
-for name in ("bench_full_n1.json", "bench_full_n1_input_host.json", "bench_single_n1.json", "bench_pss_n1.json", "bench_stream_n1.json", "bench_track_n1.json", "bench_full_n1_c64_fp32_kernel.json", "pytest_gpu.log"):
+for name in ("bench_full_n1.json", "bench_full_n1_input_host.json", "bench_single_n1.json", "bench_pss_n1.json", "bench_stream_n1.json", "bench_track_n1.json", "bench_full_n1_c64_f16_kernel.json", "pytest_gpu.log"):
     p = os.path.join(src, name)
     if os.path.exists(p):
         lines = [l for l in open(p).read().splitlines() if l.startswith("{")] if name.endswith(".json") else open(p).read().splitlines()[-6:]
