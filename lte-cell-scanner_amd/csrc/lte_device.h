@@ -109,12 +109,18 @@ __device__ __forceinline__ void qpsk_llr(cd2 sym, double np, double &l0, double 
 // butterflies of plain fp64 adds with no cross-lane traffic (the lane-per-state form moves every metric through
 // ds_bpermute: measured LDS-pipe bound, ~100 us of a whole CU per candidate).  Butterfly j reads old states 2j,
 // 2j+1 and writes new states j, j+32 INTO THE SAME TWO REGISTERS, so after k steps state s lives in slot
-// rotl6(s, k); the slot pattern repeats every 6 steps, which is the unroll depth.  Branch metrics are added one
-// generator at a time in the order of the oracle (m += +-r0; m += +-r1; m += +-r2), ties keep predecessor 2j.
+// rotl6(s, k); the slot pattern repeats every 6 steps, which is the unroll depth.  Branch metrics as IT++ forms them
+// (Convolutional_Code::calc_metric: the metrics of all 2^n output words of a step are built first, from the LAST
+// generator's observation to the first, and a path metric is old + that one value): d(o) = ((+-r2) + (+-r1)) + (+-r0),
+// d(~o) = -d(o) exactly; all three generators tap the input bit and the oldest register bit, so a butterfly needs one
+// value and its negative -- 4 fp64 adds per butterfly (round 2 added the three observations to every path metric one
+// by one: 12).  Ties keep predecessor 2j.
 #define VIT_ROTL6(s, k) ((((s) << (k)) | ((s) >> (6 - (k)))) & 63)
 template <int K>
 __host__ __device__ __forceinline__ void vit_step(double (&pm)[64], double r0, double r1, double r2, unsigned &lo, unsigned &hi) {
   lo = 0u; hi = 0u;
+  // d[i], i = o0 + 2 o1 (o2 = 0): the four words whose last output bit is 0; the others are their negatives
+  const double d[4] = {(-r2 + -r1) + -r0, (-r2 + -r1) + r0, (-r2 + r1) + -r0, (-r2 + r1) + r0};
 #pragma unroll
   for (int j = 0; j < 32; ++j) {
     const int p0 = 2 * j, p1 = 2 * j + 1;
@@ -123,9 +129,10 @@ __host__ __device__ __forceinline__ void vit_step(double (&pm)[64], double r0, d
 #pragma unroll
     for (int b = 0; b < 2; ++b) {                      // new state j + 32 b <- (input bit b, predecessor p0 / p1)
       const int g0 = (b << 6) | p0, g1 = (b << 6) | p1;
-      double m0 = o0, m1 = o1;
-      m0 += (__builtin_parity(g0 & 0133) ? r0 : -r0); m0 += (__builtin_parity(g0 & 0171) ? r1 : -r1); m0 += (__builtin_parity(g0 & 0165) ? r2 : -r2);
-      m1 += (__builtin_parity(g1 & 0133) ? r0 : -r0); m1 += (__builtin_parity(g1 & 0171) ? r1 : -r1); m1 += (__builtin_parity(g1 & 0165) ? r2 : -r2);
+      const int w0 = __builtin_parity(g0 & 0133) | (__builtin_parity(g0 & 0171) << 1) | (__builtin_parity(g0 & 0165) << 2);
+      const int w1 = __builtin_parity(g1 & 0133) | (__builtin_parity(g1 & 0171) << 1) | (__builtin_parity(g1 & 0165) << 2);
+      const double m0 = o0 + ((w0 < 4) ? d[w0 & 3] : -d[(7 - w0) & 3]);
+      const double m1 = o1 + ((w1 < 4) ? d[w1 & 3] : -d[(7 - w1) & 3]);
       const bool take1 = m1 < m0;                      // ties keep the lower-numbered predecessor
       pm[b ? sb : sa] = take1 ? m1 : m0;
       if (b) hi |= take1 ? (1u << j) : 0u; else lo |= take1 ? (1u << j) : 0u;

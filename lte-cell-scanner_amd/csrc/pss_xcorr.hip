@@ -604,6 +604,99 @@ __global__ __launch_bounds__(256) void k_collapse(const float *__restrict__ sg, 
   }
 }
 
+// The form every caller of the reference takes (arm 2, 16 columns per group, no debug copy of xc_incoherent): a lane
+// loads ONE 16-byte piece per group -- lane = quad * 16 + p, so the 16 lanes of a DPP row hold 16 consecutive positions
+// of one quad and the four neighbours of a position arrive by row shifts (v_mov_dpp) instead of four more loads; a wave
+// reads positions base-2 .. base+13 and produces the 12 in the middle.  The division by 5 is x * RN(1/5) corrected once
+// through the exact remainder (q = x * .2f; q += fma(-5, q, x) * .2f): equal to the correctly rounded quotient for every
+// finite float >= 0, denormals included (checked over all 2^31 of them on the host) at 3 operations instead of 12.  With
+// 16 columns per group, column j of group g of quad q belongs to PSS (g + q + j) mod 3: with the group loop unrolled by
+// three the accumulator of a column is known at compile time in a frame rotated by q, undone once at the end.
+template <int CTRL>
+__device__ __forceinline__ float collapse_dpp(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float collapse_arm2(float me) {      // me + (idx-1 + idx+1), then + (idx-2 + idx+2)  (ref :336)
+  float v = me + (collapse_dpp<0x111>(me) + collapse_dpp<0x101>(me));        // row_shr:1 = from lane p-1, row_shl:1 = from p+1
+  return v + (collapse_dpp<0x112>(me) + collapse_dpp<0x102>(me));
+}
+__device__ __forceinline__ float collapse_div5(float x) {
+  const float q = x * 0.2f;
+  return fmaf(fmaf(-5.0f, q, x), 0.2f, q);
+}
+typedef unsigned int collapse_u4 __attribute__((ext_vector_type(4)));
+#define COLLAPSE_OUT 12                   // positions a wave produces
+#define COLLAPSE_GB 6                     // groups in flight (a multiple of 3)
+// (amdgpu_num_vgpr is doubled by the backend on the unified register file: 28 = the 56 VGPRs that two resident correlation
+// workgroups leave free on a SIMD; the allocator otherwise spreads over the 64 its occupancy target allows)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(28))) void k_collapse_arm2(const float *__restrict__ sg, double *__restrict__ pow_, float *__restrict__ pow32,
+                                                        int *__restrict__ frq, XcGeom geo, int n_buf) {
+  LCS_TAIL_PRIO();
+  constexpr int CT = 4 * COLLAPSE_OUT;             // positions per workgroup
+  static_assert(LCS_N_IDX % CT == 0 && LCS_TG == 16, "k_collapse_arm2 tiles 9600 positions x 16 columns");
+  constexpr int NT = LCS_N_IDX / CT;
+  const int tid = threadIdx.x, lane = tid & 63, p = lane & 15, q = lane >> 4, wv = tid >> 6;
+  for (int vb = blockIdx.x; vb < NT * n_buf; vb += gridDim.x) {       // (position tile, slot), tile fastest
+    const int slot = vb / NT;
+    const int idx = (vb % NT) * CT + wv * COLLAPSE_OUT + p - 2;       // lanes p = 2 .. 13 own an output
+    const int ridx = idx < 0 ? idx + LCS_N_IDX : (idx >= LCS_N_IDX ? idx - LCS_N_IDX : idx);      // circular (ref :336)
+    const unsigned off = ((unsigned)ridx * 4u + q) * 16u;
+    // acc[k]: best of PSS (q + k) mod 3 so far, `foi` holding the COLUMN number 16 g + 4 q + j = 3 foi + pss (ascending
+    // with foi within a PSS: the same tie rule; divided by 3 once at the end).  Anything beats -inf.
+    CollapseBest acc[3] = {{-INFINITY, 0}, {-INFINITY, 0}, {-INFINITY, 0}};
+    // the buffer's groups through one buffer resource: scalar base + per-group scalar offset + the lane's 32-bit offset
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(sg + ((size_t)slot * geo.G * LCS_N_IDX) * LCS_TG), 0, geo.G * (int)(LCS_N_IDX * LCS_TG * sizeof(float)), 0x00020000);
+    constexpr int GROUP_BYTES = (int)(LCS_N_IDX * LCS_TG * sizeof(float));
+    for (int g6 = 0; g6 < geo.G; g6 += COLLAPSE_GB) {
+      // every group of the block is requested before the first one is used: in the gap beside the correlation workgroups
+      // only one of these waves fits on a SIMD, and a wave's sequential round trips to memory are its run time
+      collapse_u4 me[COLLAPSE_GB];
+      if (g6 + COLLAPSE_GB <= geo.G) {                                 // wave-uniform
+#pragma unroll
+        for (int r = 0; r < COLLAPSE_GB; ++r) me[r] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off, (g6 + r) * GROUP_BYTES, 0);
+      } else {
+#pragma unroll
+        for (int r = 0; r < COLLAPSE_GB; ++r) {                        // past the last group the resource returns zeros
+          me[r] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off, (g6 + r) * GROUP_BYTES, 0);
+        }
+      }
+      const int cb = g6 * 16 + 4 * q;                                  // column number of this lane's first column of the block
+#pragma unroll
+      for (int r = 0; r < COLLAPSE_GB; ++r) {
+        const float mv[4] = {__uint_as_float(me[r].x), __uint_as_float(me[r].y), __uint_as_float(me[r].z), __uint_as_float(me[r].w)};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float x = collapse_div5(collapse_arm2(mv[j]));
+          const int col = cb + (16 * r + j);
+          // the column's PSS is (g + q + j) mod 3 = (q + (r + j)) mod 3: g6 is a multiple of 3
+          const bool tk = (col < geo.n_tmpl) && x > acc[(r + j) % 3].v;
+          acc[(r + j) % 3].v = tk ? x : acc[(r + j) % 3].v;
+          acc[(r + j) % 3].foi = tk ? col : acc[(r + j) % 3].foi;
+        }
+      }
+    }
+    // PSS t sits in acc[(t - q) mod 3]; each PSS is merged over the four quads of a position (lanes p, p + 16, p + 32, p + 48)
+    const int k0 = (3 - q) % 3, k1 = (4 - q) % 3, k2 = (5 - q) % 3;   // where PSS 0, 1, 2 sit in this lane's frame
+    CollapseBest o0 = {(k0 == 0) ? acc[0].v : (k0 == 1 ? acc[1].v : acc[2].v), (k0 == 0) ? acc[0].foi : (k0 == 1 ? acc[1].foi : acc[2].foi)};
+    CollapseBest o1 = {(k1 == 0) ? acc[0].v : (k1 == 1 ? acc[1].v : acc[2].v), (k1 == 0) ? acc[0].foi : (k1 == 1 ? acc[1].foi : acc[2].foi)};
+    CollapseBest o2 = {(k2 == 0) ? acc[0].v : (k2 == 1 ? acc[1].v : acc[2].v), (k2 == 0) ? acc[0].foi : (k2 == 1 ? acc[1].foi : acc[2].foi)};
+    collapse_merge(o0, 16); collapse_merge(o0, 32);
+    collapse_merge(o1, 16); collapse_merge(o1, 32);
+    collapse_merge(o2, 16); collapse_merge(o2, 32);
+    if (q < 3 && p >= 2 && p < 2 + COLLAPSE_OUT) {                     // lane (q, p) writes PSS q of its position
+      const float rv = (q == 0) ? o0.v : (q == 1 ? o1.v : o2.v);
+      const int rf = ((q == 0) ? o0.foi : (q == 1 ? o1.foi : o2.foi)) / 3;
+      int oi = idx;
+      asm volatile("" : "+v"(oi));                                     // (the output addresses are formed here, not held across the loop)
+      const size_t o = ((size_t)slot * 3 + q) * LCS_N_IDX + oi;
+      pow_[o] = (double)rv;
+      pow32[o] = rv;                                                   // what the fused peak search loads
+      frq[o] = rf;
+    }
+  }
+}
+
 // group-major -> reference layout [t][idx][foi] (debug output of the stage entry point) and back
 // (lcs_peak_search receives the reference layout from the caller)
 __global__ __launch_bounds__(256) void k_single_to_ref(const float *__restrict__ sg, float *__restrict__ ref, XcGeom geo,
@@ -774,7 +867,9 @@ int lcs_launch_xcorr(lcs_ctx *c, int n_buf, const XcGeom &geo, bool want_incoh, 
     const dim3 grid((LCS_N_IDX / 64) * n_buf), block(256);
     float *incoh = want_incoh ? c->incoh : nullptr;
     float *pow32 = reinterpret_cast<float *>(c->work);
-    if (geo.ds == 2 && !incoh) hipLaunchKernelGGL((k_collapse<2, false>), grid, block, 0, c->stream, c->single, incoh, c->pow_, pow32, c->frq, geo, n_buf);
+    if (geo.ds == 2 && !incoh && geo.cpg == LCS_TG)
+      hipLaunchKernelGGL(k_collapse_arm2, dim3((LCS_N_IDX / (4 * COLLAPSE_OUT)) * n_buf), block, 0, c->stream, c->single, c->pow_, pow32, c->frq, geo, n_buf);
+    else if (geo.ds == 2 && !incoh) hipLaunchKernelGGL((k_collapse<2, false>), grid, block, 0, c->stream, c->single, incoh, c->pow_, pow32, c->frq, geo, n_buf);
     else hipLaunchKernelGGL((k_collapse<-1, true>), grid, block, 0, c->stream, c->single, incoh, c->pow_, pow32, c->frq, geo, n_buf);
   }
   HIPCHK(c, hipGetLastError());

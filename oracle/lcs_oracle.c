@@ -1115,7 +1115,11 @@ static void lte_conv_deratematch(const double *e_est, int n_e, int n_c, double *
 /* ref: src/lte_lib.cpp:538-551 lte_conv_decode -> itpp Convolutional_Code::decode_tailbite
  * (K=7, generators 0133,0171,0165; exhaustive tail-biting Viterbi: one trellis pass per
  * start state with the end state forced equal, keep the minimum-metric path).  Branch
- * metric: sum_j (out_j ? +r_j : -r_j), minimised. */
+ * metric: sum_j (out_j ? +r_j : -r_j), minimised, formed as IT++'s calc_metric
+ * forms it: the metric of each of the 2^n output words of a step is accumulated on its own,
+ * from the last generator's observation to the first, and then added to the path metric
+ * (IT++ is not in the reference tree: restated from its published algorithm; pinned at the
+ * level of the decoded bits by the reference captures' CRC-passing MIBs). */
 static void conv_decode_tailbite(const double *d_est /*[3][n]*/, int n, uint8_t *c_est) {
   static const int G[3] = {0133, 0171, 0165};
   uint8_t outbits[128][3];
@@ -1128,14 +1132,19 @@ static void conv_decode_tailbite(const double *d_est /*[3][n]*/, int n, uint8_t 
     for (int s = 0; s < 64; s++) pm[s] = INFINITY;
     pm[ss] = 0;
     for (int t = 0; t < n; t++) {
+      double delta[8];        /* output word w = out_0 + 2 out_1 + 4 out_2 */
+      for (int w = 0; w < 8; w++) {
+        double dm = 0;
+        for (int j = 2; j >= 0; j--) { double r = d_est[j * n + t]; if ((w >> j) & 1) dm += r; else dm -= r; }
+        delta[w] = dm;
+      }
       for (int s = 0; s < 64; s++) npm[s] = INFINITY;
       for (int s = 0; s < 64; s++) {
         if (pm[s] == INFINITY) continue;
         for (int b = 0; b < 2; b++) {
           int reg = (b << 6) | s;
           int ns = reg >> 1;
-          double m = pm[s];
-          for (int j = 0; j < 3; j++) { double r = d_est[j * n + t]; m += outbits[reg][j] ? r : -r; }
+          double m = pm[s] + delta[outbits[reg][0] | (outbits[reg][1] << 1) | (outbits[reg][2] << 2)];
           if (m < npm[ns]) { npm[ns] = m; surv[(size_t)t * 64 + ns] = (uint8_t)s; }
         }
       }
