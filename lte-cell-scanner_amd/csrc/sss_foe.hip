@@ -5,8 +5,9 @@
 //
 // All arithmetic in fp64 like the reference.  Per peak the work is tiny and latency-bound, so it
 // is spread as widely as the data dependences allow:
-//   k_peak_list  compacts (buffer, peak) pairs of the whole batch into a work list;
-//   k_sss_win    one workgroup per (peak, half-frame occurrence), one wave per 128-sample window
+//   k_sss_win    numbers the (buffer, peak) pairs of the whole batch (workgroup 0 writes the list for the kernels behind
+//                it; k_peak_list does that alone in front of the pss_sss_foe stage entry point);
+//                one workgroup per (peak, half-frame occurrence), one wave per 128-sample window
 //                (PSS, extended-CP SSS, normal-CP SSS): frequency-correct while staging into LDS,
 //                direct 62x128 DFT of the PSS/SSS subcarriers only (<= 60 windows per peak: an FFT
 //                would buy nothing and the direct form is the more accurate one), channel

@@ -285,7 +285,9 @@ __device__ __forceinline__ int rs_shift(const double *sc, int n_symb, int slot, 
 // Two kernels: k_tfoec_est (one workgroup per cell) runs the two reductions -- the super-fine
 // frequency estimate over the raw grid and the timing estimate over the frequency-corrected RS
 // positions, correcting just those ~11k samples on the fly -- and k_tfoec_apply applies both
-// corrections to the whole 854x72 grid with every element independent (grid = cells x row tiles).
+// corrections to the whole 854x72 grid with every element independent (grid = cells x row tiles) for the stage entry
+// point lcs_tfoec; the fused chain does not materialise the corrected grid (k_chan_est applies the same expressions to
+// the reference symbols and PBCH rows that are read afterwards).
 // The value written for an element is (tfg * rot_f) * rot_late, then * rot_delay: the reference's
 // order of the three complex products (ref :992-1005, :1061-1064).
 // rot_f of one row: exp(j 2 pi (-residual_f) ts_comp / (FS_LTE/16)), the same for its 72 subcarriers
