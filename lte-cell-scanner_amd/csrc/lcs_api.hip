@@ -255,10 +255,13 @@ int lcs_create(int device, lcs_ctx **out) {
   bool ok_streams = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_greatest) == hipSuccess;
   ok_streams = ok_streams && hipStreamCreateWithPriority(&c->stream_xc, hipStreamNonBlocking, prio_least) == hipSuccess;
   if (!ok_streams) { lcs_destroy(c); return LCS_ERR_HIP; }
-  (void)hipEventCreate(&c->ev_xc0);
-  (void)hipEventCreate(&c->ev_xc1);
-  (void)hipEventCreateWithFlags(&c->ev_pre, hipEventDisableTiming);
-  (void)hipEventCreateWithFlags(&c->ev_post, hipEventDisableTiming);
+  // events between streams of ONE device (and the two that time the correlation): no system-scope fence -- its cache
+  // write-back and invalidation at every record is paid by the kernels that follow (results reach the host through
+  // hipMemcpyAsync / stream synchronisation, which fence on their own)
+  (void)hipEventCreateWithFlags(&c->ev_xc0, LCS_EVENT_NOFENCE);
+  (void)hipEventCreateWithFlags(&c->ev_xc1, LCS_EVENT_NOFENCE);
+  (void)hipEventCreateWithFlags(&c->ev_pre, hipEventDisableTiming | LCS_EVENT_NOFENCE);
+  (void)hipEventCreateWithFlags(&c->ev_post, hipEventDisableTiming | LCS_EVENT_NOFENCE);
   // constant tables
   std::vector<double> td(3 * 137 * 2), fd(3 * 62 * 2);
   for (int t = 0; t < 3; ++t) { lcs_tables::pss_td(t, &td[t * 137 * 2]); lcs_tables::pss_fd(t, &fd[t * 62 * 2]); }

@@ -244,6 +244,10 @@ struct lcs_ctx {
   const char *last_xc_kernel = "";
 };
 
+#ifndef LCS_EVENT_NOFENCE
+#define LCS_EVENT_NOFENCE hipEventDisableSystemFence
+#endif
+
 #define HIPCHK(ctx, call)                                                        \
   do {                                                                           \
     hipError_t e_ = (call);                                                      \

@@ -831,7 +831,7 @@ int lcs_launch_xcorr(lcs_ctx *c, int n_buf, const XcGeom &geo, bool want_incoh, 
     HIPCHK(c, hipStreamWaitEvent(sxc, c->ev_pre, 0));
     std::lock_guard<std::mutex> lk(g_xc_mutex);
     hipEvent_t &ev = g_xc_done[c->device & 63];
-    if (!ev) HIPCHK(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    if (!ev) HIPCHK(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming | LCS_EVENT_NOFENCE));
     else HIPCHK(c, hipStreamWaitEvent(sxc, ev, 0));
   }
   if (time_it) HIPCHK(c, hipEventRecord(c->ev_xc0, sxc));
