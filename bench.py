@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
 """bench.py -- capture-buffers/s of the searcher hot path on MI355X (driver contract).
 
-A "step" is one pass of the chain over --batches-per-step (200) batches of --batch (64) synthetic
+A "step" is one pass of the chain over --batches-per-step (100) batches of --batch (128) synthetic
 153600-sample, 1.92 Msps capture buffers that are ALREADY RESIDENT IN HBM when the timed region
 starts (12800 buffers per step: the driver's 20 steps time ~6 s of GPU work, long enough for a 5 s
-SMI sampler to see the GPU busy).  N=1 workload = BASELINE.json configs[2], the metric's "full
+SMI sampler to see the GPU busy).  A batch is one enqueue = one correlation launch; two contexts are kept in
+flight (profiles/r03/experiments/batch_size_and_depth.txt: 128 x 2 in flight is 2.5 % faster than 64 x 3).  N=1 workload = BASELINE.json configs[2], the metric's "full
 CellSearch": PSS correlation over the full +-100 ppm grid at 739 MHz (n_f = 31), peak_search and every
 per-cell stage down to the decoded MIB (--stage pss stops after peak_search; --stage single is
 configs[1] as written: ONE host buffer per step through lcs_search_capbuf, PCIe included).
@@ -418,8 +419,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=64, help="capture buffers per enqueue (one correlation launch) per GPU")
-    ap.add_argument("--batches-per-step", type=int, default=200, help="enqueues per step: a step is batch x this many buffers per GPU")
+    ap.add_argument("--batch", type=int, default=None,
+                    help="capture buffers per enqueue (one correlation launch) per GPU; default 128 (--stage track: 64 tracked cells)")
+    ap.add_argument("--batches-per-step", type=int, default=None,
+                    help="enqueues per step: a step is batch x this many buffers per GPU; default 12800 // batch")
     ap.add_argument("--distinct", type=int, default=4, help="distinct resident batches the enqueues cycle through")
     ap.add_argument("--ppm", type=float, default=100.0)
     ap.add_argument("--stage", choices=["pss", "full", "single", "stream", "track"], default="full",
@@ -431,7 +434,7 @@ def main():
     ap.add_argument("--input", choices=["u8", "c64"], default="u8",
                     help="resident input format: raw RTL-SDR u8 I/Q (int8 MFMA correlation kernel, default) or complex<float> "
                          "(fp16 three-product MFMA correlation kernel)")
-    ap.add_argument("--pipeline", type=int, default=3,
+    ap.add_argument("--pipeline", type=int, default=2,
                     help="contexts (streams + workspaces) used round-robin: the latency-bound per-cell "
                          "stages of batch i overlap the PSS correlation of batch i+1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -444,6 +447,10 @@ def main():
                     help="feed the batches from page-locked HOST memory (lcs_batch_enqueue_host): the PCIe transfer is inside the timed region")
     ap.add_argument("--no-dense", action="store_true", help="skip the dense-band line (2-3 cells planted in every buffer) reported in config.dense_band")
     args = ap.parse_args()
+    if args.batch is None:
+        args.batch = 64 if args.stage == "track" else 128
+    if args.batches_per_step is None:
+        args.batches_per_step = max(1, 12800 // args.batch)
 
     # --gpus N is the number of ranks.  Started by a launcher (WORLD_SIZE set, e.g. the driver's torch.distributed.run
     # line) the two must agree; started plainly with N > 1, start the N ranks ourselves.
@@ -516,7 +523,7 @@ def main():
     ctxs = [pkg.Searcher(local_rank if world > 1 else 0) for _ in range(max(1, args.pipeline))]
     MAXC = 16
     # one fixed-size record block per step for the all-gather: [n, then n x (n_id_cell, fc, f_off, pss_pow, sfn)]
-    MAXREC = 64 * K
+    MAXREC = max(64, B) * K
     gather_in = [torch.zeros(1 + 5 * MAXREC, dtype=torch.float64, pin_memory=(coll_dev.type == "cuda")) for _ in range(2)] if world > 1 else None
     gather_dev = [torch.zeros(1 + 5 * MAXREC, dtype=torch.float64, device=coll_dev) for _ in range(2)] if world > 1 else None
     gather_out = [torch.zeros((world, 1 + 5 * MAXREC), dtype=torch.float64, device=coll_dev) for _ in range(2)] if world > 1 else None
@@ -674,7 +681,7 @@ def main():
         dms = dms[1:]
         dense = {"buffers_per_s": B / (min(dms) * 1e-3), "ms_per_batch": min(dms), "cells_decoded_per_buffer": cells_d / B,
                  "cells_planted_per_buffer": 2.5, "batches_timed": K_, "pipelined_mismatches": state["mismatch"] - mism0,
-                 "note": "same chain, same grid; every one of the 64 buffers of a batch carries 2-3 synthetic cells (SNR 0-10 dB)"}
+                 "note": f"same chain, same grid; every one of the {B} buffers of a batch carries 2-3 synthetic cells (SNR 0-10 dB)"}
         work.clear(); work.update(work_saved)
         seen.clear(); seen.update(seen_saved)
         state["mismatch"], state["collected"] = mism0, coll_saved

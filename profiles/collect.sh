@@ -14,13 +14,16 @@ mkdir -p "$OUT"
 cd /tmp; export TMPDIR=/tmp
 B="python $REPO/bench.py"
 SHORT="--steps 2 --warmup 1 --batches-per-step 8 --no-cpu-baseline --no-dense"
-timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_full_p1" -- $B $SHORT --pipeline 1 > "$OUT/stats_full_p1.log" 2>&1
+# every kernel alone, per 64-buffer batch (the unit of DESIGN 3.2's table since round 1), then the bench's default command
+# (128 buffers per launch, two contexts in flight): the correlation kernel's average duration there is what bench.py's
+# roofline.kernel_ms must agree with
+timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_full_p1" -- $B $SHORT --batch 64 --pipeline 1 > "$OUT/stats_full_p1.log" 2>&1
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_full_default" -- $B $SHORT > "$OUT/stats_full_default.log" 2>&1
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS" \
            "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
-  timeout 200 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d "$OUT/pmc_$i" -- $B --steps 1 --warmup 0 --batches-per-step 4 --pipeline 1 --no-cpu-baseline --no-dense > "$OUT/pmc_$i.log" 2>&1
+  timeout 200 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d "$OUT/pmc_$i" -- $B --steps 1 --warmup 0 --batch 64 --batches-per-step 4 --pipeline 1 --no-cpu-baseline --no-dense > "$OUT/pmc_$i.log" 2>&1
 done
 # the bench lines last: bench.py reports roofline.traffic only from a PMC summary taken from the running kernel sources
 (cd "$REPO" && python profiles/summarize.py "$TAG" > /dev/null 2>&1)
@@ -30,5 +33,5 @@ timeout 120 $B --stage pss --no-cpu-baseline > "$OUT/bench_pss_n1.json" 2> "$OUT
 timeout 120 $B --stage single --steps 200 --warmup 20 > "$OUT/bench_single_n1.json" 2> "$OUT/bench_single_n1.err"
 timeout 120 $B --stage stream --steps 400 --warmup 20 > "$OUT/bench_stream_n1.json" 2> "$OUT/bench_stream_n1.err"
 timeout 120 $B --stage track > "$OUT/bench_track_n1.json" 2> "$OUT/bench_track_n1.err"
-timeout 200 $B --steps 10 --warmup 2 --batches-per-step 40 --input c64 --no-cpu-baseline > "$OUT/bench_full_n1_c64_f16_kernel.json" 2> "$OUT/bench_c64.err"
+timeout 200 $B --steps 10 --warmup 2 --batches-per-step 20 --input c64 --no-cpu-baseline > "$OUT/bench_full_n1_c64_f16_kernel.json" 2> "$OUT/bench_c64.err"
 echo collected > "$OUT/done"

@@ -18,7 +18,7 @@ for name in ("bench_full_n1.json", "bench_full_n1_input_host.json", "bench_singl
             open(os.path.join(dst, name), "w").write((lines[-1] if name.endswith(".json") else "\n".join(lines)) + "\n")
 
 for d, out in (("stats_full_p1", "kernel_stats_full_chain_b64_nf31_pipeline1.csv"),
-               ("stats_full_default", "kernel_stats_full_chain_b64_nf31_default.csv")):
+               ("stats_full_default", "kernel_stats_full_chain_b128_nf31_default_command.csv")):
     f = sorted(glob.glob(os.path.join(src, d, "*", "*_kernel_stats.csv")), key=os.path.getmtime)     # newest collection wins
     if f:
         shutil.copy(f[-1], os.path.join(dst, out))
@@ -49,7 +49,7 @@ def kernel_source_sha():          # the same digest bench.py computes: traffic i
     return h.hexdigest()[:16]
 summary = {
     "source": "profiles/collect.sh: rocprofv3 --pmc <group> --kernel-trace --output-format csv -- python bench.py --steps 1 "
-              "--warmup 0 --batches-per-step 4 --pipeline 1 --no-cpu-baseline --no-dense, one pass per counter group; values are per-launch averages "
+              "--warmup 0 --batch 64 --batches-per-step 4 --pipeline 1 --no-cpu-baseline --no-dense, one pass per counter group; values are per-launch averages "
               "(64 buffers per launch, n_f = 31); kernel_source_sha = sha256 of the correlation kernel sources the counters were taken from",
     "corrections": "FETCH_SIZE is reported in KiB and, on gfx950, as half of the bytes fetched; WRITE_SIZE in KiB is exact "
                    "(MI355X_MICROARCH.md, HBM / rocprofv3 section).  hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024",
