@@ -316,6 +316,38 @@ def test_host_fed_batches_pipelined(pkg, capbuf_0000):
         A.host_free(pin[0]); B.host_free(pin[1])
 
 
+def test_large_batch_equals_small_batches(pkg, capbuf_0000):
+    """bench.py's batch shape: 128 buffers in ONE correlation launch (16 buffers per XCD queue position instead of 8; plus a
+    ragged 77 = 72 through the XCD-aware mapping + 5 through the plain one).  Every buffer's cells and every collapsed array
+    must equal what the same buffer gives in a batch of 8."""
+    import torch
+    cap, fc = capbuf_0000
+    g = golden("capbuf_0000")["iq_u8"]
+    f = f_search_set_for(fc, 100)
+    rng = np.random.default_rng(12)
+    noise = np.clip(np.rint(rng.normal(127.0, 11.0, g.size)), 0, 255).astype(np.uint8)
+    base = [g, noise, np.roll(g, 2 * 999), np.roll(g, 2 * 5000), np.roll(noise, 77), np.roll(g, 2 * 31), np.roll(g, 2 * 8000), np.roll(noise, 4001)]
+    key = lambda c: tuple(v for v in c.as_dict().values() if v == v)
+    with pkg.Searcher(0) as S:
+        fcs8 = fc + 100e3 * np.arange(8)
+        d8 = torch.from_numpy(np.stack(base)).cuda()
+        ref = S.search_batch(d8.data_ptr(), pkg.FMT_IQ_U8, 8, cap.size, f, fcs8, fcs8, FS, pkg.STAGE_FULL)
+        ref_arr = [S.batch_readback(i, f.size) for i in range(8)]
+        assert [c.n_id_cell() for c in ref[0]] == [277, 271]
+        for n in (128, 77):
+            order = [(5 * i + 3) % 8 for i in range(n)]
+            dn = torch.from_numpy(np.stack([base[k] for k in order])).cuda()
+            fcsn = fcs8[order]
+            got = S.search_batch(dn.data_ptr(), pkg.FMT_IQ_U8, n, cap.size, f, fcsn, fcsn, FS, pkg.STAGE_FULL)
+            assert len(got) == n
+            for i, k in enumerate(order):
+                assert [key(c) for c in got[i]] == [key(c) for c in ref[k]], (n, i, k)
+            for i in sorted({0, 7, 8, 63, 64, 71, 72, n - 1}):
+                a, b = S.batch_readback(i, f.size), ref_arr[order[i]]
+                for name in ("pow", "frq", "single"):
+                    assert np.array_equal(a[name], b[name]), (n, i, name)
+
+
 def test_bad_arguments_fail_loudly(S, pkg, capbuf_0000):
     cap, fc = capbuf_0000
     with pytest.raises(pkg.SearcherError):
