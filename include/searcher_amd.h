@@ -275,6 +275,38 @@ class Searcher {
   }
   void stream_close() { check(lcs_stream_close(h_)); }
 
+  // Continuous tracking (lcs_track_stream_block): the next n_sym OFDM symbols of every tracked cell, as the producer thread
+  // queues them (td [cell][sym][128], freq_off / frame_timing / late [cell][sym]).  The rows that became computable with
+  // this block come back in `out`, under their index in the whole stream (include/lcs.h).
+  struct TrackRows {
+    int n_cells, max_rs, max_off;
+    std::vector<double> meas;            // [cell][4][max_rs][LCS_TRK_MEAS]
+    std::vector<int32_t> n_meas;         // [cell][4]
+    std::vector<int32_t> mib_ok;         // [cell][max_off]
+    std::vector<uint64_t> mib_bits;      // [cell][max_off]
+    std::vector<int64_t> mib_from;       // [cell]
+    std::vector<int32_t> n_mib;          // [cell]
+    const double *meas_rows(int cell, int port) const { return &meas[(((size_t)cell * 4 + port) * max_rs) * LCS_TRK_MEAS]; }
+  };
+  void track_stream_block(std::vector<lcs_track_cell> &cells, int n_sym, const std::complex<double> *td, const double *freq_off,
+                          const double *frame_timing, const double *late, double fc_requested, double fc_programmed,
+                          double fs_programmed, TrackRows &out) {
+    const int n = (int)cells.size();
+    out.n_cells = n;
+    out.max_rs = n_sym / 3 + 8;
+    out.max_off = n_sym / 120 + 4;
+    out.meas.assign((size_t)n * 4 * out.max_rs * LCS_TRK_MEAS, 0.0);
+    out.n_meas.assign((size_t)n * 4, 0);
+    out.mib_ok.assign((size_t)n * out.max_off, -1);
+    out.mib_bits.assign((size_t)n * out.max_off, 0);
+    out.mib_from.assign(n, 0);
+    out.n_mib.assign(n, 0);
+    check(lcs_track_stream_block(h_, cells.data(), n, n_sym, td, freq_off, frame_timing, late, fc_requested, fc_programmed,
+                                 fs_programmed, 0, 0, 0, 0, 0, 0, out.meas.data(), 0, 0, out.max_rs, out.n_meas.data(),
+                                 out.mib_ok.data(), out.mib_bits.data(), out.max_off, out.mib_from.data(), out.n_mib.data()));
+  }
+  void track_stream_reset() { check(lcs_track_stream_reset(h_)); }
+
  private:
   enum { LCS_MAX_CELLS_STREAM = 64 };
   void check(int rc) {

@@ -195,3 +195,58 @@ def test_stream_search_consumer_loop(tmp_path):
     assert lines[4].startswith("buffer 4: 0 new, 2 tracked") and lines[5].startswith("buffer 5: 0 new, 0 tracked")
     assert "tracked: 277 271" in r.stdout
     assert subprocess.run([exe], capture_output=True, text=True).returncode == 2
+
+
+@pytest.mark.gpu
+def test_track_cells_consumer_loop(tmp_path):
+    """host/TrackCells.cpp: LTE-Tracker's producer thread and tracker-thread loop in C++ (symbol cutter of
+    src/producer_thread.cpp:96-131, 196-246, lcs_track_stream_block, the lcs::track recurrences).  Its per-block figures
+    must equal what the Python host side (tracker.cut_symbols, Searcher.track_stream_block, tracker.fold_*) computes from the
+    same capture: same cells, same symbols, same measurements, same loops."""
+    pkg = load_pkg()
+    g = golden("capbuf_0000")
+    it = __import__("importlib").import_module("lte_cell_scanner_amd.itfile")
+    cap = iq_u8_to_capbuf(g["iq_u8"])
+    fc = float(g["fc"][0])
+    it.write_it(str(tmp_path / "capbuf_0000.it"), {"capbuf": cap, "fc": g["fc"].astype(np.int32)})
+    exe = os.path.join(ROOT, "host", "TrackCells")
+    block = 200
+    r = subprocess.run([exe, "-b", str(block), str(tmp_path / "capbuf_0000.it")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    lines = [l.split() for l in r.stdout.splitlines() if l.startswith("symbols ")]
+    # the same in Python
+    FS = 1.92e6
+    n_extra = int(np.floor((fc * 120 / 1e6 + 2.5e3) / 5e3))
+    f = 5e3 * np.arange(-n_extra, n_extra + 1)
+    with pkg.Searcher(0) as S:
+        found, _ = S.search_capbuf(cap, f, fc, fc, FS)
+        cells = [c for c in found if c.n_rb_dl > 0]
+        assert [c.n_id_cell() for c in cells] == [277, 271]
+        feeds = []
+        for c in cells:
+            kf = (fc - c.freq_superfine) / fc
+            feeds.append(pkg.tracker.cut_symbols(cap, c.frame_start * (30.72e6 / 16) / (FS * kf), c.cp_type, c.freq_superfine, fc, fc, FS, 10 ** 9))
+        n_total = min(fd[0].shape[0] for fd in feeds)
+        assert f"tracking 2 cell(s), {n_total} OFDM symbols each, {block} per block" in r.stdout
+        f_off = [c.freq_superfine for c in cells]
+        f_tim = [fd[2][0] for fd in feeds]
+        codes = [[], []]
+        want = []
+        for s0 in range(0, n_total, block):
+            n = min(block, n_total - s0)
+            o = S.track_stream_block(cells, np.stack([fd[0][s0:s0 + n] for fd in feeds]), np.stack([fd[3][s0:s0 + n] for fd in feeds]),
+                                     np.stack([fd[2][s0:s0 + n] for fd in feeds]), np.stack([fd[1][s0:s0 + n] for fd in feeds]), fc, fc, FS)
+            for i in range(2):
+                m = o["meas"][i, 0, :o["n_meas"][i, 0]]
+                f_off[i] = pkg.tracker.fold_frequency_offset(f_off[i], m)
+                f_tim[i] = pkg.tracker.fold_frame_timing(f_tim[i], m)
+                codes[i] += list(o["mib_ok"][i, :o["n_mib"][i]])
+                fl, sy, at, _ = pkg.tracker.mib_lock_walk(np.array(codes[i], np.int32)) if codes[i] else (0.0, False, 0, False)
+                want.append((s0 + n, cells[i].n_id_cell(), f_off[i], f_tim[i], at, fl, "LOCKED" if sy else "searching"))
+    assert len(lines) == len(want) and len(want) >= 8
+    for l, w in zip(lines, want):
+        assert int(l[1]) == w[0] and int(l[3]) == w[1]
+        assert abs(float(l[5]) - w[2]) < 1e-5 and abs(float(l[7]) - w[3]) < 1e-5          # printed with 6 decimals
+        assert int(l[10]) == w[4] and abs(float(l[12]) - w[5]) < 0.01 and l[13] == w[6]
+    assert want[-1][6] == "LOCKED" and want[-2][6] == "LOCKED"          # 80 ms hold four full frames from some offset: both cells lock
+    assert subprocess.run([exe], capture_output=True, text=True).returncode == 2
