@@ -19,6 +19,8 @@ SHORT="--steps 2 --warmup 1 --batches-per-step 8 --no-cpu-baseline --no-dense"
 # roofline.kernel_ms must agree with
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_full_p1" -- $B $SHORT --batch 64 --pipeline 1 > "$OUT/stats_full_p1.log" 2>&1
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_full_default" -- $B $SHORT > "$OUT/stats_full_default.log" 2>&1
+# complex<float> batches (k_xcorr_f16x3), every kernel alone
+timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_c64_p1" -- $B $SHORT --batch 64 --pipeline 1 --input c64 > "$OUT/stats_c64_p1.log" 2>&1
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS" \
            "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum"; do

@@ -18,7 +18,8 @@ for name in ("bench_full_n1.json", "bench_full_n1_input_host.json", "bench_singl
             open(os.path.join(dst, name), "w").write((lines[-1] if name.endswith(".json") else "\n".join(lines)) + "\n")
 
 for d, out in (("stats_full_p1", "kernel_stats_full_chain_b64_nf31_pipeline1.csv"),
-               ("stats_full_default", "kernel_stats_full_chain_b128_nf31_default_command.csv")):
+               ("stats_full_default", "kernel_stats_full_chain_b128_nf31_default_command.csv"),
+               ("stats_c64_p1", "kernel_stats_full_chain_b64_nf31_c64_pipeline1.csv")):
     f = sorted(glob.glob(os.path.join(src, d, "*", "*_kernel_stats.csv")), key=os.path.getmtime)     # newest collection wins
     if f:
         shutil.copy(f[-1], os.path.join(dst, out))
