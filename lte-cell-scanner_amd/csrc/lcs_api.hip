@@ -451,8 +451,8 @@ int lcs_batch_enqueue(lcs_ctx *c, const void *d_capbufs, int fmt, int n_buf, uin
   c->use_f16 = fmt == LCS_FMT_C64;            // complex<float> sources: fp16 hi / lo operands, three products (pss_xcorr_f16.hip)
   if (fmt == LCS_FMT_IQ_U8 && (rc = ensure_i8(c))) return rc;      // int8 copies: every u8 source (the fp64 stages read them)
   if (fmt == LCS_FMT_C64 && (rc = ensure_f16(c))) return rc;
-  if ((rc = lcs_launch_ingest(c, d_capbufs, fmt, n_buf, n_cap))) return rc;
-  if (c->use_f16 && (rc = lcs_launch_ingest_f16(c, n_buf, n_cap))) return rc;
+  if (c->use_f16) { if ((rc = lcs_launch_ingest_f16(c, d_capbufs, n_buf, n_cap))) return rc; }
+  else if ((rc = lcs_launch_ingest(c, d_capbufs, fmt, n_buf, n_cap))) return rc;
   if ((rc = lcs_launch_xcorr(c, n_buf, geo, false, true))) return rc;
   if ((rc = lcs_launch_peak_search(c, n_buf, geo, std::pow(10.0, -12.0 / 10.0), true))) return rc;
   if (stage_mask & 2) {

@@ -281,7 +281,7 @@ int lcs_launch_single_layout(lcs_ctx *c, const XcGeom &geo, int slot, float *ref
 int lcs_launch_fill_btab_i8(lcs_ctx *c, int n_buf, const XcGeom &geo);
 int lcs_launch_xcorr_i8(lcs_ctx *c, hipStream_t sxc, const XcGeom &geo, int slot0, int n_slots, int xcd_map);
 // pss_xcorr_f16.hip
-int lcs_launch_ingest_f16(lcs_ctx *c, int n_buf, uint32_t n_cap);          // cap32 -> fp16 hi / lo pairs + per-buffer scale
+int lcs_launch_ingest_f16(lcs_ctx *c, const void *d_src, int n_buf, uint32_t n_cap);   // complex<float> -> cap32 + fp16 hi / lo pairs + per-buffer scale
 int lcs_launch_fill_btab_f16(lcs_ctx *c, int n_buf, const XcGeom &geo);
 int lcs_launch_xcorr_f16(lcs_ctx *c, hipStream_t sxc, const XcGeom &geo, int slot0, int n_slots, int xcd_map);
 size_t lcs_bt16_elems_per_wg(void);
