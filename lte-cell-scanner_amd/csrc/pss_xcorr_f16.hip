@@ -220,8 +220,9 @@ __global__ __launch_bounds__(256, 2) void k_xcorr_f16x3(const uint32_t *__restri
     }                                                                                                        \
   }
   // 16 bytes = 4 samples from a 4-byte aligned LDS address (the window starts at any sample)
-  typedef uint4 __attribute__((aligned(4))) uint4_a4;
-#define F16_RD_A(U) { const uint4 th_ = *reinterpret_cast<const uint4_a4 *>(bufAh + 16 * (U)); const uint4 tl_ = *reinterpret_cast<const uint4_a4 *>(bufAl + 16 * (U)); \
+  typedef unsigned int u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#define F16_RD_A(U) { const u32x4 th_ = *reinterpret_cast<const u32x4_a4 *>(bufAh + 16 * (U)); const u32x4 tl_ = *reinterpret_cast<const u32x4_a4 *>(bufAl + 16 * (U)); \
                       Ah[(U) % (F16_MT + 1)] = __builtin_bit_cast(h8, th_); Al[(U) % (F16_MT + 1)] = __builtin_bit_cast(h8, tl_); }
 
   F16_DMA_A(0);
