@@ -443,6 +443,10 @@ def main():
     ap.add_argument("--lib", default=None, help="developer A/B runs: load this build of liblcs_amd.so instead of the in-tree one")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (testing the multi-rank path on one GPU)")
     ap.add_argument("--share-gpu0", action="store_true", help="testing only: every rank uses GPU 0")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="take the multi-rank branch with ONE rank: process group (RCCL), device-identity all-gather, the per-step "
+                         "asynchronous all-gather of the cell records, the timing all-gather / MAX all-reduce -- so that the first 8-GPU "
+                         "run is not the collective code's first execution")
     ap.add_argument("--input-host", action="store_true",
                     help="feed the batches from page-locked HOST memory (lcs_batch_enqueue_host): the PCIe transfer is inside the timed region")
     ap.add_argument("--no-dense", action="store_true", help="skip the dense-band line (2-3 cells planted in every buffer) reported in config.dense_band")
@@ -470,19 +474,21 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     devices = None
-    if world > 1:
+    multi = world > 1 or args.force_dist      # the multi-rank code path (collectives live), whatever the rank count
+    if multi:
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if args.share_gpu0:
             local_rank = 0
         elif torch.cuda.device_count() < world:
             sys.exit(f"bench.py: {world} ranks but only {torch.cuda.device_count()} GPU(s) visible (testing on one GPU: --share-gpu0 --dist-backend gloo)")
         torch.cuda.set_device(local_rank)
         if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), rank=rank, world_size=world)
         else:
-            dist.init_process_group(args.dist_backend)
+            dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
         # every rank must own a different GPU
         devices = [None] * world
         dist.all_gather_object(devices, device_identity(torch, local_rank))
@@ -490,7 +496,7 @@ def main():
             sys.exit(f"bench.py: the {world} ranks do not sit on {world} distinct GPUs: {devices}")
     else:
         torch.cuda.set_device(0)
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    dev = torch.device("cuda", local_rank if multi else 0)
     coll_dev = dev if args.dist_backend == "nccl" else torch.device("cpu")
 
     if args.stage == "stream":
@@ -520,13 +526,13 @@ def main():
     if fmt == pkg.FMT_C64:
         d_caps = [torch.view_as_complex(((x.to(torch.float32) - 127.0) / 128.0).view(B, N_CAP, 2).contiguous()) for x in d_caps]
     torch.cuda.synchronize()
-    ctxs = [pkg.Searcher(local_rank if world > 1 else 0) for _ in range(max(1, args.pipeline))]
+    ctxs = [pkg.Searcher(local_rank if multi else 0) for _ in range(max(1, args.pipeline))]
     MAXC = 16
     # one fixed-size record block per step for the all-gather: [n, then n x (n_id_cell, fc, f_off, pss_pow, sfn)]
     MAXREC = max(64, B) * K
-    gather_in = [torch.zeros(1 + 5 * MAXREC, dtype=torch.float64, pin_memory=(coll_dev.type == "cuda")) for _ in range(2)] if world > 1 else None
-    gather_dev = [torch.zeros(1 + 5 * MAXREC, dtype=torch.float64, device=coll_dev) for _ in range(2)] if world > 1 else None
-    gather_out = [torch.zeros((world, 1 + 5 * MAXREC), dtype=torch.float64, device=coll_dev) for _ in range(2)] if world > 1 else None
+    gather_in = [torch.zeros(1 + 5 * MAXREC, dtype=torch.float64, pin_memory=(coll_dev.type == "cuda")) for _ in range(2)] if multi else None
+    gather_dev = [torch.zeros(1 + 5 * MAXREC, dtype=torch.float64, device=coll_dev) for _ in range(2)] if multi else None
+    gather_out = [torch.zeros((world, 1 + 5 * MAXREC), dtype=torch.float64, device=coll_dev) for _ in range(2)] if multi else None
     pending = {"work": None}
 
     host_t = {"enqueue": 0.0, "collect": 0.0, "n": 0}
@@ -597,7 +603,7 @@ def main():
                 if xc_ms is not None and not args.no_xc_timing:
                     xc_ms.append(ctxs[j % depth].last_xcorr_ms()[0])
                 if (j + 1) % K == 0:
-                    if world > 1 and gather:
+                    if multi and gather:
                         gather_step(first_step + j // K, recs)
                     recs = []
                     if step_ms is not None:
@@ -626,6 +632,14 @@ def main():
         pending["work"] = None
     torch.cuda.synchronize()
     dt_own = time.perf_counter() - t0
+    if multi:
+        # identity check of the record all-gather (outside the clock): this rank's row of the last step's gather must be
+        # what it contributed, and every rank's row must carry a plausible count
+        li = (args.warmup + args.steps - 1) % 2
+        got = gather_out[li].cpu()
+        if not torch.equal(got[rank], gather_in[li]):
+            sys.exit("bench.py: the all-gathered cell records of this rank differ from what it sent")
+        state["gathered"] = [int(got[r, 0].item()) for r in range(world)]
     if dist is not None:
         dist.barrier()
     dt = time.perf_counter() - t0
@@ -740,7 +754,9 @@ def main():
                        "xcorr_kernel": "mfma_i32_16x16x64_i8, three int8 digits per 24-bit integer template tap" if i8 else
                                        ("mfma_f32_16x16x32_f16, hi / lo fp16 split of samples and templates, three products" if f16 else "mfma_f32_16x16x4_f32"),
                        "pipeline_depth": len(ctxs),
-                       "parallelism": f"carrier-sweep shard x{world}, one async RCCL all-gather of the cell records per step" if world > 1 else "single GPU",
+                       "parallelism": (f"carrier-sweep shard x{world}, one async {'RCCL' if args.dist_backend == 'nccl' else args.dist_backend} all-gather of the "
+                                       f"cell records per step") if multi else "single GPU",
+                       "collectives": ({"backend": dist.get_backend(), "world": world, "gathered_records_last_step": state.get("gathered")} if multi else None),
                        "baseline_note": "vs_baseline = value / (1 buffer per ~6 s), doc/CellSearch.html:52-54 (dual-core i7-2640, ppm 100; BASELINE.md section 1)",
                        "cells_per_distinct_batch": n_cells_per_batch,
                        "cells_per_buffer": float(np.mean(n_cells_per_batch)) / B,

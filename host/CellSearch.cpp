@@ -13,7 +13,8 @@
 // A recorded capture holds exactly (u8-127)/128 per component (src/capbuf.cpp:172-181): such buffers go to the GPU
 // as raw bytes, 64 carriers per batch, and take the int8 correlation kernel; anything else (synthetic complex
 // data) is searched one buffer at a time as complex<double>.  Extra option: -g/--gpu N selects the device, -g all
-// shards the carrier sweep over every visible GPU (one thread and two batches in flight per device).
+// shards the carrier sweep over every visible GPU (one thread and two batches in flight per device), -g a,b,... over the
+// listed devices (an index may repeat).
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -58,6 +59,7 @@ struct Options {
   std::string data_dir = ".";
   long device_index = -1, gpu = -1;
   bool gpu_all = false;          // -g all: shard the carriers over every visible GPU
+  std::vector<long> gpu_list;    // -g a,b,...: one device thread per entry (an index may repeat: "0,0" = two threads on GPU 0)
   long batch = 64;               // carriers per GPU batch (one correlation launch)
   int verbosity = 1;
 };
@@ -75,7 +77,7 @@ const OptSpec kSpecs[] = {
     {'v', "verbose", FLAG, 0, {"increase status messages from program", 0}},
     {'b', "brief", FLAG, 0, {"reduce status messages from program", 0}},
     {'i', "device-index", INDEX, "device index", {"(accepted for compatibility; there is no RTLSDR dongle on a GPU node)", 0}},
-    {'g', "gpu", INDEX, "gpu index", {"GPU to run the searcher on (default: current device); 'all' shards the carriers over every GPU", 0}},
+    {'g', "gpu", INDEX, "gpu index", {"GPU to run the searcher on (default: current device); 'all' shards the carriers over every GPU, 'a,b,..' over the listed ones", 0}},
     {'B', "batch", INDEX, "batch size", {"carriers searched per GPU batch (default 64)", 0}},
     {'s', "freq-start", REAL, "start frequency", {"frequency where cell search should start", 0}},
     {'e', "freq-end", REAL, "end frequency", {"frequency where cell search should end", 0}},
@@ -129,6 +131,17 @@ void store(Options &o, const OptSpec &s, const char *value) {
     }
     case INDEX: {
       if (s.letter == 'g' && std::strcmp(value, "all") == 0) { o.gpu_all = true; return; }
+      if (s.letter == 'g' && std::strchr(value, ',')) {       // device list
+        o.gpu_list.clear();
+        for (const char *p = value;;) {
+          const long v = std::strtol(p, &end, 10);
+          if (end == p || v < 0 || (*end && *end != ',')) die("could not parse gpu index");
+          o.gpu_list.push_back(v);
+          if (!*end) break;
+          p = end + 1;
+        }
+        return;
+      }
       const long v = std::strtol(value, &end, 10);
       if (end == value || *end) die(std::string("could not parse ") + s.what);
       if (v < 0) die(s.letter == 'i' ? "device index cannot be negative" : s.letter == 'g' ? "could not parse gpu index" : "could not parse batch size");
@@ -434,6 +447,14 @@ int main(int argc, char *const argv[]) {
     const int n = lcs::Searcher::device_count();
     if (n < 1) { std::cerr << "Error: lcs_create failed (an MI355X is required; there is no CPU fallback)" << std::endl; return 2; }
     for (int d = 0; d < std::min(n, sw.n_batches); ++d) devices.push_back(d);
+  } else if (!opt.gpu_list.empty()) {
+    // one device thread (two contexts, two batches in flight) per list entry; a repeated index puts several threads on one
+    // GPU -- the merge path of -g all on a one-GPU box
+    const int n = lcs::Searcher::device_count();
+    for (long d : opt.gpu_list) {
+      if (d >= n) { std::cerr << "Error: gpu index " << d << " but only " << n << " GPU(s) are visible" << std::endl; return 2; }
+      devices.push_back((int)d);
+    }
   } else {
     devices.push_back((int)opt.gpu);
   }

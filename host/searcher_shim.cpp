@@ -16,6 +16,7 @@
 namespace {
 
 std::atomic<int> g_device(-1);
+std::atomic<bool> g_want_xc(false);
 
 lcs::Searcher &gpu() {
   // lives as long as the thread and is destroyed (streams, events, workspace) when the thread exits; a failing
@@ -56,17 +57,22 @@ Cell from_lcs(const lcs_cell &c) {
 // its context keeps its device).
 void lcs_shim_set_device(int device) { g_device.store(device); }
 
+// The raw correlations `xc` (include/searcher.h:35) are a debug output only test/test_xcorr_pss.cpp:104-109 reads --
+// 136 MB at n_f = 37, computed by a separate fp64 kernel with the reference's arithmetic (complex<double> accumulation,
+// complex<float> storage, src/searcher.cpp:136,167-169).  Off by default (`xc` comes back empty, as no other caller
+// looks at it); a caller that wants them switches them on here.  Process-wide, applies from the next xcorr_pss call.
+void lcs_shim_want_xc(bool on) { g_want_xc.store(on); }
+
 void xcorr_pss(const itpp::cvec &capbuf, const itpp::vec &f_search_set, const uint8 &ds_comb_arm,
                const double &fc_requested, const double &fc_programmed, const double &fs_programmed,
                itpp::mat &xc_incoherent_collapsed_pow, itpp::imat &xc_incoherent_collapsed_frq,
                vf3d &xc_incoherent_single, vf3d &xc_incoherent, itpp::vec &sp_incoherent, vcf3d &xc, itpp::vec &sp,
                uint16 &n_comb_xc, uint16 &n_comb_sp) {
   unsigned short ncx = 0, ncs = 0;
-  // the raw correlations `xc` are a debug output nobody but test/test_xcorr_pss.cpp reads (136 MB at n_f = 37): the
-  // shim leaves them empty; lcs::Searcher::xcorr_pss(..., want_xc = true) produces them when asked
+  // `xc` is filled only after lcs_shim_want_xc(true) (see there); otherwise it comes back empty
   gpu().xcorr_pss(capbuf, f_search_set, ds_comb_arm, fc_requested, fc_programmed, fs_programmed,
                   xc_incoherent_collapsed_pow, xc_incoherent_collapsed_frq, xc_incoherent_single, xc_incoherent,
-                  sp_incoherent, xc, sp, ncx, ncs, false);
+                  sp_incoherent, xc, sp, ncx, ncs, g_want_xc.load());
   n_comb_xc = ncx;
   n_comb_sp = ncs;
 }

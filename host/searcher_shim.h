@@ -106,4 +106,7 @@ void del_oob(itpp::ivec &v);
 
 // Which GPU the shim's per-thread contexts use (default: the current HIP device).  Not part of the reference's API.
 void lcs_shim_set_device(int device);
+// xcorr_pss fills its `vcf3d &xc` argument (the raw correlations, a debug output: include/searcher.h:35,
+// test/test_xcorr_pss.cpp:104-109) only after lcs_shim_want_xc(true); default off, `xc` then comes back empty
+void lcs_shim_want_xc(bool on);
 #endif

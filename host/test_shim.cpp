@@ -3,10 +3,14 @@
 // TFOEC -> MIB) on one recorded capture buffer and prints what it decodes.  Used by tests/test_cli.py.
 //   test_shim <capbuf_NNNN.it> [ppm]      one line per decoded cell
 //   test_shim --del-oob                   host-only check of del_oob (no GPU needed)
+//   test_shim --xc <capbuf.it> <out.bin> [f0 f1 ...]   xcorr_pss with lcs_shim_want_xc(true): every output flattened the way
+//                                         test/test_xcorr_pss.cpp:104-124 flattens them, written as raw doubles / ints
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <exception>
+#include <stdexcept>
+#include <stdint.h>
 
 #include "../include/lcs.h"
 #include "itfile.hpp"
@@ -27,8 +31,59 @@ static int check_del_oob() {
   return ok ? 0 : 1;
 }
 
+// test/test_xcorr_pss.cpp:94-124 through the shim: call xcorr_pss with the reference's argument list, flatten xc, sp,
+// sp_incoherent, xc_incoherent_single, xc_incoherent, the collapsed powers and frequency indices exactly as the
+// reference's test does (itpp_ext::flatten: first index fastest; cvectorize: column-major) and dump them; the Python
+// side applies the reference test's tolerances against the oracle.
+static void put(std::FILE *f, const void *p, size_t bytes) { if (std::fwrite(p, 1, bytes, f) != bytes) throw std::runtime_error("short write"); }
+static int dump_xc(int argc, char **argv) {
+  if (argc < 4) { std::fprintf(stderr, "usage: test_shim --xc <capbuf.it> <out.bin> [f ...]\n"); return 2; }
+  std::map<std::string, itfile::Var> vars = itfile::read_all(argv[2]);
+  const std::vector<std::complex<double> > samples = itfile::get_dcvec(vars, "capbuf");
+  const double fc = (double)itfile::get_ivec(vars, "fc").at(0);
+  itpp::cvec capbuf((int)samples.size());
+  for (size_t i = 0; i < samples.size(); ++i) capbuf((int)i) = samples[i];
+  itpp::vec f_search_set(argc > 4 ? argc - 4 : 1);
+  f_search_set(0) = 0.0;
+  for (int i = 4; i < argc; ++i) f_search_set(i - 4) = std::atof(argv[i]);
+  itpp::mat pow;
+  itpp::imat frq;
+  vf3d single, incoherent;
+  itpp::vec sp_incoherent, sp;
+  vcf3d xc;
+  uint16 n_comb_xc = 0, n_comb_sp = 0;
+  xcorr_pss(capbuf, f_search_set, 2, fc, fc, 1.92e6, pow, frq, single, incoherent, sp_incoherent, xc, sp, n_comb_xc, n_comb_sp);
+  const bool empty_by_default = xc.empty();
+  lcs_shim_want_xc(true);
+  xcorr_pss(capbuf, f_search_set, 2, fc, fc, 1.92e6, pow, frq, single, incoherent, sp_incoherent, xc, sp, n_comb_xc, n_comb_sp);
+  std::FILE *f = std::fopen(argv[3], "wb");
+  if (!f) throw std::runtime_error("cannot write the output file");
+  const int64_t hdr[8] = {(int64_t)xc.size(), (int64_t)xc.at(0).size(), (int64_t)xc.at(0).at(0).size(), sp.length(), sp_incoherent.length(),
+                          n_comb_xc, n_comb_sp, empty_by_default};
+  put(f, hdr, sizeof(hdr));
+  for (size_t d3 = 0; d3 < xc[0][0].size(); ++d3)            // itpp_ext::flatten(vcf3d), src/itpp_ext.cpp:37-62
+    for (size_t d2 = 0; d2 < xc[0].size(); ++d2)
+      for (size_t d1 = 0; d1 < xc.size(); ++d1) { const std::complex<double> v(xc[d1][d2][d3]); put(f, &v, sizeof(v)); }
+  put(f, sp._data(), sizeof(double) * sp.length());
+  put(f, sp_incoherent._data(), sizeof(double) * sp_incoherent.length());
+  const vf3d *both[2] = {&single, &incoherent};
+  for (int w = 0; w < 2; ++w)
+    for (size_t d3 = 0; d3 < (*both[w])[0][0].size(); ++d3)
+      for (size_t d2 = 0; d2 < (*both[w])[0].size(); ++d2)
+        for (size_t d1 = 0; d1 < both[w]->size(); ++d1) { const double v = (*both[w])[d1][d2][d3]; put(f, &v, sizeof(v)); }
+  for (int c = 0; c < pow.cols(); ++c) for (int r = 0; r < pow.rows(); ++r) put(f, &pow(r, c), sizeof(double));      // cvectorize
+  for (int c = 0; c < frq.cols(); ++c) for (int r = 0; r < frq.rows(); ++r) { const int64_t v = frq(r, c); put(f, &v, sizeof(v)); }
+  std::fclose(f);
+  lcs_shim_want_xc(false);
+  std::printf("xc %zu x %zu x %zu n_comb_xc %d n_comb_sp %d\n", xc.size(), xc[0].size(), xc[0][0].size(), (int)n_comb_xc, (int)n_comb_sp);
+  return 0;
+}
+
 int main(int argc, char **argv) {
   if (argc >= 2 && !std::strcmp(argv[1], "--del-oob")) return check_del_oob();
+  if (argc >= 2 && !std::strcmp(argv[1], "--xc")) {
+    try { return dump_xc(argc, argv); } catch (const std::exception &e) { std::fprintf(stderr, "Error: %s\n", e.what()); return 1; }
+  }
   if (argc < 2) { std::fprintf(stderr, "usage: test_shim <capbuf.it> [ppm] | --del-oob\n"); return 2; }
   try {
     std::map<std::string, itfile::Var> vars = itfile::read_all(argv[1]);

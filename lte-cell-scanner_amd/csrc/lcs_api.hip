@@ -198,6 +198,7 @@ int upload_host_capbuf(lcs_ctx *c, const double *capbuf, uint32_t n_cap, const d
   const XcGeom geo32 = pack_grid(n_cap, n_f, ds, f_search_set, &fc_req, &fc_prog, 1, fs_prog, kMaxTapsF32);
   const XcGeom geo8 = pack_grid(n_cap, n_f, ds, f_search_set, &fc_req, &fc_prog, 1, fs_prog, kMaxTapsI8);
   int rc;
+  c->foe_ready = false;      // slot 0 is overwritten: a pending lcs_foe_partial result is gone (lcs_foe_partial sets it again)
   if ((rc = ensure_ws(c, 1, n_cap, n_f, debug, std::max(geo32.G, geo8.G)))) return rc;
   // the int8 copies cannot be (re)allocated under an open stream's graph: such a context keeps the fp32 kernel
   const bool can_i8 = c->i8_ready || !c->st_open;
@@ -433,6 +434,7 @@ int lcs_batch_enqueue(lcs_ctx *c, const void *d_capbufs, int fmt, int n_buf, uin
   if (!d_capbufs || !f_search_set || !fc_requested || !fc_programmed || n_buf < 1) { c->err = "bad argument"; return LCS_ERR_BAD_ARG; }
   if (fmt != LCS_FMT_C64 && fmt != LCS_FMT_IQ_U8) { c->err = "unknown capture format"; return LCS_ERR_BAD_ARG; }
   HIPCHK(c, hipSetDevice(c->device));
+  c->foe_ready = false;      // the batch overwrites the buffers a pending lcs_foe_partial left for lcs_foe_finish
   // u8 I/Q is exact in int8: the int8 three-digit kernel (pss_xcorr_i8.hip), 137 taps + window-start spread <= 160 inside
   // every template group; every other source takes the fp32 kernel (spread <= 111); pack_grid thins the groups of a grid
   // that is too sparse for that
@@ -448,9 +450,11 @@ int lcs_batch_enqueue(lcs_ctx *c, const void *d_capbufs, int fmt, int n_buf, uin
   HIPCHK(c, hipMemcpyAsync(c->fset, hf, sizeof(double) * n_f, hipMemcpyHostToDevice, c->stream));
   c->cap64_valid = false;
   c->use_i8 = fmt == LCS_FMT_IQ_U8;
-  c->use_f16 = fmt == LCS_FMT_C64;            // complex<float> sources: fp16 hi / lo operands, three products (pss_xcorr_f16.hip)
+  // complex<float> sources: fp16 hi / lo operands, three products (pss_xcorr_f16.hip) -- unless its buffers would have to be
+  // allocated under an open stream's graph: such a context keeps the fp32 kernel for them (160 taps per group fit it too)
+  c->use_f16 = fmt == LCS_FMT_C64 && (c->f16_ready || !c->st_open);
   if (fmt == LCS_FMT_IQ_U8 && (rc = ensure_i8(c))) return rc;      // int8 copies: every u8 source (the fp64 stages read them)
-  if (fmt == LCS_FMT_C64 && (rc = ensure_f16(c))) return rc;
+  if (c->use_f16 && (rc = ensure_f16(c))) return rc;
   if (c->use_f16) { if ((rc = lcs_launch_ingest_f16(c, d_capbufs, n_buf, n_cap))) return rc; }
   else if ((rc = lcs_launch_ingest(c, d_capbufs, fmt, n_buf, n_cap))) return rc;
   if ((rc = lcs_launch_xcorr(c, n_buf, geo, false, true))) return rc;
@@ -926,6 +930,7 @@ int stream_chain(lcs_ctx *c, int k) {
   int rc;
   c->use_i8 = c->st_fmt == LCS_FMT_IQ_U8;      // one hypothesis: no window-start spread, the int8 kernel always fits
   c->use_f16 = false;
+  c->foe_ready = false;
   HIPCHK(c, hipMemcpyAsync(c->st_din, c->st_hin[k], c->st_in_bytes, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->params, &h->p, sizeof(SlotParams), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->fset, &h->f, sizeof(double), hipMemcpyHostToDevice, c->stream));
@@ -1025,6 +1030,7 @@ int lcs_stream_push(lcs_ctx *c, const void *samples, double f_off, const int16_t
   if (c->st_count >= 2) { c->err = "two buffers are in flight already: lcs_stream_collect first"; return LCS_ERR_BAD_ARG; }
   if (n_tracked < 0 || n_tracked > 504 || (n_tracked > 0 && !tracked_ids)) { c->err = "bad tracked list"; return LCS_ERR_BAD_ARG; }
   HIPCHK(c, hipSetDevice(c->device));
+  c->foe_ready = false;      // the graph overwrites slot 0
   const int k = (c->st_head + c->st_count) & 1;
   std::memcpy(c->st_hin[k], samples, c->st_in_bytes);
   c->st_host[k]->f = f_off;

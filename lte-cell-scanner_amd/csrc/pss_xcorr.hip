@@ -870,6 +870,7 @@ int lcs_launch_xcorr(lcs_ctx *c, int n_buf, const XcGeom &geo, bool want_incoh, 
     if (geo.ds == 2 && !incoh && geo.cpg == LCS_TG)
       hipLaunchKernelGGL(k_collapse_arm2, dim3((LCS_N_IDX / (4 * COLLAPSE_OUT)) * n_buf), block, 0, c->stream, c->single, c->pow_, pow32, c->frq, geo, n_buf);
     else if (geo.ds == 2 && !incoh) hipLaunchKernelGGL((k_collapse<2, false>), grid, block, 0, c->stream, c->single, incoh, c->pow_, pow32, c->frq, geo, n_buf);
+    else if (!incoh) hipLaunchKernelGGL((k_collapse<-1, false>), grid, block, 0, c->stream, c->single, incoh, c->pow_, pow32, c->frq, geo, n_buf);   // any arm, no debug copy
     else hipLaunchKernelGGL((k_collapse<-1, true>), grid, block, 0, c->stream, c->single, incoh, c->pow_, pow32, c->frq, geo, n_buf);
   }
   HIPCHK(c, hipGetLastError());

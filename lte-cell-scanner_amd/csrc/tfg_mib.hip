@@ -714,7 +714,7 @@ __global__ __launch_bounds__(CE_THREADS) void k_chan_est(const lcs_cell *__restr
       if (m_r1 < 0) m_r1 = 0;
       if (m_rs < 0) m_rs = 0;
 #pragma unroll
-      for (int off = 1; off < 32; off <<= 1) {
+      for (int off = 1; off < 64; off <<= 1) {      // whole wave: n_tri may reach 64
         const int o0 = __shfl_up(m_mine, off), o1 = __shfl_up(m_r1, off), o2 = __shfl_up(m_rs, off);
         if (lane >= off) { m_mine = max(m_mine, o0); m_r1 = max(m_r1, o1); m_rs = max(m_rs, o2); }
       }

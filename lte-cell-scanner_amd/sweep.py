@@ -110,7 +110,8 @@ def run_sweep(search_fn: Callable, get_capbufs: Callable[[np.ndarray], object], 
             for j, cells in enumerate(res):
                 cnt[a + j] = min(len(cells), MAXC)
                 rec[a + j, :cnt[a + j]] = cells_to_records(cells[:MAXC])
-    if world > 1:      # the sweep's only collective: counts ride in front of the records
+    if dist is not None:      # the sweep's only collective: counts ride in front of the records.  Also run at world 1 when
+        # a process group is live: the RCCL path of an 8-GPU node exercised on one GPU (tests/test_gpu_rccl.py)
         blob = np.concatenate([cnt.view(np.uint8), rec.view(np.uint8).reshape(-1)])
         blobs = _all_gather_bytes(blob, dist, device, world)
         parts = [(b[:cnt.nbytes].view(np.int32), b[cnt.nbytes:].view(cell_dtype()).reshape(rec.shape)) for b in blobs]
@@ -171,7 +172,7 @@ def search_capbuf_foe_split(stages, capbuf, f_search_set, fc_requested, fc_progr
         words = pack_pow_frq(r["pow"], own[0] + r["frq"])
         single_full[:, :, own] = r["single"]
         sp_inc, n_comb_xc = r["sp_incoherent"], int(r["n_comb_xc"])
-    if world > 1:
+    if dist is not None:
         t = torch.from_numpy(words)
         if device is not None:
             t = t.to(device)
@@ -212,7 +213,7 @@ def search_capbuf_foe_split(stages, capbuf, f_search_set, fc_requested, fc_progr
     if mine:
         rec[:len(mine)] = cells_to_records([c for _, c in mine[:MAXC]])
         order[:len(mine)] = [o for o, _ in mine[:MAXC]]
-    if world > 1:
+    if dist is not None:
         blobs = _all_gather_bytes(np.concatenate([order.view(np.uint8), rec.view(np.uint8)]), dist, device, world)
         allc = []
         for b in blobs:
@@ -239,7 +240,7 @@ def search_capbuf_foe_split_dev(searcher, capbuf, f_search_set, fc_requested, fc
     meta = torch.empty(9601, dtype=torch.float64, device=dev)
     searcher.foe_partial(capbuf, f, int(own[0]) if own.size else 0, int(own.size), fc_requested, fc_programmed, fs_programmed,
                          words.data_ptr(), meta.data_ptr())
-    if world > 1:
+    if dist is not None:
         dist.all_reduce(words, op=dist.ReduceOp.MAX)
         dist.broadcast(meta, src=0)
         torch.cuda.synchronize(dev)
@@ -250,7 +251,7 @@ def search_capbuf_foe_split_dev(searcher, capbuf, f_search_set, fc_requested, fc
     if n:
         rec[:n] = cells_to_records(cells[:n])
         ordv[:n] = order[:n]
-    if world > 1:
+    if dist is not None:
         gdev = dev if dist.get_backend() == "nccl" else None        # the record gather of a gloo test run goes through host tensors
         blobs = _all_gather_bytes(np.concatenate([ordv.view(np.uint8), rec.view(np.uint8)]), dist, gdev, world)
     else:

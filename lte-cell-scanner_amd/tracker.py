@@ -126,6 +126,8 @@ def mib_lock_walk(mib_ok, failures: float = 0.0, synchronized: bool = False, dro
         codes = np.where(a, 3, 0)
     elif np.issubdtype(a.dtype, np.integer):
         codes = a
+        if codes.size and (codes.min() < -1 or codes.max() > 3):
+            raise ValueError("mib_lock_walk: integer input must be track_block's mib_ok codes (-1, 0..3); pass booleans for plain lock flags")
     else:
         raise ValueError("mib_lock_walk takes track_block's integer mib_ok codes or booleans")
     o, attempts = 0, 0

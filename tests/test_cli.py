@@ -69,7 +69,7 @@ def test_shim_links_against_the_reference_signatures_and_del_oob():
     r = subprocess.run([SHIM, "--del-oob"], capture_output=True, text=True, timeout=60)
     assert r.returncode == 0 and "del_oob ok" in r.stdout
     syms = subprocess.run(["nm", "-C", os.path.join(ROOT, "host", "searcher_shim.o")], capture_output=True, text=True).stdout
-    for fn in ("xcorr_pss(", "peak_search(", "sss_detect(", "pss_sss_foe(", "extract_tfg(", "tfoec(", "decode_mib(", "del_oob("):
+    for fn in ("xcorr_pss(", "peak_search(", "sss_detect(", "pss_sss_foe(", "extract_tfg(", "tfoec(", "decode_mib(", "del_oob(", "lcs_shim_want_xc(bool)"):
         assert re.search(r" T " + re.escape(fn), syms), fn
     assert re.search(r" T tfoec\(Cell const&, .*RS_DL const&", syms) and re.search(r" T decode_mib\(Cell const&, .*RS_DL const&\)", syms)
 
@@ -123,6 +123,54 @@ def test_shim_runs_the_reference_call_sequence(tmp_path):
 
 
 @pytest.mark.gpu
+def test_shim_replays_the_reference_xcorr_pss_test(tmp_path):
+    """test/test_xcorr_pss.cpp:94-124 through the reference-shaped xcorr_pss of host/searcher_shim.cpp: `xc` (searcher.h:35)
+    comes back empty by default and filled after lcs_shim_want_xc(true); every output, flattened as the reference's test
+    flattens it, against the oracle with that test's tolerances where it states absolute ones our arithmetic meets (xc 1e-6,
+    the frequency indices equal) and this repository's bars elsewhere (1e-5 relative on the powers, 1e-11 on the power
+    estimates) -- the reference's own expected vectors (test_xcorr_pss.it) are not shipped."""
+    import oracle as O
+    g = golden("capbuf_0000")
+    cap = iq_u8_to_capbuf(g["iq_u8"])
+    pkg = load_pkg()
+    pkg_it = __import__("importlib").import_module("lte_cell_scanner_amd.itfile")
+    pkg_it.write_it(str(tmp_path / "capbuf_0000.it"), {"capbuf": cap, "fc": g["fc"].astype(np.int32)})
+    f = [30e3, 35e3, 40e3]
+    out = tmp_path / "xc.bin"
+    r = subprocess.run([SHIM, "--xc", str(tmp_path / "capbuf_0000.it"), str(out)] + [repr(x) for x in f], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    raw = out.read_bytes()
+    hdr = np.frombuffer(raw, np.int64, 8)
+    d1, d2, d3, n_sp, n_spi, ncx, ncs, empty_default = [int(x) for x in hdr]
+    assert (d1, d2, d3) == (3, 153600 - 136, 3) and (ncx, ncs) == (15, 15) and empty_default == 1
+    o = 64
+    def take(n, dt):
+        nonlocal o
+        a = np.frombuffer(raw, dt, n, o)
+        o += a.nbytes
+        return a
+    xc = take(d1 * d2 * d3, np.complex128).reshape(d3, d2, d1).transpose(2, 1, 0)     # first index fastest -> [t][k][foi]
+    sp, spi = take(n_sp, np.float64), take(n_spi, np.float64)
+    single = take(3 * 9600 * 3, np.float64).reshape(3, 9600, 3).transpose(2, 1, 0)
+    incoh = take(3 * 9600 * 3, np.float64).reshape(3, 9600, 3).transpose(2, 1, 0)
+    pw = take(3 * 9600, np.float64).reshape(9600, 3).T                                 # cvectorize: column-major
+    fq = take(3 * 9600, np.int64).reshape(9600, 3).T
+    assert o == len(raw)
+    O.set_threads(8)
+    fc = float(g["fc"][0])
+    ro = O.xcorr_pss(cap, np.array(f), 2, fc, fc, 1.92e6, want_xc=True, want_sp=True)
+    assert np.abs(xc - ro["xc"]).max() < 1e-6                                          # test_xcorr_pss.cpp:105
+    assert (np.abs(sp - ro["sp"]) / ro["sp"]).max() < 1e-11 and (np.abs(spi - ro["sp_incoherent"]) / ro["sp_incoherent"]).max() < 1e-11
+    assert (np.abs(single - ro["single"]) / ro["single"]).max() < 1e-5 and (np.abs(incoh - ro["incoherent"]) / ro["incoherent"]).max() < 1e-5
+    assert (np.abs(pw - ro["pow"]) / ro["pow"]).max() < 1e-5
+    bad = np.argwhere(fq != ro["frq"])
+    assert len(bad) <= 4                                                               # numerical ties only (INTEGRATION.md section 1)
+    for t, i in bad:
+        a, b = ro["incoherent"][t, i, fq[t, i]], ro["incoherent"][t, i, ro["frq"][t, i]]
+        assert abs(float(a) - float(b)) <= 5e-7 * float(b)
+
+
+@pytest.mark.gpu
 def test_sweep_mixes_byte_exact_and_arbitrary_captures(tmp_path):
     """Three carriers: two recorded (byte-exact -> one int8 batch), one arbitrary complex buffer in between (-> single
     fp32 search).  Output order, duplicate merging across carriers and the table must follow the reference's rules."""
@@ -162,12 +210,18 @@ def test_sharded_sweep_gives_the_same_report(tmp_path):
     base = ["-s", "739.0e6", "-e", "739.4e6", "-l", "-d", str(tmp_path)]
     one = _run(base)
     assert one.returncode == 0, one.stderr
-    for extra in (["-g", "all", "-B", "2"], ["-g", "0", "-B", "1"], ["--gpu=all", "--batch", "3"]):
+    # -g 0,0 / 0,0,0: two / three device threads (two contexts each) on the one GPU -- the block-cyclic batch assignment and
+    # the in-order merge of `-g all` on a multi-GPU node (src/CellSearch.cpp:471-569), byte-identical report
+    for extra in (["-g", "all", "-B", "2"], ["-g", "0", "-B", "1"], ["--gpu=all", "--batch", "3"], ["-g", "0,0", "-B", "1"],
+                  ["-g", "0,0", "-B", "2"], ["--gpu=0,0,0", "-B", "1"]):
         r = _run(base + extra)
         assert r.returncode == 0, r.stderr
         assert r.stdout == one.stdout, (extra, r.stdout, one.stdout)
     assert one.stdout.count("Detected a cell!") == 4 and one.stdout.count("center frequency did not match") == 4
     assert "could not parse gpu index" in _run(base + ["-g", "some"]).stderr
+    assert "could not parse gpu index" in _run(base + ["-g", "0,x"]).stderr
+    bad = _run(base + ["-g", "0,99"])
+    assert bad.returncode == 2 and "GPU(s) are visible" in bad.stderr
 
 
 @pytest.mark.gpu

@@ -397,9 +397,27 @@ def test_fp16_kernel_on_unquantised_float_sources(S, pkg):
         assert (np.abs(r["pow"] - ro["pow"]) / ro["pow"]).max() < RTOL
         co, _ = O.search_capbuf(bufs[k].astype(np.complex128), f, fc, fc, FS)
         assert [(c.n_id_cell(), c.ind, c.sfn) for c in res[k]] == [(c.n_id_cell(), c.ind, c.sfn) for c in co], k
-    assert [c.n_id_cell() for c in res[0]] == [181, 27] or len(res[0]) >= 1
+    # the planted identities (60, 1), (9, 0) and (130, 2) come back decoded, at the oracle's positions
+    assert [(c.n_id_cell(), c.ind, c.sfn, c.n_rb_dl) for c in res[0]] == [(181, 5211, 656, 50), (27, 5179, 503, 50)]
+    assert [(c.n_id_cell(), c.ind, c.sfn, c.n_rb_dl) for c in res[1]] == [(392, 474, 158, 50)]
     # the nearly empty buffer: absolute agreement (most positions correlate to exactly zero in both)
     ro = O.xcorr_pss(bufs[3].astype(np.complex128), f, 2, fc, fc, FS)
     r = S.batch_readback(3, f.size)
     assert np.abs(r["single"].astype(np.float64) - ro["single"]).max() < 1e-6 * ro["single"].max()
     print(f"fp16 three-product kernel: worst relative deviation of xc_incoherent_single from the oracle {worst:.2e}")
+
+
+@pytest.mark.parametrize("ds", [0, 1, 3])
+def test_xcorr_pss_other_delay_spread_arms_without_debug_copy(S, capbuf_0000, ds):
+    """ds_comb_arm != 2 with incoherent == NULL (lcs.h: "incoherent may be NULL"): the generic collapse kernel must not
+    store the debug copy it was not given a buffer for (round-3 advisory: it did), and the collapsed arrays must equal
+    the ones of the call that asks for the copy and the oracle's (src/searcher.cpp:312-383)."""
+    cap, fc = capbuf_0000
+    f = np.array([30e3, 35e3, 40e3])
+    a = S.xcorr_pss(cap, f, ds, fc, fc, FS, want_incoherent=False)
+    b = S.xcorr_pss(cap, f, ds, fc, fc, FS, want_incoherent=True)
+    assert a["incoherent"] is None and np.array_equal(a["pow"], b["pow"]) and np.array_equal(a["frq"], b["frq"])
+    ro = O.xcorr_pss(cap, f, ds, fc, fc, FS)
+    assert (np.abs(a["pow"] - ro["pow"]) / ro["pow"]).max() < RTOL
+    _check_frq(a["frq"], ro, f"ds_comb_arm {ds}")
+    assert (np.abs(b["incoherent"].astype(np.float64) - ro["incoherent"]) / ro["incoherent"]).max() < RTOL

@@ -55,6 +55,8 @@ def main():
     ap.add_argument("--seed", type=int, default=2024)
     ap.add_argument("--dist-backend", default="nccl")
     ap.add_argument("--share-gpu0", action="store_true", help="testing only: every rank uses GPU 0")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the process group and run the record all-gather even with ONE rank (the RCCL path on a one-GPU box)")
     ap.add_argument("--json", action="store_true", help="print a JSON summary line instead of the table")
     ap.add_argument("--write-it", default=None, help="also write every carrier's buffer as capbuf_NNNN.it into this directory")
     args = ap.parse_args()
@@ -69,13 +71,15 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        kw = dict(rank=rank, world_size=world)
         if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, **kw)
         else:
-            dist.init_process_group(args.dist_backend)
+            dist.init_process_group(args.dist_backend, **kw)
 
     # raster handling and the frequency grid exactly as the CLI: n_extra from freq_start only (CellSearch.cpp:463)
     fs_, fe_ = round(args.freq_start / 100e3) * 100e3, round(args.freq_end / 100e3) * 100e3
@@ -131,12 +135,13 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     final, detected = sw.run_sweep(search_fn, get_capbufs, fcs, rank, world, dist,
-                                   dev if (world > 1 and args.dist_backend == "nccl") else None, batch=args.batch)
+                                   dev if (dist is not None and args.dist_backend == "nccl") else None, batch=args.batch)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if rank == 0:
         if args.json:
             print(json.dumps({"carriers": int(len(fcs)), "n_f": int(len(f_set)), "n_gpus": world, "seconds_search": dt,
+                              "collective": (f"{dist.get_backend()} all-gather, world {world}" if dist is not None else None),
                               "carriers_per_s": len(fcs) / dt, "seconds_making_buffers_resident_rank0": t_gen,
                               "planted": {str(k): v for k, v in sorted(truth.items())} if world == 1 else None,
                               "cells": [(c["n_id_cell"], c["fc_requested"], c["n_rb_dl"], c["n_ports"]) for c in final]}))
