@@ -210,7 +210,10 @@ int lcs_host_free(lcs_ctx *ctx, void *p);
 int lcs_device_count(void);
 
 /* Enqueue-only variant for timing: same work, results stay on the device until
- * lcs_batch_collect.  Between enqueue and collect nothing synchronises with the host. */
+ * lcs_batch_collect.  Between enqueue and collect nothing synchronises with the host.
+ * The caller's device buffers must stay valid and unchanged until lcs_batch_collect has returned: u8 buffers are
+ * converted by the first kernel of the chain, complex<float> buffers (even n_cap, 16-byte aligned) are read IN PLACE by
+ * the SSS / FOE / grid stages as well -- the library keeps no float copy of them. */
 int lcs_batch_enqueue(lcs_ctx *ctx, const void *d_capbufs, int fmt, int n_buf, uint32_t n_cap,
                       const double *f_search_set, uint16_t n_f, const double *fc_requested,
                       const double *fc_programmed, double fs_programmed, int stage_mask);

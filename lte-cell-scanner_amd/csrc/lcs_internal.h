@@ -152,6 +152,7 @@ struct lcs_ctx {
   unsigned *xmax16 = nullptr;        // per slot: bits of the largest |component|
   bool f16_ready = false, use_f16 = false;
   bool src_u8 = false;               // the resident buffers came from a u8 source: the fp64 stages read cap8
+  const float2 *src32 = nullptr;     // complex<float> batches read in place: the CALLER's buffers, which the fp64 stages read (no cap32 copy)
   double2 *cap64 = nullptr;          // slot 0 only: fp64 copy for the host (complex<double>) entry points
   bool cap64_valid = false;
   SlotParams *params = nullptr;

@@ -752,7 +752,7 @@ CapSrc lcs_cap_src(const lcs_ctx *c, uint32_t n_cap) {
   CapSrc s{nullptr, nullptr, nullptr, n_cap};
   if (c->cap64_valid) s.c64 = c->cap64;
   else if (c->src_u8) s.c8 = c->cap8;
-  else s.c32 = c->cap32;
+  else s.c32 = c->src32 ? c->src32 : c->cap32;
   return s;
 }
 
@@ -760,6 +760,7 @@ CapSrc lcs_cap_src(const lcs_ctx *c, uint32_t n_cap) {
 // the correlation kernel from it).  Needs the int8 buffers (ensure_i8 in lcs_api.hip).
 int lcs_launch_ingest_c128(lcs_ctx *c, uint32_t n_cap, bool *exact) {
   c->src_u8 = false;
+  c->src32 = nullptr;
   HIPCHK(c, hipMemsetAsync(c->d_flag, 0, sizeof(int), c->stream));
   const unsigned nb = (unsigned)((lcs_cap8_stride(n_cap) / 8 + 255) / 256);
   hipLaunchKernelGGL(k_ingest_c128, dim3(nb), dim3(256), 0, c->stream, c->cap64, n_cap, c->cap32, c->cap8, c->cap8s, c->d_flag);
@@ -773,6 +774,7 @@ int lcs_launch_ingest_c128(lcs_ctx *c, uint32_t n_cap, bool *exact) {
 
 int lcs_launch_ingest(lcs_ctx *c, const void *d_src, int fmt, int n_buf, uint32_t n_cap) {
   c->src_u8 = fmt == LCS_FMT_IQ_U8;
+  c->src32 = nullptr;
   if (fmt == LCS_FMT_IQ_U8) {
     const unsigned nb = (unsigned)((lcs_cap8_stride(n_cap) / 8 + 255) / 256);
     hipLaunchKernelGGL(k_ingest_u8, dim3(nb, n_buf), dim3(256), 0, c->stream, (const uint8_t *)d_src, n_cap, c->cap8, c->cap8s);

@@ -37,6 +37,13 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 #define F16_AW (F16_LAGS + 16 * F16_NKB + 16)             // staged samples per window
 #define F16_ADW (((F16_AW + 63) / 64) * 64)               // dwords (= samples) per staged array: whole 64-dword LDS-DMA pieces
 #define F16_CHUNK (2 * F16_CH * 2 * 64)                   // uint4 per B chunk: [term hi / lo][kb][op][lane]
+// F16_A64: TWO staged copies of a window (shifted by 0 / 1 sample): a lane's 16-byte operand then starts 8-byte aligned in
+// the copy matching the parity of its first sample and is read with two ds_read_b64 instead of two ds_read2_b32
+#ifndef F16_A64
+#define F16_A64 0
+#endif
+#define F16_NCOPY (F16_A64 ? 2 : 1)
+#define F16_ACOPY (F16_ADW + (F16_A64 ? 32 : 0))          // copy stride: the two copies 32 banks apart
 #define F16_TARGET_EXP 9                                  // operands are scaled into [2^9, 2^10)
 
 __device__ __forceinline__ uint32_t f16_bits(_Float16 h) { return (uint32_t)__builtin_bit_cast(unsigned short, h); }
@@ -45,18 +52,25 @@ __device__ __forceinline__ void f16_split(float v, _Float16 &hi, _Float16 &lo) {
   lo = (_Float16)(v - (float)hi);
 }
 
-// ---- per buffer: the power of two that brings the largest sample component into [512, 1024).  The maximum is taken while
-// the caller's complex<float> buffers are copied into cap32 (the copy the fp64 stages read): one pass, 32 bytes per lane
-// and load (round 3 first ran a plain copy and a separate maximum pass over the copy: 26 + 51 us per 64 buffers).
-__global__ __launch_bounds__(256) void k_f16_copy_max(const float4 *__restrict__ src, uint32_t n_cap, float4 *__restrict__ cap32,
-                                                      unsigned *__restrict__ xmax_bits) {
+// ---- per buffer: the power of two that brings the largest sample component into [512, 1024).
+// Round 4: no copy at all when the caller's buffers can be read in place (even n_cap, 16-byte aligned): the fp64 stages read
+// them through CapSrc (lcs_cap_src), so only the per-buffer maximum is taken here -- a read-only pass with four 16-byte loads
+// in flight per lane.
+__global__ __launch_bounds__(256) void k_f16_max4(const float4 *__restrict__ src, uint32_t n_cap, unsigned *__restrict__ xmax_bits) {
   LCS_TAIL_PRIO();
   const int slot = blockIdx.y;
-  const size_t base = (size_t)slot * (n_cap / 2);            // float4 = two samples; n_cap is even (checked by the launcher)
+  const uint32_t n4 = n_cap / 2;
+  const float4 *b = src + (size_t)slot * n4;
   float m = 0.f;
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_cap / 2; i += gridDim.x * blockDim.x) {
-    const float4 v = src[base + i];
-    cap32[base + i] = v;
+  const uint32_t step = gridDim.x * blockDim.x;
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + 3 * step < n4; i += 4 * step) {
+    const float4 v0 = b[i], v1 = b[i + step], v2 = b[i + 2 * step], v3 = b[i + 3 * step];
+    m = fmaxf(m, fmaxf(fmaxf(fmaxf(fabsf(v0.x), fabsf(v0.y)), fmaxf(fabsf(v0.z), fabsf(v0.w))), fmaxf(fmaxf(fabsf(v1.x), fabsf(v1.y)), fmaxf(fabsf(v1.z), fabsf(v1.w)))));
+    m = fmaxf(m, fmaxf(fmaxf(fmaxf(fabsf(v2.x), fabsf(v2.y)), fmaxf(fabsf(v2.z), fabsf(v2.w))), fmaxf(fmaxf(fabsf(v3.x), fabsf(v3.y)), fmaxf(fabsf(v3.z), fabsf(v3.w)))));
+  }
+  for (; i < n4; i += step) {
+    const float4 v = b[i];
     m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
   }
   for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_down(m, off));
@@ -77,27 +91,44 @@ __global__ __launch_bounds__(256) void k_f16_max(const float2 *__restrict__ cap3
 }
 __device__ __forceinline__ int f16_scale_exp(float mx) { return (mx > 0.f) ? F16_TARGET_EXP - ilogbf(mx) : 0; }
 
-// cap32 -> (re, im) fp16 pairs, hi and lo parts, zero-padded behind n_cap like the int8 copies (the LDS-DMA of the
-// correlation reads past the end)
-__global__ __launch_bounds__(256) void k_f16_ingest(const float2 *__restrict__ cap32, uint32_t n_cap, const unsigned *__restrict__ xmax_bits,
+// complex<float> buffers (the caller's, or cap32) -> (re, im) fp16 pairs, hi and lo parts, zero-padded behind n_cap like the
+// int8 copies (the LDS-DMA of the correlation reads past the end).  PAIRS: one 16-byte load and two 8-byte stores per lane
+// (even n_cap, 16-byte aligned source; the slot stride of the fp16 copies is a multiple of 8 samples).
+__device__ __forceinline__ void f16_split_sample(float2 v, int k, uint32_t &h, uint32_t &l) {
+  _Float16 rh, rl, ih, il;
+  f16_split(ldexpf(v.x, k), rh, rl);
+  f16_split(ldexpf(v.y, k), ih, il);
+  h = f16_bits(rh) | (f16_bits(ih) << 16);
+  l = f16_bits(rl) | (f16_bits(il) << 16);
+}
+template <bool PAIRS>
+__global__ __launch_bounds__(256) void k_f16_ingest(const float2 *__restrict__ src32, uint32_t n_cap, const unsigned *__restrict__ xmax_bits,
                                                     uint32_t *__restrict__ cap16h, uint32_t *__restrict__ cap16l) {
   LCS_TAIL_PRIO();
   const int slot = blockIdx.y;
   const size_t stride = lcs_cap8_stride(n_cap);
   const int k = f16_scale_exp(__uint_as_float(xmax_bits[slot]));
-  const float2 *c = cap32 + (size_t)slot * n_cap;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < stride; i += (size_t)gridDim.x * blockDim.x) {
-    uint32_t h = 0, l = 0;
-    if (i < n_cap) {
-      const float2 v = c[i];
-      _Float16 rh, rl, ih, il;
-      f16_split(ldexpf(v.x, k), rh, rl);
-      f16_split(ldexpf(v.y, k), ih, il);
-      h = f16_bits(rh) | (f16_bits(ih) << 16);
-      l = f16_bits(rl) | (f16_bits(il) << 16);
+  const float2 *c = src32 + (size_t)slot * n_cap;
+  if (PAIRS) {
+    const float4 *c4 = reinterpret_cast<const float4 *>(c);
+    uint2 *oh = reinterpret_cast<uint2 *>(cap16h + (size_t)slot * stride), *ol = reinterpret_cast<uint2 *>(cap16l + (size_t)slot * stride);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < stride / 2; i += (size_t)gridDim.x * blockDim.x) {
+      uint2 h = make_uint2(0u, 0u), l = make_uint2(0u, 0u);
+      if (2 * i < n_cap) {
+        const float4 v = c4[i];
+        f16_split_sample(make_float2(v.x, v.y), k, h.x, l.x);
+        f16_split_sample(make_float2(v.z, v.w), k, h.y, l.y);
+      }
+      oh[i] = h;
+      ol[i] = l;
     }
-    cap16h[(size_t)slot * stride + i] = h;
-    cap16l[(size_t)slot * stride + i] = l;
+  } else {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < stride; i += (size_t)gridDim.x * blockDim.x) {
+      uint32_t h = 0, l = 0;
+      if (i < n_cap) f16_split_sample(c[i], k, h, l);
+      cap16h[(size_t)slot * stride + i] = h;
+      cap16l[(size_t)slot * stride + i] = l;
+    }
   }
 }
 
@@ -180,10 +211,10 @@ __global__ __launch_bounds__(256, 2) void k_xcorr_f16x3(const uint32_t *__restri
   const int slot = slot0 + sidx, g = q / F16_TILES, idx0 = (q % F16_TILES) * F16_LAGS;
   const int widx0 = idx0 + wave * (F16_MT * 16);
 
-  __shared__ uint32_t ldsA[2][2][F16_ADW];       // [window & 1][hi, lo][sample]
+  __shared__ __attribute__((aligned(16))) uint32_t ldsA[2][2][F16_NCOPY][F16_ACOPY];       // [window & 1][hi, lo][copy][sample]
   __shared__ uint4 ldsB[2][F16_CHUNK];           // [chunk counter & 1]
   constexpr int NCB = F16_CHUNK / 64;            // 1 KiB pieces of a B chunk
-  constexpr int NCA = 2 * (F16_ADW / 64);        // 256-byte pieces of the two sample arrays
+  constexpr int NCA = 2 * F16_NCOPY * (F16_ADW / 64);        // 256-byte pieces of the sample arrays
   const size_t cstride = lcs_cap8_stride(geo.n_cap);
   const uint32_t *caph = cap16h + (size_t)slot * cstride + lane, *capl = cap16l + (size_t)slot * cstride + lane;
   const int *smin_s = smin + (size_t)slot * NW * GM + g;
@@ -202,9 +233,9 @@ __global__ __launch_bounds__(256, 2) void k_xcorr_f16x3(const uint32_t *__restri
     _Pragma("unroll") for (int c_ = 0; c_ < (NCA + 3) / 4; ++c_) {                                           \
       const int ca_ = wave + 4 * c_;                                                                         \
       if (ca_ < NCA) {                                                                                       \
-        const int hl_ = ca_ / (F16_ADW / 64), k_ = ca_ % (F16_ADW / 64);                                     \
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)((hl_ ? capl : caph) + L0_ + 64 * k_), \
-                                         (__attribute__((address_space(3))) void *)(ldsA[(W) & 1][hl_] + 64 * k_), 4, 0, 0); \
+        const int hc_ = ca_ / (F16_ADW / 64), k_ = ca_ % (F16_ADW / 64), hl_ = hc_ / F16_NCOPY, cp_ = hc_ % F16_NCOPY; \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)((hl_ ? capl : caph) + L0_ + cp_ + 64 * k_), \
+                                         (__attribute__((address_space(3))) void *)(ldsA[(W) & 1][hl_][cp_] + 64 * k_), 4, 0, 0); \
       }                                                                                                      \
     }                                                                                                        \
   }
@@ -222,8 +253,17 @@ __global__ __launch_bounds__(256, 2) void k_xcorr_f16x3(const uint32_t *__restri
   // 16 bytes = 4 samples from a 4-byte aligned LDS address (the window starts at any sample)
   typedef unsigned int u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#if F16_A64
+  typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+  // two 8-byte reads per operand (relaxed wave-scope atomic loads compile to plain ds_read_b64 and are not merged into ds_read2_b64)
+#define F16_LD64(P) __hip_atomic_load(reinterpret_cast<const unsigned long long *>(P), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT)
+#define F16_RD_A(U) { const u64x2 th_ = {F16_LD64(bufAh + 16 * (U)), F16_LD64(bufAh + 16 * (U) + 2)};        \
+                      const u64x2 tl_ = {F16_LD64(bufAl + 16 * (U)), F16_LD64(bufAl + 16 * (U) + 2)};        \
+                      Ah[(U) % (F16_MT + 1)] = __builtin_bit_cast(h8, th_); Al[(U) % (F16_MT + 1)] = __builtin_bit_cast(h8, tl_); }
+#else
 #define F16_RD_A(U) { const u32x4 th_ = *reinterpret_cast<const u32x4_a4 *>(bufAh + 16 * (U)); const u32x4 tl_ = *reinterpret_cast<const u32x4_a4 *>(bufAl + 16 * (U)); \
                       Ah[(U) % (F16_MT + 1)] = __builtin_bit_cast(h8, th_); Al[(U) % (F16_MT + 1)] = __builtin_bit_cast(h8, tl_); }
+#endif
 
   F16_DMA_A(0);
   F16_DMA_B(0, 0, 0);
@@ -231,7 +271,8 @@ __global__ __launch_bounds__(256, 2) void k_xcorr_f16x3(const uint32_t *__restri
   for (int w = 0; w < geo.n_comb; ++w) {
     f32x4 aR[F16_MT], aI[F16_MT];
     h8 Ah[F16_MT + 1], Al[F16_MT + 1];        // operands u = kb .. kb + 7 of the current block, one slot ahead for the next
-    const uint32_t *bufAh = ldsA[w & 1][0] + p0, *bufAl = ldsA[w & 1][1] + p0;
+    const int par = F16_A64 ? (p0 & 1) : 0;       // the copy whose sample p0 sits at an even dword
+    const uint32_t *bufAh = ldsA[w & 1][0][par] + (p0 - par), *bufAl = ldsA[w & 1][1][par] + (p0 - par);
 #pragma unroll
     for (int c = 0; c < 2; ++c, ++cc) {
       __syncthreads();                        // this chunk's operands (and, at c == 0, the window's samples) have landed; the other buffers are free
@@ -289,16 +330,20 @@ __global__ __launch_bounds__(256, 2) void k_xcorr_f16x3(const uint32_t *__restri
 // d_src: the caller's complex<float> buffers (LCS_FMT_C64, device memory); replaces lcs_launch_ingest for these batches
 int lcs_launch_ingest_f16(lcs_ctx *c, const void *d_src, int n_buf, uint32_t n_cap) {
   c->src_u8 = false;
+  c->src32 = nullptr;
   HIPCHK(c, hipMemsetAsync(c->xmax16, 0, sizeof(unsigned) * n_buf, c->stream));
   if ((n_cap & 1u) == 0 && (reinterpret_cast<uintptr_t>(d_src) & 15u) == 0) {
-    hipLaunchKernelGGL(k_f16_copy_max, dim3(96, n_buf), dim3(256), 0, c->stream, static_cast<const float4 *>(d_src), n_cap,
-                       reinterpret_cast<float4 *>(c->cap32), c->xmax16);
+    // read in place: no copy into cap32; the fp64 stages read the caller's buffers (they stay valid until the batch is
+    // collected, include/lcs.h), the maximum is a read-only pass
+    c->src32 = static_cast<const float2 *>(d_src);
+    hipLaunchKernelGGL(k_f16_max4, dim3(40, n_buf), dim3(256), 0, c->stream, static_cast<const float4 *>(d_src), n_cap, c->xmax16);
+    hipLaunchKernelGGL((k_f16_ingest<true>), dim3(80, n_buf), dim3(256), 0, c->stream, c->src32, n_cap, c->xmax16, c->cap16h, c->cap16l);
   } else {
     int rc = lcs_launch_ingest(c, d_src, LCS_FMT_C64, n_buf, n_cap);
     if (rc) return rc;
     hipLaunchKernelGGL(k_f16_max, dim3(32, n_buf), dim3(256), 0, c->stream, c->cap32, n_cap, c->xmax16);
+    hipLaunchKernelGGL((k_f16_ingest<false>), dim3(64, n_buf), dim3(256), 0, c->stream, c->cap32, n_cap, c->xmax16, c->cap16h, c->cap16l);
   }
-  hipLaunchKernelGGL(k_f16_ingest, dim3(64, n_buf), dim3(256), 0, c->stream, c->cap32, n_cap, c->xmax16, c->cap16h, c->cap16l);
   HIPCHK(c, hipGetLastError());
   return LCS_OK;
 }
