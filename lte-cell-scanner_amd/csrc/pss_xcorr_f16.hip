@@ -37,13 +37,6 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 #define F16_AW (F16_LAGS + 16 * F16_NKB + 16)             // staged samples per window
 #define F16_ADW (((F16_AW + 63) / 64) * 64)               // dwords (= samples) per staged array: whole 64-dword LDS-DMA pieces
 #define F16_CHUNK (2 * F16_CH * 2 * 64)                   // uint4 per B chunk: [term hi / lo][kb][op][lane]
-// F16_A64: TWO staged copies of a window (shifted by 0 / 1 sample): a lane's 16-byte operand then starts 8-byte aligned in
-// the copy matching the parity of its first sample and is read with two ds_read_b64 instead of two ds_read2_b32
-#ifndef F16_A64
-#define F16_A64 0
-#endif
-#define F16_NCOPY (F16_A64 ? 2 : 1)
-#define F16_ACOPY (F16_ADW + (F16_A64 ? 32 : 0))          // copy stride: the two copies 32 banks apart
 #define F16_TARGET_EXP 9                                  // operands are scaled into [2^9, 2^10)
 
 __device__ __forceinline__ uint32_t f16_bits(_Float16 h) { return (uint32_t)__builtin_bit_cast(unsigned short, h); }
@@ -211,10 +204,10 @@ __global__ __launch_bounds__(256, 2) void k_xcorr_f16x3(const uint32_t *__restri
   const int slot = slot0 + sidx, g = q / F16_TILES, idx0 = (q % F16_TILES) * F16_LAGS;
   const int widx0 = idx0 + wave * (F16_MT * 16);
 
-  __shared__ __attribute__((aligned(16))) uint32_t ldsA[2][2][F16_NCOPY][F16_ACOPY];       // [window & 1][hi, lo][copy][sample]
+  __shared__ uint32_t ldsA[2][2][F16_ADW];       // [window & 1][hi, lo][sample]
   __shared__ uint4 ldsB[2][F16_CHUNK];           // [chunk counter & 1]
   constexpr int NCB = F16_CHUNK / 64;            // 1 KiB pieces of a B chunk
-  constexpr int NCA = 2 * F16_NCOPY * (F16_ADW / 64);        // 256-byte pieces of the sample arrays
+  constexpr int NCA = 2 * (F16_ADW / 64);        // 256-byte pieces of the two sample arrays
   const size_t cstride = lcs_cap8_stride(geo.n_cap);
   const uint32_t *caph = cap16h + (size_t)slot * cstride + lane, *capl = cap16l + (size_t)slot * cstride + lane;
   const int *smin_s = smin + (size_t)slot * NW * GM + g;
@@ -233,9 +226,9 @@ __global__ __launch_bounds__(256, 2) void k_xcorr_f16x3(const uint32_t *__restri
     _Pragma("unroll") for (int c_ = 0; c_ < (NCA + 3) / 4; ++c_) {                                           \
       const int ca_ = wave + 4 * c_;                                                                         \
       if (ca_ < NCA) {                                                                                       \
-        const int hc_ = ca_ / (F16_ADW / 64), k_ = ca_ % (F16_ADW / 64), hl_ = hc_ / F16_NCOPY, cp_ = hc_ % F16_NCOPY; \
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)((hl_ ? capl : caph) + L0_ + cp_ + 64 * k_), \
-                                         (__attribute__((address_space(3))) void *)(ldsA[(W) & 1][hl_][cp_] + 64 * k_), 4, 0, 0); \
+        const int hl_ = ca_ / (F16_ADW / 64), k_ = ca_ % (F16_ADW / 64);                                     \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)((hl_ ? capl : caph) + L0_ + 64 * k_), \
+                                         (__attribute__((address_space(3))) void *)(ldsA[(W) & 1][hl_] + 64 * k_), 4, 0, 0); \
       }                                                                                                      \
     }                                                                                                        \
   }
@@ -253,17 +246,8 @@ __global__ __launch_bounds__(256, 2) void k_xcorr_f16x3(const uint32_t *__restri
   // 16 bytes = 4 samples from a 4-byte aligned LDS address (the window starts at any sample)
   typedef unsigned int u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-#if F16_A64
-  typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
-  // two 8-byte reads per operand (relaxed wave-scope atomic loads compile to plain ds_read_b64 and are not merged into ds_read2_b64)
-#define F16_LD64(P) __hip_atomic_load(reinterpret_cast<const unsigned long long *>(P), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT)
-#define F16_RD_A(U) { const u64x2 th_ = {F16_LD64(bufAh + 16 * (U)), F16_LD64(bufAh + 16 * (U) + 2)};        \
-                      const u64x2 tl_ = {F16_LD64(bufAl + 16 * (U)), F16_LD64(bufAl + 16 * (U) + 2)};        \
-                      Ah[(U) % (F16_MT + 1)] = __builtin_bit_cast(h8, th_); Al[(U) % (F16_MT + 1)] = __builtin_bit_cast(h8, tl_); }
-#else
 #define F16_RD_A(U) { const u32x4 th_ = *reinterpret_cast<const u32x4_a4 *>(bufAh + 16 * (U)); const u32x4 tl_ = *reinterpret_cast<const u32x4_a4 *>(bufAl + 16 * (U)); \
                       Ah[(U) % (F16_MT + 1)] = __builtin_bit_cast(h8, th_); Al[(U) % (F16_MT + 1)] = __builtin_bit_cast(h8, tl_); }
-#endif
 
   F16_DMA_A(0);
   F16_DMA_B(0, 0, 0);
@@ -271,8 +255,7 @@ __global__ __launch_bounds__(256, 2) void k_xcorr_f16x3(const uint32_t *__restri
   for (int w = 0; w < geo.n_comb; ++w) {
     f32x4 aR[F16_MT], aI[F16_MT];
     h8 Ah[F16_MT + 1], Al[F16_MT + 1];        // operands u = kb .. kb + 7 of the current block, one slot ahead for the next
-    const int par = F16_A64 ? (p0 & 1) : 0;       // the copy whose sample p0 sits at an even dword
-    const uint32_t *bufAh = ldsA[w & 1][0][par] + (p0 - par), *bufAl = ldsA[w & 1][1][par] + (p0 - par);
+    const uint32_t *bufAh = ldsA[w & 1][0] + p0, *bufAl = ldsA[w & 1][1] + p0;
 #pragma unroll
     for (int c = 0; c < 2; ++c, ++cc) {
       __syncthreads();                        // this chunk's operands (and, at c == 0, the window's samples) have landed; the other buffers are free

@@ -39,10 +39,7 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 #ifndef I8_MT
 #define I8_MT 8                                          // 16-lag sub-tiles per wave
 #endif
-#ifndef I8_WAVES
-#define I8_WAVES 4                                       // waves per workgroup (they share the window's B operands in LDS)
-#endif
-#define I8_LAGS (I8_WAVES * I8_MT * 16)
+#define I8_LAGS (4 * I8_MT * 16)
 #define I8_TILES ((LCS_N_IDX + I8_LAGS - 1) / I8_LAGS)
 #define I8_NKB LCS_I8_KB                                  // 32-tap blocks per window: 137 taps + spread <= 160
 #define I8_AW (I8_LAGS + 32 * I8_NKB + 32)                // staged samples per window
@@ -51,13 +48,6 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 // (natural copy, banks 0..12 of a 32-lane group) and the odd-lag lanes (shifted copy) of one ds_read never meet
 // on a bank (with + 2 they did: SQ_LDS_BANK_CONFLICT = 16 % of the kernel's cycles)
 #define I8_ACOPY (I8_ADW + 16)
-// I8_A64: FOUR staged copies of a window (shifted by 0..3 samples) instead of two: every lane's 16-byte operand then starts
-// 8-byte aligned in the copy matching (its first sample) mod 4 and is read with two ds_read_b64 instead of two
-// ds_read2_b32 (tools/microbench/mfma_valu_coissue.hip: a ds_read2_b32 behind an MFMA costs ~10 x a ds_read_b64)
-#ifndef I8_A64
-#define I8_A64 0
-#endif
-#define I8_NCOPY (I8_A64 ? 4 : 2)
 #define I8_QMAX 8300000.0                                 // |T_int| bound: three balanced base-256 digits reach 8 355 711
 
 // Per template (slot, foi, t): q = I8_QMAX / max tap magnitude; sc = 1 / (128 q) converts the integer
@@ -170,10 +160,7 @@ __global__ __launch_bounds__(256) void k_fill_btab_i8(const float2 *__restrict__
 // Measured (isolated, 64 buffers, 16x16x64 issues every ~18 cycles: tools/microbench/mfma_rate.hip): the 15 tap
 // blocks of a window run at the MFMA issue rate (0.059 ms per block-launch); the rest is per-window and
 // per-workgroup cost (barrier, epilogue, prologue of each of the 15 workgroup rounds, last round 25 % full).
-#ifndef I8_KATTR
-#define I8_KATTR __launch_bounds__(64 * I8_WAVES, 2)
-#endif
-__global__ I8_KATTR void k_xcorr_i8x3(const uint16_t *__restrict__ cap8, const uint16_t *__restrict__ cap8s,
+__global__ __launch_bounds__(256, 2) void k_xcorr_i8x3(const uint16_t *__restrict__ cap8, const uint16_t *__restrict__ cap8s,
                                                           const int *__restrict__ smin, const uint4 *__restrict__ bt8,
                                                           const float *__restrict__ sc, float *__restrict__ sg, XcGeom geo,
                                                           int slot0, int n_slots, int xcd_map) {
@@ -186,11 +173,11 @@ __global__ I8_KATTR void k_xcorr_i8x3(const uint16_t *__restrict__ cap8, const u
   const int slot = slot0 + sidx, g = q / I8_TILES, idx0 = (q % I8_TILES) * I8_LAGS;
   const int widx0 = idx0 + wave * (I8_MT * 16);
 
-  __shared__ __attribute__((aligned(16))) uint32_t ldsA[2][I8_NCOPY][I8_ACOPY];
+  __shared__ uint32_t ldsA[2][2][I8_ACOPY];
   constexpr int NBLK = 3 * I8_NKB;
   constexpr int BW = NBLK * 2 * 64;       // uint4 per window (30 KB), table order [digit][kb][op][lane]
   constexpr int NCH = BW / 64;            // 1 KiB chunks: one global_load_lds_dwordx4 per wave each
-  constexpr int NCA = I8_NCOPY * (I8_ADW / 64);  // 256-byte chunks of the sample copies: one global_load_lds_dword per wave each
+  constexpr int NCA = 2 * (I8_ADW / 64);  // 256-byte chunks of the two sample copies: one global_load_lds_dword per wave each
   __shared__ uint4 ldsB[2][BW];
   const size_t cstride = lcs_cap8_stride(geo.n_cap);
   const uint32_t *capd = reinterpret_cast<const uint32_t *>(cap8 + (size_t)slot * cstride) + lane;     // dword j = samples (2j, 2j+1)
@@ -200,7 +187,7 @@ __global__ I8_KATTR void k_xcorr_i8x3(const uint16_t *__restrict__ cap8, const u
   const size_t bt_wstride = (size_t)geo.G * BW;
   const float my_sc = sc[(size_t)slot * GM * LCS_TG + g * LCS_TG + (lane & 15)];
   const int p0 = wave * (I8_MT * 16) + (lane & 15) + 8 * (lane >> 4);
-  const int par = p0 & (I8_NCOPY - 1);
+  const int par = p0 & 1;
   const int a_dw = (p0 - par) >> 1;
 
   f32x4 P[I8_MT];
@@ -210,35 +197,27 @@ __global__ I8_KATTR void k_xcorr_i8x3(const uint16_t *__restrict__ cap8, const u
   // one (L0 + 2i + 1, L0 + 2i + 2); an odd L0 swaps the roles of cap8 and cap8s
 #define I8_DMA(W)                                                                                            \
   {                                                                                                          \
-    const int L0_ = idx0 + smin_s[(W) * GM];                                                                 \
-    _Pragma("unroll") for (int c_ = 0; c_ < (NCA + I8_WAVES - 1) / I8_WAVES; ++c_) {                         \
-      const int ca_ = wave + I8_WAVES * c_;   /* chunk = (copy, 64-dword piece) */                           \
+    const int L0_ = idx0 + smin_s[(W) * GM], h_ = L0_ >> 1;                                                  \
+    const uint32_t *nat_ = ((L0_ & 1) ? capsd : capd) + h_;                                                  \
+    const uint32_t *shf_ = (L0_ & 1) ? capd + h_ + 1 : capsd + h_;                                           \
+    _Pragma("unroll") for (int c_ = 0; c_ < (NCA + 3) / 4; ++c_) {                                           \
+      const int ca_ = wave + 4 * c_;          /* chunk = (copy, 64-dword piece) */                           \
       if (ca_ < NCA) {                                                                                       \
         const int cp_ = ca_ / (I8_ADW / 64), k_ = ca_ % (I8_ADW / 64);                                       \
-        const int Ls_ = L0_ + cp_;            /* copy cp_ starts at sample L0 + cp_: dword aligned in cap8 or in cap8s */ \
-        const uint32_t *src_a_ = ((Ls_ & 1) ? capsd : capd) + (Ls_ >> 1);                                    \
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src_a_ + 64 * k_), \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)((cp_ ? shf_ : nat_) + 64 * k_), \
                                          (__attribute__((address_space(3))) void *)(ldsA[(W) & 1][cp_] + 64 * k_), 4, 0, 0); \
       }                                                                                                      \
     }                                                                                                        \
     uint4 *dst_ = ldsB[(W) & 1];                                                                             \
     const uint4 *src_ = bt_s + (size_t)(W) * bt_wstride;                                                     \
-    _Pragma("unroll") for (int c_ = 0; c_ < (NCH + I8_WAVES - 1) / I8_WAVES; ++c_) {                         \
-      const int ch_ = wave + I8_WAVES * c_;   /* chunk = (digit, kb, op) in table order */                   \
+    _Pragma("unroll") for (int c_ = 0; c_ < (NCH + 3) / 4; ++c_) {                                           \
+      const int ch_ = wave + 4 * c_;          /* chunk = (digit, kb, op) in table order */                   \
       if (ch_ < NCH)                                                                                         \
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src_ + ch_ * 64),  \
                                          (__attribute__((address_space(3))) void *)(dst_ + ch_ * 64), 16, 0, 0); \
     }                                                                                                        \
   }
-#if I8_A64
-  // two 8-byte reads (relaxed wave-scope atomic loads compile to plain ds_read_b64 and are not merged into ds_read2_b64)
-#define I8_RD_A(S) { const unsigned long long *p_ = reinterpret_cast<const unsigned long long *>(bufA + 8 * (S));      \
-                     const unsigned long long lo_ = __hip_atomic_load(p_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); \
-                     const unsigned long long hi_ = __hip_atomic_load(p_ + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); \
-                     Aw[S] = (i32x4){(int)(unsigned)lo_, (int)(unsigned)(lo_ >> 32), (int)(unsigned)hi_, (int)(unsigned)(hi_ >> 32)}; }
-#else
 #define I8_RD_A(S) { const uint32_t *p_ = bufA + 8 * (S); Aw[S] = (i32x4){(int)p_[0], (int)p_[1], (int)p_[2], (int)p_[3]}; }
-#endif
 #define I8_RD_B(E, Q)                                                                                        \
   {                                                                                                          \
     constexpr int d_ = (E) / I8_NKB, j_ = (E) % I8_NKB, kb_ = (d_ == 1) ? I8_NKB - 1 - j_ : j_;              \
@@ -345,11 +324,11 @@ int lcs_launch_fill_btab_i8(lcs_ctx *c, int n_buf, const XcGeom &geo) {
 }
 int lcs_launch_xcorr_i8(lcs_ctx *c, hipStream_t sxc, const XcGeom &geo, int slot0, int n_slots, int xcd_map) {
   const unsigned grid = (unsigned)(I8_TILES * geo.G * n_slots);
-  hipLaunchKernelGGL(k_xcorr_i8x3, dim3(grid), dim3(64 * I8_WAVES), 0, sxc, c->cap8, c->cap8s, c->smin, c->bt8, c->tsc, c->single, geo, slot0,
+  hipLaunchKernelGGL(k_xcorr_i8x3, dim3(grid), dim3(256), 0, sxc, c->cap8, c->cap8s, c->smin, c->bt8, c->tsc, c->single, geo, slot0,
                      n_slots, xcd_map);
   HIPCHK(c, hipGetLastError());
   // executed work: per wave and window 3 digits x I8_NKB tap blocks x I8_MT sub-tiles x (re, im) MFMAs of 16x16x64 MACs
-  c->last_xc_ops += (double)grid * I8_WAVES * geo.n_comb * (3.0 * I8_NKB * I8_MT * 2) * (2.0 * 16 * 16 * 64);
+  c->last_xc_ops += (double)grid * 4 * geo.n_comb * (3.0 * I8_NKB * I8_MT * 2) * (2.0 * 16 * 16 * 64);
   c->last_xc_kernel = "k_xcorr_i8x3";
   return LCS_OK;
 }
