@@ -89,10 +89,10 @@ const char *lcs_last_error(const lcs_ctx *ctx);
 const char *lcs_version(void);
 void lcs_cell_init(lcs_cell *c);                      /* src/common.cpp:36-56 */
 /* Memory-footprint limit: the per-cell stages (time-frequency grid, channel estimate, PBCH) hold at most n
- * detected cells at a time (default and maximum 512, ~6 MB each); a batch with more cells is processed in
- * rounds: lcs_batch_enqueue launches the rounds a typical batch needs (one detected cell per buffer on average),
- * lcs_batch_collect launches the rest if the device-side count says the batch had more.  Results do not depend
- * on it and no batch is truncated. */
+ * detected cells at a time (default and maximum 1024, ~6 MB each, allocated on first use); a batch with more cells is
+ * processed in rounds: lcs_batch_enqueue launches the rounds the PREVIOUS batch of the context needed (at least one
+ * detected cell per buffer), lcs_batch_collect launches the rest if the device-side count says the batch had more.
+ * Results do not depend on it and no batch is truncated. */
 int lcs_set_max_cells_in_flight(lcs_ctx *ctx, int n);
 
 /* ---- stage entry points (host buffers in / out) ------------------------------------ */

@@ -306,7 +306,7 @@ class Searcher:
 
     # ---- LTE-Tracker's per-symbol pipeline on a block of symbols (src/tracker_thread.cpp:823-1068) ----
     def track_block(self, cells, td, freq_off, frame_timing, late, fc_requested, fc_programmed, fs_programmed,
-                    want_syms=True, want_ce=True, td_device_ptr=None, n_sym=None):
+                    want_syms=True, want_ce=True, td_device_ptr=None, n_sym=None, out=None):
         """cells: list of searcher records (LcsCell with n_id_1/2, cp_type, n_ports, n_rb_dl, PHICH fields) or LcsTrackCell;
         td [n_cells][n_sym][128] complex128 (or a device pointer via td_device_ptr + n_sym); the metadata arrays are
         [n_cells][n_sym].  Returns a dict (see lcs_track_block in include/lcs.h); 'bpo' = bulk phase after the block."""
@@ -326,12 +326,16 @@ class Searcher:
         else:
             tdp, on_dev = C.c_void_p(td_device_ptr), 1
         max_rs, max_off = n_sym // 3 + 4, max(1, n_sym // 120 - 3)
-        out = dict(syms=np.empty((n_cells, n_sym, 72), np.complex128) if want_syms else None,
-                   ce=np.full((n_cells, 4, n_sym, 72), np.nan + 0j, np.complex128) if want_ce else None,
-                   ce_pw=np.full((n_cells, 4, n_sym, 4), np.nan) if want_ce else None,
-                   ce_upto=np.zeros((n_cells, 4), np.int32), meas=np.full((n_cells, 4, max_rs, 9), np.nan),
-                   n_meas=np.zeros((n_cells, 4), np.int32), mib_ok=np.full((n_cells, max_off), -1, np.int32),
-                   mib_bits=np.zeros((n_cells, max_off), np.uint64))
+        if out is not None:      # a dict this method returned for the same block shape: its arrays are reused (rows beyond n_meas keep old values)
+            assert out["meas"].shape == (n_cells, 4, max_rs, 9) and out["mib_ok"].shape == (n_cells, max_off)
+            assert (out["syms"] is not None) == bool(want_syms) and (out["ce"] is not None) == bool(want_ce)
+        else:
+            out = dict(syms=np.empty((n_cells, n_sym, 72), np.complex128) if want_syms else None,
+                       ce=np.full((n_cells, 4, n_sym, 72), np.nan + 0j, np.complex128) if want_ce else None,
+                       ce_pw=np.full((n_cells, 4, n_sym, 4), np.nan) if want_ce else None,
+                       ce_upto=np.zeros((n_cells, 4), np.int32), meas=np.full((n_cells, 4, max_rs, 9), np.nan),
+                       n_meas=np.zeros((n_cells, 4), np.int32), mib_ok=np.full((n_cells, max_off), -1, np.int32),
+                       mib_bits=np.zeros((n_cells, max_off), np.uint64))
         ms = C.c_float(0)
         rc = self._lib.lcs_track_block(self._h, tc, n_cells, n_sym, tdp, on_dev, _dp(fo), _dp(ft), _dp(lt), fc_requested, fc_programmed,
                                        fs_programmed, _dp(out["syms"]), _dp(out["ce"]), _dp(out["ce_pw"]), _ip(out["ce_upto"]),

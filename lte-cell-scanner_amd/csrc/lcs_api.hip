@@ -320,6 +320,7 @@ void lcs_destroy(lcs_ctx *c) {
                   c->trk_syncce, c->trk_sync, c->d_flag};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+  if (c->trk_hpin) (void)hipHostFree(c->trk_hpin);
   for (int k = 0; k < 2; ++k) {
     if (c->h_stage[k]) (void)hipHostFree(c->h_stage[k]);
     if (c->ev_stage[k]) (void)hipEventDestroy(c->ev_stage[k]);
@@ -467,8 +468,14 @@ int lcs_batch_enqueue(lcs_ctx *c, const void *d_capbufs, int fmt, int n_buf, uin
     // count says the batch had more, so no batch overflows and sparse batches pay for no empty rounds.
     c->needed_rows_only = true;
     c->round_cells = c->max_work;          // fixed for this batch: lcs_set_max_cells_in_flight applies from the next one
-    c->grid_items = std::min(c->round_cells, std::max(64, n_buf / 2));
-    const int rounds = (n_buf + c->round_cells - 1) / c->round_cells;
+    // Round 4: the batch before is the predictor.  A busy band carries 4-5 cells per buffer past SSS: with the rounds and
+    // the per-cell grids sized for one cell per buffer, every such batch needed a second round launched from
+    // lcs_batch_collect (a host round trip in the middle of the pipeline) and every workgroup walked ~8 cells one after
+    // the other.  A wrong guess costs time only: the kernels loop over whatever the list holds, and collect still
+    // launches missing rounds.
+    const int expect = std::max(n_buf, c->work_hint + c->work_hint / 4);
+    c->grid_items = std::min(c->round_cells, std::max(64, std::max(n_buf / 2, c->work_hint + c->work_hint / 8)));
+    const int rounds = std::min(8, (expect + c->round_cells - 1) / c->round_cells);
     for (int r = 0; r < rounds; ++r)
       if ((rc = percell_round(c, n_buf, n_cap, r))) return rc;
     c->last_cell_rounds = rounds;
@@ -491,6 +498,7 @@ int lcs_batch_collect(lcs_ctx *c, lcs_cell *cells, int max_cells_per_buf, int *n
   if (full) HIPCHK(c, hipMemcpyAsync(work_cnt, c->n_work, sizeof(work_cnt), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   int rc = LCS_OK;
+  if (full) c->work_hint = work_cnt[1];
   if (full && work_cnt[1] > c->last_cell_rounds * c->round_cells) {
     // more cells passed SSS than the enqueued rounds decode: run the remaining rounds now (rare: dense batches)
     const int rounds = (work_cnt[1] + c->round_cells - 1) / c->round_cells;

@@ -34,7 +34,7 @@
 #define LCS_PS 336           // LDS plane stride in floats: >= 64 + 2*KP2_MAX, == 16 (mod 32)
 #define LCS_MAXP 64          // peaks kept per capture buffer
 #define LCS_I8_KB 5          // 32-tap blocks of the int8 correlation kernel: taps + window-start spread <= 160
-#define LCS_MAX_WORK 512     // cells carried into the TFG/MIB stages per batch
+#define LCS_MAX_WORK 1024    // cells carried into the TFG/MIB stages per round (~6 MB each: 6 GB per context, allocated on first use)
 // grid sizes of the work-list kernels (every one loops over its list, so these only trade latency for workgroups)
 #define LCS_WIN_GRID 4096
 #define LCS_ITEM_GRID 1024
@@ -218,6 +218,8 @@ struct lcs_ctx {
   double *trk_sync = nullptr;
   int trk_stat_cells = 0, trk_stat_sym = 0;
   void *trk_stream = nullptr;        // carried state of lcs_track_stream_block (tracker.hip)
+  void *trk_hpin = nullptr;          // page-locked staging of lcs_track_block: metadata up, measurement tables down
+  size_t trk_hpin_bytes = 0;
   // host staging
   SlotParams h_params{};             // source of asynchronous parameter uploads of the single-buffer entry points
   void *h_pinned = nullptr;
@@ -235,6 +237,7 @@ struct lcs_ctx {
   int last_cell_rounds = 0;          // per-cell rounds launched for the last batch (round_cells cells each)
   int round_cells = LCS_MAX_WORK;    // max_work as it was when the last batch was enqueued
   int grid_items = 64;               // workgroups per work-list axis of the per-cell kernels (they loop over the list)
+  int work_hint = 0;                 // cells the last collected batch carried into the per-cell stages: sizes the next batch's rounds and grids
   XcGeom last_geo{};
   XcGeom foe_geo{};                  // lcs_foe_partial -> lcs_foe_finish: this rank's share of the hypotheses
   bool foe_ready = false;

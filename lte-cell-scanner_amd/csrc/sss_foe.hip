@@ -26,6 +26,8 @@
 
 struct cd2 { double re, im; };
 __device__ __forceinline__ cd2 mk(double a, double b) { cd2 r; r.re = a; r.im = b; return r; }
+// exp(j x): one sincos call (one argument reduction; cos(x) and sin(x) as two calls cost 1.8 x the instructions)
+__device__ __forceinline__ cd2 cis(double x) { double s_, c_; sincos(x, &s_, &c_); return mk(c_, s_); }
 __device__ __forceinline__ cd2 cadd(cd2 a, cd2 b) { return mk(a.re + b.re, a.im + b.im); }
 __device__ __forceinline__ cd2 csub(cd2 a, cd2 b) { return mk(a.re - b.re, a.im - b.im); }
 __device__ __forceinline__ cd2 cmul(cd2 a, cd2 b) { return mk(a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re); }
@@ -69,13 +71,31 @@ __device__ __forceinline__ cd2 stage_sample(const CapView &cap, uint32_t n_cap, 
   return cmul(v, mk(cs, sn));
 }
 
-// One of the 62 PSS/SSS bins [97..127, 1..31] of a staged window, /sqrt(128) (ref :527-529); the
-// sum runs over n ascending.
-__device__ __forceinline__ cd2 dft62_bin(const cd2 *W, const cd2 *win, int bin_idx) {
+// 128-point transform of one staged window by ONE wave, in place (decimation in frequency: natural order in,
+// bit-reversed order out), one butterfly per lane and stage; tw[stg] = this lane's twiddle of stage stg, held in registers
+// (fft_twiddles).  Rounds 1-3 summed each of the 62 wanted bins directly (128 terms per bin, twiddles gathered from LDS at
+// strides that collide on the banks): 10 x the operations of the 7 stages.  No other wave touches the window and a wave's
+// LDS accesses execute in program order, so no workgroup barrier is needed between the stages.
+__device__ __forceinline__ void fft_twiddles(const cd2 *W, int lane, cd2 (&tw)[7]) {
+#pragma unroll
+  for (int stg = 0; stg < 7; ++stg) tw[stg] = W[(lane & ((64 >> stg) - 1)) << stg];
+}
+__device__ __forceinline__ void fft128_wave(cd2 *x, const cd2 (&tw)[7], int lane) {
+#pragma unroll
+  for (int stg = 0; stg < 7; ++stg) {
+    const int half = 64 >> stg;
+    const int pos = lane & (half - 1);
+    const int i0 = ((lane >> (6 - stg)) << (7 - stg)) + pos, i1 = i0 + half;
+    const cd2 a = x[i0], b = x[i1];
+    x[i0] = cadd(a, b);
+    x[i1] = cmul(csub(a, b), tw[stg]);
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+// One of the 62 PSS/SSS bins [97..127, 1..31] of a transformed window, /sqrt(128) (ref :527-529)
+__device__ __forceinline__ cd2 fft62_bin(const cd2 *x, int bin_idx) {
   const int bin = (bin_idx < 31) ? 97 + bin_idx : bin_idx - 30;
-  cd2 acc = mk(0, 0);
-  for (int n = 0; n < 128; ++n) acc = cadd(acc, cmul(win[n], W[(bin * n) & 127]));
-  return cdivr(acc, sqrt(128.0));
+  return cdivr(x[__brev((unsigned)bin) >> 25], sqrt(128.0));
 }
 
 // h_raw -> h_sm (13-tap mean, ref :584-588) for subcarrier t
@@ -172,6 +192,9 @@ __global__ __launch_bounds__(SW_THREADS) void k_sss_win(const lcs_cell *__restri
   __shared__ cd2 h_raw[62], h_sm[62];
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
   fill_twiddles(W, tid);
+  __syncthreads();
+  cd2 tw[7];
+  fft_twiddles(W, lane, tw);
   // the work list: numbered here from the per-buffer counts; workgroup 0 also writes it out for the kernels that follow
   if (blockIdx.x == 0 && w == 0) peak_list_write(npeaks, n_buf, items, n_items, lane);
   const int n_jobs = peak_total(npeaks, n_buf, lane) * MAX_HF;
@@ -193,9 +216,10 @@ __global__ __launch_bounds__(SW_THREADS) void k_sss_win(const lcs_cell *__restri
       win[w][lane] = stage_sample(cap, n_cap, loc, g.kph, lane);
       win[w][lane + 64] = stage_sample(cap, n_cap, loc, g.kph, lane + 64);
     }
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();          // wave w staged window w itself
+    fft128_wave(win[w], tw, lane);
     if (lane < 62) {
-      const cd2 o = dft62_bin(W, win[w], lane);
+      const cd2 o = fft62_bin(win[w], lane);
       if (w == 0) { const double2 f = pss_fd[cell.n_id_2 * 62 + lane]; h_raw[lane] = cmul(o, mk(f.x, -f.y)); }
       else { rec[(w == 1 ? SW_EXT : SW_NRM) + 2 * lane] = o.re; rec[(w == 1 ? SW_EXT : SW_NRM) + 2 * lane + 1] = o.im; }
     }
@@ -272,7 +296,7 @@ __global__ __launch_bounds__(SF_THREADS) void k_sss_ml(lcs_cell *__restrict__ pe
         acc = cadd(acc, cmul(cconj(est[i]), mk(tv, 0)));
       }
       const double ang = atan2(acc.im, acc.re);
-      const cd2 rot = mk(cos(-ang), sin(-ang));
+      const cd2 rot = cis(-ang);
       double s1 = 0, s2 = 0;
       for (int i = 0; i < 124; ++i) {      // the two sums of ref :649 keep their own order; x/np as x*(1/np)
         const double tv = (double)(i < 62 ? first[i] : second[i - 62]);
@@ -378,6 +402,9 @@ __global__ __launch_bounds__(FW_THREADS) void k_foe_win(const lcs_cell *__restri
   __shared__ cd2 h_raw[62], h_sm[62], aux[62];
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
   fill_twiddles(W, tid);
+  __syncthreads();
+  cd2 tw[7];
+  fft_twiddles(W, lane, tw);
   const int n_jobs = *n_items * MAX_HF;
   for (int job = blockIdx.x; job < n_jobs; job += gridDim.x) {
     const int it = job / MAX_HF, k = job % MAX_HF;
@@ -395,9 +422,10 @@ __global__ __launch_bounds__(FW_THREADS) void k_foe_win(const lcs_cell *__restri
       win[w][lane] = stage_sample(cap, n_cap, loc, g.kph, lane);
       win[w][lane + 64] = stage_sample(cap, n_cap, loc, g.kph, lane + 64);
     }
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();          // wave w staged window w itself
+    fft128_wave(win[w], tw, lane);
     if (lane < 62) {
-      const cd2 o = dft62_bin(W, win[w], lane);
+      const cd2 o = fft62_bin(win[w], lane);
       if (w == 0) { const double2 f = pss_fd[cell.n_id_2 * 62 + lane]; h_raw[lane] = cmul(o, mk(f.x, -f.y)); }
       else {
         // exp(J*pi*-freq/(FS_LTE/16/2)*-pss_sss_dist), evaluated left to right (ref :832)
@@ -405,7 +433,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_foe_win(const lcs_cell *__restri
         ph_im = ph_im * (-cell.freq);
         ph_im = ph_im / (FS_LTE / 16 / 2);
         ph_im = ph_im * (double)(-g.pss_sss_dist);
-        const cd2 ph = mk(cos(ph_im), sin(ph_im));
+        const cd2 ph = cis(ph_im);
         // the slot number toggles with every occurrence, starting from sn_init (ref :800, :813)
         const int sn = ((k & 1) == 0) ? g.sn_init : 10 - g.sn_init;
         const double sf = (double)sss_fd[((cell.n_id_1 * 3 + cell.n_id_2) * 2 + (sn != 0)) * 62 + lane];

@@ -187,6 +187,13 @@ __global__ __launch_bounds__(TFG_THREADS) void k_tfg(const lcs_cell *__restrict_
   __shared__ int s_loc[TFG_SYM], s_row[TFG_SYM];
   const int tid = threadIdx.x;
   if (tid < 128) { double s, c; sincospi((double)tid / 64.0, &s, &c); W[tid] = mk(c, -s); }
+  __syncthreads();
+  // the seven twiddles of this lane's butterflies, in registers for every job (read per stage from the LDS table their
+  // power-of-two strides put up to 16 lanes of a group on one bank: the 3.2 conflict cycles per LDS instruction of
+  // profiles/r03/pmc_summary.json)
+  cd2 twr[7];
+#pragma unroll
+  for (int stg = 0; stg < 7; ++stg) twr[stg] = W[((tid & 63) & ((64 >> stg) - 1)) << stg];
   const int nw = *n_work;
   // a job = 8 consecutive rows (full grid), or the needed rows of one slot pair (at most 5 + 3)
   const int jobs_per_item = needed_only ? 61 : (ROWS + TFG_SYM - 1) / TFG_SYM;
@@ -243,7 +250,7 @@ __global__ __launch_bounds__(TFG_THREADS) void k_tfg(const lcs_cell *__restrict_
         const int half = 64 >> stg;
         const int pos = lane & (half - 1);
         const int i0 = ((lane >> (6 - stg)) << (7 - stg)) + pos, i1 = i0 + half;
-        const cd2 tw = W[pos << stg];
+        const cd2 tw = twr[stg];
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
           cd2 *x = win[wv + 4 * pass];
@@ -251,8 +258,12 @@ __global__ __launch_bounds__(TFG_THREADS) void k_tfg(const lcs_cell *__restrict_
           x[i0] = cadd(a, b);
           x[i1] = cmul(csub(a, b), tw);
         }
-        __syncthreads();
+        // wave wv owns windows wv and wv + 4 through all seven stages: no other wave touches them, and one wave's LDS
+        // accesses execute in program order -- a workgroup barrier per stage (round 3) only made the four waves wait for
+        // each other seven times per job
+        __builtin_amdgcn_wave_barrier();
       }
+      __syncthreads();                        // the output pass below reads every wave's windows
       for (int e = tid; e < TFG_SYM * NSC; e += TFG_THREADS) {
         const int sidx = e / NSC, i = e % NSC;
         const int t = s_row[sidx];
@@ -264,7 +275,7 @@ __global__ __launch_bounds__(TFG_THREADS) void k_tfg(const lcs_cell *__restrict_
         double k_im = -1.0;
         k_im = k_im * 2; k_im = k_im * M_PI; k_im = k_im * late; k_im = k_im / 128;
         const double ph = k_im * (double)cn_of(i);
-        a = cmul(a, mk(cos(ph), sin(ph)));
+        a = cmul(a, cis(ph));
         st(&tfg[((size_t)it * ROWS + t) * NSC + i], a);
       }
       PH(32);
@@ -295,7 +306,7 @@ __device__ __forceinline__ cd2 foc_row_rot(double ts_t, double k_res, double res
   const double tc = k_res * ts_t;
   double a_im = 1.0;
   a_im = a_im * 2; a_im = a_im * M_PI; a_im = a_im * (-residual_f); a_im = a_im * tc; a_im = a_im / (FS_LTE / 16);
-  return mk(cos(a_im), sin(a_im));
+  return cis(a_im);
 }
 __device__ __forceinline__ cd2 foc_value(const double2 *g, int t, int i, double ts_t, double k_res, cd2 rot_f) {
   const double tc = k_res * ts_t;
@@ -304,7 +315,7 @@ __device__ __forceinline__ cd2 foc_value(const double2 *g, int t, int i, double 
   k_im = k_im * 2; k_im = k_im * M_PI; k_im = k_im * late; k_im = k_im / 128;
   const double ph = k_im * (double)cn_of(i);
   const cd2 v = cmul(ld(&g[(size_t)t * NSC + i]), rot_f);
-  return cmul(v, mk(cos(ph), sin(ph)));
+  return cmul(v, cis(ph));
 }
 
 #define TF_THREADS 256
@@ -406,7 +417,7 @@ __device__ __forceinline__ cd2 toc_subcarrier_rot(double delay, int i) {
   double k_im = 1.0;
   k_im = k_im * 2; k_im = k_im * M_PI; k_im = k_im / 128; k_im = k_im * delay;
   const double ph = k_im * (double)cn_of(i);
-  return mk(cos(ph), sin(ph));
+  return cis(ph);
 }
 
 #define TFA_ROWS 8

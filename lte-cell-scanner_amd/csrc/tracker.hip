@@ -91,7 +91,7 @@ __global__ __launch_bounds__(64 * TRK_FD_SYM) void k_trk_fd(const lcs_track_cell
     for (int h = 0; h < 2; ++h) {
       const int t = lane + 64 * h;
       const double2 x = src[t];
-      const cd2 v = cmul(mk(x.x, x.y), mk(cos(k * t), sin(k * t)));
+      const cd2 v = cmul(mk(x.x, x.y), cis(k * t));
       win[wv][(t + 126) & 127] = v;                                                 // remove the 2 sample delay (:128-134)
     }
   }
@@ -113,13 +113,13 @@ __global__ __launch_bounds__(64 * TRK_FD_SYM) void k_trk_fd(const lcs_track_cell
   (void)c;
   const double kl = 2 * M_PI * late[(size_t)cell * n_sym + i] / 128;
   const double b = bpo[(size_t)cell * n_sym + i];
-  const cd2 bpo_coeff = mk(cos(b), sin(b));
+  const cd2 bpo_coeff = cis(b);
   for (int j = lane; j < 72; j += 64) {
     const int bin = (j < 36) ? 92 + j : j - 35;                                     // :138-141
     cd2 a = cdivr(win[wv][__brev((unsigned)bin) >> 25], sqrt(128.0));
     const int t = (j >= 36) ? j - 35 : 36 - j;
     const double phase = -kl * t;
-    cd2 coeff = mk(cos(phase), sin(phase));
+    cd2 coeff = cis(phase);
     if (j < 36) coeff.im = -coeff.im;
     a = cmul(a, cmul(bpo_coeff, coeff));                                            // :158-165
     st(&syms[((size_t)cell * n_sym + i) * 72 + j], a);
@@ -504,11 +504,30 @@ extern "C" int lcs_track_block(lcs_ctx *c, lcs_track_cell *cells, int n_cells, i
   double *d_fm = L.d_fm, *d_meas = L.d_meas;
   unsigned long long *d_mibbits = L.d_mibbits;
   const double2 *d_td = td_on_device ? (const double2 *)td : c->trk_td;
+  // Page-locked staging (round 4): the three metadata arrays go up as ONE copy (d_fo, d_ft, d_late are adjacent in
+  // trk_meta), the measurement tables come down into the same block -- pageable copies of these 8 MB and the zero-filled
+  // vectors they landed in were most of the 2 ms of host time a 64-cell block cost next to 1.15 ms of GPU time.
+  const size_t n_meas_d = C4 * rs_cap * TRK_MEAS, n_small = C4 * 2 + (size_t)n_cells * n_off, n_bits = (size_t)n_cells * n_off + 1;
+  const size_t up_bytes = sizeof(double) * 3 * N + sizeof(lcs_track_cell) * n_cells;
+  const size_t down_bytes = sizeof(double) * n_meas_d + sizeof(unsigned long long) * n_bits + sizeof(int) * n_small + sizeof(lcs_track_cell) * n_cells;
+  if (up_bytes + down_bytes + 64 > c->trk_hpin_bytes) {
+    if (c->trk_hpin) { HIPCHK(c, hipStreamSynchronize(c->stream)); (void)hipHostFree(c->trk_hpin); c->trk_hpin = nullptr; c->trk_hpin_bytes = 0; }
+    HIPCHK(c, hipHostMalloc(&c->trk_hpin, up_bytes + down_bytes + 64, hipHostMallocDefault));
+    c->trk_hpin_bytes = up_bytes + down_bytes + 64;
+  }
+  double *h_up = static_cast<double *>(c->trk_hpin);
+  lcs_track_cell *h_cells_up = reinterpret_cast<lcs_track_cell *>(h_up + 3 * N);
+  double *h_meas = reinterpret_cast<double *>(static_cast<char *>(c->trk_hpin) + ((up_bytes + 15) & ~(size_t)15));
+  unsigned long long *h_bits = reinterpret_cast<unsigned long long *>(h_meas + n_meas_d);
+  int *h_small = reinterpret_cast<int *>(h_bits + n_bits);
+  lcs_track_cell *h_cells_down = reinterpret_cast<lcs_track_cell *>(h_small + ((n_small + 1) & ~(size_t)1));
+  std::memcpy(h_up, freq_off, sizeof(double) * N);
+  std::memcpy(h_up + N, frame_timing, sizeof(double) * N);
+  std::memcpy(h_up + 2 * N, late, sizeof(double) * N);
+  std::memcpy(h_cells_up, cells, sizeof(lcs_track_cell) * n_cells);
   if (!td_on_device) HIPCHK(c, hipMemcpyAsync(c->trk_td, td, sizeof(double2) * N * 128, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(d_fo, freq_off, sizeof(double) * N, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(d_ft, frame_timing, sizeof(double) * N, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(d_late, late, sizeof(double) * N, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->trk_cells, cells, sizeof(lcs_track_cell) * n_cells, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d_fo, h_up, sizeof(double) * 3 * N, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->trk_cells, h_cells_up, sizeof(lcs_track_cell) * n_cells, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipEventRecord(c->ev_xc0, c->stream));
   hipLaunchKernelGGL(k_trk_prep, dim3(n_cells), dim3(128), 0, c->stream, c->trk_cells, n_sym, d_fo, c->d_pn_jump, d_rs, d_shift, d_bpo, d_idx,
                      d_nrs, rs_cap);
@@ -523,17 +542,15 @@ extern "C" int lcs_track_block(lcs_ctx *c, lcs_track_cell *cells, int n_cells, i
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipEventRecord(c->ev_xc1, c->stream));
   // results
-  HIPCHK(c, hipMemcpyAsync(cells, c->trk_cells, sizeof(lcs_track_cell) * n_cells, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(h_cells_down, c->trk_cells, sizeof(lcs_track_cell) * n_cells, hipMemcpyDeviceToHost, c->stream));
   if (syms) HIPCHK(c, hipMemcpyAsync(syms, c->trk_syms, sizeof(double2) * N * 72, hipMemcpyDeviceToHost, c->stream));
   if (ce) HIPCHK(c, hipMemcpyAsync(ce, c->trk_ce, sizeof(double2) * C4 * n_sym * 72, hipMemcpyDeviceToHost, c->stream));
   if (ce_pw) HIPCHK(c, hipMemcpyAsync(ce_pw, c->trk_pw, sizeof(double) * C4 * n_sym * 4, hipMemcpyDeviceToHost, c->stream));
-  std::vector<double> h_meas(C4 * rs_cap * TRK_MEAS);
-  std::vector<int> h_small(C4 * 2 + (size_t)n_cells * n_off);
-  std::vector<unsigned long long> h_bits((size_t)n_cells * n_off + 1);
-  HIPCHK(c, hipMemcpyAsync(h_meas.data(), d_meas, sizeof(double) * h_meas.size(), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipMemcpyAsync(h_small.data(), c->trk_small, sizeof(int) * h_small.size(), hipMemcpyDeviceToHost, c->stream));
-  if (n_off > 0) HIPCHK(c, hipMemcpyAsync(h_bits.data(), d_mibbits, sizeof(unsigned long long) * n_cells * n_off, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(h_meas, d_meas, sizeof(double) * n_meas_d, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(h_small, c->trk_small, sizeof(int) * n_small, hipMemcpyDeviceToHost, c->stream));
+  if (n_off > 0) HIPCHK(c, hipMemcpyAsync(h_bits, d_mibbits, sizeof(unsigned long long) * n_cells * n_off, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  std::memcpy(cells, h_cells_down, sizeof(lcs_track_cell) * n_cells);
   if (gpu_ms) HIPCHK(c, hipEventElapsedTime(gpu_ms, c->ev_xc0, c->ev_xc1));
   rc = LCS_OK;
   for (size_t q = 0; q < C4; ++q) {
@@ -541,7 +558,7 @@ extern "C" int lcs_track_block(lcs_ctx *c, lcs_track_cell *cells, int n_cells, i
     if (n_meas) n_meas[q] = std::min(nm, max_rs);
     if (nm > max_rs) rc = LCS_ERR_OVERFLOW;
     if (ce_upto) ce_upto[q] = h_small[C4 + q];
-    if (meas) for (int r = 0; r < std::min(nm, max_rs); ++r) std::memcpy(meas + (q * max_rs + r) * TRK_MEAS, &h_meas[(q * rs_cap + r) * TRK_MEAS], sizeof(double) * TRK_MEAS);
+    if (meas && nm > 0) std::memcpy(meas + q * (size_t)max_rs * TRK_MEAS, h_meas + q * (size_t)rs_cap * TRK_MEAS, sizeof(double) * TRK_MEAS * std::min(nm, max_rs));
   }
   for (int i = 0; i < n_cells; ++i)
     for (int o = 0; o < max_off; ++o) {

@@ -124,7 +124,12 @@ def test_per_cell_rounds_and_overflow(S, pkg, synth_buf):
     with pkg.Searcher(0) as S3:
         S3.set_max_cells_in_flight(3)
         res = S3.search_batch(d.data_ptr(), pkg.FMT_IQ_U8, len(order), 153600, f, FC, FC, FS, pkg.STAGE_FULL)
+        # the second batch of a context sizes its rounds and grids from the first one's cell count (round 4): same result
+        res2 = S3.search_batch(d.data_ptr(), pkg.FMT_IQ_U8, len(order), 153600, f, FC, FC, FS, pkg.STAGE_FULL)
+        res3 = S3.search_batch(d.data_ptr(), pkg.FMT_IQ_U8, 2, 153600, f, FC, FC, FS, pkg.STAGE_FULL)      # and a small batch after a busy one
     assert [[key(c) for c in r] for r in res] == [[key(c) for c in r] for r in ref]
+    assert [[key(c) for c in r] for r in res2] == [[key(c) for c in r] for r in ref]
+    assert [[key(c) for c in r] for r in res3] == [[key(c) for c in r] for r in ref[:2]]
     assert sum(len(r) for r in ref) == 2 * len(order)
 
 
