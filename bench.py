@@ -359,6 +359,24 @@ def track_bench(pkg, args, rank, world, local_rank, dist):
     alone_ms = float(np.mean(gpu_ms[1:]))
     gpu_ms[:] = [alone_ms]
     locks = locks[0]
+    # the continuous form (lcs_track_stream_block: symbols arrive block after block, the carried frames' rows stay on the
+    # device): the same cells fed 980 symbols per call, host samples in (PCIe inside), measurements and MIB attempts out
+    stream_form = None
+    if not args.no_dense:
+        reps = 6
+        ctxs[0].track_stream_reset()
+        ctxs[0].track_stream_block(cells, td, fov, ftv, late, fc, fc, FS, want_syms=False, want_ce=False)      # first block: no tail yet
+        ctxs[0].track_stream_block(cells, td, fov, ftv, late, fc, fc, FS, want_syms=False, want_ce=False)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            so = ctxs[0].track_stream_block(cells, td, fov, ftv, late, fc, fc, FS, want_syms=False, want_ce=False)
+        torch.cuda.synchronize()
+        dts = (time.perf_counter() - t1) / reps
+        stream_form = {"symbols_per_s": C * n_sym / dts, "ms_per_call": 1e3 * dts, "symbols_per_call": n_sym, "mib_attempts_per_call": int(so["n_mib"].sum()),
+                       "note": "one context, one thread, time-domain symbols handed over in HOST memory (80 MB per call); the three carried frames are "
+                               "not transformed again (their frequency-domain rows stay on the device) and no frame offset is decoded twice"}
+        ctxs[0].track_stream_reset()
     if rank == 0:
         value = world * C * n_sym * args.steps / dt
         out = {"metric": "OFDM symbols/s, LTE-Tracker per-symbol pipeline (get_fd + CRS channel estimate + FOE/TOE + MIB re-decode)",
@@ -367,7 +385,7 @@ def track_bench(pkg, args, rank, world, local_rank, dist):
                "data": "symbols cut from tests/golden/capbuf_0000 (cells 277, 271), tiled over the tracked cells",
                "config": {"workload": f"SURVEY 8 f4: {C} tracked cells x {n_sym} OFDM symbols (70 ms) per step, time-domain symbols resident in HBM",
                           "tracked_cells": C, "symbols_per_block": n_sym, "gpu_ms_per_block": alone_ms,
-                          "gpu_ms_per_block_in_the_pipelined_run": pipelined_ms, "contexts_in_flight": depth,
+                          "gpu_ms_per_block_in_the_pipelined_run": pipelined_ms, "contexts_in_flight": depth, "stream_form": stream_form,
                           "mib_locks_per_block": locks, "cells_in_real_time": value / world / 14000.0,
                           "parallelism": "replicas" if world > 1 else "single GPU"}}
         # algorithmic bytes of a block: the time-domain symbols in (128 complex<double> each) + symbols and the two ports'
@@ -465,7 +483,7 @@ def main():
     ap.add_argument("--input", choices=["u8", "c64"], default="u8",
                     help="resident input format: raw RTL-SDR u8 I/Q (int8 MFMA correlation kernel, default) or complex<float> "
                          "(fp16 three-product MFMA correlation kernel)")
-    ap.add_argument("--pipeline", type=int, default=2,
+    ap.add_argument("--pipeline", type=int, default=None,
                     help="contexts (streams + workspaces) used round-robin: the latency-bound per-cell "
                          "stages of batch i overlap the PSS correlation of batch i+1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -486,6 +504,8 @@ def main():
     args = ap.parse_args()
     if args.batch is None:
         args.batch = 64 if args.stage == "track" else 128
+    if args.pipeline is None:
+        args.pipeline = 3 if args.stage == "track" else 2      # contexts in flight (track: profiles/r04/bench_track_n1.json)
     if args.batches_per_step is None:
         args.batches_per_step = max(1, 12800 // args.batch)
 

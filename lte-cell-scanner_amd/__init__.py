@@ -346,7 +346,8 @@ class Searcher:
         out["gpu_ms"] = ms.value
         return out
 
-    def track_stream_block(self, cells, td, freq_off, frame_timing, late, fc_requested, fc_programmed, fs_programmed, want_stats=False):
+    def track_stream_block(self, cells, td, freq_off, frame_timing, late, fc_requested, fc_programmed, fs_programmed, want_stats=False,
+                           want_syms=True, want_ce=True):
         """Continuous tracking (lcs_track_stream_block): the next block of a symbol stream.  `cells` as in track_block; the
         objects' bulk_phase_offset attribute (if any) seeds the first call.  Returns a dict whose rows carry their index in
         the whole stream: syms [c][n_sym][72]; meas [c][4][n_meas][9] (+ ac_fd, ac_td with want_stats); ce / ce_pw lists per
@@ -366,8 +367,9 @@ class Searcher:
         lt = np.ascontiguousarray(late, np.float64).reshape(n_cells, n_sym)
         tdh = np.ascontiguousarray(td, np.complex128).reshape(n_cells, n_sym, 128)
         max_rs, ce_cap, max_off = n_sym // 3 + 8, n_sym + 64, n_sym // 120 + 4
-        o = dict(syms=np.empty((n_cells, n_sym, 72), np.complex128), ce=np.full((n_cells, 4, ce_cap, 72), np.nan + 0j, np.complex128),
-                 ce_pw=np.full((n_cells, 4, ce_cap, 4), np.nan), ce_from=np.zeros((n_cells, 4), np.int64), ce_n=np.zeros((n_cells, 4), np.int32),
+        o = dict(syms=np.empty((n_cells, n_sym, 72), np.complex128) if want_syms else None,
+                 ce=np.full((n_cells, 4, ce_cap, 72), np.nan + 0j, np.complex128) if want_ce else None,
+                 ce_pw=np.full((n_cells, 4, ce_cap, 4), np.nan) if want_ce else None, ce_from=np.zeros((n_cells, 4), np.int64), ce_n=np.zeros((n_cells, 4), np.int32),
                  meas=np.full((n_cells, 4, max_rs, 9), np.nan), n_meas=np.zeros((n_cells, 4), np.int32),
                  ac_fd=np.full((n_cells, 4, max_rs, 12), np.nan + 0j, np.complex128) if want_stats else None,
                  ac_td=np.full((n_cells, 4, max_rs, 72), np.nan + 0j, np.complex128) if want_stats else None,

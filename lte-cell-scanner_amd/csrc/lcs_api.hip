@@ -320,7 +320,7 @@ void lcs_destroy(lcs_ctx *c) {
                   c->trk_syncce, c->trk_sync, c->d_flag};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   if (c->h_pinned) (void)hipHostFree(c->h_pinned);
-  if (c->trk_hpin) (void)hipHostFree(c->trk_hpin);
+  if (c->trk_hpin) free(c->trk_hpin);
   for (int k = 0; k < 2; ++k) {
     if (c->h_stage[k]) (void)hipHostFree(c->h_stage[k]);
     if (c->ev_stage[k]) (void)hipEventDestroy(c->ev_stage[k]);

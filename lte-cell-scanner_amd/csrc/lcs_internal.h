@@ -218,7 +218,7 @@ struct lcs_ctx {
   double *trk_sync = nullptr;
   int trk_stat_cells = 0, trk_stat_sym = 0;
   void *trk_stream = nullptr;        // carried state of lcs_track_stream_block (tracker.hip)
-  void *trk_hpin = nullptr;          // page-locked staging of lcs_track_block: metadata up, measurement tables down
+  void *trk_hpin = nullptr;          // reusable host staging block of lcs_track_block (malloc): metadata up, measurement tables down
   size_t trk_hpin_bytes = 0;
   // host staging
   SlotParams h_params{};             // source of asynchronous parameter uploads of the single-buffer entry points

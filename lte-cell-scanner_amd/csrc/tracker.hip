@@ -72,14 +72,15 @@ __global__ __launch_bounds__(128) void k_trk_prep(lcs_track_cell *__restrict__ c
 
 // get_fd: one wave per OFDM symbol, 4 symbols per workgroup.
 #define TRK_FD_SYM 4
-__global__ __launch_bounds__(64 * TRK_FD_SYM) void k_trk_fd(const lcs_track_cell *__restrict__ cells, int n_sym, const double2 *__restrict__ td,
+__global__ __launch_bounds__(64 * TRK_FD_SYM) void k_trk_fd(const lcs_track_cell *__restrict__ cells, int n_sym, int sym_first, const double2 *__restrict__ td,
                                                             const double *__restrict__ freq_off, const double *__restrict__ late,
                                                             const double *__restrict__ bpo, double fc_req, double fc_prog, double fs_prog,
                                                             double2 *__restrict__ syms) {
   __shared__ cd2 W[64];
   __shared__ cd2 win[TRK_FD_SYM][128];
   const int cell = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int i = blockIdx.x * TRK_FD_SYM + wv;
+  // symbols below sym_first already have their rows in `syms` (continuous tracking: the carried frames of the previous call)
+  const int i = sym_first + blockIdx.x * TRK_FD_SYM + wv;
   const bool live = i < n_sym;
   if (tid < 64) { double s, c; sincospi((double)tid / 64.0, &s, &c); W[tid] = mk(c, -s); }
   if (live) {
@@ -96,17 +97,21 @@ __global__ __launch_bounds__(64 * TRK_FD_SYM) void k_trk_fd(const lcs_track_cell
     }
   }
   __syncthreads();
+  // 128-point decimation-in-frequency FFT, bit-reversed order out.  A wave owns its window: no workgroup barrier between
+  // the stages, and the lane's seven twiddles come out of the table once (their power-of-two strides collide on the banks)
+  cd2 twr[7];
 #pragma unroll
-  for (int stg = 0; stg < 7; ++stg) {     // 128-point decimation-in-frequency FFT, bit-reversed order out
+  for (int stg = 0; stg < 7; ++stg) twr[stg] = W[(lane & ((64 >> stg) - 1)) << stg];
+#pragma unroll
+  for (int stg = 0; stg < 7; ++stg) {
     const int half = 64 >> stg;
     const int pos = lane & (half - 1);
     const int i0 = ((lane >> (6 - stg)) << (7 - stg)) + pos, i1 = i0 + half;
-    const cd2 tw = W[pos << stg];
     cd2 *x = win[wv];
     const cd2 a = x[i0], b = x[i1];
     x[i0] = cadd(a, b);
-    x[i1] = cmul(csub(a, b), tw);
-    __syncthreads();
+    x[i1] = cmul(csub(a, b), twr[stg]);
+    __builtin_amdgcn_wave_barrier();
   }
   if (!live) return;
   const lcs_track_cell c = cells[cell];
@@ -280,11 +285,16 @@ __global__ __launch_bounds__(TRK_PB_THREADS) __attribute__((amdgpu_waves_per_eu(
                                                            const double2 *__restrict__ syms, const double2 *__restrict__ ce,
                                                            const double *__restrict__ ce_pw, const int *__restrict__ ce_upto,
                                                            const uint8_t *__restrict__ pbch_scr, const int16_t *__restrict__ derm_inv,
-                                                           int *__restrict__ mib_ok, unsigned long long *__restrict__ mib_bits) {
+                                                           int *__restrict__ mib_ok, unsigned long long *__restrict__ mib_bits,
+                                                           const int *__restrict__ mib_first /* nullable */) {
   __shared__ unsigned long long surv[40 * 64];      // survivor words [step][trellis]; holds the LLRs until they are de-ratematched
   __shared__ double d_est[3][40];
   double *e_est = reinterpret_cast<double *>(surv);
   const int off = blockIdx.x, cell = blockIdx.y, tid = threadIdx.x;
+  if (mib_first && off < mib_first[cell]) {          // continuous tracking: an earlier call attempted this frame offset already
+    if (tid == 0) { mib_ok[(size_t)cell * n_off + off] = -1; mib_bits[(size_t)cell * n_off + off] = 0ull; }
+    return;
+  }
   const lcs_track_cell c = cells[cell];
   const int n_symb = trk_n_symb(c), per_frame = 20 * n_symb, id = c.n_id_2 + 3 * c.n_id_1;
   const int last = (off + 3) * per_frame + n_symb + 3;            // last PBCH symbol of the attempt
@@ -442,7 +452,7 @@ struct TrkLayout {
   int rs_cap, n_off;
   size_t N, C4;
   double *d_fo, *d_ft, *d_late, *d_bpo, *d_rs, *d_shift, *d_fm, *d_meas;
-  int *d_idx, *d_nrs, *d_nmeas, *d_upto, *d_mibok;
+  int *d_idx, *d_nrs, *d_nmeas, *d_upto, *d_mibok, *d_mibfirst;
   double2 *d_raw, *d_filt;
   unsigned long long *d_mibbits;
   TrkLayout(const lcs_ctx *c, int n_cells, int n_sym) {
@@ -456,6 +466,7 @@ struct TrkLayout {
     d_fm = c->trk_fmeta; d_meas = d_fm + C4 * rs_cap * 4;
     d_nmeas = c->trk_small; d_upto = d_nmeas + C4; d_mibok = d_upto + C4;
     d_mibbits = reinterpret_cast<unsigned long long *>(d_mibok + (((size_t)n_cells * n_off + 1) & ~(size_t)1));
+    d_mibfirst = c->trk_small + C4 * 2 + (size_t)n_cells * (n_off + 1) * 3;
   }
 };
 template <typename T>
@@ -466,36 +477,44 @@ int trk_alloc(lcs_ctx *c, T **p, size_t n) {
 }
 }  // namespace
 
-extern "C" int lcs_track_block(lcs_ctx *c, lcs_track_cell *cells, int n_cells, int n_sym, const void *td, int td_on_device,
-                               const double *freq_off, const double *frame_timing, const double *late, double fc_requested,
-                               double fc_programmed, double fs_programmed, double *syms, double *ce, double *ce_pw,
-                               int32_t *ce_upto, double *meas, int max_rs, int32_t *n_meas, int32_t *mib_ok, uint64_t *mib_bits,
-                               int max_off, float *gpu_ms) {
-  if (!c) return LCS_ERR_BAD_ARG;
-  if (!cells || !td || !freq_off || !frame_timing || !late || n_cells < 1 || n_sym < 1 || max_rs < 0 || max_off < 0) { c->err = "bad argument"; return LCS_ERR_BAD_ARG; }
-  for (int i = 0; i < n_cells; ++i) {
-    const lcs_track_cell &t = cells[i];
-    if (t.n_id_1 < 0 || t.n_id_1 > 167 || t.n_id_2 < 0 || t.n_id_2 > 2 || (t.cp_type != LCS_CP_NORMAL && t.cp_type != LCS_CP_EXTENDED) ||
-        t.n_ports < 1 || t.n_ports > 4) { c->err = "tracked cell needs n_id_1, n_id_2, a known cp_type and 1..4 ports"; return LCS_ERR_BAD_ARG; }
-  }
-  HIPCHK(c, hipSetDevice(c->device));
+namespace {
+// What the block workspace already holds when lcs_track_stream_block calls in (continuous tracking)
+struct TrkCarried {
+  int n_tail;              // the first n_tail symbols of every cell have their frequency-domain rows in trk_syms (restored from the previous call)
+  const int *mib_first;    // host [n_cells]: frame offsets below were attempted by an earlier call and are not decoded again
+};
+
+// The workspace is laid out for one block shape
+int trk_ensure_ws(lcs_ctx *c, int n_cells, int n_sym) {
+  if (n_cells == c->trk_cells_cap && n_sym == c->trk_sym_cap) return LCS_OK;
+  const int rs_cap = n_sym / 3 + 4, n_off = std::max(0, n_sym / 120 - 3);     // as TrkLayout
+  const size_t N = (size_t)n_cells * n_sym, C4 = (size_t)n_cells * 4;
+  int rc;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  // the caps describe a complete workspace or nothing: if an allocation below fails, later calls (and
+  // lcs_track_stats, which trusts them) must not take the half-replaced buffers for the old shape
+  c->trk_cells_cap = c->trk_sym_cap = 0;
+  c->trk_stat_cells = c->trk_stat_sym = 0;
+  if ((rc = trk_alloc(c, &c->trk_td, N * 128)) || (rc = trk_alloc(c, &c->trk_meta, N * 4)) || (rc = trk_alloc(c, &c->trk_cells, (size_t)n_cells)) ||
+      (rc = trk_alloc(c, &c->trk_syms, N * 72)) || (rc = trk_alloc(c, &c->trk_rs, (size_t)n_cells * 140 * 28)) ||
+      (rc = trk_alloc(c, &c->trk_idx, C4 * (rs_cap + 1))) || (rc = trk_alloc(c, &c->trk_raw, C4 * rs_cap * 24)) ||
+      (rc = trk_alloc(c, &c->trk_fmeta, C4 * rs_cap * (4 + TRK_MEAS))) || (rc = trk_alloc(c, &c->trk_ce, C4 * n_sym * 72)) ||
+      (rc = trk_alloc(c, &c->trk_pw, C4 * n_sym * 4)) || (rc = trk_alloc(c, &c->trk_small, C4 * 2 + (size_t)n_cells * (n_off + 1) * 3 + n_cells)))
+    return rc;
+  c->trk_cells_cap = n_cells; c->trk_sym_cap = n_sym;
+  return LCS_OK;
+}
+
+// td: [n_cells][n_sym][128] on the host (td_on_device 0), on the device (1), or -- td_on_device 2, the continuous form --
+// already in trk_td (rows carry->n_tail .. n_sym - 1; the rows before are never read)
+int trk_block(lcs_ctx *c, lcs_track_cell *cells, int n_cells, int n_sym, const void *td, int td_on_device,
+              const double *freq_off, const double *frame_timing, const double *late, double fc_requested,
+              double fc_programmed, double fs_programmed, double *syms, double *ce, double *ce_pw,
+              int32_t *ce_upto, double *meas, int max_rs, int32_t *n_meas, int32_t *mib_ok, uint64_t *mib_bits,
+              int max_off, float *gpu_ms, const TrkCarried *carry) {
   const int rs_cap = n_sym / 3 + 4, n_off = std::max(0, n_sym / 120 - 3);     // as TrkLayout
   int rc;
-  if (n_cells != c->trk_cells_cap || n_sym != c->trk_sym_cap) {      // workspace laid out for one block shape
-    const size_t N = (size_t)n_cells * n_sym, C4 = (size_t)n_cells * 4;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    // the caps describe a complete workspace or nothing: if an allocation below fails, later calls (and
-    // lcs_track_stats, which trusts them) must not take the half-replaced buffers for the old shape
-    c->trk_cells_cap = c->trk_sym_cap = 0;
-    c->trk_stat_cells = c->trk_stat_sym = 0;
-    if ((rc = trk_alloc(c, &c->trk_td, N * 128)) || (rc = trk_alloc(c, &c->trk_meta, N * 4)) || (rc = trk_alloc(c, &c->trk_cells, (size_t)n_cells)) ||
-        (rc = trk_alloc(c, &c->trk_syms, N * 72)) || (rc = trk_alloc(c, &c->trk_rs, (size_t)n_cells * 140 * 28)) ||
-        (rc = trk_alloc(c, &c->trk_idx, C4 * (rs_cap + 1))) || (rc = trk_alloc(c, &c->trk_raw, C4 * rs_cap * 24)) ||
-        (rc = trk_alloc(c, &c->trk_fmeta, C4 * rs_cap * (4 + TRK_MEAS))) || (rc = trk_alloc(c, &c->trk_ce, C4 * n_sym * 72)) ||
-        (rc = trk_alloc(c, &c->trk_pw, C4 * n_sym * 4)) || (rc = trk_alloc(c, &c->trk_small, C4 * 2 + (size_t)n_cells * (n_off + 1) * 3)))
-      return rc;
-    c->trk_cells_cap = n_cells; c->trk_sym_cap = n_sym;
-  }
+  if ((rc = trk_ensure_ws(c, n_cells, n_sym))) return rc;
   const TrkLayout L(c, n_cells, n_sym);
   const size_t N = L.N, C4 = L.C4;
   double *d_fo = L.d_fo, *d_ft = L.d_ft, *d_late = L.d_late, *d_bpo = L.d_bpo, *d_rs = L.d_rs, *d_shift = L.d_shift;
@@ -503,16 +522,20 @@ extern "C" int lcs_track_block(lcs_ctx *c, lcs_track_cell *cells, int n_cells, i
   double2 *d_raw = L.d_raw, *d_filt = L.d_filt;
   double *d_fm = L.d_fm, *d_meas = L.d_meas;
   unsigned long long *d_mibbits = L.d_mibbits;
-  const double2 *d_td = td_on_device ? (const double2 *)td : c->trk_td;
-  // Page-locked staging (round 4): the three metadata arrays go up as ONE copy (d_fo, d_ft, d_late are adjacent in
-  // trk_meta), the measurement tables come down into the same block -- pageable copies of these 8 MB and the zero-filled
-  // vectors they landed in were most of the 2 ms of host time a 64-cell block cost next to 1.15 ms of GPU time.
+  const double2 *d_td = (td_on_device == 1) ? (const double2 *)td : c->trk_td;
+  const int sym_first = carry ? carry->n_tail : 0;
+  // One reusable host block for the small traffic of a call (round 4): the three metadata arrays go up as ONE copy (d_fo,
+  // d_ft, d_late are adjacent in trk_meta), the measurement tables come down into the same block -- no per-call vectors
+  // (6 MB zero-filled and 71 k row copies per call before).  Plain pageable memory on purpose: with a PAGE-LOCKED block the
+  // copies become asynchronous stream operations on the copy engines, and blocks of different contexts stopped overlapping
+  // (three contexts in flight: 43 M symbols/s page-locked, 73 M pageable; profiles/r04/experiments/tracker_staging.txt).
   const size_t n_meas_d = C4 * rs_cap * TRK_MEAS, n_small = C4 * 2 + (size_t)n_cells * n_off, n_bits = (size_t)n_cells * n_off + 1;
   const size_t up_bytes = sizeof(double) * 3 * N + sizeof(lcs_track_cell) * n_cells;
   const size_t down_bytes = sizeof(double) * n_meas_d + sizeof(unsigned long long) * n_bits + sizeof(int) * n_small + sizeof(lcs_track_cell) * n_cells;
   if (up_bytes + down_bytes + 64 > c->trk_hpin_bytes) {
-    if (c->trk_hpin) { HIPCHK(c, hipStreamSynchronize(c->stream)); (void)hipHostFree(c->trk_hpin); c->trk_hpin = nullptr; c->trk_hpin_bytes = 0; }
-    HIPCHK(c, hipHostMalloc(&c->trk_hpin, up_bytes + down_bytes + 64, hipHostMallocDefault));
+    if (c->trk_hpin) { HIPCHK(c, hipStreamSynchronize(c->stream)); free(c->trk_hpin); c->trk_hpin = nullptr; c->trk_hpin_bytes = 0; }
+    c->trk_hpin = malloc(up_bytes + down_bytes + 64);
+    if (!c->trk_hpin) { c->err = "out of host memory"; return LCS_ERR_HIP; }
     c->trk_hpin_bytes = up_bytes + down_bytes + 64;
   }
   double *h_up = static_cast<double *>(c->trk_hpin);
@@ -526,19 +549,22 @@ extern "C" int lcs_track_block(lcs_ctx *c, lcs_track_cell *cells, int n_cells, i
   std::memcpy(h_up + 2 * N, late, sizeof(double) * N);
   std::memcpy(h_cells_up, cells, sizeof(lcs_track_cell) * n_cells);
   if (!td_on_device) HIPCHK(c, hipMemcpyAsync(c->trk_td, td, sizeof(double2) * N * 128, hipMemcpyHostToDevice, c->stream));
+  if (carry && carry->mib_first) HIPCHK(c, hipMemcpyAsync(L.d_mibfirst, carry->mib_first, sizeof(int) * n_cells, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(d_fo, h_up, sizeof(double) * 3 * N, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->trk_cells, h_cells_up, sizeof(lcs_track_cell) * n_cells, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipEventRecord(c->ev_xc0, c->stream));
   hipLaunchKernelGGL(k_trk_prep, dim3(n_cells), dim3(128), 0, c->stream, c->trk_cells, n_sym, d_fo, c->d_pn_jump, d_rs, d_shift, d_bpo, d_idx,
                      d_nrs, rs_cap);
-  hipLaunchKernelGGL(k_trk_fd, dim3((n_sym + TRK_FD_SYM - 1) / TRK_FD_SYM, n_cells), dim3(64 * TRK_FD_SYM), 0, c->stream, c->trk_cells, n_sym,
-                     d_td, d_fo, d_late, d_bpo, fc_requested, fc_programmed, fs_programmed, c->trk_syms);
+  if (n_sym > sym_first)
+    hipLaunchKernelGGL(k_trk_fd, dim3((n_sym - sym_first + TRK_FD_SYM - 1) / TRK_FD_SYM, n_cells), dim3(64 * TRK_FD_SYM), 0, c->stream, c->trk_cells, n_sym,
+                       sym_first, d_td, d_fo, d_late, d_bpo, fc_requested, fc_programmed, fs_programmed, c->trk_syms);
   hipLaunchKernelGGL(k_trk_ce, dim3(4, n_cells), dim3(TRK_CE_THREADS), 0, c->stream, c->trk_cells, n_sym, c->trk_syms, d_fo, d_ft, d_rs, d_shift,
                      d_idx, d_nrs, rs_cap, fc_requested, fc_programmed, fs_programmed, d_raw, d_filt, d_fm, d_meas, d_nmeas, c->trk_ce,
                      c->trk_pw, d_upto);
   if (n_off > 0)
     hipLaunchKernelGGL(k_trk_mib, dim3(n_off, n_cells), dim3(TRK_PB_THREADS), 0, c->stream, c->trk_cells, n_sym, n_off, c->trk_syms, c->trk_ce,
-                       c->trk_pw, d_upto, c->d_pbch_scr, c->d_derm_inv, d_mibok, d_mibbits);
+                       c->trk_pw, d_upto, c->d_pbch_scr, c->d_derm_inv, d_mibok, d_mibbits,
+                       (carry && carry->mib_first) ? (const int *)L.d_mibfirst : (const int *)nullptr);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipEventRecord(c->ev_xc1, c->stream));
   // results
@@ -567,6 +593,24 @@ extern "C" int lcs_track_block(lcs_ctx *c, lcs_track_cell *cells, int n_cells, i
     }
   if (rc) c->err = "more reference symbols per port than max_rs rows";
   return rc;
+}
+}  // namespace
+
+extern "C" int lcs_track_block(lcs_ctx *c, lcs_track_cell *cells, int n_cells, int n_sym, const void *td, int td_on_device,
+                               const double *freq_off, const double *frame_timing, const double *late, double fc_requested,
+                               double fc_programmed, double fs_programmed, double *syms, double *ce, double *ce_pw,
+                               int32_t *ce_upto, double *meas, int max_rs, int32_t *n_meas, int32_t *mib_ok, uint64_t *mib_bits,
+                               int max_off, float *gpu_ms) {
+  if (!c) return LCS_ERR_BAD_ARG;
+  if (!cells || !td || !freq_off || !frame_timing || !late || n_cells < 1 || n_sym < 1 || max_rs < 0 || max_off < 0) { c->err = "bad argument"; return LCS_ERR_BAD_ARG; }
+  for (int i = 0; i < n_cells; ++i) {
+    const lcs_track_cell &t = cells[i];
+    if (t.n_id_1 < 0 || t.n_id_1 > 167 || t.n_id_2 < 0 || t.n_id_2 > 2 || (t.cp_type != LCS_CP_NORMAL && t.cp_type != LCS_CP_EXTENDED) ||
+        t.n_ports < 1 || t.n_ports > 4) { c->err = "tracked cell needs n_id_1, n_id_2, a known cp_type and 1..4 ports"; return LCS_ERR_BAD_ARG; }
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  return trk_block(c, cells, n_cells, n_sym, td, td_on_device ? 1 : 0, freq_off, frame_timing, late, fc_requested, fc_programmed, fs_programmed, syms, ce,
+                   ce_pw, ce_upto, meas, max_rs, n_meas, mib_ok, mib_bits, max_off, gpu_ms, nullptr);
 }
 
 // Statistics of the block the last lcs_track_block call on this context processed (its workspace is read, not recomputed).
@@ -645,8 +689,7 @@ extern "C" int lcs_track_stats(lcs_ctx *c, int n_cells, int n_sym, double *ac_fd
 // The price is recomputing the carried frames (3-4 frames per call: x1.4 for 7-frame blocks).
 namespace {
 struct TrkStreamCell {
-  std::vector<double> td;                    // carried symbols [n_tail][128][2]
-  std::vector<double> fo, ft, late;          // their metadata
+  std::vector<double> fo, ft, late;          // metadata of the carried symbols
   double bpo_before_tail = 0;                // bulk phase before the first carried symbol
   long long tail_start = 0;                  // stream index of the first carried symbol (a frame boundary)
   long long n_seen = 0;                      // symbols delivered so far
@@ -655,11 +698,19 @@ struct TrkStreamCell {
   long long mib_next = 0;                    // first frame offset not attempted yet
   int cp_type = 0, n_id_1 = -1, n_id_2 = -1, n_ports = 0;
 };
-struct TrkStream { std::vector<TrkStreamCell> cells; };
+// The carried symbols themselves stay on the DEVICE, already transformed: per CP type the frequency-domain rows
+// [cells of that type][carried symbols][72] of the previous call (round 3 kept the time-domain samples on the host and ran
+// them through get_fd again with every call).
+struct TrkStream {
+  std::vector<TrkStreamCell> cells;
+  double2 *d_tail[3] = {nullptr, nullptr, nullptr};      // indexed by LCS_CP_NORMAL / LCS_CP_EXTENDED
+};
 }  // namespace
 
 void lcs_track_stream_free(lcs_ctx *c) {
-  delete static_cast<TrkStream *>(c->trk_stream);
+  TrkStream *st = static_cast<TrkStream *>(c->trk_stream);
+  if (st) for (double2 *p : st->d_tail) if (p) (void)hipFree(p);
+  delete st;
   c->trk_stream = nullptr;
 }
 
@@ -700,59 +751,85 @@ extern "C" int lcs_track_stream_block(lcs_ctx *c, lcs_track_cell *cells, int n_c
   }
   const double *tdv = static_cast<const double *>(td);
   int rc_all = LCS_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  // The stream's state is committed only after EVERY group of cells went through (round-3 advisory: a failure in the second
+  // group used to leave the first one advanced): the new per-cell records and device tails are built aside.
+  std::vector<TrkStreamCell> next = st->cells;
+  double2 *new_tail[3] = {nullptr, nullptr, nullptr};
+  bool group_done[3] = {false, false, false};
+  auto fail = [&](int rc) { for (double2 *p : new_tail) if (p) (void)hipFree(p); return rc; };
   // cells of one CP type carry the same number of frames: one extended block per CP type
   for (int cp = LCS_CP_NORMAL; cp <= LCS_CP_EXTENDED; ++cp) {
     std::vector<int> idx;
     for (int i = 0; i < n_cells; ++i) if (cells[i].cp_type == cp) idx.push_back(i);
     if (idx.empty()) continue;
-    const int G = (int)idx.size(), F = (cp == LCS_CP_NORMAL) ? 140 : 120, n_symb = F / 20;
+    const int G = (int)idx.size(), F = (cp == LCS_CP_NORMAL) ? 140 : 120;
     const int n_tail = (int)(st->cells[idx[0]].n_seen - st->cells[idx[0]].tail_start);
     const int L = n_tail + n_sym;
     const long long T = st->cells[idx[0]].tail_start;
     for (int g = 0; g < G; ++g)
-      if (st->cells[idx[g]].n_seen - st->cells[idx[g]].tail_start != n_tail || st->cells[idx[g]].tail_start != T) { c->err = "streams out of step"; return LCS_ERR_BAD_ARG; }
+      if (st->cells[idx[g]].n_seen - st->cells[idx[g]].tail_start != n_tail || st->cells[idx[g]].tail_start != T) { c->err = "streams out of step"; return fail(LCS_ERR_BAD_ARG); }
     std::vector<lcs_track_cell> gc(G);
-    std::vector<double> x_td((size_t)G * L * 256), x_fo((size_t)G * L), x_ft((size_t)G * L), x_late((size_t)G * L);
+    std::vector<double> x_fo((size_t)G * L), x_ft((size_t)G * L), x_late((size_t)G * L);
+    std::vector<int> mib_first(G);
+    int rc = trk_ensure_ws(c, G, L);
+    if (rc != LCS_OK) return fail(rc);
+    // the carried rows go back to the head of every cell's rows, the new samples behind them
+    if (n_tail > 0)
+      HIPCHK(c, hipMemcpy2DAsync(c->trk_syms, sizeof(double2) * 72 * (size_t)L, st->d_tail[cp], sizeof(double2) * 72 * (size_t)n_tail,
+                                 sizeof(double2) * 72 * (size_t)n_tail, G, hipMemcpyDeviceToDevice, c->stream));
     for (int g = 0; g < G; ++g) {
       const TrkStreamCell &sc = st->cells[idx[g]];
       gc[g] = cells[idx[g]];
       gc[g].bulk_phase_offset = sc.bpo_before_tail;
-      std::copy(sc.td.begin(), sc.td.end(), x_td.begin() + (size_t)g * L * 256);
-      std::copy(tdv + (size_t)idx[g] * n_sym * 256, tdv + (size_t)(idx[g] + 1) * n_sym * 256, x_td.begin() + ((size_t)g * L + n_tail) * 256);
+      HIPCHK(c, hipMemcpyAsync(c->trk_td + ((size_t)g * L + n_tail) * 128, tdv + (size_t)idx[g] * n_sym * 256, sizeof(double2) * 128 * (size_t)n_sym,
+                               hipMemcpyHostToDevice, c->stream));
       auto join = [&](const std::vector<double> &tail, const double *fresh, std::vector<double> &out) {
         std::copy(tail.begin(), tail.end(), out.begin() + (size_t)g * L);
         std::copy(fresh + (size_t)idx[g] * n_sym, fresh + (size_t)(idx[g] + 1) * n_sym, out.begin() + (size_t)g * L + n_tail);
       };
       join(sc.fo, freq_off, x_fo); join(sc.ft, frame_timing, x_ft); join(sc.late, late, x_late);
+      mib_first[g] = (int)std::max<long long>(0, sc.mib_next - T / F);
     }
     const int rs_cap = L / 3 + 4, n_off = std::max(0, L / 120 - 3);
-    std::vector<double> o_syms(syms ? (size_t)G * L * 144 : 0), o_ce((ce || mib_ok) ? (size_t)G * 4 * L * 144 : 0), o_pw((ce_pw || ce) ? (size_t)G * 4 * L * 4 : 0);
+    std::vector<double> o_syms(syms ? (size_t)G * L * 144 : 0), o_ce(ce ? (size_t)G * 4 * L * 144 : 0), o_pw((ce_pw || ce) ? (size_t)G * 4 * L * 4 : 0);
     std::vector<double> o_meas((size_t)G * 4 * rs_cap * LCS_TRK_MEAS);
     std::vector<int32_t> o_upto((size_t)G * 4), o_nmeas((size_t)G * 4), o_ok((size_t)G * std::max(1, n_off));
     std::vector<uint64_t> o_bits((size_t)G * std::max(1, n_off));
-    int rc = lcs_track_block(c, gc.data(), G, L, x_td.data(), 0, x_fo.data(), x_ft.data(), x_late.data(), fc_requested, fc_programmed, fs_programmed,
-                             syms ? o_syms.data() : nullptr, ce ? o_ce.data() : nullptr, (ce || ce_pw) ? o_pw.data() : nullptr, o_upto.data(),
-                             o_meas.data(), rs_cap, o_nmeas.data(), o_ok.data(), o_bits.data(), std::max(1, n_off), nullptr);
-    if (rc != LCS_OK) return rc;
+    const TrkCarried carried = {n_tail, mib_first.data()};
+    rc = trk_block(c, gc.data(), G, L, c->trk_td, 2, x_fo.data(), x_ft.data(), x_late.data(), fc_requested, fc_programmed, fs_programmed,
+                   syms ? o_syms.data() : nullptr, ce ? o_ce.data() : nullptr, (ce || ce_pw) ? o_pw.data() : nullptr, o_upto.data(),
+                   o_meas.data(), rs_cap, o_nmeas.data(), o_ok.data(), o_bits.data(), std::max(1, n_off), nullptr, &carried);
+    if (rc != LCS_OK) return fail(rc);
     std::vector<double> o_fd, o_tdc;
     if (ac_fd || ac_td) {
       if (ac_fd) o_fd.resize((size_t)G * 4 * rs_cap * 24);
       if (ac_td) o_tdc.resize((size_t)G * 4 * rs_cap * 144);
       rc = lcs_track_stats(c, G, L, ac_fd ? o_fd.data() : nullptr, ac_td ? o_tdc.data() : nullptr, rs_cap, nullptr, nullptr, 0, nullptr);
-      if (rc != LCS_OK && rc != LCS_ERR_OVERFLOW) return rc;      // no PSS/SSS rows were asked for: their overflow is of no concern
+      if (rc != LCS_OK && rc != LCS_ERR_OVERFLOW) return fail(rc);      // no PSS/SSS rows were asked for: their overflow is of no concern
     }
-    // the bulk phase before the first symbol of the NEXT carried tail = the value used at the symbol before it
+    // the next carried tail: whole frames from T_next on -- its frequency-domain rows into a fresh device buffer, the bulk
+    // phase before its first symbol (= the value used at the symbol before it) in ONE strided copy
     const long long n_after = st->cells[idx[0]].n_seen + n_sym;
     const long long T_next = std::max<long long>(0, (n_after - 3 * F) / F * F);
+    const size_t keep_from = (size_t)(T_next - T), n_keep = (size_t)(n_after - T_next);
     std::vector<double> bpo_at(G, 0.0);
-    if (T_next > T) {
+    {
+      const hipError_t e = hipMalloc((void **)&new_tail[cp], sizeof(double2) * 72 * n_keep * G);
+      if (e != hipSuccess) { new_tail[cp] = nullptr; c->err = std::string("hipMalloc (carried symbols): ") + hipGetErrorString(e); return fail(LCS_ERR_HIP); }
       const TrkLayout Lay(c, G, L);
-      for (int g = 0; g < G; ++g)
-        HIPCHK(c, hipMemcpy(&bpo_at[g], Lay.d_bpo + (size_t)g * L + (size_t)(T_next - T - 1), sizeof(double), hipMemcpyDeviceToHost));
+      hipError_t e2 = hipMemcpy2DAsync(new_tail[cp], sizeof(double2) * 72 * n_keep, c->trk_syms + keep_from * 72, sizeof(double2) * 72 * (size_t)L,
+                                       sizeof(double2) * 72 * n_keep, G, hipMemcpyDeviceToDevice, c->stream);
+      if (e2 == hipSuccess && T_next > T)
+        e2 = hipMemcpy2DAsync(bpo_at.data(), sizeof(double), Lay.d_bpo + (size_t)(T_next - T - 1), sizeof(double) * (size_t)L, sizeof(double), G,
+                              hipMemcpyDeviceToHost, c->stream);
+      if (e2 == hipSuccess) e2 = hipStreamSynchronize(c->stream);
+      if (e2 != hipSuccess) { c->err = std::string("carrying the stream's tail: ") + hipGetErrorString(e2); return fail(LCS_ERR_HIP); }
     }
+    group_done[cp] = true;
     for (int g = 0; g < G; ++g) {
       const int i = idx[g];
-      TrkStreamCell &sc = st->cells[i];
+      TrkStreamCell &sc = next[i];
       cells[i].bulk_phase_offset = gc[g].bulk_phase_offset;
       if (syms) std::memcpy(syms + (size_t)i * n_sym * 144, &o_syms[((size_t)g * L + n_tail) * 144], sizeof(double) * n_sym * 144);
       for (int p = 0; p < 4; ++p) {
@@ -805,21 +882,19 @@ extern "C" int lcs_track_stream_block(lcs_ctx *c, lcs_track_cell *cells, int n_c
         sc.mib_next = og + 1;
       }
       if (n_mib) n_mib[i] = std::min(em, max_off);
-      // carry: whole frames from T_next on
+      // the metadata of the carried symbols
       sc.n_seen = n_after;
-      const size_t keep_from = (size_t)(T_next - T);
-      const size_t n_keep = (size_t)(n_after - T_next);
-      std::vector<double> ntd(n_keep * 256), nfo(n_keep), nft(n_keep), nlate(n_keep);
-      std::copy(x_td.begin() + ((size_t)g * L + keep_from) * 256, x_td.begin() + ((size_t)g * L + keep_from + n_keep) * 256, ntd.begin());
-      std::copy(x_fo.begin() + (size_t)g * L + keep_from, x_fo.begin() + (size_t)g * L + keep_from + n_keep, nfo.begin());
-      std::copy(x_ft.begin() + (size_t)g * L + keep_from, x_ft.begin() + (size_t)g * L + keep_from + n_keep, nft.begin());
-      std::copy(x_late.begin() + (size_t)g * L + keep_from, x_late.begin() + (size_t)g * L + keep_from + n_keep, nlate.begin());
-      sc.td.swap(ntd); sc.fo.swap(nfo); sc.ft.swap(nft); sc.late.swap(nlate);
+      sc.fo.assign(x_fo.begin() + (size_t)g * L + keep_from, x_fo.begin() + (size_t)g * L + keep_from + n_keep);
+      sc.ft.assign(x_ft.begin() + (size_t)g * L + keep_from, x_ft.begin() + (size_t)g * L + keep_from + n_keep);
+      sc.late.assign(x_late.begin() + (size_t)g * L + keep_from, x_late.begin() + (size_t)g * L + keep_from + n_keep);
       if (T_next > T) sc.bpo_before_tail = bpo_at[g];
       sc.tail_start = T_next;
-      (void)n_symb;
     }
   }
+  // commit
+  st->cells.swap(next);
+  for (int cp = LCS_CP_NORMAL; cp <= LCS_CP_EXTENDED; ++cp)
+    if (group_done[cp]) { if (st->d_tail[cp]) (void)hipFree(st->d_tail[cp]); st->d_tail[cp] = new_tail[cp]; }
   if (rc_all) c->err = "more rows than the output arrays hold (rows beyond the capacity were dropped)";
   return rc_all;
 }
