@@ -781,7 +781,7 @@ def main():
         # corrected as MI355X_MICROARCH.md prescribes), taken from the committed summary ONLY if it was collected from
         # exactly the kernel sources that are running now.
         traffic, traffic_src = None, None
-        for tag in ("r03", "r02", "r01"):
+        for tag in ("r04", "r03", "r02", "r01"):
             try:
                 pmj = json.load(open(os.path.join(ROOT, "profiles", tag, "pmc_summary.json")))
                 pm = pmj["kernels"][pmj["dominant_kernel"]]

@@ -1,12 +1,12 @@
 #!/bin/bash
 # Collect a round's profiling artifacts on a GPU box (run from the repository root through gpurun):
-#   bash profiles/collect.sh r03
+#   bash profiles/collect.sh r04
 # GPU tests first, then the bench lines, the kernel-trace statistics (one context = isolated kernel times, default
 # pipeline = under load) and the PMC counters -- kernel-trace statistics and counters in SEPARATE rocprofv3 runs, one
 # counter group per pass, as MI355X_MICROARCH.md prescribes.  Outputs land in gpurun_out/<tag>/; profiles/summarize.py
 # reduces them to the small files kept under profiles/<tag>/.
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 REPO=$PWD
 OUT=$REPO/gpurun_out/$TAG
 mkdir -p "$OUT"
@@ -19,6 +19,8 @@ SHORT="--steps 2 --warmup 1 --batches-per-step 8 --no-cpu-baseline --no-dense"
 # roofline.kernel_ms must agree with
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_full_p1" -- $B $SHORT --batch 64 --pipeline 1 > "$OUT/stats_full_p1.log" 2>&1
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_full_default" -- $B $SHORT > "$OUT/stats_full_default.log" 2>&1
+# the dense band (2-3 cells planted in every buffer) under the default command: where the per-cell chain's time goes
+timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_dense_default" -- $B $SHORT --dense-main > "$OUT/stats_dense_default.log" 2>&1
 # complex<float> batches (k_xcorr_f16x3), every kernel alone
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_c64_p1" -- $B $SHORT --batch 64 --pipeline 1 --input c64 > "$OUT/stats_c64_p1.log" 2>&1
 i=0
@@ -30,6 +32,9 @@ done
 # the bench lines last: bench.py reports roofline.traffic only from a PMC summary taken from the running kernel sources
 (cd "$REPO" && python profiles/summarize.py "$TAG" > /dev/null 2>&1)
 timeout 300 $B --steps 20 --warmup 5 > "$OUT/bench_full_n1.json" 2> "$OUT/bench_full_n1.err"
+# the multi-rank code path with ONE rank over RCCL (process group, device-identity all-gather, asynchronous record all-gather per
+# step, timing collectives): its value must stay within 2 % of the plain line's
+timeout 300 $B --gpus 1 --force-dist --dist-backend nccl --steps 20 --warmup 5 --no-cpu-baseline --no-dense > "$OUT/bench_forced_dist_n1.json" 2> "$OUT/bench_forced_dist.err"
 timeout 200 $B --steps 20 --warmup 5 --input-host --no-cpu-baseline --no-dense > "$OUT/bench_full_n1_input_host.json" 2> "$OUT/bench_host.err"
 timeout 120 $B --stage pss --no-cpu-baseline > "$OUT/bench_pss_n1.json" 2> "$OUT/bench_pss_n1.err"
 timeout 120 $B --stage single --steps 200 --warmup 20 > "$OUT/bench_single_n1.json" 2> "$OUT/bench_single_n1.err"

@@ -5,12 +5,12 @@
 """
 import csv, glob, json, os, shutil, sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(root, "gpurun_out", tag), os.path.join(root, "profiles", tag)
 os.makedirs(dst, exist_ok=True)
 
-for name in ("bench_full_n1.json", "bench_full_n1_input_host.json", "bench_single_n1.json", "bench_pss_n1.json", "bench_stream_n1.json", "bench_track_n1.json", "bench_full_n1_c64_f16_kernel.json", "pytest_gpu.log"):
+for name in ("bench_full_n1.json", "bench_forced_dist_n1.json", "bench_full_n1_input_host.json", "bench_single_n1.json", "bench_pss_n1.json", "bench_stream_n1.json", "bench_track_n1.json", "bench_full_n1_c64_f16_kernel.json", "pytest_gpu.log"):
     p = os.path.join(src, name)
     if os.path.exists(p):
         lines = [l for l in open(p).read().splitlines() if l.startswith("{")] if name.endswith(".json") else open(p).read().splitlines()[-6:]
@@ -19,6 +19,7 @@ for name in ("bench_full_n1.json", "bench_full_n1_input_host.json", "bench_singl
 
 for d, out in (("stats_full_p1", "kernel_stats_full_chain_b64_nf31_pipeline1.csv"),
                ("stats_full_default", "kernel_stats_full_chain_b128_nf31_default_command.csv"),
+               ("stats_dense_default", "kernel_stats_dense_band_b128_nf31_default_command.csv"),
                ("stats_c64_p1", "kernel_stats_full_chain_b64_nf31_c64_pipeline1.csv")):
     f = sorted(glob.glob(os.path.join(src, d, "*", "*_kernel_stats.csv")), key=os.path.getmtime)     # newest collection wins
     if f:
@@ -56,6 +57,9 @@ summary = {
                    "(MI355X_MICROARCH.md, HBM / rocprofv3 section).  hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024",
     "kernels": kern,
     "kernel_source_sha": kernel_source_sha(),
+    # LDS bank-conflict cycles per LDS instruction of the kernels that transform windows in LDS (round-3 review: 3.2 / 2.4 / 1.9)
+    "lds_conflict_cycles_per_lds_instruction": {k: v["SQ_LDS_BANK_CONFLICT"] / v["SQ_INSTS_LDS"] for k, v in kern.items()
+                                                if v.get("SQ_INSTS_LDS") and "SQ_LDS_BANK_CONFLICT" in v and v["SQ_INSTS_LDS"] > 1000},
 }
 if dom:
     k = kern[dom]
