@@ -680,13 +680,15 @@ extern "C" int lcs_track_stats(lcs_ctx *c, int n_cells, int n_sym, double *ac_fd
 // the interpolation between consecutive filtered reference symbols (:383-477), the 72-deep history of do_ac_td (:343-371)
 // and the four-frame fifo of do_mib_decode (:552-745) all reach across any boundary one could cut the symbol stream at.
 // lcs_track_block cuts it: each call starts from nothing.  lcs_track_stream_block removes the cut for a caller that
-// delivers a cell's symbols block after block: the context keeps the INPUTS (time-domain symbols and their metadata) of
-// the last three-to-four frames of every stream and the bulk phase at their first symbol, and every call processes
-// [carried frames ++ new symbols] as one block that starts at a frame boundary, with the same kernels -- so each output
-// row is computed exactly as a single call over the whole stream would compute it (nothing in the pipeline reaches back
-// further than the carried frames) -- and hands out only the rows no earlier call could: every filtered reference symbol,
-// channel-estimate row, autocorrelation row and MIB attempt exactly once, under its index in the whole stream.
-// The price is recomputing the carried frames (3-4 frames per call: x1.4 for 7-frame blocks).
+// delivers a cell's symbols block after block: the context keeps the last three-to-four frames of every stream -- their
+// frequency-domain rows (get_fd's output) on the device, their metadata and the bulk phase at their first symbol on the
+// host -- and every call processes [carried frames ++ new symbols] as one block that starts at a frame boundary, with the
+// same kernels, so each output row is computed exactly as a single call over the whole stream would compute it (nothing in
+// the pipeline reaches back further than the carried frames), and hands out only the rows no earlier call could: every
+// filtered reference symbol, channel-estimate row, autocorrelation row and MIB attempt exactly once, under its index in the
+// whole stream.  The carried frames are not transformed again (k_trk_fd starts behind them; the rows are the ones the
+// previous call computed, bit for bit) and frame offsets an earlier call attempted are not decoded again (k_trk_mib skips
+// them); the per-port passes of k_trk_ce still run over them (the raw estimates and filter windows they rebuild are cheap).
 namespace {
 struct TrkStreamCell {
   std::vector<double> fo, ft, late;          // metadata of the carried symbols
