@@ -118,7 +118,21 @@ __device__ __forceinline__ void qpsk_llr(cd2 sym, double np, double &l0, double 
 // value and its negative -- 4 fp64 adds per butterfly (round 2 added the three observations to every path metric one
 // by one: 12).  Ties keep predecessor 2j.
 #define VIT_ROTL6(s, k) ((((s) << (k)) | ((s) >> (6 - (k)))) & 63)
-template <int K>
+// Survivor words are built by PUSHING decisions (word = 2 word + decision): within a step the decision of new state
+// 32 b + j is pushed j-th into word b, so it ends at bit 31 - j of that word = bit (n ^ 31) of the 64-bit word for state n.
+// FAST (every observation finite: path metrics are finite or +inf, never NaN): the survivor metric is min(m0, m1) -- equal
+// to the select for every such pair, ties included -- and on the device the decision goes from the compare's carry
+// straight into the word (v_cmp writes VCC, v_addc shifts it in): 4 instructions per new state instead of 5.5, and no
+// compare result travels through an SGPR pair into three v_cndmask (round 3: 410 hazard s_nop per 6 steps).  !FAST keeps
+// the compare-and-select form, whose NaN behaviour is the reference's `<`.
+__host__ __device__ __forceinline__ void vit_push(unsigned &word, double m1, double m0) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm("v_cmp_lt_f64 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(word) : "v"(m1), "v"(m0) : "vcc");
+#else
+  word = (word << 1) | ((m1 < m0) ? 1u : 0u);
+#endif
+}
+template <int K, bool FAST>
 __host__ __device__ __forceinline__ void vit_step(double (&pm)[64], double r0, double r1, double r2, unsigned &lo, unsigned &hi) {
   lo = 0u; hi = 0u;
   // d[i], i = o0 + 2 o1 (o2 = 0): the four words whose last output bit is 0; the others are their negatives
@@ -135,21 +149,27 @@ __host__ __device__ __forceinline__ void vit_step(double (&pm)[64], double r0, d
       const int w1 = __builtin_parity(g1 & 0133) | (__builtin_parity(g1 & 0171) << 1) | (__builtin_parity(g1 & 0165) << 2);
       const double m0 = o0 + ((w0 < 4) ? d[w0 & 3] : -d[(7 - w0) & 3]);
       const double m1 = o1 + ((w1 < 4) ? d[w1 & 3] : -d[(7 - w1) & 3]);
-      const bool take1 = m1 < m0;                      // ties keep the lower-numbered predecessor
-      pm[b ? sb : sa] = take1 ? m1 : m0;
-      if (b) hi |= take1 ? (1u << j) : 0u; else lo |= take1 ? (1u << j) : 0u;
+      if (FAST) {
+        pm[b ? sb : sa] = fmin(m0, m1);
+        vit_push(b ? hi : lo, m1, m0);
+      } else {
+        const bool take1 = m1 < m0;                    // ties keep the lower-numbered predecessor
+        pm[b ? sb : sa] = take1 ? m1 : m0;
+        if (b) hi = (hi << 1) | (take1 ? 1u : 0u); else lo = (lo << 1) | (take1 ? 1u : 0u);
+      }
     }
   }
 }
-// all 40 steps of the trellis that starts in state ss; surv[t * stride]: bit n = decision of new state n at step t.
+// all 40 steps of the trellis that starts in state ss; surv[t * stride]: bit n ^ 31 = decision of new state n at step t.
 // Returns the metric of the forced end state ss.
+template <bool FAST>
 __host__ __device__ __forceinline__ double vit_trellis(const double *d0, const double *d1, const double *d2, int ss,
                                                        unsigned long long *surv, int stride) {
   double pm[64];
 #pragma unroll
   for (int s = 0; s < 64; ++s) pm[s] = (s == ss) ? 0.0 : INFINITY;
   unsigned lo, hi;
-#define VIT_S(K, T) do { vit_step<K>(pm, d0[T], d1[T], d2[T], lo, hi); surv[(size_t)(T) * stride] = ((unsigned long long)hi << 32) | lo; } while (0)
+#define VIT_S(K, T) do { vit_step<K, FAST>(pm, d0[T], d1[T], d2[T], lo, hi); surv[(size_t)(T) * stride] = ((unsigned long long)hi << 32) | lo; } while (0)
   for (int t6 = 0; t6 < 42; t6 += 6) {
     VIT_S(0, t6); VIT_S(1, t6 + 1); VIT_S(2, t6 + 2); VIT_S(3, t6 + 3);
     if (t6 + 4 < 40) { VIT_S(4, t6 + 4); VIT_S(5, t6 + 5); }
@@ -161,13 +181,15 @@ __host__ __device__ __forceinline__ double vit_trellis(const double *d0, const d
   for (int s = 0; s < 64; ++s) fin = (s == ss) ? pm[VIT_ROTL6(s, 4)] : fin;
   return fin;
 }
+// true when every one of the 3 x 40 observations is finite (the FAST form is then exact)
+__host__ __device__ __forceinline__ bool vit_finite(double x) { return x - x == 0.0; }
 // decoded bits of the trellis whose survivor words are surv[t * stride] and whose start = end state is ss
 __host__ __device__ __forceinline__ unsigned long long vit_traceback(const unsigned long long *surv, int stride, int ss) {
   int s = ss;
   unsigned long long bits = 0ull;                      // bit t = decoded bit c_est(t)
   for (int t = 39; t >= 0; --t) {
     bits |= (unsigned long long)((s >> 5) & 1) << t;
-    const int dec = (int)((surv[(size_t)t * stride] >> s) & 1ull);
+    const int dec = (int)((surv[(size_t)t * stride] >> (s ^ 31)) & 1ull);
     s = ((s << 1) & 63) | dec;
   }
   return bits;
@@ -194,8 +216,9 @@ __host__ __device__ __forceinline__ int pbch_crc_ok(unsigned long long bits, int
 // entry (they are dead once de-ratematched); called by all 64 lanes after a barrier behind the LLR writes; ok / bits40
 // are valid on every lane afterwards.
 // The trellis pass stays out of line: it takes ~240 registers of its own; inlined, whatever lives across it spills.
+template <bool FAST>
 static __device__ __noinline__ double pbch_trellis_pass(const double (*d_est)[40], int ss, unsigned long long *surv) {
-  return vit_trellis(d_est[0], d_est[1], d_est[2], ss, surv, 64);
+  return vit_trellis<FAST>(d_est[0], d_est[1], d_est[2], ss, surv, 64);
 }
 __device__ __forceinline__ void pbch_decode_wave(unsigned long long *surv, double (*d_est)[40], const int16_t *__restrict__ derm_inv,
                                                  int m_bit, int n_ports, int lane, int &ok, unsigned long long &bits40) {
@@ -218,8 +241,10 @@ __device__ __forceinline__ void pbch_decode_wave(unsigned long long *surv, doubl
   d_est[lane / 40][lane % 40] = dsum[0];
   if (lane + 64 < 120) d_est[(lane + 64) / 40][(lane + 64) % 40] = dsum[1];
   __syncthreads();
-  // lane = start state; the best end metric wins, the lowest start state among equals (ascending, strict < in the reference)
-  const double fin = pbch_trellis_pass(d_est, lane, surv + lane);
+  // lane = start state; the best end metric wins, the lowest start state among equals (ascending, strict < in the reference).
+  // Finite observations (every real capture) take the min / carry form of the step; anything else the compare-and-select form.
+  const bool finite = !__any(!(vit_finite(dsum[0]) && vit_finite(dsum[1])));
+  const double fin = finite ? pbch_trellis_pass<true>(d_est, lane, surv + lane) : pbch_trellis_pass<false>(d_est, lane, surv + lane);
   double best = (fin < INFINITY) ? fin : INFINITY;       // NaN / unreachable never win
   int best_ss = lane;
 #pragma unroll

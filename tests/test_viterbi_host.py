@@ -24,6 +24,7 @@ def libs():
     H = C.CDLL(LIB)
     H.vit_host_decode.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_int), C.POINTER(C.c_double)]
     H.vit_host_crc_ok.argtypes = [C.c_uint64, C.c_int]
+    H.vit_host_forms_agree.argtypes = [C.POINTER(C.c_double)]
     O = C.CDLL(os.path.join(ROOT, "oracle", "liblcs_oracle.so"))
     O.orc_conv_decode_tailbite.argtypes = [C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_uint8)]
     O.orc_conv_decode_tailbite.restype = None
@@ -73,7 +74,29 @@ def test_matches_oracle_on_random_and_tied_inputs(libs):
             d = -encode(msg) * 4.0 + rng.normal(0, 2.0, (3, 40))
         got, ref, _ = both(libs, d)
         assert np.array_equal(got, ref), f"case {k}"
+        # the two forms of the step (min + carry-chain survivor words / compare-and-select) agree bit for bit on finite input
+        dd = np.ascontiguousarray(d, np.float64)
+        assert libs[0].vit_host_forms_agree(dd.ctypes.data_as(C.POINTER(C.c_double))) == 1, f"case {k}"
     assert n_tie_cases == 40
+
+
+def test_non_finite_observations_take_the_reference_form(libs):
+    """An infinite or NaN observation (a zero channel estimate upstream) switches the decoder to the compare-and-select
+    form, whose `<` on NaN is the reference's: the result must still equal the oracle's exhaustive decoder."""
+    rng = np.random.default_rng(9)
+    for k in range(12):
+        d = rng.normal(0, 3, (3, 40))
+        d[rng.integers(0, 3), rng.integers(0, 40)] = [np.inf, -np.inf][k % 2]
+        got, ref, _ = both(libs, d)
+        assert np.array_equal(got, ref), f"case {k}"
+    # a NaN observation poisons every path metric: no start state wins in either implementation (the reference then traces
+    # back from an unset state -- undefined); here the decode reports "nothing" (all-zero bits, which fail the CRC)
+    d = rng.normal(0, 3, (3, 40))
+    d[1, 17] = np.nan
+    bits, ss, met = C.c_uint64(7), C.c_int(0), C.c_double(0)
+    dd = np.ascontiguousarray(d)
+    assert libs[0].vit_host_decode(dd.ctypes.data_as(C.POINTER(C.c_double)), C.byref(bits), C.byref(ss), C.byref(met)) == 0
+    assert ss.value == -1 and bits.value == 0
 
 
 def test_decodes_clean_codewords_and_crc(libs):
