@@ -320,10 +320,12 @@ int lcs_track_stats(lcs_ctx *ctx, int n_cells, int n_sym, double *ac_fd, double 
  * first call of a stream starts at slot 0 symbol 0 of a frame; every later call continues where the previous one ended
  * (any n_sym >= 1, the same cells in the same order).  Nothing is lost at the cut: the three-symbol window of filter_ce
  * (:176-201), the interpolation between filtered reference symbols (:383-477), the 72-deep history of do_ac_td (:343-371)
- * and the four-frame PBCH fifo (:552-745) all see the previous blocks' symbols, because the context carries the inputs of the
- * last 3-4 frames and processes them again in front of the new symbols (same kernels, so every row is bit-identical to
- * what ONE lcs_track_block call over the whole stream returns).  Every output row is handed out exactly once, by the first
- * call that can compute it, under its index in the whole stream:
+ * and the four-frame PBCH fifo (:552-745) all see the previous blocks' symbols, because the context carries the last 3-4
+ * frames -- as frequency-domain rows (get_fd's output) on the device -- in front of the new symbols and runs the same
+ * kernels over both (so every row is bit-identical to what ONE lcs_track_block call over the whole stream returns); the
+ * carried frames are not transformed again, and frame offsets an earlier call attempted are not decoded again.  A call that
+ * fails leaves the stream where it was.  Every output row is handed out exactly once, by the first call that can compute it,
+ * under its index in the whole stream:
  *   syms      [n_cells][n_sym][72]: get_fd of the symbols of this call
  *   meas, ac_fd, ac_td [n_cells][4][max_rs][9 | 12 | 72 complex]: the filtered reference symbols that became available (a
  *             reference symbol's filter needs the NEXT one, so the last one of a block arrives with the next call); n_meas

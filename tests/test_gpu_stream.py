@@ -118,3 +118,29 @@ def test_kalibrate_on_recorded_buffer(pkg):
         # a correction that moves the grid by +35 kHz finds the same cell on the shifted grid
         best2, resid2, _ = pkg.kalibrate(S, cap, FC, FC, FS, ppm=20.0, correction=1.0 + 35e3 / FC)
         assert best2.n_id_cell() == 277 and abs(resid2 - resid) < 1.0
+
+
+def test_complex64_batch_on_a_context_with_an_open_stream(pkg):
+    """A context whose stream graph is open cannot allocate the fp16 operand buffers (the graph holds the workspace): a
+    complex<float> batch of one buffer (what fits the stream's workspace) then keeps the fp32 correlation kernel instead of
+    failing (round-3 advisory), and the results are those of a fresh context's fp16 kernel."""
+    import torch
+    g = golden("capbuf_0000")["iq_u8"]
+    cap = iq_u8_to_capbuf(g).astype(np.complex64)
+    d = torch.from_numpy(cap[None, :]).cuda()
+    f = np.array([35e3])
+    with pkg.Searcher(0) as S, pkg.Searcher(0) as F:
+        S.stream_open(pkg.FMT_C64, 153600, FC, FC, FS)
+        a = S.search_batch(d.data_ptr(), pkg.FMT_C64, 1, 153600, f, np.array([FC]), np.array([FC]), FS, pkg.STAGE_FULL)[0]
+        assert S.last_xcorr_info()[0].startswith("k_xcorr_mfma_blk")
+        b = F.search_batch(d.data_ptr(), pkg.FMT_C64, 1, 153600, f, np.array([FC]), np.array([FC]), FS, pkg.STAGE_FULL)[0]
+        assert F.last_xcorr_info()[0] == "k_xcorr_f16x3"
+        assert [_key(c)[:4] for c in a] == [_key(c)[:4] for c in b] and [c.n_id_cell() for c in a] == [277, 271]
+        for x, y in zip(a, b):
+            assert (x.ind, x.n_id_1, x.n_ports, x.n_rb_dl, x.sfn) == (y.ind, y.n_id_1, y.n_ports, y.n_rb_dl, y.sfn)
+            assert abs(x.pss_pow - y.pss_pow) < 1e-5 * y.pss_pow and abs(x.freq_superfine - y.freq_superfine) < 1e-3
+        # the stream still works afterwards
+        S.stream_push(cap, 35e3)
+        cells, _, _ = S.stream_collect()
+        assert [c.n_id_cell() for c in cells] == [277, 271]
+        S.stream_close()
