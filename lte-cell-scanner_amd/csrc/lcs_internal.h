@@ -150,6 +150,7 @@ struct lcs_ctx {
   int *texp16 = nullptr;             // per template column: power-of-two scale exponent
   float *tsc16 = nullptr;            // per template column: 2^-(k_x + k_t)
   unsigned *xmax16 = nullptr;        // per slot: bits of the largest |component|
+  unsigned *xpart16 = nullptr;       // per slot: 128 partial maxima (one per workgroup of the read-only maximum pass)
   bool f16_ready = false, use_f16 = false;
   bool src_u8 = false;               // the resident buffers came from a u8 source: the fp64 stages read cap8
   const float2 *src32 = nullptr;     // complex<float> batches read in place: the CALLER's buffers, which the fp64 stages read (no cap32 copy)

@@ -49,25 +49,44 @@ __device__ __forceinline__ void f16_split(float v, _Float16 &hi, _Float16 &lo) {
 // Round 4: no copy at all when the caller's buffers can be read in place (even n_cap, 16-byte aligned): the fp64 stages read
 // them through CapSrc (lcs_cap_src), so only the per-buffer maximum is taken here -- a read-only pass with four 16-byte loads
 // in flight per lane.
-__global__ __launch_bounds__(256) void k_f16_max4(const float4 *__restrict__ src, uint32_t n_cap, unsigned *__restrict__ xmax_bits) {
+#define F16_MAX_ILP 4           // independent 16-byte loads per lane, all in flight before the first use
+#define F16_MAXP 128            // partial maxima per buffer (workgroups of k_f16_max4 per buffer: 75 for 153600 samples)
+__global__ __launch_bounds__(256) void k_f16_max4(const float4 *__restrict__ src, uint32_t n_cap, unsigned *__restrict__ xpart) {
   LCS_TAIL_PRIO();
+  __shared__ float wmax[4];
   const int slot = blockIdx.y;
   const uint32_t n4 = n_cap / 2;
   const float4 *b = src + (size_t)slot * n4;
+  // workgroup w covers float4s [w * 1024, w * 1024 + 1024): lane t takes t, t + 256, t + 512, t + 768 (no loop, four
+  // loads outstanding per lane, 64 KB per wave-instruction group coalesced)
+  const uint32_t i0 = blockIdx.x * (256 * F16_MAX_ILP) + threadIdx.x;
+  float4 v[F16_MAX_ILP];
+#pragma unroll
+  for (int k = 0; k < F16_MAX_ILP; ++k) {
+    const uint32_t i = i0 + 256 * k;
+    v[k] = b[min(i, n4 - 1)];                 // unconditional (a branch per load would serialise them); the tail re-reads the last pair
+  }
   float m = 0.f;
-  const uint32_t step = gridDim.x * blockDim.x;
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  for (; i + 3 * step < n4; i += 4 * step) {
-    const float4 v0 = b[i], v1 = b[i + step], v2 = b[i + 2 * step], v3 = b[i + 3 * step];
-    m = fmaxf(m, fmaxf(fmaxf(fmaxf(fabsf(v0.x), fabsf(v0.y)), fmaxf(fabsf(v0.z), fabsf(v0.w))), fmaxf(fmaxf(fabsf(v1.x), fabsf(v1.y)), fmaxf(fabsf(v1.z), fabsf(v1.w)))));
-    m = fmaxf(m, fmaxf(fmaxf(fmaxf(fabsf(v2.x), fabsf(v2.y)), fmaxf(fabsf(v2.z), fabsf(v2.w))), fmaxf(fmaxf(fabsf(v3.x), fabsf(v3.y)), fmaxf(fabsf(v3.z), fabsf(v3.w)))));
-  }
-  for (; i < n4; i += step) {
-    const float4 v = b[i];
-    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
-  }
+#pragma unroll
+  for (int k = 0; k < F16_MAX_ILP; ++k) m = fmaxf(m, fmaxf(fmaxf(fabsf(v[k].x), fabsf(v[k].y)), fmaxf(fabsf(v[k].z), fabsf(v[k].w))));
   for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_down(m, off));
-  if ((threadIdx.x & 63) == 0 && m > 0.f && m < INFINITY) atomicMax(xmax_bits + slot, __float_as_uint(m));     // non-negative floats order like their bits
+  // one plain store per workgroup: 300 atomicMax per buffer on ONE address took 145 us per 64 buffers, 7 x the pass itself
+  if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float w = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+    xpart[(size_t)slot * F16_MAXP + blockIdx.x] = (w > 0.f && w < INFINITY) ? __float_as_uint(w) : 0u;     // non-negative floats order like their bits
+  }
+}
+__global__ __launch_bounds__(128) void k_f16_max_fold(const unsigned *__restrict__ xpart, int n_part, unsigned *__restrict__ xmax_bits) {
+  LCS_TAIL_PRIO();
+  const int slot = blockIdx.x, t = threadIdx.x;
+  __shared__ unsigned w2[2];
+  unsigned m = (t < n_part) ? xpart[(size_t)slot * F16_MAXP + t] : 0u;
+  for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_down((int)m, off));
+  if ((t & 63) == 0) w2[t >> 6] = m;
+  __syncthreads();
+  if (t == 0) xmax_bits[slot] = max(w2[0], w2[1]);
 }
 // the same maximum over an existing cap32 (odd n_cap)
 __global__ __launch_bounds__(256) void k_f16_max(const float2 *__restrict__ cap32, uint32_t n_cap, unsigned *__restrict__ xmax_bits) {
@@ -103,14 +122,24 @@ __global__ __launch_bounds__(256) void k_f16_ingest(const float2 *__restrict__ s
   const int k = f16_scale_exp(__uint_as_float(xmax_bits[slot]));
   const float2 *c = src32 + (size_t)slot * n_cap;
   if (PAIRS) {
+    // workgroup w covers sample pairs [w * 1024, w * 1024 + 1024) of the padded slot, four independent pairs per lane
     const float4 *c4 = reinterpret_cast<const float4 *>(c);
     uint2 *oh = reinterpret_cast<uint2 *>(cap16h + (size_t)slot * stride), *ol = reinterpret_cast<uint2 *>(cap16l + (size_t)slot * stride);
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < stride / 2; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t i0 = (size_t)blockIdx.x * (256 * F16_MAX_ILP) + threadIdx.x;
+    float4 v[F16_MAX_ILP];
+#pragma unroll
+    for (int q = 0; q < F16_MAX_ILP; ++q) {
+      const size_t i = i0 + 256 * q;
+      v[q] = c4[min(i, (size_t)n_cap / 2 - 1)];        // unconditional loads: all four in flight; lanes past the data mask below
+    }
+#pragma unroll
+    for (int q = 0; q < F16_MAX_ILP; ++q) {
+      const size_t i = i0 + 256 * q;
+      if (i >= stride / 2) continue;
       uint2 h = make_uint2(0u, 0u), l = make_uint2(0u, 0u);
       if (2 * i < n_cap) {
-        const float4 v = c4[i];
-        f16_split_sample(make_float2(v.x, v.y), k, h.x, l.x);
-        f16_split_sample(make_float2(v.z, v.w), k, h.y, l.y);
+        f16_split_sample(make_float2(v[q].x, v[q].y), k, h.x, l.x);
+        f16_split_sample(make_float2(v[q].z, v[q].w), k, h.y, l.y);
       }
       oh[i] = h;
       ol[i] = l;
@@ -319,8 +348,12 @@ int lcs_launch_ingest_f16(lcs_ctx *c, const void *d_src, int n_buf, uint32_t n_c
     // read in place: no copy into cap32; the fp64 stages read the caller's buffers (they stay valid until the batch is
     // collected, include/lcs.h), the maximum is a read-only pass
     c->src32 = static_cast<const float2 *>(d_src);
-    hipLaunchKernelGGL(k_f16_max4, dim3(40, n_buf), dim3(256), 0, c->stream, static_cast<const float4 *>(d_src), n_cap, c->xmax16);
-    hipLaunchKernelGGL((k_f16_ingest<true>), dim3(80, n_buf), dim3(256), 0, c->stream, c->src32, n_cap, c->xmax16, c->cap16h, c->cap16l);
+    const unsigned per_wg = 256 * F16_MAX_ILP, n_part = (n_cap / 2 + per_wg - 1) / per_wg;
+    if (n_part > F16_MAXP) { c->err = "capture buffer too long for the fp16 path's partial maxima"; return LCS_ERR_BAD_ARG; }     // > 262144 samples: check_common refuses those
+    hipLaunchKernelGGL(k_f16_max4, dim3(n_part, n_buf), dim3(256), 0, c->stream, static_cast<const float4 *>(d_src), n_cap, c->xpart16);
+    hipLaunchKernelGGL(k_f16_max_fold, dim3(n_buf), dim3(128), 0, c->stream, c->xpart16, (int)n_part, c->xmax16);
+    hipLaunchKernelGGL((k_f16_ingest<true>), dim3((unsigned)((lcs_cap8_stride(n_cap) / 2 + per_wg - 1) / per_wg), n_buf), dim3(256), 0, c->stream, c->src32,
+                       n_cap, c->xmax16, c->cap16h, c->cap16l);
   } else {
     int rc = lcs_launch_ingest(c, d_src, LCS_FMT_C64, n_buf, n_cap);
     if (rc) return rc;
