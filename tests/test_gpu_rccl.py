@@ -27,7 +27,8 @@ def _json_line(stdout):
 def test_bench_forced_dist_over_rccl():
     """bench.py --gpus 1 --force-dist --dist-backend nccl takes the world > 1 branch with one rank: same verified result,
     collectives reported, and a rate close to the plain run's (the all-gather is asynchronous and waited for a step later)."""
-    common = ["--steps", "3", "--warmup", "1", "--batch", "32", "--batches-per-step", "8", "--no-cpu-baseline", "--no-dense"]
+    steps, K = 4, 12
+    common = ["--steps", str(steps), "--warmup", "1", "--batch", "64", "--batches-per-step", str(K), "--no-cpu-baseline", "--no-dense"]
     plain = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common, env=ENV, capture_output=True, text=True, timeout=900)
     assert plain.returncode == 0, plain.stderr[-3000:]
     forced = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--dist-backend", "nccl"] + common,
@@ -39,10 +40,12 @@ def test_bench_forced_dist_over_rccl():
     c = b["config"]["collectives"]
     assert c["backend"] == "nccl" and c["world"] == 1 and len(c["gathered_records_last_step"]) == 1
     # the records of the last step went through the all-gather: as many as the run found per step
-    assert c["gathered_records_last_step"][0] == sum(b["config"]["cells_per_distinct_batch"][d % 4] for d in range(3 * 8 - 8, 3 * 8))
+    assert c["gathered_records_last_step"][0] == sum(b["config"]["cells_per_distinct_batch"][d % 4] for d in range(steps * K - K, steps * K))
     assert len(b["config"]["devices"]) == 1 and "RCCL" in b["config"]["parallelism"]
     assert b["config"]["cells_per_distinct_batch"] == a["config"]["cells_per_distinct_batch"]
-    assert b["value"] > 0.85 * a["value"], (a["value"], b["value"])      # short runs; the 2 % comparison is in profiles/r04
+    # round 4 found the multi-rank branch at 0.80 x (per-buffer Python packing of the gathered records); short runs are noisy,
+    # the 1 % comparison at full size is profiles/r04/bench_forced_dist_n1.json
+    assert b["value"] > 0.88 * a["value"], (a["value"], b["value"])
 
 
 WORKER = textwrap.dedent("""
