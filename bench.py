@@ -309,7 +309,7 @@ def track_bench(pkg, args, rank, world, local_rank, dist):
     # Two contexts, one host thread each (the shape of host/TrackCells.cpp's tracker threads): while one context's block is on
     # the GPU the other thread prepares, launches and unpacks its own -- lcs_track_block is synchronous per context, the
     # library call releases the interpreter lock.  Round 3 ran ONE context from one thread: 1.15 ms of GPU work in a 3.3 ms
-    # step.  Every block is a full, independent pass (same cells, same symbols); a step = one block.
+    # step.  Every block is a full, independent pass (same cells, same symbols); a step = one block.  Four contexts by default.
     import threading
     depth = max(1, args.pipeline)
     ctxs = [S] + [pkg.Searcher(dev_i) for _ in range(depth - 1)]
@@ -505,7 +505,7 @@ def main():
     if args.batch is None:
         args.batch = 64 if args.stage == "track" else 128
     if args.pipeline is None:
-        args.pipeline = 3 if args.stage == "track" else 2      # contexts in flight (track: profiles/r04/bench_track_n1.json)
+        args.pipeline = 4 if args.stage == "track" else 2      # contexts in flight (track: profiles/r04/experiments/tracker_depth.txt)
     if args.batches_per_step is None:
         args.batches_per_step = max(1, 12800 // args.batch)
 

@@ -30,12 +30,19 @@ __device__ __forceinline__ double trk_sym_len(int cp_type, int sym) {           
 }
 
 // Per cell: RS_DL, the running bulk phase of get_fd at every symbol (:151-153), and per port the list of symbols that
-// carry its reference symbols.  128 threads: lanes 0..59 one RS row each, thread 64 the phase walk, threads 65..68
-// the per-port lists.
+// carry its reference symbols.  128 threads.  The bulk phase is a scalar recurrence with a WRAP per step (one lane walks it,
+// as the reference does), but nothing else about it is serial: the per-symbol increments are formed by all lanes into LDS
+// first and the results leave through LDS afterwards (round 3 loaded a frequency offset and stored a phase inside every step
+// of the walk: 0.29 us per step, the latency of the load -- 282 us of the block's 1.09 ms), and a port's symbol list is one
+// frame's pattern repeated (round 3: four lanes walking all symbols with a global read each).
+#define TRK_PREP_CHUNK 1024
 __global__ __launch_bounds__(128) void k_trk_prep(lcs_track_cell *__restrict__ cells, int n_sym, const double *__restrict__ freq_off,
                                                  const uint32_t *__restrict__ pn_jump, double *__restrict__ rs /*[c][140][24]*/,
                                                  double *__restrict__ shift /*[c][140][4]*/, double *__restrict__ bpo /*[c][n_sym]*/,
                                                  int *__restrict__ rs_idx /*[c][4][max_rs]*/, int *__restrict__ n_rs /*[c][4]*/, int max_rs) {
+  __shared__ double s_inc[TRK_PREP_CHUNK], s_b[TRK_PREP_CHUNK];
+  __shared__ double s_sh[140 * 4];
+  __shared__ int s_fl[4][44], s_cnt[4];
   const int cell = blockIdx.x, tid = threadIdx.x;
   const lcs_track_cell c = cells[cell];
   const int n_symb = trk_n_symb(c), id = c.n_id_2 + 3 * c.n_id_1;
@@ -47,26 +54,45 @@ __global__ __launch_bounds__(128) void k_trk_prep(lcs_track_cell *__restrict__ c
     const int sym = (t == 2) ? (n_symb - 3) : t, row = slot * n_symb + sym;
     rs_dl_row(slot, t, id, c.cp_type, n_symb, pn_jump, rs + ((size_t)cell * 140 + row) * 24, sh + row * 4);
   }
-  if (tid == 64) {
-    double b = c.bulk_phase_offset;
-    int sym = 0;
-    for (int i = 0; i < n_sym; ++i) {
-      b = trk_wrap(b + 2 * M_PI * trk_sym_len(c.cp_type, sym) * (1 / (FS_LTE / 16)) * -freq_off[(size_t)cell * n_sym + i], -M_PI, M_PI);
-      bpo[(size_t)cell * n_sym + i] = b;
-      sym = (sym + 1 == n_symb) ? 0 : sym + 1;
+  // the bulk phase, TRK_PREP_CHUNK symbols at a time
+  double b = c.bulk_phase_offset;                     // carried by thread 64
+  for (int base = 0; base < n_sym; base += TRK_PREP_CHUNK) {
+    const int n = min(TRK_PREP_CHUNK, n_sym - base);
+    for (int e = tid; e < n; e += 128) {
+      const int i = base + e;
+      s_inc[e] = 2 * M_PI * trk_sym_len(c.cp_type, i % n_symb) * (1 / (FS_LTE / 16)) * -freq_off[(size_t)cell * n_sym + i];
     }
-    cells[cell].bulk_phase_offset = b;
+    __syncthreads();
+    if (tid == 64)
+      for (int e = 0; e < n; ++e) { b = trk_wrap(b + s_inc[e], -M_PI, M_PI); s_b[e] = b; }
+    __syncthreads();
+    for (int e = tid; e < n; e += 128) bpo[(size_t)cell * n_sym + base + e] = s_b[e];
+    __syncthreads();
+  }
+  if (tid == 64) cells[cell].bulk_phase_offset = b;
+  // per port: the rows of ONE frame that carry its reference symbols, then the list = that pattern frame after frame
+  for (int e = tid; e < 140 * 4; e += 128) s_sh[e] = sh[e];
+  __syncthreads();
+  const int F = 20 * n_symb;
+  if (tid < 4) {
+    int cnt = 0;
+    if (tid < c.n_ports)
+      for (int row = 0; row < F; ++row)
+        if (s_sh[row * 4 + tid] >= 0.0 && cnt < 44) s_fl[tid][cnt++] = row;
+    s_cnt[tid] = cnt;
   }
   __syncthreads();
-  if (tid >= 65 && tid < 69) {
-    const int port = tid - 65;
-    int m = 0;
-    if (port < c.n_ports)
-      for (int i = 0; i < n_sym; ++i) {
-        const int row = i % (20 * n_symb);
-        if (sh[row * 4 + port] >= 0.0 && m < max_rs) rs_idx[((size_t)cell * 4 + port) * max_rs + m++] = i;
-      }
-    n_rs[cell * 4 + port] = m;
+  for (int port = 0; port < 4; ++port) {
+    const int cnt = s_cnt[port];
+    int total = 0;
+    if (cnt > 0) {
+      const int full = n_sym / F, rem = n_sym - full * F;
+      int tail = 0;
+      for (int k = 0; k < cnt; ++k) tail += (s_fl[port][k] < rem) ? 1 : 0;
+      total = min(full * cnt + tail, max_rs);
+      for (int m = tid; m < total; m += 128) rs_idx[((size_t)cell * 4 + port) * max_rs + m] = (m / cnt) * F + s_fl[port][m % cnt];
+    }
+    if (tid == 0) n_rs[cell * 4 + port] = total;
   }
 }
 
@@ -141,7 +167,8 @@ __device__ __forceinline__ cd2 trk_interp72(const double2 *__restrict__ filt, in
 
 // One workgroup per (port, cell): raw channel estimates on the reference symbols, filter_ce + powers + FOE/TOE
 // measurements for every reference symbol that has both neighbours, then the 2-D interpolation onto every symbol.
-#define TRK_CE_THREADS 256
+#define TRK_CE_THREADS 512
+#define TRK_CE_SYMS 512       // symbols whose interpolation brackets are held in LDS at a time
 __global__ __launch_bounds__(TRK_CE_THREADS) void k_trk_ce(const lcs_track_cell *__restrict__ cells, int n_sym, const double2 *__restrict__ syms,
                                                           const double *__restrict__ freq_off, const double *__restrict__ frame_timing,
                                                           const double *__restrict__ rs, const double *__restrict__ shift,
@@ -251,31 +278,46 @@ __global__ __launch_bounds__(TRK_CE_THREADS) void k_trk_ce(const lcs_track_cell 
   if (tid == 0) { n_meas[cp] = nf; ce_upto[cp] = upto; }
   double2 *ce_p = ce + cp * n_sym * 72;
   double *pw_p = ce_pw + cp * n_sym * 4;
-  for (int e = tid; e < upto * 72; e += TRK_CE_THREADS) {
-    const int i = e / 72, t = e % 72;
-    int lo = 0, hi = nf - 2;                                      // largest j <= nf - 2 with idx[j + 1] <= i (0 when i is in front of all)
-    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (idx[mid + 1] <= i) lo = mid; else hi = mid - 1; }
-    const int j = lo;
-    const int i_prev = idx[j + 1], i_cur = idx[j + 2];
-    const int sym_prev = i_prev % n_symb;
-    double time_diff;
-    if (port > 2) time_diff = 0.0005;                             // the reference's `port_num>2`
-    else if (c.cp_type == LCS_CP_EXTENDED) time_diff = 3 * (128 + 32) * (1 / (FS_LTE / 16));
-    else if (sym_prev == 0) time_diff = 4 * (128 + 9) * (1 / (FS_LTE / 16));
-    else time_diff = (2 * (128 + 9) + (128 + 10)) * (1 / (FS_LTE / 16));
-    double time_offset = 0;
-    for (int q = i_prev; q < i; ++q) {                            // the reference's running sum, same order
-      const int sy = q % n_symb;
-      if (c.cp_type == LCS_CP_EXTENDED) time_offset += (128 + 32) * (1 / (FS_LTE / 16));
-      else if (sy == 6) time_offset += (128 + 10) * (1 / (FS_LTE / 16));
-      else time_offset += (128 + 9) * (1 / (FS_LTE / 16));
+  // Per SYMBOL first (round 3 repeated this for each of its 72 subcarriers -- a binary search over the symbol list in
+  // global memory and the running time sum, 70 k times per port): the bracketing pair j and the weight, TRK_CE_SYMS symbols
+  // at a time into LDS; then the 72 subcarriers of those symbols.
+  __shared__ int s_j[TRK_CE_SYMS];
+  __shared__ double s_w[TRK_CE_SYMS];
+  for (int base = 0; base < upto; base += TRK_CE_SYMS) {
+    const int ns = min(TRK_CE_SYMS, upto - base);
+    __syncthreads();
+    for (int q0 = tid; q0 < ns; q0 += TRK_CE_THREADS) {
+      const int i = base + q0;
+      int lo = 0, hi = nf - 2;                                    // largest j <= nf - 2 with idx[j + 1] <= i (0 when i is in front of all)
+      while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (idx[mid + 1] <= i) lo = mid; else hi = mid - 1; }
+      const int j = lo;
+      const int i_prev = idx[j + 1];
+      const int sym_prev = i_prev % n_symb;
+      double time_diff;
+      if (port > 2) time_diff = 0.0005;                           // the reference's `port_num>2`
+      else if (c.cp_type == LCS_CP_EXTENDED) time_diff = 3 * (128 + 32) * (1 / (FS_LTE / 16));
+      else if (sym_prev == 0) time_diff = 4 * (128 + 9) * (1 / (FS_LTE / 16));
+      else time_diff = (2 * (128 + 9) + (128 + 10)) * (1 / (FS_LTE / 16));
+      double time_offset = 0;
+      for (int q = i_prev; q < i; ++q) {                          // the reference's running sum, same order
+        const int sy = q % n_symb;
+        if (c.cp_type == LCS_CP_EXTENDED) time_offset += (128 + 32) * (1 / (FS_LTE / 16));
+        else if (sy == 6) time_offset += (128 + 10) * (1 / (FS_LTE / 16));
+        else time_offset += (128 + 9) * (1 / (FS_LTE / 16));
+      }
+      s_j[q0] = j;
+      s_w[q0] = time_offset / time_diff;
     }
-    (void)i_cur;
-    const double w = time_offset / time_diff;
-    const int sh_a = (int)sh[(i_prev % per_frame) * 4 + port], sh_b = (int)sh[(idx[j + 2] % per_frame) * 4 + port];
-    const cd2 a = trk_interp72(filt_p + j * 12, sh_a, t), b = trk_interp72(filt_p + (j + 1) * 12, sh_b, t);
-    st(&ce_p[e], cadd(a, cscale(csub(b, a), w)));
-    if (t < 4) pw_p[i * 4 + t] = fm[j * 4 + t] + (fm[(j + 1) * 4 + t] - fm[j * 4 + t]) * w;
+    __syncthreads();
+    for (int e = tid; e < ns * 72; e += TRK_CE_THREADS) {
+      const int q0 = e / 72, t = e % 72, i = base + q0;
+      const int j = s_j[q0];
+      const double w = s_w[q0];
+      const int sh_a = (int)sh[(idx[j + 1] % per_frame) * 4 + port], sh_b = (int)sh[(idx[j + 2] % per_frame) * 4 + port];
+      const cd2 a = trk_interp72(filt_p + j * 12, sh_a, t), b = trk_interp72(filt_p + (j + 1) * 12, sh_b, t);
+      st(&ce_p[(size_t)i * 72 + t], cadd(a, cscale(csub(b, a), w)));
+      if (t < 4) pw_p[i * 4 + t] = fm[j * 4 + t] + (fm[(j + 1) * 4 + t] - fm[j * 4 + t]) * w;
+    }
   }
 }
 

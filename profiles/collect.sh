@@ -39,6 +39,6 @@ timeout 200 $B --steps 20 --warmup 5 --input-host --no-cpu-baseline --no-dense >
 timeout 120 $B --stage pss --no-cpu-baseline > "$OUT/bench_pss_n1.json" 2> "$OUT/bench_pss_n1.err"
 timeout 120 $B --stage single --steps 200 --warmup 20 > "$OUT/bench_single_n1.json" 2> "$OUT/bench_single_n1.err"
 timeout 120 $B --stage stream --steps 400 --warmup 20 > "$OUT/bench_stream_n1.json" 2> "$OUT/bench_stream_n1.err"
-timeout 120 $B --stage track > "$OUT/bench_track_n1.json" 2> "$OUT/bench_track_n1.err"
+timeout 120 $B --stage track --steps 60 --warmup 6 > "$OUT/bench_track_n1.json" 2> "$OUT/bench_track_n1.err"
 timeout 200 $B --steps 10 --warmup 2 --batches-per-step 20 --input c64 --no-cpu-baseline > "$OUT/bench_full_n1_c64_f16_kernel.json" 2> "$OUT/bench_c64.err"
 echo collected > "$OUT/done"
