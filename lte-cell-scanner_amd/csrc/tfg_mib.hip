@@ -185,7 +185,6 @@ __global__ __launch_bounds__(TFG_THREADS) void k_tfg(const lcs_cell *__restrict_
   __shared__ cd2 W[128];
   __shared__ cd2 win[TFG_SYM][128];
   __shared__ int s_loc[TFG_SYM], s_row[TFG_SYM];
-  __shared__ cd2 s_rot[TFG_SYM];            // fshift rotation of each window's first sample
   const int tid = threadIdx.x;
   if (tid < 128) { double s, c; sincospi((double)tid / 64.0, &s, &c); W[tid] = mk(c, -s); }
   __syncthreads();
@@ -223,16 +222,8 @@ __global__ __launch_bounds__(TFG_THREADS) void k_tfg(const lcs_cell *__restrict_
       }
       if (row >= n_ofdm) row = -1;
       s_row[tid] = row;
-      const int loc = (row >= 0) ? d_round_i(tsi[row]) : 0;
-      s_loc[tid] = loc;
-      double sn, cs;
-      sincospi(kk * (double)loc, &sn, &cs);
-      s_rot[tid] = mk(cs, sn);
+      s_loc[tid] = (row >= 0) ? d_round_i(tsi[row]) : 0;
     }
-    // exp(j pi kk (loc + n)) = exp(j pi kk loc) exp(j pi kk n): a lane's four samples share n (the windows are 128 long, the
-    // stride of the loop is 256), so one sincospi per lane and job instead of one per sample
-    cd2 rot_n;
-    { double sn, cs; sincospi(kk * (double)(tid & 127), &sn, &cs); rot_n = mk(cs, sn); }
     __syncthreads();
     for (int e = tid; e < TFG_SYM * 128; e += TFG_THREADS) {
       const int s = e >> 7, n = e & 127;
@@ -241,7 +232,9 @@ __global__ __launch_bounds__(TFG_THREADS) void k_tfg(const lcs_cell *__restrict_
         const long src = (long)s_loc[s] + n;
         if (src >= 0 && (uint64_t)src < n_cap) {
           const double2 x = cap_at(cap, (size_t)src);
-          v = cmul(mk(x.x, x.y), cmul(s_rot[s], rot_n));
+          double sn, cs;
+          sincospi(kk * (double)src, &sn, &cs);
+          v = cmul(mk(x.x, x.y), mk(cs, sn));
         } else sc[CS_OOB] = 1.0;               // any sample of a DFT window outside the buffer: the reference would read out of bounds
       }
       win[s][n] = v;
