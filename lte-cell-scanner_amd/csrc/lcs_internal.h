@@ -214,10 +214,11 @@ struct lcs_ctx {
   double *trk_meta = nullptr, *trk_rs = nullptr, *trk_fmeta = nullptr, *trk_pw = nullptr;
   int *trk_idx = nullptr, *trk_small = nullptr;
   lcs_track_cell *trk_cells = nullptr;
-  int trk_cells_cap = 0, trk_sym_cap = 0;
+  int trk_cells_cap = 0, trk_sym_cap = 0;     // the workspace holds any block of up to this many cells x symbols
+  int trk_last_cells = 0, trk_last_sym = 0;   // shape of the block the last lcs_track_block call processed (lcs_track_stats reads it)
   double2 *trk_acfd = nullptr, *trk_actd = nullptr, *trk_syncce = nullptr;   // lcs_track_stats outputs
   double *trk_sync = nullptr;
-  int trk_stat_cells = 0, trk_stat_sym = 0;
+  int trk_stat_cells = 0, trk_stat_sym = 0;   // capacity of the statistics buffers
   void *trk_stream = nullptr;        // carried state of lcs_track_stream_block (tracker.hip)
   void *trk_hpin = nullptr;          // reusable host staging block of lcs_track_block (malloc): metadata up, measurement tables down
   size_t trk_hpin_bytes = 0;

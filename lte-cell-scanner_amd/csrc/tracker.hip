@@ -526,24 +526,30 @@ struct TrkCarried {
   const int *mib_first;    // host [n_cells]: frame offsets below were attempted by an earlier call and are not decoded again
 };
 
-// The workspace is laid out for one block shape
+// The workspace grows to the largest (cells, symbols) shape seen and serves every smaller one: TrkLayout places the arrays
+// by the block's own shape, every array's size is monotone in both.  (Round 3 reallocated all eleven buffers -- eleven
+// device-wide synchronisations -- whenever the shape changed, which the continuous form does with every call whose block is
+// not a whole number of frames.)
 int trk_ensure_ws(lcs_ctx *c, int n_cells, int n_sym) {
-  if (n_cells == c->trk_cells_cap && n_sym == c->trk_sym_cap) return LCS_OK;
-  const int rs_cap = n_sym / 3 + 4, n_off = std::max(0, n_sym / 120 - 3);     // as TrkLayout
-  const size_t N = (size_t)n_cells * n_sym, C4 = (size_t)n_cells * 4;
-  int rc;
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  // the caps describe a complete workspace or nothing: if an allocation below fails, later calls (and
-  // lcs_track_stats, which trusts them) must not take the half-replaced buffers for the old shape
-  c->trk_cells_cap = c->trk_sym_cap = 0;
-  c->trk_stat_cells = c->trk_stat_sym = 0;
-  if ((rc = trk_alloc(c, &c->trk_td, N * 128)) || (rc = trk_alloc(c, &c->trk_meta, N * 4)) || (rc = trk_alloc(c, &c->trk_cells, (size_t)n_cells)) ||
-      (rc = trk_alloc(c, &c->trk_syms, N * 72)) || (rc = trk_alloc(c, &c->trk_rs, (size_t)n_cells * 140 * 28)) ||
-      (rc = trk_alloc(c, &c->trk_idx, C4 * (rs_cap + 1))) || (rc = trk_alloc(c, &c->trk_raw, C4 * rs_cap * 24)) ||
-      (rc = trk_alloc(c, &c->trk_fmeta, C4 * rs_cap * (4 + TRK_MEAS))) || (rc = trk_alloc(c, &c->trk_ce, C4 * n_sym * 72)) ||
-      (rc = trk_alloc(c, &c->trk_pw, C4 * n_sym * 4)) || (rc = trk_alloc(c, &c->trk_small, C4 * 2 + (size_t)n_cells * (n_off + 1) * 3 + n_cells)))
-    return rc;
-  c->trk_cells_cap = n_cells; c->trk_sym_cap = n_sym;
+  c->trk_last_cells = c->trk_last_sym = 0;
+  if (n_cells > c->trk_cells_cap || n_sym > c->trk_sym_cap) {
+    const int cc = std::max(n_cells, c->trk_cells_cap), cs = std::max(n_sym + n_sym / 8, c->trk_sym_cap);     // head room for the tail's varying length
+    const int rs_cap = cs / 3 + 4, n_off = std::max(0, cs / 120 - 3);     // as TrkLayout
+    const size_t N = (size_t)cc * cs, C4 = (size_t)cc * 4;
+    int rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    // the caps describe a complete workspace or nothing: if an allocation below fails, later calls must not take the
+    // half-replaced buffers for the old shape
+    c->trk_cells_cap = c->trk_sym_cap = 0;
+    if ((rc = trk_alloc(c, &c->trk_td, N * 128)) || (rc = trk_alloc(c, &c->trk_meta, N * 4)) || (rc = trk_alloc(c, &c->trk_cells, (size_t)cc)) ||
+        (rc = trk_alloc(c, &c->trk_syms, N * 72)) || (rc = trk_alloc(c, &c->trk_rs, (size_t)cc * 140 * 28)) ||
+        (rc = trk_alloc(c, &c->trk_idx, C4 * (rs_cap + 1))) || (rc = trk_alloc(c, &c->trk_raw, C4 * rs_cap * 24)) ||
+        (rc = trk_alloc(c, &c->trk_fmeta, C4 * rs_cap * (4 + TRK_MEAS))) || (rc = trk_alloc(c, &c->trk_ce, C4 * cs * 72)) ||
+        (rc = trk_alloc(c, &c->trk_pw, C4 * cs * 4)) || (rc = trk_alloc(c, &c->trk_small, C4 * 2 + (size_t)cc * (n_off + 1) * 3 + cc)))
+      return rc;
+    c->trk_cells_cap = cc; c->trk_sym_cap = cs;
+  }
+  c->trk_last_cells = n_cells; c->trk_last_sym = n_sym;
   return LCS_OK;
 }
 
@@ -659,7 +665,7 @@ extern "C" int lcs_track_block(lcs_ctx *c, lcs_track_cell *cells, int n_cells, i
 extern "C" int lcs_track_stats(lcs_ctx *c, int n_cells, int n_sym, double *ac_fd, double *ac_td, int max_rs, double *sync, double *sync_ce,
                                int max_hf, int32_t *n_hf) {
   if (!c) return LCS_ERR_BAD_ARG;
-  if (n_cells < 1 || n_cells != c->trk_cells_cap || n_sym != c->trk_sym_cap || max_rs < 0 || max_hf < 0) {
+  if (n_cells < 1 || n_cells != c->trk_last_cells || n_sym != c->trk_last_sym || max_rs < 0 || max_hf < 0) {
     c->err = "lcs_track_stats describes the block of the last lcs_track_block call on this context (same n_cells, n_sym)";
     return LCS_ERR_BAD_ARG;
   }
@@ -669,13 +675,15 @@ extern "C" int lcs_track_stats(lcs_ctx *c, int n_cells, int n_sym, double *ac_fd
   const size_t C4 = L.C4;
   const int hf_cap = n_sym / 60 + 2;                       // PSS/SSS pairs of the block: two per frame of >= 120 symbols
   int rc;
-  if (c->trk_stat_cells != n_cells || c->trk_stat_sym != n_sym) {
+  if (n_cells > c->trk_stat_cells || n_sym > c->trk_stat_sym) {      // grow only, like the block workspace
+    const int cc = std::max(n_cells, c->trk_stat_cells), cs = std::max(n_sym + n_sym / 8, c->trk_stat_sym);
+    const size_t C4c = (size_t)cc * 4, rsc = (size_t)cs / 3 + 4, hfc = (size_t)cs / 60 + 2;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->trk_stat_cells = c->trk_stat_sym = 0;
-    if ((rc = trk_alloc(c, &c->trk_acfd, C4 * rs_cap * 12)) || (rc = trk_alloc(c, &c->trk_actd, C4 * rs_cap * 72)) ||
-        (rc = trk_alloc(c, &c->trk_sync, (size_t)n_cells * hf_cap * 4)) || (rc = trk_alloc(c, &c->trk_syncce, (size_t)n_cells * hf_cap * 72)))
+    if ((rc = trk_alloc(c, &c->trk_acfd, C4c * rsc * 12)) || (rc = trk_alloc(c, &c->trk_actd, C4c * rsc * 72)) ||
+        (rc = trk_alloc(c, &c->trk_sync, (size_t)cc * hfc * 4)) || (rc = trk_alloc(c, &c->trk_syncce, (size_t)cc * hfc * 72)))
       return rc;
-    c->trk_stat_cells = n_cells; c->trk_stat_sym = n_sym;
+    c->trk_stat_cells = cc; c->trk_stat_sym = cs;
   }
   const double2 *d_raw = L.d_raw;
   const double *d_meas = L.d_meas;
@@ -747,13 +755,19 @@ struct TrkStreamCell {
 // them through get_fd again with every call).
 struct TrkStream {
   std::vector<TrkStreamCell> cells;
-  double2 *d_tail[3] = {nullptr, nullptr, nullptr};      // indexed by LCS_CP_NORMAL / LCS_CP_EXTENDED
+  // indexed by LCS_CP_NORMAL / LCS_CP_EXTENDED: the carried rows, and a second buffer the next call's tail is written into
+  // before the two change places at the commit (no allocation or hipFree -- a device-wide synchronisation -- per call)
+  double2 *d_tail[3] = {nullptr, nullptr, nullptr}, *d_spare[3] = {nullptr, nullptr, nullptr};
+  size_t tail_cap[3] = {0, 0, 0}, spare_cap[3] = {0, 0, 0};      // capacities in double2
 };
 }  // namespace
 
 void lcs_track_stream_free(lcs_ctx *c) {
   TrkStream *st = static_cast<TrkStream *>(c->trk_stream);
-  if (st) for (double2 *p : st->d_tail) if (p) (void)hipFree(p);
+  if (st) {
+    for (double2 *p : st->d_tail) if (p) (void)hipFree(p);
+    for (double2 *p : st->d_spare) if (p) (void)hipFree(p);
+  }
   delete st;
   c->trk_stream = nullptr;
 }
@@ -799,9 +813,8 @@ extern "C" int lcs_track_stream_block(lcs_ctx *c, lcs_track_cell *cells, int n_c
   // The stream's state is committed only after EVERY group of cells went through (round-3 advisory: a failure in the second
   // group used to leave the first one advanced): the new per-cell records and device tails are built aside.
   std::vector<TrkStreamCell> next = st->cells;
-  double2 *new_tail[3] = {nullptr, nullptr, nullptr};
   bool group_done[3] = {false, false, false};
-  auto fail = [&](int rc) { for (double2 *p : new_tail) if (p) (void)hipFree(p); return rc; };
+  auto fail = [&](int rc) { return rc; };              // nothing to undo: the new tails sit in the spare buffers until the commit
   // cells of one CP type carry the same number of frames: one extended block per CP type
   for (int cp = LCS_CP_NORMAL; cp <= LCS_CP_EXTENDED; ++cp) {
     std::vector<int> idx;
@@ -859,10 +872,16 @@ extern "C" int lcs_track_stream_block(lcs_ctx *c, lcs_track_cell *cells, int n_c
     const size_t keep_from = (size_t)(T_next - T), n_keep = (size_t)(n_after - T_next);
     std::vector<double> bpo_at(G, 0.0);
     {
-      const hipError_t e = hipMalloc((void **)&new_tail[cp], sizeof(double2) * 72 * n_keep * G);
-      if (e != hipSuccess) { new_tail[cp] = nullptr; c->err = std::string("hipMalloc (carried symbols): ") + hipGetErrorString(e); return fail(LCS_ERR_HIP); }
+      const size_t need = (size_t)72 * n_keep * G;
+      if (need > st->spare_cap[cp]) {
+        if (st->d_spare[cp]) { (void)hipFree(st->d_spare[cp]); st->d_spare[cp] = nullptr; st->spare_cap[cp] = 0; }
+        const size_t cap = need + need / 4;               // head room: the tail's length varies by up to a frame from call to call
+        const hipError_t e = hipMalloc((void **)&st->d_spare[cp], sizeof(double2) * cap);
+        if (e != hipSuccess) { st->d_spare[cp] = nullptr; c->err = std::string("hipMalloc (carried symbols): ") + hipGetErrorString(e); return fail(LCS_ERR_HIP); }
+        st->spare_cap[cp] = cap;
+      }
       const TrkLayout Lay(c, G, L);
-      hipError_t e2 = hipMemcpy2DAsync(new_tail[cp], sizeof(double2) * 72 * n_keep, c->trk_syms + keep_from * 72, sizeof(double2) * 72 * (size_t)L,
+      hipError_t e2 = hipMemcpy2DAsync(st->d_spare[cp], sizeof(double2) * 72 * n_keep, c->trk_syms + keep_from * 72, sizeof(double2) * 72 * (size_t)L,
                                        sizeof(double2) * 72 * n_keep, G, hipMemcpyDeviceToDevice, c->stream);
       if (e2 == hipSuccess && T_next > T)
         e2 = hipMemcpy2DAsync(bpo_at.data(), sizeof(double), Lay.d_bpo + (size_t)(T_next - T - 1), sizeof(double) * (size_t)L, sizeof(double), G,
@@ -938,7 +957,7 @@ extern "C" int lcs_track_stream_block(lcs_ctx *c, lcs_track_cell *cells, int n_c
   // commit
   st->cells.swap(next);
   for (int cp = LCS_CP_NORMAL; cp <= LCS_CP_EXTENDED; ++cp)
-    if (group_done[cp]) { if (st->d_tail[cp]) (void)hipFree(st->d_tail[cp]); st->d_tail[cp] = new_tail[cp]; }
+    if (group_done[cp]) { std::swap(st->d_tail[cp], st->d_spare[cp]); std::swap(st->tail_cap[cp], st->spare_cap[cp]); }
   if (rc_all) c->err = "more rows than the output arrays hold (rows beyond the capacity were dropped)";
   return rc_all;
 }
