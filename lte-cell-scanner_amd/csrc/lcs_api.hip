@@ -85,7 +85,7 @@ int ensure_ws(lcs_ctx *c, int n_slots, uint32_t n_cap, int n_f, bool debug, int 
 #undef A
   if (c->cap8) { (void)hipFree(c->cap8); c->cap8 = nullptr; }
   if (c->cap8s) { (void)hipFree(c->cap8s); c->cap8s = nullptr; }
-  if (c->bt8) { (void)hipFree(c->bt8); c->bt8 = nullptr; }
+  if (c->brow8) { (void)hipFree(c->brow8); c->brow8 = nullptr; }
   if (c->tq) { (void)hipFree(c->tq); c->tq = nullptr; }
   if (c->tsc) { (void)hipFree(c->tsc); c->tsc = nullptr; }
   c->i8_ready = false;
@@ -109,7 +109,7 @@ int ensure_i8(lcs_ctx *c) {
   int rc;
   const size_t n8 = S * lcs_cap8_stride(c->cap_n_cap);
   if ((rc = dev_alloc(c, &c->cap8, n8)) || (rc = dev_alloc(c, &c->cap8s, n8))) return rc;
-  if ((rc = dev_alloc(c, &c->bt8, S * LCS_NW_MAX * G * (size_t)(3 * LCS_I8_KB * 2 * 64)))) return rc;
+  if ((rc = dev_alloc(c, &c->brow8, S * G * (size_t)LCS_I8_IMG))) return rc;
   if ((rc = dev_alloc(c, &c->tq, S * LCS_G_MAX * LCS_TG))) return rc;
   if ((rc = dev_alloc(c, &c->tsc, S * LCS_G_MAX * LCS_TG))) return rc;
   c->i8_ready = true;
@@ -187,7 +187,7 @@ XcGeom pack_grid(uint32_t n_cap, int n_f, int ds, const double *fset, const doub
   }
   return make_geo(n_cap, n_f, ds, 3);
 }
-constexpr int kMaxTapsI8 = 32 * LCS_I8_KB;                               // int8 kernel: 5 blocks of 32 taps
+constexpr int kMaxTapsI8 = LCS_I8_MAX_TAPS;                               // int8 kernel: 137 taps + delays below LCS_I8_OFF (the fp16 kernel holds 160)
 constexpr int kMaxTapsF32 = 2 * (LCS_KP2_MAX - LCS_KP2_UNROLL);          // fp32 kernel: 124 tap pairs
 
 // complex<double> host buffer -> device (cap64, slot 0) and the choice of the correlation kernel: a buffer whose every
@@ -315,7 +315,7 @@ void lcs_destroy(lcs_ctx *c) {
                   c->incoh, c->sref, c->pow_, c->work, c->spinc, c->zth, c->sp, c->frq, c->peaks, c->npeaks, c->xc,
                   c->work_items, c->n_work, c->tfg, c->tfg_comp, c->ce, c->tfg_ts, c->tfg_ts_comp, c->cell_scratch,
                   c->cells_out, c->d_pss_td, c->d_pss_fd, c->d_sss_fd, c->d_pbch_scr, c->d_derm_inv, c->d_dbg, c->pk_items, c->n_pk,
-                  c->sss_ws, c->d_pn_jump, c->cap8, c->cap8s, c->bt8, c->tq, c->tsc, c->cap16h, c->cap16l, c->bt16, c->texp16, c->tsc16, c->xmax16, c->xpart16, c->h2d, c->trk_td, c->trk_syms, c->trk_raw, c->trk_ce,
+                  c->sss_ws, c->d_pn_jump, c->cap8, c->cap8s, c->brow8, c->tq, c->tsc, c->cap16h, c->cap16l, c->bt16, c->texp16, c->tsc16, c->xmax16, c->xpart16, c->h2d, c->trk_td, c->trk_syms, c->trk_raw, c->trk_ce,
                   c->trk_meta, c->trk_rs, c->trk_fmeta, c->trk_pw, c->trk_idx, c->trk_small, c->trk_cells, c->trk_acfd, c->trk_actd,
                   c->trk_syncce, c->trk_sync, c->d_flag};
   for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -436,11 +436,11 @@ int lcs_batch_enqueue(lcs_ctx *c, const void *d_capbufs, int fmt, int n_buf, uin
   if (fmt != LCS_FMT_C64 && fmt != LCS_FMT_IQ_U8) { c->err = "unknown capture format"; return LCS_ERR_BAD_ARG; }
   HIPCHK(c, hipSetDevice(c->device));
   c->foe_ready = false;      // the batch overwrites the buffers a pending lcs_foe_partial left for lcs_foe_finish
-  // u8 I/Q is exact in int8: the int8 three-digit kernel (pss_xcorr_i8.hip), 137 taps + window-start spread <= 160 inside
+  // u8 I/Q is exact in int8: the int8 three-digit kernel (pss_xcorr_i8.hip), 137 taps + window-start spread <= 152 inside
   // every template group; every other source takes the fp32 kernel (spread <= 111); pack_grid thins the groups of a grid
   // that is too sparse for that
   const XcGeom geo = pack_grid(n_cap, n_f, 2 /* DS_COMB_ARM, ref src/CellSearch.cpp:484 */, f_search_set, fc_requested, fc_programmed,
-                               n_buf, fs_programmed, kMaxTapsI8);      // the int8 and the fp16 kernel both hold 160 taps per group
+                               n_buf, fs_programmed, kMaxTapsI8);      // the fp16 kernel holds 160 taps per group and shares the int8 kernel's packing
   if ((rc = ensure_ws(c, n_buf, n_cap, n_f, false, geo.G))) return rc;
   if ((rc = pinned(c, sizeof(SlotParams) * n_buf + sizeof(double) * LCS_NF_MAX))) return rc;
   SlotParams *hp = (SlotParams *)c->h_pinned;

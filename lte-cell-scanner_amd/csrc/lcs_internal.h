@@ -7,7 +7,8 @@
 //   tmpl    [S][n_f][3][137]      float2   conj(fshift(pss_td))/137   (searcher.cpp:146-151)
 //   start   [S][NW][n_f]          int      round_i(m*.005*k_factor*fs) (searcher.cpp:298)
 //   smin/kp2[S][NW][G]            int      per (window, 16-template group): first lag offset, tap pairs
-//   btab    [S][NW][G][KP2][64]   float    MFMA B operands: delay-shifted templates
+//   btab    [S][NW][G][KP2][64]   float    MFMA B operands: delay-shifted templates (fp32 kernel)
+//   brow8   [S][G][LCS_I8_IMG]    uint32   int8 kernel: three-digit operand rows of a group, as they sit in LDS
 //   single  [S][G][9600][16]      float    xc_incoherent_single, group-major (16 templates = one 64 B row)
 //   sref    [3][9600][n_f]        float    reference-layout staging of single for the stage entry points
 //   pow/frq [S][3][9600]          double/int
@@ -33,7 +34,10 @@
 #define LCS_LAG_TILE 64      // lags per wave
 #define LCS_PS 336           // LDS plane stride in floats: >= 64 + 2*KP2_MAX, == 16 (mod 32)
 #define LCS_MAXP 64          // peaks kept per capture buffer
-#define LCS_I8_KB 5          // 32-tap blocks of the int8 correlation kernel: taps + window-start spread <= 160
+#define LCS_I8_KB 5          // 32-tap blocks of the int8 correlation kernel
+#define LCS_I8_OFF 16        // int8 kernel: a template column's delay inside its group (window-start spread) stays below this
+#define LCS_I8_MAX_TAPS (137 + LCS_I8_OFF - 1)
+#define LCS_I8_IMG 17024     // dwords of the int8 kernel's operand image per (buffer, group) (pss_xcorr_i8.hip)
 #define LCS_MAX_WORK 1024    // cells carried into the TFG/MIB stages per round (~6 MB each: 6 GB per context, allocated on first use)
 // grid sizes of the work-list kernels (every one loops over its list, so these only trade latency for workgroups)
 #define LCS_WIN_GRID 4096
@@ -140,7 +144,7 @@ struct lcs_ctx {
   float2 *cap32 = nullptr;
   uint16_t *cap8 = nullptr;          // capture buffers as (re, im) int8 pairs 127 - u8, slot stride lcs_cap8_stride (pss_xcorr_i8.hip)
   uint16_t *cap8s = nullptr;         // the same shifted down by one sample: cap8s[i] = cap8[i + 1]
-  uint4 *bt8 = nullptr;              // int8 three-digit template operands
+  uint32_t *brow8 = nullptr;         // int8 three-digit template operands: one image of resident rows per (slot, group)
   double *tq = nullptr;              // per template: integer scale q
   float *tsc = nullptr;              // per template: 1 / (128 q)
   bool i8_ready = false, use_i8 = false;
@@ -284,7 +288,7 @@ int lcs_launch_ingest_c128(lcs_ctx *c, uint32_t n_cap, bool *exact);   // cap64 
 int lcs_launch_xcorr(lcs_ctx *c, int n_buf, const XcGeom &geo, bool want_incoh, bool time_it);
 int lcs_launch_single_layout(lcs_ctx *c, const XcGeom &geo, int slot, float *ref_layout, int to_ref);   // group-major <-> [t][idx][foi]
 // pss_xcorr_i8.hip
-int lcs_launch_fill_btab_i8(lcs_ctx *c, int n_buf, const XcGeom &geo);
+int lcs_launch_fill_brow_i8(lcs_ctx *c, int n_buf, const XcGeom &geo);
 int lcs_launch_xcorr_i8(lcs_ctx *c, hipStream_t sxc, const XcGeom &geo, int slot0, int n_slots, int xcd_map);
 // pss_xcorr_f16.hip
 int lcs_launch_ingest_f16(lcs_ctx *c, const void *d_src, int n_buf, uint32_t n_cap);   // complex<float> -> cap32 + fp16 hi / lo pairs + per-buffer scale

@@ -510,7 +510,7 @@ __global__ __launch_bounds__(256) void k_sp_i8(const uint16_t *__restrict__ cap8
 // candidates -- larger value, on equal values the lower foi: what a single scan in ascending (foi, pss) order with a
 // strict comparison keeps.  No LDS, no barrier (round 2 staged the rows in LDS with a 17-float stride whose dword
 // writes collided four ways; 85 us alone for 229 MB), 32 VGPRs: the workgroups fit beside two resident correlation
-// workgroups (see k_fill_btab_i8).  DS = the arm as a compile-time constant (2: every caller of the reference), or
+// workgroups (512 - 2 x 232 = 48 VGPRs are free on a SIMD lane).  DS = the arm as a compile-time constant (2: every caller of the reference), or
 // -1 = read it from geo.
 struct CollapseBest { float v; int foi; };
 __device__ __forceinline__ void collapse_merge(CollapseBest &b, int lane_xor) {
@@ -798,7 +798,7 @@ int lcs_launch_xcorr(lcs_ctx *c, int n_buf, const XcGeom &geo, bool want_incoh, 
   hipLaunchKernelGGL(k_prep_tables, dim3(n_buf, 4), dim3(256), 0, c->stream, c->params, c->fset, c->d_pss_td, c->tmpl,
                      c->start, c->smin, c->kp2, geo);
   if (c->use_i8) {
-    int rc_ = lcs_launch_fill_btab_i8(c, n_buf, geo);
+    int rc_ = lcs_launch_fill_brow_i8(c, n_buf, geo);
     if (rc_) return rc_;
   } else if (c->use_f16) {
     int rc_ = lcs_launch_fill_btab_f16(c, n_buf, geo);

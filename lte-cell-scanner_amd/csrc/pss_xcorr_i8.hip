@@ -17,15 +17,27 @@
 // are 2 bytes, lanes start at any sample: LDS holds the window twice, the second copy shifted by one sample,
 // so that every lane reads 4 aligned dwords from the copy matching its parity.
 //
-// Tiling: 256-thread workgroup = 512 output positions x one 16-template group, 8
-// sub-tiles per wave; per window 3 digit passes x 5 tap blocks, fully unrolled; the window's B operands
-// (30 KB) sit in LDS next to the capture samples.  Digit 2 has its own int32 accumulator; digits 1
-// and 0 share one (shifted left by 8 between the passes), so int -> float conversion happens twice per
-// output and window, not per digit.
+// Tiling: 256-thread workgroup = 512 output positions x one 16-template group, 8 sub-tiles per wave; per window
+// 3 digit passes x 5 tap blocks, fully unrolled.  Digit 2 has its own int32 accumulator; digits 1 and 0 share one
+// (shifted left by 8 between the passes), so int -> float conversion happens twice per output and window, not per
+// digit.
 //
-// k_xcorr_i8x3: B operands go global -> LDS by LDS-DMA (global_load_lds_dwordx4), one window ahead; the
-// operands of tap block e + 1 are read from LDS behind the first MFMA pair of block e; the digit passes walk
-// the tap blocks boustrophedon.
+// B operands: resident rows (round 4).  Across the 15 windows of a buffer a template column changes only by its
+// delay delta = start[w][foi] - smin[w][g] inside its group.  Rounds 1-3 wrote one 30 KB operand table per (window,
+// group) -- 2.8 MB per buffer, written by a fill kernel, streamed through L2 by each of the 19 lag tiles and copied
+// into LDS window by window (the kernel's HBM traffic was 1.83 x its algorithmic bytes).  Now a workgroup loads ONE
+// image per (buffer, group) at its start (66.5 KB, LDS-DMA) and keeps it for its whole life: per column, digit and
+// output the row of (re, im) digit pairs at tap positions -I8R_OFF .. 159 (zeros outside the 137 taps); lane (n, kg)
+// reads its 8 taps of tap block kb at dword 16 kb + 4 kg + I8R_OFF / 2 - (delta >> 1) of column n's row.  A pair is 2
+// bytes and the delay is any integer: the image holds every row twice, natural (dword i = positions 2i, 2i + 1) and
+// shifted by one tap (dword i = positions 2i - 1, 2i), and a lane reads 4 aligned dwords from the copy matching its
+// delay's parity -- the scheme of the capture samples.  Rows of consecutive columns sit 88 dwords apart plus n >> 2:
+// 88 n = -8 n (mod 32) gives banks {0, 24, 16, 8} + (n >> 2), so the 32 lanes of a dword read (16 columns x 2 tap
+// octets, 4 banks apart) fall on 32 different banks when their delays agree.  The per-window LDS-DMA carries only the
+// capture samples (6.4 KB of the workgroup's 72.7 KB).  Measured against the table form on one box: kernel alone
+// 2.18-2.21 against 2.22-2.27 ms per 128 buffers, in the chain 2.64-2.66 against 2.72-2.74, step + 3.2 %
+// (profiles/r04/experiments/ab_i8_resident_rows.txt; a single-copy variant that shifts odd delays into place with
+// v_alignbyte_b32 -- 44 KB of LDS -- was 8 % slower, same file).
 #include "lcs_internal.h"
 #include <algorithm>
 
@@ -41,7 +53,7 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 #endif
 #define I8_LAGS (4 * I8_MT * 16)
 #define I8_TILES ((LCS_N_IDX + I8_LAGS - 1) / I8_LAGS)
-#define I8_NKB LCS_I8_KB                                  // 32-tap blocks per window: 137 taps + spread <= 160
+#define I8_NKB LCS_I8_KB                                  // 32-tap blocks per window: 137 taps + delay < 160
 #define I8_AW (I8_LAGS + 32 * I8_NKB + 32)                // staged samples per window
 #define I8_ADW (((I8_AW / 2 + 63) / 64) * 64)             // dwords per staged copy: whole 64-dword LDS-DMA chunks
 // I8_ADW is a multiple of 32, + 16 puts the shifted copy 16 banks away from the natural one, so the even-lag lanes
@@ -50,14 +62,24 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 #define I8_ACOPY (I8_ADW + 16)
 #define I8_QMAX 8300000.0                                 // |T_int| bound: three balanced base-256 digits reach 8 355 711
 
+// Geometry of the operand image (LCS_I8_OFF, LCS_I8_IMG: lcs_internal.h)
+#define I8R_OFF LCS_I8_OFF                                // row position of tap 0; delays stay below it
+#define I8R_ROW 88                                        // dwords between the rows of consecutive columns (+ n >> 2)
+#define I8R_RLEN 88                                       // dwords of a row: the last one read is 16 * 4 + 4 * 3 + I8R_OFF / 2 + 3
+#define I8R_BLK 1412                                      // dwords per (digit, output) block of 16 rows
+#define I8R_COPY 8512                                     // dwords per copy: 6 blocks, rounded to whole 64-dword LDS-DMA pieces (and the same banks in both copies)
+#define I8R_IMG LCS_I8_IMG
+static_assert(I8R_RLEN >= 16 * (I8_NKB - 1) + 12 + I8R_OFF / 2 + 4 && I8R_BLK >= 15 * I8R_ROW + 3 + I8R_RLEN && I8R_COPY >= 6 * I8R_BLK &&
+              I8R_COPY % 64 == 0 && I8R_IMG == 2 * I8R_COPY && 137 + I8R_OFF - 1 <= 32 * I8_NKB, "operand image geometry");
+__host__ __device__ static inline int i8r_rowoff(int n) { return n * I8R_ROW + (n >> 2); }
+
 // Per template (slot, foi, t): q = I8_QMAX / max tap magnitude; sc = 1 / (128 q) converts the integer
 // correlation back to the reference's units.
 __global__ __launch_bounds__(256) void k_i8_scales(const float2 *__restrict__ tmpl, double *__restrict__ tq,
                                                    float *__restrict__ sc, XcGeom geo) {
   LCS_TAIL_PRIO();
   const int slot = blockIdx.x;
-  __shared__ float part[LCS_G_MAX * LCS_TG][4];
-  for (int e = threadIdx.x; e < geo.G * LCS_TG * 4; e += 256) {      // 4 threads per template, 35 taps each
+  for (int e = threadIdx.x; e < geo.G * LCS_TG * 4; e += 256) {      // 4 adjacent lanes per template, 35 taps each
     const int col = e >> 2, qd = e & 3;            // column index: group col / 16, column col % 16
     const int c = lcs_col_tmpl(geo, col >> 4, col & 15);
     float mx = 0.f;
@@ -66,14 +88,13 @@ __global__ __launch_bounds__(256) void k_i8_scales(const float2 *__restrict__ tm
       const float2 *T = tmpl + (((size_t)slot * NFM + foi) * 3 + t) * 137;
       for (int m = qd * 35; m < min(137, qd * 35 + 35); ++m) mx = fmaxf(mx, fmaxf(fabsf(T[m].x), fabsf(T[m].y)));
     }
-    part[col][qd] = mx;
-  }
-  __syncthreads();
-  for (int c = threadIdx.x; c < geo.G * LCS_TG; c += 256) {
-    const float mx = fmaxf(fmaxf(part[c][0], part[c][1]), fmaxf(part[c][2], part[c][3]));
-    const double q = (mx > 0.f) ? I8_QMAX / (double)mx : 0.0;
-    tq[(size_t)slot * GM * LCS_TG + c] = q;
-    sc[(size_t)slot * GM * LCS_TG + c] = (q > 0.0) ? (float)(1.0 / (128.0 * q)) : 0.f;
+    mx = fmaxf(mx, __shfl_xor(mx, 1));             // the loop bound is a multiple of 4: a quad is active as a whole
+    mx = fmaxf(mx, __shfl_xor(mx, 2));
+    if (qd == 0) {
+      const double q = (mx > 0.f) ? I8_QMAX / (double)mx : 0.0;
+      tq[(size_t)slot * GM * LCS_TG + col] = q;
+      sc[(size_t)slot * GM * LCS_TG + col] = (q > 0.0) ? (float)(1.0 / (128.0 * q)) : 0.f;
+    }
   }
 }
 
@@ -84,76 +105,54 @@ __device__ __forceinline__ void digits3(int v, int &d0, int &d1, int &d2) {   //
   d2 = (v1 - d1) >> 8;
 }
 
-// bt8[slot][w][g][digit][kb][op][lane] (uint4 = 16 int8): lane (n, kg) holds taps 32 kb + 8 kg .. +7 of template
-// column c = 16 g + n delayed by start[w][foi(c)] - smin[w][g] (zero outside its 137 taps), as digit `digit` of
-// the integer pairs (tr, -ti) (op 0, real output) or (ti, tr) (op 1, imaginary output).
-__global__ __launch_bounds__(256) void k_fill_btab_i8(const float2 *__restrict__ tmpl, const int *__restrict__ start,
-                                                      const int *__restrict__ smin, const double *__restrict__ tq,
-                                                      uint4 *__restrict__ bt8, XcGeom geo) {
+// brow[slot][g][copy][digit][op][row(n)][i]: the operand image of one (buffer, group) exactly as it sits in LDS.
+// dword i of a natural row = tap positions (2i, 2i + 1), of a shifted row (2i - 1, 2i); position p = tap p - I8R_OFF;
+// op 0: pairs (tr, -ti) (real output), op 1: pairs (ti, tr) (imaginary output); digit d of the 24-bit integers.
+__global__ __launch_bounds__(256) void k_fill_brow_i8(const float2 *__restrict__ tmpl, const double *__restrict__ tq,
+                                                      uint32_t *__restrict__ brow, XcGeom geo) {
   LCS_TAIL_PRIO();
-  const int slot = blockIdx.z;
-  const int wg = blockIdx.y;
-  const int w = wg / geo.G, g = wg % geo.G;
-  const int s0 = smin[((size_t)slot * NW + w) * GM + g];
-  uint4 *out = bt8 + (((size_t)slot * geo.n_comb + w) * geo.G + g) * (size_t)(3 * I8_NKB * 2 * 64);
-  // one thread per (tap block, lane, half of the lane's 8 taps): 4 taps = 8 operand bytes per digit and output.
-  // 30 VGPRs: under the 48 that two resident correlation workgroups leave free on a SIMD (512 - 2 x 232), so these
-  // workgroups start beside them instead of waiting for one to retire; the table is stored with non-temporal
-  // stores (it is read ~1.5 ms later by another kernel; allocating 173 MB of it in L2 only evicts the running
-  // correlation's operands).  Together -1 % step time in the pipelined chain -- what this kernel costs there is its
-  // memory traffic (skip-kernel ablation: 45 us per batch before, ~35 after).
-  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < I8_NKB * 64 * 2; e += gridDim.x * blockDim.x) {
-    const int hf = e & 1, lane = (e >> 1) & 63, kb = e >> 7;
-    const int c = lcs_col_tmpl(geo, g, lane & 15), kg = lane >> 4;
-    int tr[4], ti[4];
-#pragma unroll
-    for (int m = 0; m < 4; ++m) { tr[m] = 0; ti[m] = 0; }
+  const int slot = blockIdx.z, g = blockIdx.y;
+  uint32_t *out = brow + ((size_t)slot * geo.G + g) * I8R_IMG;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < LCS_TG * 2 * I8R_RLEN; e += gridDim.x * blockDim.x) {
+    const int n = e / (2 * I8R_RLEN), r = e % (2 * I8R_RLEN), cpy = r / I8R_RLEN, i = r % I8R_RLEN;
+    const int c = lcs_col_tmpl(geo, g, n);
+    int tr[2] = {0, 0}, ti[2] = {0, 0};
     if (c >= 0) {
       const int foi = c / 3, t = c % 3;
-      const int delta = start[((size_t)slot * NW + w) * NFM + foi] - s0;
-      const double q = tq[(size_t)slot * GM * LCS_TG + g * LCS_TG + (lane & 15)];      // scales are stored per column
+      const double q = tq[(size_t)slot * GM * LCS_TG + g * LCS_TG + n];      // scales are stored per column
       const float2 *T = tmpl + (((size_t)slot * NFM + foi) * 3 + t) * 137;
 #pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        const int tap = 32 * kb + 8 * kg + 4 * hf + m - delta;
+      for (int m = 0; m < 2; ++m) {
+        const int tap = 2 * i - cpy + m - I8R_OFF;
         if (tap >= 0 && tap < 137) { tr[m] = (int)rint((double)T[tap].x * q); ti[m] = (int)rint((double)T[tap].y * q); }
       }
     }
 #pragma unroll
-    for (int op = 0; op < 2; ++op) {                  // op 0: pairs (tr, -ti), op 1: pairs (ti, tr)
-      uint32_t pk[3][2];
+    for (int op = 0; op < 2; ++op) {
+      uint32_t pk[3] = {0u, 0u, 0u};
 #pragma unroll
-      for (int d = 0; d < 3; ++d) { pk[d][0] = 0u; pk[d][1] = 0u; }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
+      for (int j = 0; j < 4; ++j) {
         const int m = j >> 1;
         const int v = op ? ((j & 1) ? tr[m] : ti[m]) : ((j & 1) ? -ti[m] : tr[m]);
         int d0, d1, d2;
         digits3(v, d0, d1, d2);
-        const int sh = 8 * (j & 3);
-        pk[0][j >> 2] |= (uint32_t)(d0 & 255) << sh;
-        pk[1][j >> 2] |= (uint32_t)(d1 & 255) << sh;
-        pk[2][j >> 2] |= (uint32_t)(d2 & 255) << sh;
+        pk[0] |= (uint32_t)(d0 & 255) << (8 * j);
+        pk[1] |= (uint32_t)(d1 & 255) << (8 * j);
+        pk[2] |= (uint32_t)(d2 & 255) << (8 * j);
       }
 #pragma unroll
-      for (int d = 0; d < 3; ++d)
-      {
-        typedef unsigned u2v __attribute__((ext_vector_type(2)));
-        u2v val = {pk[d][0], pk[d][1]};
-        __builtin_nontemporal_store(val, reinterpret_cast<u2v *>(out + (((size_t)d * I8_NKB + kb) * 2 + op) * 64 + lane) + hf);
-      }
+      for (int d = 0; d < 3; ++d) out[(size_t)cpy * I8R_COPY + (d * 2 + op) * I8R_BLK + i8r_rowoff(n) + i] = pk[d];
     }
   }
 }
 
-// Everything a window needs reaches LDS by LDS-DMA (global_load_lds: no staging registers, no ds_write pass), issued
-// one window ahead right behind the barrier: the B operands (30 KB, dwordx4 chunks of the per-window table) and the
-// capture samples -- two copies of the window, natural and shifted by one sample, each a run of dwords (= sample pairs)
-// taken from cap8 or cap8s, whichever holds the window start dword aligned.  The registers that frees pay for a
-// one-block-deep operand prefetch: the B operands and the two new A operands of tap block e + 1 are read from LDS
-// behind the first MFMA pair of block e, so the LDS latency sits under 14 MFMAs instead of in front of every
-// block.  The digit passes walk the tap blocks boustrophedon (digit 2: kb 0..4, digit 1: kb 4..0, digit 0: kb 0..4)
-// so the sliding A window never restarts: 32 A-operand reads per window instead of 48.
+// The operand image reaches LDS once, at the workgroup's start; the capture samples of a window -- two copies, natural
+// and shifted by one sample, each a run of dwords (= sample pairs) taken from cap8 or cap8s, whichever holds the window
+// start dword aligned -- one window ahead right behind the window's barrier; both by LDS-DMA (global_load_lds: no
+// staging registers, no ds_write pass).  The B operands and the two new A operands of tap block e + 1 are read from LDS
+// behind the first MFMA pair of block e, so the LDS latency sits under 14 MFMAs instead of in front of every block.
+// The digit passes walk the tap blocks boustrophedon (digit 2: kb 0..4, digit 1: kb 4..0, digit 0: kb 0..4) so the
+// sliding A window never restarts: 32 A-operand reads per window instead of 48.
 // Epilogue work is spread under the MFMA stream where its inputs allow: the digit-2 sums are converted to float
 // while the digit-1 pass runs, the << 8 of the shared digit-1/0 accumulator sits in front of each sub-tile's first
 // digit-0 MFMA; what is left behind the last block is 6 VALU operations per output.
@@ -161,7 +160,8 @@ __global__ __launch_bounds__(256) void k_fill_btab_i8(const float2 *__restrict__
 // blocks of a window run at the MFMA issue rate (0.059 ms per block-launch); the rest is per-window and
 // per-workgroup cost (barrier, epilogue, prologue of each of the 15 workgroup rounds, last round 25 % full).
 __global__ __launch_bounds__(256, 2) void k_xcorr_i8x3(const uint16_t *__restrict__ cap8, const uint16_t *__restrict__ cap8s,
-                                                          const int *__restrict__ smin, const uint4 *__restrict__ bt8,
+                                                          const int *__restrict__ smin, const int *__restrict__ start,
+                                                          const uint32_t *__restrict__ brow,
                                                           const float *__restrict__ sc, float *__restrict__ sg, XcGeom geo,
                                                           int slot0, int n_slots, int xcd_map) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -174,17 +174,34 @@ __global__ __launch_bounds__(256, 2) void k_xcorr_i8x3(const uint16_t *__restric
   const int widx0 = idx0 + wave * (I8_MT * 16);
 
   __shared__ uint32_t ldsA[2][2][I8_ACOPY];
+  __shared__ uint32_t ldsR[I8R_IMG];
   constexpr int NBLK = 3 * I8_NKB;
-  constexpr int BW = NBLK * 2 * 64;       // uint4 per window (30 KB), table order [digit][kb][op][lane]
-  constexpr int NCH = BW / 64;            // 1 KiB chunks: one global_load_lds_dwordx4 per wave each
   constexpr int NCA = 2 * (I8_ADW / 64);  // 256-byte chunks of the two sample copies: one global_load_lds_dword per wave each
-  __shared__ uint4 ldsB[2][BW];
   const size_t cstride = lcs_cap8_stride(geo.n_cap);
   const uint32_t *capd = reinterpret_cast<const uint32_t *>(cap8 + (size_t)slot * cstride) + lane;     // dword j = samples (2j, 2j+1)
   const uint32_t *capsd = reinterpret_cast<const uint32_t *>(cap8s + (size_t)slot * cstride) + lane;   // dword j = samples (2j+1, 2j+2)
   const int *smin_s = smin + (size_t)slot * NW * GM + g;
-  const uint4 *bt_s = bt8 + ((size_t)slot * geo.n_comb * geo.G + g) * (size_t)BW + lane;
-  const size_t bt_wstride = (size_t)geo.G * BW;
+  // this lane's column: its delay in window w is start[w][foi] - smin[w][g]; where its row starts in the image
+  const int col = lcs_col_tmpl(geo, g, lane & 15);
+  const int *start_l = start + (size_t)slot * NW * NFM + (col >= 0 ? col / 3 : 0);
+  const int rowbase = i8r_rowoff(lane & 15) + 4 * (lane >> 4) + I8R_OFF / 2;
+  {
+    // the group's operand image: whole 1 KiB chunks (one global_load_lds_dwordx4 per wave each) + 64-dword pieces
+    const uint32_t *img = brow + ((size_t)slot * geo.G + g) * I8R_IMG;
+    constexpr int NCI = I8R_IMG / 256, NTL = (I8R_IMG - NCI * 256) / 64;
+    static_assert(I8R_IMG == NCI * 256 + NTL * 64 && NTL < 4, "image = whole 1 KiB chunks + up to three 64-dword pieces");
+#pragma unroll
+    for (int c_ = 0; c_ < (NCI + 3) / 4; ++c_) {
+      const int ch_ = wave + 4 * c_;
+      if (ch_ < NCI)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(img + ch_ * 256 + lane * 4),
+                                         (__attribute__((address_space(3))) void *)(ldsR + ch_ * 256), 16, 0, 0);
+    }
+    if (wave < NTL)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(img + NCI * 256 + wave * 64 + lane),
+                                       (__attribute__((address_space(3))) void *)(ldsR + NCI * 256 + wave * 64), 4, 0, 0);
+  }
+  int dl_next = (col >= 0) ? start_l[0] - smin_s[0] : 0;
   const float my_sc = sc[(size_t)slot * GM * LCS_TG + g * LCS_TG + (lane & 15)];
   const int p0 = wave * (I8_MT * 16) + (lane & 15) + 8 * (lane >> 4);
   const int par = p0 & 1;
@@ -208,30 +225,21 @@ __global__ __launch_bounds__(256, 2) void k_xcorr_i8x3(const uint16_t *__restric
                                          (__attribute__((address_space(3))) void *)(ldsA[(W) & 1][cp_] + 64 * k_), 4, 0, 0); \
       }                                                                                                      \
     }                                                                                                        \
-    uint4 *dst_ = ldsB[(W) & 1];                                                                             \
-    const uint4 *src_ = bt_s + (size_t)(W) * bt_wstride;                                                     \
-    _Pragma("unroll") for (int c_ = 0; c_ < (NCH + 3) / 4; ++c_) {                                           \
-      const int ch_ = wave + 4 * c_;          /* chunk = (digit, kb, op) in table order */                   \
-      if (ch_ < NCH)                                                                                         \
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src_ + ch_ * 64),  \
-                                         (__attribute__((address_space(3))) void *)(dst_ + ch_ * 64), 16, 0, 0); \
-    }                                                                                                        \
   }
 #define I8_RD_A(S) { const uint32_t *p_ = bufA + 8 * (S); Aw[S] = (i32x4){(int)p_[0], (int)p_[1], (int)p_[2], (int)p_[3]}; }
-#define I8_RD_B(E, Q)                                                                                        \
+  // B operand of (digit D, tap block KB, output OP): 4 dwords of this lane's row in the copy matching its delay's parity
+#define I8_RD_B(D, KB, OP, DST)                                                                              \
   {                                                                                                          \
-    constexpr int d_ = (E) / I8_NKB, j_ = (E) % I8_NKB, kb_ = (d_ == 1) ? I8_NKB - 1 - j_ : j_;              \
-    constexpr int tb_ = (2 - d_) * I8_NKB + kb_;                                                             \
-    _Pragma("unroll") for (int op_ = 0; op_ < 2; ++op_) {                                                    \
-      const uint4 t_ = bl[(tb_ * 2 + op_) * 64];                                                             \
-      Bq[Q][op_] = (i32x4){(int)t_.x, (int)t_.y, (int)t_.z, (int)t_.w};                                      \
-    }                                                                                                        \
+    const uint32_t *q_ = bl + ((D) * 2 + (OP)) * I8R_BLK + 16 * (KB);                                        \
+    DST = (i32x4){(int)q_[0], (int)q_[1], (int)q_[2], (int)q_[3]};                                           \
   }
   I8_DMA(0);
   for (int w = 0; w < geo.n_comb; ++w) {
     __syncthreads();                       // drains this wave's LDS-DMA chunks of window w (vmcnt(0)), then everybody's
-    if (w + 1 < geo.n_comb) I8_DMA(w + 1); // buffers (w + 1) & 1: last read in window w - 1
-    const uint4 *bl = ldsB[w & 1] + lane;
+    if (w + 1 < geo.n_comb) I8_DMA(w + 1); // buffer (w + 1) & 1: last read in window w - 1
+    const int dl = dl_next;                // this lane's delay in window w; the next window's is fetched under this one
+    if (w + 1 < geo.n_comb) dl_next = (col >= 0) ? start_l[(w + 1) * NFM] - smin_s[(w + 1) * GM] : 0;
+    const uint32_t *bl = ldsR + (dl & 1) * I8R_COPY + rowbase - (dl >> 1);
     const uint32_t *bufA = ldsA[w & 1][par] + a_dw;
     // digit 2 accumulates into (tR, tI); digits 1 and 0 share one int32 accumulator: after the digit-1 pass it is
     // shifted left by 8 and the digit-0 products are added on top (|S1| <= 274 * 128 * 128 = 4.5e6, so
@@ -242,7 +250,8 @@ __global__ __launch_bounds__(256, 2) void k_xcorr_i8x3(const uint16_t *__restric
     i32x4 Bq[2][2];
 #pragma unroll
     for (int s = 0; s < I8_MT; ++s) I8_RD_A(s);
-    I8_RD_B(0, 0);
+#pragma unroll
+    for (int op = 0; op < 2; ++op) I8_RD_B(2, 0, op, Bq[0][op]);
 #define I8_PF_MFMA(MT)                                                                                       \
   {                                                                                                          \
     if (d == 0) {                                                                                            \
@@ -258,7 +267,7 @@ __global__ __launch_bounds__(256, 2) void k_xcorr_i8x3(const uint16_t *__restric
     }                                                                                                        \
   }
 #pragma unroll
-    for (int e = 0; e < NBLK; ++e) {
+    for (int e = 0; e < NBLK; ++e) {       // pass d = e / 5 multiplies digit 2 - d
       const int d = e / I8_NKB, j = e % I8_NKB;
       const int kb = (d == 1) ? I8_NKB - 1 - j : j;
       // The first MFMA pair of block e carries the wait for block e's operands (read during block e - 1); the reads
@@ -269,14 +278,8 @@ __global__ __launch_bounds__(256, 2) void k_xcorr_i8x3(const uint16_t *__restric
       if (e + 1 < NBLK) {                  // operands of block e + 1
         const int d1 = (e + 1) / I8_NKB, j1 = (e + 1) % I8_NKB;
         const int kb1 = (d1 == 1) ? I8_NKB - 1 - j1 : j1;
-        {
-          const int tb = (2 - d1) * I8_NKB + kb1;
 #pragma unroll
-          for (int op = 0; op < 2; ++op) {
-            const uint4 t_ = bl[(tb * 2 + op) * 64];
-            Bq[(e + 1) & 1][op] = (i32x4){(int)t_.x, (int)t_.y, (int)t_.z, (int)t_.w};
-          }
-        }
+        for (int op = 0; op < 2; ++op) I8_RD_B(2 - d1, kb1, op, Bq[(e + 1) & 1][op]);
         if (kb1 > kb) { I8_RD_A(2 * kb1 + I8_MT - 2); I8_RD_A(2 * kb1 + I8_MT - 1); }
         else if (kb1 < kb) { I8_RD_A(2 * kb1); I8_RD_A(2 * kb1 + 1); }
       }
@@ -315,16 +318,15 @@ __global__ __launch_bounds__(256, 2) void k_xcorr_i8x3(const uint16_t *__restric
     }
 }
 
-int lcs_launch_fill_btab_i8(lcs_ctx *c, int n_buf, const XcGeom &geo) {
+int lcs_launch_fill_brow_i8(lcs_ctx *c, int n_buf, const XcGeom &geo) {
   hipLaunchKernelGGL(k_i8_scales, dim3(n_buf), dim3(256), 0, c->stream, c->tmpl, c->tq, c->tsc, geo);
-  hipLaunchKernelGGL(k_fill_btab_i8, dim3((I8_NKB * 128 + 255) / 256, geo.n_comb * geo.G, n_buf), dim3(256), 0, c->stream, c->tmpl, c->start, c->smin,
-                     c->tq, c->bt8, geo);
+  hipLaunchKernelGGL(k_fill_brow_i8, dim3((LCS_TG * 2 * I8R_RLEN + 255) / 256, geo.G, n_buf), dim3(256), 0, c->stream, c->tmpl, c->tq, c->brow8, geo);
   HIPCHK(c, hipGetLastError());
   return LCS_OK;
 }
 int lcs_launch_xcorr_i8(lcs_ctx *c, hipStream_t sxc, const XcGeom &geo, int slot0, int n_slots, int xcd_map) {
   const unsigned grid = (unsigned)(I8_TILES * geo.G * n_slots);
-  hipLaunchKernelGGL(k_xcorr_i8x3, dim3(grid), dim3(256), 0, sxc, c->cap8, c->cap8s, c->smin, c->bt8, c->tsc, c->single, geo, slot0,
+  hipLaunchKernelGGL(k_xcorr_i8x3, dim3(grid), dim3(256), 0, sxc, c->cap8, c->cap8s, c->smin, c->start, c->brow8, c->tsc, c->single, geo, slot0,
                      n_slots, xcd_map);
   HIPCHK(c, hipGetLastError());
   // executed work: per wave and window 3 digits x I8_NKB tap blocks x I8_MT sub-tiles x (re, im) MFMAs of 16x16x64 MACs
