@@ -54,12 +54,12 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 #define I8_LAGS (4 * I8_MT * 16)
 #define I8_TILES ((LCS_N_IDX + I8_LAGS - 1) / I8_LAGS)
 #define I8_NKB LCS_I8_KB                                  // 32-tap blocks per window: 137 taps + delay < 160
-#define I8_AW (I8_LAGS + 32 * I8_NKB + 32)                // staged samples per window
-#define I8_ADW (((I8_AW / 2 + 63) / 64) * 64)             // dwords per staged copy: whole 64-dword LDS-DMA chunks
-// I8_ADW is a multiple of 32, + 16 puts the shifted copy 16 banks away from the natural one, so the even-lag lanes
-// (natural copy, banks 0..12 of a 32-lane group) and the odd-lag lanes (shifted copy) of one ds_read never meet
-// on a bank (with + 2 they did: SQ_LDS_BANK_CONFLICT = 16 % of the kernel's cycles)
-#define I8_ACOPY (I8_ADW + 16)
+// A wave's own staged samples: 128 lags + 32 * I8_NKB taps; lane (i, kg) reads dwords (i + 8 kg) / 2 + 8 S .. + 3 of
+// operand S = 2 kb + mt <= 15: 143 dwords per copy.  The shifted copy sits 144 dwords = 16 banks (mod 32) behind the
+// natural one, so the even-lag lanes (natural copy, banks 0..12 of a 32-lane group) and the odd-lag lanes (shifted
+// copy) of one ds_read never meet on a bank (2 banks apart they did: SQ_LDS_BANK_CONFLICT = 16 % of the kernel's cycles)
+#define I8_PCPY 144
+static_assert(I8_PCPY >= (15 + 24) / 2 + 8 * (2 * (I8_NKB - 1) + I8_MT - 1) + 4 && I8_PCPY % 32 == 16 && I8_PCPY % 4 == 0, "sample staging");
 #define I8_QMAX 8300000.0                                 // |T_int| bound: three balanced base-256 digits reach 8 355 711
 
 // Geometry of the operand image (LCS_I8_OFF, LCS_I8_IMG: lcs_internal.h)
@@ -146,19 +146,22 @@ __global__ __launch_bounds__(256) void k_fill_brow_i8(const float2 *__restrict__
   }
 }
 
-// The operand image reaches LDS once, at the workgroup's start; the capture samples of a window -- two copies, natural
-// and shifted by one sample, each a run of dwords (= sample pairs) taken from cap8 or cap8s, whichever holds the window
-// start dword aligned -- one window ahead right behind the window's barrier; both by LDS-DMA (global_load_lds: no
-// staging registers, no ds_write pass).  The B operands and the two new A operands of tap block e + 1 are read from LDS
-// behind the first MFMA pair of block e, so the LDS latency sits under 14 MFMAs instead of in front of every block.
-// The digit passes walk the tap blocks boustrophedon (digit 2: kb 0..4, digit 1: kb 4..0, digit 0: kb 0..4) so the
-// sliding A window never restarts: 32 A-operand reads per window instead of 48.
+// The operand image reaches LDS once, at the workgroup's start (one barrier).  From there on a wave works alone: it
+// stages its OWN samples -- 128 lags + 160 taps as two copies, natural and shifted by one sample, each a run of dwords
+// (= sample pairs) taken from cap8 or cap8s, whichever holds the window start dword aligned: two global_load_lds_dwordx4
+// of 36 lanes -- one window ahead, waits only for its own LDS-DMA (s_waitcnt vmcnt(0) at the top of a window), and
+// never meets the other three waves at a barrier again (round 4; rounds 1-3 staged one window per workgroup behind a
+// barrier per window: same-box A/B + 1 %, 1.8 x the sample bytes through LDS-DMA, 9.2 instead of 6.4 KB of LDS).
+// The B operands and the two new A operands of tap block e + 1 are read from LDS behind the first MFMA pair of block e,
+// so the LDS latency sits under 14 MFMAs instead of in front of every block.  The digit passes walk the tap blocks
+// boustrophedon (digit 2: kb 0..4, digit 1: kb 4..0, digit 0: kb 0..4) so the sliding A window never restarts: 32
+// A-operand reads per window instead of 48.
 // Epilogue work is spread under the MFMA stream where its inputs allow: the digit-2 sums are converted to float
 // while the digit-1 pass runs, the << 8 of the shared digit-1/0 accumulator sits in front of each sub-tile's first
 // digit-0 MFMA; what is left behind the last block is 6 VALU operations per output.
-// Measured (isolated, 64 buffers, 16x16x64 issues every ~18 cycles: tools/microbench/mfma_rate.hip): the 15 tap
-// blocks of a window run at the MFMA issue rate (0.059 ms per block-launch); the rest is per-window and
-// per-workgroup cost (barrier, epilogue, prologue of each of the 15 workgroup rounds, last round 25 % full).
+// Measured (isolated, 16x16x64 issues every ~18 cycles: tools/microbench/mfma_rate.hip): 240 MFMAs x 18 cycles x 15
+// windows x 2 waves per SIMD = 130 k of a workgroup's ~160 k cycles; the rest is the image load, the per-window operand
+// latency in front of the first MFMA, and the share of the epilogues the SIMD's other wave does not cover.
 __global__ __launch_bounds__(256, 2) void k_xcorr_i8x3(const uint16_t *__restrict__ cap8, const uint16_t *__restrict__ cap8s,
                                                           const int *__restrict__ smin, const int *__restrict__ start,
                                                           const uint32_t *__restrict__ brow,
@@ -173,13 +176,13 @@ __global__ __launch_bounds__(256, 2) void k_xcorr_i8x3(const uint16_t *__restric
   const int slot = slot0 + sidx, g = q / I8_TILES, idx0 = (q % I8_TILES) * I8_LAGS;
   const int widx0 = idx0 + wave * (I8_MT * 16);
 
-  __shared__ uint32_t ldsA[2][2][I8_ACOPY];
+  constexpr int PCPY = I8_PCPY, PBUF = 2 * PCPY;
+  __shared__ uint32_t ldsA0[4][PBUF], ldsA1[4][PBUF];      // per wave: [natural copy | shifted copy], two buffers (two VARIABLES, see below)
   __shared__ uint32_t ldsR[I8R_IMG];
   constexpr int NBLK = 3 * I8_NKB;
-  constexpr int NCA = 2 * (I8_ADW / 64);  // 256-byte chunks of the two sample copies: one global_load_lds_dword per wave each
   const size_t cstride = lcs_cap8_stride(geo.n_cap);
-  const uint32_t *capd = reinterpret_cast<const uint32_t *>(cap8 + (size_t)slot * cstride) + lane;     // dword j = samples (2j, 2j+1)
-  const uint32_t *capsd = reinterpret_cast<const uint32_t *>(cap8s + (size_t)slot * cstride) + lane;   // dword j = samples (2j+1, 2j+2)
+  const uint32_t *capd = reinterpret_cast<const uint32_t *>(cap8 + (size_t)slot * cstride) + 4 * lane;     // dword j = samples (2j, 2j+1)
+  const uint32_t *capsd = reinterpret_cast<const uint32_t *>(cap8s + (size_t)slot * cstride) + 4 * lane;   // dword j = samples (2j+1, 2j+2)
   const int *smin_s = smin + (size_t)slot * NW * GM + g;
   // this lane's column: its delay in window w is start[w][foi] - smin[w][g]; where its row starts in the image
   const int col = lcs_col_tmpl(geo, g, lane & 15);
@@ -201,31 +204,34 @@ __global__ __launch_bounds__(256, 2) void k_xcorr_i8x3(const uint16_t *__restric
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(img + NCI * 256 + wave * 64 + lane),
                                        (__attribute__((address_space(3))) void *)(ldsR + NCI * 256 + wave * 64), 4, 0, 0);
   }
-  int dl_next = (col >= 0) ? start_l[0] - smin_s[0] : 0;
+  int st_next = start_l[0];              // this lane's window start, fetched one window ahead (I8_DELAY_AND_PREFETCH)
   const float my_sc = sc[(size_t)slot * GM * LCS_TG + g * LCS_TG + (lane & 15)];
-  const int p0 = wave * (I8_MT * 16) + (lane & 15) + 8 * (lane >> 4);
+  const int p0 = (lane & 15) + 8 * (lane >> 4);          // relative to the wave's own staged window
   const int par = p0 & 1;
   const int a_dw = (p0 - par) >> 1;
 
   f32x4 P[I8_MT];
 #pragma unroll
   for (int mt = 0; mt < I8_MT; ++mt) P[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  // window W: samples L0 .. of this slot as the natural copy (dword i = samples L0 + 2i, L0 + 2i + 1) and the shifted
+  // The two sample buffers are two LDS VARIABLES and the window loop is unrolled by two, so that in every window the
+  // LDS-DMA destination (the next window's buffer) and the buffer the ds_reads take their operands from are different
+  // objects at compile time.  With one array indexed by w & 1 (rounds 1-3) the compiler cannot tell the two halves apart
+  // and places s_waitcnt vmcnt(0) in front of the window's first ds_read: every window waited for the NEXT window's
+  // samples (and, before the resident rows, its 30 KB of operands) -- the prefetch was never one.  (Removing that wait
+  // moved the kernel by < 1 %: the SIMD's other wave covered it.)
+  // window W of this wave: samples L0 .. as the natural copy (dword i = samples L0 + 2i, L0 + 2i + 1) and the shifted
   // one (L0 + 2i + 1, L0 + 2i + 2); an odd L0 swaps the roles of cap8 and cap8s
-#define I8_DMA(W)                                                                                            \
-  {                                                                                                          \
-    const int L0_ = idx0 + smin_s[(W) * GM], h_ = L0_ >> 1;                                                  \
-    const uint32_t *nat_ = ((L0_ & 1) ? capsd : capd) + h_;                                                  \
-    const uint32_t *shf_ = (L0_ & 1) ? capd + h_ + 1 : capsd + h_;                                           \
-    _Pragma("unroll") for (int c_ = 0; c_ < (NCA + 3) / 4; ++c_) {                                           \
-      const int ca_ = wave + 4 * c_;          /* chunk = (copy, 64-dword piece) */                           \
-      if (ca_ < NCA) {                                                                                       \
-        const int cp_ = ca_ / (I8_ADW / 64), k_ = ca_ % (I8_ADW / 64);                                       \
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)((cp_ ? shf_ : nat_) + 64 * k_), \
-                                         (__attribute__((address_space(3))) void *)(ldsA[(W) & 1][cp_] + 64 * k_), 4, 0, 0); \
-      }                                                                                                      \
-    }                                                                                                        \
-  }
+  auto dma = [&](int W, uint32_t (*dst)[PBUF]) __attribute__((always_inline)) {
+    const int L0_ = widx0 + smin_s[W * GM], h_ = L0_ >> 1;
+    const uint32_t *nat_ = ((L0_ & 1) ? capsd : capd) + h_;
+    const uint32_t *shf_ = (L0_ & 1) ? capd + h_ + 1 : capsd + h_;
+    if (lane < PCPY / 4) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)nat_,
+                                       (__attribute__((address_space(3))) void *)(dst[wave]), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)shf_,
+                                       (__attribute__((address_space(3))) void *)(dst[wave] + PCPY), 16, 0, 0);
+    }
+  };
 #define I8_RD_A(S) { const uint32_t *p_ = bufA + 8 * (S); Aw[S] = (i32x4){(int)p_[0], (int)p_[1], (int)p_[2], (int)p_[3]}; }
   // B operand of (digit D, tap block KB, output OP): 4 dwords of this lane's row in the copy matching its delay's parity
 #define I8_RD_B(D, KB, OP, DST)                                                                              \
@@ -233,14 +239,22 @@ __global__ __launch_bounds__(256, 2) void k_xcorr_i8x3(const uint16_t *__restric
     const uint32_t *q_ = bl + ((D) * 2 + (OP)) * I8R_BLK + 16 * (KB);                                        \
     DST = (i32x4){(int)q_[0], (int)q_[1], (int)q_[2], (int)q_[3]};                                           \
   }
-  I8_DMA(0);
-  for (int w = 0; w < geo.n_comb; ++w) {
-    __syncthreads();                       // drains this wave's LDS-DMA chunks of window w (vmcnt(0)), then everybody's
-    if (w + 1 < geo.n_comb) I8_DMA(w + 1); // buffer (w + 1) & 1: last read in window w - 1
-    const int dl = dl_next;                // this lane's delay in window w; the next window's is fetched under this one
-    if (w + 1 < geo.n_comb) dl_next = (col >= 0) ? start_l[(w + 1) * NFM] - smin_s[(w + 1) * GM] : 0;
-    const uint32_t *bl = ldsR + (dl & 1) * I8R_COPY + rowbase - (dl >> 1);
-    const uint32_t *bufA = ldsA[w & 1][par] + a_dw;
+  // behind the wait that opens a window nothing is in flight: the delay fetched during the last window is consumed HERE,
+  // before anything new is requested (vmcnt counts in order -- looked at later, the value would drag a wait for the
+  // samples requested in between with it); then the next window's start, then its samples (the other buffer: last read
+  // in window w - 1)
+#define I8_DELAY_AND_PREFETCH                                                                                \
+    const int dl = (col >= 0) ? st_next - smin_s[w * GM] : 0;      /* this lane's delay in window w */        \
+    const uint32_t *bl = ldsR + (dl & 1) * I8R_COPY + rowbase - (dl >> 1);                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    if (w + 1 < geo.n_comb) { st_next = start_l[(w + 1) * NFM]; dma(w + 1, wrA); }                           \
+    __builtin_amdgcn_sched_barrier(0);
+  auto window = [&](int w, const uint32_t (*rdA)[PBUF], uint32_t (*wrA)[PBUF]) __attribute__((always_inline)) {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);    // vmcnt(0), other counters untouched: this wave's own samples of window w have landed; nobody else reads them
+    __builtin_amdgcn_sched_barrier(0);
+    I8_DELAY_AND_PREFETCH
+    const uint32_t *bufA = rdA[wave] + par * PCPY + a_dw;
     // digit 2 accumulates into (tR, tI); digits 1 and 0 share one int32 accumulator: after the digit-1 pass it is
     // shifted left by 8 and the digit-0 products are added on top (|S1| <= 274 * 128 * 128 = 4.5e6, so
     // 256 S1 + S0 stays below 2^31): one int -> float conversion per digit group instead of per digit.
@@ -303,9 +317,15 @@ __global__ __launch_bounds__(256, 2) void k_xcorr_i8x3(const uint16_t *__restric
         const float xi = fmaf(fI[mt][r], 65536.f, (float)aI[mt][r]);
         P[mt][r] = fmaf(xi, xi, fmaf(xr, xr, P[mt][r]));
       }
+  };
+  dma(0, ldsA0);
+  __syncthreads();                         // the operand image is complete (every wave's chunks: vmcnt(0) in front of the barrier)
+  for (int w = 0; w < geo.n_comb; w += 2) {
+    window(w, ldsA0, ldsA1);
+    if (w + 1 < geo.n_comb) window(w + 1, ldsA1, ldsA0);
   }
-#undef I8_DMA
 #undef I8_RD_A
+#undef I8_DELAY_AND_PREFETCH
 #undef I8_RD_B
   const float ncomb = (float)geo.n_comb;
   float *o = sg + (((size_t)slot * geo.G + g) * LCS_N_IDX) * LCS_TG + (lane & 15);
