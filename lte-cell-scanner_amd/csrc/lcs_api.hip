@@ -89,7 +89,7 @@ int ensure_ws(lcs_ctx *c, int n_slots, uint32_t n_cap, int n_f, bool debug, int 
   if (c->tq) { (void)hipFree(c->tq); c->tq = nullptr; }
   if (c->tsc) { (void)hipFree(c->tsc); c->tsc = nullptr; }
   c->i8_ready = false;
-  for (void **q : {(void **)&c->cap16h, (void **)&c->cap16l, (void **)&c->bt16, (void **)&c->texp16, (void **)&c->tsc16, (void **)&c->xmax16, (void **)&c->xpart16})
+  for (void **q : {(void **)&c->cap16h, (void **)&c->cap16l, (void **)&c->brow16, (void **)&c->texp16, (void **)&c->tsc16, (void **)&c->xmax16, (void **)&c->xpart16})
     if (*q) { (void)hipFree(*q); *q = nullptr; }
   c->f16_ready = false;
   c->cap_slots = n_slots;
@@ -124,7 +124,7 @@ int ensure_f16(lcs_ctx *c) {
   int rc;
   const size_t n16 = S * lcs_cap8_stride(c->cap_n_cap);
   if ((rc = dev_alloc(c, &c->cap16h, n16)) || (rc = dev_alloc(c, &c->cap16l, n16))) return rc;
-  if ((rc = dev_alloc(c, &c->bt16, S * LCS_NW_MAX * c->cap_G * lcs_bt16_elems_per_wg()))) return rc;
+  if ((rc = dev_alloc(c, &c->brow16, S * c->cap_G * (size_t)LCS_F16_IMG))) return rc;
   if ((rc = dev_alloc(c, &c->texp16, S * LCS_G_MAX * LCS_TG)) || (rc = dev_alloc(c, &c->tsc16, S * LCS_G_MAX * LCS_TG))) return rc;
   if ((rc = dev_alloc(c, &c->xmax16, S)) || (rc = dev_alloc(c, &c->xpart16, S * 128))) return rc;
   c->f16_ready = true;
@@ -315,7 +315,7 @@ void lcs_destroy(lcs_ctx *c) {
                   c->incoh, c->sref, c->pow_, c->work, c->spinc, c->zth, c->sp, c->frq, c->peaks, c->npeaks, c->xc,
                   c->work_items, c->n_work, c->tfg, c->tfg_comp, c->ce, c->tfg_ts, c->tfg_ts_comp, c->cell_scratch,
                   c->cells_out, c->d_pss_td, c->d_pss_fd, c->d_sss_fd, c->d_pbch_scr, c->d_derm_inv, c->d_dbg, c->pk_items, c->n_pk,
-                  c->sss_ws, c->d_pn_jump, c->cap8, c->cap8s, c->brow8, c->tq, c->tsc, c->cap16h, c->cap16l, c->bt16, c->texp16, c->tsc16, c->xmax16, c->xpart16, c->h2d, c->trk_td, c->trk_syms, c->trk_raw, c->trk_ce,
+                  c->sss_ws, c->d_pn_jump, c->cap8, c->cap8s, c->brow8, c->tq, c->tsc, c->cap16h, c->cap16l, c->brow16, c->texp16, c->tsc16, c->xmax16, c->xpart16, c->h2d, c->trk_td, c->trk_syms, c->trk_raw, c->trk_ce,
                   c->trk_meta, c->trk_rs, c->trk_fmeta, c->trk_pw, c->trk_idx, c->trk_small, c->trk_cells, c->trk_acfd, c->trk_actd,
                   c->trk_syncce, c->trk_sync, c->d_flag};
   for (void *p : ptrs) if (p) (void)hipFree(p);

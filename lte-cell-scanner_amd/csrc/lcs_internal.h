@@ -38,6 +38,7 @@
 #define LCS_I8_OFF 16        // int8 kernel: a template column's delay inside its group (window-start spread) stays below this
 #define LCS_I8_MAX_TAPS (137 + LCS_I8_OFF - 1)
 #define LCS_I8_IMG 17024     // dwords of the int8 kernel's operand image per (buffer, group) (pss_xcorr_i8.hip)
+#define LCS_F16_IMG 11840    // the same for the fp16 kernel (pss_xcorr_f16.hip)
 #define LCS_MAX_WORK 1024    // cells carried into the TFG/MIB stages per round (~6 MB each: 6 GB per context, allocated on first use)
 // grid sizes of the work-list kernels (every one loops over its list, so these only trade latency for workgroups)
 #define LCS_WIN_GRID 4096
@@ -150,7 +151,7 @@ struct lcs_ctx {
   bool i8_ready = false, use_i8 = false;
   // fp16 three-product path (pss_xcorr_f16.hip): complex<float> sources of the batched device entry points
   uint32_t *cap16h = nullptr, *cap16l = nullptr;   // (re, im) fp16 pairs, hi and lo parts, slot stride lcs_cap8_stride
-  uint4 *bt16 = nullptr;             // template operands, hi and lo terms
+  uint32_t *brow16 = nullptr;        // template operands, hi and lo terms: one image of resident rows per (slot, group)
   int *texp16 = nullptr;             // per template column: power-of-two scale exponent
   float *tsc16 = nullptr;            // per template column: 2^-(k_x + k_t)
   unsigned *xmax16 = nullptr;        // per slot: bits of the largest |component|
@@ -292,9 +293,8 @@ int lcs_launch_fill_brow_i8(lcs_ctx *c, int n_buf, const XcGeom &geo);
 int lcs_launch_xcorr_i8(lcs_ctx *c, hipStream_t sxc, const XcGeom &geo, int slot0, int n_slots, int xcd_map);
 // pss_xcorr_f16.hip
 int lcs_launch_ingest_f16(lcs_ctx *c, const void *d_src, int n_buf, uint32_t n_cap);   // complex<float> -> cap32 + fp16 hi / lo pairs + per-buffer scale
-int lcs_launch_fill_btab_f16(lcs_ctx *c, int n_buf, const XcGeom &geo);
+int lcs_launch_fill_brow_f16(lcs_ctx *c, int n_buf, const XcGeom &geo);
 int lcs_launch_xcorr_f16(lcs_ctx *c, hipStream_t sxc, const XcGeom &geo, int slot0, int n_slots, int xcd_map);
-size_t lcs_bt16_elems_per_wg(void);
 
 int lcs_launch_xc_debug(lcs_ctx *c, const XcGeom &geo);   // raw xc for slot 0 (debug output only)
 // peak_search.hip

@@ -801,7 +801,7 @@ int lcs_launch_xcorr(lcs_ctx *c, int n_buf, const XcGeom &geo, bool want_incoh, 
     int rc_ = lcs_launch_fill_brow_i8(c, n_buf, geo);
     if (rc_) return rc_;
   } else if (c->use_f16) {
-    int rc_ = lcs_launch_fill_btab_f16(c, n_buf, geo);
+    int rc_ = lcs_launch_fill_brow_f16(c, n_buf, geo);
     if (rc_) return rc_;
   } else
     hipLaunchKernelGGL(k_fill_btab, dim3(geo.n_comb * geo.G * n_buf), dim3(256), 0, c->stream, c->tmpl,

@@ -15,10 +15,9 @@
 // delays.  v_mfma_f32_16x16x32_f16 takes K = 32 = 16 taps: lane (i, kg) of an A operand holds samples lag_i + 16 kb +
 // 4 kg .. + 3 (16 bytes, read from LDS at 4-byte alignment), the operand of (sub-tile mt, tap block kb) depends on mt + kb
 // only and slides by one operand per block.  256-thread workgroup = 512 lags x one 16-template group, 8 sub-tiles per
-// wave; a window is 10 tap blocks (160 taps) in two chunks of 5: the B operands of a chunk (hi and lo terms, both
-// outputs: 20 KB) are double-buffered in LDS by LDS-DMA one chunk ahead, the samples (hi and lo, 5.6 KB) one window
-// ahead.  52 KB of LDS, 64 fp32 accumulators + 32 power sums per lane: no digit recombination, the epilogue is two FMAs
-// per output and window.
+// wave; a window is 10 tap blocks (160 taps).  The B operands are resident rows (below: one 46 KB image per (buffer,
+// group), loaded once per workgroup), the samples are staged per wave one window ahead; 64 KB of LDS, 64 fp32
+// accumulators + 32 power sums per lane: no digit recombination, the epilogue is two FMAs per output and window.
 #include "lcs_internal.h"
 #include <algorithm>
 
@@ -33,10 +32,6 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 #define F16_LAGS (4 * F16_MT * 16)
 #define F16_TILES ((LCS_N_IDX + F16_LAGS - 1) / F16_LAGS)
 #define F16_NKB 10                                        // 16-tap blocks per window: 137 taps + spread <= 160
-#define F16_CH 5                                          // tap blocks per B chunk
-#define F16_AW (F16_LAGS + 16 * F16_NKB + 16)             // staged samples per window
-#define F16_ADW (((F16_AW + 63) / 64) * 64)               // dwords (= samples) per staged array: whole 64-dword LDS-DMA pieces
-#define F16_CHUNK (2 * F16_CH * 2 * 64)                   // uint4 per B chunk: [term hi / lo][kb][op][lane]
 #define F16_TARGET_EXP 9                                  // operands are scaled into [2^9, 2^10)
 
 __device__ __forceinline__ uint32_t f16_bits(_Float16 h) { return (uint32_t)__builtin_bit_cast(unsigned short, h); }
@@ -174,56 +169,63 @@ __global__ __launch_bounds__(256) void k_f16_scales(const float2 *__restrict__ t
   }
 }
 
-// bt16[slot][w][g][chunk][term][kbc][op][lane] (uint4 = 8 fp16): lane (n, kg) holds taps 16 kb + 4 kg .. + 3 (kb = 5 chunk +
-// kbc) of template column 16 g + n delayed by start[w][foi] - smin[w][g] (zero outside its 137 taps) as the pairs (tr, -ti)
-// (op 0, real output) or (ti, tr) (op 1, imaginary output); term 0 = fp16(value), term 1 = fp16(value - term 0).
-__global__ __launch_bounds__(256) void k_fill_btab_f16(const float2 *__restrict__ tmpl, const int *__restrict__ start, const int *__restrict__ smin,
-                                                       const int *__restrict__ texp, uint4 *__restrict__ bt16, XcGeom geo) {
+// Resident operand rows, as in pss_xcorr_i8.hip: across the windows of a buffer a template column changes only by its
+// delay inside its group, so a workgroup loads ONE operand image per (buffer, group) into LDS at its start (46 KB) and
+// every lane reads its 4 taps of tap block kb at dword 16 kb + 4 kg + F16R_OFF - delay of its column's row.  An fp16
+// (re, im) pair is one dword, so any integer delay is dword aligned: one copy of every row (the int8 kernel's 2-byte
+// pairs need two).  brow16[slot][g][term][op][row(n)][i]: position i = tap i - F16R_OFF; term 0 = fp16(value), term 1 =
+// fp16(value - term 0); op 0: pairs (tr, -ti) (real output), op 1: pairs (ti, tr) (imaginary output).  Rows of
+// consecutive columns sit 184 dwords apart plus n >> 2: 184 n = -8 n (mod 32) gives banks {0, 24, 16, 8} + (n >> 2), so
+// the 32 lanes of a dword read (16 columns x 2 tap quads, 4 banks apart) fall on 32 different banks when their delays agree.
+// (Rounds 3-4a: a 40 KB operand table per (window, group), copied into LDS in two chunks per window behind two barriers.)
+#define F16R_OFF LCS_I8_OFF
+#define F16R_ROW 184
+#define F16R_RLEN 176
+#define F16R_BLK 2948
+#define F16R_IMG LCS_F16_IMG
+static_assert(F16R_RLEN >= 16 * (F16_NKB - 1) + 12 + F16R_OFF + 4 && F16R_BLK >= 15 * F16R_ROW + 3 + F16R_RLEN && F16R_IMG >= 4 * F16R_BLK &&
+              F16R_IMG % 64 == 0 && F16R_ROW % 32 == 24 && 137 + F16R_OFF - 1 <= 16 * F16_NKB, "operand image geometry");
+__host__ __device__ static inline int f16r_rowoff(int n) { return n * F16R_ROW + (n >> 2); }
+
+__global__ __launch_bounds__(256) void k_fill_brow_f16(const float2 *__restrict__ tmpl, const int *__restrict__ texp, uint32_t *__restrict__ brow,
+                                                       XcGeom geo) {
   LCS_TAIL_PRIO();
-  const int slot = blockIdx.z, wg = blockIdx.y, w = wg / geo.G, g = wg % geo.G;
-  const int s0 = smin[((size_t)slot * NW + w) * GM + g];
-  uint4 *out = bt16 + (((size_t)slot * geo.n_comb + w) * geo.G + g) * (size_t)(2 * F16_CHUNK);
-  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < F16_NKB * 64; e += gridDim.x * blockDim.x) {
-    const int lane = e & 63, kb = e >> 6;
-    const int c = lcs_col_tmpl(geo, g, lane & 15), kg = lane >> 4;
-    float tr[4] = {0.f, 0.f, 0.f, 0.f}, ti[4] = {0.f, 0.f, 0.f, 0.f};
-    if (c >= 0) {
-      const int foi = c / 3, t = c % 3;
-      const int delta = start[((size_t)slot * NW + w) * NFM + foi] - s0;
-      const int kt = texp[(size_t)slot * GM * LCS_TG + g * LCS_TG + (lane & 15)];
-      const float2 *T = tmpl + (((size_t)slot * NFM + foi) * 3 + t) * 137;
-#pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        const int tap = 16 * kb + 4 * kg + m - delta;
-        if (tap >= 0 && tap < 137) { tr[m] = ldexpf(T[tap].x, kt); ti[m] = ldexpf(T[tap].y, kt); }
-      }
+  const int slot = blockIdx.z, g = blockIdx.y;
+  uint32_t *out = brow + ((size_t)slot * geo.G + g) * F16R_IMG;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < LCS_TG * F16R_RLEN; e += gridDim.x * blockDim.x) {
+    const int n = e / F16R_RLEN, i = e % F16R_RLEN;
+    const int c = lcs_col_tmpl(geo, g, n), tap = i - F16R_OFF;
+    float tr = 0.f, ti = 0.f;
+    if (c >= 0 && tap >= 0 && tap < 137) {
+      const int kt = texp[(size_t)slot * GM * LCS_TG + g * LCS_TG + n];
+      const float2 T = tmpl[(((size_t)slot * NFM + c / 3) * 3 + c % 3) * 137 + tap];
+      tr = ldexpf(T.x, kt); ti = ldexpf(T.y, kt);
     }
 #pragma unroll
     for (int op = 0; op < 2; ++op) {
-      uint32_t hi[4], lo[4];
-#pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        const float a = op ? ti[m] : tr[m], b = op ? tr[m] : -ti[m];       // (tr, -ti) or (ti, tr)
-        _Float16 ah, al, bh, bl;
-        f16_split(a, ah, al);
-        f16_split(b, bh, bl);
-        hi[m] = f16_bits(ah) | (f16_bits(bh) << 16);
-        lo[m] = f16_bits(al) | (f16_bits(bl) << 16);
-      }
-      const int chunk = kb / F16_CH, kbc = kb % F16_CH;
-      uint4 *o = out + (size_t)chunk * F16_CHUNK;
-      typedef unsigned u4v __attribute__((ext_vector_type(4)));
-      const u4v vh = {hi[0], hi[1], hi[2], hi[3]}, vl = {lo[0], lo[1], lo[2], lo[3]};
-      __builtin_nontemporal_store(vh, reinterpret_cast<u4v *>(o + ((0 * F16_CH + kbc) * 2 + op) * 64 + lane));
-      __builtin_nontemporal_store(vl, reinterpret_cast<u4v *>(o + ((1 * F16_CH + kbc) * 2 + op) * 64 + lane));
+      const float a = op ? ti : tr, b = op ? tr : -ti;       // (tr, -ti) or (ti, tr)
+      _Float16 ah, al, bh, bl;
+      f16_split(a, ah, al);
+      f16_split(b, bh, bl);
+      out[(0 * 2 + op) * F16R_BLK + f16r_rowoff(n) + i] = f16_bits(ah) | (f16_bits(bh) << 16);
+      out[(1 * 2 + op) * F16R_BLK + f16r_rowoff(n) + i] = f16_bits(al) | (f16_bits(bl) << 16);
     }
   }
 }
 
+// One barrier behind the image load; from there on every wave stages its OWN samples (hi and lo arrays of 128 lags + 160
+// taps, two global_load_lds_dwordx4 of 36 lanes each) one window ahead into one of two LDS VARIABLES -- the window loop is
+// unrolled by two so that the LDS-DMA destination and the array the operands are read from are different objects at
+// compile time (with one array indexed by w & 1 the compiler waits for the next window's samples in front of the first
+// operand read; the same happens when the operands are read as under-aligned 16-byte vectors instead of dwords, or when
+// the LDS-DMA instructions of a window sit in more than one conditional block) -- and waits only for its own LDS-DMA.
+// Per window 10 tap blocks x 3 products x 8 sub-tiles x (re, im) MFMAs.
+#define F16_PA 288                                        // dwords (= samples) of a wave's staged array: 27 + 16 * 16 + 4 <= 288
+static_assert(F16_PA >= 15 + 12 + 16 * (F16_NKB - 1 + F16_MT - 1) + 4 && F16_PA % 8 == 0 && F16_PA / 8 <= 64, "sample staging");
 __global__ __launch_bounds__(256, 2) void k_xcorr_f16x3(const uint32_t *__restrict__ cap16h, const uint32_t *__restrict__ cap16l,
-                                                        const int *__restrict__ smin, const uint4 *__restrict__ bt16,
-                                                        const float *__restrict__ sc, float *__restrict__ sg, XcGeom geo, int slot0,
-                                                        int n_slots, int xcd_map) {
+                                                        const int *__restrict__ smin, const int *__restrict__ start,
+                                                        const uint32_t *__restrict__ brow, const float *__restrict__ sc, float *__restrict__ sg,
+                                                        XcGeom geo, int slot0, int n_slots, int xcd_map) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int per_slot = F16_TILES * geo.G;
   int q, sidx;
@@ -233,88 +235,100 @@ __global__ __launch_bounds__(256, 2) void k_xcorr_f16x3(const uint32_t *__restri
   const int slot = slot0 + sidx, g = q / F16_TILES, idx0 = (q % F16_TILES) * F16_LAGS;
   const int widx0 = idx0 + wave * (F16_MT * 16);
 
-  __shared__ uint32_t ldsA[2][2][F16_ADW];       // [window & 1][hi, lo][sample]
-  __shared__ uint4 ldsB[2][F16_CHUNK];           // [chunk counter & 1]
-  constexpr int NCB = F16_CHUNK / 64;            // 1 KiB pieces of a B chunk
-  constexpr int NCA = 2 * (F16_ADW / 64);        // 256-byte pieces of the two sample arrays
+  __shared__ uint32_t ldsA0[4][2][F16_PA], ldsA1[4][2][F16_PA];      // per wave: [hi, lo][sample], two buffers = two variables
+  __shared__ uint32_t ldsR[F16R_IMG];
   const size_t cstride = lcs_cap8_stride(geo.n_cap);
-  const uint32_t *caph = cap16h + (size_t)slot * cstride + lane, *capl = cap16l + (size_t)slot * cstride + lane;
+  const uint32_t *caph = cap16h + (size_t)slot * cstride + 4 * lane, *capl = cap16l + (size_t)slot * cstride + 4 * lane;
   const int *smin_s = smin + (size_t)slot * NW * GM + g;
-  const uint4 *bt_s = bt16 + ((size_t)slot * geo.n_comb * geo.G + g) * (size_t)(2 * F16_CHUNK) + lane;
-  const size_t bt_wstride = (size_t)geo.G * (2 * F16_CHUNK);
+  const int col = lcs_col_tmpl(geo, g, lane & 15);
+  const int *start_l = start + (size_t)slot * NW * NFM + (col >= 0 ? col / 3 : 0);
+  const int rowbase = f16r_rowoff(lane & 15) + 4 * (lane >> 4) + F16R_OFF;
+  {
+    const uint32_t *img = brow + ((size_t)slot * geo.G + g) * F16R_IMG;
+    constexpr int NCI = F16R_IMG / 256, NTL = (F16R_IMG - NCI * 256) / 64;
+    static_assert(F16R_IMG == NCI * 256 + NTL * 64 && NTL < 4, "image = whole 1 KiB chunks + up to three 64-dword pieces");
+#pragma unroll
+    for (int c_ = 0; c_ < (NCI + 3) / 4; ++c_) {
+      const int ch_ = wave + 4 * c_;
+      if (ch_ < NCI)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(img + ch_ * 256 + lane * 4),
+                                         (__attribute__((address_space(3))) void *)(ldsR + ch_ * 256), 16, 0, 0);
+    }
+    if (wave < NTL)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(img + NCI * 256 + wave * 64 + lane),
+                                       (__attribute__((address_space(3))) void *)(ldsR + NCI * 256 + wave * 64), 4, 0, 0);
+  }
+  int st_next = start_l[0];              // this lane's window start, fetched one window ahead
   const float my_sc = sc[(size_t)slot * GM * LCS_TG + g * LCS_TG + (lane & 15)];
-  const int p0 = wave * (F16_MT * 16) + (lane & 15) + 4 * (lane >> 4);     // first sample of this lane's operand 0 in the staged window
+  const int p0 = (lane & 15) + 4 * (lane >> 4);     // first sample of this lane's operand 0 in the wave's staged window
 
   f32x4 P[F16_MT];
 #pragma unroll
   for (int mt = 0; mt < F16_MT; ++mt) P[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-#define F16_DMA_A(W)                                                                                         \
-  {                                                                                                          \
-    const int L0_ = idx0 + smin_s[(W) * GM];                                                                 \
-    _Pragma("unroll") for (int c_ = 0; c_ < (NCA + 3) / 4; ++c_) {                                           \
-      const int ca_ = wave + 4 * c_;                                                                         \
-      if (ca_ < NCA) {                                                                                       \
-        const int hl_ = ca_ / (F16_ADW / 64), k_ = ca_ % (F16_ADW / 64);                                     \
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)((hl_ ? capl : caph) + L0_ + 64 * k_), \
-                                         (__attribute__((address_space(3))) void *)(ldsA[(W) & 1][hl_] + 64 * k_), 4, 0, 0); \
-      }                                                                                                      \
-    }                                                                                                        \
-  }
-#define F16_DMA_B(W, C, CC)                                                                                  \
-  {                                                                                                          \
-    uint4 *dst_ = ldsB[(CC) & 1];                                                                            \
-    const uint4 *src_ = bt_s + (size_t)(W) * bt_wstride + (size_t)(C) * F16_CHUNK;                           \
-    _Pragma("unroll") for (int c_ = 0; c_ < (NCB + 3) / 4; ++c_) {                                           \
-      const int ch_ = wave + 4 * c_;                                                                         \
-      if (ch_ < NCB)                                                                                         \
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src_ + ch_ * 64),  \
-                                         (__attribute__((address_space(3))) void *)(dst_ + ch_ * 64), 16, 0, 0); \
-    }                                                                                                        \
-  }
-  // 16 bytes = 4 samples from a 4-byte aligned LDS address (the window starts at any sample)
-  typedef unsigned int u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+  auto dma = [&](int W, uint32_t (*dst)[2][F16_PA]) __attribute__((always_inline)) {
+    const int L0_ = widx0 + smin_s[W * GM];
+    if (lane < F16_PA / 8) {               // 36 lanes x 16 bytes = half an array per instruction
+#pragma unroll
+      for (int hl = 0; hl < 2; ++hl)
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)((hl ? capl : caph) + (L0_ + half * (F16_PA / 2))),
+                                           (__attribute__((address_space(3))) void *)(dst[wave][hl] + half * (F16_PA / 2)), 16, 0, 0);
+    }
+  };
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-#define F16_RD_A(U) { const u32x4 th_ = *reinterpret_cast<const u32x4_a4 *>(bufAh + 16 * (U)); const u32x4 tl_ = *reinterpret_cast<const u32x4_a4 *>(bufAl + 16 * (U)); \
-                      Ah[(U) % (F16_MT + 1)] = __builtin_bit_cast(h8, th_); Al[(U) % (F16_MT + 1)] = __builtin_bit_cast(h8, tl_); }
+  // 16 bytes = 4 samples from a 4-byte aligned LDS address (the window starts at any sample), read as four dwords
+#define F16_RD_AH(U) { const uint32_t *ph_ = bufAh + 16 * (U); const u32x4 th_ = {ph_[0], ph_[1], ph_[2], ph_[3]}; Ah[(U) % F16_MT] = __builtin_bit_cast(h8, th_); }
+#define F16_RD_AL(U) { const uint32_t *pl_ = bufAl + 16 * (U); const u32x4 tl_ = {pl_[0], pl_[1], pl_[2], pl_[3]}; Al[(U) % F16_MT] = __builtin_bit_cast(h8, tl_); }
+#define F16_RD_B(KB, TERM, DST)                                                                              \
+    _Pragma("unroll") for (int op_ = 0; op_ < 2; ++op_)                                                      \
+      { const uint32_t *q_ = bl + ((TERM) * 2 + op_) * F16R_BLK + 16 * (KB);                                  \
+        const u32x4 t_ = {q_[0], q_[1], q_[2], q_[3]}; DST[op_] = __builtin_bit_cast(h8, t_); }
 
-  F16_DMA_A(0);
-  F16_DMA_B(0, 0, 0);
-  int cc = 0;                                 // chunk counter: the B buffer in use is cc & 1
-  for (int w = 0; w < geo.n_comb; ++w) {
+  auto window = [&](int w, const uint32_t (*rdA)[2][F16_PA], uint32_t (*wrA)[2][F16_PA]) __attribute__((always_inline)) {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);    // vmcnt(0), other counters untouched: this wave's own samples of window w have landed
+    __builtin_amdgcn_sched_barrier(0);
+    // nothing is in flight here: the delay fetched during the last window is consumed before anything new is requested
+    const int dl = (col >= 0) ? st_next - smin_s[w * GM] : 0;
+    const uint32_t *bl = ldsR + rowbase - dl;
+    __builtin_amdgcn_sched_barrier(0);
+    if (w + 1 < geo.n_comb) { st_next = start_l[(w + 1) * NFM]; dma(w + 1, wrA); }
+    __builtin_amdgcn_sched_barrier(0);
+    const uint32_t *bufAh = rdA[wave][0] + p0, *bufAl = rdA[wave][1] + p0;
     f32x4 aR[F16_MT], aI[F16_MT];
-    h8 Ah[F16_MT + 1], Al[F16_MT + 1];        // operands u = kb .. kb + 7 of the current block, one slot ahead for the next
-    const uint32_t *bufAh = ldsA[w & 1][0] + p0, *bufAl = ldsA[w & 1][1] + p0;
+    h8 Ah[F16_MT], Al[F16_MT];                // operands u = kb .. kb + 7 of the current block; operand kb + 8 replaces operand kb once its last product is issued
+    // two operand sets rotate: block kb holds its hi term in S[kb & 1]; behind the first MFMA pair of product 0 the lo term
+    // goes into the other set (product 1 multiplies it), behind the first pair of product 2 (hi term again) the NEXT block's
+    // hi term replaces it: every B read has 14+ MFMAs to land, in 16 registers.  The samples slide the same way: the hi part
+    // of operand kb is last used by the first pair of product 1, the lo part by the first pair of product 2.
+    h8 S[2][2];                               // [set][op]
 #pragma unroll
-    for (int c = 0; c < 2; ++c, ++cc) {
-      __syncthreads();                        // this chunk's operands (and, at c == 0, the window's samples) have landed; the other buffers are free
-      if (c == 0) { F16_DMA_B(w, 1, cc + 1); }
-      else if (w + 1 < geo.n_comb) { F16_DMA_A(w + 1); F16_DMA_B(w + 1, 0, cc + 1); }
-      const uint4 *bl = ldsB[cc & 1] + lane;
-      if (c == 0) {
+    for (int u = 0; u < F16_MT; ++u) { F16_RD_AH(u); F16_RD_AL(u); }
+    F16_RD_B(0, 0, S[0]);
 #pragma unroll
-        for (int u = 0; u < F16_MT; ++u) F16_RD_A(u);
-      }
+    for (int kb = 0; kb < F16_NKB; ++kb) {
+      // three products per output: xh th, xh tl, xl th; sixteen independent accumulators between two uses of one
 #pragma unroll
-      for (int kbc = 0; kbc < F16_CH; ++kbc) {
-        const int kb = F16_CH * c + kbc;
-        h8 B[2][2];                           // [term][op]
+      for (int pr = 0; pr < 3; ++pr) {
 #pragma unroll
-        for (int term = 0; term < 2; ++term)
-#pragma unroll
-          for (int op = 0; op < 2; ++op) B[term][op] = __builtin_bit_cast(h8, bl[((term * F16_CH + kbc) * 2 + op) * 64]);
-        if (kb + 1 < F16_NKB) F16_RD_A(kb + F16_MT);          // the operand the next block adds
-        // three products per output: xh th, xh tl, xl th; sixteen independent accumulators between two uses of one
-#pragma unroll
-        for (int pr = 0; pr < 3; ++pr) {
-#pragma unroll
-          for (int mt = 0; mt < F16_MT; ++mt) {
-            const h8 a = (pr == 2) ? Al[(kb + mt) % (F16_MT + 1)] : Ah[(kb + mt) % (F16_MT + 1)];
-            const int term = (pr == 1) ? 1 : 0;
-            const f32x4 cr = (kb == 0 && pr == 0) ? (f32x4){0.f, 0.f, 0.f, 0.f} : aR[mt];
-            const f32x4 ci = (kb == 0 && pr == 0) ? (f32x4){0.f, 0.f, 0.f, 0.f} : aI[mt];
-            aR[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, B[term][0], cr, 0, 0, 0);
-            aI[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, B[term][1], ci, 0, 0, 0);
+        for (int mt = 0; mt < F16_MT; ++mt) {
+          const h8 a = (pr == 2) ? Al[(kb + mt) % F16_MT] : Ah[(kb + mt) % F16_MT];
+          const int term = (pr == 1) ? 1 : 0;
+          const f32x4 cr = (kb == 0 && pr == 0) ? (f32x4){0.f, 0.f, 0.f, 0.f} : aR[mt];
+          const f32x4 ci = (kb == 0 && pr == 0) ? (f32x4){0.f, 0.f, 0.f, 0.f} : aI[mt];
+          const int set = (kb + term) & 1;
+          aR[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, S[set][0], cr, 0, 0, 0);
+          aI[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, S[set][1], ci, 0, 0, 0);
+          if (mt == 0) {                      // behind a product's first MFMA pair: the next operands
+            __builtin_amdgcn_sched_barrier(0);
+            if (pr == 0) { F16_RD_B(kb, 1, S[(kb + 1) & 1]); }
+            else if (kb + 1 < F16_NKB) {
+              if (pr == 1) { F16_RD_AH(kb + F16_MT); }
+              else { F16_RD_B(kb + 1, 0, S[(kb + 1) & 1]); F16_RD_AL(kb + F16_MT); }
+            }
+            __builtin_amdgcn_sched_barrier(0);
           }
         }
       }
@@ -323,10 +337,16 @@ __global__ __launch_bounds__(256, 2) void k_xcorr_f16x3(const uint32_t *__restri
     for (int mt = 0; mt < F16_MT; ++mt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) P[mt][r] = fmaf(aI[mt][r], aI[mt][r], fmaf(aR[mt][r], aR[mt][r], P[mt][r]));
+  };
+  dma(0, ldsA0);
+  __syncthreads();                         // the operand image is complete (every wave's chunks: vmcnt(0) in front of the barrier)
+  for (int w = 0; w < geo.n_comb; w += 2) {
+    window(w, ldsA0, ldsA1);
+    if (w + 1 < geo.n_comb) window(w + 1, ldsA1, ldsA0);
   }
-#undef F16_DMA_A
-#undef F16_DMA_B
-#undef F16_RD_A
+#undef F16_RD_AH
+#undef F16_RD_AL
+#undef F16_RD_B
   const float ncomb = (float)geo.n_comb;
   float *o = sg + (((size_t)slot * geo.G + g) * LCS_N_IDX) * LCS_TG + (lane & 15);
 #pragma unroll
@@ -363,21 +383,19 @@ int lcs_launch_ingest_f16(lcs_ctx *c, const void *d_src, int n_buf, uint32_t n_c
   HIPCHK(c, hipGetLastError());
   return LCS_OK;
 }
-int lcs_launch_fill_btab_f16(lcs_ctx *c, int n_buf, const XcGeom &geo) {
+int lcs_launch_fill_brow_f16(lcs_ctx *c, int n_buf, const XcGeom &geo) {
   hipLaunchKernelGGL(k_f16_scales, dim3(n_buf), dim3(256), 0, c->stream, c->tmpl, c->xmax16, c->texp16, c->tsc16, geo);
-  hipLaunchKernelGGL(k_fill_btab_f16, dim3((F16_NKB * 64 + 255) / 256, geo.n_comb * geo.G, n_buf), dim3(256), 0, c->stream, c->tmpl, c->start,
-                     c->smin, c->texp16, c->bt16, geo);
+  hipLaunchKernelGGL(k_fill_brow_f16, dim3((LCS_TG * F16R_RLEN + 255) / 256, geo.G, n_buf), dim3(256), 0, c->stream, c->tmpl, c->texp16, c->brow16, geo);
   HIPCHK(c, hipGetLastError());
   return LCS_OK;
 }
 int lcs_launch_xcorr_f16(lcs_ctx *c, hipStream_t sxc, const XcGeom &geo, int slot0, int n_slots, int xcd_map) {
   const unsigned grid = (unsigned)(F16_TILES * geo.G * n_slots);
-  hipLaunchKernelGGL(k_xcorr_f16x3, dim3(grid), dim3(256), 0, sxc, c->cap16h, c->cap16l, c->smin, c->bt16, c->tsc16, c->single, geo, slot0, n_slots,
-                     xcd_map);
+  hipLaunchKernelGGL(k_xcorr_f16x3, dim3(grid), dim3(256), 0, sxc, c->cap16h, c->cap16l, c->smin, c->start, c->brow16, c->tsc16, c->single, geo, slot0,
+                     n_slots, xcd_map);
   HIPCHK(c, hipGetLastError());
   // executed work: per wave and window 3 products x F16_NKB tap blocks x F16_MT sub-tiles x (re, im) MFMAs of 16x16x32 MACs
   c->last_xc_ops += (double)grid * 4 * geo.n_comb * (3.0 * F16_NKB * F16_MT * 2) * (2.0 * 16 * 16 * 32);
   c->last_xc_kernel = "k_xcorr_f16x3";
   return LCS_OK;
 }
-size_t lcs_bt16_elems_per_wg(void) { return (size_t)(2 * F16_CHUNK); }

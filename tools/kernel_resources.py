@@ -5,7 +5,7 @@ import os, re, subprocess, sys
 
 csrc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "lte-cell-scanner_amd", "csrc")
 pat = re.compile(r"remark:\s+(Function Name|VGPRs|AGPRs|ScratchSize \[bytes/lane\]|LDS Size \[bytes/block\]|Occupancy \[waves/SIMD\]): (\S+)")
-for f in ("pss_xcorr", "pss_xcorr_i8", "peak_search", "sss_foe", "tfg_mib", "tracker"):
+for f in ("pss_xcorr", "pss_xcorr_i8", "pss_xcorr_f16", "peak_search", "sss_foe", "tfg_mib", "tracker"):
     src = os.path.join(csrc, f + ".hip")
     if not os.path.exists(src):
         continue
