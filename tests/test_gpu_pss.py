@@ -369,6 +369,18 @@ def test_sparse_frequency_grids_are_repacked(S, pkg, capbuf_0000):
         _batch_arrays_vs_oracle(S, pkg, [g["iq_u8"]], f, np.array([fc]), 153600, f"sparse grid step {f[1] - f[0]}")
 
 
+def test_operand_row_delay_limit(S, pkg):
+    """The matrix-core kernels keep one operand image per template group in LDS and apply a column's window-start delay
+    when they read it; the rows hold delays 0 .. 15 (LCS_I8_OFF).  At 739 MHz a 16 kHz grid reaches exactly 15 inside a
+    16-column group (kept dense), 17 kHz reaches 16 (repacked with 15 columns per group: 13) and 20 kHz reaches 15 with
+    15 columns: the boundary from both sides, every element of every array against the oracle, int8 and fp16 kernels."""
+    g = golden("capbuf_0000")
+    fc = float(g["fc"][0])
+    for step in (16e3, 17e3, 20e3):
+        f = np.arange(-10, 11) * step
+        _batch_arrays_vs_oracle(S, pkg, [g["iq_u8"]], f, np.array([fc]), 153600, f"delay limit, grid step {step}")
+
+
 def test_fp16_kernel_on_unquantised_float_sources(S, pkg):
     """complex<float> batches whose samples are NOT dongle values take the fp16 three-product kernel (samples and templates
     as fp16 hi + lo parts, 22 bits each): genuinely 24-bit float data of very different scales in one batch (each buffer
