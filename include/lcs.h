@@ -24,7 +24,7 @@
  *    in three int8 digits, exact int32 accumulation); batches of complex<float> buffers (LCS_FMT_C64) run on the fp16
  *    matrix cores (fp16 hi + lo parts of samples and templates, three products, fp32 accumulation), any other single
  *    buffer on the fp32 MFMA kernel.  All agree with the reference to ~1e-6 relative or better.  Templates are processed 16 to a group; any f_search_set is accepted: a grid whose
- *    hypotheses' window starts drift apart by more samples than a group's tap blocks hold (> 23 samples for int8, > 111
+ *    hypotheses' window starts drift apart by more samples than a group's operand rows hold (> 15 samples for int8 / fp16, > 111
  *    for fp32 -- far sparser than the 5 kHz grids of the CLI) is packed with fewer whole hypotheses per group, down to
  *    one, at proportionally more work.
  *  - a context owns one HIP device + stream + workspace; calls on one context are
