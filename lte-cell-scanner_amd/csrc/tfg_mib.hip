@@ -786,11 +786,12 @@ __device__ __forceinline__ double np_from_partials(const double *sc, int port) {
 __global__ __launch_bounds__(PB_THREADS * PB_CANDS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_pbch(const lcs_cell *__restrict__ cells, const int *__restrict__ n_work,
                                                       const double2 *__restrict__ tfg_comp, const double2 *__restrict__ ce,
                                                       double *__restrict__ scratch, const uint8_t *__restrict__ pbch_scr,
-                                                      const int16_t *__restrict__ derm_inv /*[2][120][16]*/) {
+                                                      const int16_t *__restrict__ derm_inv /*[2][120][16]*/, int y0) {
   LCS_TAIL_PRIO();
   __shared__ unsigned long long surv_all[PB_CANDS][40 * 64];      // per wave: survivor words [step][trellis]; holds the LLRs until they are de-ratematched
   __shared__ double d_est_all[PB_CANDS][3][40];
-  const int wv = threadIdx.x >> 6, tid = threadIdx.x & 63, cand = blockIdx.y * PB_CANDS + wv;
+  // y0 >= 0: this launch runs candidate range y0 (grid.y = 1) and may skip decoded cells; y0 < 0: all ranges in one launch
+  const int wv = threadIdx.x >> 6, tid = threadIdx.x & 63, cand0 = (y0 < 0 ? (int)blockIdx.y : y0) * PB_CANDS, cand = cand0 + wv;
   unsigned long long *surv = surv_all[wv];
   double (*d_est)[40] = d_est_all[wv];
   double *e_est = reinterpret_cast<double *>(surv);  // 1920 doubles = 15 KB of the 20 KB
@@ -798,6 +799,17 @@ __global__ __launch_bounds__(PB_THREADS * PB_CANDS) __attribute__((amdgpu_waves_
   for (int it = blockIdx.x; it < *n_work; it += gridDim.x) {
     const lcs_cell c = cells[it];
     double *sc = scratch + (size_t)it * CS_SIZE;
+    // The reference tries the candidates in order and stops at the first that passes (ref :1547, :1567, :1638-1686): a
+    // candidate behind a passing one can never be chosen.  The launches of the later candidate ranges therefore skip the cells
+    // an earlier range (an earlier launch on this stream) already decoded -- the same for every wave of the workgroup.
+    if (y0 > 0) {
+      bool decided = false;
+      for (int k = 0; k < cand0; ++k) decided |= sc[CS_CAND + k * 4] != 0.0;
+      if (decided) {
+        if (tid == 0) { sc[CS_CAND + cand * 4 + 0] = 0.0; sc[CS_CAND + cand * 4 + 1] = 0.0; }
+        continue;
+      }
+    }
     const int n_symb = cell_n_symb(c), id = cell_id(c);
     const int m_bit = (c.cp_type == LCS_CP_NORMAL) ? 1920 : 1728;
     const int n_sym = m_bit / 2, per_frame = n_sym / 4;
@@ -949,8 +961,16 @@ int lcs_launch_mib(lcs_ctx *c, bool fused) {
   hipLaunchKernelGGL(k_chan_est, dim3(c->grid_items, 4, CE_NCHUNK), dim3(CE_THREADS), 0, c->stream, c->cells_out, c->n_work,
                      c->tfg_comp, fused ? (const double2 *)c->tfg : (const double2 *)nullptr, (const double *)c->tfg_ts, c->cell_scratch,
                      c->ce, c->needed_rows_only ? 1 : 0);
-  hipLaunchKernelGGL(k_pbch, dim3(c->grid_items, 12 / PB_CANDS), dim3(PB_THREADS * PB_CANDS), 0, c->stream, c->cells_out, c->n_work, c->tfg_comp,
-                     c->ce, c->cell_scratch, c->d_pbch_scr, c->d_derm_inv);
+  // batches: one launch per range of four candidates, in the reference's order -- a range skips the cells an earlier one
+  // decoded (default band + 0.4 %, dense band + 0.7 %: profiles/r04/experiments/ab_pbch_candidate_ranges.txt); the streaming
+  // mode's graph replays every launch for every buffer, mostly on empty work lists: one launch there
+  if (c->single_stream)
+    hipLaunchKernelGGL(k_pbch, dim3(c->grid_items, 12 / PB_CANDS), dim3(PB_THREADS * PB_CANDS), 0, c->stream, c->cells_out, c->n_work, c->tfg_comp,
+                       c->ce, c->cell_scratch, c->d_pbch_scr, c->d_derm_inv, -1);
+  else
+    for (int y = 0; y < 12 / PB_CANDS; ++y)
+      hipLaunchKernelGGL(k_pbch, dim3(c->grid_items, 1), dim3(PB_THREADS * PB_CANDS), 0, c->stream, c->cells_out, c->n_work, c->tfg_comp,
+                         c->ce, c->cell_scratch, c->d_pbch_scr, c->d_derm_inv, y);
   hipLaunchKernelGGL(k_mib_select, dim3((LCS_MAX_WORK + 63) / 64), dim3(64), 0, c->stream, c->cells_out, c->n_work,
                      c->cell_scratch, scatter_back ? c->peaks : nullptr, c->work_items);
   HIPCHK(c, hipGetLastError());
