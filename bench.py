@@ -448,6 +448,43 @@ def device_identity(torch, index):
     return f"{socket.gethostname()}/cuda:{index}" + (f" ({extra})" if extra else "")
 
 
+def power_probe(run_steps, device_index, seconds=2.0):
+    """Outside the timed region: keep the same pipelined steps running for ~`seconds` while rocm-smi is sampled, and report
+    the shader clock and the socket power the chain holds (the correlation runs at the chip's power cap: DESIGN 3.0).
+    Returns None when rocm-smi is not there or does not answer."""
+    import subprocess, threading
+    samples, stop = [], threading.Event()
+
+    def sampler():
+        while not stop.is_set():
+            try:
+                p = subprocess.run(["rocm-smi", "-d", str(device_index), "--showclocks", "--showpower", "--json"], capture_output=True, text=True, timeout=5)
+                card = next(iter(json.loads(p.stdout).values()))
+                sclk = next((v for k, v in card.items() if "sclk" in k.lower() and "mhz" in str(v).lower()), None)
+                pw = next((v for k, v in card.items() if "power (w)" in k.lower()), None)
+                if sclk is not None and pw is not None:
+                    samples.append((float("".join(ch for ch in str(sclk) if ch.isdigit() or ch == ".")), float(pw)))
+            except Exception:
+                return
+            stop.wait(0.25)
+
+    th = threading.Thread(target=sampler, daemon=True)
+    t0 = time.perf_counter()
+    th.start()
+    n = 0
+    while time.perf_counter() - t0 < seconds:
+        run_steps()
+        n += 1
+    stop.set()
+    th.join(timeout=6)
+    busy = samples[1:] if len(samples) > 2 else samples        # the first sample may predate the load
+    if not busy:
+        return None
+    return {"sclk_mhz": sorted(s for s, _ in busy)[len(busy) // 2], "socket_power_w": sorted(w for _, w in busy)[len(busy) // 2],
+            "samples": len(busy), "steps_run": n,
+            "note": "median of rocm-smi samples taken while the same pipelined steps ran on, AFTER the timed region (MI355X: 2400 MHz peak, 1400 W cap)"}
+
+
 def kernel_source_sha():
     """sha256 over the sources of the dominant kernel: roofline.traffic is only reported when the committed PMC
     summary was collected from exactly this code."""
@@ -487,6 +524,7 @@ def main():
                     help="contexts (streams + workspaces) used round-robin: the latency-bound per-cell "
                          "stages of batch i overlap the PSS correlation of batch i+1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-power-probe", action="store_true", help="skip the ~2 s of extra steps under rocm-smi sampling (roofline.power_probe)")
     ap.add_argument("--no-xc-timing", action="store_true", help="developer A/B runs with builds that record no kernel events")
     ap.add_argument("--synth-cache", default=None, help="developer A/B runs: directory caching the synthetic host batch between runs")
     ap.add_argument("--lib", default=None, help="developer A/B runs: load this build of liblcs_amd.so instead of the in-tree one")
@@ -713,6 +751,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    probe = None
+    if rank == 0 and not multi and not args.no_power_probe:
+        probe = power_probe(lambda: run(1, gather=False), 0)
+
     # ---- verification (outside the timed region) -------------------------------------------------------------
     # (1) every pipelined collect of a distinct batch returned identical bytes (state["mismatch"] == 0);
     # (2) a sequential, single-context, synchronous run of each distinct batch returns those bytes too;
@@ -852,7 +894,8 @@ def main():
                          "hbm_algorithmic_GBps": bytes_per_buf * B / (k_ms * 1e-3) / 1e9, "hbm_peak_GBps": 8000.0,
                          "hbm_frac_algorithmic": bytes_per_buf * B / (k_ms * 1e-3) / 1e9 / 8000.0,
                          "hbm_measured_GBps": (traffic / (k_ms * 1e-3) / 1e9) if traffic else None,
-                         "hbm_frac_measured": (traffic / (k_ms * 1e-3) / 1e9 / 8000.0) if traffic else None},
+                         "hbm_frac_measured": (traffic / (k_ms * 1e-3) / 1e9 / 8000.0) if traffic else None,
+                         "power_probe": probe},
         }
         if not args.no_cpu_baseline:
             cb, ocells = cpu_baseline(pkg, host, f, fcs, args.stage)

@@ -13,7 +13,7 @@ mkdir -p "$OUT"
 (cd "$REPO" && timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -6) > "$OUT/pytest_gpu.log"
 cd /tmp; export TMPDIR=/tmp
 B="python $REPO/bench.py"
-SHORT="--steps 2 --warmup 1 --batches-per-step 8 --no-cpu-baseline --no-dense"
+SHORT="--steps 2 --warmup 1 --batches-per-step 8 --no-cpu-baseline --no-dense --no-power-probe"
 # every kernel alone, per 64-buffer batch (the unit of DESIGN 3.2's table since round 1), then the bench's default command
 # (128 buffers per launch, two contexts in flight): the correlation kernel's average duration there is what bench.py's
 # roofline.kernel_ms must agree with
@@ -27,7 +27,7 @@ i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS" \
            "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
-  timeout 200 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d "$OUT/pmc_$i" -- $B --steps 1 --warmup 0 --batch 64 --batches-per-step 4 --pipeline 1 --no-cpu-baseline --no-dense > "$OUT/pmc_$i.log" 2>&1
+  timeout 200 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d "$OUT/pmc_$i" -- $B --steps 1 --warmup 0 --batch 64 --batches-per-step 4 --pipeline 1 --no-cpu-baseline --no-dense --no-power-probe > "$OUT/pmc_$i.log" 2>&1
 done
 # the bench lines last: bench.py reports roofline.traffic only from a PMC summary taken from the running kernel sources
 (cd "$REPO" && python profiles/summarize.py "$TAG" > /dev/null 2>&1)

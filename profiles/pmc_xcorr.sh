@@ -3,7 +3,7 @@
 #   bash profiles/pmc_xcorr.sh <tag>   -> gpurun_out/<tag>/pmc_*/...counter_collection.csv
 TAG=${1:-pmcx}; R=$PWD; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
-B="python $R/bench.py --stage pss --pipeline 1 --steps 1 --warmup 0 --batches-per-step 4 --no-cpu-baseline"
+B="python $R/bench.py --stage pss --pipeline 1 --steps 1 --warmup 0 --batches-per-step 4 --no-cpu-baseline --no-power-probe"
 i=0
 for grp in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_WAVES" \
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_WAIT_INST_LDS" \

@@ -7,7 +7,7 @@ out = os.path.join(root, "gpurun_out", f"ab_{tag}.txt")
 os.makedirs(os.path.dirname(out), exist_ok=True)
 for spec in sys.argv[2:]:
     t0 = time.time()
-    p = subprocess.run(f"timeout 240 python {root}/bench.py --no-cpu-baseline --synth-cache /tmp/synth {spec}", shell=True, capture_output=True, text=True, cwd="/tmp")
+    p = subprocess.run(f"timeout 240 python {root}/bench.py --no-cpu-baseline --no-power-probe --synth-cache /tmp/synth {spec}", shell=True, capture_output=True, text=True, cwd="/tmp")
     line = f"{spec:60s} "
     try:
         j = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
