@@ -340,6 +340,7 @@ __global__ __launch_bounds__(256, 2) void k_xcorr_f16x3(const uint32_t *__restri
   };
   dma(0, ldsA0);
   __syncthreads();                         // the operand image is complete (every wave's chunks: vmcnt(0) in front of the barrier)
+  if (widx0 >= LCS_N_IDX) return;          // the fourth wave of the 19th lag tile owns no lag; nothing below synchronises with it
   for (int w = 0; w < geo.n_comb; w += 2) {
     window(w, ldsA0, ldsA1);
     if (w + 1 < geo.n_comb) window(w + 1, ldsA1, ldsA0);
@@ -395,7 +396,8 @@ int lcs_launch_xcorr_f16(lcs_ctx *c, hipStream_t sxc, const XcGeom &geo, int slo
                      n_slots, xcd_map);
   HIPCHK(c, hipGetLastError());
   // executed work: per wave and window 3 products x F16_NKB tap blocks x F16_MT sub-tiles x (re, im) MFMAs of 16x16x32 MACs
-  c->last_xc_ops += (double)grid * 4 * geo.n_comb * (3.0 * F16_NKB * F16_MT * 2) * (2.0 * 16 * 16 * 32);
+  const double waves = (double)n_slots * geo.G * ((LCS_N_IDX + F16_MT * 16 - 1) / (F16_MT * 16));      // the waves that own lags (75 of a group's 76)
+  c->last_xc_ops += waves * geo.n_comb * (3.0 * F16_NKB * F16_MT * 2) * (2.0 * 16 * 16 * 32);
   c->last_xc_kernel = "k_xcorr_f16x3";
   return LCS_OK;
 }

@@ -320,6 +320,9 @@ __global__ __launch_bounds__(256, 2) void k_xcorr_i8x3(const uint16_t *__restric
   };
   dma(0, ldsA0);
   __syncthreads();                         // the operand image is complete (every wave's chunks: vmcnt(0) in front of the barrier)
+  // 9600 lags = 75 wave tiles of 128: the fourth wave of the 19th lag tile owns none.  It has done its share of the image load;
+  // nothing below synchronises with it (1 wave in 76: 1.3 % of the launch's MFMAs)
+  if (widx0 >= LCS_N_IDX) return;
   for (int w = 0; w < geo.n_comb; w += 2) {
     window(w, ldsA0, ldsA1);
     if (w + 1 < geo.n_comb) window(w + 1, ldsA1, ldsA0);
@@ -350,7 +353,8 @@ int lcs_launch_xcorr_i8(lcs_ctx *c, hipStream_t sxc, const XcGeom &geo, int slot
                      n_slots, xcd_map);
   HIPCHK(c, hipGetLastError());
   // executed work: per wave and window 3 digits x I8_NKB tap blocks x I8_MT sub-tiles x (re, im) MFMAs of 16x16x64 MACs
-  c->last_xc_ops += (double)grid * 4 * geo.n_comb * (3.0 * I8_NKB * I8_MT * 2) * (2.0 * 16 * 16 * 64);
+  const double waves = (double)n_slots * geo.G * ((LCS_N_IDX + I8_MT * 16 - 1) / (I8_MT * 16));      // the waves that own lags (75 of a group's 76)
+  c->last_xc_ops += waves * geo.n_comb * (3.0 * I8_NKB * I8_MT * 2) * (2.0 * 16 * 16 * 64);
   c->last_xc_kernel = "k_xcorr_i8x3";
   return LCS_OK;
 }
