@@ -86,3 +86,19 @@ def test_gpu_chain_matches_oracle_on_synthetic_batch(pkg):
             assert abs(x.frame_start - y.frame_start) < 1e-6 and abs(x.freq_superfine - y.freq_superfine) < 1e-3
         assert sorted((c.n_id_cell(), c.n_ports, c.n_rb_dl, c.cp_type, c.phich_duration, c.phich_resource) for c in got) == \
             sorted(_truth_key(t) for t in truth), b
+
+
+def test_bench_power_probe_never_breaks_a_run():
+    """bench.py samples rocm-smi while extra steps run (roofline.power_probe); without rocm-smi or without a GPU the probe
+    answers None and the bench line goes out unchanged."""
+    import importlib.util
+    import os
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    ran = []
+    res = bench.power_probe(lambda: (ran.append(1), time.sleep(0.02)), 0, seconds=0.3)
+    assert ran, "the probe keeps the steps running while it samples"
+    assert res is None or ({"sclk_mhz", "socket_power_w", "samples"} <= set(res) and res["samples"] >= 1)
