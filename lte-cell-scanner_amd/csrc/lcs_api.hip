@@ -40,6 +40,7 @@ XcGeom make_geo(uint32_t n_cap, int n_f, int ds, int cpg = LCS_TG) {
   g.n_comb = (int)((n_cap - 136 - 100) / 9600);   // ref src/searcher.cpp:276
   g.ds = ds;
   g.foi0 = 0;
+  g.n_narrow = (n_f == 1 || cpg == 3) ? g.n_comb : 0;     // one hypothesis per group: no spread at all; otherwise pack_grid looks at the grid
   return g;
 }
 
@@ -171,6 +172,24 @@ int grid_taps(const XcGeom &geo, const double *fset, double fc_req, double fc_pr
   return worst;
 }
 
+// Number of leading combining windows in which the window starts of every group's hypotheses stay within LCS_NARROW_SPREAD
+// samples (the spread grows with the window index; the count stops at the first window that exceeds it).
+int grid_narrow_windows(const XcGeom &geo, const double *fset, double fc_req, double fc_prog, double fs_prog) {
+  for (int w = 0; w < geo.n_comb; ++w)
+    for (int g = 0; g < geo.G; ++g) {
+      const int c_hi = std::min(g * geo.cpg + geo.cpg - 1, geo.n_tmpl - 1);
+      const int f_lo = (g * geo.cpg) / 3, f_hi = c_hi / 3;
+      int mn = 0, mx = 0;
+      for (int f = f_lo; f <= f_hi; ++f) {
+        const double kf = (fc_req - fset[f]) / fc_prog;
+        const int s = (int)std::rint((((double)w * .005) * kf) * fs_prog);
+        if (f == f_lo) { mn = mx = s; } else { mn = std::min(mn, s); mx = std::max(mx, s); }
+      }
+      if (mx - mn > LCS_NARROW_SPREAD) return w;
+    }
+  return geo.n_comb;
+}
+
 // Choose how the 3 n_f templates are packed into 16-column groups: densely when the window starts of a group's
 // hypotheses stay within `max_taps` - 137 samples of each other over the whole buffer (every grid the CLI builds), else
 // with fewer whole hypotheses per group -- one per group always fits (its three templates share a window start).
@@ -178,12 +197,19 @@ XcGeom pack_grid(uint32_t n_cap, int n_f, int ds, const double *fset, const doub
                  double fs_prog, int max_taps) {
   static const int packings[] = {LCS_TG, 15, 12, 9, 6, 3};
   for (int cpg : packings) {
-    const XcGeom geo = make_geo(n_cap, n_f, ds, cpg);
+    XcGeom geo = make_geo(n_cap, n_f, ds, cpg);
     bool fits = true;
     for (int i = 0; i < n_buf && fits; ++i)
       if (i == 0 || fc_req[i] != fc_req[i - 1] || fc_prog[i] != fc_prog[i - 1])
         fits = grid_taps(geo, fset, fc_req[i], fc_prog[i], fs_prog) <= max_taps;
-    if (fits || cpg == 3) return geo;
+    if (fits || cpg == 3) {
+      int nn = geo.n_comb;
+      for (int i = 0; i < n_buf && nn > 0; ++i)
+        if (i == 0 || fc_req[i] != fc_req[i - 1] || fc_prog[i] != fc_prog[i - 1])
+          nn = std::min(nn, grid_narrow_windows(geo, fset, fc_req[i], fc_prog[i], fs_prog));
+      geo.n_narrow = nn;
+      return geo;
+    }
   }
   return make_geo(n_cap, n_f, ds, 3);
 }

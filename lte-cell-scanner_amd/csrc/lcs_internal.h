@@ -61,7 +61,12 @@ struct XcGeom {
   int n_comb;   // n_comb_xc
   int ds;       // ds_comb_arm
   int foi0;     // hypothesis split over GPUs (lcs_foe_*): global index of this rank's first hypothesis; frq then holds GLOBAL indices
+  int n_narrow; // windows 0 .. n_narrow - 1: the window starts of every template group (of every buffer of the call) lie within
+                // LCS_NARROW_SPREAD samples of each other, so 137 taps + delay fit 144.  When that holds for every window of a call
+                // (every grid the CLI builds) the fp16 kernel runs nine 16-tap blocks per window instead of ten (pss_xcorr_f16.hip);
+                // the int8 kernel's half-depth last block was built and measured: no gain (profiles/r04/experiments)
 };
+#define LCS_NARROW_SPREAD 7
 
 // int8 copies of a u8 capture buffer: slot stride in samples (a multiple of 8, so that every slot starts 16-byte
 // aligned) with LCS_I8_PAD zero samples behind the data -- the correlation kernel's LDS-DMA reads run past n_cap

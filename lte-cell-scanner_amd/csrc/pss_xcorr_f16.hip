@@ -222,6 +222,8 @@ __global__ __launch_bounds__(256) void k_fill_brow_f16(const float2 *__restrict_
 // Per window 10 tap blocks x 3 products x 8 sub-tiles x (re, im) MFMAs.
 #define F16_PA 288                                        // dwords (= samples) of a wave's staged array: 27 + 16 * 16 + 4 <= 288
 static_assert(F16_PA >= 15 + 12 + 16 * (F16_NKB - 1 + F16_MT - 1) + 4 && F16_PA % 8 == 0 && F16_PA / 8 <= 64, "sample staging");
+// NARROW: every window of the launch is narrow (geo.n_narrow == geo.n_comb: 137 taps + delay end below position 144): nine tap blocks, not ten.
+template <bool NARROW>
 __global__ __launch_bounds__(256, 2) void k_xcorr_f16x3(const uint32_t *__restrict__ cap16h, const uint32_t *__restrict__ cap16l,
                                                         const int *__restrict__ smin, const int *__restrict__ start,
                                                         const uint32_t *__restrict__ brow, const float *__restrict__ sc, float *__restrict__ sg,
@@ -304,11 +306,12 @@ __global__ __launch_bounds__(256, 2) void k_xcorr_f16x3(const uint32_t *__restri
     // hi term replaces it: every B read has 14+ MFMAs to land, in 16 registers.  The samples slide the same way: the hi part
     // of operand kb is last used by the first pair of product 1, the lo part by the first pair of product 2.
     h8 S[2][2];                               // [set][op]
+    constexpr int NKBW = NARROW ? F16_NKB - 1 : F16_NKB;
 #pragma unroll
     for (int u = 0; u < F16_MT; ++u) { F16_RD_AH(u); F16_RD_AL(u); }
     F16_RD_B(0, 0, S[0]);
 #pragma unroll
-    for (int kb = 0; kb < F16_NKB; ++kb) {
+    for (int kb = 0; kb < NKBW; ++kb) {
       // three products per output: xh th, xh tl, xl th; sixteen independent accumulators between two uses of one
 #pragma unroll
       for (int pr = 0; pr < 3; ++pr) {
@@ -324,7 +327,7 @@ __global__ __launch_bounds__(256, 2) void k_xcorr_f16x3(const uint32_t *__restri
           if (mt == 0) {                      // behind a product's first MFMA pair: the next operands
             __builtin_amdgcn_sched_barrier(0);
             if (pr == 0) { F16_RD_B(kb, 1, S[(kb + 1) & 1]); }
-            else if (kb + 1 < F16_NKB) {
+            else if (kb + 1 < NKBW) {
               if (pr == 1) { F16_RD_AH(kb + F16_MT); }
               else { F16_RD_B(kb + 1, 0, S[(kb + 1) & 1]); F16_RD_AL(kb + F16_MT); }
             }
@@ -392,12 +395,17 @@ int lcs_launch_fill_brow_f16(lcs_ctx *c, int n_buf, const XcGeom &geo) {
 }
 int lcs_launch_xcorr_f16(lcs_ctx *c, hipStream_t sxc, const XcGeom &geo, int slot0, int n_slots, int xcd_map) {
   const unsigned grid = (unsigned)(F16_TILES * geo.G * n_slots);
-  hipLaunchKernelGGL(k_xcorr_f16x3, dim3(grid), dim3(256), 0, sxc, c->cap16h, c->cap16l, c->smin, c->start, c->brow16, c->tsc16, c->single, geo, slot0,
-                     n_slots, xcd_map);
+  const bool narrow = geo.n_narrow >= geo.n_comb;
+  if (narrow)
+    hipLaunchKernelGGL(k_xcorr_f16x3<true>, dim3(grid), dim3(256), 0, sxc, c->cap16h, c->cap16l, c->smin, c->start, c->brow16, c->tsc16, c->single, geo,
+                       slot0, n_slots, xcd_map);
+  else
+    hipLaunchKernelGGL(k_xcorr_f16x3<false>, dim3(grid), dim3(256), 0, sxc, c->cap16h, c->cap16l, c->smin, c->start, c->brow16, c->tsc16, c->single, geo,
+                       slot0, n_slots, xcd_map);
   HIPCHK(c, hipGetLastError());
   // executed work: per wave and window 3 products x F16_NKB tap blocks x F16_MT sub-tiles x (re, im) MFMAs of 16x16x32 MACs
   const double waves = (double)n_slots * geo.G * ((LCS_N_IDX + F16_MT * 16 - 1) / (F16_MT * 16));      // the waves that own lags (75 of a group's 76)
-  c->last_xc_ops += waves * geo.n_comb * (3.0 * F16_NKB * F16_MT * 2) * (2.0 * 16 * 16 * 32);
+  c->last_xc_ops += waves * geo.n_comb * (3.0 * (narrow ? F16_NKB - 1 : F16_NKB) * F16_MT * 2) * (2.0 * 16 * 16 * 32);
   c->last_xc_kernel = "k_xcorr_f16x3";
   return LCS_OK;
 }

@@ -181,12 +181,14 @@ __global__ __launch_bounds__(256, 2) void k_xcorr_i8x3(const uint16_t *__restric
   __shared__ uint32_t ldsR[I8R_IMG];
   constexpr int NBLK = 3 * I8_NKB;
   const size_t cstride = lcs_cap8_stride(geo.n_cap);
-  const uint32_t *capd = reinterpret_cast<const uint32_t *>(cap8 + (size_t)slot * cstride) + 4 * lane;     // dword j = samples (2j, 2j+1)
-  const uint32_t *capsd = reinterpret_cast<const uint32_t *>(cap8s + (size_t)slot * cstride) + 4 * lane;   // dword j = samples (2j+1, 2j+2)
+  // (uniform pointers and 32-bit per-lane offsets wherever a lane's address is formed: the kernel sits at its register budget)
+  const uint32_t *capd = reinterpret_cast<const uint32_t *>(cap8 + (size_t)slot * cstride);     // dword j = samples (2j, 2j+1)
+  const uint32_t *capsd = reinterpret_cast<const uint32_t *>(cap8s + (size_t)slot * cstride);   // dword j = samples (2j+1, 2j+2)
   const int *smin_s = smin + (size_t)slot * NW * GM + g;
   // this lane's column: its delay in window w is start[w][foi] - smin[w][g]; where its row starts in the image
   const int col = lcs_col_tmpl(geo, g, lane & 15);
-  const int *start_l = start + (size_t)slot * NW * NFM + (col >= 0 ? col / 3 : 0);
+  const int *start_s = start + (size_t)slot * NW * NFM;
+  const int foi_l = (col >= 0) ? col / 3 : 0;
   const int rowbase = i8r_rowoff(lane & 15) + 4 * (lane >> 4) + I8R_OFF / 2;
   {
     // the group's operand image: whole 1 KiB chunks (one global_load_lds_dwordx4 per wave each) + 64-dword pieces
@@ -204,8 +206,7 @@ __global__ __launch_bounds__(256, 2) void k_xcorr_i8x3(const uint16_t *__restric
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(img + NCI * 256 + wave * 64 + lane),
                                        (__attribute__((address_space(3))) void *)(ldsR + NCI * 256 + wave * 64), 4, 0, 0);
   }
-  int st_next = start_l[0];              // this lane's window start, fetched one window ahead (I8_DELAY_AND_PREFETCH)
-  const float my_sc = sc[(size_t)slot * GM * LCS_TG + g * LCS_TG + (lane & 15)];
+  int st_next = start_s[foi_l];              // this lane's window start, fetched one window ahead (I8_DELAY_AND_PREFETCH)
   const int p0 = (lane & 15) + 8 * (lane >> 4);          // relative to the wave's own staged window
   const int par = p0 & 1;
   const int a_dw = (p0 - par) >> 1;
@@ -226,9 +227,9 @@ __global__ __launch_bounds__(256, 2) void k_xcorr_i8x3(const uint16_t *__restric
     const uint32_t *nat_ = ((L0_ & 1) ? capsd : capd) + h_;
     const uint32_t *shf_ = (L0_ & 1) ? capd + h_ + 1 : capsd + h_;
     if (lane < PCPY / 4) {
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)nat_,
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(nat_ + 4 * lane),
                                        (__attribute__((address_space(3))) void *)(dst[wave]), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)shf_,
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(shf_ + 4 * lane),
                                        (__attribute__((address_space(3))) void *)(dst[wave] + PCPY), 16, 0, 0);
     }
   };
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(256, 2) void k_xcorr_i8x3(const uint16_t *__restric
     const int dl = (col >= 0) ? st_next - smin_s[w * GM] : 0;      /* this lane's delay in window w */        \
     const uint32_t *bl = ldsR + (dl & 1) * I8R_COPY + rowbase - (dl >> 1);                                   \
     __builtin_amdgcn_sched_barrier(0);                                                                       \
-    if (w + 1 < geo.n_comb) { st_next = start_l[(w + 1) * NFM]; dma(w + 1, wrA); }                           \
+    if (w + 1 < geo.n_comb) { st_next = start_s[(w + 1) * NFM + foi_l]; dma(w + 1, wrA); }                           \
     __builtin_amdgcn_sched_barrier(0);
   auto window = [&](int w, const uint32_t (*rdA)[PBUF], uint32_t (*wrA)[PBUF]) __attribute__((always_inline)) {
     __builtin_amdgcn_sched_barrier(0);
@@ -331,6 +332,7 @@ __global__ __launch_bounds__(256, 2) void k_xcorr_i8x3(const uint16_t *__restric
 #undef I8_DELAY_AND_PREFETCH
 #undef I8_RD_B
   const float ncomb = (float)geo.n_comb;
+  const float my_sc = sc[(size_t)slot * GM * LCS_TG + g * LCS_TG + (lane & 15)];
   float *o = sg + (((size_t)slot * geo.G + g) * LCS_N_IDX) * LCS_TG + (lane & 15);
 #pragma unroll
   for (int mt = 0; mt < I8_MT; ++mt)
