@@ -57,6 +57,13 @@ extern "C" {
 #define LCS_N_IDX 9600          /* 5 ms at 1.92 Msps */
 #define LCS_TFG_NSC 72
 #define LCS_TFG_MAX_OFDM 854    /* 6 frames + 2 slots, normal CP (src/searcher.cpp:895) */
+/* The reference's peak_search appends to a std::list<Cell> without a bound (src/searcher.cpp:468-476).  The list is bounded
+ * all the same: every peak zeroes 274 positions either side of itself in its PSS row (:480-485), so two peaks of one row lie
+ * at least 275 positions apart on the circle of 9600 -- at most 34 per row, 102 per buffer -- and the loop ends at the
+ * first maximum below Z_th1 (:449).  The library keeps LCS_MAX_PEAKS records per buffer: every list the reference can return
+ * for a buffer whose thresholds are positive fits.  (A buffer of zeros has Z_th1 == 0 everywhere: the reference's loop then
+ * never ends; here it stops at LCS_MAX_PEAKS peaks and the call reports LCS_ERR_OVERFLOW.) */
+#define LCS_MAX_PEAKS 104
 
 /* POD mirror of class Cell -- include/common.h.in:101-129, defaults src/common.cpp:36-56. */
 typedef struct lcs_cell {
@@ -89,10 +96,12 @@ const char *lcs_last_error(const lcs_ctx *ctx);
 const char *lcs_version(void);
 void lcs_cell_init(lcs_cell *c);                      /* src/common.cpp:36-56 */
 /* Memory-footprint limit: the per-cell stages (time-frequency grid, channel estimate, PBCH) hold at most n
- * detected cells at a time (default and maximum 1024, ~6 MB each, allocated on first use); a batch with more cells is
- * processed in rounds: lcs_batch_enqueue launches the rounds the PREVIOUS batch of the context needed (at least one
- * detected cell per buffer), lcs_batch_collect launches the rest if the device-side count says the batch had more.
- * Results do not depend on it and no batch is truncated. */
+ * detected cells at a time, ~6 MB each, allocated on first use FOR THAT MANY CELLS (n <= 1024).  Without this call a context
+ * starts at 512 (3 GB) and doubles to 1024 by itself after a batch that carried more cells past SSS than that (a busy
+ * band); after the call the limit stays where the caller put it.  A batch with more cells is processed in rounds:
+ * lcs_batch_enqueue launches the rounds the PREVIOUS batch of the same shape needed (at least one detected cell per buffer),
+ * lcs_batch_collect launches the rest if the device-side count says the batch had more.  Results do not depend on it and
+ * no batch is truncated. */
 int lcs_set_max_cells_in_flight(lcs_ctx *ctx, int n);
 
 /* ---- stage entry points (host buffers in / out) ------------------------------------ */
@@ -213,7 +222,9 @@ int lcs_device_count(void);
  * lcs_batch_collect.  Between enqueue and collect nothing synchronises with the host.
  * The caller's device buffers must stay valid and unchanged until lcs_batch_collect has returned: u8 buffers are
  * converted by the first kernel of the chain, complex<float> buffers (even n_cap, 16-byte aligned) are read IN PLACE by
- * the SSS / FOE / grid stages as well -- the library keeps no float copy of them. */
+ * the SSS / FOE / grid stages as well -- the library keeps no float copy of them (lcs_batch_collect drops the reference
+ * to them when it returns).  lcs_batch_collect copies only what the batch found: the records are compacted on the device,
+ * and one small copy into page-locked memory of the context brings them over (no allocation inside the call). */
 int lcs_batch_enqueue(lcs_ctx *ctx, const void *d_capbufs, int fmt, int n_buf, uint32_t n_cap,
                       const double *f_search_set, uint16_t n_f, const double *fc_requested,
                       const double *fc_programmed, double fs_programmed, int stage_mask);
@@ -224,6 +235,15 @@ int lcs_batch_collect(lcs_ctx *ctx, lcs_cell *cells, int max_cells_per_buf, int 
 int lcs_batch_readback(lcs_ctx *ctx, int buf, float *xc_incoherent_single /*[3][9600][n_f]*/,
                        double *xc_incoherent_collapsed_pow /*[3][9600]*/, int32_t *xc_incoherent_collapsed_frq /*[3][9600]*/,
                        double *sp_incoherent /*[9600]*/, double *z_th1 /*[9600]*/);
+/* xc_incoherent_collapsed_frq is an integer output of the reference (include/searcher.h:31): the first maximum over the
+ * hypotheses of float values which the matrix-core kernels reproduce to ~1e-7, not to the bit.  Positions whose best two
+ * hypotheses lie within 4e-6 (relative) of each other are therefore recomputed in the reference's own arithmetic (fp64
+ * accumulation in tap order -> complex<float> -> float running sum over the windows -> float box filter, src/searcher.cpp:
+ * 160-169, 299-305, 329-345) and decided with its strict comparison (:374): a few positions per buffer, rewritten in place
+ * (index and power) before the peak search reads them.  *n_positions = how many the last correlation call of the context
+ * repaired (all buffers of the batch).  Not applied by lcs_foe_partial, where a near-tie may span two ranks' shares: there the
+ * index is exact except at such near-ties, whatever the number of ranks. */
+int lcs_last_frq_repairs(lcs_ctx *ctx, int *n_positions);
 /* HIP-event time (ms) of the PSS correlation kernel launches of the last enqueue, and the
  * number of launches it covers; used by bench.py for the roofline figure. */
 int lcs_last_xcorr_ms(lcs_ctx *ctx, float *ms, int *n_launches);

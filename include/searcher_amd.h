@@ -112,7 +112,7 @@ class Searcher {
     for (int t = 0; t < 3; ++t)
       for (int k = 0; k < 9600; ++k)
         for (int f = 0; f < n_f; ++f) single[((size_t)t * 9600 + k) * n_f + f] = xc_incoherent_single[t][k][f];
-    std::vector<lcs_cell> out(64);
+    std::vector<lcs_cell> out(LCS_MAX_PEAKS);
     int n = 0;
     check(lcs_peak_search(h_, p.data(), q.data(), Z_th1._data(), f_search_set._data(), (uint16_t)n_f, fc_requested,
                           fc_programmed, single.data(), ds_comb_arm, out.data(), (int)out.size(), &n));
@@ -186,7 +186,7 @@ class Searcher {
   // whole per-buffer chain of the CLI main loop, device-resident (src/CellSearch.cpp:484-558)
   void search_capbuf(const cn::cvec &capbuf, const cn::vec &f_search_set, double fc_requested, double fc_programmed,
                      double fs_programmed, std::list<Cell> &cells) {
-    std::vector<lcs_cell> out(64);
+    std::vector<lcs_cell> out(LCS_MAX_PEAKS);
     int n = 0;
     check(lcs_search_capbuf(h_, reinterpret_cast<const double *>(capbuf._data()), (uint32_t)capbuf.length(),
                             f_search_set._data(), (uint16_t)f_search_set.length(), fc_requested, fc_programmed,
@@ -199,7 +199,7 @@ class Searcher {
   // 172-181) or complex<float> (LCS_FMT_C64), one carrier frequency per buffer.  cells[b] receives buffer b's cells.
   void search_batch_host(const void *h_capbufs, int fmt, int n_buf, uint32_t n_cap, const cn::vec &f_search_set,
                          const std::vector<double> &fc_requested, const std::vector<double> &fc_programmed,
-                         double fs_programmed, std::vector<std::list<Cell> > &cells, int max_cells_per_buf = 16) {
+                         double fs_programmed, std::vector<std::list<Cell> > &cells, int max_cells_per_buf = LCS_MAX_PEAKS) {
     std::vector<lcs_cell> out((size_t)n_buf * max_cells_per_buf);
     std::vector<int> cnt(n_buf);
     const int rc = lcs_search_batch_host(h_, h_capbufs, fmt, n_buf, n_cap, f_search_set._data(), (uint16_t)f_search_set.length(),
@@ -222,7 +222,7 @@ class Searcher {
                                  &fc_requested[0], &fc_programmed[0], fs_programmed, LCS_STAGE_FULL));
     pending_ = n_buf;
   }
-  void collect_batch(std::vector<std::list<Cell> > &cells, int max_cells_per_buf = 16) {
+  void collect_batch(std::vector<std::list<Cell> > &cells, int max_cells_per_buf = LCS_MAX_PEAKS) {
     const int n_buf = pending_;
     std::vector<lcs_cell> out((size_t)n_buf * max_cells_per_buf);
     std::vector<int> cnt(n_buf);

@@ -20,7 +20,7 @@ from . import synth
 from . import sweep
 from . import itfile
 from . import tracker
-from .capi import LcsCell, LcsTrackCell, FMT_C64, FMT_IQ_U8, STAGE_PSS, STAGE_FULL
+from .capi import LcsCell, LcsTrackCell, FMT_C64, FMT_IQ_U8, STAGE_PSS, STAGE_FULL, MAX_PEAKS
 
 FS_LTE = 30720000.0        # include/constants.h:32
 DS_COMB_ARM = 2            # src/CellSearch.cpp:484
@@ -117,7 +117,7 @@ class Searcher:
 
     # ---- searcher.h:44-56 -------------------------------------------------------------
     def peak_search(self, pow_, frq, Z_th1, f_search_set, fc_requested, fc_programmed, single, ds_comb_arm,
-                    max_cells=64):
+                    max_cells=MAX_PEAKS):
         pow_ = np.ascontiguousarray(pow_, np.float64)
         frq = np.ascontiguousarray(frq, np.int32)
         Z = np.ascontiguousarray(Z_th1, np.float64)
@@ -192,15 +192,15 @@ class Searcher:
         return ce, npw.value
 
     # ---- CellSearch.cpp:484-558, one buffer -----------------------------------------
-    def search_capbuf(self, capbuf, f_search_set, fc_requested, fc_programmed, fs_programmed, max_cells=64):
+    def search_capbuf(self, capbuf, f_search_set, fc_requested, fc_programmed, fs_programmed, max_cells=MAX_PEAKS):
         cap = np.ascontiguousarray(capbuf, np.complex128)
         f = np.ascontiguousarray(f_search_set, np.float64)
-        cells, peaks = (LcsCell * max_cells)(), (LcsCell * 64)()
+        cells, peaks = (LcsCell * max_cells)(), (LcsCell * MAX_PEAKS)()
         n, npk = C.c_int(0), C.c_int(0)
         rc = self._lib.lcs_search_capbuf(self._h, _dp(cap), cap.size, _dp(f), f.size, fc_requested, fc_programmed,
-                                         fs_programmed, cells, max_cells, C.byref(n), peaks, 64, C.byref(npk))
+                                         fs_programmed, cells, max_cells, C.byref(n), peaks, MAX_PEAKS, C.byref(npk))
         self._chk(rc, "lcs_search_capbuf")
-        return [cells[i].copy() for i in range(min(n.value, max_cells))], [peaks[i].copy() for i in range(min(npk.value, 64))]
+        return [cells[i].copy() for i in range(min(n.value, max_cells))], [peaks[i].copy() for i in range(min(npk.value, MAX_PEAKS))]
 
     # ---- one buffer, hypotheses split over GPUs (lcs_foe_*; driver: sweep.search_capbuf_foe_split_dev) ----
     def foe_partial(self, capbuf, f_search_set, f_first: int, f_count: int, fc_requested, fc_programmed, fs_programmed,
@@ -210,16 +210,16 @@ class Searcher:
         self._chk(self._lib.lcs_foe_partial(self._h, _dp(cap), cap.size, _dp(f), f.size, int(f_first), int(f_count), fc_requested,
                                             fc_programmed, fs_programmed, C.c_void_p(d_words_ptr), C.c_void_p(d_meta_ptr)), "lcs_foe_partial")
 
-    def foe_finish(self, d_words_ptr: int, d_meta_ptr: int, f_search_set, max_cells: int = 64):
+    def foe_finish(self, d_words_ptr: int, d_meta_ptr: int, f_search_set, max_cells: int = MAX_PEAKS):
         """-> (cells this rank decoded, their positions in the peak list, the whole peak list)"""
         f = np.ascontiguousarray(f_search_set, np.float64)
-        cells, peaks = (LcsCell * max_cells)(), (LcsCell * 64)()
+        cells, peaks = (LcsCell * max_cells)(), (LcsCell * MAX_PEAKS)()
         order = np.zeros(max_cells, np.int32)
         n, npk = C.c_int(0), C.c_int(0)
         rc = self._lib.lcs_foe_finish(self._h, C.c_void_p(d_words_ptr), C.c_void_p(d_meta_ptr), _dp(f), f.size, cells, _ip(order), max_cells,
-                                      C.byref(n), peaks, 64, C.byref(npk))
+                                      C.byref(n), peaks, MAX_PEAKS, C.byref(npk))
         self._chk(rc, "lcs_foe_finish")
-        return [cells[i].copy() for i in range(n.value)], order[:n.value].copy(), [peaks[i].copy() for i in range(min(npk.value, 64))]
+        return [cells[i].copy() for i in range(n.value)], order[:n.value].copy(), [peaks[i].copy() for i in range(min(npk.value, MAX_PEAKS))]
 
     # ---- batched, device-resident ---------------------------------------------------
     def batch_enqueue(self, d_ptr: int, fmt: int, n_buf: int, n_cap: int, f_search_set, fc_requested, fc_programmed,
@@ -289,6 +289,8 @@ class Searcher:
                            fs_programmed: float, stage_mask: int = STAGE_FULL):
         """Asynchronous host-fed batch (lcs_batch_enqueue_host): returns once the copy and the kernels are queued;
         results come from batch_collect / batch_collect_raw.  The array must stay untouched until then."""
+        # (the same lifetime rule holds for batch_enqueue's DEVICE buffers: complex<float> batches are read in place by
+        # every stage until batch_collect returns -- include/lcs.h)
         a = h_capbufs if (isinstance(h_capbufs, np.ndarray) and h_capbufs.flags.c_contiguous) else np.ascontiguousarray(h_capbufs)
         assert a.nbytes == n_buf * n_cap * (2 if fmt == FMT_IQ_U8 else 8)
         f = np.ascontiguousarray(f_search_set, np.float64)
@@ -433,6 +435,13 @@ class Searcher:
         ms, n = C.c_float(0), C.c_int(0)
         self._chk(self._lib.lcs_last_xcorr_ms(self._h, C.byref(ms), C.byref(n)), "lcs_last_xcorr_ms")
         return ms.value, n.value
+
+    def last_frq_repairs(self) -> int:
+        """Positions of xc_incoherent_collapsed_frq the last correlation call recomputed in the reference's arithmetic
+        (near-ties of the arg-max, lcs_last_frq_repairs)."""
+        n = C.c_int(0)
+        self._chk(self._lib.lcs_last_frq_repairs(self._h, C.byref(n)), "lcs_last_frq_repairs")
+        return n.value
 
     def last_xcorr_info(self):
         """-> (kernel name, matrix-core operations executed by the last enqueue's correlation launches)."""

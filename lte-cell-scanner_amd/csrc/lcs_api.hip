@@ -76,6 +76,8 @@ int ensure_ws(lcs_ctx *c, int n_slots, uint32_t n_cap, int n_f, bool debug, int 
   A(pow_, S * NE);
   A(work, S * NE);
   A(frq, S * NE);
+  A(fix_list, S * NE);
+  A(n_fix, 4);
   A(spinc, S * LCS_N_IDX);
   A(zth, S * LCS_N_IDX);
   A(peaks, S * LCS_MAXP);
@@ -132,11 +134,14 @@ int ensure_f16(lcs_ctx *c) {
   return LCS_OK;
 }
 
-// Buffers of the per-cell stages (allocated on first use: ~3 GB for 512 cells in flight).
+// Buffers of the per-cell stages, allocated on first use for c->max_work cells (~6 MB each: 3 GB at the default 512) and
+// again when the limit was raised since (lcs_set_max_cells_in_flight, or by itself after a batch that carried more cells).
 int ensure_percell(lcs_ctx *c) {
-  if (c->percell_ready) return LCS_OK;
+  if (c->percell_ready && c->max_work <= c->percell_cap) return LCS_OK;
+  if (c->st_open && c->percell_ready) return LCS_OK;      // the open stream's graph holds these addresses: keep what it was captured with
   int rc;
-  const size_t W = LCS_MAX_WORK, GRID = (size_t)LCS_TFG_ROWS * LCS_TFG_NSC;
+  if (c->percell_ready) HIPCHK(c, hipStreamSynchronize(c->stream));
+  const size_t W = (size_t)std::max(c->max_work, c->percell_cap), GRID = (size_t)LCS_TFG_ROWS * LCS_TFG_NSC;
 #define A(p, n) if ((rc = dev_alloc(c, &c->p, (n))) != LCS_OK) return rc
   A(work_items, W);
   A(n_work, 4);
@@ -150,6 +155,24 @@ int ensure_percell(lcs_ctx *c) {
   A(d_dbg, 2048);
 #undef A
   c->percell_ready = true;
+  c->percell_cap = (int)W;
+  return LCS_OK;
+}
+
+// Device block the results of a batch are compacted into (k_pack_results) and its page-locked mirror, sized for the worst case
+// of n_buf buffers (every buffer LCS_MAXP records): allocated when a larger batch arrives, never inside lcs_batch_collect.
+int ensure_res_pack(lcs_ctx *c, int n_buf) {
+  const size_t need = lcs_pack_rec_offset(n_buf) + (size_t)n_buf * LCS_MAXP * sizeof(lcs_cell);
+  if (need <= c->res_pack_bytes) return LCS_OK;
+  if (c->st_open) { c->err = "lcs_stream_close first"; return LCS_ERR_BAD_ARG; }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->res_pack) (void)hipFree(c->res_pack);
+  if (c->h_res) (void)hipHostFree(c->h_res);
+  c->res_pack = c->h_res = nullptr;
+  c->res_pack_bytes = 0;
+  HIPCHK(c, hipMalloc(&c->res_pack, need));
+  HIPCHK(c, hipHostMalloc(&c->h_res, need, hipHostMallocDefault));
+  c->res_pack_bytes = need;
   return LCS_OK;
 }
 
@@ -338,7 +361,7 @@ void lcs_destroy(lcs_ctx *c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->stream_xc) (void)hipStreamSynchronize(c->stream_xc);
   void *ptrs[] = {c->cap32, c->cap64, c->params, c->fset, c->tmpl, c->start, c->smin, c->kp2, c->btab, c->single,
-                  c->incoh, c->sref, c->pow_, c->work, c->spinc, c->zth, c->sp, c->frq, c->peaks, c->npeaks, c->xc,
+                  c->incoh, c->sref, c->pow_, c->work, c->spinc, c->zth, c->sp, c->frq, c->fix_list, c->n_fix, c->peaks, c->npeaks, c->xc,
                   c->work_items, c->n_work, c->tfg, c->tfg_comp, c->ce, c->tfg_ts, c->tfg_ts_comp, c->cell_scratch,
                   c->cells_out, c->d_pss_td, c->d_pss_fd, c->d_sss_fd, c->d_pbch_scr, c->d_derm_inv, c->d_dbg, c->pk_items, c->n_pk,
                   c->sss_ws, c->d_pn_jump, c->cap8, c->cap8s, c->brow8, c->tq, c->tsc, c->cap16h, c->cap16l, c->brow16, c->texp16, c->tsc16, c->xmax16, c->xpart16, c->h2d, c->trk_td, c->trk_syms, c->trk_raw, c->trk_ce,
@@ -346,6 +369,8 @@ void lcs_destroy(lcs_ctx *c) {
                   c->trk_syncce, c->trk_sync, c->d_flag};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+  if (c->res_pack) (void)hipFree(c->res_pack);
+  if (c->h_res) (void)hipHostFree(c->h_res);
   if (c->trk_hpin) free(c->trk_hpin);
   for (int k = 0; k < 2; ++k) {
     if (c->h_stage[k]) (void)hipHostFree(c->h_stage[k]);
@@ -365,6 +390,7 @@ const char *lcs_last_error(const lcs_ctx *c) { return c ? c->err.c_str() : "null
 int lcs_set_max_cells_in_flight(lcs_ctx *c, int n) {
   if (!c || n < 1) return LCS_ERR_BAD_ARG;
   c->max_work = std::min(n, (int)LCS_MAX_WORK);
+  c->max_work_pinned = true;          // the limit no longer grows by itself
   return LCS_OK;
 }
 
@@ -468,6 +494,7 @@ int lcs_batch_enqueue(lcs_ctx *c, const void *d_capbufs, int fmt, int n_buf, uin
   const XcGeom geo = pack_grid(n_cap, n_f, 2 /* DS_COMB_ARM, ref src/CellSearch.cpp:484 */, f_search_set, fc_requested, fc_programmed,
                                n_buf, fs_programmed, kMaxTapsI8);      // the fp16 kernel holds 160 taps per group and shares the int8 kernel's packing
   if ((rc = ensure_ws(c, n_buf, n_cap, n_f, false, geo.G))) return rc;
+  if ((rc = ensure_res_pack(c, n_buf))) return rc;
   if ((rc = pinned(c, sizeof(SlotParams) * n_buf + sizeof(double) * LCS_NF_MAX))) return rc;
   SlotParams *hp = (SlotParams *)c->h_pinned;
   double *hf = (double *)(hp + n_buf);
@@ -487,66 +514,88 @@ int lcs_batch_enqueue(lcs_ctx *c, const void *d_capbufs, int fmt, int n_buf, uin
   if ((rc = lcs_launch_xcorr(c, n_buf, geo, false, true))) return rc;
   if ((rc = lcs_launch_peak_search(c, n_buf, geo, std::pow(10.0, -12.0 / 10.0), true))) return rc;
   if (stage_mask & 2) {
+    // The per-cell stages hold max_work cells at a time, in rounds.  Round 4: the batch before is the predictor for how many
+    // rounds to enqueue and how wide the per-cell grids are.  A busy band carries 4-5 cells per buffer past SSS: with the
+    // rounds and grids sized for one cell per buffer, every such batch needed a second round launched from
+    // lcs_batch_collect (a host round trip in the middle of the pipeline) and every workgroup walked ~8 cells one after
+    // the other.  A wrong guess costs time only: the kernels loop over whatever the list holds, and collect launches the
+    // missing rounds, so no batch overflows and sparse batches pay for no empty rounds.  The hint was measured on a batch
+    // of hint_n_buf buffers of one format and stage mask: it is scaled to this batch's size and forgotten when the shape changed.
+    int hint = 0;
+    if (c->hint_n_buf > 0 && c->hint_fmt == fmt && c->hint_stage == stage_mask)
+      hint = (int)std::min<long long>((long long)c->work_hint * n_buf / c->hint_n_buf, (long long)n_buf * LCS_MAXP);
+    // a batch that carried more cells than a round holds: the limit doubles (up to LCS_MAX_WORK) unless the caller pinned it
+    if (!c->max_work_pinned && !c->st_open && hint > c->max_work && c->max_work < LCS_MAX_WORK)
+      c->max_work = std::min<int>(LCS_MAX_WORK, 2 * c->max_work);
     if ((rc = ensure_percell(c))) return rc;
     if ((rc = lcs_launch_sss_foe(c, n_buf, n_cap, 3.0 /* THRESH2_N_SIGMA, ref src/CellSearch.cpp:528 */, nullptr))) return rc;
-    // The per-cell stages hold max_work cells at a time.  The rounds enqueued here cover one detected cell per
-    // buffer on average (a band scan finds far fewer); lcs_batch_collect launches further rounds if the device-side
-    // count says the batch had more, so no batch overflows and sparse batches pay for no empty rounds.
     c->needed_rows_only = true;
-    c->round_cells = c->max_work;          // fixed for this batch: lcs_set_max_cells_in_flight applies from the next one
-    // Round 4: the batch before is the predictor.  A busy band carries 4-5 cells per buffer past SSS: with the rounds and
-    // the per-cell grids sized for one cell per buffer, every such batch needed a second round launched from
-    // lcs_batch_collect (a host round trip in the middle of the pipeline) and every workgroup walked ~8 cells one after
-    // the other.  A wrong guess costs time only: the kernels loop over whatever the list holds, and collect still
-    // launches missing rounds.
-    const int expect = std::max(n_buf, c->work_hint + c->work_hint / 4);
-    c->grid_items = std::min(c->round_cells, std::max(64, std::max(n_buf / 2, c->work_hint + c->work_hint / 8)));
+    c->round_cells = std::min(c->max_work, c->percell_cap);      // fixed for this batch
+    const int expect = std::max(n_buf, hint + hint / 4);
+    c->grid_items = std::min(c->round_cells, std::max(64, std::max(n_buf / 2, hint + hint / 8)));
     const int rounds = std::min(8, (expect + c->round_cells - 1) / c->round_cells);
     for (int r = 0; r < rounds; ++r)
       if ((rc = percell_round(c, n_buf, n_cap, r))) return rc;
     c->last_cell_rounds = rounds;
   }
+  if ((rc = lcs_launch_pack_results(c, n_buf, (stage_mask & 2) != 0))) return rc;
   c->last_n_buf = n_buf;
   c->last_stage_mask = stage_mask;
+  c->last_fmt = fmt;
   c->last_geo = geo;
   return LCS_OK;
 }
 
+// Round 5: the results arrive compacted (k_pack_results at the end of the enqueued chain).  ONE copy of the header, the
+// per-buffer counts and as many records as the previous batch returned (+ 25 %) into page-locked memory owned by the
+// context, one synchronisation; a second copy only when the batch returned more.  No allocation, no pageable staging
+// (rounds 1-4 copied n_buf x 64 records, 786 KB per 128-buffer batch, into a vector built inside the call).
 int lcs_batch_collect(lcs_ctx *c, lcs_cell *cells, int max_cells_per_buf, int *n_cells) {
   if (!c || !n_cells || c->last_n_buf <= 0) return LCS_ERR_BAD_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
   const int nb = c->last_n_buf;
-  std::vector<lcs_cell> tmp((size_t)nb * LCS_MAXP);
-  std::vector<int> cnt(nb);
-  HIPCHK(c, hipMemcpyAsync(tmp.data(), c->peaks, sizeof(lcs_cell) * tmp.size(), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipMemcpyAsync(cnt.data(), c->npeaks, sizeof(int) * nb, hipMemcpyDeviceToHost, c->stream));
-  int work_cnt[2] = {0, 0};
   const bool full = (c->last_stage_mask & 2) != 0;
-  if (full) HIPCHK(c, hipMemcpyAsync(work_cnt, c->n_work, sizeof(work_cnt), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const size_t rec_off = lcs_pack_rec_offset(nb);
+  const int *hdr = static_cast<const int *>(c->h_res);
+  const int *cnt = hdr + 8;
+  const lcs_cell *rec = reinterpret_cast<const lcs_cell *>(static_cast<const char *>(c->h_res) + rec_off);
   int rc = LCS_OK;
-  if (full) c->work_hint = work_cnt[1];
-  if (full && work_cnt[1] > c->last_cell_rounds * c->round_cells) {
-    // more cells passed SSS than the enqueued rounds decode: run the remaining rounds now (rare: dense batches)
-    const int rounds = (work_cnt[1] + c->round_cells - 1) / c->round_cells;
-    for (int r = c->last_cell_rounds; r < rounds; ++r)
-      if ((rc = percell_round(c, nb, c->last_geo.n_cap, r))) return rc;
-    c->last_cell_rounds = rounds;
-    HIPCHK(c, hipMemcpyAsync(tmp.data(), c->peaks, sizeof(lcs_cell) * tmp.size(), hipMemcpyDeviceToHost, c->stream));
+  for (int pass = 0;; ++pass) {
+    const size_t first = std::min<size_t>((size_t)nb * LCS_MAXP, (size_t)std::max(nb / 2, c->collect_hint + c->collect_hint / 4 + 8));
+    HIPCHK(c, hipMemcpyAsync(c->h_res, c->res_pack, rec_off + first * sizeof(lcs_cell), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-  }
-  for (int b = 0; b < nb; ++b) {
-    const int np = std::min(cnt[b], (int)LCS_MAXP);
-    if (cnt[b] > LCS_MAXP) rc = LCS_ERR_OVERFLOW;
-    int n = 0;
-    for (int i = 0; i < np; ++i) {
-      const lcs_cell &pc = tmp[(size_t)b * LCS_MAXP + i];
-      // the reference erases peaks without SSS (src/CellSearch.cpp:530-534) or MIB (:554-558)
-      if (full && (pc.n_id_1 == -1 || pc.n_rb_dl == -1)) continue;
-      if (n < max_cells_per_buf) cells[(size_t)b * max_cells_per_buf + n] = pc; else rc = LCS_ERR_OVERFLOW;
-      ++n;
+    const int work_total = hdr[5];
+    if (full && pass == 0) { c->work_hint = work_total; c->hint_n_buf = nb; c->hint_fmt = c->last_fmt; c->hint_stage = c->last_stage_mask; }
+    if (full && pass == 0 && work_total > c->last_cell_rounds * c->round_cells) {
+      // more cells passed SSS than the enqueued rounds decode: run the remaining rounds now (rare: the first dense batch)
+      const int rounds = (work_total + c->round_cells - 1) / c->round_cells;
+      for (int r = c->last_cell_rounds; r < rounds; ++r)
+        if ((rc = percell_round(c, nb, c->last_geo.n_cap, r))) return rc;
+      c->last_cell_rounds = rounds;
+      if ((rc = lcs_launch_pack_results(c, nb, true))) return rc;
+      continue;
     }
+    const int total = hdr[0];
+    if ((size_t)total > first) {
+      HIPCHK(c, hipMemcpyAsync(static_cast<char *>(c->h_res) + rec_off + first * sizeof(lcs_cell),
+                               static_cast<const char *>(c->res_pack) + rec_off + first * sizeof(lcs_cell),
+                               ((size_t)total - first) * sizeof(lcs_cell), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    c->collect_hint = total;
+    break;
+  }
+  if (hdr[1]) rc = LCS_ERR_OVERFLOW;          // a buffer with more than LCS_MAXP peaks: only with non-positive thresholds (lcs.h)
+  size_t at = 0;
+  for (int b = 0; b < nb; ++b) {
+    const int n = cnt[b];
+    const int take = std::min(n, max_cells_per_buf);
+    if (take > 0) std::memcpy(cells + (size_t)b * max_cells_per_buf, rec + at, (size_t)take * sizeof(lcs_cell));
+    if (n > max_cells_per_buf) rc = LCS_ERR_OVERFLOW;
+    at += (size_t)n;
     n_cells[b] = n;
   }
+  c->src32 = nullptr;      // complex<float> batches were read in place: the caller's buffers are no longer referenced
   if (rc) c->err = "more results than the output array holds";
   return rc;
 }
@@ -892,7 +941,12 @@ int lcs_foe_partial(lcs_ctx *c, const double *capbuf, uint32_t n_cap, const doub
   XcGeom geo;
   if ((rc = upload_host_capbuf(c, capbuf, n_cap, f_search_set + first, cnt, 2, fc_req, fc_prog, fs_prog, false, &geo))) return rc;
   if ((rc = ensure_percell(c))) return rc;
-  if ((rc = lcs_launch_xcorr(c, 1, geo, false, false))) return rc;
+  // no tie repair here: a near-tie may span two ranks' shares, and what a rank does must not depend on how the grid was split
+  // (the collapsed arrays after the all-reduce are bit-identical for every world size; exact except at near-ties, lcs.h)
+  c->skip_frq_repair = true;
+  rc = lcs_launch_xcorr(c, 1, geo, false, false);
+  c->skip_frq_repair = false;
+  if (rc) return rc;
   geo.foi0 = f_count ? f_first : -1;            // -1: owns nothing
   if ((rc = lcs_launch_foe_pack(c, geo, static_cast<long long *>(d_words), d_meta))) return rc;
   HIPCHK(c, hipStreamSynchronize(c->stream));    // the caller's collective runs on another stream
@@ -1089,7 +1143,7 @@ int lcs_stream_collect(lcs_ctx *c, lcs_cell *cells, int max_cells, int *n_cells,
   const StreamHost *h = c->st_host[k];
   int rc = LCS_OK, n = 0;
   const int np = std::min(h->n_peaks, (int)LCS_MAXP);
-  if (h->n_peaks > LCS_MAXP || h->n_work[1] > c->max_work) rc = LCS_ERR_OVERFLOW;
+  if (h->n_peaks > LCS_MAXP || h->n_work[1] > std::min(c->max_work, c->percell_cap)) rc = LCS_ERR_OVERFLOW;
   for (int i = 0; i < np; ++i) {
     const lcs_cell &pc = h->res[i];
     if (pc.n_id_1 == -1 || pc.n_rb_dl == -1) continue;     // no SSS / no MIB / already tracked (never decoded)
@@ -1107,6 +1161,14 @@ int lcs_last_xcorr_ms(lcs_ctx *c, float *ms, int *n_launches) {
   HIPCHK(c, hipEventSynchronize(c->ev_xc1));
   HIPCHK(c, hipEventElapsedTime(ms, c->ev_xc0, c->ev_xc1));
   if (n_launches) *n_launches = c->last_xc_launches;
+  return LCS_OK;
+}
+
+int lcs_last_frq_repairs(lcs_ctx *c, int *n_positions) {
+  if (!c || !n_positions || !c->n_fix) return LCS_ERR_BAD_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipMemcpyAsync(n_positions, c->n_fix, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
   return LCS_OK;
 }
 

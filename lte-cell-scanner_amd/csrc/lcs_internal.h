@@ -33,13 +33,18 @@
 #define LCS_KP2_UNROLL 4
 #define LCS_LAG_TILE 64      // lags per wave
 #define LCS_PS 336           // LDS plane stride in floats: >= 64 + 2*KP2_MAX, == 16 (mod 32)
-#define LCS_MAXP 64          // peaks kept per capture buffer
+#define LCS_MAXP LCS_MAX_PEAKS   // peaks kept per capture buffer: the most peak_search can return (lcs.h)
+// xc_incoherent_collapsed_frq: positions whose two best hypotheses lie within this (relative) of each other are recomputed in the
+// reference's arithmetic (k_frq_repair, pss_xcorr.hip).  The correlation kernels' values deviate from the reference's by ~1e-7
+// (worst element ever measured: 1e-6 of the buffer's largest); two values further apart than this keep their order.
+#define LCS_FRQ_TIE_EPS 4e-6f
 #define LCS_I8_KB 5          // 32-tap blocks of the int8 correlation kernel
 #define LCS_I8_OFF 16        // int8 kernel: a template column's delay inside its group (window-start spread) stays below this
 #define LCS_I8_MAX_TAPS (137 + LCS_I8_OFF - 1)
 #define LCS_I8_IMG 17024     // dwords of the int8 kernel's operand image per (buffer, group) (pss_xcorr_i8.hip)
 #define LCS_F16_IMG 11840    // the same for the fp16 kernel (pss_xcorr_f16.hip)
-#define LCS_MAX_WORK 1024    // cells carried into the TFG/MIB stages per round (~6 MB each: 6 GB per context, allocated on first use)
+#define LCS_MAX_WORK 1024    // most cells carried into the TFG/MIB stages per round (~6 MB each)
+#define LCS_WORK_DEFAULT 512 // cells per round a context starts with (3 GB, allocated on first use); it doubles by itself when a batch carries more
 // grid sizes of the work-list kernels (every one loops over its list, so these only trade latency for workgroups)
 #define LCS_WIN_GRID 4096
 #define LCS_ITEM_GRID 1024
@@ -174,6 +179,9 @@ struct lcs_ctx {
   float *single = nullptr, *incoh = nullptr, *sref = nullptr;
   double *pow_ = nullptr, *work = nullptr, *spinc = nullptr, *zth = nullptr, *sp = nullptr;
   int *frq = nullptr;
+  unsigned *fix_list = nullptr;      // [S][3][9600]: positions (slot * 3 + t) * 9600 + idx whose arg-max is a near-tie (capacity: every position)
+  int *n_fix = nullptr;              // [4]: entries on the list (zeroed by k_prep_tables)
+  bool skip_frq_repair = false;      // lcs_foe_partial: a rank sees only its share of the hypotheses (a near-tie may span two ranks)
   lcs_cell *peaks = nullptr;
   int *npeaks = nullptr;
   float2 *xc = nullptr;             // debug: raw correlations [3][n_cap-136][n_f]
@@ -232,6 +240,10 @@ struct lcs_ctx {
   void *trk_stream = nullptr;        // carried state of lcs_track_stream_block (tracker.hip)
   void *trk_hpin = nullptr;          // reusable host staging block of lcs_track_block (malloc): metadata up, measurement tables down
   size_t trk_hpin_bytes = 0;
+  // results of a batch, compacted on the device (k_pack_results): [8 ints header][n_buf counts][records]; h_res = its page-locked mirror
+  void *res_pack = nullptr, *h_res = nullptr;
+  size_t res_pack_bytes = 0;
+  int collect_hint = 0;              // records the last collected batch returned: sizes the first copy of the next collect
   // host staging
   SlotParams h_params{};             // source of asynchronous parameter uploads of the single-buffer entry points
   void *h_pinned = nullptr;
@@ -244,12 +256,16 @@ struct lcs_ctx {
   // last batch bookkeeping
   int last_n_buf = 0;
   int last_stage_mask = 0;
+  int last_fmt = 0;
   bool needed_rows_only = false;     // fused chains: compute only the grid rows later stages read (tfg_mib.hip)
-  int max_work = LCS_MAX_WORK;       // cells per per-cell round (lcs_set_max_cells_in_flight)
+  int max_work = LCS_WORK_DEFAULT;   // cells per per-cell round (lcs_set_max_cells_in_flight; grows to LCS_MAX_WORK by itself unless the caller set it)
+  bool max_work_pinned = false;      // the caller set the limit: it stays
+  int percell_cap = 0;               // cells the per-cell buffers are allocated for
   int last_cell_rounds = 0;          // per-cell rounds launched for the last batch (round_cells cells each)
-  int round_cells = LCS_MAX_WORK;    // max_work as it was when the last batch was enqueued
+  int round_cells = LCS_WORK_DEFAULT; // max_work as it was when the last batch was enqueued
   int grid_items = 64;               // workgroups per work-list axis of the per-cell kernels (they loop over the list)
   int work_hint = 0;                 // cells the last collected batch carried into the per-cell stages: sizes the next batch's rounds and grids
+  int hint_n_buf = 0, hint_fmt = -1, hint_stage = 0;   // the batch shape the hint was measured on
   XcGeom last_geo{};
   XcGeom foe_geo{};                  // lcs_foe_partial -> lcs_foe_finish: this rank's share of the hypotheses
   bool foe_ready = false;
@@ -313,6 +329,8 @@ int lcs_launch_foe_only(lcs_ctx *c, uint32_t n_cap);
 // tfg_mib.hip
 int lcs_launch_gather_work(lcs_ctx *c, int n_buf, int skip /* cells already handled by earlier rounds */,
                            int limit = 0 /* cells of this round; 0: max_work */);
+__host__ __device__ static inline size_t lcs_pack_rec_offset(int n_buf) { return ((size_t)(8 + n_buf) * sizeof(int) + 63) & ~(size_t)63; }
+int lcs_launch_pack_results(lcs_ctx *c, int n_buf, bool full);   // peaks / npeaks (+ n_work) -> c->res_pack
 int lcs_launch_rs_build(lcs_ctx *c);
 int lcs_launch_tfg(lcs_ctx *c, uint32_t n_cap, bool with_rs /* also build RS_DL (the fused chain) */);
 int lcs_launch_tfoec(lcs_ctx *c, bool apply_grid);

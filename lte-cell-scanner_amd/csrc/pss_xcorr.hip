@@ -137,9 +137,10 @@ __global__ __launch_bounds__(256) void k_prep_tables(const SlotParams *__restric
                                                       const double *__restrict__ fset,
                                                       const double2 *__restrict__ pss_td, float2 *__restrict__ tmpl,
                                                       int *__restrict__ start, int *__restrict__ smin,
-                                                      int *__restrict__ kp2, XcGeom geo) {
+                                                      int *__restrict__ kp2, int *__restrict__ n_fix, XcGeom geo) {
   LCS_TAIL_PRIO();
   const int slot = blockIdx.x;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *n_fix = 0;      // this call's list of near-tied positions (k_collapse*, k_frq_repair)
   const SlotParams p = params[slot];
   __shared__ int s_start[NW][NFM];
   // the templates (3 x 137 sincos per hypothesis, the long part) are spread over gridDim.y workgroups; the window
@@ -512,13 +513,29 @@ __global__ __launch_bounds__(256) void k_sp_i8(const uint16_t *__restrict__ cap8
 // writes collided four ways; 85 us alone for 229 MB), 32 VGPRs: the workgroups fit beside two resident correlation
 // workgroups (512 - 2 x 232 = 48 VGPRs are free on a SIMD lane).  DS = the arm as a compile-time constant (2: every caller of the reference), or
 // -1 = read it from geo.
-struct CollapseBest { float v; int foi; };
+// Round 5: next to the first maximum the scan keeps the RUNNER-UP value `s` (the largest value of any other hypothesis: the
+// middle of {x, best, runner-up} after every column -- one v_med3_f32).  A position whose runner-up lies within
+// LCS_FRQ_TIE_EPS of its maximum is a near-tie: the correlation kernels reproduce the reference's values to ~1e-7, not to the
+// bit, so there -- and only there -- the arg-max may differ from the reference's.  Such positions go on a list and
+// k_frq_repair recomputes their candidates in the reference's own arithmetic.
+struct CollapseBest { float v; int foi; float s; };
+__device__ __forceinline__ void collapse_step(CollapseBest &b, float xe, int foi) {      // xe = -inf for a column that holds no template
+  const bool tk = xe > b.v;
+  b.s = __builtin_amdgcn_fmed3f(xe, b.v, b.s);
+  b.v = tk ? xe : b.v;
+  b.foi = tk ? foi : b.foi;
+}
 __device__ __forceinline__ void collapse_merge(CollapseBest &b, int lane_xor) {
   const float ov = __shfl_xor(b.v, lane_xor);
+  const float os = __shfl_xor(b.s, lane_xor);
   const int of = __shfl_xor(b.foi, lane_xor);
   const bool tk = ov > b.v || (ov == b.v && of < b.foi);
+  b.s = fmaxf(fminf(b.v, ov), fmaxf(b.s, os));
   b.v = tk ? ov : b.v;
   b.foi = tk ? of : b.foi;
+}
+__device__ __forceinline__ void collapse_flag(const CollapseBest &r, unsigned pos, unsigned *__restrict__ fix_list, int *__restrict__ n_fix) {
+  if (r.v > 0.f && r.s >= r.v * (1.0f - LCS_FRQ_TIE_EPS)) fix_list[atomicAdd(n_fix, 1)] = pos;
 }
 typedef const __attribute__((address_space(1))) char *collapse_gptr;
 typedef float collapse_f4 __attribute__((ext_vector_type(4)));
@@ -529,7 +546,8 @@ __device__ __forceinline__ float4 collapse_row(collapse_gptr base, unsigned byte
 template <int DS, bool INCOH>
 __global__ __launch_bounds__(256) void k_collapse(const float *__restrict__ sg, float *__restrict__ incoh,
                                                    double *__restrict__ pow_, float *__restrict__ pow32,
-                                                   int *__restrict__ frq, XcGeom geo, int n_buf) {
+                                                   int *__restrict__ frq, unsigned *__restrict__ fix_list, int *__restrict__ n_fix,
+                                                   XcGeom geo, int n_buf) {
   LCS_TAIL_PRIO();
   constexpr int CT = 64;                           // positions per workgroup
   static_assert(LCS_N_IDX % CT == 0 && LCS_TG == 16, "k_collapse tiles 9600 positions x 16 columns");
@@ -549,7 +567,7 @@ __global__ __launch_bounds__(256) void k_collapse(const float *__restrict__ sg, 
       om[d - 1] = ((unsigned)((idx - d < 0) ? idx - d + LCS_N_IDX : idx - d) * 4u + q) * 16u;
       op[d - 1] = ((unsigned)((idx + d >= LCS_N_IDX) ? idx + d - LCS_N_IDX : idx + d) * 4u + q) * 16u;
     }
-    CollapseBest b0 = {-INFINITY, 0}, b1 = {-INFINITY, 0}, b2 = {-INFINITY, 0};  // any value beats it: foi 0 is always taken
+    CollapseBest b0 = {-INFINITY, 0, -INFINITY}, b1 = {-INFINITY, 0, -INFINITY}, b2 = {-INFINITY, 0, -INFINITY};  // any value beats it: foi 0 is always taken
 #pragma unroll 1
     for (int g = 0; g < geo.G; ++g) {
       // the group's rows: a wave-uniform base kept in scalar registers (the loads then take base + 32-bit lane offset)
@@ -585,10 +603,9 @@ __global__ __launch_bounds__(256) void k_collapse(const float *__restrict__ sg, 
         const bool valid = (4 * q + j < geo.cpg) && (cq + j < geo.n_tmpl);       // lcs_col_tmpl(geo, g, 4q + j) >= 0
         const float x = vv[j];
         if (INCOH) { if (valid) incoh[((((size_t)slot * 3 + t) * LCS_N_IDX) + idx) * geo.n_f + foi] = x; }
-        const bool k0 = valid && t == 0 && x > b0.v, k1 = valid && t == 1 && x > b1.v, k2 = valid && t == 2 && x > b2.v;
-        b0.v = k0 ? x : b0.v; b0.foi = k0 ? foi : b0.foi;
-        b1.v = k1 ? x : b1.v; b1.foi = k1 ? foi : b1.foi;
-        b2.v = k2 ? x : b2.v; b2.foi = k2 ? foi : b2.foi;
+        collapse_step(b0, (valid && t == 0) ? x : -INFINITY, foi);
+        collapse_step(b1, (valid && t == 1) ? x : -INFINITY, foi);
+        collapse_step(b2, (valid && t == 2) ? x : -INFINITY, foi);
       }
     }
     collapse_merge(b0, 1); collapse_merge(b0, 2);
@@ -600,6 +617,7 @@ __global__ __launch_bounds__(256) void k_collapse(const float *__restrict__ sg, 
       pow_[o] = (double)r.v;
       pow32[o] = r.v;                                                  // what the fused peak search loads
       frq[o] = r.foi;
+      collapse_flag(r, (unsigned)o, fix_list, n_fix);
     }
   }
 }
@@ -626,11 +644,12 @@ __device__ __forceinline__ float collapse_div5(float x) {
 }
 typedef unsigned int collapse_u4 __attribute__((ext_vector_type(4)));
 #define COLLAPSE_OUT 12                   // positions a wave produces
-#define COLLAPSE_GB 6                     // groups in flight (a multiple of 3)
+#define COLLAPSE_GB 3                     // groups in flight (a multiple of 3; round 4 measured 3 and 6 alike, and the runner-up values need the registers)
 // (amdgpu_num_vgpr is doubled by the backend on the unified register file: 28 = the 56 VGPRs that two resident correlation
 // workgroups leave free on a SIMD; the allocator otherwise spreads over the 64 its occupancy target allows)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(28))) void k_collapse_arm2(const float *__restrict__ sg, double *__restrict__ pow_, float *__restrict__ pow32,
-                                                        int *__restrict__ frq, XcGeom geo, int n_buf) {
+                                                        int *__restrict__ frq, unsigned *__restrict__ fix_list, int *__restrict__ n_fix,
+                                                        XcGeom geo, int n_buf) {
   LCS_TAIL_PRIO();
   constexpr int CT = 4 * COLLAPSE_OUT;             // positions per workgroup
   static_assert(LCS_N_IDX % CT == 0 && LCS_TG == 16, "k_collapse_arm2 tiles 9600 positions x 16 columns");
@@ -643,7 +662,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(28))) void k_co
     const unsigned off = ((unsigned)ridx * 4u + q) * 16u;
     // acc[k]: best of PSS (q + k) mod 3 so far, `foi` holding the COLUMN number 16 g + 4 q + j = 3 foi + pss (ascending
     // with foi within a PSS: the same tie rule; divided by 3 once at the end).  Anything beats -inf.
-    CollapseBest acc[3] = {{-INFINITY, 0}, {-INFINITY, 0}, {-INFINITY, 0}};
+    CollapseBest acc[3] = {{-INFINITY, 0, -INFINITY}, {-INFINITY, 0, -INFINITY}, {-INFINITY, 0, -INFINITY}};
     // the buffer's groups through one buffer resource: scalar base + per-group scalar offset + the lane's 32-bit offset
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(sg + ((size_t)slot * geo.G * LCS_N_IDX) * LCS_TG), 0, geo.G * (int)(LCS_N_IDX * LCS_TG * sizeof(float)), 0x00020000);
@@ -670,29 +689,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(28))) void k_co
           const float x = collapse_div5(collapse_arm2(mv[j]));
           const int col = cb + (16 * r + j);
           // the column's PSS is (g + q + j) mod 3 = (q + (r + j)) mod 3: g6 is a multiple of 3
-          const bool tk = (col < geo.n_tmpl) && x > acc[(r + j) % 3].v;
-          acc[(r + j) % 3].v = tk ? x : acc[(r + j) % 3].v;
-          acc[(r + j) % 3].foi = tk ? col : acc[(r + j) % 3].foi;
+          collapse_step(acc[(r + j) % 3], (col < geo.n_tmpl) ? x : -INFINITY, col);
         }
       }
     }
     // PSS t sits in acc[(t - q) mod 3]; each PSS is merged over the four quads of a position (lanes p, p + 16, p + 32, p + 48)
     const int k0 = (3 - q) % 3, k1 = (4 - q) % 3, k2 = (5 - q) % 3;   // where PSS 0, 1, 2 sit in this lane's frame
-    CollapseBest o0 = {(k0 == 0) ? acc[0].v : (k0 == 1 ? acc[1].v : acc[2].v), (k0 == 0) ? acc[0].foi : (k0 == 1 ? acc[1].foi : acc[2].foi)};
-    CollapseBest o1 = {(k1 == 0) ? acc[0].v : (k1 == 1 ? acc[1].v : acc[2].v), (k1 == 0) ? acc[0].foi : (k1 == 1 ? acc[1].foi : acc[2].foi)};
-    CollapseBest o2 = {(k2 == 0) ? acc[0].v : (k2 == 1 ? acc[1].v : acc[2].v), (k2 == 0) ? acc[0].foi : (k2 == 1 ? acc[1].foi : acc[2].foi)};
+    CollapseBest o0 = (k0 == 0) ? acc[0] : (k0 == 1 ? acc[1] : acc[2]);
+    CollapseBest o1 = (k1 == 0) ? acc[0] : (k1 == 1 ? acc[1] : acc[2]);
+    CollapseBest o2 = (k2 == 0) ? acc[0] : (k2 == 1 ? acc[1] : acc[2]);
     collapse_merge(o0, 16); collapse_merge(o0, 32);
     collapse_merge(o1, 16); collapse_merge(o1, 32);
     collapse_merge(o2, 16); collapse_merge(o2, 32);
     if (q < 3 && p >= 2 && p < 2 + COLLAPSE_OUT) {                     // lane (q, p) writes PSS q of its position
-      const float rv = (q == 0) ? o0.v : (q == 1 ? o1.v : o2.v);
-      const int rf = ((q == 0) ? o0.foi : (q == 1 ? o1.foi : o2.foi)) / 3;
+      const CollapseBest rb = (q == 0) ? o0 : (q == 1 ? o1 : o2);
+      const float rv = rb.v;
+      const int rf = rb.foi / 3;
       int oi = idx;
       asm volatile("" : "+v"(oi));                                     // (the output addresses are formed here, not held across the loop)
       const size_t o = ((size_t)slot * 3 + q) * LCS_N_IDX + oi;
       pow_[o] = (double)rv;
       pow32[o] = rv;                                                   // what the fused peak search loads
       frq[o] = rf;
+      collapse_flag(rb, (unsigned)o, fix_list, n_fix);
     }
   }
 }
@@ -747,6 +766,114 @@ __global__ __launch_bounds__(256) void k_xc_debug(const double2 *__restrict__ ca
   }
 }
 
+// ------------------------------------------------- K3b: near-ties of the arg-max in the reference's own arithmetic
+// xc_incoherent_collapsed_frq is an INTEGER output (ref include/searcher.h:31, src/searcher.cpp:353-383): the first maximum over
+// the hypotheses of float values that the matrix-core kernels reproduce to ~1e-7 relative, not to the bit.  Wherever the best two
+// hypotheses of a (PSS, position) lie within LCS_FRQ_TIE_EPS of each other (k_collapse* list those: a few per buffer) one wave
+// recomputes every hypothesis within that distance of the maximum exactly as the reference does --
+//   xc[t][k][foi]      fp64 accumulate over the 137 taps in tap order, stored as complex<float>      (:136, :160-169)
+//   single += sqr(xc)  the square in double, the running sum a float, window by window, then / n_comb (:299-305)
+//   incoherent         float adds  s[i] + (s[i-d] + s[i+d]),  d = 1 .. arm, then / (2 arm + 1)       (:329-345)
+// -- and takes the first maximum among them with the reference's strict comparison (:374).  Position, collapsed power
+// (then the reference's own float, bit for bit) and index are rewritten in place before the peak search reads them.
+__device__ __forceinline__ float repair_gpu_value(const float *__restrict__ sgs, const XcGeom &geo, int c, int idx) {
+  const int g = c / geo.cpg, j = c - g * geo.cpg;
+  const float *col = sgs + ((size_t)g * LCS_N_IDX) * LCS_TG + j;
+  float v = col[(size_t)idx * LCS_TG];
+  for (int d = 1; d <= geo.ds; ++d) {
+    const int im = (idx - d < 0) ? idx - d + LCS_N_IDX : idx - d, ip = (idx + d >= LCS_N_IDX) ? idx + d - LCS_N_IDX : idx + d;
+    v = v + (col[(size_t)im * LCS_TG] + col[(size_t)ip * LCS_TG]);
+  }
+  return __fdiv_rn(v, (float)(2 * geo.ds + 1));
+}
+#define REPAIR_WAVES 4
+#define REPAIR_MAX_LAGS 17          // 2 * 8 + 1: lcs_xcorr_pss refuses arms beyond 8
+__global__ __launch_bounds__(REPAIR_WAVES * 64) void k_frq_repair(const float *__restrict__ sg, const unsigned *__restrict__ fix_list,
+                                                                   const int *__restrict__ n_fix, const CapSrc src,
+                                                                   const SlotParams *__restrict__ params, const double *__restrict__ fset,
+                                                                   const double2 *__restrict__ pss_td, const int *__restrict__ start,
+                                                                   double *__restrict__ pow_, float *__restrict__ pow32, int *__restrict__ frq,
+                                                                   XcGeom geo) {
+  LCS_TAIL_PRIO();
+  __shared__ double2 s_tmpl[REPAIR_WAVES][137];
+  __shared__ double s_sq[REPAIR_WAVES][REPAIR_MAX_LAGS * LCS_NW_MAX];
+  __shared__ float s_lag[REPAIR_WAVES][REPAIR_MAX_LAGS];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int n = *n_fix;
+  const int n_lag = 2 * geo.ds + 1;
+  for (int e = blockIdx.x * REPAIR_WAVES + wv; e < n; e += gridDim.x * REPAIR_WAVES) {
+    const unsigned pos = fix_list[e];
+    const int idx = (int)(pos % LCS_N_IDX), t = (int)((pos / LCS_N_IDX) % 3), slot = (int)(pos / (3 * LCS_N_IDX));
+    const float *sgs = sg + (size_t)slot * geo.G * LCS_N_IDX * LCS_TG;
+    const SlotParams p = params[slot];
+    const CapView cap = cap_view(src, slot);
+    // the values the collapse kernel compared (same expression, same rounding), lane f and f + 64
+    const float x0 = lane < geo.n_f ? repair_gpu_value(sgs, geo, 3 * lane + t, idx) : -INFINITY;
+    const float x1 = lane + 64 < geo.n_f ? repair_gpu_value(sgs, geo, 3 * (lane + 64) + t, idx) : -INFINITY;
+    float mx = fmaxf(x0, x1);
+    for (int o = 32; o; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    const float lim = mx * (1.0f - LCS_FRQ_TIE_EPS);
+    const unsigned long long m0 = __ballot(x0 >= lim), m1 = __ballot(x1 >= lim);
+    float best = -INFINITY;
+    int best_f = 0;
+    for (int half = 0; half < 2; ++half) {
+      unsigned long long m = half ? m1 : m0;
+      while (m) {                                                        // ascending in foi: the reference's scan order
+        const int f = __builtin_ctzll(m) + 64 * half;
+        m &= m - 1;
+        // conj(fshift(pss_td, f_off, fs_programmed * k_factor)) / 137 in double (ref :146-151, dsp.h:40-53)
+        const double f_off = fset[f];
+        const double kf = (p.fc_req - f_off) / p.fc_prog;
+        const double k = M_PI * f_off / ((p.fs_prog * kf) / 2);
+        for (int mm = lane; mm < 137; mm += 64) {
+          double sn, cs;
+          sincos(k * (double)mm, &sn, &cs);
+          const double2 s = pss_td[t * 137 + mm];
+          s_tmpl[wv][mm] = make_double2((s.x * cs - s.y * sn) / 137, -(s.x * sn + s.y * cs) / 137);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int it = lane; it < n_lag * geo.n_comb; it += 64) {         // (lag, window): one 137-tap correlation each
+          const int l = it / geo.n_comb, w = it - l * geo.n_comb;
+          int ii = idx + l - geo.ds;
+          ii = ii < 0 ? ii + LCS_N_IDX : (ii >= LCS_N_IDX ? ii - LCS_N_IDX : ii);
+          const size_t k0 = (size_t)ii + (size_t)start[((size_t)slot * LCS_NW_MAX + w) * LCS_NF_MAX + f];
+          double ar = 0, ai = 0;
+          for (int mm = 0; mm < 137; ++mm) {
+            const double2 a = s_tmpl[wv][mm], b = cap_at(cap, k0 + mm);
+            ar += a.x * b.x - a.y * b.y;
+            ai += a.x * b.y + a.y * b.x;
+          }
+          const float fr = (float)ar, fi = (float)ai;                    // xc is complex<float>
+          s_sq[wv][it] = (double)fr * (double)fr + (double)fi * (double)fi;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane < n_lag) {                                              // the float running sum over the windows, in window order
+          float o = 0.f;
+          for (int w = 0; w < geo.n_comb; ++w) o = (float)((double)o + s_sq[wv][lane * geo.n_comb + w]);
+          s_lag[wv][lane] = __fdiv_rn(o, (float)geo.n_comb);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        float v = s_lag[wv][geo.ds];
+        for (int d = 1; d <= geo.ds; ++d) v = v + (s_lag[wv][geo.ds - d] + s_lag[wv][geo.ds + d]);
+        v = __fdiv_rn(v, (float)n_lag);
+        if (v > best) { best = v; best_f = f; }                          // strict: the lowest index wins a tie (ref :374)
+        __builtin_amdgcn_wave_barrier();                                 // s_tmpl / s_sq / s_lag are rewritten by the next candidate
+      }
+    }
+    if (lane == 0) {
+      pow_[pos] = (double)best;
+      pow32[pos] = best;
+      frq[pos] = best_f;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------ launch
 CapSrc lcs_cap_src(const lcs_ctx *c, uint32_t n_cap) {
   CapSrc s{nullptr, nullptr, nullptr, n_cap};
@@ -796,7 +923,7 @@ static hipEvent_t g_xc_done[64] = {};
 
 int lcs_launch_xcorr(lcs_ctx *c, int n_buf, const XcGeom &geo, bool want_incoh, bool time_it) {
   hipLaunchKernelGGL(k_prep_tables, dim3(n_buf, 4), dim3(256), 0, c->stream, c->params, c->fset, c->d_pss_td, c->tmpl,
-                     c->start, c->smin, c->kp2, geo);
+                     c->start, c->smin, c->kp2, c->n_fix, geo);
   if (c->use_i8) {
     int rc_ = lcs_launch_fill_brow_i8(c, n_buf, geo);
     if (rc_) return rc_;
@@ -870,10 +997,14 @@ int lcs_launch_xcorr(lcs_ctx *c, int n_buf, const XcGeom &geo, bool want_incoh, 
     float *incoh = want_incoh ? c->incoh : nullptr;
     float *pow32 = reinterpret_cast<float *>(c->work);
     if (geo.ds == 2 && !incoh && geo.cpg == LCS_TG)
-      hipLaunchKernelGGL(k_collapse_arm2, dim3((LCS_N_IDX / (4 * COLLAPSE_OUT)) * n_buf), block, 0, c->stream, c->single, c->pow_, pow32, c->frq, geo, n_buf);
-    else if (geo.ds == 2 && !incoh) hipLaunchKernelGGL((k_collapse<2, false>), grid, block, 0, c->stream, c->single, incoh, c->pow_, pow32, c->frq, geo, n_buf);
-    else if (!incoh) hipLaunchKernelGGL((k_collapse<-1, false>), grid, block, 0, c->stream, c->single, incoh, c->pow_, pow32, c->frq, geo, n_buf);   // any arm, no debug copy
-    else hipLaunchKernelGGL((k_collapse<-1, true>), grid, block, 0, c->stream, c->single, incoh, c->pow_, pow32, c->frq, geo, n_buf);
+      hipLaunchKernelGGL(k_collapse_arm2, dim3((LCS_N_IDX / (4 * COLLAPSE_OUT)) * n_buf), block, 0, c->stream, c->single, c->pow_, pow32, c->frq, c->fix_list, c->n_fix, geo, n_buf);
+    else if (geo.ds == 2 && !incoh) hipLaunchKernelGGL((k_collapse<2, false>), grid, block, 0, c->stream, c->single, incoh, c->pow_, pow32, c->frq, c->fix_list, c->n_fix, geo, n_buf);
+    else if (!incoh) hipLaunchKernelGGL((k_collapse<-1, false>), grid, block, 0, c->stream, c->single, incoh, c->pow_, pow32, c->frq, c->fix_list, c->n_fix, geo, n_buf);   // any arm, no debug copy
+    else hipLaunchKernelGGL((k_collapse<-1, true>), grid, block, 0, c->stream, c->single, incoh, c->pow_, pow32, c->frq, c->fix_list, c->n_fix, geo, n_buf);
+    // near-ties of the arg-max, recomputed in the reference's arithmetic (a few positions per buffer; the kernel loops over the list)
+    if (!c->skip_frq_repair)
+    hipLaunchKernelGGL(k_frq_repair, dim3(std::min(256, 8 * n_buf)), dim3(REPAIR_WAVES * 64), 0, c->stream, c->single, c->fix_list, c->n_fix,
+                       lcs_cap_src(c, geo.n_cap), c->params, c->fset, c->d_pss_td, c->start, c->pow_, pow32, c->frq, geo);
   }
   HIPCHK(c, hipGetLastError());
   return LCS_OK;

@@ -97,6 +97,42 @@ __global__ __launch_bounds__(64) void k_gather_work(const lcs_cell *__restrict__
   for (int off = 32; off > 0; off >>= 1) dup += __shfl_down(dup, off);
   if (lane == 0) { n_work[0] = min(max(base - skip, 0), limit); n_work[1] = base; n_work[2] = dup; }
 }
+// Results of a batch, compacted on the device for lcs_batch_collect: hdr[0] = records written, hdr[1] = 1 if a buffer
+// found more peaks than LCS_MAXP holds (impossible for a buffer with positive thresholds, lcs.h), hdr[4..7] = n_work;
+// cnt[b] = records of buffer b; rec = the records, buffer after buffer.  full: only peaks with SSS and MIB (the reference
+// erases the others, src/CellSearch.cpp:530-534, :554-558); otherwise every peak.  The host then copies a few KB from
+// ONE place instead of n_buf x LCS_MAXP records.
+__global__ __launch_bounds__(64) void k_pack_results(const lcs_cell *__restrict__ peaks, const int *__restrict__ npeaks, int n_buf, int full,
+                                                     const int *__restrict__ n_work, int *__restrict__ hdr, int *__restrict__ cnt,
+                                                     lcs_cell *__restrict__ rec) {
+  LCS_TAIL_PRIO();
+  const int lane = threadIdx.x;
+  int base = 0, ovf = 0;
+  for (int s0 = 0; s0 < n_buf; s0 += 64) {
+    const int s = s0 + lane;
+    const int raw = (s < n_buf) ? max(npeaks[s], 0) : 0;
+    const int np = min(raw, LCS_MAXP);
+    ovf |= raw > LCS_MAXP;
+    int c = 0;
+    for (int p = 0; p < np; ++p) {
+      const lcs_cell &pc = peaks[(size_t)s * LCS_MAXP + p];
+      c += !(full && (pc.n_id_1 == -1 || pc.n_rb_dl == -1));
+    }
+    int incl = c;
+    for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(incl, off); if (lane >= off) incl += v; }
+    int at = base + incl - c;
+    for (int p = 0; p < np; ++p) {
+      const lcs_cell pc = peaks[(size_t)s * LCS_MAXP + p];
+      if (full && (pc.n_id_1 == -1 || pc.n_rb_dl == -1)) continue;
+      rec[at++] = pc;
+    }
+    if (s < n_buf) cnt[s] = c;
+    base += __shfl(incl, 63);
+  }
+  ovf = __any(ovf);
+  if (lane == 0) { hdr[0] = base; hdr[1] = ovf; hdr[2] = 0; hdr[3] = 0; }
+  if (lane < 4) hdr[4 + lane] = n_work ? n_work[lane] : 0;
+}
 // ------------------------------------------------------------ extract_tfg: timestamps
 // ref :875-889 and the running dft_location of :903-920 (kept sequential: each timestamp is a
 // floating-point running sum).  One thread per cell.
@@ -918,9 +954,16 @@ __global__ __launch_bounds__(64) void k_mib_select(lcs_cell *__restrict__ cells,
 // ------------------------------------------------------------------------------ launch
 // workgroups loop over the work list; c->grid_items of them per list axis (64: a typical 64-buffer batch in one round)
 int lcs_launch_gather_work(lcs_ctx *c, int n_buf, int skip, int limit) {
-  hipLaunchKernelGGL(k_gather_work, dim3(1), dim3(64), 0, c->stream, c->peaks, c->npeaks, n_buf, skip, limit > 0 ? limit : c->max_work,
+  hipLaunchKernelGGL(k_gather_work, dim3(1), dim3(64), 0, c->stream, c->peaks, c->npeaks, n_buf, skip, limit > 0 ? limit : std::min(c->max_work, c->percell_cap),
                      c->st_open ? c->st_dtracked : nullptr, c->st_dntracked, c->work_items, c->n_work,
                      c->cells_out);
+  HIPCHK(c, hipGetLastError());
+  return LCS_OK;
+}
+int lcs_launch_pack_results(lcs_ctx *c, int n_buf, bool full) {
+  int *hdr = reinterpret_cast<int *>(c->res_pack);
+  hipLaunchKernelGGL(k_pack_results, dim3(1), dim3(64), 0, c->stream, c->peaks, c->npeaks, n_buf, full ? 1 : 0, full ? c->n_work : nullptr, hdr, hdr + 8,
+                     reinterpret_cast<lcs_cell *>(reinterpret_cast<char *>(c->res_pack) + lcs_pack_rec_offset(n_buf)));
   HIPCHK(c, hipGetLastError());
   return LCS_OK;
 }

@@ -22,7 +22,7 @@ from typing import Callable, List, Sequence
 
 import numpy as np
 
-MAXC = 16            # cell records kept per carrier
+MAXC = 104   # == capi.MAX_PEAKS: cell records kept per carrier: the longest list the reference can return (include/lcs.h LCS_MAX_PEAKS)
 FIELDS = ("fc_requested", "fc_programmed", "pss_pow", "freq", "frame_start", "freq_fine", "freq_superfine",
           "ind", "n_id_2", "n_id_1", "cp_type", "n_ports", "n_rb_dl", "phich_duration", "phich_resource", "sfn")
 
