@@ -17,8 +17,9 @@ for a step later, off the critical path.  --input-host feeds the same batches fr
 memory (lcs_batch_enqueue_host: PCIe inside the timed region).
 
 The run verifies itself: every batch collected inside the timed, pipelined region must return the
-same bytes as a sequential single-context run of the same buffers afterwards, and buffer 0 is
-checked against the CPU oracle ("verified" in the JSON line).
+same bytes as a sequential single-context run of the same buffers afterwards, and 16 buffers (12 of
+the timed batch, 4 of the dense band) are checked against the CPU oracle ("verified" in the JSON line;
+tools/parity_population.py checks every timed buffer and 512 more).
 
 Prints ONE JSON line on rank 0.
 """
@@ -99,6 +100,8 @@ def cpu_baseline(pkg, host_u8, f, fcs, stage, n_sample=4):
                 break
     except OSError:
         pass
+    cpu_baseline.results = res       # the oracle's cells of the sampled buffers (the verification leg reuses them)
+    cpu_baseline.threads = ncpu
     return ({"value": n_sample / dt, "unit": "capture-buffers/s", "cores": 1, "kind": "port",
              "sample": f"{n_sample} synthetic buffers of the bench batch, n_f={f.size}, stage={stage}, {dt:.2f} s single-thread "
                        f"(C oracle, gcc -O3); {ncpu} threads (OpenMP over lags as the reference): {n_sample / dt_mt:.3f} buffers/s",
@@ -738,6 +741,10 @@ def main():
         if not torch.equal(got[rank], gather_in[li]):
             sys.exit("bench.py: the all-gathered cell records of this rank differ from what it sent")
         state["gathered"] = [int(got[r, 0].item()) for r in range(world)]
+        # carriers named in every rank's records (column 1 of a row): rank r searches FC + 100 kHz * (r B .. r B + B - 1)
+        rows = [got[r, 1:1 + 5 * state["gathered"][r]].view(-1, 5) for r in range(world)]
+        state["gathered_fc"] = [[float(x[:, 1].min()), float(x[:, 1].max())] if len(x) else None for x in rows]
+        state["gather_shape"] = list(got.shape)
     if dist is not None:
         dist.barrier()
     dt = time.perf_counter() - t0
@@ -773,7 +780,7 @@ def main():
     kname, executed_ops = ctxs[0].last_xcorr_info()
     # ---- dense band (reported next to the default, never part of `value`): 2-3 cells planted in EVERY buffer, so the
     # per-cell stages carry ~8x the cells of the band-scan workload above
-    dense = None
+    dense, dense_rec, dense_host = None, None, None
     if args.stage == "full" and not args.no_dense and fmt == pkg.FMT_IQ_U8 and world == 1:
         dh = synth_batch(pkg, B, 4321, fcs, dense=True)
         dd = torch.from_numpy(dh).to(dev)
@@ -795,6 +802,9 @@ def main():
             dms.append(1e3 * (time.perf_counter() - t1) / K_)
         cells_d = int(last_d[1].sum())
         dms = dms[1:]
+        ctxs[0].batch_enqueue(dd.data_ptr(), fmt, B, N_CAP, f, fcs, fcs, FS, stage_mask)       # the un-rolled dense batch once more, alone: the
+        dense_rec = ctxs[0].batch_collect_raw(B, MAXC)                                        # records the oracle leg below checks
+        dense_host = dh
         dense = {"buffers_per_s": B / (min(dms) * 1e-3), "ms_per_batch": min(dms), "cells_decoded_per_buffer": cells_d / B,
                  "cells_planted_per_buffer": 2.5, "batches_timed": K_, "pipelined_mismatches": state["mismatch"] - mism0,
                  "note": f"same chain, same grid; every one of the {B} buffers of a batch carries 2-3 synthetic cells (SNR 0-10 dB)"}
@@ -803,7 +813,7 @@ def main():
         state["mismatch"], state["collected"] = mism0, coll_saved
         host_t.update(host_saved)
     verify = {"pipelined_collects": state["collected"], "pipelined_mismatches": state["mismatch"],
-              "sequential_run_identical": bool(seq_ok), "oracle_buffer0": None}
+              "sequential_run_identical": bool(seq_ok), "oracle_buffer0": None, "oracle_buffers_checked": [], "oracle_buffers_differing": []}
 
     if rank == 0:
         n_f = f.size
@@ -859,7 +869,8 @@ def main():
                        "pipeline_depth": len(ctxs),
                        "parallelism": (f"carrier-sweep shard x{world}, one async {'RCCL' if args.dist_backend == 'nccl' else args.dist_backend} all-gather of the "
                                        f"cell records per step") if multi else "single GPU",
-                       "collectives": ({"backend": dist.get_backend(), "world": world, "gathered_records_last_step": state.get("gathered")} if multi else None),
+                       "collectives": ({"backend": dist.get_backend(), "world": world, "gathered_records_last_step": state.get("gathered"),
+                                        "gathered_fc_min_max_per_rank": state.get("gathered_fc"), "gather_out_shape": state.get("gather_shape")} if multi else None),
                        "baseline_note": "vs_baseline = value / (1 buffer per ~6 s), doc/CellSearch.html:52-54 (dual-core i7-2640, ppm 100; BASELINE.md section 1)",
                        "cells_per_distinct_batch": n_cells_per_batch,
                        "cells_per_buffer": float(np.mean(n_cells_per_batch)) / B,
@@ -900,18 +911,50 @@ def main():
         if not args.no_cpu_baseline:
             cb, ocells = cpu_baseline(pkg, host, f, fcs, args.stage)
             out["cpu_baseline"] = cb
-            # (3) the GPU's records for buffer 0 against the oracle's: identities exact, powers 1e-5, frequencies 1e-3 Hz
-            got = rec0[0, :cnt0[0]]
-            ok = len(got) == len(ocells)
-            for g_, o_ in zip(got, ocells):
-                ok = ok and (int(g_["n_id_2"]), int(g_["ind"]), float(g_["freq"])) == (o_.n_id_2, o_.ind, o_.freq)
-                ok = ok and abs(float(g_["pss_pow"]) - o_.pss_pow) <= 1e-5 * o_.pss_pow
+            # (3) the GPU's records against the oracle's, buffer by buffer: identities exact, powers 1e-5, frequencies 1e-3 Hz.
+            # Round 5: 12 buffers of the timed batch (the 4 of the baseline sample + 8 more, occupied carriers among them)
+            # and 4 of the dense band -- the whole population (every timed buffer, 512 synthetic ones) is
+            # tools/parity_population.py's job, profiles/r05/parity_population.json its record.
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import oracle as O
+
+            def same(got, ocells):
+                ok = len(got) == len(ocells)
+                for g_, o_ in zip(got, ocells):
+                    ok = ok and (int(g_["n_id_2"]), int(g_["ind"]), float(g_["freq"])) == (o_.n_id_2, o_.ind, o_.freq)
+                    ok = ok and abs(float(g_["pss_pow"]) - o_.pss_pow) <= 1e-5 * o_.pss_pow
+                    if args.stage == "full":
+                        ok = ok and (int(g_["n_id_1"]), int(g_["cp_type"]), int(g_["n_ports"]), int(g_["n_rb_dl"]), int(g_["phich_duration"]),
+                                     int(g_["phich_resource"]), int(g_["sfn"])) == (o_.n_id_1, o_.cp_type, o_.n_ports, o_.n_rb_dl,
+                                                                                     o_.phich_duration, o_.phich_resource, o_.sfn)
+                        ok = ok and abs(float(g_["freq_superfine"]) - o_.freq_superfine) < 1e-3
+                return bool(ok)
+
+            def oracle_cells(u8, fc):
+                x = u8.astype(np.float64)
+                cap = ((x[0::2] - 127.0) / 128.0) + 1j * ((x[1::2] - 127.0) / 128.0)
                 if args.stage == "full":
-                    ok = ok and (int(g_["n_id_1"]), int(g_["cp_type"]), int(g_["n_ports"]), int(g_["n_rb_dl"]), int(g_["phich_duration"]),
-                                 int(g_["phich_resource"]), int(g_["sfn"])) == (o_.n_id_1, o_.cp_type, o_.n_ports, o_.n_rb_dl,
-                                                                                 o_.phich_duration, o_.phich_resource, o_.sfn)
-                    ok = ok and abs(float(g_["freq_superfine"]) - o_.freq_superfine) < 1e-3
-            verify["oracle_buffer0"] = bool(ok)
+                    return O.search_capbuf(cap, f, fc, fc, FS)[0]
+                r = O.xcorr_pss(cap, f, 2, fc, fc, FS)
+                return O.peak_search(r["pow"], r["frq"], O.z_th1(r["sp_incoherent"], r["n_comb_xc"]), f, fc, fc, r["single"], 2)
+
+            O.set_threads(cpu_baseline.threads)
+            checked, bad = [], []
+            main_ids = [b for b in (0, 1, 2, 3, 4, 8, 12, 16, 20, 24, 28, 5) if b < B]
+            for b in main_ids:
+                oc = cpu_baseline.results[b] if b < len(cpu_baseline.results) else oracle_cells(host[b], float(fcs[b]))
+                checked.append(f"timed/{b}")
+                if not same(rec0[b, :cnt0[b]], oc):
+                    bad.append(f"timed/{b}")
+            if dense_rec is not None:
+                for b in [b for b in (0, 1, 2, 3) if b < B]:
+                    checked.append(f"dense/{b}")
+                    if not same(dense_rec[0][b, :dense_rec[1][b]], oracle_cells(dense_host[b], float(fcs[b]))):
+                        bad.append(f"dense/{b}")
+            ok = not bad
+            verify["oracle_buffer0"] = bool("timed/0" not in bad)
+            verify["oracle_buffers_checked"] = checked
+            verify["oracle_buffers_differing"] = bad
             out["verified"] = bool(out["verified"] and ok)
         out["verify"] = verify
         print(json.dumps(out))

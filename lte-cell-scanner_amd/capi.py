@@ -139,7 +139,8 @@ def load() -> C.CDLL:
     L.lcs_stream_close.argtypes = [vp]
     L.lcs_last_xcorr_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]
     L.lcs_last_xcorr_info.argtypes = [vp, dp, C.POINTER(C.c_char_p)]
-    L.lcs_last_frq_repairs.argtypes = [vp, C.POINTER(C.c_int)]
+    if hasattr(L, "lcs_last_frq_repairs"):      # (absent from older developer builds loaded through bench.py --lib)
+        L.lcs_last_frq_repairs.argtypes = [vp, C.POINTER(C.c_int)]
     L.lcs_stream.argtypes = [vp]
     L.lcs_stream.restype = vp
     L.lcs_sync.argtypes = [vp]

@@ -164,8 +164,7 @@ int ensure_percell(lcs_ctx *c) {
 int ensure_res_pack(lcs_ctx *c, int n_buf) {
   const size_t need = lcs_pack_rec_offset(n_buf) + (size_t)n_buf * LCS_MAXP * sizeof(lcs_cell);
   if (need <= c->res_pack_bytes) return LCS_OK;
-  if (c->st_open) { c->err = "lcs_stream_close first"; return LCS_ERR_BAD_ARG; }
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));      // (the streaming mode's graph does not reference this block: it may grow under an open stream)
   if (c->res_pack) (void)hipFree(c->res_pack);
   if (c->h_res) (void)hipHostFree(c->h_res);
   c->res_pack = c->h_res = nullptr;

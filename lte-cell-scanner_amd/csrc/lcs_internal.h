@@ -102,6 +102,14 @@ struct CapView {
   const uint16_t *c8;
 };
 #ifdef __HIPCC__
+// Hand-over of LDS data between the lanes of ONE wave (the wave-local FFT stages): the wave barrier alone is IntrNoMem --
+// no memory fence -- so the ordering of the LDS accesses around it is pinned by a release / acquire fence pair at
+// wavefront scope (no instructions beyond the s_waitcnt the LDS reads need anyway).
+__device__ __forceinline__ void lcs_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 __device__ __forceinline__ CapView cap_view(const CapSrc &s, int slot) {
   CapView v;
   v.c32 = s.c32 ? s.c32 + (size_t)slot * s.n_cap : nullptr;

@@ -125,6 +125,9 @@ __device__ __forceinline__ void qpsk_llr(cd2 sym, double np, double &l0, double 
 // straight into the word (v_cmp writes VCC, v_addc shifts it in): 4 instructions per new state instead of 5.5, and no
 // compare result travels through an SGPR pair into three v_cndmask (round 3: 410 hazard s_nop per 6 steps).  !FAST keeps
 // the compare-and-select form, whose NaN behaviour is the reference's `<`.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "vit_push: the carry-chain form is gfx9 / wave64 assembly (VCC is a 64-bit pair): this library is built for gfx950 only"
+#endif
 __host__ __device__ __forceinline__ void vit_push(unsigned &word, double m1, double m0) {
 #if defined(__HIP_DEVICE_COMPILE__)
   asm("v_cmp_lt_f64 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(word) : "v"(m1), "v"(m0) : "vcc");
@@ -150,7 +153,11 @@ __host__ __device__ __forceinline__ void vit_step(double (&pm)[64], double r0, d
       const double m0 = o0 + ((w0 < 4) ? d[w0 & 3] : -d[(7 - w0) & 3]);
       const double m1 = o1 + ((w1 < 4) ? d[w1 & 3] : -d[(7 - w1) & 3]);
       if (FAST) {
-        pm[b ? sb : sa] = fmin(m0, m1);
+#if defined(__HIP_DEVICE_COMPILE__)
+        pm[b ? sb : sa] = fmin(m0, m1);                // v_min_f64; differs from the select below at most in the SIGN of a zero metric (+0 / -0 tie)
+#else
+        pm[b ? sb : sa] = (m1 < m0) ? m1 : m0;         // the host twin: the decision's own comparison (C's fmin leaves the zero's sign open)
+#endif
         vit_push(b ? hi : lo, m1, m0);
       } else {
         const bool take1 = m1 < m0;                    // ties keep the lower-numbered predecessor

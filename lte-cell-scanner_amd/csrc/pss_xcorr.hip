@@ -831,9 +831,7 @@ __global__ __launch_bounds__(REPAIR_WAVES * 64) void k_frq_repair(const float *_
           const double2 s = pss_td[t * 137 + mm];
           s_tmpl[wv][mm] = make_double2((s.x * cs - s.y * sn) / 137, -(s.x * sn + s.y * cs) / 137);
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        lcs_wave_sync();
         for (int it = lane; it < n_lag * geo.n_comb; it += 64) {         // (lag, window): one 137-tap correlation each
           const int l = it / geo.n_comb, w = it - l * geo.n_comb;
           int ii = idx + l - geo.ds;
@@ -848,22 +846,18 @@ __global__ __launch_bounds__(REPAIR_WAVES * 64) void k_frq_repair(const float *_
           const float fr = (float)ar, fi = (float)ai;                    // xc is complex<float>
           s_sq[wv][it] = (double)fr * (double)fr + (double)fi * (double)fi;
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        lcs_wave_sync();
         if (lane < n_lag) {                                              // the float running sum over the windows, in window order
           float o = 0.f;
           for (int w = 0; w < geo.n_comb; ++w) o = (float)((double)o + s_sq[wv][lane * geo.n_comb + w]);
           s_lag[wv][lane] = __fdiv_rn(o, (float)geo.n_comb);
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        lcs_wave_sync();
         float v = s_lag[wv][geo.ds];
         for (int d = 1; d <= geo.ds; ++d) v = v + (s_lag[wv][geo.ds - d] + s_lag[wv][geo.ds + d]);
         v = __fdiv_rn(v, (float)n_lag);
         if (v > best) { best = v; best_f = f; }                          // strict: the lowest index wins a tie (ref :374)
-        __builtin_amdgcn_wave_barrier();                                 // s_tmpl / s_sq / s_lag are rewritten by the next candidate
+        lcs_wave_sync();                                                 // s_tmpl / s_sq / s_lag are rewritten by the next candidate
       }
     }
     if (lane == 0) {

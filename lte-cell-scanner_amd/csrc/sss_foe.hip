@@ -89,7 +89,7 @@ __device__ __forceinline__ void fft128_wave(cd2 *x, const cd2 (&tw)[7], int lane
     const cd2 a = x[i0], b = x[i1];
     x[i0] = cadd(a, b);
     x[i1] = cmul(csub(a, b), tw[stg]);
-    __builtin_amdgcn_wave_barrier();
+    lcs_wave_sync();
   }
 }
 // One of the 62 PSS/SSS bins [97..127, 1..31] of a transformed window, /sqrt(128) (ref :527-529)
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(SW_THREADS) void k_sss_win(const lcs_cell *__restri
       win[w][lane] = stage_sample(cap, n_cap, loc, g.kph, lane);
       win[w][lane + 64] = stage_sample(cap, n_cap, loc, g.kph, lane + 64);
     }
-    __builtin_amdgcn_wave_barrier();          // wave w staged window w itself
+    lcs_wave_sync();          // wave w staged window w itself
     fft128_wave(win[w], tw, lane);
     if (lane < 62) {
       const cd2 o = fft62_bin(win[w], lane);
@@ -422,7 +422,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_foe_win(const lcs_cell *__restri
       win[w][lane] = stage_sample(cap, n_cap, loc, g.kph, lane);
       win[w][lane + 64] = stage_sample(cap, n_cap, loc, g.kph, lane + 64);
     }
-    __builtin_amdgcn_wave_barrier();          // wave w staged window w itself
+    lcs_wave_sync();          // wave w staged window w itself
     fft128_wave(win[w], tw, lane);
     if (lane < 62) {
       const cd2 o = fft62_bin(win[w], lane);

@@ -297,7 +297,7 @@ __global__ __launch_bounds__(TFG_THREADS) void k_tfg(const lcs_cell *__restrict_
         // wave wv owns windows wv and wv + 4 through all seven stages: no other wave touches them, and one wave's LDS
         // accesses execute in program order -- a workgroup barrier per stage (round 3) only made the four waves wait for
         // each other seven times per job
-        __builtin_amdgcn_wave_barrier();
+        lcs_wave_sync();
       }
       __syncthreads();                        // the output pass below reads every wave's windows
       for (int e = tid; e < TFG_SYM * NSC; e += TFG_THREADS) {

@@ -137,7 +137,7 @@ __global__ __launch_bounds__(64 * TRK_FD_SYM) void k_trk_fd(const lcs_track_cell
     const cd2 a = x[i0], b = x[i1];
     x[i0] = cadd(a, b);
     x[i1] = cmul(csub(a, b), twr[stg]);
-    __builtin_amdgcn_wave_barrier();
+    lcs_wave_sync();
   }
   if (!live) return;
   const lcs_track_cell c = cells[cell];

@@ -227,17 +227,9 @@ def frac_resample(x, u, half=24, beta=9.0):
     return out
 
 
-def make_capbuf(seed, fc, cells=(), snr_db=10.0, n_cap=N_CAP, rms=0.15, quantise=True, fc_programmed=None, fs_programmed=FS):
-    """One capture buffer as the receiver would record it.
-
-    fc is the frequency the caller asked for (fc_requested); fc_programmed / fs_programmed are what the dongle reports
-    it was actually set to (ref src/CellSearch.cpp:380-390): the crystal error then is k_factor = (fc - f_off) /
-    fc_programmed and the true sample rate fs_programmed * k_factor (src/searcher.cpp:147).
-
-    cells: dicts with n_id_1, n_id_2 and optionally cp_normal, n_ports, n_rb_dl, phich_duration_ext,
-    phich_res, sfn0, load, f_off (Hz, the dongle's LO error: +f_off means the cell appears f_off
-    above DC), t0 (samples into the first frame), gain_db.  Returns (iq_u8 or complex128, truth)."""
-    rng = np.random.default_rng(seed)
+def make_signal(rng, fc, cells=(), n_cap=N_CAP, fc_programmed=None, fs_programmed=FS):
+    """The noise-free part of a capture buffer: the sum of the cells' waveforms as the receiver samples them.
+    -> (signal, ref_pow = sample power of the first cell's PSS/SSS symbols or None without cells, truth)."""
     n = np.arange(n_cap, dtype=np.float64)
     sig = np.zeros(n_cap, np.complex128)
     truth = []
@@ -259,19 +251,37 @@ def make_capbuf(seed, fc, cells=(), snr_db=10.0, n_cap=N_CAP, rms=0.15, quantise
         if ref_pow is None:
             ref_pow = g * g * 62.0 / 128.0       # sample power of a PSS/SSS symbol (62 of 128 bins, unit RE power)
         truth.append(dict(cd, t0=t0, n_id_cell=cd["n_id_2"] + 3 * cd["n_id_1"], k_factor=k_factor))
-    if ref_pow is None:
-        ref_pow = 1.0
-        noise_pow = 1.0
-    else:
-        noise_pow = ref_pow / 10 ** (snr_db / 10)
+    return sig, ref_pow, truth
+
+
+def add_noise_and_quantise(rng, sig, ref_pow, snr_db=10.0, rms=0.15, quantise=True):
+    """AWGN at `snr_db` below the first cell's PSS/SSS sample power (unit noise without cells), AGC to `rms`, and the
+    RTL-SDR's 8-bit quantisation (x -> clip(round(128 x + 127)), ref src/capbuf.cpp:174)."""
+    n_cap = sig.size
+    noise_pow = 1.0 if ref_pow is None else ref_pow / 10 ** (snr_db / 10)
     x = sig + np.sqrt(noise_pow / 2) * (rng.standard_normal(n_cap) + 1j * rng.standard_normal(n_cap))
     x *= rms / np.sqrt(np.mean(np.abs(x) ** 2))
     if not quantise:
-        return x, truth
+        return x
     iq = np.empty(2 * n_cap, np.uint8)
     iq[0::2] = np.clip(np.rint(128 * x.real + 127), 0, 255).astype(np.uint8)
     iq[1::2] = np.clip(np.rint(128 * x.imag + 127), 0, 255).astype(np.uint8)
-    return iq, truth
+    return iq
+
+
+def make_capbuf(seed, fc, cells=(), snr_db=10.0, n_cap=N_CAP, rms=0.15, quantise=True, fc_programmed=None, fs_programmed=FS):
+    """One capture buffer as the receiver would record it.
+
+    fc is the frequency the caller asked for (fc_requested); fc_programmed / fs_programmed are what the dongle reports
+    it was actually set to (ref src/CellSearch.cpp:380-390): the crystal error then is k_factor = (fc - f_off) /
+    fc_programmed and the true sample rate fs_programmed * k_factor (src/searcher.cpp:147).
+
+    cells: dicts with n_id_1, n_id_2 and optionally cp_normal, n_ports, n_rb_dl, phich_duration_ext,
+    phich_res, sfn0, load, f_off (Hz, the dongle's LO error: +f_off means the cell appears f_off
+    above DC), t0 (samples into the first frame), gain_db.  Returns (iq_u8 or complex128, truth)."""
+    rng = np.random.default_rng(seed)
+    sig, ref_pow, truth = make_signal(rng, fc, cells, n_cap, fc_programmed, fs_programmed)
+    return add_noise_and_quantise(rng, sig, ref_pow, snr_db, rms, quantise), truth
 
 
 def iq_u8_to_complex(iq):

@@ -1,0 +1,93 @@
+"""World size 8 before the hardware sees it: every multi-rank driver run with EIGHT ranks on the one GPU a test box has
+(gloo for the collectives, `--share-gpu0`): rank arithmetic of the carrier shard (rank 7's carriers), the shape of the
+per-step record all-gather (8 x (1 + 5 MAXREC)), the per-rank identity check, eight per-rank rates; the sweep tool's table at
+world 8 equal to world 1; host/CellSearch with eight device threads byte-identical to one.  No scaling curve comes from
+this -- the eight ranks share one GPU -- it is the logic that an 8-GPU node then only has to run faster."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, golden, iq_u8_to_capbuf, load_pkg
+
+pytestmark = pytest.mark.gpu
+
+ENV = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+ENV.update(MASTER_ADDR="127.0.0.1", GPU_MAX_HW_QUEUES="8", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+
+
+def _json_line(stdout):
+    return json.loads([l for l in stdout.splitlines() if l.startswith("{")][-1])
+
+
+def test_bench_world_8_on_one_gpu():
+    """`python bench.py --gpus 8` starts eight ranks itself; every rank owns its carriers FC + 100 kHz * (r B + b), keeps two
+    batches in flight, packs its step's records, and the asynchronous all-gather brings 8 x (1 + 5 MAXREC) doubles to everyone."""
+    B, K, steps = 8, 2, 2
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--share-gpu0", "--dist-backend", "gloo", "--steps", str(steps),
+                        "--warmup", "1", "--batch", str(B), "--batches-per-step", str(K), "--no-cpu-baseline", "--no-dense", "--no-power-probe"],
+                       env=dict(ENV, MASTER_PORT="29571"), capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                            # rank 0 alone prints
+    j = json.loads(lines[0])
+    c = j["config"]
+    assert j["n_gpus"] == 8 and j["verified"] is True and j["scaling"] == "weak"
+    assert len(c["per_rank_buffers_per_s"]) == 8 and len(c["devices"]) == 8
+    assert c["buffers_timed"] == 8 * B * K * steps
+    assert j["value"] <= sum(c["per_rank_buffers_per_s"]) * 1.001    # whole job / the slowest rank's time
+    coll = c["collectives"]
+    assert coll["world"] == 8 and coll["backend"] == "gloo" and len(coll["gathered_records_last_step"]) == 8
+    maxrec = max(64, B) * K
+    assert coll["gather_out_shape"] == [8, 1 + 5 * maxrec]
+    # every rank found its planted cells (buffer 0 of every batch of 8 is occupied) and names only its own carriers
+    FC = 739e6
+    for rank, (n, rng) in enumerate(zip(coll["gathered_records_last_step"], coll["gathered_fc_min_max_per_rank"])):
+        assert n >= K, (rank, n)
+        lo, hi = FC + 100e3 * rank * B, FC + 100e3 * (rank * B + B - 1)
+        assert lo <= rng[0] <= rng[1] <= hi, (rank, rng, lo, hi)
+    assert coll["gathered_fc_min_max_per_rank"][7][0] >= FC + 100e3 * 56
+
+
+def test_sweep_tool_world_8_equals_world_1():
+    """tools/sweep_cellsearch.py over 24 carriers: eight ranks of three carriers each (block-cyclic), one all-gather of the
+    raw records, the merged table equal to the single-rank table."""
+    tool = os.path.join(ROOT, "tools", "sweep_cellsearch.py")
+    args = ["-s", "738e6", "-e", "740.3e6", "--occupied-every", "5", "--json"]
+    a = subprocess.run([sys.executable, tool] + args, env=ENV, capture_output=True, text=True, timeout=900)
+    assert a.returncode == 0, a.stderr[-2000:]
+    b = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr", "127.0.0.1",
+                        "--master-port", "29573", tool] + args + ["--share-gpu0", "--dist-backend", "gloo"], env=ENV,
+                       capture_output=True, text=True, timeout=1500)
+    assert b.returncode == 0, b.stderr[-2000:]
+    ja, jb = _json_line(a.stdout), _json_line(b.stdout)
+    assert ja["cells"] == jb["cells"] and ja["carriers"] == jb["carriers"] == 24 and len(ja["cells"]) >= 3
+    assert jb["n_gpus"] == 8 and ja["n_gpus"] == 1
+
+
+def test_cellsearch_cli_eight_device_threads(tmp_path):
+    """host/CellSearch -g 0,0,0,0,0,0,0,0: eight device threads (two contexts each) share the one GPU; batches go to them
+    block-cyclically and the report must be byte-identical to -g 0."""
+    pkg = load_pkg()
+    it = __import__("importlib").import_module("lte_cell_scanner_amd.itfile")
+    g = golden("capbuf_0000")
+    cap = iq_u8_to_capbuf(g["iq_u8"])
+    rng = np.random.default_rng(8)
+    fc0 = int(g["fc"][0])
+    n = 18
+    for k in range(n):                     # carriers 2, 9, 16 hold the recorded capture, the rest noise: more batches (-B 1) than threads
+        if k % 7 == 2:
+            buf = cap
+        else:
+            buf = iq_u8_to_capbuf(np.clip(np.rint(rng.normal(127.0, 12.0, g["iq_u8"].size)), 0, 255).astype(np.uint8))
+        it.write_it(str(tmp_path / f"capbuf_{k:04d}.it"), {"capbuf": buf, "fc": np.array([fc0 + 100000 * (k - 2)], np.int32)})
+    exe = os.path.join(ROOT, "host", "CellSearch")
+    base = [exe, "-s", str(fc0 - 200000), "-e", str(fc0 + 100000 * (n - 3)), "-l", "-d", str(tmp_path)]
+    one = subprocess.run(base + ["-g", "0", "-B", "1"], capture_output=True, text=True, timeout=900)
+    assert one.returncode == 0, one.stderr[-2000:]
+    eight = subprocess.run(base + ["-g", "0,0,0,0,0,0,0,0", "-B", "1"], capture_output=True, text=True, timeout=1500)
+    assert eight.returncode == 0, eight.stderr[-2000:]
+    assert one.stdout == eight.stdout and "277" in one.stdout and "271" in one.stdout
