@@ -629,7 +629,7 @@ def main():
     gather_out = [torch.zeros((world, 1 + 5 * MAXREC), dtype=torch.float64, device=coll_dev) for _ in range(2)] if multi else None
     pending = {"work": None}
 
-    host_t = {"enqueue": 0.0, "collect": 0.0, "n": 0}
+    host_t = {"enqueue": 0.0, "collect": 0.0, "n": 0, "lib_us": 0.0 if hasattr(pkg.capi.load(), "lcs_last_collect_host_us") else None}
     seen = {}            # distinct-batch index -> digest of the first collect; every later collect must match
     state = {"mismatch": 0, "collected": 0}
 
@@ -657,6 +657,8 @@ def main():
         rec, cnt = ctxs[i % len(ctxs)].batch_collect_raw(B, MAXC)
         host_t["collect"] += time.perf_counter() - t
         host_t["n"] += 1
+        if host_t["lib_us"] is not None:
+            host_t["lib_us"] += ctxs[i % len(ctxs)].last_collect_host_us()
         dg = digest(rec, cnt)
         if seen.setdefault(i % len(work["caps"]), dg) != dg:
             state["mismatch"] += 1
@@ -719,7 +721,7 @@ def main():
     t_pre = time.perf_counter()
     while time.perf_counter() - t_pre < 0.6:
         run(1, gather=False)      # time-based, so no collective in here (ranks may differ in count)
-    host_t.update(enqueue=0.0, collect=0.0, n=0)
+    host_t.update(enqueue=0.0, collect=0.0, n=0, lib_us=(0.0 if host_t["lib_us"] is not None else None))
     if args.warmup:
         run(args.warmup, first_step=0)
     xc_ms, step_ms = [], []
@@ -880,7 +882,8 @@ def main():
                        "ms_per_batch": 1e3 * dt / (args.steps * K),
                        "step_ms": {"min": float(sm.min()), "median": float(np.median(sm)), "max": float(sm.max())} if sm.size else None,
                        "host_ms_per_batch": {"enqueue": 1e3 * host_t["enqueue"] / max(1, host_t["n"]),
-                                             "collect_incl_wait": 1e3 * host_t["collect"] / max(1, host_t["n"])}},
+                                             "collect_incl_wait": 1e3 * host_t["collect"] / max(1, host_t["n"]),
+                                             "collect_excl_wait_in_library": (1e-3 * host_t["lib_us"] / max(1, host_t["n"])) if host_t["lib_us"] is not None else None}},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TOP/s" if i8 else "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic,
                          "frac_algorithmic": flops_consumed * B / (k_ms * 1e-3) / 1e12 / peak,

@@ -229,6 +229,9 @@ int lcs_batch_enqueue(lcs_ctx *ctx, const void *d_capbufs, int fmt, int n_buf, u
                       const double *f_search_set, uint16_t n_f, const double *fc_requested,
                       const double *fc_programmed, double fs_programmed, int stage_mask);
 int lcs_batch_collect(lcs_ctx *ctx, lcs_cell *cells, int max_cells_per_buf, int *n_cells);
+/* Host time (microseconds) the last lcs_batch_collect of the context spent OUTSIDE its wait for the GPU: queueing the copy
+ * and scattering the records into the caller's array (bench.py reports it as host_ms_per_batch.collect_excl_wait). */
+int lcs_last_collect_host_us(lcs_ctx *ctx, double *us);
 /* Debug readback of the last batch (after lcs_batch_collect / lcs_search_batch_*): the xcorr_pss outputs of
  * buffer `buf` in the layouts of lcs_xcorr_pss, plus the detection threshold Z_th1 (src/CellSearch.cpp:500-503).
  * Every pointer may be NULL.  This is how the tests pin the batched kernels to the oracle array by array. */

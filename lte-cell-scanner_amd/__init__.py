@@ -443,6 +443,12 @@ class Searcher:
         self._chk(self._lib.lcs_last_frq_repairs(self._h, C.byref(n)), "lcs_last_frq_repairs")
         return n.value
 
+    def last_collect_host_us(self) -> float:
+        """Host microseconds the last batch_collect spent outside its wait for the GPU (lcs_last_collect_host_us)."""
+        us = C.c_double(0)
+        self._chk(self._lib.lcs_last_collect_host_us(self._h, C.byref(us)), "lcs_last_collect_host_us")
+        return us.value
+
     def last_xcorr_info(self):
         """-> (kernel name, matrix-core operations executed by the last enqueue's correlation launches)."""
         ops, name = C.c_double(0), C.c_char_p()

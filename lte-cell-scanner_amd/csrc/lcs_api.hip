@@ -5,6 +5,7 @@
 #include <cstring>
 #include <cstdlib>
 #include <algorithm>
+#include <chrono>
 
 #include "lcs_internal.h"
 
@@ -148,6 +149,7 @@ int ensure_percell(lcs_ctx *c) {
   A(tfg, W * GRID);
   A(tfg_comp, W * GRID);
   A(ce, W * 4 * GRID);
+  A(tfg_desc, W * (size_t)LCS_TFG_DESC_BYTES);
   A(tfg_ts, W * LCS_TFG_ROWS);
   A(tfg_ts_comp, W * LCS_TFG_ROWS);
   A(cell_scratch, W * LCS_CELL_SCRATCH);
@@ -361,7 +363,7 @@ void lcs_destroy(lcs_ctx *c) {
   if (c->stream_xc) (void)hipStreamSynchronize(c->stream_xc);
   void *ptrs[] = {c->cap32, c->cap64, c->params, c->fset, c->tmpl, c->start, c->smin, c->kp2, c->btab, c->single,
                   c->incoh, c->sref, c->pow_, c->work, c->spinc, c->zth, c->sp, c->frq, c->fix_list, c->n_fix, c->peaks, c->npeaks, c->xc,
-                  c->work_items, c->n_work, c->tfg, c->tfg_comp, c->ce, c->tfg_ts, c->tfg_ts_comp, c->cell_scratch,
+                  c->work_items, c->n_work, c->tfg, c->tfg_comp, c->ce, c->tfg_ts, c->tfg_desc, c->tfg_ts_comp, c->cell_scratch,
                   c->cells_out, c->d_pss_td, c->d_pss_fd, c->d_sss_fd, c->d_pbch_scr, c->d_derm_inv, c->d_dbg, c->pk_items, c->n_pk,
                   c->sss_ws, c->d_pn_jump, c->cap8, c->cap8s, c->brow8, c->tq, c->tsc, c->cap16h, c->cap16l, c->brow16, c->texp16, c->tsc16, c->xmax16, c->xpart16, c->h2d, c->trk_td, c->trk_syms, c->trk_raw, c->trk_ce,
                   c->trk_meta, c->trk_rs, c->trk_fmeta, c->trk_pw, c->trk_idx, c->trk_small, c->trk_cells, c->trk_acfd, c->trk_actd,
@@ -559,10 +561,16 @@ int lcs_batch_collect(lcs_ctx *c, lcs_cell *cells, int max_cells_per_buf, int *n
   const int *cnt = hdr + 8;
   const lcs_cell *rec = reinterpret_cast<const lcs_cell *>(static_cast<const char *>(c->h_res) + rec_off);
   int rc = LCS_OK;
+  double host_us = 0;                                   // host time of this call outside the wait for the GPU (lcs_last_collect_host_us)
+  auto t_sync_done = std::chrono::steady_clock::now();
   for (int pass = 0;; ++pass) {
     const size_t first = std::min<size_t>((size_t)nb * LCS_MAXP, (size_t)std::max(nb / 2, c->collect_hint + c->collect_hint / 4 + 8));
+    const auto t_a = std::chrono::steady_clock::now();
     HIPCHK(c, hipMemcpyAsync(c->h_res, c->res_pack, rec_off + first * sizeof(lcs_cell), hipMemcpyDeviceToHost, c->stream));
+    const auto t_b = std::chrono::steady_clock::now();
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    t_sync_done = std::chrono::steady_clock::now();
+    host_us += std::chrono::duration<double, std::micro>(t_b - t_a).count();
     const int work_total = hdr[5];
     if (full && pass == 0) { c->work_hint = work_total; c->hint_n_buf = nb; c->hint_fmt = c->last_fmt; c->hint_stage = c->last_stage_mask; }
     if (full && pass == 0 && work_total > c->last_cell_rounds * c->round_cells) {
@@ -595,8 +603,15 @@ int lcs_batch_collect(lcs_ctx *c, lcs_cell *cells, int max_cells_per_buf, int *n
     n_cells[b] = n;
   }
   c->src32 = nullptr;      // complex<float> batches were read in place: the caller's buffers are no longer referenced
+  c->last_collect_host_us = host_us + std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_sync_done).count();
   if (rc) c->err = "more results than the output array holds";
   return rc;
+}
+
+int lcs_last_collect_host_us(lcs_ctx *c, double *us) {
+  if (!c || !us) return LCS_ERR_BAD_ARG;
+  *us = c->last_collect_host_us;
+  return LCS_OK;
 }
 
 int lcs_search_batch_dev(lcs_ctx *c, const void *d_capbufs, int fmt, int n_buf, uint32_t n_cap, const double *f_search_set,

@@ -51,6 +51,7 @@
 #define LCS_TFG_GRID 4096
 #define LCS_TFA_GRID 2048
 #define LCS_TFG_ROWS 854
+#define LCS_TFG_DESC_BYTES (856 * 32 + 128 * 16)   // tfg_mib.hip: TfgRow records + the frequency correction's position factors
 #define LCS_CELL_SCRATCH 4608 // doubles of per-cell scratch (RS table, shifts, noise powers, PBCH candidates)
 
 struct SlotParams {
@@ -205,6 +206,7 @@ struct lcs_ctx {
   double2 *tfg = nullptr;           // [MAX_WORK][854][72]
   double2 *tfg_comp = nullptr;      // [MAX_WORK][854][72]
   double2 *ce = nullptr;            // [MAX_WORK][4][854][72]
+  char *tfg_desc = nullptr;         // [MAX_WORK][LCS_TFG_DESC_BYTES]: per cell 856 window records in k_tfg's job order + 128 position factors (k_cell_prep)
   double *tfg_ts = nullptr;         // [MAX_WORK][854]
   double *tfg_ts_comp = nullptr;    // [MAX_WORK][854]
   double *cell_scratch = nullptr;   // [MAX_WORK][CELL_SCRATCH]
@@ -251,6 +253,7 @@ struct lcs_ctx {
   // results of a batch, compacted on the device (k_pack_results): [8 ints header][n_buf counts][records]; h_res = its page-locked mirror
   void *res_pack = nullptr, *h_res = nullptr;
   size_t res_pack_bytes = 0;
+  double last_collect_host_us = 0;   // host time of the last lcs_batch_collect outside its wait for the GPU
   int collect_hint = 0;              // records the last collected batch returned: sizes the first copy of the next collect
   // host staging
   SlotParams h_params{};             // source of asynchronous parameter uploads of the single-buffer entry points

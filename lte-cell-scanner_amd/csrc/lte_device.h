@@ -7,6 +7,31 @@ struct cd2 { double re, im; };
 __device__ __forceinline__ cd2 mk(double a, double b) { cd2 r; r.re = a; r.im = b; return r; }
 // exp(j x): one sincos call (one argument reduction; cos(x) and sin(x) as two calls cost 1.8 x the instructions)
 __device__ __forceinline__ cd2 cis(double x) { double s_, c_; sincos(x, &s_, &c_); return mk(c_, s_); }
+// exp(j x) for |x| <= 1 (callers state why): Taylor polynomials in x^2 to x^17 / x^18, Horner with fused multiply-adds; absolute
+// error <= 1.5e-16 over the interval (checked against extended precision on 2 M points) at 21 instructions instead of ~100
+__device__ __forceinline__ cd2 cis_small(double x) {
+  const double z = x * x;
+  double s_ = 2.8114572543455208e-15;            // 1/17!
+  s_ = fma(s_, z, -7.6471637318198165e-13);      // -1/15!
+  s_ = fma(s_, z, 1.6059043836821613e-10);       // 1/13!
+  s_ = fma(s_, z, -2.5052108385441719e-08);      // -1/11!
+  s_ = fma(s_, z, 2.7557319223985893e-06);       // 1/9!
+  s_ = fma(s_, z, -1.9841269841269841e-04);      // -1/7!
+  s_ = fma(s_, z, 8.3333333333333332e-03);       // 1/5!
+  s_ = fma(s_, z, -1.6666666666666666e-01);      // -1/3!
+  s_ = fma(s_, z, 1.0);
+  double c_ = -1.5619206968586226e-16;           // -1/18!
+  c_ = fma(c_, z, 4.7794773323873853e-14);       // 1/16!
+  c_ = fma(c_, z, -1.1470745597729725e-11);      // -1/14!
+  c_ = fma(c_, z, 2.0876756987868099e-09);       // 1/12!
+  c_ = fma(c_, z, -2.7557319223985888e-07);      // -1/10!
+  c_ = fma(c_, z, 2.4801587301587302e-05);       // 1/8!
+  c_ = fma(c_, z, -1.3888888888888889e-03);      // -1/6!
+  c_ = fma(c_, z, 4.1666666666666664e-02);       // 1/4!
+  c_ = fma(c_, z, -0.5);
+  c_ = fma(c_, z, 1.0);
+  return mk(c_, x * s_);
+}
 __device__ __forceinline__ cd2 cadd(cd2 a, cd2 b) { return mk(a.re + b.re, a.im + b.im); }
 __device__ __forceinline__ cd2 csub(cd2 a, cd2 b) { return mk(a.re - b.re, a.im - b.im); }
 __device__ __forceinline__ cd2 cmul(cd2 a, cd2 b) { return mk(a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re); }
@@ -31,6 +56,91 @@ __device__ __forceinline__ int d_imod(int k, int n) { int r = k % n; return r < 
 __device__ __forceinline__ int cell_n_symb(const lcs_cell &c) { return c.cp_type == LCS_CP_NORMAL ? 7 : (c.cp_type == LCS_CP_EXTENDED ? 6 : -1); }
 __device__ __forceinline__ int cell_id(const lcs_cell &c) { return (c.n_id_1 >= 0 && c.n_id_2 >= 0) ? c.n_id_2 + 3 * c.n_id_1 : -1; }
 __device__ __forceinline__ int cn_of(int i) { return (i < 36) ? (i - 36) : (i - 35); }
+
+// ---- 128-point transforms, EIGHT windows per wave, sixteen points per lane in registers (round 5) ----------------------
+// Rounds 1-4 kept a window in LDS and ran seven radix-2 stages over it, one butterfly per lane and stage: 28.7 KB of LDS
+// traffic per window as 16-byte accesses at power-of-two strides (3.2 conflict cycles per LDS instruction on k_tfg, which
+// made the kernel LDS-bound: 2.7 us of a whole CU per 8-window job).  Here lane (w, l) = (lane >> 3, lane & 7) holds the
+// points n = l + 8 j, j = 0..15, of window w:
+//   Y_l[k2] = sum_j x[l + 8 j] W16^(j k2)            16-point transform in registers (fft16)
+//   Z_l[k2] = Y_l[k2] W128^(l k2)                    twiddles from a 2 KB table in LDS (fft128_twiddle_table)
+//   X[k2 + 16 k1] = sum_l Z_l[k2] W8^(l k1)          across the 8 lanes of a window: a transpose through LDS in two halves
+//                                                    (k2 = 0..7, then 8..15: lane l' receives k2 = l' + 8 c for every l), each
+//                                                    followed by an 8-point transform in registers (fft8)
+// 4 KB of LDS traffic per window, conflict-free: the 8 lanes of a window write 128 contiguous bytes per store (the store's
+// lane groups are 8 contiguous lanes); a column is rotated by k2 >> 1 inside its 8 entries and windows sit 68 entries
+// apart, so the 16 lanes of a 16-byte read group (MI355X_MICROARCH.md: {0-3, 12-15, 20-27} ...) fall on 64 different banks
+// (checked by enumeration).  8.5 KB of LDS per wave: four waves of a workgroup stay below 40 KB, so that the compiler aims at
+// four waves per SIMD (128 registers) -- with a 17 KB buffer it saw two, used all 256, and the kernels no longer fitted
+// beside ONE resident correlation workgroup (284 registers are free there): k_sss_win waited 1 ms for a whole CU.
+#define FFT128_WSTRIDE 68                               // entries (16 B) per window in the transpose buffer
+__device__ __forceinline__ cd2 cmul_mi(cd2 a) { return mk(a.im, -a.re); }                       // a * (-i)
+__device__ __forceinline__ void fft4(cd2 &a0, cd2 &a1, cd2 &a2, cd2 &a3) {                      // forward, in place, natural order
+  const cd2 t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), t3 = cmul_mi(csub(a1, a3));
+  a0 = cadd(t0, t2); a2 = csub(t0, t2); a1 = cadd(t1, t3); a3 = csub(t1, t3);
+}
+// x[n], n = 4 n1 + n2 -> X[k], k = k1 + 4 k2: a 4-point transform over n1 per n2, twiddles W16^(n2 k1), a 4-point transform over n2
+__device__ __forceinline__ void fft16(cd2 (&x)[16]) {
+  const double C1 = 0.92387953251128673848, S1 = 0.38268343236508978178, R2 = 0.70710678118654752440;   // cos, sin (pi / 8), sqrt(1/2)
+#pragma unroll
+  for (int n2 = 0; n2 < 4; ++n2) fft4(x[n2], x[4 + n2], x[8 + n2], x[12 + n2]);      // x[4 k1 + n2] = A_n2[k1]
+  // W16^m = (cos(pi m / 8), -sin(pi m / 8)):  n2 k1 in {1, 2, 3, 2, 4, 6, 3, 6, 9}
+  x[4 + 1] = cmul(x[4 + 1], mk(C1, -S1));   x[8 + 1] = cmul(x[8 + 1], mk(R2, -R2));    x[12 + 1] = cmul(x[12 + 1], mk(S1, -C1));
+  x[4 + 2] = cmul(x[4 + 2], mk(R2, -R2));   x[8 + 2] = cmul_mi(x[8 + 2]);              x[12 + 2] = cmul(x[12 + 2], mk(-R2, -R2));
+  x[4 + 3] = cmul(x[4 + 3], mk(S1, -C1));   x[8 + 3] = cmul(x[8 + 3], mk(-R2, -R2));   x[12 + 3] = cmul(x[12 + 3], mk(-C1, S1));
+#pragma unroll
+  for (int k1 = 0; k1 < 4; ++k1) fft4(x[4 * k1], x[4 * k1 + 1], x[4 * k1 + 2], x[4 * k1 + 3]);   // x[4 k1 + k2] = X[k1 + 4 k2]
+}
+__device__ __forceinline__ cd2 fft16_out(const cd2 (&x)[16], int k) { return x[4 * (k & 3) + (k >> 2)]; }    // X[k] after fft16
+// 8 points in place: x[l] -> X[k1] at x[k1]
+__device__ __forceinline__ void fft8(cd2 (&x)[8]) {
+  const double R2 = 0.70710678118654752440;
+  // l = 2 l1 + l2, k1 = q1 + 4 q2:  B_l2[q1] = sum_l1 x[2 l1 + l2] W4^(l1 q1);  X[q1 + 4 q2] = B_0[q1] + (-1)^q2 W8^q1 B_1[q1]
+  fft4(x[0], x[2], x[4], x[6]);
+  fft4(x[1], x[3], x[5], x[7]);
+  const cd2 b1 = cmul(x[3], mk(R2, -R2)), b2 = cmul_mi(x[5]), b3 = cmul(x[7], mk(-R2, -R2));
+  const cd2 e0 = x[0], e1 = x[2], e2 = x[4], e3 = x[6], o0 = x[1];
+  x[0] = cadd(e0, o0); x[4] = csub(e0, o0);
+  x[1] = cadd(e1, b1); x[5] = csub(e1, b1);
+  x[2] = cadd(e2, b2); x[6] = csub(e2, b2);
+  x[3] = cadd(e3, b3); x[7] = csub(e3, b3);
+}
+// W128^(l k2) for l = 0..7, k2 = 0..15 at tw[k2 * 8 + l] (one workgroup-wide table; 128 threads fill it)
+__device__ __forceinline__ void fft128_twiddle_table(cd2 *tw, int tid, int n_threads) {
+  for (int t = tid; t < 128; t += n_threads) { double s_, c_; sincospi(-(double)((t & 7) * (t >> 3)) / 64.0, &s_, &c_); tw[t] = mk(c_, s_); }
+}
+// The whole transform for this lane's window: in x[j] = point l + 8 j (j = 0..15); out X[(l' + 8 c) + 16 k1] at x[8 c + k1] with
+// l' = this lane's l.  tb: this WAVE's transpose buffer (8 * FFT128_WSTRIDE entries), tw: the twiddle table.
+__device__ __forceinline__ void fft128_x8(cd2 (&x)[16], cd2 *tb, const cd2 *tw, int lane) {
+  const int w = lane >> 3, l = lane & 7;
+  fft16(x);
+  cd2 *col = tb + w * FFT128_WSTRIDE;
+  // the second half's eight values leave x first (the first half's results then overwrite x[0..7] while they wait)
+  cd2 zh[8];
+#pragma unroll
+  for (int kk = 0; kk < 8; ++kk) zh[kk] = cmul(fft16_out(x, 8 + kk), tw[(8 + kk) * 8 + l]);
+#pragma unroll
+  for (int kk = 0; kk < 8; ++kk) {
+    cd2 z = fft16_out(x, kk);
+    if (kk) z = cmul(z, tw[kk * 8 + l]);
+    col[kk * 8 + ((l + (kk >> 1)) & 7)] = z;
+  }
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    if (c) {
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) col[kk * 8 + ((l + (kk >> 1)) & 7)] = zh[kk];
+    }
+    lcs_wave_sync();
+    cd2 y[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) y[i] = col[l * 8 + ((i + (l >> 1)) & 7)];              // Z_i[l + 8 c]
+    lcs_wave_sync();                                     // the buffer is rewritten by the second half / the wave's next job
+    fft8(y);
+#pragma unroll
+    for (int k1 = 0; k1 < 8; ++k1) x[8 * c + k1] = y[k1];
+  }
+}
 
 // ---- one row of RS_DL (ref src/lte_lib.cpp:305-383): the cell-specific reference symbols of the 6 centre resource
 // blocks in OFDM symbol `sym` of slot `slot` (t = 0, 1, 2 -> sym 0, 1, n_symb - 3) as 12 (re, im) pairs, and the per-port

@@ -786,27 +786,47 @@ __device__ __forceinline__ float repair_gpu_value(const float *__restrict__ sgs,
   }
   return __fdiv_rn(v, (float)(2 * geo.ds + 1));
 }
-#define REPAIR_WAVES 4
+// One wave per position.  Per candidate the samples all its correlations read -- for every combining window the 137 taps +
+// 2 arm lags that follow the window start -- are first staged in LDS by coalesced loads, IN THE SOURCE'S OWN FORMAT (2 bytes per
+// sample for dongle data; a lane that walked its own window through global memory met one cache line per tap: 140 us per
+// batch for ~300 positions); the 137-term sums then run on LDS operands, one (lag, window) pair per lane.  WAVES waves share
+// a workgroup (dongle data: four -- in the pipelined chain a workgroup of this kernel starts where a correlation workgroup
+// retired, and four waves fill that slot's four SIMDs).
 #define REPAIR_MAX_LAGS 17          // 2 * 8 + 1: lcs_xcorr_pss refuses arms beyond 8
-__global__ __launch_bounds__(REPAIR_WAVES * 64) void k_frq_repair(const float *__restrict__ sg, const unsigned *__restrict__ fix_list,
-                                                                   const int *__restrict__ n_fix, const CapSrc src,
-                                                                   const SlotParams *__restrict__ params, const double *__restrict__ fset,
-                                                                   const double2 *__restrict__ pss_td, const int *__restrict__ start,
-                                                                   double *__restrict__ pow_, float *__restrict__ pow32, int *__restrict__ frq,
-                                                                   XcGeom geo) {
+#define REPAIR_SPAN (137 + REPAIR_MAX_LAGS - 1)
+template <int KIND> struct RepairSample;
+template <> struct RepairSample<0> { typedef uint16_t T; static __device__ __forceinline__ double2 cvt(uint16_t p) { return make_double2(-(double)(int)(int8_t)(p & 255u) / 128.0, -(double)(int)(int8_t)(p >> 8) / 128.0); } };
+template <> struct RepairSample<1> { typedef float2 T; static __device__ __forceinline__ double2 cvt(float2 f) { return make_double2((double)f.x, (double)f.y); } };
+template <> struct RepairSample<2> { typedef double2 T; static __device__ __forceinline__ double2 cvt(double2 d) { return d; } };
+template <int KIND, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_frq_repair(const float *__restrict__ sg, const unsigned *__restrict__ fix_list,
+                                                           const int *__restrict__ n_fix, const CapSrc src,
+                                                           const SlotParams *__restrict__ params, const double *__restrict__ fset,
+                                                           const double2 *__restrict__ pss_td, const int *__restrict__ start,
+                                                           double *__restrict__ pow_, float *__restrict__ pow32, int *__restrict__ frq,
+                                                           XcGeom geo) {
   LCS_TAIL_PRIO();
-  __shared__ double2 s_tmpl[REPAIR_WAVES][137];
-  __shared__ double s_sq[REPAIR_WAVES][REPAIR_MAX_LAGS * LCS_NW_MAX];
-  __shared__ float s_lag[REPAIR_WAVES][REPAIR_MAX_LAGS];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  typedef typename RepairSample<KIND>::T ST;
+  __shared__ double2 s_tmpl_all[WAVES][137];
+  __shared__ ST s_smp_all[WAVES][LCS_NW_MAX][REPAIR_SPAN + 1];
+  __shared__ double s_sq_all[WAVES][REPAIR_MAX_LAGS * LCS_NW_MAX];
+  __shared__ float s_lag_all[WAVES][REPAIR_MAX_LAGS];
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  double2 *s_tmpl = s_tmpl_all[wv];
+  ST (*s_smp)[REPAIR_SPAN + 1] = s_smp_all[wv];
+  double *s_sq = s_sq_all[wv];
+  float *s_lag = s_lag_all[wv];
+  const ST *capbase = KIND == 0 ? reinterpret_cast<const ST *>(src.c8) : (KIND == 1 ? reinterpret_cast<const ST *>(src.c32) : reinterpret_cast<const ST *>(src.c64));
+  const size_t cap_stride = KIND == 0 ? lcs_cap8_stride(src.n_cap) : (size_t)src.n_cap;
   const int n = *n_fix;
-  const int n_lag = 2 * geo.ds + 1;
-  for (int e = blockIdx.x * REPAIR_WAVES + wv; e < n; e += gridDim.x * REPAIR_WAVES) {
+  const int n_lag = 2 * geo.ds + 1, span = 137 + n_lag - 1;
+  for (int e = blockIdx.x * WAVES + wv; e < n; e += gridDim.x * WAVES) {
     const unsigned pos = fix_list[e];
     const int idx = (int)(pos % LCS_N_IDX), t = (int)((pos / LCS_N_IDX) % 3), slot = (int)(pos / (3 * LCS_N_IDX));
     const float *sgs = sg + (size_t)slot * geo.G * LCS_N_IDX * LCS_TG;
     const SlotParams p = params[slot];
-    const CapView cap = cap_view(src, slot);
+    const ST *cap = capbase + (size_t)slot * cap_stride;
     // the values the collapse kernel compared (same expression, same rounding), lane f and f + 64
     const float x0 = lane < geo.n_f ? repair_gpu_value(sgs, geo, 3 * lane + t, idx) : -INFINITY;
     const float x1 = lane + 64 < geo.n_f ? repair_gpu_value(sgs, geo, 3 * (lane + 64) + t, idx) : -INFINITY;
@@ -829,35 +849,66 @@ __global__ __launch_bounds__(REPAIR_WAVES * 64) void k_frq_repair(const float *_
           double sn, cs;
           sincos(k * (double)mm, &sn, &cs);
           const double2 s = pss_td[t * 137 + mm];
-          s_tmpl[wv][mm] = make_double2((s.x * cs - s.y * sn) / 137, -(s.x * sn + s.y * cs) / 137);
+          s_tmpl[mm] = make_double2((s.x * cs - s.y * sn) / 137, -(s.x * sn + s.y * cs) / 137);
+        }
+        const int *st = start + ((size_t)slot * LCS_NW_MAX) * LCS_NF_MAX + f;
+        {
+          // lane -> sample o of window w, eight loads in flight per lane.  Sample o of window w is what the positions idx - arm ..
+          // idx + arm read at tap o - lag: position (idx - arm + o), circular in 9600 for the LAG part only (ref :336) -- a window whose
+          // lags wrap is staged lag by lag below instead
+          const int n_it = geo.n_comb * span;
+          for (int i0 = lane; i0 < n_it; i0 += 64 * 8) {
+            ST v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              const int i = min(i0 + 64 * u, n_it - 1), w = i / span, o = i - w * span;
+              v[u] = cap[(size_t)(idx - geo.ds + o + (idx - geo.ds < 0 ? LCS_N_IDX : 0)) + (size_t)st[(size_t)w * LCS_NF_MAX]];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              const int i = i0 + 64 * u, w = i / span, o = i - w * span;
+              if (i < n_it) s_smp[w][o] = v[u];
+            }
+          }
         }
         lcs_wave_sync();
         for (int it = lane; it < n_lag * geo.n_comb; it += 64) {         // (lag, window): one 137-tap correlation each
           const int l = it / geo.n_comb, w = it - l * geo.n_comb;
-          int ii = idx + l - geo.ds;
-          ii = ii < 0 ? ii + LCS_N_IDX : (ii >= LCS_N_IDX ? ii - LCS_N_IDX : ii);
-          const size_t k0 = (size_t)ii + (size_t)start[((size_t)slot * LCS_NW_MAX + w) * LCS_NF_MAX + f];
           double ar = 0, ai = 0;
-          for (int mm = 0; mm < 137; ++mm) {
-            const double2 a = s_tmpl[wv][mm], b = cap_at(cap, k0 + mm);
-            ar += a.x * b.x - a.y * b.y;
-            ai += a.x * b.y + a.y * b.x;
+          const int ii = idx + l - geo.ds;                               // this lag's position before the circular wrap
+          const bool staged = (idx - geo.ds < 0) ? (ii < 0) : (ii < LCS_N_IDX);      // the run staged above covers the un-wrapped (or all-wrapped-low) lags
+          if (staged) {
+            const ST *x = &s_smp[w][l];
+#pragma unroll 8
+            for (int mm = 0; mm < 137; ++mm) {           // (the LDS reads of eight taps in flight; the sums stay in tap order)
+              const double2 a = s_tmpl[mm], b = RepairSample<KIND>::cvt(x[mm]);
+              ar += a.x * b.x - a.y * b.y;
+              ai += a.x * b.y + a.y * b.x;
+            }
+          } else {                                       // the few lags on the other side of the wrap: straight from memory
+            const int iw = ii < 0 ? ii + LCS_N_IDX : (ii >= LCS_N_IDX ? ii - LCS_N_IDX : ii);
+            const size_t k0 = (size_t)iw + (size_t)st[(size_t)w * LCS_NF_MAX];
+            for (int mm = 0; mm < 137; ++mm) {
+              const double2 a = s_tmpl[mm], b = RepairSample<KIND>::cvt(cap[k0 + mm]);
+              ar += a.x * b.x - a.y * b.y;
+              ai += a.x * b.y + a.y * b.x;
+            }
           }
           const float fr = (float)ar, fi = (float)ai;                    // xc is complex<float>
-          s_sq[wv][it] = (double)fr * (double)fr + (double)fi * (double)fi;
+          s_sq[it] = (double)fr * (double)fr + (double)fi * (double)fi;
         }
         lcs_wave_sync();
         if (lane < n_lag) {                                              // the float running sum over the windows, in window order
           float o = 0.f;
-          for (int w = 0; w < geo.n_comb; ++w) o = (float)((double)o + s_sq[wv][lane * geo.n_comb + w]);
-          s_lag[wv][lane] = __fdiv_rn(o, (float)geo.n_comb);
+          for (int w = 0; w < geo.n_comb; ++w) o = (float)((double)o + s_sq[lane * geo.n_comb + w]);
+          s_lag[lane] = __fdiv_rn(o, (float)geo.n_comb);
         }
         lcs_wave_sync();
-        float v = s_lag[wv][geo.ds];
-        for (int d = 1; d <= geo.ds; ++d) v = v + (s_lag[wv][geo.ds - d] + s_lag[wv][geo.ds + d]);
+        float v = s_lag[geo.ds];
+        for (int d = 1; d <= geo.ds; ++d) v = v + (s_lag[geo.ds - d] + s_lag[geo.ds + d]);
         v = __fdiv_rn(v, (float)n_lag);
         if (v > best) { best = v; best_f = f; }                          // strict: the lowest index wins a tie (ref :374)
-        lcs_wave_sync();                                                 // s_tmpl / s_sq / s_lag are rewritten by the next candidate
+        lcs_wave_sync();                                                 // the LDS arrays are rewritten by the next candidate
       }
     }
     if (lane == 0) {
@@ -996,9 +1047,16 @@ int lcs_launch_xcorr(lcs_ctx *c, int n_buf, const XcGeom &geo, bool want_incoh, 
     else if (!incoh) hipLaunchKernelGGL((k_collapse<-1, false>), grid, block, 0, c->stream, c->single, incoh, c->pow_, pow32, c->frq, c->fix_list, c->n_fix, geo, n_buf);   // any arm, no debug copy
     else hipLaunchKernelGGL((k_collapse<-1, true>), grid, block, 0, c->stream, c->single, incoh, c->pow_, pow32, c->frq, c->fix_list, c->n_fix, geo, n_buf);
     // near-ties of the arg-max, recomputed in the reference's arithmetic (a few positions per buffer; the kernel loops over the list)
-    if (!c->skip_frq_repair)
-    hipLaunchKernelGGL(k_frq_repair, dim3(std::min(256, 8 * n_buf)), dim3(REPAIR_WAVES * 64), 0, c->stream, c->single, c->fix_list, c->n_fix,
-                       lcs_cap_src(c, geo.n_cap), c->params, c->fset, c->d_pss_td, c->start, c->pow_, pow32, c->frq, geo);
+    if (!c->skip_frq_repair) {
+      const CapSrc cs = lcs_cap_src(c, geo.n_cap);
+      const int ng = std::min(256, 4 * n_buf);
+#define REPAIR_LAUNCH(KIND, WAVES) hipLaunchKernelGGL((k_frq_repair<KIND, WAVES>), dim3(ng * 4 / WAVES), dim3(64 * WAVES), 0, c->stream, c->single, c->fix_list, \
+                                                      c->n_fix, cs, c->params, c->fset, c->d_pss_td, c->start, c->pow_, pow32, c->frq, geo)
+      if (cs.c8) REPAIR_LAUNCH(0, 4);
+      else if (cs.c32) REPAIR_LAUNCH(1, 2);
+      else REPAIR_LAUNCH(2, 1);
+#undef REPAIR_LAUNCH
+    }
   }
   HIPCHK(c, hipGetLastError());
   return LCS_OK;

@@ -24,19 +24,8 @@
 #define MAX_HF 20
 #define FS_LTE 30720000.0
 
-struct cd2 { double re, im; };
-__device__ __forceinline__ cd2 mk(double a, double b) { cd2 r; r.re = a; r.im = b; return r; }
-// exp(j x): one sincos call (one argument reduction; cos(x) and sin(x) as two calls cost 1.8 x the instructions)
-__device__ __forceinline__ cd2 cis(double x) { double s_, c_; sincos(x, &s_, &c_); return mk(c_, s_); }
-__device__ __forceinline__ cd2 cadd(cd2 a, cd2 b) { return mk(a.re + b.re, a.im + b.im); }
-__device__ __forceinline__ cd2 csub(cd2 a, cd2 b) { return mk(a.re - b.re, a.im - b.im); }
-__device__ __forceinline__ cd2 cmul(cd2 a, cd2 b) { return mk(a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re); }
-__device__ __forceinline__ cd2 cconj(cd2 a) { return mk(a.re, -a.im); }
-__device__ __forceinline__ cd2 cscale(cd2 a, double s) { return mk(a.re * s, a.im * s); }
-__device__ __forceinline__ cd2 cdivr(cd2 a, double s) { return mk(a.re / s, a.im / s); }
-__device__ __forceinline__ double cabs2(cd2 a) { return a.re * a.re + a.im * a.im; }
+#include "lte_device.h"
 
-__device__ __forceinline__ int d_round_i(double x) { return (int)rint(x); }
 __device__ __forceinline__ int d_floor_i(double x) { return (int)floor(x); }
 __device__ __forceinline__ double d_matlab_mod(double k, double n) { return (n == 0) ? k : (k - n * d_floor_i(k / n)); }
 __device__ __forceinline__ double d_wrap(double x, double sm, double lg) { return d_matlab_mod(x - sm, lg - sm) + sm; }
@@ -55,47 +44,73 @@ __device__ __forceinline__ int d_range_len(double first, double incr, double las
 #define SW_REC 376
 #define SW_ITEM ((size_t)MAX_HF * SW_REC)
 
-// Twiddles exp(-j 2 pi m / 128) for the workgroup.
-__device__ __forceinline__ void fill_twiddles(cd2 *W, int tid) {
-  if (tid < 128) { double s, c; sincospi((double)tid / 64.0, &s, &c); W[tid] = mk(c, -s); }
-}
-
-// capbuf.mid(loc,128) -> fshift(., foc_freq, fs) -> rotate left by 2 (ref :523-525), one sample
-__device__ __forceinline__ cd2 stage_sample(const CapView &cap, uint32_t n_cap, long loc, double k, int n) {
-  const int t = (n + 2) & 127;
-  const long src = loc + t;
-  cd2 v = mk(0, 0);
-  if (src >= 0 && (uint64_t)src < n_cap) { const double2 c = cap_at(cap, (size_t)src); v = mk(c.x, c.y); }
-  double sn, cs;
-  sincos(k * (double)t, &sn, &cs);
-  return cmul(v, mk(cs, sn));
-}
-
-// 128-point transform of one staged window by ONE wave, in place (decimation in frequency: natural order in,
-// bit-reversed order out), one butterfly per lane and stage; tw[stg] = this lane's twiddle of stage stg, held in registers
-// (fft_twiddles).  Rounds 1-3 summed each of the 62 wanted bins directly (128 terms per bin, twiddles gathered from LDS at
-// strides that collide on the banks): 10 x the operations of the 7 stages.  No other wave touches the window and a wave's
-// LDS accesses execute in program order, so no workgroup barrier is needed between the stages.
-__device__ __forceinline__ void fft_twiddles(const cd2 *W, int lane, cd2 (&tw)[7]) {
+// ---- 128-sample windows of the synchronisation signals, eight per wave (round 5; lte_device.h: fft128_x8) -----------------
+// capbuf.mid(loc, 128) -> fshift(., foc_freq, fs) -> rotate left by 2 -> 128-point transform (ref :516-530): sample t of the
+// window, rotated by cis(k t), is input n = (t - 2) & 127 of the transform.  Lane (w, l) holds inputs n = l + 8 j, i.e. samples
+// t = (l + 2 + 8 j) & 127: cis(k t) = cis(k (l + 2)) cis(8 k j) -- one factor per lane and sixteen per window, which the
+// window's eight lanes compute two each and share through LDS -- except where t wraps (j = 15, l >= 6: t = l - 6).  Four
+// sincos per lane and 8 windows instead of sixteen (rounds 1-4: one per sample).
+template <int KIND>
+__device__ __forceinline__ void win_load16(const CapView &cap, long loc, int l, uint32_t n_cap, bool valid, cd2 (&x)[16]) {
+  uint16_t r8[16];
+  float2 r32[16];
+  unsigned in_mask = 0;
 #pragma unroll
-  for (int stg = 0; stg < 7; ++stg) tw[stg] = W[(lane & ((64 >> stg) - 1)) << stg];
-}
-__device__ __forceinline__ void fft128_wave(cd2 *x, const cd2 (&tw)[7], int lane) {
+  for (int j = 0; j < 16; ++j) {
+    const long sidx = loc + ((l + 2 + 8 * j) & 127);
+    const bool in = valid && sidx >= 0 && (uint64_t)sidx < n_cap;
+    const size_t ci = in ? (size_t)sidx : 0;
+    in_mask |= (in ? 1u : 0u) << j;
+    if (KIND == 0) r8[j] = cap.c8[ci];
+    else if (KIND == 1) r32[j] = cap.c32[ci];
+    else { const double2 v = cap.c64[ci]; x[j] = mk(v.x, v.y); }
+  }
 #pragma unroll
-  for (int stg = 0; stg < 7; ++stg) {
-    const int half = 64 >> stg;
-    const int pos = lane & (half - 1);
-    const int i0 = ((lane >> (6 - stg)) << (7 - stg)) + pos, i1 = i0 + half;
-    const cd2 a = x[i0], b = x[i1];
-    x[i0] = cadd(a, b);
-    x[i1] = cmul(csub(a, b), tw[stg]);
-    lcs_wave_sync();
+  for (int j = 0; j < 16; ++j) {
+    if (KIND == 0) { const uint32_t pr = r8[j]; x[j] = mk(-(double)(int)(int8_t)(pr & 255u) / 128.0, -(double)(int)(int8_t)(pr >> 8) / 128.0); }
+    else if (KIND == 1) x[j] = mk((double)r32[j].x, (double)r32[j].y);
+    if (!((in_mask >> j) & 1u)) x[j] = mk(0, 0);      // beyond the buffer: zeros (the reference's mid() would read out of bounds)
   }
 }
-// One of the 62 PSS/SSS bins [97..127, 1..31] of a transformed window, /sqrt(128) (ref :527-529)
-__device__ __forceinline__ cd2 fft62_bin(const cd2 *x, int bin_idx) {
-  const int bin = (bin_idx < 31) ? 97 + bin_idx : bin_idx - 30;
-  return cdivr(x[__brev((unsigned)bin) >> 25], sqrt(128.0));
+// trot: this wave's [8][16] table in LDS.  The factors are computed BEFORE the samples are loaded (four sincos expansions with
+// sixteen samples live beside them needed every register the wave can have).
+struct WinRot { cd2 cu, cw; };
+__device__ __forceinline__ WinRot win_rot_prepare(double k, int lane, cd2 *trot) {
+  const int w = lane >> 3, l = lane & 7;
+  WinRot r;
+  r.cu = cis(k * (double)(l + 2));
+  __builtin_amdgcn_sched_barrier(0);
+  r.cw = cis(k * (double)(l - 6));                       // the wrapped sample of lanes l >= 6
+  __builtin_amdgcn_sched_barrier(0);
+  trot[w * 16 + l + 1] = cis(k * (double)(8 * (l + 1)));
+  __builtin_amdgcn_sched_barrier(0);
+  if (l < 7) trot[w * 16 + l + 9] = cis(k * (double)(8 * (l + 9)));
+  lcs_wave_sync();
+  return r;
+}
+__device__ __forceinline__ void win_rotate16(cd2 (&x)[16], const WinRot &r, int lane, const cd2 *trot) {
+  const int w = lane >> 3, l = lane & 7;
+  x[0] = cmul(x[0], r.cu);
+#pragma unroll
+  for (int j = 1; j < 15; ++j) x[j] = cmul(x[j], cmul(r.cu, trot[w * 16 + j]));
+  x[15] = cmul(x[15], (l >= 6) ? r.cw : cmul(r.cu, trot[w * 16 + 15]));
+  lcs_wave_sync();                                       // trot is rewritten by the wave's next job
+}
+// the 62 PSS / SSS bins [97..127, 1..31] among this lane's sixteen outputs X[(l + 8 c) + 16 k1] = x[8 c + k1]: index 0..61 or -1
+__device__ __forceinline__ int win_bin62(int l, int q) {
+  const int bin = (l + 8 * (q >> 3)) + 16 * (q & 7);
+  return (bin >= 97) ? bin - 97 : ((bin >= 1 && bin <= 31) ? bin + 30 : -1);
+}
+__device__ __forceinline__ void win_fft8(const CapView &cap, long loc, bool valid, double k, uint32_t n_cap, int lane, cd2 *tb, const cd2 *tw,
+                                         cd2 *trot, cd2 (&x)[16]) {
+  const int l = lane & 7;
+  const WinRot r = win_rot_prepare(k, lane, trot);
+  __builtin_amdgcn_sched_barrier(0);                     // the sample loads stay behind the sincos expansions
+  if (cap.c8) win_load16<0>(cap, loc, l, n_cap, valid, x);
+  else if (cap.c32) win_load16<1>(cap, loc, l, n_cap, valid, x);
+  else win_load16<2>(cap, loc, l, n_cap, valid, x);
+  win_rotate16(x, r, lane, trot);
+  fft128_x8(x, tb, tw, lane);
 }
 
 // h_raw -> h_sm (13-tap mean, ref :584-588) for subcarrier t
@@ -180,57 +195,70 @@ __device__ __forceinline__ SssGeo sss_geometry(const lcs_cell &cell, const SlotP
   return g;
 }
 
-#define SW_THREADS 192
+// One wave per workgroup; a job = TWO occurrences (k = 2 m, 2 m + 1) of one peak = 6 windows (window slot w: occurrence w / 3;
+// kind w % 3 = PSS window, extended-CP SSS window, normal-CP SSS window, ref :578-597); slots 6, 7 idle.
+#define SW_WAVES 4           // independent waves per workgroup (a workgroup then fills the slot of the correlation workgroup it displaces)
+#define SW_THREADS (64 * SW_WAVES)
+#define SW_PAIRS (MAX_HF / 2)
 __global__ __launch_bounds__(SW_THREADS) void k_sss_win(const lcs_cell *__restrict__ peaks, const int *__restrict__ npeaks, int n_buf,
                                                         WorkItem *__restrict__ items, int *__restrict__ n_items,
                                                         const CapSrc src,
                                                         uint32_t n_cap, const SlotParams *__restrict__ params,
                                                         const double2 *__restrict__ pss_fd, double *__restrict__ ws) {
   LCS_TAIL_PRIO();
-  __shared__ cd2 W[128];
-  __shared__ cd2 win[3][128];
-  __shared__ cd2 h_raw[62], h_sm[62];
-  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-  fill_twiddles(W, tid);
+  __shared__ cd2 tw[128];
+  __shared__ cd2 tb_all[SW_WAVES][8 * FFT128_WSTRIDE];
+  const int lane = threadIdx.x & 63, w = lane >> 3, l = lane & 7;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // wave-uniform, and the compiler is told so: the job's records load into SGPRs
+  // a wave's transpose buffer also holds its rotation table (before the transform) and the PSS channel estimates (after it)
+  cd2 *tb = tb_all[wv], *trot = tb;
+  cd2 (*h_raw)[62] = reinterpret_cast<cd2 (*)[62]>(tb), (*h_sm)[62] = reinterpret_cast<cd2 (*)[62]>(tb + 2 * 62);
+  static_assert(4 * 62 <= 8 * FFT128_WSTRIDE, "the estimates fit the transpose buffer");
+  fft128_twiddle_table(tw, threadIdx.x, SW_THREADS);
   __syncthreads();
-  cd2 tw[7];
-  fft_twiddles(W, lane, tw);
   // the work list: numbered here from the per-buffer counts; workgroup 0 also writes it out for the kernels that follow
-  if (blockIdx.x == 0 && w == 0) peak_list_write(npeaks, n_buf, items, n_items, lane);
-  const int n_jobs = peak_total(npeaks, n_buf, lane) * MAX_HF;
-  for (int job = blockIdx.x; job < n_jobs; job += gridDim.x) {
-    const int it = job / MAX_HF, k = job % MAX_HF;
+  if (blockIdx.x == 0 && wv == 0) peak_list_write(npeaks, n_buf, items, n_items, lane);
+  const int n_jobs = peak_total(npeaks, n_buf, lane) * SW_PAIRS;
+  for (int job = blockIdx.x * SW_WAVES + wv; job < n_jobs; job += gridDim.x * SW_WAVES) {
+    const int it = job / SW_PAIRS, k0 = 2 * (job % SW_PAIRS);
     const WorkItem wi = peak_lookup(npeaks, n_buf, it, lane);
-    const int slot = wi.slot;
-    const lcs_cell cell = peaks[(size_t)slot * LCS_MAXP + wi.peak];
+    const int slot = __builtin_amdgcn_readfirstlane(wi.slot), pk = __builtin_amdgcn_readfirstlane(wi.peak);
+    const lcs_cell cell = peaks[(size_t)slot * LCS_MAXP + pk];
     const SlotParams p = params[slot];
     const SssGeo g = sss_geometry(cell, p, n_cap);
-    if (k >= g.n_pss) continue;
+    if (k0 >= g.n_pss) continue;
     const CapView cap = cap_view(src, slot);
+    const int occ = w / 3, kind = w - 3 * occ, k = k0 + occ;
+    const bool valid = w < 6 && k < g.n_pss;
+    const uint32_t pss_loc = (uint32_t)d_round_i(g.peak_loc + k * (g.k_factor * 9600));
+    const long pss_dft = (long)(pss_loc + 9 - 2);
+    const long loc = (kind == 0) ? pss_dft : (kind == 1 ? pss_dft - 128 - 32 : pss_dft - 128 - 9);
+    cd2 x[16];
+    win_fft8(cap, loc, valid, g.kph, n_cap, lane, tb, tw, trot, x);
     double *rec = ws + (size_t)it * SW_ITEM + (size_t)k * SW_REC;
-    __syncthreads();
-    {   // the PSS window, the extended-CP SSS window and the normal-CP SSS window (ref :578-597)
-      const uint32_t pss_loc = (uint32_t)d_round_i(g.peak_loc + k * (g.k_factor * 9600));
-      const long pss_dft = (long)(pss_loc + 9 - 2);
-      const long loc = (w == 0) ? pss_dft : (w == 1 ? pss_dft - 128 - 32 : pss_dft - 128 - 9);
-      win[w][lane] = stage_sample(cap, n_cap, loc, g.kph, lane);
-      win[w][lane + 64] = stage_sample(cap, n_cap, loc, g.kph, lane + 64);
+    if (valid) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int b = win_bin62(l, q);
+        if (b < 0) continue;
+        const cd2 o = cdivr(x[q], sqrt(128.0));                         // /sqrt(128) (ref :527-529)
+        if (kind == 0) { const double2 f = pss_fd[cell.n_id_2 * 62 + b]; h_raw[occ][b] = cmul(o, mk(f.x, -f.y)); }
+        else { rec[(kind == 1 ? SW_EXT : SW_NRM) + 2 * b] = o.re; rec[(kind == 1 ? SW_EXT : SW_NRM) + 2 * b + 1] = o.im; }
+      }
     }
-    lcs_wave_sync();          // wave w staged window w itself
-    fft128_wave(win[w], tw, lane);
-    if (lane < 62) {
-      const cd2 o = fft62_bin(win[w], lane);
-      if (w == 0) { const double2 f = pss_fd[cell.n_id_2 * 62 + lane]; h_raw[lane] = cmul(o, mk(f.x, -f.y)); }
-      else { rec[(w == 1 ? SW_EXT : SW_NRM) + 2 * lane] = o.re; rec[(w == 1 ? SW_EXT : SW_NRM) + 2 * lane + 1] = o.im; }
+    lcs_wave_sync();
+    for (int o2 = 0; o2 < 2; ++o2) {
+      if (k0 + o2 >= g.n_pss) break;
+      double *r2 = ws + (size_t)it * SW_ITEM + (size_t)(k0 + o2) * SW_REC;
+      if (lane < 62) {
+        const cd2 v = smooth13(h_raw[o2], lane);
+        h_sm[o2][lane] = v;
+        r2[SW_HSM + 2 * lane] = v.re; r2[SW_HSM + 2 * lane + 1] = v.im;
+      }
     }
-    __syncthreads();
-    if (tid < 62) {
-      const cd2 v = smooth13(h_raw, tid);
-      h_sm[tid] = v;
-      rec[SW_HSM + 2 * tid] = v.re; rec[SW_HSM + 2 * tid + 1] = v.im;
-    }
-    __syncthreads();
-    if (tid == 0) rec[SW_NP] = noise_power(h_sm, h_raw);
+    lcs_wave_sync();
+    if (lane < 2 && k0 + lane < g.n_pss) ws[(size_t)it * SW_ITEM + (size_t)(k0 + lane) * SW_REC + SW_NP] = noise_power(h_sm[lane], h_raw[lane]);
+    lcs_wave_sync();                                     // the buffer is rewritten by the wave's next job
   }
 }
 
@@ -389,7 +417,11 @@ __device__ __forceinline__ FoeGeo foe_geometry(const lcs_cell &cell, const SlotP
   return g;
 }
 
-#define FW_THREADS 128
+// One wave per workgroup; a job = FOUR occurrences of one peak = 8 windows (window slot w: occurrence w >> 1; w & 1 = 0: the
+// PSS window, 1: the SSS window in front of it, ref :803-845).
+#define FW_WAVES 4
+#define FW_THREADS (64 * FW_WAVES)
+#define FW_QUADS (MAX_HF / 4)
 __global__ __launch_bounds__(FW_THREADS) void k_foe_win(const lcs_cell *__restrict__ peaks, const WorkItem *__restrict__ items,
                                                         const int *__restrict__ n_items,
                                                         const CapSrc src,
@@ -397,62 +429,68 @@ __global__ __launch_bounds__(FW_THREADS) void k_foe_win(const lcs_cell *__restri
                                                         const double2 *__restrict__ pss_fd, const int8_t *__restrict__ sss_fd,
                                                         double *__restrict__ ws) {
   LCS_TAIL_PRIO();
-  __shared__ cd2 W[128];
-  __shared__ cd2 win[2][128];
-  __shared__ cd2 h_raw[62], h_sm[62], aux[62];
-  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-  fill_twiddles(W, tid);
+  __shared__ cd2 tw[128];
+  __shared__ cd2 tb_all[FW_WAVES][8 * FFT128_WSTRIDE];
+  const int lane = threadIdx.x & 63, w = lane >> 3, l = lane & 7;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // wave-uniform, and the compiler is told so: the job's records load into SGPRs
+  __shared__ cd2 h_sm_all[FW_WAVES][4][62];
+  cd2 *tb = tb_all[wv], *trot = tb;                      // (the buffer also holds the rotation table before and the estimates after the transform)
+  cd2 (*h_raw)[62] = reinterpret_cast<cd2 (*)[62]>(tb), (*aux)[62] = reinterpret_cast<cd2 (*)[62]>(tb + 4 * 62), (*h_sm)[62] = h_sm_all[wv];
+  static_assert(8 * 62 <= 8 * FFT128_WSTRIDE && 8 * 16 <= 8 * FFT128_WSTRIDE, "the estimates / the rotation table fit the transpose buffer");
+  fft128_twiddle_table(tw, threadIdx.x, FW_THREADS);
   __syncthreads();
-  cd2 tw[7];
-  fft_twiddles(W, lane, tw);
-  const int n_jobs = *n_items * MAX_HF;
-  for (int job = blockIdx.x; job < n_jobs; job += gridDim.x) {
-    const int it = job / MAX_HF, k = job % MAX_HF;
+  const int n_jobs = *n_items * FW_QUADS;
+  for (int job = blockIdx.x * FW_WAVES + wv; job < n_jobs; job += gridDim.x * FW_WAVES) {
+    const int it = job / FW_QUADS, k0 = 4 * (job % FW_QUADS);
     const int slot = items[it].slot;
     const lcs_cell cell = peaks[(size_t)slot * LCS_MAXP + items[it].peak];
     const SlotParams p = params[slot];
     const FoeGeo g = foe_geometry(cell, p, n_cap);
-    if (!g.ok || k >= g.n_sss) continue;
+    if (!g.ok || k0 >= g.n_sss) continue;
     const CapView cap = cap_view(src, slot);
-    double *rec = ws + (size_t)it * SW_ITEM + (size_t)k * SW_REC;
-    __syncthreads();
-    {
-      const uint32_t sss_loc = (uint32_t)d_round_i(g.first_sss + k * g.step);
-      const long loc = (w == 0) ? (long)(sss_loc + g.pss_sss_dist) : (long)sss_loc;
-      win[w][lane] = stage_sample(cap, n_cap, loc, g.kph, lane);
-      win[w][lane + 64] = stage_sample(cap, n_cap, loc, g.kph, lane + 64);
-    }
-    lcs_wave_sync();          // wave w staged window w itself
-    fft128_wave(win[w], tw, lane);
-    if (lane < 62) {
-      const cd2 o = fft62_bin(win[w], lane);
-      if (w == 0) { const double2 f = pss_fd[cell.n_id_2 * 62 + lane]; h_raw[lane] = cmul(o, mk(f.x, -f.y)); }
-      else {
-        // exp(J*pi*-freq/(FS_LTE/16/2)*-pss_sss_dist), evaluated left to right (ref :832)
-        double ph_im = M_PI;
-        ph_im = ph_im * (-cell.freq);
-        ph_im = ph_im / (FS_LTE / 16 / 2);
-        ph_im = ph_im * (double)(-g.pss_sss_dist);
-        const cd2 ph = cis(ph_im);
-        // the slot number toggles with every occurrence, starting from sn_init (ref :800, :813)
-        const int sn = ((k & 1) == 0) ? g.sn_init : 10 - g.sn_init;
-        const double sf = (double)sss_fd[((cell.n_id_1 * 3 + cell.n_id_2) * 2 + (sn != 0)) * 62 + lane];
-        aux[lane] = cmul(cmul(o, ph), mk(sf, 0));
+    const int occ = w >> 1, is_sss = w & 1, k = k0 + occ;
+    const bool valid = k < g.n_sss;
+    const uint32_t sss_loc = (uint32_t)d_round_i(g.first_sss + k * g.step);
+    const long loc = is_sss ? (long)sss_loc : (long)(sss_loc + g.pss_sss_dist);
+    cd2 x[16];
+    win_fft8(cap, loc, valid, g.kph, n_cap, lane, tb, tw, trot, x);
+    if (valid) {
+      // exp(J*pi*-freq/(FS_LTE/16/2)*-pss_sss_dist), evaluated left to right (ref :832)
+      double ph_im = M_PI;
+      ph_im = ph_im * (-cell.freq);
+      ph_im = ph_im / (FS_LTE / 16 / 2);
+      ph_im = ph_im * (double)(-g.pss_sss_dist);
+      const cd2 ph = cis(ph_im);
+      // the slot number toggles with every occurrence, starting from sn_init (ref :800, :813)
+      const int sn = ((k & 1) == 0) ? g.sn_init : 10 - g.sn_init;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int b = win_bin62(l, q);
+        if (b < 0) continue;
+        const cd2 o = cdivr(x[q], sqrt(128.0));
+        if (!is_sss) { const double2 f = pss_fd[cell.n_id_2 * 62 + b]; h_raw[occ][b] = cmul(o, mk(f.x, -f.y)); }
+        else {
+          const double sf = (double)sss_fd[((cell.n_id_1 * 3 + cell.n_id_2) * 2 + (sn != 0)) * 62 + b];
+          aux[occ][b] = cmul(cmul(o, ph), mk(sf, 0));
+        }
       }
     }
-    __syncthreads();
-    if (tid < 62) h_sm[tid] = smooth13(h_raw, tid);
-    __syncthreads();
-    if (tid == 0) {     // sum over the 62 subcarriers, in subcarrier order (ref :836-843)
-      const double np = noise_power(h_sm, h_raw);
+    lcs_wave_sync();
+    for (int o2 = 0; o2 < 4; ++o2)
+      if (k0 + o2 < g.n_sss && lane < 62) h_sm[o2][lane] = smooth13(h_raw[o2], lane);
+    lcs_wave_sync();
+    if (lane < 4 && k0 + lane < g.n_sss) {     // sum over the 62 subcarriers, in subcarrier order (ref :836-843)
+      const double np = noise_power(h_sm[lane], h_raw[lane]);
       cd2 acc = mk(0, 0);
       for (int t = 0; t < 62; ++t) {
-        const double a2 = cabs2(h_sm[t]);
+        const double a2 = cabs2(h_sm[lane][t]);
         const double wgt = a2 * (1.0 / (2 * a2 * np + np * np));
-        acc = cadd(acc, cmul(cmul(cconj(aux[t]), h_raw[t]), mk(wgt, 0)));
+        acc = cadd(acc, cmul(cmul(cconj(aux[lane][t]), h_raw[lane][t]), mk(wgt, 0)));
       }
+      double *rec = ws + (size_t)it * SW_ITEM + (size_t)(k0 + lane) * SW_REC;
       rec[SW_ACC] = acc.re; rec[SW_ACC + 1] = acc.im;
     }
+    lcs_wave_sync();                                     // the buffer is rewritten by the next job
   }
 }
 
@@ -491,7 +529,7 @@ static int run_sss_foe(lcs_ctx *c, int n_buf, uint32_t n_cap, double thresh2, in
   const CapSrc src = lcs_cap_src(c, n_cap);
   // enough workgroups for every (peak, occurrence) of a typical batch to be resident at once; the
   // kernels loop over the work list, so larger batches only take more rounds
-  const int win_grid = (int)std::min<size_t>(cap_items * MAX_HF, LCS_WIN_GRID);
+  const int win_grid = (int)std::min<size_t>((cap_items * (MAX_HF / 2) + 3) / 4, LCS_WIN_GRID);      // four jobs in flight per workgroup
   const int item_grid = (int)std::min<size_t>(cap_items, LCS_ITEM_GRID);
   if (!(mode & 1)) hipLaunchKernelGGL(k_peak_list, dim3(1), dim3(64), 0, c->stream, c->npeaks, n_buf, c->pk_items, c->n_pk);
   if (mode & 1) {

@@ -136,7 +136,7 @@ __global__ __launch_bounds__(64) void k_pack_results(const lcs_cell *__restrict_
 // ------------------------------------------------------------ extract_tfg: timestamps
 // ref :875-889 and the running dft_location of :903-920 (kept sequential: each timestamp is a
 // floating-point running sum).  One thread per cell.
-__device__ void tfg_timestamps(const lcs_cell &c, const SlotParams &p, double *t_out, double *sc) {
+__device__ void tfg_timestamps(const lcs_cell &c, const SlotParams &p, double *t_out, double *t_lds, double *sc) {
   const double k_factor = (p.fc_req - c.freq_fine) / p.fc_prog;
   const int n_symb = cell_n_symb(c);
   double loc;
@@ -151,12 +151,12 @@ __device__ void tfg_timestamps(const lcs_cell &c, const SlotParams &p, double *t
   if (n_symb == 6) {
     for (int sl = 0; sl < n_ofdm / 6; ++sl) {
 #pragma unroll
-      for (int q = 0; q < 6; ++q) { t_out[sl * 6 + q] = loc; loc += inc_ext; }
+      for (int q = 0; q < 6; ++q) { t_out[sl * 6 + q] = loc; t_lds[sl * 6 + q] = loc; loc += inc_ext; }
     }
   } else {
     for (int sl = 0; sl < n_ofdm / 7; ++sl) {
 #pragma unroll
-      for (int q = 0; q < 7; ++q) { t_out[sl * 7 + q] = loc; loc += (q == 6) ? inc_10 : inc_9; }
+      for (int q = 0; q < 7; ++q) { t_out[sl * 7 + q] = loc; t_lds[sl * 7 + q] = loc; loc += (q == 6) ? inc_10 : inc_9; }
     }
   }
   sc[CS_N_OFDM] = (double)n_ofdm;
@@ -169,16 +169,69 @@ __device__ void tfg_timestamps(const lcs_cell &c, const SlotParams &p, double *t
 // cell's CRS table RS_DL (mode bit 1,
 // ref src/lte_lib.cpp:305-383: values for the 6 centre RBs and the per-port frequency shifts of
 // every (slot, symbol) that carries RS, one Gold sequence per lane).
+// Round 5: wave 1 then also writes what a DFT window of k_tfg needs, one 32-byte record per window in the ORDER k_tfg takes
+// them (TfgRow: the grid row, its ideal timestamp, and the frequency correction's factor for the window's first sample):
+// extract_tfg rotates sample i of the buffer by cis(pi kk i), kk = -freq_fine / (fs / 2) (fshift, ref :892, dsp.h:40-53); for
+// sample loc + n of a window that is cis(pi kk loc) cis(pi kk n) -- one factor per window and one per position (128 per
+// cell, behind the records): 982 sincospi per cell here instead of one per sample in k_tfg (49 k per cell).
+struct TfgRow { double2 rot; double ideal; int row; int pad; };
+#define TFG_NDESC 856                                    // 107 jobs x 8 windows >= ROWS
+#define TFG_DESC_BYTES LCS_TFG_DESC_BYTES
+static_assert(sizeof(TfgRow) == 32 && TFG_DESC_BYTES == TFG_NDESC * 32 + 128 * 16, "descriptor block layout (lcs_internal.h)");
+// The k-th row of the grid that the fused chain ever reads (tfg_row_needed below) -- slots carry 3 such rows, the PBCH slot of a
+// frame 5 (normal CP) or 4 -- or -1 past the last one.
+__device__ __forceinline__ int tfg_needed_row(int k, int n_symb, int n_ofdm) {
+  const int extra = (n_symb == 7) ? 2 : 1, per_frame = 60 + extra;
+  const int fr = k / per_frame, r = k - fr * per_frame;
+  int slot, q;                                           // q-th needed row of the slot
+  if (r < 3) { slot = 0; q = r; }
+  else if (r < 6 + extra) { slot = 1; q = r - 3; }
+  else { slot = 2 + (r - 6 - extra) / 3; q = (r - 6 - extra) % 3; }
+  int sym;
+  if (slot == 1) sym = q;                                // 0, 1, 2, 3 (, 4): n_symb - 3 is the last of them
+  else sym = (q == 2) ? n_symb - 3 : q;
+  const int row = (fr * 20 + slot) * n_symb + sym;
+  return row < n_ofdm ? row : -1;
+}
 __global__ __launch_bounds__(128) void k_cell_prep(const lcs_cell *__restrict__ cells, const WorkItem *__restrict__ items,
                                                   const int *__restrict__ n_work, const SlotParams *__restrict__ params,
                                                   const uint32_t *__restrict__ pn_jump, double *__restrict__ ts,
-                                                  double *__restrict__ scratch, int mode) {
+                                                  double *__restrict__ scratch, char *__restrict__ desc, int mode, int needed_only) {
   LCS_TAIL_PRIO();
+  __shared__ double s_ts[ROWS];
   const int tid = threadIdx.x;
   for (int it = blockIdx.x; it < *n_work; it += gridDim.x) {
     const lcs_cell c = cells[it];
     double *sc = scratch + (size_t)it * CS_SIZE;
-    if ((mode & 1) && tid == 64) tfg_timestamps(c, params[items[it].slot], ts + (size_t)it * ROWS, sc);
+    if ((mode & 1) && tid >= 64) {
+      const SlotParams p = params[items[it].slot];
+      if (tid == 64) tfg_timestamps(c, p, ts + (size_t)it * ROWS, s_ts, sc);
+      lcs_wave_sync();                                  // lane 0 of this wave wrote s_ts
+      const int n_symb = cell_n_symb(c);
+      const int n_ofdm = 6 * 10 * 2 * n_symb + 2 * n_symb;
+      const double k_factor = (p.fc_req - c.freq_fine) / p.fc_prog;
+      // fshift phase pi * (-f) / (fs/2) * n (ref dsp.h:40-53) as sincospi((-f)/(fs/2) * n): the absolute
+      // sample index reaches 153600, far into the slow argument-reduction path of sincos
+      const double kk = (-c.freq_fine) / ((p.fs_prog * k_factor) / 2);
+      TfgRow *rd = reinterpret_cast<TfgRow *>(desc + (size_t)it * TFG_DESC_BYTES);
+      double2 *pos = reinterpret_cast<double2 *>(rd + TFG_NDESC);
+      for (int q = tid - 64; q < TFG_NDESC + 128; q += 64) {
+        double sn, cs;
+        if (q < TFG_NDESC) {
+          int row = needed_only ? tfg_needed_row(q, n_symb, n_ofdm) : q;
+          if (row >= n_ofdm) row = -1;
+          const double ideal = row >= 0 ? s_ts[row] : 0.0;
+          sincospi(kk * (double)d_round_i(ideal), &sn, &cs);
+          TfgRow r;
+          r.rot = make_double2(cs, sn); r.ideal = ideal; r.row = row; r.pad = 0;
+          rd[q] = r;
+        } else {
+          sincospi(kk * (double)(q - TFG_NDESC), &sn, &cs);
+          pos[q - TFG_NDESC] = make_double2(cs, sn);
+        }
+      }
+      lcs_wave_sync();                                  // s_ts is rewritten by the next item
+    }
     if (!(mode & 2)) continue;
     const int n_symb = cell_n_symb(c), id = cell_id(c);
     if (n_symb < 0 || id < 0) continue;
@@ -206,116 +259,112 @@ __device__ __forceinline__ bool tfg_row_needed(int t, int n_symb) {
 }
 
 // ------------------------------------------------------------------ extract_tfg: grid
-// 8 OFDM symbols per workgroup pass: frequency-correct 8x128 samples of the capture buffer into
-// LDS (the reference rotates all 153600 samples per cell, ref :892; only the 854x128 that feed a
-// DFT are touched here, with the same absolute-index phase), 128-point FFT, the 72 occupied bins
-// /sqrt(128), then the sub-sample timing phase ramp (ref :923-931).
-#define TFG_SYM 8            // 8 x 2 KB windows + twiddles = 18 KB of LDS
-#define TFG_THREADS 256     // 4 waves: wave v transforms windows v and v + 4, one radix-2 butterfly per lane and stage
-__global__ __launch_bounds__(TFG_THREADS) void k_tfg(const lcs_cell *__restrict__ cells, const WorkItem *__restrict__ items,
-                                                     const int *__restrict__ n_work, const SlotParams *__restrict__ params,
-                                                     const CapSrc src, uint32_t n_cap,
-                                                     const double *__restrict__ ts, double *__restrict__ scratch,
-                                                     double2 *__restrict__ tfg, int needed_only) {
+// One wave per workgroup, 8 OFDM symbols (DFT windows) per job: lane (w, l) loads the 16 samples l + 8 j of window w straight
+// from the capture buffer into registers, frequency-corrects them (the reference rotates all 153600 samples per cell, ref
+// :892; only the windows that feed a DFT are touched here, with the same absolute-index phase, factored per window and per
+// position by k_cell_prep), runs the register-resident 128-point transform (lte_device.h: fft128_x8), keeps the 72 occupied
+// bins / sqrt(128) and applies the sub-sample timing phase ramp (ref :923-931).  Rounds 1-4: the windows lived in LDS through
+// a fill pass and seven radix-2 stages (LDS-bound, and a sincospi per sample).  A job's dependent memory round trips are two:
+// its window records (k_cell_prep wrote them in job order) and the work item, then the samples.
+#define TFG_SYM 8
+#define TFG_WAVES 4          // four independent waves per workgroup: in the pipelined chain a workgroup of this kernel starts where a
+                             // correlation workgroup (4 waves, one per SIMD) retired -- as one-wave workgroups spread over the chip every
+                             // one of them kept a whole correlation slot empty for the sake of one SIMD (measured: step - 9 %)
+#define TFG_THREADS (64 * TFG_WAVES)
+template <int KIND>      // which copy of the capture buffer: 0 = int8 pairs (dongle bytes), 1 = complex<float>, 2 = complex<double>
+__device__ __forceinline__ void tfg_load16(const CapView &cap, long loc, int l, uint32_t n_cap, cd2 (&x)[16], bool &oob) {
+  // sixteen loads in flight in the source's own width, no branch between them; converted afterwards
+  uint16_t r8[16];
+  float2 r32[16];
+  unsigned in_mask = 0;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const long sidx = loc + l + 8 * j;
+    const bool in = sidx >= 0 && (uint64_t)sidx < n_cap;
+    const size_t ci = in ? (size_t)sidx : 0;
+    in_mask |= (in ? 1u : 0u) << j;
+    if (KIND == 0) r8[j] = cap.c8[ci];
+    else if (KIND == 1) r32[j] = cap.c32[ci];
+    else { const double2 v = cap.c64[ci]; x[j] = mk(v.x, v.y); }
+  }
+  oob |= in_mask != 0xffffu;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    if (KIND == 0) { const uint32_t pr = r8[j]; x[j] = mk(-(double)(int)(int8_t)(pr & 255u) / 128.0, -(double)(int)(int8_t)(pr >> 8) / 128.0); }
+    else if (KIND == 1) x[j] = mk((double)r32[j].x, (double)r32[j].y);
+    if (!((in_mask >> j) & 1u)) x[j] = mk(0, 0);
+  }
+}
+__global__ __launch_bounds__(TFG_THREADS) void k_tfg(const WorkItem *__restrict__ items, const int *__restrict__ n_work,
+                                                     const CapSrc src, uint32_t n_cap, double *__restrict__ scratch,
+                                                     const char *__restrict__ desc, double2 *__restrict__ tfg, int needed_only) {
   LCS_TAIL_PRIO();
-  __shared__ cd2 W[128];
-  __shared__ cd2 win[TFG_SYM][128];
-  __shared__ int s_loc[TFG_SYM], s_row[TFG_SYM];
-  const int tid = threadIdx.x;
-  if (tid < 128) { double s, c; sincospi((double)tid / 64.0, &s, &c); W[tid] = mk(c, -s); }
+  __shared__ cd2 tw[128];
+  __shared__ cd2 tb_all[TFG_WAVES][TFG_SYM * FFT128_WSTRIDE];
+  const int lane = threadIdx.x & 63, w = lane >> 3, l = lane & 7;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // wave-uniform, and the compiler is told so: the job's records load into SGPRs
+  cd2 *tb = tb_all[wv];
+  fft128_twiddle_table(tw, threadIdx.x, TFG_THREADS);
   __syncthreads();
-  // the seven twiddles of this lane's butterflies, in registers for every job (read per stage from the LDS table their
-  // power-of-two strides put up to 16 lanes of a group on one bank: the 3.2 conflict cycles per LDS instruction of
-  // profiles/r03/pmc_summary.json)
-  cd2 twr[7];
-#pragma unroll
-  for (int stg = 0; stg < 7; ++stg) twr[stg] = W[((tid & 63) & ((64 >> stg) - 1)) << stg];
   const int nw = *n_work;
-  // a job = 8 consecutive rows (full grid), or the needed rows of one slot pair (at most 5 + 3)
-  const int jobs_per_item = needed_only ? 61 : (ROWS + TFG_SYM - 1) / TFG_SYM;
-  for (int job = blockIdx.x; job < nw * jobs_per_item; job += gridDim.x) {
+  // a job = 8 consecutive rows (full grid), or 8 consecutive NEEDED rows (380 of the 854 with the normal CP: 48 jobs)
+  const int jobs_per_item = needed_only ? 48 : TFG_NDESC / TFG_SYM;
+  for (int job = blockIdx.x * TFG_WAVES + wv; job < nw * jobs_per_item; job += gridDim.x * TFG_WAVES) {
     const int it = job / jobs_per_item, jj = job % jobs_per_item;
-    double *sc = scratch + (size_t)it * CS_SIZE;
-    const int n_ofdm = (int)sc[CS_N_OFDM];
-    const double k_factor = sc[CS_KFACTOR];
-    const lcs_cell c = cells[it];
-    const SlotParams p = params[items[it].slot];
+    const TfgRow *rd = reinterpret_cast<const TfgRow *>(desc + (size_t)it * TFG_DESC_BYTES);
+    const double2 *pos = reinterpret_cast<const double2 *>(rd + TFG_NDESC);
+    const TfgRow d = rd[jj * TFG_SYM + w];
     const CapView cap = cap_view(src, items[it].slot);
-    const double *tsi = ts + (size_t)it * ROWS;
-    // fshift phase pi * (-f) / (fs/2) * n (ref dsp.h:40-53) as sincospi((-f)/(fs/2) * n): the absolute
-    // sample index reaches 153600, far into the slow argument-reduction path of sincos
-    const double kk = (-c.freq_fine) / ((p.fs_prog * k_factor) / 2);
-    __syncthreads();
     PH(30);
-    if (tid < TFG_SYM) {
-      int row = -1;
-      if (!needed_only) row = jj * TFG_SYM + tid;
-      else {            // the tid-th needed row of slots 2 jj, 2 jj + 1
-        const int n_symb = cell_n_symb(c), r0 = jj * 2 * n_symb;
-        int k = -1;
-        for (int r = 0; r < 2 * n_symb; ++r)
-          if (tfg_row_needed(r0 + r, n_symb) && ++k == tid) { row = r0 + r; break; }
+    const int row = d.row;
+    cd2 x[16];
+    bool oob = false;
+    const long loc = (long)d_round_i(d.ideal);
+    if (cap.c8) tfg_load16<0>(cap, loc, l, n_cap, x, oob);
+    else if (cap.c32) tfg_load16<1>(cap, loc, l, n_cap, x, oob);
+    else tfg_load16<2>(cap, loc, l, n_cap, x, oob);
+    if (row >= 0) {
+      // sample n = l + 8 j of the window is rotated by cis(pi kk (loc + n)): [window factor x position factor l] x position
+      // factor 8 j, the latter as P(8 (j & 3)) P(32 (j >> 2)) -- six table values (uniform: scalar loads) instead of sixteen
+      const cd2 c0 = cmul(mk(d.rot.x, d.rot.y), ld(&pos[l]));
+      const cd2 a1 = ld(&pos[8]), a2 = ld(&pos[16]), a3 = ld(&pos[24]);
+#pragma unroll
+      for (int jh = 0; jh < 4; ++jh) {
+        const cd2 ch = jh ? cmul(c0, ld(&pos[32 * jh])) : c0;
+        x[4 * jh] = cmul(x[4 * jh], ch);
+        x[4 * jh + 1] = cmul(x[4 * jh + 1], cmul(ch, a1));
+        x[4 * jh + 2] = cmul(x[4 * jh + 2], cmul(ch, a2));
+        x[4 * jh + 3] = cmul(x[4 * jh + 3], cmul(ch, a3));
       }
-      if (row >= n_ofdm) row = -1;
-      s_row[tid] = row;
-      s_loc[tid] = (row >= 0) ? d_round_i(tsi[row]) : 0;
+      if (oob) scratch[(size_t)it * CS_SIZE + CS_OOB] = 1.0;   // a sample of a DFT window outside the buffer: the reference would read out of bounds
+    } else {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) x[j] = mk(0, 0);
     }
-    __syncthreads();
-    for (int e = tid; e < TFG_SYM * 128; e += TFG_THREADS) {
-      const int s = e >> 7, n = e & 127;
-      cd2 v = mk(0, 0);
-      if (s_row[s] >= 0) {
-        const long src = (long)s_loc[s] + n;
-        if (src >= 0 && (uint64_t)src < n_cap) {
-          const double2 x = cap_at(cap, (size_t)src);
-          double sn, cs;
-          sincospi(kk * (double)src, &sn, &cs);
-          v = cmul(mk(x.x, x.y), mk(cs, sn));
-        } else sc[CS_OOB] = 1.0;               // any sample of a DFT window outside the buffer: the reference would read out of bounds
-      }
-      win[s][n] = v;
-    }
-    __syncthreads();
     PH(31);
-    {
-      // 128-point decimation-in-frequency FFT in place (natural order in, bit-reversed order out), like
-      // the reference's FFTW call (ref :904): 7 stages of 64 butterflies; 72 of the 128 bins are kept.
-      const int lane = tid & 63, wv = tid >> 6;
+    fft128_x8(x, tb, tw, lane);
+    if (row >= 0) {
+      const double late = (double)d_round_i(d.ideal) - d.ideal;      // |late| <= 1/2
+      double k_im = -1.0;
+      k_im = k_im * 2; k_im = k_im * M_PI; k_im = k_im * late; k_im = k_im / 128;
+      // the timing phase ramp cis(k_im cn), cn = bin (1..36) or bin - 128 (-36..-1), bin = (l + 8 c) + 16 k1: cis(k_im (l + 8 c))
+      // x cis(16 k_im m) with m = k1 or k1 - 8 in -3 .. 2; |k_im| <= pi / 128, so every argument below is < 0.4
+      const cd2 e0 = cis_small(k_im * (double)l), e1 = cis_small(k_im * (double)(l + 8));
+      const cd2 f1 = cis_small(k_im * 16.0), f2 = cmul(f1, f1), f3 = cmul(f2, f1);
+      double2 *out = tfg + ((size_t)it * ROWS + row) * NSC;
 #pragma unroll
-      for (int stg = 0; stg < 7; ++stg) {
-        const int half = 64 >> stg;
-        const int pos = lane & (half - 1);
-        const int i0 = ((lane >> (6 - stg)) << (7 - stg)) + pos, i1 = i0 + half;
-        const cd2 tw = twr[stg];
-#pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
-          cd2 *x = win[wv + 4 * pass];
-          const cd2 a = x[i0], b = x[i1];
-          x[i0] = cadd(a, b);
-          x[i1] = cmul(csub(a, b), tw);
-        }
-        // wave wv owns windows wv and wv + 4 through all seven stages: no other wave touches them, and one wave's LDS
-        // accesses execute in program order -- a workgroup barrier per stage (round 3) only made the four waves wait for
-        // each other seven times per job
-        lcs_wave_sync();
+      for (int q = 0; q < 16; ++q) {
+        const int c = q >> 3, k1 = q & 7;
+        if (k1 == 3 || k1 == 4) continue;                           // bins 48 .. 95: never kept
+        const int bin = (l + 8 * c) + 16 * k1;                       // x[8 c + k1] = X[(l + 8 c) + 16 k1]
+        const int i = (bin >= 92) ? bin - 92 : ((bin >= 1 && bin <= 36) ? bin + 35 : -1);
+        if (i < 0) continue;
+        const cd2 f = (k1 == 0) ? mk(1, 0) : (k1 == 1 ? f1 : (k1 == 2 ? f2 : (k1 == 5 ? cconj(f3) : (k1 == 6 ? cconj(f2) : cconj(f1)))));
+        const cd2 a = cdivr(x[q], sqrt(128.0));
+        st(&out[i], cmul(a, cmul(c ? e1 : e0, f)));
       }
-      __syncthreads();                        // the output pass below reads every wave's windows
-      for (int e = tid; e < TFG_SYM * NSC; e += TFG_THREADS) {
-        const int sidx = e / NSC, i = e % NSC;
-        const int t = s_row[sidx];
-        if (t < 0) continue;
-        const int bin = (i < 36) ? 92 + i : i - 35;
-        cd2 a = cdivr(win[sidx][__brev((unsigned)bin) >> 25], sqrt(128.0));
-        const double ideal = tsi[t];
-        const double late = (double)d_round_i(ideal) - ideal;
-        double k_im = -1.0;
-        k_im = k_im * 2; k_im = k_im * M_PI; k_im = k_im * late; k_im = k_im / 128;
-        const double ph = k_im * (double)cn_of(i);
-        a = cmul(a, cis(ph));
-        st(&tfg[((size_t)it * ROWS + t) * NSC + i], a);
-      }
-      PH(32);
     }
+    PH(32);
   }
 }
 
@@ -969,15 +1018,15 @@ int lcs_launch_pack_results(lcs_ctx *c, int n_buf, bool full) {
 }
 int lcs_launch_tfg(lcs_ctx *c, uint32_t n_cap, bool with_rs) {
   hipLaunchKernelGGL(k_cell_prep, dim3(c->grid_items), dim3(128), 0, c->stream, c->cells_out, c->work_items, c->n_work, c->params,
-                     c->d_pn_jump, c->tfg_ts, c->cell_scratch, with_rs ? 3 : 1);
-  hipLaunchKernelGGL(k_tfg, dim3(LCS_TFG_GRID), dim3(TFG_THREADS), 0, c->stream, c->cells_out, c->work_items, c->n_work, c->params,
-                     lcs_cap_src(c, n_cap), n_cap, c->tfg_ts, c->cell_scratch, c->tfg, c->needed_rows_only ? 1 : 0);
+                     c->d_pn_jump, c->tfg_ts, c->cell_scratch, c->tfg_desc, with_rs ? 3 : 1, c->needed_rows_only ? 1 : 0);
+  hipLaunchKernelGGL(k_tfg, dim3(LCS_TFG_GRID), dim3(TFG_THREADS), 0, c->stream, c->work_items, c->n_work,
+                     lcs_cap_src(c, n_cap), n_cap, c->cell_scratch, c->tfg_desc, c->tfg, c->needed_rows_only ? 1 : 0);
   HIPCHK(c, hipGetLastError());
   return LCS_OK;
 }
 int lcs_launch_rs_build(lcs_ctx *c) {
   hipLaunchKernelGGL(k_cell_prep, dim3(c->grid_items), dim3(128), 0, c->stream, c->cells_out, c->work_items, c->n_work, c->params,
-                     c->d_pn_jump, c->tfg_ts, c->cell_scratch, 2);
+                     c->d_pn_jump, c->tfg_ts, c->cell_scratch, c->tfg_desc, 2, 0);
   HIPCHK(c, hipGetLastError());
   return LCS_OK;
 }
