@@ -786,48 +786,45 @@ __device__ __forceinline__ float repair_gpu_value(const float *__restrict__ sgs,
   }
   return __fdiv_rn(v, (float)(2 * geo.ds + 1));
 }
-// One wave per position.  Per candidate the samples all its correlations read -- for every combining window the 137 taps +
-// 2 arm lags that follow the window start -- are first staged in LDS by coalesced loads, IN THE SOURCE'S OWN FORMAT (2 bytes per
-// sample for dongle data; a lane that walked its own window through global memory met one cache line per tap: 140 us per
-// batch for ~300 positions); the 137-term sums then run on LDS operands, one (lag, window) pair per lane.  WAVES waves share
-// a workgroup (dongle data: four -- in the pipelined chain a workgroup of this kernel starts where a correlation workgroup
-// retired, and four waves fill that slot's four SIMDs).
+// One 256-thread workgroup per position.  Per candidate the samples all its correlations read -- for every combining window the
+// 137 taps + 2 arm lags that follow the window start -- are first staged in LDS by coalesced loads, IN THE SOURCE'S OWN FORMAT
+// (2 bytes per sample for dongle data; a lane that walked its own window through global memory met one cache line per tap:
+// 140 us per batch for ~300 positions); the 137-term sums then run on LDS operands, one (lag, window) pair per thread.  The
+// kernel sits between the collapse and the peak search of every batch: what counts is its latency (a workgroup per position,
+// its four waves sharing one candidate's staging and sums; as one wave per position it took 70-120 us).
 #define REPAIR_MAX_LAGS 17          // 2 * 8 + 1: lcs_xcorr_pss refuses arms beyond 8
 #define REPAIR_SPAN (137 + REPAIR_MAX_LAGS - 1)
+#define REPAIR_THREADS 256
 template <int KIND> struct RepairSample;
 template <> struct RepairSample<0> { typedef uint16_t T; static __device__ __forceinline__ double2 cvt(uint16_t p) { return make_double2(-(double)(int)(int8_t)(p & 255u) / 128.0, -(double)(int)(int8_t)(p >> 8) / 128.0); } };
 template <> struct RepairSample<1> { typedef float2 T; static __device__ __forceinline__ double2 cvt(float2 f) { return make_double2((double)f.x, (double)f.y); } };
 template <> struct RepairSample<2> { typedef double2 T; static __device__ __forceinline__ double2 cvt(double2 d) { return d; } };
-template <int KIND, int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void k_frq_repair(const float *__restrict__ sg, const unsigned *__restrict__ fix_list,
-                                                           const int *__restrict__ n_fix, const CapSrc src,
-                                                           const SlotParams *__restrict__ params, const double *__restrict__ fset,
-                                                           const double2 *__restrict__ pss_td, const int *__restrict__ start,
-                                                           double *__restrict__ pow_, float *__restrict__ pow32, int *__restrict__ frq,
-                                                           XcGeom geo) {
+template <int KIND>
+__global__ __launch_bounds__(REPAIR_THREADS) void k_frq_repair(const float *__restrict__ sg, const unsigned *__restrict__ fix_list,
+                                                               const int *__restrict__ n_fix, const CapSrc src,
+                                                               const SlotParams *__restrict__ params, const double *__restrict__ fset,
+                                                               const double2 *__restrict__ pss_td, const int *__restrict__ start,
+                                                               double *__restrict__ pow_, float *__restrict__ pow32, int *__restrict__ frq,
+                                                               XcGeom geo) {
   LCS_TAIL_PRIO();
   typedef typename RepairSample<KIND>::T ST;
-  __shared__ double2 s_tmpl_all[WAVES][137];
-  __shared__ ST s_smp_all[WAVES][LCS_NW_MAX][REPAIR_SPAN + 1];
-  __shared__ double s_sq_all[WAVES][REPAIR_MAX_LAGS * LCS_NW_MAX];
-  __shared__ float s_lag_all[WAVES][REPAIR_MAX_LAGS];
-  const int lane = threadIdx.x & 63;
-  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  double2 *s_tmpl = s_tmpl_all[wv];
-  ST (*s_smp)[REPAIR_SPAN + 1] = s_smp_all[wv];
-  double *s_sq = s_sq_all[wv];
-  float *s_lag = s_lag_all[wv];
+  __shared__ double2 s_tmpl[137];
+  __shared__ ST s_smp[LCS_NW_MAX][REPAIR_SPAN + 1];
+  __shared__ double s_sq[REPAIR_MAX_LAGS * LCS_NW_MAX];
+  __shared__ float s_lag[REPAIR_MAX_LAGS];
+  const int tid = threadIdx.x, lane = tid & 63;
   const ST *capbase = KIND == 0 ? reinterpret_cast<const ST *>(src.c8) : (KIND == 1 ? reinterpret_cast<const ST *>(src.c32) : reinterpret_cast<const ST *>(src.c64));
   const size_t cap_stride = KIND == 0 ? lcs_cap8_stride(src.n_cap) : (size_t)src.n_cap;
   const int n = *n_fix;
   const int n_lag = 2 * geo.ds + 1, span = 137 + n_lag - 1;
-  for (int e = blockIdx.x * WAVES + wv; e < n; e += gridDim.x * WAVES) {
+  for (int e = blockIdx.x; e < n; e += gridDim.x) {
     const unsigned pos = fix_list[e];
     const int idx = (int)(pos % LCS_N_IDX), t = (int)((pos / LCS_N_IDX) % 3), slot = (int)(pos / (3 * LCS_N_IDX));
     const float *sgs = sg + (size_t)slot * geo.G * LCS_N_IDX * LCS_TG;
     const SlotParams p = params[slot];
     const ST *cap = capbase + (size_t)slot * cap_stride;
-    // the values the collapse kernel compared (same expression, same rounding), lane f and f + 64
+    // the values the collapse kernel compared (same expression, same rounding), lane f and f + 64; every wave computes the same
+    // candidate masks (no exchange needed)
     const float x0 = lane < geo.n_f ? repair_gpu_value(sgs, geo, 3 * lane + t, idx) : -INFINITY;
     const float x1 = lane + 64 < geo.n_f ? repair_gpu_value(sgs, geo, 3 * (lane + 64) + t, idx) : -INFINITY;
     float mx = fmaxf(x0, x1);
@@ -845,38 +842,39 @@ __global__ __launch_bounds__(64 * WAVES) void k_frq_repair(const float *__restri
         const double f_off = fset[f];
         const double kf = (p.fc_req - f_off) / p.fc_prog;
         const double k = M_PI * f_off / ((p.fs_prog * kf) / 2);
-        for (int mm = lane; mm < 137; mm += 64) {
+        if (tid < 137) {
           double sn, cs;
-          sincos(k * (double)mm, &sn, &cs);
-          const double2 s = pss_td[t * 137 + mm];
-          s_tmpl[mm] = make_double2((s.x * cs - s.y * sn) / 137, -(s.x * sn + s.y * cs) / 137);
+          sincos(k * (double)tid, &sn, &cs);
+          const double2 s = pss_td[t * 137 + tid];
+          s_tmpl[tid] = make_double2((s.x * cs - s.y * sn) / 137, -(s.x * sn + s.y * cs) / 137);
         }
         const int *st = start + ((size_t)slot * LCS_NW_MAX) * LCS_NF_MAX + f;
         {
-          // lane -> sample o of window w, eight loads in flight per lane.  Sample o of window w is what the positions idx - arm ..
-          // idx + arm read at tap o - lag: position (idx - arm + o), circular in 9600 for the LAG part only (ref :336) -- a window whose
-          // lags wrap is staged lag by lag below instead
+          // thread -> sample o of window w, all of a thread's loads in flight together.  Sample o of window w is what the positions
+          // idx - arm .. idx + arm read at tap o - lag; the positions are circular in 9600 (ref :336): the run staged here starts at
+          // idx - arm (+ 9600 when that is negative) and serves the lags on its side of the wrap, the others read memory directly
           const int n_it = geo.n_comb * span;
-          for (int i0 = lane; i0 < n_it; i0 += 64 * 8) {
-            ST v[8];
+          const size_t at0 = (size_t)(idx - geo.ds + (idx - geo.ds < 0 ? LCS_N_IDX : 0));
+          for (int i0 = tid; i0 < n_it; i0 += REPAIR_THREADS * 5) {
+            ST v[5];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-              const int i = min(i0 + 64 * u, n_it - 1), w = i / span, o = i - w * span;
-              v[u] = cap[(size_t)(idx - geo.ds + o + (idx - geo.ds < 0 ? LCS_N_IDX : 0)) + (size_t)st[(size_t)w * LCS_NF_MAX]];
+            for (int u = 0; u < 5; ++u) {
+              const int i = min(i0 + REPAIR_THREADS * u, n_it - 1), w = i / span, o = i - w * span;
+              v[u] = cap[at0 + (size_t)o + (size_t)st[(size_t)w * LCS_NF_MAX]];
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-              const int i = i0 + 64 * u, w = i / span, o = i - w * span;
+            for (int u = 0; u < 5; ++u) {
+              const int i = i0 + REPAIR_THREADS * u, w = i / span, o = i - w * span;
               if (i < n_it) s_smp[w][o] = v[u];
             }
           }
         }
-        lcs_wave_sync();
-        for (int it = lane; it < n_lag * geo.n_comb; it += 64) {         // (lag, window): one 137-tap correlation each
+        __syncthreads();
+        for (int it = tid; it < n_lag * geo.n_comb; it += REPAIR_THREADS) {      // (lag, window): one 137-tap correlation each
           const int l = it / geo.n_comb, w = it - l * geo.n_comb;
           double ar = 0, ai = 0;
           const int ii = idx + l - geo.ds;                               // this lag's position before the circular wrap
-          const bool staged = (idx - geo.ds < 0) ? (ii < 0) : (ii < LCS_N_IDX);      // the run staged above covers the un-wrapped (or all-wrapped-low) lags
+          const bool staged = (idx - geo.ds < 0) ? (ii < 0) : (ii < LCS_N_IDX);
           if (staged) {
             const ST *x = &s_smp[w][l];
 #pragma unroll 8
@@ -897,21 +895,21 @@ __global__ __launch_bounds__(64 * WAVES) void k_frq_repair(const float *__restri
           const float fr = (float)ar, fi = (float)ai;                    // xc is complex<float>
           s_sq[it] = (double)fr * (double)fr + (double)fi * (double)fi;
         }
-        lcs_wave_sync();
-        if (lane < n_lag) {                                              // the float running sum over the windows, in window order
+        __syncthreads();
+        if (tid < n_lag) {                                               // the float running sum over the windows, in window order
           float o = 0.f;
-          for (int w = 0; w < geo.n_comb; ++w) o = (float)((double)o + s_sq[lane * geo.n_comb + w]);
-          s_lag[lane] = __fdiv_rn(o, (float)geo.n_comb);
+          for (int w = 0; w < geo.n_comb; ++w) o = (float)((double)o + s_sq[tid * geo.n_comb + w]);
+          s_lag[tid] = __fdiv_rn(o, (float)geo.n_comb);
         }
-        lcs_wave_sync();
+        __syncthreads();
         float v = s_lag[geo.ds];
         for (int d = 1; d <= geo.ds; ++d) v = v + (s_lag[geo.ds - d] + s_lag[geo.ds + d]);
         v = __fdiv_rn(v, (float)n_lag);
         if (v > best) { best = v; best_f = f; }                          // strict: the lowest index wins a tie (ref :374)
-        lcs_wave_sync();                                                 // the LDS arrays are rewritten by the next candidate
+        __syncthreads();                                                 // the LDS arrays are rewritten by the next candidate
       }
     }
-    if (lane == 0) {
+    if (tid == 0) {
       pow_[pos] = (double)best;
       pow32[pos] = best;
       frq[pos] = best_f;
@@ -1049,12 +1047,12 @@ int lcs_launch_xcorr(lcs_ctx *c, int n_buf, const XcGeom &geo, bool want_incoh, 
     // near-ties of the arg-max, recomputed in the reference's arithmetic (a few positions per buffer; the kernel loops over the list)
     if (!c->skip_frq_repair) {
       const CapSrc cs = lcs_cap_src(c, geo.n_cap);
-      const int ng = std::min(256, 4 * n_buf);
-#define REPAIR_LAUNCH(KIND, WAVES) hipLaunchKernelGGL((k_frq_repair<KIND, WAVES>), dim3(ng * 4 / WAVES), dim3(64 * WAVES), 0, c->stream, c->single, c->fix_list, \
-                                                      c->n_fix, cs, c->params, c->fset, c->d_pss_td, c->start, c->pow_, pow32, c->frq, geo)
-      if (cs.c8) REPAIR_LAUNCH(0, 4);
-      else if (cs.c32) REPAIR_LAUNCH(1, 2);
-      else REPAIR_LAUNCH(2, 1);
+      const int ng = std::min(512, 8 * n_buf);
+#define REPAIR_LAUNCH(KIND) hipLaunchKernelGGL((k_frq_repair<KIND>), dim3(ng), dim3(REPAIR_THREADS), 0, c->stream, c->single, c->fix_list, \
+                                               c->n_fix, cs, c->params, c->fset, c->d_pss_td, c->start, c->pow_, pow32, c->frq, geo)
+      if (cs.c8) REPAIR_LAUNCH(0);
+      else if (cs.c32) REPAIR_LAUNCH(1);
+      else REPAIR_LAUNCH(2);
 #undef REPAIR_LAUNCH
     }
   }

@@ -94,18 +94,17 @@ __device__ __forceinline__ void win_rotate16(cd2 (&x)[16], const WinRot &r, int 
 #pragma unroll
   for (int j = 1; j < 15; ++j) x[j] = cmul(x[j], cmul(r.cu, trot[w * 16 + j]));
   x[15] = cmul(x[15], (l >= 6) ? r.cw : cmul(r.cu, trot[w * 16 + 15]));
-  lcs_wave_sync();                                       // trot is rewritten by the wave's next job
 }
 // the 62 PSS / SSS bins [97..127, 1..31] among this lane's sixteen outputs X[(l + 8 c) + 16 k1] = x[8 c + k1]: index 0..61 or -1
 __device__ __forceinline__ int win_bin62(int l, int q) {
   const int bin = (l + 8 * (q >> 3)) + 16 * (q & 7);
   return (bin >= 97) ? bin - 97 : ((bin >= 1 && bin <= 31) ? bin + 30 : -1);
 }
-__device__ __forceinline__ void win_fft8(const CapView &cap, long loc, bool valid, double k, uint32_t n_cap, int lane, cd2 *tb, const cd2 *tw,
-                                         cd2 *trot, cd2 (&x)[16]) {
+// One window per lane group with the peak's rotation factors prepared before (win_rot_prepare: they depend on the peak's
+// frequency only, so a wave computes them once per peak and keeps the table in LDS for all of the peak's occurrences)
+__device__ __forceinline__ void win_fft8(const CapView &cap, long loc, bool valid, const WinRot &r, uint32_t n_cap, int lane, cd2 *tb, const cd2 *tw,
+                                         const cd2 *trot, cd2 (&x)[16]) {
   const int l = lane & 7;
-  const WinRot r = win_rot_prepare(k, lane, trot);
-  __builtin_amdgcn_sched_barrier(0);                     // the sample loads stay behind the sincos expansions
   if (cap.c8) win_load16<0>(cap, loc, l, n_cap, valid, x);
   else if (cap.c32) win_load16<1>(cap, loc, l, n_cap, valid, x);
   else win_load16<2>(cap, loc, l, n_cap, valid, x);
@@ -199,7 +198,6 @@ __device__ __forceinline__ SssGeo sss_geometry(const lcs_cell &cell, const SlotP
 // kind w % 3 = PSS window, extended-CP SSS window, normal-CP SSS window, ref :578-597); slots 6, 7 idle.
 #define SW_WAVES 4           // independent waves per workgroup (a workgroup then fills the slot of the correlation workgroup it displaces)
 #define SW_THREADS (64 * SW_WAVES)
-#define SW_PAIRS (MAX_HF / 2)
 __global__ __launch_bounds__(SW_THREADS) void k_sss_win(const lcs_cell *__restrict__ peaks, const int *__restrict__ npeaks, int n_buf,
                                                         WorkItem *__restrict__ items, int *__restrict__ n_items,
                                                         const CapSrc src,
@@ -208,57 +206,63 @@ __global__ __launch_bounds__(SW_THREADS) void k_sss_win(const lcs_cell *__restri
   LCS_TAIL_PRIO();
   __shared__ cd2 tw[128];
   __shared__ cd2 tb_all[SW_WAVES][8 * FFT128_WSTRIDE];
+  __shared__ cd2 trot_all[SW_WAVES][8 * 16];
   const int lane = threadIdx.x & 63, w = lane >> 3, l = lane & 7;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // wave-uniform, and the compiler is told so: the job's records load into SGPRs
-  // a wave's transpose buffer also holds its rotation table (before the transform) and the PSS channel estimates (after it)
-  cd2 *tb = tb_all[wv], *trot = tb;
+  // a wave's transpose buffer also holds the PSS channel estimates after the transform
+  cd2 *tb = tb_all[wv], *trot = trot_all[wv];
   cd2 (*h_raw)[62] = reinterpret_cast<cd2 (*)[62]>(tb), (*h_sm)[62] = reinterpret_cast<cd2 (*)[62]>(tb + 2 * 62);
   static_assert(4 * 62 <= 8 * FFT128_WSTRIDE, "the estimates fit the transpose buffer");
   fft128_twiddle_table(tw, threadIdx.x, SW_THREADS);
   __syncthreads();
   // the work list: numbered here from the per-buffer counts; workgroup 0 also writes it out for the kernels that follow
   if (blockIdx.x == 0 && wv == 0) peak_list_write(npeaks, n_buf, items, n_items, lane);
-  const int n_jobs = peak_total(npeaks, n_buf, lane) * SW_PAIRS;
-  for (int job = blockIdx.x * SW_WAVES + wv; job < n_jobs; job += gridDim.x * SW_WAVES) {
-    const int it = job / SW_PAIRS, k0 = 2 * (job % SW_PAIRS);
+  const int n_pk = peak_total(npeaks, n_buf, lane);
+  // a job = one PEAK: its record, geometry and rotation factors once, then its occurrences two at a time (k = k0, k0 + 1: window
+  // slot w -> occurrence w / 3; kind w % 3 = PSS window, extended-CP SSS window, normal-CP SSS window, ref :578-597; slots 6, 7 idle)
+  for (int it = blockIdx.x * SW_WAVES + wv; it < n_pk; it += gridDim.x * SW_WAVES) {
     const WorkItem wi = peak_lookup(npeaks, n_buf, it, lane);
     const int slot = __builtin_amdgcn_readfirstlane(wi.slot), pk = __builtin_amdgcn_readfirstlane(wi.peak);
     const lcs_cell cell = peaks[(size_t)slot * LCS_MAXP + pk];
     const SlotParams p = params[slot];
     const SssGeo g = sss_geometry(cell, p, n_cap);
-    if (k0 >= g.n_pss) continue;
     const CapView cap = cap_view(src, slot);
-    const int occ = w / 3, kind = w - 3 * occ, k = k0 + occ;
-    const bool valid = w < 6 && k < g.n_pss;
-    const uint32_t pss_loc = (uint32_t)d_round_i(g.peak_loc + k * (g.k_factor * 9600));
-    const long pss_dft = (long)(pss_loc + 9 - 2);
-    const long loc = (kind == 0) ? pss_dft : (kind == 1 ? pss_dft - 128 - 32 : pss_dft - 128 - 9);
-    cd2 x[16];
-    win_fft8(cap, loc, valid, g.kph, n_cap, lane, tb, tw, trot, x);
-    double *rec = ws + (size_t)it * SW_ITEM + (size_t)k * SW_REC;
-    if (valid) {
+    const WinRot rot = win_rot_prepare(g.kph, lane, trot);
+    const int occ = w / 3, kind = w - 3 * occ;
+    for (int k0 = 0; k0 < g.n_pss; k0 += 2) {
+      const int k = k0 + occ;
+      const bool valid = w < 6 && k < g.n_pss;
+      const uint32_t pss_loc = (uint32_t)d_round_i(g.peak_loc + k * (g.k_factor * 9600));
+      const long pss_dft = (long)(pss_loc + 9 - 2);
+      const long loc = (kind == 0) ? pss_dft : (kind == 1 ? pss_dft - 128 - 32 : pss_dft - 128 - 9);
+      cd2 x[16];
+      win_fft8(cap, loc, valid, rot, n_cap, lane, tb, tw, trot, x);
+      double *rec = ws + (size_t)it * SW_ITEM + (size_t)k * SW_REC;
+      if (valid) {
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int b = win_bin62(l, q);
-        if (b < 0) continue;
-        const cd2 o = cdivr(x[q], sqrt(128.0));                         // /sqrt(128) (ref :527-529)
-        if (kind == 0) { const double2 f = pss_fd[cell.n_id_2 * 62 + b]; h_raw[occ][b] = cmul(o, mk(f.x, -f.y)); }
-        else { rec[(kind == 1 ? SW_EXT : SW_NRM) + 2 * b] = o.re; rec[(kind == 1 ? SW_EXT : SW_NRM) + 2 * b + 1] = o.im; }
+        for (int q = 0; q < 16; ++q) {
+          const int b = win_bin62(l, q);
+          if (b < 0) continue;
+          const cd2 o = cdivr(x[q], sqrt(128.0));                         // /sqrt(128) (ref :527-529)
+          if (kind == 0) { const double2 f = pss_fd[cell.n_id_2 * 62 + b]; h_raw[occ][b] = cmul(o, mk(f.x, -f.y)); }
+          else { rec[(kind == 1 ? SW_EXT : SW_NRM) + 2 * b] = o.re; rec[(kind == 1 ? SW_EXT : SW_NRM) + 2 * b + 1] = o.im; }
+        }
       }
-    }
-    lcs_wave_sync();
-    for (int o2 = 0; o2 < 2; ++o2) {
-      if (k0 + o2 >= g.n_pss) break;
-      double *r2 = ws + (size_t)it * SW_ITEM + (size_t)(k0 + o2) * SW_REC;
-      if (lane < 62) {
-        const cd2 v = smooth13(h_raw[o2], lane);
-        h_sm[o2][lane] = v;
-        r2[SW_HSM + 2 * lane] = v.re; r2[SW_HSM + 2 * lane + 1] = v.im;
+      lcs_wave_sync();
+      for (int o2 = 0; o2 < 2; ++o2) {
+        if (k0 + o2 >= g.n_pss) break;
+        double *r2 = ws + (size_t)it * SW_ITEM + (size_t)(k0 + o2) * SW_REC;
+        if (lane < 62) {
+          const cd2 v = smooth13(h_raw[o2], lane);
+          h_sm[o2][lane] = v;
+          r2[SW_HSM + 2 * lane] = v.re; r2[SW_HSM + 2 * lane + 1] = v.im;
+        }
       }
+      lcs_wave_sync();
+      if (lane < 2 && k0 + lane < g.n_pss) ws[(size_t)it * SW_ITEM + (size_t)(k0 + lane) * SW_REC + SW_NP] = noise_power(h_sm[lane], h_raw[lane]);
+      lcs_wave_sync();                                   // the buffer is rewritten by the next pair of occurrences
     }
-    lcs_wave_sync();
-    if (lane < 2 && k0 + lane < g.n_pss) ws[(size_t)it * SW_ITEM + (size_t)(k0 + lane) * SW_REC + SW_NP] = noise_power(h_sm[lane], h_raw[lane]);
-    lcs_wave_sync();                                     // the buffer is rewritten by the wave's next job
+    lcs_wave_sync();                                     // the rotation table is rewritten by the wave's next peak
   }
 }
 
@@ -431,14 +435,18 @@ __global__ __launch_bounds__(FW_THREADS) void k_foe_win(const lcs_cell *__restri
   LCS_TAIL_PRIO();
   __shared__ cd2 tw[128];
   __shared__ cd2 tb_all[FW_WAVES][8 * FFT128_WSTRIDE];
+  __shared__ cd2 trot_all[FW_WAVES][8 * 16];
+  __shared__ cd2 h_sm_all[FW_WAVES][4][62];
   const int lane = threadIdx.x & 63, w = lane >> 3, l = lane & 7;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // wave-uniform, and the compiler is told so: the job's records load into SGPRs
-  __shared__ cd2 h_sm_all[FW_WAVES][4][62];
-  cd2 *tb = tb_all[wv], *trot = tb;                      // (the buffer also holds the rotation table before and the estimates after the transform)
+  cd2 *tb = tb_all[wv], *trot = trot_all[wv];            // (the transpose buffer also holds the estimates after the transform)
   cd2 (*h_raw)[62] = reinterpret_cast<cd2 (*)[62]>(tb), (*aux)[62] = reinterpret_cast<cd2 (*)[62]>(tb + 4 * 62), (*h_sm)[62] = h_sm_all[wv];
-  static_assert(8 * 62 <= 8 * FFT128_WSTRIDE && 8 * 16 <= 8 * FFT128_WSTRIDE, "the estimates / the rotation table fit the transpose buffer");
+  static_assert(8 * 62 <= 8 * FFT128_WSTRIDE, "the estimates fit the transpose buffer");
   fft128_twiddle_table(tw, threadIdx.x, FW_THREADS);
   __syncthreads();
+  // a job = FOUR occurrences of one peak (cell) = 8 windows (window slot w -> occurrence w >> 1; w & 1 = 0: the PSS window, 1: the
+  // SSS window in front of it, ref :803-845).  (One wave per cell walking all its occurrences -- the form k_sss_win takes -- was
+  // measured slower here: a cell has only four such jobs, and a batch only a few hundred cells.)
   const int n_jobs = *n_items * FW_QUADS;
   for (int job = blockIdx.x * FW_WAVES + wv; job < n_jobs; job += gridDim.x * FW_WAVES) {
     const int it = job / FW_QUADS, k0 = 4 * (job % FW_QUADS);
@@ -448,49 +456,53 @@ __global__ __launch_bounds__(FW_THREADS) void k_foe_win(const lcs_cell *__restri
     const FoeGeo g = foe_geometry(cell, p, n_cap);
     if (!g.ok || k0 >= g.n_sss) continue;
     const CapView cap = cap_view(src, slot);
-    const int occ = w >> 1, is_sss = w & 1, k = k0 + occ;
-    const bool valid = k < g.n_sss;
-    const uint32_t sss_loc = (uint32_t)d_round_i(g.first_sss + k * g.step);
-    const long loc = is_sss ? (long)sss_loc : (long)(sss_loc + g.pss_sss_dist);
-    cd2 x[16];
-    win_fft8(cap, loc, valid, g.kph, n_cap, lane, tb, tw, trot, x);
-    if (valid) {
-      // exp(J*pi*-freq/(FS_LTE/16/2)*-pss_sss_dist), evaluated left to right (ref :832)
-      double ph_im = M_PI;
-      ph_im = ph_im * (-cell.freq);
-      ph_im = ph_im / (FS_LTE / 16 / 2);
-      ph_im = ph_im * (double)(-g.pss_sss_dist);
-      const cd2 ph = cis(ph_im);
-      // the slot number toggles with every occurrence, starting from sn_init (ref :800, :813)
-      const int sn = ((k & 1) == 0) ? g.sn_init : 10 - g.sn_init;
+    const WinRot rot = win_rot_prepare(g.kph, lane, trot);
+    // exp(J*pi*-freq/(FS_LTE/16/2)*-pss_sss_dist), evaluated left to right (ref :832)
+    double ph_im = M_PI;
+    ph_im = ph_im * (-cell.freq);
+    ph_im = ph_im / (FS_LTE / 16 / 2);
+    ph_im = ph_im * (double)(-g.pss_sss_dist);
+    const cd2 ph = cis(ph_im);
+    const int occ = w >> 1, is_sss = w & 1;
+    {
+      const int k = k0 + occ;
+      const bool valid = k < g.n_sss;
+      const uint32_t sss_loc = (uint32_t)d_round_i(g.first_sss + k * g.step);
+      const long loc = is_sss ? (long)sss_loc : (long)(sss_loc + g.pss_sss_dist);
+      cd2 x[16];
+      win_fft8(cap, loc, valid, rot, n_cap, lane, tb, tw, trot, x);
+      if (valid) {
+        // the slot number toggles with every occurrence, starting from sn_init (ref :800, :813)
+        const int sn = ((k & 1) == 0) ? g.sn_init : 10 - g.sn_init;
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int b = win_bin62(l, q);
-        if (b < 0) continue;
-        const cd2 o = cdivr(x[q], sqrt(128.0));
-        if (!is_sss) { const double2 f = pss_fd[cell.n_id_2 * 62 + b]; h_raw[occ][b] = cmul(o, mk(f.x, -f.y)); }
-        else {
-          const double sf = (double)sss_fd[((cell.n_id_1 * 3 + cell.n_id_2) * 2 + (sn != 0)) * 62 + b];
-          aux[occ][b] = cmul(cmul(o, ph), mk(sf, 0));
+        for (int q = 0; q < 16; ++q) {
+          const int b = win_bin62(l, q);
+          if (b < 0) continue;
+          const cd2 o = cdivr(x[q], sqrt(128.0));
+          if (!is_sss) { const double2 f = pss_fd[cell.n_id_2 * 62 + b]; h_raw[occ][b] = cmul(o, mk(f.x, -f.y)); }
+          else {
+            const double sf = (double)sss_fd[((cell.n_id_1 * 3 + cell.n_id_2) * 2 + (sn != 0)) * 62 + b];
+            aux[occ][b] = cmul(cmul(o, ph), mk(sf, 0));
+          }
         }
       }
-    }
-    lcs_wave_sync();
-    for (int o2 = 0; o2 < 4; ++o2)
-      if (k0 + o2 < g.n_sss && lane < 62) h_sm[o2][lane] = smooth13(h_raw[o2], lane);
-    lcs_wave_sync();
-    if (lane < 4 && k0 + lane < g.n_sss) {     // sum over the 62 subcarriers, in subcarrier order (ref :836-843)
-      const double np = noise_power(h_sm[lane], h_raw[lane]);
-      cd2 acc = mk(0, 0);
-      for (int t = 0; t < 62; ++t) {
-        const double a2 = cabs2(h_sm[lane][t]);
-        const double wgt = a2 * (1.0 / (2 * a2 * np + np * np));
-        acc = cadd(acc, cmul(cmul(cconj(aux[lane][t]), h_raw[lane][t]), mk(wgt, 0)));
+      lcs_wave_sync();
+      for (int o2 = 0; o2 < 4; ++o2)
+        if (k0 + o2 < g.n_sss && lane < 62) h_sm[o2][lane] = smooth13(h_raw[o2], lane);
+      lcs_wave_sync();
+      if (lane < 4 && k0 + lane < g.n_sss) {     // sum over the 62 subcarriers, in subcarrier order (ref :836-843)
+        const double np = noise_power(h_sm[lane], h_raw[lane]);
+        cd2 acc = mk(0, 0);
+        for (int t = 0; t < 62; ++t) {
+          const double a2 = cabs2(h_sm[lane][t]);
+          const double wgt = a2 * (1.0 / (2 * a2 * np + np * np));
+          acc = cadd(acc, cmul(cmul(cconj(aux[lane][t]), h_raw[lane][t]), mk(wgt, 0)));
+        }
+        double *rec = ws + (size_t)it * SW_ITEM + (size_t)(k0 + lane) * SW_REC;
+        rec[SW_ACC] = acc.re; rec[SW_ACC + 1] = acc.im;
       }
-      double *rec = ws + (size_t)it * SW_ITEM + (size_t)(k0 + lane) * SW_REC;
-      rec[SW_ACC] = acc.re; rec[SW_ACC + 1] = acc.im;
+      lcs_wave_sync();                                   // the buffers are rewritten by the wave's next job
     }
-    lcs_wave_sync();                                     // the buffer is rewritten by the next job
   }
 }
 
@@ -529,7 +541,7 @@ static int run_sss_foe(lcs_ctx *c, int n_buf, uint32_t n_cap, double thresh2, in
   const CapSrc src = lcs_cap_src(c, n_cap);
   // enough workgroups for every (peak, occurrence) of a typical batch to be resident at once; the
   // kernels loop over the work list, so larger batches only take more rounds
-  const int win_grid = (int)std::min<size_t>((cap_items * (MAX_HF / 2) + 3) / 4, LCS_WIN_GRID);      // four jobs in flight per workgroup
+  const int win_grid = (int)std::min<size_t>((cap_items + 3) / 4, LCS_WIN_GRID);      // a wave per peak, four waves per workgroup
   const int item_grid = (int)std::min<size_t>(cap_items, LCS_ITEM_GRID);
   if (!(mode & 1)) hipLaunchKernelGGL(k_peak_list, dim3(1), dim3(64), 0, c->stream, c->npeaks, n_buf, c->pk_items, c->n_pk);
   if (mode & 1) {
@@ -539,7 +551,7 @@ static int run_sss_foe(lcs_ctx *c, int n_buf, uint32_t n_cap, double thresh2, in
                        c->params, thresh2, c->d_sss_fd, c->sss_ws, dbg);
   }
   if (mode & 2) {
-    hipLaunchKernelGGL(k_foe_win, dim3(win_grid), dim3(FW_THREADS), 0, c->stream, c->peaks, c->pk_items, c->n_pk, src,
+    hipLaunchKernelGGL(k_foe_win, dim3((int)std::min<size_t>((cap_items * FW_QUADS + 3) / 4, LCS_WIN_GRID)), dim3(FW_THREADS), 0, c->stream, c->peaks, c->pk_items, c->n_pk, src,
                        n_cap, c->params, c->d_pss_fd, c->d_sss_fd, c->sss_ws);
     hipLaunchKernelGGL(k_foe_fin, dim3((unsigned)((cap_items + 63) / 64)), dim3(64), 0, c->stream, c->peaks, c->pk_items,
                        c->n_pk, n_cap, c->params, c->sss_ws);

@@ -193,7 +193,8 @@ __device__ __forceinline__ int tfg_needed_row(int k, int n_symb, int n_ofdm) {
   const int row = (fr * 20 + slot) * n_symb + sym;
   return row < n_ofdm ? row : -1;
 }
-__global__ __launch_bounds__(128) void k_cell_prep(const lcs_cell *__restrict__ cells, const WorkItem *__restrict__ items,
+#define CP_THREADS 256
+__global__ __launch_bounds__(CP_THREADS) void k_cell_prep(const lcs_cell *__restrict__ cells, const WorkItem *__restrict__ items,
                                                   const int *__restrict__ n_work, const SlotParams *__restrict__ params,
                                                   const uint32_t *__restrict__ pn_jump, double *__restrict__ ts,
                                                   double *__restrict__ scratch, char *__restrict__ desc, int mode, int needed_only) {
@@ -203,11 +204,21 @@ __global__ __launch_bounds__(128) void k_cell_prep(const lcs_cell *__restrict__ 
   for (int it = blockIdx.x; it < *n_work; it += gridDim.x) {
     const lcs_cell c = cells[it];
     double *sc = scratch + (size_t)it * CS_SIZE;
-    if ((mode & 1) && tid >= 64) {
-      const SlotParams p = params[items[it].slot];
-      if (tid == 64) tfg_timestamps(c, p, ts + (size_t)it * ROWS, s_ts, sc);
-      lcs_wave_sync();                                  // lane 0 of this wave wrote s_ts
-      const int n_symb = cell_n_symb(c);
+    const SlotParams p = params[items[it].slot];
+    const int n_symb = cell_n_symb(c), id = cell_id(c);
+    // wave 1, lane 0: the timestamp walk; wave 0 meanwhile: the CRS table
+    if ((mode & 1) && tid == 64) tfg_timestamps(c, p, ts + (size_t)it * ROWS, s_ts, sc);
+    if ((mode & 2) && tid < 64 && n_symb >= 0 && id >= 0) {
+      for (int e = tid; e < 140 * 4; e += 64) sc[CS_SHIFT + e] = -1.0;
+      lcs_wave_sync();
+      if (tid < 60) {      // one (slot, RS symbol) per lane
+        const int slot = tid / 3, t = tid % 3;
+        const int sym = (t == 2) ? (n_symb - 3) : t, row = slot * n_symb + sym;
+        rs_dl_row(slot, t, id, c.cp_type, n_symb, pn_jump, &sc[CS_RS + row * 24], &sc[CS_SHIFT + row * 4]);
+      }
+    }
+    __syncthreads();
+    if ((mode & 1) && tid >= 64) {                       // waves 1-3: the window records and position factors
       const int n_ofdm = 6 * 10 * 2 * n_symb + 2 * n_symb;
       const double k_factor = (p.fc_req - c.freq_fine) / p.fc_prog;
       // fshift phase pi * (-f) / (fs/2) * n (ref dsp.h:40-53) as sincospi((-f)/(fs/2) * n): the absolute
@@ -215,7 +226,7 @@ __global__ __launch_bounds__(128) void k_cell_prep(const lcs_cell *__restrict__ 
       const double kk = (-c.freq_fine) / ((p.fs_prog * k_factor) / 2);
       TfgRow *rd = reinterpret_cast<TfgRow *>(desc + (size_t)it * TFG_DESC_BYTES);
       double2 *pos = reinterpret_cast<double2 *>(rd + TFG_NDESC);
-      for (int q = tid - 64; q < TFG_NDESC + 128; q += 64) {
+      for (int q = tid - 64; q < TFG_NDESC + 128; q += CP_THREADS - 64) {
         double sn, cs;
         if (q < TFG_NDESC) {
           int row = needed_only ? tfg_needed_row(q, n_symb, n_ofdm) : q;
@@ -230,19 +241,8 @@ __global__ __launch_bounds__(128) void k_cell_prep(const lcs_cell *__restrict__ 
           pos[q - TFG_NDESC] = make_double2(cs, sn);
         }
       }
-      lcs_wave_sync();                                  // s_ts is rewritten by the next item
     }
-    if (!(mode & 2)) continue;
-    const int n_symb = cell_n_symb(c), id = cell_id(c);
-    if (n_symb < 0 || id < 0) continue;
-    if (tid < 64) for (int e = tid; e < 140 * 4; e += 64) sc[CS_SHIFT + e] = -1.0;
-    __syncthreads();
-    if (tid < 60) {      // one (slot, RS symbol) per lane
-      const int slot = tid / 3, t = tid % 3;
-      const int sym = (t == 2) ? (n_symb - 3) : t, row = slot * n_symb + sym;
-      rs_dl_row(slot, t, id, c.cp_type, n_symb, pn_jump, &sc[CS_RS + row * 24], &sc[CS_SHIFT + row * 4]);
-    }
-    __syncthreads();
+    __syncthreads();                                     // s_ts is rewritten by the next item
   }
 }
 
@@ -1017,7 +1017,7 @@ int lcs_launch_pack_results(lcs_ctx *c, int n_buf, bool full) {
   return LCS_OK;
 }
 int lcs_launch_tfg(lcs_ctx *c, uint32_t n_cap, bool with_rs) {
-  hipLaunchKernelGGL(k_cell_prep, dim3(c->grid_items), dim3(128), 0, c->stream, c->cells_out, c->work_items, c->n_work, c->params,
+  hipLaunchKernelGGL(k_cell_prep, dim3(c->grid_items), dim3(CP_THREADS), 0, c->stream, c->cells_out, c->work_items, c->n_work, c->params,
                      c->d_pn_jump, c->tfg_ts, c->cell_scratch, c->tfg_desc, with_rs ? 3 : 1, c->needed_rows_only ? 1 : 0);
   hipLaunchKernelGGL(k_tfg, dim3(LCS_TFG_GRID), dim3(TFG_THREADS), 0, c->stream, c->work_items, c->n_work,
                      lcs_cap_src(c, n_cap), n_cap, c->cell_scratch, c->tfg_desc, c->tfg, c->needed_rows_only ? 1 : 0);
@@ -1025,7 +1025,7 @@ int lcs_launch_tfg(lcs_ctx *c, uint32_t n_cap, bool with_rs) {
   return LCS_OK;
 }
 int lcs_launch_rs_build(lcs_ctx *c) {
-  hipLaunchKernelGGL(k_cell_prep, dim3(c->grid_items), dim3(128), 0, c->stream, c->cells_out, c->work_items, c->n_work, c->params,
+  hipLaunchKernelGGL(k_cell_prep, dim3(c->grid_items), dim3(CP_THREADS), 0, c->stream, c->cells_out, c->work_items, c->n_work, c->params,
                      c->d_pn_jump, c->tfg_ts, c->cell_scratch, c->tfg_desc, 2, 0);
   HIPCHK(c, hipGetLastError());
   return LCS_OK;
