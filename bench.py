@@ -340,6 +340,24 @@ def track_bench(pkg, args, rank, world, local_rank, dist):
         for t in ts: t.start()
         for t in ts: t.join()
 
+    # Round 5: the timed loop runs in C++ (host/TrackBench: one host thread per context calling lcs_track_block on the same block,
+    # symbols resident in HBM) -- round 4's Python threads made the figure follow the box's host (91-150 M symbols/s for the
+    # same 0.50 ms of GPU time per block).  The Python loop below stays as the fallback and as `python_loop_symbols_per_s`.
+    cxx = None
+    exe = os.path.join(ROOT, "host", "TrackBench")
+    if os.path.exists(exe) and not args.lib:
+        import struct, subprocess, tempfile
+        tc = (pkg.capi.LcsTrackCell * C)()
+        for i, c in enumerate(cells):
+            for fld in ("n_id_1", "n_id_2", "cp_type", "n_ports", "n_rb_dl", "phich_duration", "phich_resource"):
+                setattr(tc[i], fld, int(getattr(c, fld)))
+        with tempfile.NamedTemporaryFile(suffix=".trkblock", delete=False) as fh:
+            fh.write(struct.pack("<ii3d", C, n_sym, fc, fc, FS))
+            fh.write(bytes(tc))
+            for a in (fov, ftv, late):
+                fh.write(np.ascontiguousarray(a, np.float64).tobytes())
+            fh.write(np.ascontiguousarray(td, np.complex128).tobytes())
+            blk_path = fh.name
     run_blocks(max(depth, args.warmup))
     gpu_ms.clear()
     if dist is not None:
@@ -348,9 +366,21 @@ def track_bench(pkg, args, rank, world, local_rank, dist):
     t0 = time.perf_counter()
     run_blocks(args.steps)
     torch.cuda.synchronize()
+    dt_py = time.perf_counter() - t0
+    python_rate = C * n_sym * args.steps / dt_py
+    if os.path.exists(exe) and not args.lib:
+        if dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        r = subprocess.run([exe, blk_path, str(depth), str(args.steps), str(max(depth, args.warmup)), str(dev_i)], capture_output=True, text=True, timeout=600)
+        os.unlink(blk_path)
+        try:
+            cxx = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        except Exception:
+            sys.stderr.write("bench.py: host/TrackBench failed (%s): the Python loop's figure is reported\n" % r.stderr[-300:])
     if dist is not None:
         dist.barrier()
-    dt = time.perf_counter() - t0
+    dt = cxx["seconds"] if cxx else dt_py
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -376,9 +406,22 @@ def track_bench(pkg, args, rank, world, local_rank, dist):
             so = ctxs[0].track_stream_block(cells, td, fov, ftv, late, fc, fc, FS, want_syms=False, want_ce=False)
         torch.cuda.synchronize()
         dts = (time.perf_counter() - t1) / reps
+        # the same with the new symbols already in HBM (round 5: the call takes host, page-locked or device memory): what is left
+        # of a call without the 128 MB PCIe copy from pageable memory
+        ctxs[0].track_stream_reset()
+        for _ in range(2):
+            ctxs[0].track_stream_block(cells, None, fov, ftv, late, fc, fc, FS, want_syms=False, want_ce=False, td_device_ptr=d_td.data_ptr())
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            ctxs[0].track_stream_block(cells, None, fov, ftv, late, fc, fc, FS, want_syms=False, want_ce=False, td_device_ptr=d_td.data_ptr())
+        torch.cuda.synchronize()
+        dtd = (time.perf_counter() - t1) / reps
         stream_form = {"symbols_per_s": C * n_sym / dts, "ms_per_call": 1e3 * dts, "symbols_per_call": n_sym, "mib_attempts_per_call": int(so["n_mib"].sum()),
-                       "note": "one context, one thread, time-domain symbols handed over in HOST memory (80 MB per call); the three carried frames are "
-                               "not transformed again (their frequency-domain rows stay on the device) and no frame offset is decoded twice"}
+                       "ms_per_call_symbols_in_hbm": 1e3 * dtd, "symbols_per_s_symbols_in_hbm": C * n_sym / dtd,
+                       "note": "one context, one thread; ms_per_call: time-domain symbols handed over in pageable HOST memory (128 MB per call of 64 cells: "
+                               "the PCIe copy is most of it); ms_per_call_symbols_in_hbm: the same call on symbols already resident in HBM.  The three carried "
+                               "frames are not transformed again (their frequency-domain rows stay on the device) and no frame offset is decoded twice"}
         ctxs[0].track_stream_reset()
     if rank == 0:
         value = world * C * n_sym * args.steps / dt
@@ -390,6 +433,8 @@ def track_bench(pkg, args, rank, world, local_rank, dist):
                           "tracked_cells": C, "symbols_per_block": n_sym, "gpu_ms_per_block": alone_ms,
                           "gpu_ms_per_block_in_the_pipelined_run": pipelined_ms, "contexts_in_flight": depth, "stream_form": stream_form,
                           "mib_locks_per_block": locks, "cells_in_real_time": value / world / 14000.0,
+                          "timed_loop": ("host/TrackBench (C++): one host thread per context" if cxx else "Python threads (host/TrackBench not built)"),
+                          "cxx_driver": cxx, "python_loop_symbols_per_s": python_rate,
                           "parallelism": "replicas" if world > 1 else "single GPU"}}
         # algorithmic bytes of a block: the time-domain symbols in (128 complex<double> each) + symbols and the two ports'
         # channel estimates out (72 complex<double> per symbol each)
@@ -493,7 +538,7 @@ def kernel_source_sha():
     summary was collected from exactly this code."""
     import hashlib
     h = hashlib.sha256()
-    for name in ("pss_xcorr_i8.hip", "pss_xcorr.hip", "lcs_internal.h"):
+    for name in ("pss_xcorr_i8.hip", "pss_xcorr_f16.hip", "pss_xcorr.hip", "lcs_internal.h"):
         h.update(open(os.path.join(ROOT, "lte-cell-scanner_amd", "csrc", name), "rb").read())
     return h.hexdigest()[:16]
 
@@ -835,13 +880,16 @@ def main():
         # corrected as MI355X_MICROARCH.md prescribes), taken from the committed summary ONLY if it was collected from
         # exactly the kernel sources that are running now.
         traffic, traffic_src = None, None
-        for tag in ("r04", "r03", "r02", "r01"):
+        for tag in ("r05", "r04", "r03", "r02", "r01"):
             try:
                 pmj = json.load(open(os.path.join(ROOT, "profiles", tag, "pmc_summary.json")))
-                pm = pmj["kernels"][pmj["dominant_kernel"]]
-                if (pmj.get("kernel_source_sha") == kernel_source_sha() and int(pm["n_f"]) == int(n_f)
-                        and pmj["dominant_kernel"].startswith(kname.split("<")[0])):
-                    traffic, traffic_src = float(pm["hbm_bytes_per_buffer"]) * B, f"profiles/{tag}/pmc_summary.json"
+                if pmj.get("kernel_source_sha") != kernel_source_sha():
+                    continue
+                # the running correlation kernel's entry: the int8 kernel's counters come from the u8 passes, the fp16 kernel's
+                # from the passes over complex<float> batches (profiles/collect.sh)
+                name = next((k for k, v in pmj["kernels"].items() if k.startswith(kname.split("<")[0]) and "hbm_bytes_per_buffer" in v), None)
+                if name and int(pmj["kernels"][name]["n_f"]) == int(n_f):
+                    traffic, traffic_src = float(pmj["kernels"][name]["hbm_bytes_per_buffer"]) * B, f"profiles/{tag}/pmc_summary.json"
                     break
             except Exception:
                 continue
@@ -886,6 +934,11 @@ def main():
                                              "collect_excl_wait_in_library": (1e-3 * host_t["lib_us"] / max(1, host_t["n"])) if host_t["lib_us"] is not None else None}},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TOP/s" if i8 else "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic,
+                         "peak_source": ("MI355X_MICROARCH.md lists no int8 MFMA line in its spec table: 5000 TOP/s = 2 x its dense bf16 figure (the 8-bit "
+                                         "formats' ratio); the guide's own measured ceiling for v_mfma_i32_16x16x64_i8 is 3944 TOP/s (frac_vs_measured_ceiling)"
+                                         if i8 else "MI355X_MICROARCH.md spec table: dense fp16 / bf16 MFMA 2.5 PFLOP/s" if f16 else
+                                         "MI355X_MICROARCH.md spec table: dense fp32 MFMA 157.3 TFLOP/s"),
+                         "frac_vs_measured_ceiling": (achieved / 3944.0) if i8 else None,
                          "frac_algorithmic": flops_consumed * B / (k_ms * 1e-3) / 1e12 / peak,
                          "frac_executed": (executed_ops / (k_ms * 1e-3) / 1e12 / peak) if executed_ops else None,
                          "note": ("achieved = SURVEY 8(d) algorithmic flops of one launch (8*137*3*(N-136)*n_f per buffer x %d buffers, counted ONCE) / "

@@ -214,6 +214,11 @@ int lcs_batch_enqueue_host(lcs_ctx *ctx, const void *h_capbufs, int fmt, int n_b
 /* Page-locked host memory for capture buffers (freed with lcs_host_free before the context is destroyed). */
 int lcs_host_alloc(lcs_ctx *ctx, size_t bytes, void **out);
 int lcs_host_free(lcs_ctx *ctx, void *p);
+/* Device memory for callers that have no HIP toolchain of their own (the host tools are plain g++): buffers they hand to the
+ * device-resident entry points (lcs_batch_enqueue, lcs_track_block with td_on_device, lcs_track_stream_block). */
+int lcs_device_alloc(lcs_ctx *ctx, size_t bytes, void **out);
+int lcs_device_free(lcs_ctx *ctx, void *p);
+int lcs_device_upload(lcs_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);      /* synchronous host -> device copy */
 /* Number of usable GPUs (0 without one): a sweep driver creates one context per device and shards the carriers
  * (host/CellSearch.cpp -g all; src/CellSearch.cpp:471-569 is the loop being sharded). */
 int lcs_device_count(void);
@@ -355,7 +360,8 @@ int lcs_track_stats(lcs_ctx *ctx, int n_cells, int n_sym, double *ac_fd, double 
  *             [n_cells][4] rows; meas[.][0] is the symbol index counted from the start of the stream
  *   ce, ce_pw [n_cells][4][ce_cap][72 complex | 4]: row r = symbol ce_from[cell][port] + r of the stream, ce_n rows
  *   mib_ok, mib_bits [n_cells][max_off]: entry k = frame offset mib_from[cell] + k of the stream (frames o..o+3), n_mib entries
- * cells[].bulk_phase_offset: in at the first call, out after every call.  Host td only.  lcs_track_stream_reset forgets the
+ * cells[].bulk_phase_offset: in at the first call, out after every call.  td may be ordinary host memory, page-locked host
+ * memory (lcs_host_alloc: DMA'd in place) or device memory (the kind is detected).  lcs_track_stream_reset forgets the
  * stream (the next call starts a new one).  The PSS/SSS statistics (do_pss_sss_sigpower_ce) have no state across symbols
  * and stay with lcs_track_stats. */
 int lcs_track_stream_block(lcs_ctx *ctx, lcs_track_cell *cells, int n_cells, int n_sym, const void *td, const double *freq_off,

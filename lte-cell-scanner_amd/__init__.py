@@ -349,7 +349,7 @@ class Searcher:
         return out
 
     def track_stream_block(self, cells, td, freq_off, frame_timing, late, fc_requested, fc_programmed, fs_programmed, want_stats=False,
-                           want_syms=True, want_ce=True):
+                           want_syms=True, want_ce=True, td_device_ptr=None):
         """Continuous tracking (lcs_track_stream_block): the next block of a symbol stream.  `cells` as in track_block; the
         objects' bulk_phase_offset attribute (if any) seeds the first call.  Returns a dict whose rows carry their index in
         the whole stream: syms [c][n_sym][72]; meas [c][4][n_meas][9] (+ ac_fd, ac_td with want_stats); ce / ce_pw lists per
@@ -367,7 +367,11 @@ class Searcher:
         n_sym = fo.shape[1]
         ft = np.ascontiguousarray(frame_timing, np.float64).reshape(n_cells, n_sym)
         lt = np.ascontiguousarray(late, np.float64).reshape(n_cells, n_sym)
-        tdh = np.ascontiguousarray(td, np.complex128).reshape(n_cells, n_sym, 128)
+        if td_device_ptr is None:      # host samples (a page-locked array from host_alloc is DMA'd in place); else [n_cells][n_sym][128] complex128 in HBM
+            tdh = np.ascontiguousarray(td, np.complex128).reshape(n_cells, n_sym, 128)
+            td_arg = tdh.ctypes.data_as(C.c_void_p)
+        else:
+            td_arg = C.c_void_p(td_device_ptr)
         max_rs, ce_cap, max_off = n_sym // 3 + 8, n_sym + 64, n_sym // 120 + 4
         o = dict(syms=np.empty((n_cells, n_sym, 72), np.complex128) if want_syms else None,
                  ce=np.full((n_cells, 4, ce_cap, 72), np.nan + 0j, np.complex128) if want_ce else None,
@@ -378,7 +382,7 @@ class Searcher:
                  mib_ok=np.full((n_cells, max_off), -1, np.int32), mib_bits=np.zeros((n_cells, max_off), np.uint64),
                  mib_from=np.zeros(n_cells, np.int64), n_mib=np.zeros(n_cells, np.int32))
         i64 = lambda a: a.ctypes.data_as(C.POINTER(C.c_int64))
-        rc = self._lib.lcs_track_stream_block(self._h, tc, n_cells, n_sym, tdh.ctypes.data_as(C.c_void_p), _dp(fo), _dp(ft), _dp(lt),
+        rc = self._lib.lcs_track_stream_block(self._h, tc, n_cells, n_sym, td_arg, _dp(fo), _dp(ft), _dp(lt),
                                               fc_requested, fc_programmed, fs_programmed, _dp(o["syms"]), _dp(o["ce"]), _dp(o["ce_pw"]), ce_cap,
                                               i64(o["ce_from"]), _ip(o["ce_n"]), _dp(o["meas"]), _dp(o["ac_fd"]), _dp(o["ac_td"]), max_rs,
                                               _ip(o["n_meas"]), _ip(o["mib_ok"]), o["mib_bits"].ctypes.data_as(C.POINTER(C.c_uint64)), max_off,

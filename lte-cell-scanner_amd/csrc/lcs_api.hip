@@ -649,6 +649,30 @@ int lcs_host_free(lcs_ctx *c, void *p) {
   return LCS_OK;
 }
 
+// Device memory for callers without a HIP toolchain of their own (the host tools are plain g++): buffers they hand to the
+// device-resident entry points (lcs_batch_enqueue, lcs_track_block with td_on_device, lcs_track_stream_block).
+int lcs_device_alloc(lcs_ctx *c, size_t bytes, void **out) {
+  if (!c || !out) return LCS_ERR_BAD_ARG;
+  *out = nullptr;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipMalloc(out, bytes ? bytes : 1));
+  return LCS_OK;
+}
+
+int lcs_device_free(lcs_ctx *c, void *p) {
+  if (!c) return LCS_ERR_BAD_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  if (p) HIPCHK(c, hipFree(p));
+  return LCS_OK;
+}
+
+int lcs_device_upload(lcs_ctx *c, void *d_dst, const void *h_src, size_t bytes) {
+  if (!c || !d_dst || !h_src) return LCS_ERR_BAD_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipMemcpy(d_dst, h_src, bytes, hipMemcpyHostToDevice));
+  return LCS_OK;
+}
+
 int lcs_batch_enqueue_host(lcs_ctx *c, const void *h_capbufs, int fmt, int n_buf, uint32_t n_cap, const double *f_search_set,
                            uint16_t n_f, const double *fc_requested, const double *fc_programmed, double fs_programmed,
                            int stage_mask) {

@@ -839,8 +839,9 @@ extern "C" int lcs_track_stream_block(lcs_ctx *c, lcs_track_cell *cells, int n_c
       const TrkStreamCell &sc = st->cells[idx[g]];
       gc[g] = cells[idx[g]];
       gc[g].bulk_phase_offset = sc.bpo_before_tail;
+      // (hipMemcpyDefault: td may be pageable host memory, page-locked host memory -- DMA'd in place -- or device memory)
       HIPCHK(c, hipMemcpyAsync(c->trk_td + ((size_t)g * L + n_tail) * 128, tdv + (size_t)idx[g] * n_sym * 256, sizeof(double2) * 128 * (size_t)n_sym,
-                               hipMemcpyHostToDevice, c->stream));
+                               hipMemcpyDefault, c->stream));
       auto join = [&](const std::vector<double> &tail, const double *fresh, std::vector<double> &out) {
         std::copy(tail.begin(), tail.end(), out.begin() + (size_t)g * L);
         std::copy(fresh + (size_t)idx[g] * n_sym, fresh + (size_t)(idx[g] + 1) * n_sym, out.begin() + (size_t)g * L + n_tail);

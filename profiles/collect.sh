@@ -1,16 +1,16 @@
 #!/bin/bash
 # Collect a round's profiling artifacts on a GPU box (run from the repository root through gpurun):
-#   bash profiles/collect.sh r04
+#   bash profiles/collect.sh r05
 # GPU tests first, then the bench lines, the kernel-trace statistics (one context = isolated kernel times, default
 # pipeline = under load) and the PMC counters -- kernel-trace statistics and counters in SEPARATE rocprofv3 runs, one
 # counter group per pass, as MI355X_MICROARCH.md prescribes.  Outputs land in gpurun_out/<tag>/; profiles/summarize.py
 # reduces them to the small files kept under profiles/<tag>/.
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 REPO=$PWD
 OUT=$REPO/gpurun_out/$TAG
 mkdir -p "$OUT"
-(cd "$REPO" && timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -6) > "$OUT/pytest_gpu.log"
+(cd "$REPO" && timeout 1800 python -m pytest tests -m gpu -x -q 2>&1 | tail -6) > "$OUT/pytest_gpu.log"
 cd /tmp; export TMPDIR=/tmp
 B="python $REPO/bench.py"
 SHORT="--steps 2 --warmup 1 --batches-per-step 8 --no-cpu-baseline --no-dense --no-power-probe"
@@ -29,6 +29,15 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFL
   i=$((i+1))
   timeout 200 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d "$OUT/pmc_$i" -- $B --steps 1 --warmup 0 --batch 64 --batches-per-step 4 --pipeline 1 --no-cpu-baseline --no-dense --no-power-probe > "$OUT/pmc_$i.log" 2>&1
 done
+# the fp16 kernel's HBM traffic (complex<float> batches): its own two passes
+i=0
+for grp in "FETCH_SIZE" "WRITE_SIZE"; do
+  i=$((i+1))
+  timeout 200 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d "$OUT/pmcf_$i" -- $B --steps 1 --warmup 0 --batch 64 --batches-per-step 4 --pipeline 1 --no-cpu-baseline --no-dense --no-power-probe --input c64 > "$OUT/pmcf_$i.log" 2>&1
+done
+# population parity (tools/parity_population.py: 1152 buffers, GPU chain against the oracle) and BASELINE configs[3]'s sweep on this library
+(cd "$REPO" && timeout 1500 python tools/parity_population.py --out "$OUT/parity_population.json" > "$OUT/parity_population.log" 2>&1)
+(cd "$REPO" && timeout 900 bash profiles/sweep_cli.sh "$TAG" > "$OUT/sweep_cli.log" 2>&1)
 # the bench lines last: bench.py reports roofline.traffic only from a PMC summary taken from the running kernel sources
 (cd "$REPO" && python profiles/summarize.py "$TAG" > /dev/null 2>&1)
 timeout 300 $B --steps 20 --warmup 5 > "$OUT/bench_full_n1.json" 2> "$OUT/bench_full_n1.err"

@@ -5,11 +5,15 @@
 """
 import csv, glob, json, os, shutil, sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(root, "gpurun_out", tag), os.path.join(root, "profiles", tag)
 os.makedirs(dst, exist_ok=True)
 
+for name in ("parity_population.json", "sweep_715_768_n1.json", "cli_time.txt", "cli_sweep_table.txt"):
+    p = os.path.join(src, name)
+    if os.path.exists(p):
+        shutil.copy(p, os.path.join(dst, name))
 for name in ("bench_full_n1.json", "bench_forced_dist_n1.json", "bench_full_n1_input_host.json", "bench_single_n1.json", "bench_pss_n1.json", "bench_stream_n1.json", "bench_track_n1.json", "bench_full_n1_c64_f16_kernel.json", "pytest_gpu.log"):
     p = os.path.join(src, name)
     if os.path.exists(p):
@@ -46,7 +50,7 @@ sys.path.insert(0, root)
 import hashlib
 def kernel_source_sha():          # the same digest bench.py computes: traffic is only reported for exactly these sources
     h = hashlib.sha256()
-    for name in ("pss_xcorr_i8.hip", "pss_xcorr.hip", "lcs_internal.h"):
+    for name in ("pss_xcorr_i8.hip", "pss_xcorr_f16.hip", "pss_xcorr.hip", "lcs_internal.h"):
         h.update(open(os.path.join(root, "lte-cell-scanner_amd", "csrc", name), "rb").read())
     return h.hexdigest()[:16]
 summary = {
@@ -80,5 +84,23 @@ if dom:
     if "hbm_bytes_per_launch" in d:
         k["hbm_bytes_per_launch"] = d["hbm_bytes_per_launch"]
         k["hbm_bytes_per_buffer"] = d["hbm_bytes_per_launch"] / 64
+# the fp16 kernel's traffic (complex<float> batches): its own FETCH_SIZE / WRITE_SIZE passes (pmcf_*), so that the --input c64 line
+# carries roofline.traffic as well
+kf = {}
+for d in sorted(glob.glob(os.path.join(src, "pmcf_*"))):
+    for f in sorted(glob.glob(os.path.join(d, "*", "*_counter_collection.csv")), key=os.path.getmtime)[-1:]:
+        acc = {}
+        for r in csv.DictReader(open(f)):
+            if "k_xcorr_f16x3" not in r["Kernel_Name"]:
+                continue
+            acc.setdefault(r["Counter_Name"], {}).setdefault(r["Dispatch_Id"], 0.0)
+            acc[r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
+        for cname, per in acc.items():
+            kf[cname] = sum(per.values()) / len(per)
+if "FETCH_SIZE" in kf and "WRITE_SIZE" in kf:
+    kf["n_f"], kf["buffers_per_launch"] = 31, 64
+    kf["hbm_bytes_per_launch"] = (2 * kf["FETCH_SIZE"] + kf["WRITE_SIZE"]) * 1024
+    kf["hbm_bytes_per_buffer"] = kf["hbm_bytes_per_launch"] / 64
+    summary["kernels"]["k_xcorr_f16x3 (complex<float> batches, own passes)"] = kf
 json.dump(summary, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1)
 print("wrote", dst, "kernels:", len(kern))

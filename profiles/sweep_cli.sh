@@ -14,4 +14,5 @@ t1=$(date +%s.%N)
 t2=$(date +%s.%N)
 python3 -c "print('CellSearch -s 715e6 -e 768e6 -l on 531 capbuf_NNNN.it files (2.46 MB each, complex<double>): %.2f s wall first run, %.2f s second run' % ($t1 - $t0, $t2 - $t1))" | tee $OUT/cli_time.txt
 tail -6 $OUT/cli_sweep.txt
+sed -n '/Detected the following cells/,$p' $OUT/cli_sweep.txt > $OUT/cli_sweep_table.txt
 rm -rf $D

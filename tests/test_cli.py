@@ -300,3 +300,42 @@ def test_track_cells_consumer_loop(tmp_path):
         assert int(l[10]) == w[4] and abs(float(l[12]) - w[5]) < 0.01 and l[13] == w[6]
     assert want[-1][6] == "LOCKED" and want[-2][6] == "LOCKED"          # 80 ms hold four full frames from some offset: both cells lock
     assert subprocess.run([exe], capture_output=True, text=True).returncode == 2
+
+
+@pytest.mark.gpu
+def test_track_bench_cxx_driver(tmp_path):
+    """host/TrackBench.cpp (the timed loop of `bench.py --stage track`): a small block file through two host threads; every block
+    must come back (no failed call) with the MIB locks the Python call finds on the same block."""
+    import json
+    import struct
+    pkg = load_pkg()
+    g = golden("capbuf_0000")
+    cap = iq_u8_to_capbuf(g["iq_u8"])
+    fc, FS = float(g["fc"][0]), 1.92e6
+    with pkg.Searcher(0) as S:
+        found, _ = S.search_capbuf(cap, np.array([30e3, 35e3, 40e3]), fc, fc, FS)
+        per = []
+        for c in found:
+            kf = (fc - c.freq_superfine) / fc
+            per.append(pkg.tracker.cut_symbols(cap, c.frame_start * (30.72e6 / 16) / (FS * kf), c.cp_type, c.freq_superfine, fc, fc, FS, 980))
+        cells = [found[i % 2] for i in range(4)]
+        td = np.stack([per[i % 2][0] for i in range(4)]); late = np.stack([per[i % 2][1] for i in range(4)])
+        ftv = np.stack([per[i % 2][2] for i in range(4)]); fov = np.stack([per[i % 2][3] for i in range(4)])
+        want = int(np.count_nonzero(S.track_block(cells, td, fov, ftv, late, fc, fc, FS, want_syms=False, want_ce=False)["mib_ok"] == 3))
+    tc = (pkg.capi.LcsTrackCell * 4)()
+    for i, c in enumerate(cells):
+        for fld in ("n_id_1", "n_id_2", "cp_type", "n_ports", "n_rb_dl", "phich_duration", "phich_resource"):
+            setattr(tc[i], fld, int(getattr(c, fld)))
+    blk = tmp_path / "block.trkblock"
+    with open(blk, "wb") as fh:
+        fh.write(struct.pack("<ii3d", 4, 980, fc, fc, FS))
+        fh.write(bytes(tc))
+        for a in (fov, ftv, late):
+            fh.write(np.ascontiguousarray(a, np.float64).tobytes())
+        fh.write(np.ascontiguousarray(td, np.complex128).tobytes())
+    r = subprocess.run([os.path.join(ROOT, "host", "TrackBench"), str(blk), "2", "6", "2"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    j = json.loads(r.stdout.strip().splitlines()[-1])
+    assert j["blocks"] == 6 and j["failed"] == 0 and j["contexts"] == 2 and j["mib_locks_per_block"] == want and want >= 4
+    assert j["symbols_per_s"] > 0 and j["gpu_ms_per_block_alone"] > 0
+    assert subprocess.run([os.path.join(ROOT, "host", "TrackBench")], capture_output=True, text=True).returncode == 2

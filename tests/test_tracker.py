@@ -215,10 +215,21 @@ def test_gpu_track_stream_blocks_equal_one_block(tracked, cuts):
         for n in cuts:
             parts.append(S.track_stream_block(recs, td[:, a:a + n], fov[:, a:a + n], ftv[:, a:a + n], late[:, a:a + n], FC, FC, FS, want_stats=True))
             a += n
-        # a second stream on the same context starts from scratch after a reset
+        # a second stream on the same context starts from scratch after a reset -- this time with its symbols handed over in
+        # DEVICE memory (round 5: the call takes pageable, page-locked or device memory alike)
         S.track_stream_reset()
-        again = S.track_stream_block(recs, td[:, :cuts[0]], fov[:, :cuts[0]], ftv[:, :cuts[0]], late[:, :cuts[0]], FC, FC, FS)
+        import torch
+        d0 = torch.from_numpy(np.ascontiguousarray(td[:, :cuts[0]])).cuda()
+        again = S.track_stream_block(recs, None, fov[:, :cuts[0]], ftv[:, :cuts[0]], late[:, :cuts[0]], FC, FC, FS, td_device_ptr=d0.data_ptr())
         assert np.array_equal(again["syms"], parts[0]["syms"])
+        assert np.array_equal(again["n_meas"], parts[0]["n_meas"]) and np.array_equal(again["meas"], parts[0]["meas"], equal_nan=True)
+        # ... and a third one from page-locked host memory
+        S.track_stream_reset()
+        h = S.host_alloc(td[:, :cuts[0]].nbytes)
+        h[:] = np.ascontiguousarray(td[:, :cuts[0]]).view(np.uint8).reshape(-1)
+        third = S.track_stream_block(recs, h.view(np.complex128).reshape(2, cuts[0], 128), fov[:, :cuts[0]], ftv[:, :cuts[0]], late[:, :cuts[0]], FC, FC, FS)
+        assert np.array_equal(third["syms"], parts[0]["syms"])
+        S.host_free(h)
     assert np.array_equal(np.concatenate([p["syms"] for p in parts], axis=1), one["syms"])
     assert np.array_equal(parts[-1]["bpo"], one["bpo"])
     for i, c in enumerate(recs):
