@@ -372,7 +372,9 @@ def track_bench(pkg, args, rank, world, local_rank, dist):
         if dist is not None:
             dist.barrier()
         t0 = time.perf_counter()
-        r = subprocess.run([exe, blk_path, str(depth), str(args.steps), str(max(depth, args.warmup)), str(dev_i)], capture_output=True, text=True, timeout=600)
+        # (at least 120 untimed blocks first: ~50 ms of load, the time the shader clock takes to come up from idle -- with 6 the 60
+        # timed blocks of the collection command measured the ramp, 95 M symbols/s instead of 155 M)
+        r = subprocess.run([exe, blk_path, str(depth), str(args.steps), str(max(depth, args.warmup, 120)), str(dev_i)], capture_output=True, text=True, timeout=600)
         os.unlink(blk_path)
         try:
             cxx = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
