@@ -1045,7 +1045,7 @@ int lcs_launch_xcorr(lcs_ctx *c, int n_buf, const XcGeom &geo, bool want_incoh, 
     else if (!incoh) hipLaunchKernelGGL((k_collapse<-1, false>), grid, block, 0, c->stream, c->single, incoh, c->pow_, pow32, c->frq, c->fix_list, c->n_fix, geo, n_buf);   // any arm, no debug copy
     else hipLaunchKernelGGL((k_collapse<-1, true>), grid, block, 0, c->stream, c->single, incoh, c->pow_, pow32, c->frq, c->fix_list, c->n_fix, geo, n_buf);
     // near-ties of the arg-max, recomputed in the reference's arithmetic (a few positions per buffer; the kernel loops over the list)
-    if (!c->skip_frq_repair) {
+    if (!c->skip_frq_repair && geo.n_f > 1) {             // (one hypothesis -- the streaming mode -- has no arg-max to repair: one graph node less)
       const CapSrc cs = lcs_cap_src(c, geo.n_cap);
       const int ng = std::min(512, 8 * n_buf);
 #define REPAIR_LAUNCH(KIND) hipLaunchKernelGGL((k_frq_repair<KIND>), dim3(ng), dim3(REPAIR_THREADS), 0, c->stream, c->single, c->fix_list, \

@@ -74,17 +74,20 @@ __device__ __forceinline__ void win_load16(const CapView &cap, long loc, int l, 
 }
 // trot: this wave's [8][16] table in LDS.  The factors are computed BEFORE the samples are loaded (four sincos expansions with
 // sixteen samples live beside them needed every register the wave can have).
+// (a real call, not inlined: four inlined sincos expansions pushed k_sss_win to 256 + 26 registers -- 288 as allocated, more than the
+// 284 a SIMD has free beside one resident correlation workgroup, tests/test_tables_abi.py)
+__device__ __attribute__((noinline)) cd2 cis_call(double x) { return cis(x); }
 struct WinRot { cd2 cu, cw; };
 __device__ __forceinline__ WinRot win_rot_prepare(double k, int lane, cd2 *trot) {
   const int w = lane >> 3, l = lane & 7;
   WinRot r;
-  r.cu = cis(k * (double)(l + 2));
+  r.cu = cis_call(k * (double)(l + 2));
   __builtin_amdgcn_sched_barrier(0);
-  r.cw = cis(k * (double)(l - 6));                       // the wrapped sample of lanes l >= 6
+  r.cw = cis_call(k * (double)(l - 6));                       // the wrapped sample of lanes l >= 6
   __builtin_amdgcn_sched_barrier(0);
-  trot[w * 16 + l + 1] = cis(k * (double)(8 * (l + 1)));
+  trot[w * 16 + l + 1] = cis_call(k * (double)(8 * (l + 1)));
   __builtin_amdgcn_sched_barrier(0);
-  if (l < 7) trot[w * 16 + l + 9] = cis(k * (double)(8 * (l + 9)));
+  if (l < 7) trot[w * 16 + l + 9] = cis_call(k * (double)(8 * (l + 9)));
   lcs_wave_sync();
   return r;
 }
@@ -220,7 +223,10 @@ __global__ __launch_bounds__(SW_THREADS) void k_sss_win(const lcs_cell *__restri
   const int n_pk = peak_total(npeaks, n_buf, lane);
   // a job = one PEAK: its record, geometry and rotation factors once, then its occurrences two at a time (k = k0, k0 + 1: window
   // slot w -> occurrence w / 3; kind w % 3 = PSS window, extended-CP SSS window, normal-CP SSS window, ref :578-597; slots 6, 7 idle)
-  for (int it = blockIdx.x * SW_WAVES + wv; it < n_pk; it += gridDim.x * SW_WAVES) {
+  // (a handful of peaks -- one buffer, the streaming mode -- are better served by latency: then a job is ONE pair of occurrences)
+  const int split = (n_pk <= 64) ? MAX_HF / 2 : 1;
+  for (int job = blockIdx.x * SW_WAVES + wv; job < n_pk * split; job += gridDim.x * SW_WAVES) {
+    const int it = job / split, part = job - it * split;
     const WorkItem wi = peak_lookup(npeaks, n_buf, it, lane);
     const int slot = __builtin_amdgcn_readfirstlane(wi.slot), pk = __builtin_amdgcn_readfirstlane(wi.peak);
     const lcs_cell cell = peaks[(size_t)slot * LCS_MAXP + pk];
@@ -229,7 +235,8 @@ __global__ __launch_bounds__(SW_THREADS) void k_sss_win(const lcs_cell *__restri
     const CapView cap = cap_view(src, slot);
     const WinRot rot = win_rot_prepare(g.kph, lane, trot);
     const int occ = w / 3, kind = w - 3 * occ;
-    for (int k0 = 0; k0 < g.n_pss; k0 += 2) {
+    const int k_first = (split == 1) ? 0 : 2 * part, k_last = (split == 1) ? g.n_pss : min(g.n_pss, 2 * part + 2);
+    for (int k0 = k_first; k0 < k_last; k0 += 2) {
       const int k = k0 + occ;
       const bool valid = w < 6 && k < g.n_pss;
       const uint32_t pss_loc = (uint32_t)d_round_i(g.peak_loc + k * (g.k_factor * 9600));

@@ -652,6 +652,7 @@ __global__ __launch_bounds__(CE_THREADS) void k_chan_est(const lcs_cell *__restr
     TfoecCorr corr = {0.0, 0.0, 0.0};
     double2 *out = ce + (((size_t)it * 4 + port) * ROWS) * NSC;
     __syncthreads();
+    PH(19);
     if (graw) {
       corr = tfoec_corr(sc);
       if (tid < NSC) toc_rot[tid] = toc_subcarrier_rot(corr.delay, tid);

@@ -76,3 +76,35 @@ def test_f_search_set_matches_cli_recipe(pkg):
     assert pkg.f_search_set_for(739e6, 100).size == 31
     assert pkg.f_search_set_for(739e6, 10).size == 3
     assert pkg.f_search_set_for(715e6, 120).size == 35
+
+
+def test_chain_kernels_fit_beside_one_correlation_workgroup():
+    """The per-cell chain runs while the NEXT batch's correlation occupies the GPU: a chain workgroup starts where one of a
+    CU's two correlation workgroups (4 waves x 228 VGPRs, 77.3 KB of LDS) retired.  On a SIMD 512 - 228 = 284 registers are
+    free then, allocated in eights; a kernel that needs more has to wait for BOTH correlation workgroups of a CU to retire at
+    once (round 5 measured that: k_sss_win at 256 + 27 registers waited 1 ms per batch).  Compiles the kernels that sit near
+    the limit and checks the compiler's own resource report."""
+    import re
+    import subprocess
+    csrc = os.path.join(ROOT, "lte-cell-scanner_amd", "csrc")
+    limits = {"k_sss_win": None, "k_foe_win": None, "k_tfg": None}
+    for f in ("sss_foe.hip", "tfg_mib.hip"):
+        p = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-c", "--cuda-device-only",
+                            "-Rpass-analysis=kernel-resource-usage", os.path.join(csrc, f), "-o", os.devnull], capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0, p.stderr[-2000:]
+        cur = None
+        for line in p.stderr.splitlines():
+            m = re.search(r"remark:\s+(Function Name|VGPRs|AGPRs|LDS Size \[bytes/block\]): (\S+)", line)
+            if not m:
+                continue
+            if m.group(1) == "Function Name":
+                cur = next((k for k in limits if f"{len(k)}{k}" in m.group(2)), None)
+                if cur:
+                    limits[cur] = {}
+            elif cur:
+                limits[cur][m.group(1).split()[0]] = int(m.group(2))
+    for k, v in limits.items():
+        assert v and "VGPRs" in v, (k, v)
+        regs = -(-(v["VGPRs"] + v.get("AGPRs", 0)) // 8) * 8
+        assert regs <= 280, f"{k}: {v['VGPRs']} + {v.get('AGPRs', 0)} registers -> {regs} allocated: does not fit beside a resident correlation workgroup (284 free)"
+        assert v["LDS"] <= 77 * 1024, (k, v)

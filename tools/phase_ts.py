@@ -25,4 +25,4 @@ with pkg.Searcher(0) as S:
     print("k_pbch   LLR phase %.1f us, decode (de-ratematch + 64 trellises + traceback + CRC) %.1f us" % (d_us(0, 1), d_us(1, 4)))
     print("k_tfg    fill %.1f us, FFT + output %.1f us" % (d_us(30, 31), d_us(31, 32)))
     print("k_tfoec  %.1f / %.1f / %.1f us" % (d_us(10, 11), d_us(11, 13), d_us(13, 14)))
-    print("k_chan_est  %.1f / %.1f / %.1f / %.1f us" % (d_us(20, 21), d_us(21, 22), d_us(22, 23), d_us(23, 24)))
+    print("k_chan_est  corrections + PBCH rows %.1f | raw estimates %.1f | filter %.1f | noise + first row %.1f | interpolation %.1f us" % (d_us(19, 20), d_us(20, 21), d_us(21, 22), d_us(22, 23), d_us(23, 24)))
