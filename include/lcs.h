@@ -249,8 +249,11 @@ int lcs_batch_readback(lcs_ctx *ctx, int buf, float *xc_incoherent_single /*[3][
  * accumulation in tap order -> complex<float> -> float running sum over the windows -> float box filter, src/searcher.cpp:
  * 160-169, 299-305, 329-345) and decided with its strict comparison (:374): a few positions per buffer, rewritten in place
  * (index and power) before the peak search reads them.  *n_positions = how many the last correlation call of the context
- * repaired (all buffers of the batch).  Not applied by lcs_foe_partial, where a near-tie may span two ranks' shares: there the
- * index is exact except at such near-ties, whatever the number of ranks. */
+ * repaired (all buffers of the batch).  lcs_search_capbuf and the streaming mode hand out no arrays, only peaks and cells: they
+ * repair only the near-ties whose power reaches their position's threshold Z_th1 (a peak's power does, src/searcher.cpp:449) --
+ * the peak list is exact all the same, and the latency of the repair stays off the single-buffer path.  Not applied by
+ * lcs_foe_partial, where a near-tie may span two ranks' shares: there the index is exact except at such near-ties, whatever
+ * the number of ranks. */
 int lcs_last_frq_repairs(lcs_ctx *ctx, int *n_positions);
 /* HIP-event time (ms) of the PSS correlation kernel launches of the last enqueue, and the
  * number of launches it covers; used by bench.py for the roofline figure. */

@@ -922,7 +922,10 @@ int lcs_search_capbuf(lcs_ctx *c, const double *capbuf, uint32_t n_cap, const do
   XcGeom geo;
   if ((rc = upload_host_capbuf(c, capbuf, n_cap, f_search_set, n_f, 2, fc_req, fc_prog, fs_prog, false, &geo))) return rc;
   if ((rc = ensure_percell(c))) return rc;
-  if ((rc = lcs_launch_xcorr(c, 1, geo, false, false))) return rc;
+  c->repair_peaks_only = true;      // no array leaves this call: the peak list is what has to be exact
+  rc = lcs_launch_xcorr(c, 1, geo, false, false);
+  c->repair_peaks_only = false;
+  if (rc) return rc;
   if ((rc = lcs_launch_peak_search(c, 1, geo, std::pow(10.0, -12.0 / 10.0), true))) return rc;
   if ((rc = lcs_launch_sss_foe(c, 1, n_cap, 3.0, nullptr))) return rc;
   c->needed_rows_only = true;

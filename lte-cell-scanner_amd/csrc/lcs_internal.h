@@ -190,6 +190,7 @@ struct lcs_ctx {
   int *frq = nullptr;
   unsigned *fix_list = nullptr;      // [S][3][9600]: positions (slot * 3 + t) * 9600 + idx whose arg-max is a near-tie (capacity: every position)
   int *n_fix = nullptr;              // [4]: entries on the list (zeroed by k_prep_tables)
+  bool repair_peaks_only = false;    // lcs_search_capbuf / the streaming chain: list only the near-ties at or above their position's Z_th1 (pss_xcorr.hip: collapse_flag)
   bool skip_frq_repair = false;      // lcs_foe_partial: a rank sees only its share of the hypotheses (a near-tie may span two ranks)
   lcs_cell *peaks = nullptr;
   int *npeaks = nullptr;

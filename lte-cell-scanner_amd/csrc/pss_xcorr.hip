@@ -534,8 +534,15 @@ __device__ __forceinline__ void collapse_merge(CollapseBest &b, int lane_xor) {
   b.v = tk ? ov : b.v;
   b.foi = tk ? of : b.foi;
 }
-__device__ __forceinline__ void collapse_flag(const CollapseBest &r, unsigned pos, unsigned *__restrict__ fix_list, int *__restrict__ n_fix) {
-  if (r.v > 0.f && r.s >= r.v * (1.0f - LCS_FRQ_TIE_EPS)) fix_list[atomicAdd(n_fix, 1)] = pos;
+// zth (nullable): the fused single-buffer chains hand out no arrays, only peaks -- and a peak's power is at least its position's
+// threshold Z_th1 (ref src/searcher.cpp:449), so there only near-ties that could become a peak are listed (with 0.1 % to spare for
+// the power's own ~1e-7): most near-ties sit in the noise, and in latency mode the repair is on the critical path.
+__device__ __forceinline__ void collapse_flag(const CollapseBest &r, unsigned pos, unsigned *__restrict__ fix_list, int *__restrict__ n_fix,
+                                              const double *__restrict__ zth) {
+  if (r.v > 0.f && r.s >= r.v * (1.0f - LCS_FRQ_TIE_EPS)) {
+    if (zth && (double)r.v < 0.999 * zth[(pos / (3 * LCS_N_IDX)) * LCS_N_IDX + pos % LCS_N_IDX]) return;
+    fix_list[atomicAdd(n_fix, 1)] = pos;
+  }
 }
 typedef const __attribute__((address_space(1))) char *collapse_gptr;
 typedef float collapse_f4 __attribute__((ext_vector_type(4)));
@@ -547,7 +554,7 @@ template <int DS, bool INCOH>
 __global__ __launch_bounds__(256) void k_collapse(const float *__restrict__ sg, float *__restrict__ incoh,
                                                    double *__restrict__ pow_, float *__restrict__ pow32,
                                                    int *__restrict__ frq, unsigned *__restrict__ fix_list, int *__restrict__ n_fix,
-                                                   XcGeom geo, int n_buf) {
+                                                   const double *__restrict__ zth, XcGeom geo, int n_buf) {
   LCS_TAIL_PRIO();
   constexpr int CT = 64;                           // positions per workgroup
   static_assert(LCS_N_IDX % CT == 0 && LCS_TG == 16, "k_collapse tiles 9600 positions x 16 columns");
@@ -617,7 +624,7 @@ __global__ __launch_bounds__(256) void k_collapse(const float *__restrict__ sg, 
       pow_[o] = (double)r.v;
       pow32[o] = r.v;                                                  // what the fused peak search loads
       frq[o] = r.foi;
-      collapse_flag(r, (unsigned)o, fix_list, n_fix);
+      collapse_flag(r, (unsigned)o, fix_list, n_fix, zth);
     }
   }
 }
@@ -649,7 +656,7 @@ typedef unsigned int collapse_u4 __attribute__((ext_vector_type(4)));
 // workgroups leave free on a SIMD; the allocator otherwise spreads over the 64 its occupancy target allows)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(28))) void k_collapse_arm2(const float *__restrict__ sg, double *__restrict__ pow_, float *__restrict__ pow32,
                                                         int *__restrict__ frq, unsigned *__restrict__ fix_list, int *__restrict__ n_fix,
-                                                        XcGeom geo, int n_buf) {
+                                                        const double *__restrict__ zth, XcGeom geo, int n_buf) {
   LCS_TAIL_PRIO();
   constexpr int CT = 4 * COLLAPSE_OUT;             // positions per workgroup
   static_assert(LCS_N_IDX % CT == 0 && LCS_TG == 16, "k_collapse_arm2 tiles 9600 positions x 16 columns");
@@ -711,7 +718,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(28))) void k_co
       pow_[o] = (double)rv;
       pow32[o] = rv;                                                   // what the fused peak search loads
       frq[o] = rf;
-      collapse_flag(rb, (unsigned)o, fix_list, n_fix);
+      collapse_flag(rb, (unsigned)o, fix_list, n_fix, zth);
     }
   }
 }
@@ -1039,11 +1046,12 @@ int lcs_launch_xcorr(lcs_ctx *c, int n_buf, const XcGeom &geo, bool want_incoh, 
     const dim3 grid((LCS_N_IDX / 64) * n_buf), block(256);
     float *incoh = want_incoh ? c->incoh : nullptr;
     float *pow32 = reinterpret_cast<float *>(c->work);
+    const double *zf = c->repair_peaks_only ? c->zth : nullptr;      // fused single-buffer chains: only near-ties that can become a peak
     if (geo.ds == 2 && !incoh && geo.cpg == LCS_TG)
-      hipLaunchKernelGGL(k_collapse_arm2, dim3((LCS_N_IDX / (4 * COLLAPSE_OUT)) * n_buf), block, 0, c->stream, c->single, c->pow_, pow32, c->frq, c->fix_list, c->n_fix, geo, n_buf);
-    else if (geo.ds == 2 && !incoh) hipLaunchKernelGGL((k_collapse<2, false>), grid, block, 0, c->stream, c->single, incoh, c->pow_, pow32, c->frq, c->fix_list, c->n_fix, geo, n_buf);
-    else if (!incoh) hipLaunchKernelGGL((k_collapse<-1, false>), grid, block, 0, c->stream, c->single, incoh, c->pow_, pow32, c->frq, c->fix_list, c->n_fix, geo, n_buf);   // any arm, no debug copy
-    else hipLaunchKernelGGL((k_collapse<-1, true>), grid, block, 0, c->stream, c->single, incoh, c->pow_, pow32, c->frq, c->fix_list, c->n_fix, geo, n_buf);
+      hipLaunchKernelGGL(k_collapse_arm2, dim3((LCS_N_IDX / (4 * COLLAPSE_OUT)) * n_buf), block, 0, c->stream, c->single, c->pow_, pow32, c->frq, c->fix_list, c->n_fix, zf, geo, n_buf);
+    else if (geo.ds == 2 && !incoh) hipLaunchKernelGGL((k_collapse<2, false>), grid, block, 0, c->stream, c->single, incoh, c->pow_, pow32, c->frq, c->fix_list, c->n_fix, zf, geo, n_buf);
+    else if (!incoh) hipLaunchKernelGGL((k_collapse<-1, false>), grid, block, 0, c->stream, c->single, incoh, c->pow_, pow32, c->frq, c->fix_list, c->n_fix, zf, geo, n_buf);   // any arm, no debug copy
+    else hipLaunchKernelGGL((k_collapse<-1, true>), grid, block, 0, c->stream, c->single, incoh, c->pow_, pow32, c->frq, c->fix_list, c->n_fix, zf, geo, n_buf);
     // near-ties of the arg-max, recomputed in the reference's arithmetic (a few positions per buffer; the kernel loops over the list)
     if (!c->skip_frq_repair && geo.n_f > 1) {             // (one hypothesis -- the streaming mode -- has no arg-max to repair: one graph node less)
       const CapSrc cs = lcs_cap_src(c, geo.n_cap);
