@@ -251,9 +251,8 @@ int lcs_batch_readback(lcs_ctx *ctx, int buf, float *xc_incoherent_single /*[3][
  * (index and power) before the peak search reads them.  *n_positions = how many the last correlation call of the context
  * repaired (all buffers of the batch).  lcs_search_capbuf and the streaming mode hand out no arrays, only peaks and cells: they
  * repair only the near-ties whose power reaches their position's threshold Z_th1 (a peak's power does, src/searcher.cpp:449) --
- * the peak list is exact all the same, and the latency of the repair stays off the single-buffer path.  Not applied by
- * lcs_foe_partial, where a near-tie may span two ranks' shares: there the index is exact except at such near-ties, whatever
- * the number of ranks. */
+ * the peak list is exact all the same, and the latency of the repair stays off the single-buffer path.  lcs_foe_partial does not
+ * repair (a near-tie may span two ranks' shares): lcs_foe_contend / lcs_foe_resolve settle those after the all-reduce. */
 int lcs_last_frq_repairs(lcs_ctx *ctx, int *n_positions);
 /* HIP-event time (ms) of the PSS correlation kernel launches of the last enqueue, and the
  * number of launches it covers; used by bench.py for the roofline figure. */
@@ -280,6 +279,17 @@ int lcs_foe_partial(lcs_ctx *ctx, const double *capbuf_re_im, uint32_t n_cap, co
                     void *d_words /*device int64[3][9600]*/, double *d_meta /*device double[9601]*/);
 int lcs_foe_finish(lcs_ctx *ctx, const void *d_words, const double *d_meta, const double *f_search_set, uint16_t n_f,
                    lcs_cell *cells, int32_t *order, int max_cells, int *n_cells, lcs_cell *peaks, int max_peaks, int *n_peaks);
+/* The exact index under the split (round 5), between the all-reduce of d_words and lcs_foe_finish:
+ *   lcs_foe_contend(ctx, f_search_set, n_f, d_words [reduced], d_words2 [device int64[3][9600], out])
+ *   MAX all-reduce of d_words2
+ *   lcs_foe_resolve(ctx, d_words, d_words2)
+ * A rank contends for a position when a hypothesis of its own other than the global winner lies within 4e-6 (relative) of the
+ * global maximum; it recomputes its contenders and the winner in the reference's arithmetic (see lcs_last_frq_repairs) and packs
+ * the exact first maximum into d_words2 (-1 where it does not contend).  After the second all-reduce and lcs_foe_resolve the words
+ * -- index and power -- are the reference's at every near-tie, identically for every world size and every split of the grid.
+ * Without these two calls the index is exact except at near-ties (the rounds before). */
+int lcs_foe_contend(lcs_ctx *ctx, const double *f_search_set, uint16_t n_f, const void *d_words, void *d_words2);
+int lcs_foe_resolve(lcs_ctx *ctx, void *d_words, const void *d_words2);
 
 /* ---- streaming mode: LTE-Tracker's searcher thread (src/searcher_thread.cpp:83-246) ----------
  * One 80 ms capture buffer at a time, a single frequency hypothesis (the tracked frequency offset,

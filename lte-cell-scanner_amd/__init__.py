@@ -210,6 +210,16 @@ class Searcher:
         self._chk(self._lib.lcs_foe_partial(self._h, _dp(cap), cap.size, _dp(f), f.size, int(f_first), int(f_count), fc_requested,
                                             fc_programmed, fs_programmed, C.c_void_p(d_words_ptr), C.c_void_p(d_meta_ptr)), "lcs_foe_partial")
 
+    def foe_contend(self, f_search_set, d_words_ptr: int, d_words2_ptr: int):
+        """After the MAX all-reduce of the words: this rank's exact packed maxima at the positions it contends for (-1 elsewhere)
+        into d_words2, which the caller MAX-all-reduces in turn (lcs_foe_contend)."""
+        f = np.ascontiguousarray(f_search_set, np.float64)
+        self._chk(self._lib.lcs_foe_contend(self._h, _dp(f), f.size, C.c_void_p(d_words_ptr), C.c_void_p(d_words2_ptr)), "lcs_foe_contend")
+
+    def foe_resolve(self, d_words_ptr: int, d_words2_ptr: int):
+        """The reduced exact words take the place of the approximate ones (lcs_foe_resolve); then foe_finish."""
+        self._chk(self._lib.lcs_foe_resolve(self._h, C.c_void_p(d_words_ptr), C.c_void_p(d_words2_ptr)), "lcs_foe_resolve")
+
     def foe_finish(self, d_words_ptr: int, d_meta_ptr: int, f_search_set, max_cells: int = MAX_PEAKS):
         """-> (cells this rank decoded, their positions in the peak list, the whole peak list)"""
         f = np.ascontiguousarray(f_search_set, np.float64)

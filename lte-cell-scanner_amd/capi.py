@@ -66,7 +66,7 @@ EXPORTS = [
     "lcs_xcorr_pss", "lcs_peak_search", "lcs_sss_detect", "lcs_pss_sss_foe", "lcs_extract_tfg", "lcs_tfoec",
     "lcs_decode_mib", "lcs_chan_est", "lcs_search_capbuf", "lcs_search_batch_dev", "lcs_search_batch_host", "lcs_batch_enqueue",
     "lcs_batch_collect", "lcs_batch_readback", "lcs_batch_enqueue_host", "lcs_host_alloc", "lcs_host_free", "lcs_device_alloc", "lcs_device_free", "lcs_device_upload", "lcs_device_count",
-    "lcs_foe_partial", "lcs_foe_finish", "lcs_track_block", "lcs_track_stats", "lcs_track_stream_block", "lcs_track_stream_reset", "lcs_stream_open", "lcs_stream_push", "lcs_stream_collect", "lcs_stream_close",
+    "lcs_foe_partial", "lcs_foe_finish", "lcs_foe_contend", "lcs_foe_resolve", "lcs_track_block", "lcs_track_stats", "lcs_track_stream_block", "lcs_track_stream_reset", "lcs_stream_open", "lcs_stream_push", "lcs_stream_collect", "lcs_stream_close",
     "lcs_last_xcorr_ms", "lcs_last_xcorr_info", "lcs_last_frq_repairs", "lcs_last_collect_host_us", "lcs_stream", "lcs_sync", "lcs_table_pss_td", "lcs_table_pss_fd", "lcs_table_sss_fd",
     "lcs_table_lte_pn", "lcs_chi2cdf_inv",
 ]
@@ -130,6 +130,9 @@ def load() -> C.CDLL:
     L.lcs_batch_collect.argtypes = [vp, cp, C.c_int, C.POINTER(C.c_int)]
     L.lcs_foe_partial.argtypes = [vp, dp, C.c_uint32, dp, C.c_uint16, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, vp, vp]
     L.lcs_foe_finish.argtypes = [vp, vp, vp, dp, C.c_uint16, cp, ip, C.c_int, C.POINTER(C.c_int), cp, C.c_int, C.POINTER(C.c_int)]
+    if hasattr(L, "lcs_foe_contend"):
+        L.lcs_foe_contend.argtypes = [vp, dp, C.c_uint16, vp, vp]
+        L.lcs_foe_resolve.argtypes = [vp, vp, vp]
     L.lcs_track_block.argtypes = [vp, C.POINTER(LcsTrackCell), C.c_int, C.c_int, vp, C.c_int, dp, dp, dp, C.c_double, C.c_double, C.c_double,
                                   dp, dp, dp, ip, dp, C.c_int, ip, ip, C.POINTER(C.c_uint64), C.c_int, C.POINTER(C.c_float)]
     L.lcs_track_stats.argtypes = [vp, C.c_int, C.c_int, dp, dp, C.c_int, dp, dp, C.c_int, ip]

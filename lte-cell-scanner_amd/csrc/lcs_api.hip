@@ -79,6 +79,8 @@ int ensure_ws(lcs_ctx *c, int n_slots, uint32_t n_cap, int n_f, bool debug, int 
   A(frq, S * NE);
   A(fix_list, S * NE);
   A(n_fix, 4);
+  A(second32, S * NE);
+  A(fset_g, (size_t)LCS_NF_MAX);
   A(spinc, S * LCS_N_IDX);
   A(zth, S * LCS_N_IDX);
   A(peaks, S * LCS_MAXP);
@@ -362,7 +364,7 @@ void lcs_destroy(lcs_ctx *c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->stream_xc) (void)hipStreamSynchronize(c->stream_xc);
   void *ptrs[] = {c->cap32, c->cap64, c->params, c->fset, c->tmpl, c->start, c->smin, c->kp2, c->btab, c->single,
-                  c->incoh, c->sref, c->pow_, c->work, c->spinc, c->zth, c->sp, c->frq, c->fix_list, c->n_fix, c->peaks, c->npeaks, c->xc,
+                  c->incoh, c->sref, c->pow_, c->work, c->spinc, c->zth, c->sp, c->frq, c->fix_list, c->n_fix, c->second32, c->fset_g, c->peaks, c->npeaks, c->xc,
                   c->work_items, c->n_work, c->tfg, c->tfg_comp, c->ce, c->tfg_ts, c->tfg_desc, c->tfg_ts_comp, c->cell_scratch,
                   c->cells_out, c->d_pss_td, c->d_pss_fd, c->d_sss_fd, c->d_pbch_scr, c->d_derm_inv, c->d_dbg, c->pk_items, c->n_pk,
                   c->sss_ws, c->d_pn_jump, c->cap8, c->cap8s, c->brow8, c->tq, c->tsc, c->cap16h, c->cap16l, c->brow16, c->texp16, c->tsc16, c->xmax16, c->xpart16, c->h2d, c->trk_td, c->trk_syms, c->trk_raw, c->trk_ce,
@@ -982,8 +984,8 @@ int lcs_foe_partial(lcs_ctx *c, const double *capbuf, uint32_t n_cap, const doub
   XcGeom geo;
   if ((rc = upload_host_capbuf(c, capbuf, n_cap, f_search_set + first, cnt, 2, fc_req, fc_prog, fs_prog, false, &geo))) return rc;
   if ((rc = ensure_percell(c))) return rc;
-  // no tie repair here: a near-tie may span two ranks' shares, and what a rank does must not depend on how the grid was split
-  // (the collapsed arrays after the all-reduce are bit-identical for every world size; exact except at near-ties, lcs.h)
+  // no tie repair here: a near-tie may span two ranks' shares -- lcs_foe_contend settles them after the all-reduce, identically
+  // for every split; the collapse keeps the runner-up values for it
   c->skip_frq_repair = true;
   rc = lcs_launch_xcorr(c, 1, geo, false, false);
   c->skip_frq_repair = false;
@@ -994,6 +996,34 @@ int lcs_foe_partial(lcs_ctx *c, const double *capbuf, uint32_t n_cap, const doub
   c->foe_geo = geo;
   c->foe_n_cap = n_cap;
   c->foe_ready = true;
+  return LCS_OK;
+}
+
+// Exactness of the split (round 5).  The packed MAX decides between float values that the kernels reproduce to ~1e-7: where two
+// hypotheses -- of one rank or of two -- lie closer than LCS_FRQ_TIE_EPS, the winner has to be decided in the reference's own
+// arithmetic (k_frq_repair).  After the all-reduce of d_words every rank knows the global maximum of every position; it CONTENDS
+// for a position when a hypothesis of its own other than the winner lies within the distance of that maximum, recomputes its
+// contenders AND the global winner exactly (it holds the whole buffer and the whole grid), and writes the packed exact first
+// maximum into d_words2 (-1 elsewhere).  The caller MAX-all-reduces d_words2 -- the exact first maximum over every contender of
+// every rank, identical whatever the split -- and lcs_foe_resolve puts those words in place of the approximate ones.
+int lcs_foe_contend(lcs_ctx *c, const double *f_search_set, uint16_t n_f, const void *d_words, void *d_words2) {
+  if (!c) return LCS_ERR_BAD_ARG;
+  if (!c->foe_ready) { c->err = "lcs_foe_contend needs the lcs_foe_partial call of the same buffer first"; return LCS_ERR_BAD_ARG; }
+  if (!f_search_set || !d_words || !d_words2 || n_f < 1 || n_f > LCS_NF_MAX) { c->err = "bad argument"; return LCS_ERR_BAD_ARG; }
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipMemcpyAsync(c->fset_g, f_search_set, sizeof(double) * n_f, hipMemcpyHostToDevice, c->stream));
+  int rc;
+  if ((rc = lcs_launch_foe_contend(c, c->foe_geo, c->fset_g, static_cast<const long long *>(d_words), static_cast<long long *>(d_words2)))) return rc;
+  HIPCHK(c, hipStreamSynchronize(c->stream));      // the caller's collective runs on another stream (and f_search_set may go away)
+  return LCS_OK;
+}
+
+int lcs_foe_resolve(lcs_ctx *c, void *d_words, const void *d_words2) {
+  if (!c || !d_words || !d_words2) return LCS_ERR_BAD_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc;
+  if ((rc = lcs_launch_foe_resolve(c, static_cast<long long *>(d_words), static_cast<const long long *>(d_words2)))) return rc;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
   return LCS_OK;
 }
 

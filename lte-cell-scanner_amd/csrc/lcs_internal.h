@@ -190,6 +190,8 @@ struct lcs_ctx {
   int *frq = nullptr;
   unsigned *fix_list = nullptr;      // [S][3][9600]: positions (slot * 3 + t) * 9600 + idx whose arg-max is a near-tie (capacity: every position)
   int *n_fix = nullptr;              // [4]: entries on the list (zeroed by k_prep_tables)
+  float *second32 = nullptr;         // [S][3][9600]: the runner-up of the collapse's maximum (written for lcs_foe_partial only: lcs_foe_contend reads it)
+  double *fset_g = nullptr;          // [LCS_NF_MAX]: the whole grid, for lcs_foe_contend (fset holds the rank's share then)
   bool repair_peaks_only = false;    // lcs_search_capbuf / the streaming chain: list only the near-ties at or above their position's Z_th1 (pss_xcorr.hip: collapse_flag)
   bool skip_frq_repair = false;      // lcs_foe_partial: a rank sees only its share of the hypotheses (a near-tie may span two ranks)
   lcs_cell *peaks = nullptr;
@@ -321,6 +323,8 @@ int lcs_launch_ingest(lcs_ctx *c, const void *d_src, int fmt, int n_buf, uint32_
 int lcs_launch_ingest_c128(lcs_ctx *c, uint32_t n_cap, bool *exact);   // cap64 -> cap32 + int8 copies; exact: every component is (u8 - 127) / 128
 int lcs_launch_xcorr(lcs_ctx *c, int n_buf, const XcGeom &geo, bool want_incoh, bool time_it);
 int lcs_launch_single_layout(lcs_ctx *c, const XcGeom &geo, int slot, float *ref_layout, int to_ref);   // group-major <-> [t][idx][foi]
+int lcs_launch_foe_contend(lcs_ctx *c, const XcGeom &geo, const double *fset_g, const long long *d_words, long long *d_words2);
+int lcs_launch_foe_resolve(lcs_ctx *c, long long *d_words, const long long *d_words2);
 // pss_xcorr_i8.hip
 int lcs_launch_fill_brow_i8(lcs_ctx *c, int n_buf, const XcGeom &geo);
 int lcs_launch_xcorr_i8(lcs_ctx *c, hipStream_t sxc, const XcGeom &geo, int slot0, int n_slots, int xcd_map);

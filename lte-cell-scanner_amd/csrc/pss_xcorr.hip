@@ -554,7 +554,7 @@ template <int DS, bool INCOH>
 __global__ __launch_bounds__(256) void k_collapse(const float *__restrict__ sg, float *__restrict__ incoh,
                                                    double *__restrict__ pow_, float *__restrict__ pow32,
                                                    int *__restrict__ frq, unsigned *__restrict__ fix_list, int *__restrict__ n_fix,
-                                                   const double *__restrict__ zth, XcGeom geo, int n_buf) {
+                                                   const double *__restrict__ zth, float *__restrict__ second32, XcGeom geo, int n_buf) {
   LCS_TAIL_PRIO();
   constexpr int CT = 64;                           // positions per workgroup
   static_assert(LCS_N_IDX % CT == 0 && LCS_TG == 16, "k_collapse tiles 9600 positions x 16 columns");
@@ -624,6 +624,7 @@ __global__ __launch_bounds__(256) void k_collapse(const float *__restrict__ sg, 
       pow_[o] = (double)r.v;
       pow32[o] = r.v;                                                  // what the fused peak search loads
       frq[o] = r.foi;
+      if (second32) second32[o] = r.s;                                 // hypotheses split over GPUs: lcs_foe_contend compares it with the GLOBAL maximum
       collapse_flag(r, (unsigned)o, fix_list, n_fix, zth);
     }
   }
@@ -656,7 +657,7 @@ typedef unsigned int collapse_u4 __attribute__((ext_vector_type(4)));
 // workgroups leave free on a SIMD; the allocator otherwise spreads over the 64 its occupancy target allows)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(28))) void k_collapse_arm2(const float *__restrict__ sg, double *__restrict__ pow_, float *__restrict__ pow32,
                                                         int *__restrict__ frq, unsigned *__restrict__ fix_list, int *__restrict__ n_fix,
-                                                        const double *__restrict__ zth, XcGeom geo, int n_buf) {
+                                                        const double *__restrict__ zth, float *__restrict__ second32, XcGeom geo, int n_buf) {
   LCS_TAIL_PRIO();
   constexpr int CT = 4 * COLLAPSE_OUT;             // positions per workgroup
   static_assert(LCS_N_IDX % CT == 0 && LCS_TG == 16, "k_collapse_arm2 tiles 9600 positions x 16 columns");
@@ -718,6 +719,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(28))) void k_co
       pow_[o] = (double)rv;
       pow32[o] = rv;                                                   // what the fused peak search loads
       frq[o] = rf;
+      if (second32) second32[o] = rb.s;
       collapse_flag(rb, (unsigned)o, fix_list, n_fix, zth);
     }
   }
@@ -806,12 +808,17 @@ template <int KIND> struct RepairSample;
 template <> struct RepairSample<0> { typedef uint16_t T; static __device__ __forceinline__ double2 cvt(uint16_t p) { return make_double2(-(double)(int)(int8_t)(p & 255u) / 128.0, -(double)(int)(int8_t)(p >> 8) / 128.0); } };
 template <> struct RepairSample<1> { typedef float2 T; static __device__ __forceinline__ double2 cvt(float2 f) { return make_double2((double)f.x, (double)f.y); } };
 template <> struct RepairSample<2> { typedef double2 T; static __device__ __forceinline__ double2 cvt(double2 d) { return d; } };
-template <int KIND>
+// SPLIT (lcs_foe_contend: one buffer's hypotheses split over GPUs): the candidates are this rank's hypotheses within the distance
+// of the GLOBAL maximum (from the all-reduced words) plus the global winner itself, whoever owns it -- every rank holds the whole
+// buffer and the whole grid (fset = the GLOBAL grid here, this rank's hypotheses sit at foi0 ..) -- and the result goes into a
+// second word array that the caller MAX-all-reduces: the exact first maximum over every contender of every rank.
+template <int KIND, bool SPLIT>
 __global__ __launch_bounds__(REPAIR_THREADS) void k_frq_repair(const float *__restrict__ sg, const unsigned *__restrict__ fix_list,
                                                                const int *__restrict__ n_fix, const CapSrc src,
                                                                const SlotParams *__restrict__ params, const double *__restrict__ fset,
                                                                const double2 *__restrict__ pss_td, const int *__restrict__ start,
                                                                double *__restrict__ pow_, float *__restrict__ pow32, int *__restrict__ frq,
+                                                               const long long *__restrict__ words, long long *__restrict__ words2,
                                                                XcGeom geo) {
   LCS_TAIL_PRIO();
   typedef typename RepairSample<KIND>::T ST;
@@ -836,15 +843,23 @@ __global__ __launch_bounds__(REPAIR_THREADS) void k_frq_repair(const float *__re
     const float x1 = lane + 64 < geo.n_f ? repair_gpu_value(sgs, geo, 3 * (lane + 64) + t, idx) : -INFINITY;
     float mx = fmaxf(x0, x1);
     for (int o = 32; o; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    int g_win = -1;                                                      // SPLIT: the global winner's index in the whole grid
+    if (SPLIT) {
+      const long long gw = words[pos];
+      mx = __uint_as_float((unsigned)(gw >> 32));
+      g_win = (int)(0xFFFFFFFFu - (unsigned)(gw & 0xFFFFFFFFll));
+    }
     const float lim = mx * (1.0f - LCS_FRQ_TIE_EPS);
-    const unsigned long long m0 = __ballot(x0 >= lim), m1 = __ballot(x1 >= lim);
+    const unsigned long long m0 = (SPLIT && geo.foi0 < 0) ? 0ull : __ballot(x0 >= lim), m1 = (SPLIT && geo.foi0 < 0) ? 0ull : __ballot(x1 >= lim);
+    const bool win_remote = SPLIT && (geo.foi0 < 0 || g_win < geo.foi0 || g_win >= geo.foi0 + geo.n_f);
     float best = -INFINITY;
     int best_f = 0;
-    for (int half = 0; half < 2; ++half) {
-      unsigned long long m = half ? m1 : m0;
+    for (int half = 0; half < (SPLIT ? 3 : 2); ++half) {
+      unsigned long long m = half == 2 ? (win_remote ? 1ull : 0ull) : (half ? m1 : m0);
       while (m) {                                                        // ascending in foi: the reference's scan order
-        const int f = __builtin_ctzll(m) + 64 * half;
+        const int f_loc = half == 2 ? -1 : __builtin_ctzll(m) + 64 * half;        // -1: the remote winner
         m &= m - 1;
+        const int f = SPLIT ? (f_loc < 0 ? g_win : geo.foi0 + f_loc) : f_loc;      // index into fset
         // conj(fshift(pss_td, f_off, fs_programmed * k_factor)) / 137 in double (ref :146-151, dsp.h:40-53)
         const double f_off = fset[f];
         const double kf = (p.fc_req - f_off) / p.fc_prog;
@@ -855,7 +870,11 @@ __global__ __launch_bounds__(REPAIR_THREADS) void k_frq_repair(const float *__re
           const double2 s = pss_td[t * 137 + tid];
           s_tmpl[tid] = make_double2((s.x * cs - s.y * sn) / 137, -(s.x * sn + s.y * cs) / 137);
         }
-        const int *st = start + ((size_t)slot * LCS_NW_MAX) * LCS_NF_MAX + f;
+        // window starts: from the table (this rank's own hypotheses) or, for a hypothesis of another rank, by k_prep_tables' expression
+        const int *st = start + ((size_t)slot * LCS_NW_MAX) * LCS_NF_MAX + (SPLIT ? max(f_loc, 0) : f);
+        __shared__ int s_st[LCS_NW_MAX];
+        if (tid < LCS_NW_MAX) s_st[tid] = (SPLIT && f_loc < 0) ? (int)rint((((double)tid * .005) * kf) * p.fs_prog) : (tid < geo.n_comb ? st[(size_t)tid * LCS_NF_MAX] : 0);
+        __syncthreads();
         {
           // thread -> sample o of window w, all of a thread's loads in flight together.  Sample o of window w is what the positions
           // idx - arm .. idx + arm read at tap o - lag; the positions are circular in 9600 (ref :336): the run staged here starts at
@@ -867,7 +886,7 @@ __global__ __launch_bounds__(REPAIR_THREADS) void k_frq_repair(const float *__re
 #pragma unroll
             for (int u = 0; u < 5; ++u) {
               const int i = min(i0 + REPAIR_THREADS * u, n_it - 1), w = i / span, o = i - w * span;
-              v[u] = cap[at0 + (size_t)o + (size_t)st[(size_t)w * LCS_NF_MAX]];
+              v[u] = cap[at0 + (size_t)o + (size_t)s_st[w]];
             }
 #pragma unroll
             for (int u = 0; u < 5; ++u) {
@@ -892,7 +911,7 @@ __global__ __launch_bounds__(REPAIR_THREADS) void k_frq_repair(const float *__re
             }
           } else {                                       // the few lags on the other side of the wrap: straight from memory
             const int iw = ii < 0 ? ii + LCS_N_IDX : (ii >= LCS_N_IDX ? ii - LCS_N_IDX : ii);
-            const size_t k0 = (size_t)iw + (size_t)st[(size_t)w * LCS_NF_MAX];
+            const size_t k0 = (size_t)iw + (size_t)s_st[w];
             for (int mm = 0; mm < 137; ++mm) {
               const double2 a = s_tmpl[mm], b = RepairSample<KIND>::cvt(cap[k0 + mm]);
               ar += a.x * b.x - a.y * b.y;
@@ -912,16 +931,39 @@ __global__ __launch_bounds__(REPAIR_THREADS) void k_frq_repair(const float *__re
         float v = s_lag[geo.ds];
         for (int d = 1; d <= geo.ds; ++d) v = v + (s_lag[geo.ds - d] + s_lag[geo.ds + d]);
         v = __fdiv_rn(v, (float)n_lag);
-        if (v > best) { best = v; best_f = f; }                          // strict: the lowest index wins a tie (ref :374)
+        if (v > best || (SPLIT && v == best && f < best_f)) { best = v; best_f = f; }      // strict: the lowest index wins a tie (ref :374)
         __syncthreads();                                                 // the LDS arrays are rewritten by the next candidate
       }
     }
     if (tid == 0) {
-      pow_[pos] = (double)best;
-      pow32[pos] = best;
-      frq[pos] = best_f;
+      if (SPLIT) words2[pos] = ((long long)__float_as_uint(best) << 32) | (long long)(0xFFFFFFFFu - (unsigned)best_f);
+      else {
+        pow_[pos] = (double)best;
+        pow32[pos] = best;
+        frq[pos] = best_f;
+      }
     }
   }
+}
+
+// lcs_foe_contend, first kernel: which positions does this rank contend for?  The owner of the global winner where its own
+// runner-up lies within the distance of the maximum; any other rank where its best does.  words2 starts at -1 (below every word).
+__global__ __launch_bounds__(256) void k_foe_flag(const long long *__restrict__ words, const float *__restrict__ pow32, const float *__restrict__ second32,
+                                                  long long *__restrict__ words2, unsigned *__restrict__ fix_list, int *__restrict__ n_fix, XcGeom geo) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 3 * LCS_N_IDX) return;
+  words2[i] = -1;
+  if (geo.foi0 < 0) return;                              // a rank without hypotheses
+  const long long gw = words[i];
+  const float g = __uint_as_float((unsigned)(gw >> 32));
+  const int win = (int)(0xFFFFFFFFu - (unsigned)(gw & 0xFFFFFFFFll));
+  const bool mine = win >= geo.foi0 && win < geo.foi0 + geo.n_f;
+  const float contender = mine ? second32[i] : pow32[i];
+  if (g > 0.f && contender >= g * (1.0f - LCS_FRQ_TIE_EPS)) fix_list[atomicAdd(n_fix, 1)] = (unsigned)i;
+}
+__global__ __launch_bounds__(256) void k_foe_resolve(long long *__restrict__ words, const long long *__restrict__ words2) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 3 * LCS_N_IDX && words2[i] >= 0) words[i] = words2[i];
 }
 
 // ------------------------------------------------------------------------------ launch
@@ -1047,23 +1089,45 @@ int lcs_launch_xcorr(lcs_ctx *c, int n_buf, const XcGeom &geo, bool want_incoh, 
     float *incoh = want_incoh ? c->incoh : nullptr;
     float *pow32 = reinterpret_cast<float *>(c->work);
     const double *zf = c->repair_peaks_only ? c->zth : nullptr;      // fused single-buffer chains: only near-ties that can become a peak
+    float *s2 = c->skip_frq_repair ? c->second32 : nullptr;          // lcs_foe_partial: the runner-up values for lcs_foe_contend
     if (geo.ds == 2 && !incoh && geo.cpg == LCS_TG)
-      hipLaunchKernelGGL(k_collapse_arm2, dim3((LCS_N_IDX / (4 * COLLAPSE_OUT)) * n_buf), block, 0, c->stream, c->single, c->pow_, pow32, c->frq, c->fix_list, c->n_fix, zf, geo, n_buf);
-    else if (geo.ds == 2 && !incoh) hipLaunchKernelGGL((k_collapse<2, false>), grid, block, 0, c->stream, c->single, incoh, c->pow_, pow32, c->frq, c->fix_list, c->n_fix, zf, geo, n_buf);
-    else if (!incoh) hipLaunchKernelGGL((k_collapse<-1, false>), grid, block, 0, c->stream, c->single, incoh, c->pow_, pow32, c->frq, c->fix_list, c->n_fix, zf, geo, n_buf);   // any arm, no debug copy
-    else hipLaunchKernelGGL((k_collapse<-1, true>), grid, block, 0, c->stream, c->single, incoh, c->pow_, pow32, c->frq, c->fix_list, c->n_fix, zf, geo, n_buf);
+      hipLaunchKernelGGL(k_collapse_arm2, dim3((LCS_N_IDX / (4 * COLLAPSE_OUT)) * n_buf), block, 0, c->stream, c->single, c->pow_, pow32, c->frq, c->fix_list, c->n_fix, zf, s2, geo, n_buf);
+    else if (geo.ds == 2 && !incoh) hipLaunchKernelGGL((k_collapse<2, false>), grid, block, 0, c->stream, c->single, incoh, c->pow_, pow32, c->frq, c->fix_list, c->n_fix, zf, s2, geo, n_buf);
+    else if (!incoh) hipLaunchKernelGGL((k_collapse<-1, false>), grid, block, 0, c->stream, c->single, incoh, c->pow_, pow32, c->frq, c->fix_list, c->n_fix, zf, s2, geo, n_buf);   // any arm, no debug copy
+    else hipLaunchKernelGGL((k_collapse<-1, true>), grid, block, 0, c->stream, c->single, incoh, c->pow_, pow32, c->frq, c->fix_list, c->n_fix, zf, s2, geo, n_buf);
     // near-ties of the arg-max, recomputed in the reference's arithmetic (a few positions per buffer; the kernel loops over the list)
     if (!c->skip_frq_repair && geo.n_f > 1) {             // (one hypothesis -- the streaming mode -- has no arg-max to repair: one graph node less)
       const CapSrc cs = lcs_cap_src(c, geo.n_cap);
       const int ng = std::min(512, 8 * n_buf);
-#define REPAIR_LAUNCH(KIND) hipLaunchKernelGGL((k_frq_repair<KIND>), dim3(ng), dim3(REPAIR_THREADS), 0, c->stream, c->single, c->fix_list, \
-                                               c->n_fix, cs, c->params, c->fset, c->d_pss_td, c->start, c->pow_, pow32, c->frq, geo)
+#define REPAIR_LAUNCH(KIND) hipLaunchKernelGGL((k_frq_repair<KIND, false>), dim3(ng), dim3(REPAIR_THREADS), 0, c->stream, c->single, c->fix_list, \
+                                               c->n_fix, cs, c->params, c->fset, c->d_pss_td, c->start, c->pow_, pow32, c->frq, nullptr, nullptr, geo)
       if (cs.c8) REPAIR_LAUNCH(0);
       else if (cs.c32) REPAIR_LAUNCH(1);
       else REPAIR_LAUNCH(2);
 #undef REPAIR_LAUNCH
     }
   }
+  HIPCHK(c, hipGetLastError());
+  return LCS_OK;
+}
+
+// lcs_foe_contend / lcs_foe_resolve (lcs_api.hip): fset_g = the WHOLE grid on the device
+int lcs_launch_foe_contend(lcs_ctx *c, const XcGeom &geo, const double *fset_g, const long long *d_words, long long *d_words2) {
+  HIPCHK(c, hipMemsetAsync(c->n_fix, 0, sizeof(int), c->stream));
+  float *pow32 = reinterpret_cast<float *>(c->work);
+  hipLaunchKernelGGL(k_foe_flag, dim3((3 * LCS_N_IDX + 255) / 256), dim3(256), 0, c->stream, d_words, pow32, c->second32, d_words2, c->fix_list, c->n_fix, geo);
+  const CapSrc cs = lcs_cap_src(c, geo.n_cap);
+#define CONTEND_LAUNCH(KIND) hipLaunchKernelGGL((k_frq_repair<KIND, true>), dim3(512), dim3(REPAIR_THREADS), 0, c->stream, c->single, c->fix_list, c->n_fix, cs, \
+                                                c->params, fset_g, c->d_pss_td, c->start, c->pow_, pow32, c->frq, d_words, d_words2, geo)
+  if (cs.c8) CONTEND_LAUNCH(0);
+  else if (cs.c32) CONTEND_LAUNCH(1);
+  else CONTEND_LAUNCH(2);
+#undef CONTEND_LAUNCH
+  HIPCHK(c, hipGetLastError());
+  return LCS_OK;
+}
+int lcs_launch_foe_resolve(lcs_ctx *c, long long *d_words, const long long *d_words2) {
+  hipLaunchKernelGGL(k_foe_resolve, dim3((3 * LCS_N_IDX + 255) / 256), dim3(256), 0, c->stream, d_words, d_words2);
   HIPCHK(c, hipGetLastError());
   return LCS_OK;
 }

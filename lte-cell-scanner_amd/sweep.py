@@ -230,7 +230,8 @@ def search_capbuf_foe_split_dev(searcher, capbuf, f_search_set, fc_requested, fc
     """The same split with everything between the correlation and the peak search staying on the GPUs: `searcher`
     (a Searcher on this rank's GPU) leaves the packed (pow, ~foi) words and the power estimate in two torch tensors on
     `device` (lcs_foe_partial), torch.distributed reduces / broadcasts them in place (RCCL: one 230 KB MAX all-reduce, one
-    77 KB broadcast -- no host copy of any array), lcs_foe_finish takes them back.  Only the decoded cell records (a few
+    77 KB broadcast, and a second 230 KB MAX all-reduce of the exactly recomputed near-ties, lcs_foe_contend -- no host copy of
+    any array), lcs_foe_finish takes them back.  Only the decoded cell records (a few
     hundred bytes) travel through the host, in one all-gather.  Returns (cells in peak order, peak list)."""
     import torch
     f = np.asarray(f_search_set, np.float64)
@@ -244,6 +245,14 @@ def search_capbuf_foe_split_dev(searcher, capbuf, f_search_set, fc_requested, fc
         dist.all_reduce(words, op=dist.ReduceOp.MAX)
         dist.broadcast(meta, src=0)
         torch.cuda.synchronize(dev)
+    # near-ties of the arg-max (within one rank's share or across two): every contending rank recomputes its contenders and the
+    # global winner in the reference's arithmetic; a second MAX all-reduce makes the exact winner everybody's (lcs.h)
+    words2 = torch.empty(3 * 9600, dtype=torch.int64, device=dev)
+    searcher.foe_contend(f, words.data_ptr(), words2.data_ptr())
+    if dist is not None:
+        dist.all_reduce(words2, op=dist.ReduceOp.MAX)
+        torch.cuda.synchronize(dev)
+    searcher.foe_resolve(words.data_ptr(), words2.data_ptr())
     cells, order, peaks = searcher.foe_finish(words.data_ptr(), meta.data_ptr(), f)
     rec = np.zeros(MAXC, cell_dtype())
     ordv = np.full(MAXC, -1, np.int32)

@@ -174,10 +174,10 @@ def test_foe_split_two_contexts_emulate_two_ranks():
     pkg = load_pkg()
     cap = iq_u8_to_capbuf(golden("capbuf_0000")["iq_u8"])
     fc, fs = 739e6, 1.92e6
-    f = f_search_set_for(fc, 100)
+    f = f_search_set_for(fc, 120)        # 37 hypotheses: this buffer then has two near-ties of the arg-max (none with the 31 of ppm 100)
     O.set_threads(8)
     exp, exp_peaks = O.search_capbuf(cap, f, fc, fc, fs)
-    shares = [(0, 16), (16, 15), (0, 0)]
+    shares = [(0, 19), (19, 18), (0, 0)]
     with pkg.Searcher(0) as A, pkg.Searcher(0) as B, pkg.Searcher(0) as Z:
         ctxs = [A, B, Z]
         words = [torch.empty(3 * 9600, dtype=torch.int64, device="cuda") for _ in ctxs]
@@ -186,8 +186,40 @@ def test_foe_split_two_contexts_emulate_two_ranks():
             S.foe_partial(cap, f, a, n, fc, fc, fs, w.data_ptr(), m.data_ptr())
         assert int(words[2].max()) == -1                       # the empty share never wins
         red = torch.maximum(torch.maximum(words[0], words[1]), words[2])
+        # round 5: near-ties of the arg-max -- inside a share or across the two -- are settled in the reference's arithmetic: every
+        # context packs the exact maxima of the positions it contends for, their MAX replaces the approximate words
+        w2 = [torch.empty(3 * 9600, dtype=torch.int64, device="cuda") for _ in ctxs]
+        for S, x in zip(ctxs, w2):
+            S.foe_contend(f, red.data_ptr(), x.data_ptr())
+        assert int(w2[2].max()) == -1
+        red2 = torch.maximum(torch.maximum(w2[0], w2[1]), w2[2])
+        reds = [red.clone() for _ in ctxs]
+        for S, x in zip(ctxs, reds):
+            S.foe_resolve(x.data_ptr(), red2.data_ptr())
+        assert torch.equal(reds[0], reds[1]) and torch.equal(reds[0], reds[2])
+        ro = O.xcorr_pss(cap, f, 2, fc, fc, fs)
+        pw, fq = pkg.sweep.unpack_pow_frq(reds[0].cpu().numpy().reshape(3, 9600))
+        settled = (red2.cpu().numpy().reshape(3, 9600) >= 0)
+        assert settled.sum() >= 1 and np.array_equal(fq, ro["frq"])                      # EVERY index equal to the oracle's
+        assert np.array_equal(pw[settled], ro["pow"][settled])                            # and the settled powers are the reference's own floats
+        assert (np.abs(pw - ro["pow"]) / ro["pow"]).max() < 1e-5
+        # the same buffer split differently, and not split at all: identical words
+        for shares_b in ([(0, 7), (7, 30)], [(0, 37)]):
+            wb = [torch.empty(3 * 9600, dtype=torch.int64, device="cuda") for _ in shares_b]
+            for S, (a, n), w in zip(ctxs, shares_b, wb):
+                S.foe_partial(cap, f, a, n, fc, fc, fs, w.data_ptr(), meta[1].data_ptr())
+            rb = wb[0] if len(wb) == 1 else torch.maximum(wb[0], wb[1])
+            wb2 = [torch.empty(3 * 9600, dtype=torch.int64, device="cuda") for _ in shares_b]
+            for S, x in zip(ctxs, wb2):
+                S.foe_contend(f, rb.data_ptr(), x.data_ptr())
+            rb2 = wb2[0] if len(wb2) == 1 else torch.maximum(wb2[0], wb2[1])
+            ctxs[0].foe_resolve(rb.data_ptr(), rb2.data_ptr())
+            assert torch.equal(rb, reds[0]), shares_b
+        # (back to the first split for the per-peak stages: the contexts' partial state is the last partial call's)
+        for S, (a, n), w, m in zip(ctxs, shares, words, meta):
+            S.foe_partial(cap, f, a, n, fc, fc, fs, w.data_ptr(), m.data_ptr())
         got, seen = [], []
-        for S in ctxs:
+        for S, red in zip(ctxs, reds):
             cells, order, peaks = S.foe_finish(red.data_ptr(), meta[0].data_ptr(), f)
             got += list(zip(order.tolist(), cells))
             seen.append([(p.n_id_2, p.freq, p.reserved) for p in peaks])
