@@ -105,12 +105,11 @@ __device__ __forceinline__ int win_bin62(int l, int q) {
 }
 // One window per lane group with the peak's rotation factors prepared before (win_rot_prepare: they depend on the peak's
 // frequency only, so a wave computes them once per peak and keeps the table in LDS for all of the peak's occurrences)
+template <int KIND>
 __device__ __forceinline__ void win_fft8(const CapView &cap, long loc, bool valid, const WinRot &r, uint32_t n_cap, int lane, cd2 *tb, const cd2 *tw,
                                          const cd2 *trot, cd2 (&x)[16]) {
   const int l = lane & 7;
-  if (cap.c8) win_load16<0>(cap, loc, l, n_cap, valid, x);
-  else if (cap.c32) win_load16<1>(cap, loc, l, n_cap, valid, x);
-  else win_load16<2>(cap, loc, l, n_cap, valid, x);
+  win_load16<KIND>(cap, loc, l, n_cap, valid, x);
   win_rotate16(x, r, lane, trot);
   fft128_x8(x, tb, tw, lane);
 }
@@ -201,6 +200,7 @@ __device__ __forceinline__ SssGeo sss_geometry(const lcs_cell &cell, const SlotP
 // kind w % 3 = PSS window, extended-CP SSS window, normal-CP SSS window, ref :578-597); slots 6, 7 idle.
 #define SW_WAVES 4           // independent waves per workgroup (a workgroup then fills the slot of the correlation workgroup it displaces)
 #define SW_THREADS (64 * SW_WAVES)
+template <int KIND>      // the source format (one instantiation each: the register allocation of a kernel holding all three load paths is the widest one's)
 __global__ __launch_bounds__(SW_THREADS) void k_sss_win(const lcs_cell *__restrict__ peaks, const int *__restrict__ npeaks, int n_buf,
                                                         WorkItem *__restrict__ items, int *__restrict__ n_items,
                                                         const CapSrc src,
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(SW_THREADS) void k_sss_win(const lcs_cell *__restri
       const long pss_dft = (long)(pss_loc + 9 - 2);
       const long loc = (kind == 0) ? pss_dft : (kind == 1 ? pss_dft - 128 - 32 : pss_dft - 128 - 9);
       cd2 x[16];
-      win_fft8(cap, loc, valid, rot, n_cap, lane, tb, tw, trot, x);
+      win_fft8<KIND>(cap, loc, valid, rot, n_cap, lane, tb, tw, trot, x);
       double *rec = ws + (size_t)it * SW_ITEM + (size_t)k * SW_REC;
       if (valid) {
 #pragma unroll
@@ -433,6 +433,7 @@ __device__ __forceinline__ FoeGeo foe_geometry(const lcs_cell &cell, const SlotP
 #define FW_WAVES 4
 #define FW_THREADS (64 * FW_WAVES)
 #define FW_QUADS (MAX_HF / 4)
+template <int KIND>
 __global__ __launch_bounds__(FW_THREADS) void k_foe_win(const lcs_cell *__restrict__ peaks, const WorkItem *__restrict__ items,
                                                         const int *__restrict__ n_items,
                                                         const CapSrc src,
@@ -477,7 +478,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_foe_win(const lcs_cell *__restri
       const uint32_t sss_loc = (uint32_t)d_round_i(g.first_sss + k * g.step);
       const long loc = is_sss ? (long)sss_loc : (long)(sss_loc + g.pss_sss_dist);
       cd2 x[16];
-      win_fft8(cap, loc, valid, rot, n_cap, lane, tb, tw, trot, x);
+      win_fft8<KIND>(cap, loc, valid, rot, n_cap, lane, tb, tw, trot, x);
       if (valid) {
         // the slot number toggles with every occurrence, starting from sn_init (ref :800, :813)
         const int sn = ((k & 1) == 0) ? g.sn_init : 10 - g.sn_init;
@@ -552,14 +553,22 @@ static int run_sss_foe(lcs_ctx *c, int n_buf, uint32_t n_cap, double thresh2, in
   const int item_grid = (int)std::min<size_t>(cap_items, LCS_ITEM_GRID);
   if (!(mode & 1)) hipLaunchKernelGGL(k_peak_list, dim3(1), dim3(64), 0, c->stream, c->npeaks, n_buf, c->pk_items, c->n_pk);
   if (mode & 1) {
-    hipLaunchKernelGGL(k_sss_win, dim3(win_grid), dim3(SW_THREADS), 0, c->stream, c->peaks, c->npeaks, n_buf, c->pk_items, c->n_pk, src,
-                       n_cap, c->params, c->d_pss_fd, c->sss_ws);
+#define SSW_LAUNCH(KIND) hipLaunchKernelGGL(k_sss_win<KIND>, dim3(win_grid), dim3(SW_THREADS), 0, c->stream, c->peaks, c->npeaks, n_buf, c->pk_items, c->n_pk, src, \
+                                            n_cap, c->params, c->d_pss_fd, c->sss_ws)
+    if (src.c8) SSW_LAUNCH(0);
+    else if (src.c32) SSW_LAUNCH(1);
+    else SSW_LAUNCH(2);
+#undef SSW_LAUNCH
     hipLaunchKernelGGL(k_sss_ml, dim3(item_grid), dim3(SF_THREADS), 0, c->stream, c->peaks, c->pk_items, c->n_pk, n_cap,
                        c->params, thresh2, c->d_sss_fd, c->sss_ws, dbg);
   }
   if (mode & 2) {
-    hipLaunchKernelGGL(k_foe_win, dim3((int)std::min<size_t>((cap_items * FW_QUADS + 3) / 4, LCS_WIN_GRID)), dim3(FW_THREADS), 0, c->stream, c->peaks, c->pk_items, c->n_pk, src,
-                       n_cap, c->params, c->d_pss_fd, c->d_sss_fd, c->sss_ws);
+#define FOW_LAUNCH(KIND) hipLaunchKernelGGL(k_foe_win<KIND>, dim3((int)std::min<size_t>((cap_items * FW_QUADS + 3) / 4, LCS_WIN_GRID)), dim3(FW_THREADS), 0, c->stream, \
+                                            c->peaks, c->pk_items, c->n_pk, src, n_cap, c->params, c->d_pss_fd, c->d_sss_fd, c->sss_ws)
+    if (src.c8) FOW_LAUNCH(0);
+    else if (src.c32) FOW_LAUNCH(1);
+    else FOW_LAUNCH(2);
+#undef FOW_LAUNCH
     hipLaunchKernelGGL(k_foe_fin, dim3((unsigned)((cap_items + 63) / 64)), dim3(64), 0, c->stream, c->peaks, c->pk_items,
                        c->n_pk, n_cap, c->params, c->sss_ws);
   }

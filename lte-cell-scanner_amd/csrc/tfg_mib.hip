@@ -295,6 +295,8 @@ __device__ __forceinline__ void tfg_load16(const CapView &cap, long loc, int l, 
     if (!((in_mask >> j) & 1u)) x[j] = mk(0, 0);
   }
 }
+// (one instantiation per source format: with the three formats' load paths in one kernel the register allocation is the widest one's)
+template <int KIND>
 __global__ __launch_bounds__(TFG_THREADS) void k_tfg(const WorkItem *__restrict__ items, const int *__restrict__ n_work,
                                                      const CapSrc src, uint32_t n_cap, double *__restrict__ scratch,
                                                      const char *__restrict__ desc, double2 *__restrict__ tfg, int needed_only) {
@@ -320,9 +322,7 @@ __global__ __launch_bounds__(TFG_THREADS) void k_tfg(const WorkItem *__restrict_
     cd2 x[16];
     bool oob = false;
     const long loc = (long)d_round_i(d.ideal);
-    if (cap.c8) tfg_load16<0>(cap, loc, l, n_cap, x, oob);
-    else if (cap.c32) tfg_load16<1>(cap, loc, l, n_cap, x, oob);
-    else tfg_load16<2>(cap, loc, l, n_cap, x, oob);
+    tfg_load16<KIND>(cap, loc, l, n_cap, x, oob);
     if (row >= 0) {
       // sample n = l + 8 j of the window is rotated by cis(pi kk (loc + n)): [window factor x position factor l] x position
       // factor 8 j, the latter as P(8 (j & 3)) P(32 (j >> 2)) -- six table values (uniform: scalar loads) instead of sixteen
@@ -1020,8 +1020,13 @@ int lcs_launch_pack_results(lcs_ctx *c, int n_buf, bool full) {
 int lcs_launch_tfg(lcs_ctx *c, uint32_t n_cap, bool with_rs) {
   hipLaunchKernelGGL(k_cell_prep, dim3(c->grid_items), dim3(CP_THREADS), 0, c->stream, c->cells_out, c->work_items, c->n_work, c->params,
                      c->d_pn_jump, c->tfg_ts, c->cell_scratch, c->tfg_desc, with_rs ? 3 : 1, c->needed_rows_only ? 1 : 0);
-  hipLaunchKernelGGL(k_tfg, dim3(LCS_TFG_GRID), dim3(TFG_THREADS), 0, c->stream, c->work_items, c->n_work,
-                     lcs_cap_src(c, n_cap), n_cap, c->cell_scratch, c->tfg_desc, c->tfg, c->needed_rows_only ? 1 : 0);
+  const CapSrc cs = lcs_cap_src(c, n_cap);
+#define TFG_LAUNCH(KIND) hipLaunchKernelGGL(k_tfg<KIND>, dim3(LCS_TFG_GRID), dim3(TFG_THREADS), 0, c->stream, c->work_items, c->n_work, cs, n_cap, \
+                                            c->cell_scratch, c->tfg_desc, c->tfg, c->needed_rows_only ? 1 : 0)
+  if (cs.c8) TFG_LAUNCH(0);
+  else if (cs.c32) TFG_LAUNCH(1);
+  else TFG_LAUNCH(2);
+#undef TFG_LAUNCH
   HIPCHK(c, hipGetLastError());
   return LCS_OK;
 }

@@ -98,13 +98,14 @@ def test_chain_kernels_fit_beside_one_correlation_workgroup():
             if not m:
                 continue
             if m.group(1) == "Function Name":
-                cur = next((k for k in limits if f"{len(k)}{k}" in m.group(2)), None)
+                cur = next((k for k in limits if f"{len(k)}{k}" in m.group(2)), None)      # every instantiation (one per source format)
                 if cur:
-                    limits[cur] = {}
+                    limits[cur] = (limits[cur] or []) + [{"name": m.group(2)}]
             elif cur:
-                limits[cur][m.group(1).split()[0]] = int(m.group(2))
-    for k, v in limits.items():
-        assert v and "VGPRs" in v, (k, v)
-        regs = -(-(v["VGPRs"] + v.get("AGPRs", 0)) // 8) * 8
-        assert regs <= 280, f"{k}: {v['VGPRs']} + {v.get('AGPRs', 0)} registers -> {regs} allocated: does not fit beside a resident correlation workgroup (284 free)"
-        assert v["LDS"] <= 77 * 1024, (k, v)
+                limits[cur][-1][m.group(1).split()[0]] = int(m.group(2))
+    for k, insts in limits.items():
+        assert insts and len(insts) == 3, (k, insts)
+        for v in insts:
+            regs = -(-(v["VGPRs"] + v.get("AGPRs", 0)) // 8) * 8
+            assert regs <= 280, f"{v['name']}: {v['VGPRs']} + {v.get('AGPRs', 0)} registers -> {regs} allocated: does not fit beside a resident correlation workgroup (284 free)"
+            assert v["LDS"] <= 77 * 1024, (k, v)
