@@ -53,9 +53,9 @@ def f_grid(freq_start, ppm):
 GRIDS = ((739e6, 100.0), (715e6, 120.0), (739e6, 120.0))      # n_f = 31 (bench), 35 (configs[3]), 37 (the CLI default)
 
 
-def synthetic_scene(synth, s):
+def synthetic_scene(synth, s, seed_offset=0):
     """Scene s of 64: the noise-free signal of 0-3 cells and the parameters the receiver reports."""
-    rng = np.random.default_rng(50_000 + s)
+    rng = np.random.default_rng(50_000 + s + 1000 * seed_offset)
     fc, ppm = GRIDS[s % 3]
     f = f_grid(fc, ppm)
     fc_req = fc + 100e3 * (s % 7)
@@ -73,7 +73,7 @@ def synthetic_scene(synth, s):
     return dict(sig=sig, ref_pow=ref_pow, f=f, fc_req=fc_req, fc_prog=fc_prog, fs_prog=fs_prog, planted=cells)
 
 
-def build_population(pkg, groups, limit=None, dense_limit=None):
+def build_population(pkg, groups, limit=None, dense_limit=None, seed_offset=0):
     """-> list of dict(name, group, iq (uint8 [2 n_cap]), f, fc_req, fc_prog, fs_prog, n_planted)."""
     import bench
     synth = pkg.synth
@@ -81,9 +81,9 @@ def build_population(pkg, groups, limit=None, dense_limit=None):
     if "synthetic" in groups:
         n_scenes = 64 if limit is None else max(1, min(64, limit // 8))
         for s in range(n_scenes):
-            sc = synthetic_scene(synth, s)
+            sc = synthetic_scene(synth, s, seed_offset)
             for v in range(8):
-                rng = np.random.default_rng(90_000 + 8 * s + v)
+                rng = np.random.default_rng(90_000 + 8 * s + v + 10_000 * seed_offset)
                 sig = np.roll(sc["sig"], int(rng.integers(0, N_CAP))) if v else sc["sig"]
                 iq = synth.add_noise_and_quantise(rng, sig, sc["ref_pow"], SNRS[v], rms=float(rng.uniform(0.08, 0.22)))
                 items.append(dict(name=f"synthetic/scene{s:02d}/snr{SNRS[v]:+.0f}dB/v{v}", group="synthetic", iq=iq, f=sc["f"],
@@ -270,14 +270,14 @@ def compare(it, g, o):
                      frq_near_ties_1e_6=int(np.count_nonzero(o["frq_margin"] < 1e-6)), frq_min_margin=float(o["frq_margin"].min()))
 
 
-def run(groups=("synthetic", "bench", "dense"), limit=None, workers=None, out_path=None, quiet=False, dense_limit=None):
+def run(groups=("synthetic", "bench", "dense"), limit=None, workers=None, out_path=None, quiet=False, dense_limit=None, seed_offset=0):
     t_start = time.perf_counter()
     workers = workers or max(1, min(len(os.sched_getaffinity(0)), 32))
     # the oracle's worker processes start BEFORE this process touches the GPU runtime (fork of a process with live HIP threads is unsafe)
     pool = mp.get_context("fork").Pool(workers)
     import __graft_entry__ as ge
     pkg = ge.load_package()
-    items = build_population(pkg, groups, limit, dense_limit)
+    items = build_population(pkg, groups, limit, dense_limit, seed_offset)
     t_built = time.perf_counter()
     res_async = pool.imap(oracle_job, items, chunksize=1)
     gpu, n_repairs, t_gpu = gpu_pass(pkg, items)
@@ -311,6 +311,7 @@ def run(groups=("synthetic", "bench", "dense"), limit=None, workers=None, out_pa
         by_stage[d["stage"]] = by_stage.get(d["stage"], 0) + 1
     report = dict(
         what="GPU chain (lcs_batch_enqueue / _collect / _readback) against oracle/lcs_oracle.c on the same capture buffers",
+        groups=list(groups), seed_offset=seed_offset,
         totals=tot, per_group=per_group, disagreements=len(all_dis), disagreements_by_stage=by_stage,
         disagreement_rate_per_buffer=len(all_dis) / max(1, tot["buffers"]),
         gpu_frq_positions_repaired=n_repairs,
@@ -335,7 +336,8 @@ if __name__ == "__main__":
     ap.add_argument("--limit", type=int, default=None, help="quick runs: at most this many buffers per group (synthetic: whole scenes of 8; bench: a quarter of it from each of the four batches)")
     ap.add_argument("--dense-limit", type=int, default=None)
     ap.add_argument("--workers", type=int, default=None)
+    ap.add_argument("--seed-offset", type=int, default=0, help="other synthetic scenes and noise realisations (the bench's and the dense band's buffers are fixed)")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "parity_population.json"))
     a = ap.parse_args()
-    r = run(tuple(a.groups.split(",")), a.limit, a.workers, a.out, dense_limit=a.dense_limit)
+    r = run(tuple(a.groups.split(",")), a.limit, a.workers, a.out, dense_limit=a.dense_limit, seed_offset=a.seed_offset)
     sys.exit(0 if r["disagreements"] == 0 else 1)
