@@ -4,12 +4,12 @@
 #include "lcs_internal.h"
 
 struct cd2 { double re, im; };
-__device__ __forceinline__ cd2 mk(double a, double b) { cd2 r; r.re = a; r.im = b; return r; }
+__host__ __device__ __forceinline__ cd2 mk(double a, double b) { cd2 r; r.re = a; r.im = b; return r; }
 // exp(j x): one sincos call (one argument reduction; cos(x) and sin(x) as two calls cost 1.8 x the instructions)
 __device__ __forceinline__ cd2 cis(double x) { double s_, c_; sincos(x, &s_, &c_); return mk(c_, s_); }
 // exp(j x) for |x| <= 1 (callers state why): Taylor polynomials in x^2 to x^17 / x^18, Horner with fused multiply-adds; absolute
 // error <= 1.5e-16 over the interval (checked against extended precision on 2 M points) at 21 instructions instead of ~100
-__device__ __forceinline__ cd2 cis_small(double x) {
+__host__ __device__ __forceinline__ cd2 cis_small(double x) {
   const double z = x * x;
   double s_ = 2.8114572543455208e-15;            // 1/17!
   s_ = fma(s_, z, -7.6471637318198165e-13);      // -1/15!
@@ -32,13 +32,13 @@ __device__ __forceinline__ cd2 cis_small(double x) {
   c_ = fma(c_, z, 1.0);
   return mk(c_, x * s_);
 }
-__device__ __forceinline__ cd2 cadd(cd2 a, cd2 b) { return mk(a.re + b.re, a.im + b.im); }
-__device__ __forceinline__ cd2 csub(cd2 a, cd2 b) { return mk(a.re - b.re, a.im - b.im); }
-__device__ __forceinline__ cd2 cmul(cd2 a, cd2 b) { return mk(a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re); }
-__device__ __forceinline__ cd2 cconj(cd2 a) { return mk(a.re, -a.im); }
-__device__ __forceinline__ cd2 cscale(cd2 a, double s) { return mk(a.re * s, a.im * s); }
-__device__ __forceinline__ cd2 cdivr(cd2 a, double s) { return mk(a.re / s, a.im / s); }
-__device__ __forceinline__ double cabs2(cd2 a) { return a.re * a.re + a.im * a.im; }
+__host__ __device__ __forceinline__ cd2 cadd(cd2 a, cd2 b) { return mk(a.re + b.re, a.im + b.im); }
+__host__ __device__ __forceinline__ cd2 csub(cd2 a, cd2 b) { return mk(a.re - b.re, a.im - b.im); }
+__host__ __device__ __forceinline__ cd2 cmul(cd2 a, cd2 b) { return mk(a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re); }
+__host__ __device__ __forceinline__ cd2 cconj(cd2 a) { return mk(a.re, -a.im); }
+__host__ __device__ __forceinline__ cd2 cscale(cd2 a, double s) { return mk(a.re * s, a.im * s); }
+__host__ __device__ __forceinline__ cd2 cdivr(cd2 a, double s) { return mk(a.re / s, a.im / s); }
+__host__ __device__ __forceinline__ double cabs2(cd2 a) { return a.re * a.re + a.im * a.im; }
 __device__ __forceinline__ cd2 ld(const double2 *p) { const double2 v = *p; return mk(v.x, v.y); }
 __device__ __forceinline__ void st(double2 *p, cd2 v) { *p = make_double2(v.re, v.im); }
 // std::complex division for finite operands (libgcc __divdc3 main path)
@@ -74,13 +74,13 @@ __device__ __forceinline__ int cn_of(int i) { return (i < 36) ? (i - 36) : (i - 
 // four waves per SIMD (128 registers) -- with a 17 KB buffer it saw two, used all 256, and the kernels no longer fitted
 // beside ONE resident correlation workgroup (284 registers are free there): k_sss_win waited 1 ms for a whole CU.
 #define FFT128_WSTRIDE 68                               // entries (16 B) per window in the transpose buffer
-__device__ __forceinline__ cd2 cmul_mi(cd2 a) { return mk(a.im, -a.re); }                       // a * (-i)
-__device__ __forceinline__ void fft4(cd2 &a0, cd2 &a1, cd2 &a2, cd2 &a3) {                      // forward, in place, natural order
+__host__ __device__ __forceinline__ cd2 cmul_mi(cd2 a) { return mk(a.im, -a.re); }                       // a * (-i)
+__host__ __device__ __forceinline__ void fft4(cd2 &a0, cd2 &a1, cd2 &a2, cd2 &a3) {                      // forward, in place, natural order
   const cd2 t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), t3 = cmul_mi(csub(a1, a3));
   a0 = cadd(t0, t2); a2 = csub(t0, t2); a1 = cadd(t1, t3); a3 = csub(t1, t3);
 }
 // x[n], n = 4 n1 + n2 -> X[k], k = k1 + 4 k2: a 4-point transform over n1 per n2, twiddles W16^(n2 k1), a 4-point transform over n2
-__device__ __forceinline__ void fft16(cd2 (&x)[16]) {
+__host__ __device__ __forceinline__ void fft16(cd2 (&x)[16]) {
   const double C1 = 0.92387953251128673848, S1 = 0.38268343236508978178, R2 = 0.70710678118654752440;   // cos, sin (pi / 8), sqrt(1/2)
 #pragma unroll
   for (int n2 = 0; n2 < 4; ++n2) fft4(x[n2], x[4 + n2], x[8 + n2], x[12 + n2]);      // x[4 k1 + n2] = A_n2[k1]
@@ -91,9 +91,9 @@ __device__ __forceinline__ void fft16(cd2 (&x)[16]) {
 #pragma unroll
   for (int k1 = 0; k1 < 4; ++k1) fft4(x[4 * k1], x[4 * k1 + 1], x[4 * k1 + 2], x[4 * k1 + 3]);   // x[4 k1 + k2] = X[k1 + 4 k2]
 }
-__device__ __forceinline__ cd2 fft16_out(const cd2 (&x)[16], int k) { return x[4 * (k & 3) + (k >> 2)]; }    // X[k] after fft16
+__host__ __device__ __forceinline__ cd2 fft16_out(const cd2 (&x)[16], int k) { return x[4 * (k & 3) + (k >> 2)]; }    // X[k] after fft16
 // 8 points in place: x[l] -> X[k1] at x[k1]
-__device__ __forceinline__ void fft8(cd2 (&x)[8]) {
+__host__ __device__ __forceinline__ void fft8(cd2 (&x)[8]) {
   const double R2 = 0.70710678118654752440;
   // l = 2 l1 + l2, k1 = q1 + 4 q2:  B_l2[q1] = sum_l1 x[2 l1 + l2] W4^(l1 q1);  X[q1 + 4 q2] = B_0[q1] + (-1)^q2 W8^q1 B_1[q1]
   fft4(x[0], x[2], x[4], x[6]);

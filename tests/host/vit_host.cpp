@@ -31,3 +31,39 @@ extern "C" int vit_host_forms_agree(const double *d_est /*[3][40]*/) {
   return a == b;
 }
 extern "C" int vit_host_crc_ok(unsigned long long bits, int n_ports) { return pbch_crc_ok(bits, n_ports); }
+
+// ---- the register-resident transform's building blocks (lte_device.h: fft16, fft8, cis_small), the same __host__ __device__ code the
+// kernels run; tests/test_viterbi_host.py compares them with numpy's FFT and libm
+extern "C" void fft_host_16(const double *in_re_im, double *out_re_im) {
+  cd2 x[16];
+  for (int j = 0; j < 16; ++j) x[j] = mk(in_re_im[2 * j], in_re_im[2 * j + 1]);
+  fft16(x);
+  for (int k = 0; k < 16; ++k) { const cd2 v = fft16_out(x, k); out_re_im[2 * k] = v.re; out_re_im[2 * k + 1] = v.im; }
+}
+extern "C" void fft_host_8(const double *in_re_im, double *out_re_im) {
+  cd2 x[8];
+  for (int j = 0; j < 8; ++j) x[j] = mk(in_re_im[2 * j], in_re_im[2 * j + 1]);
+  fft8(x);
+  for (int k = 0; k < 8; ++k) { out_re_im[2 * k] = x[k].re; out_re_im[2 * k + 1] = x[k].im; }
+}
+// the whole 128-point transform in the kernels' decomposition (lane l holds points l + 8 j; 16-point transforms, twiddles W128^(l k2),
+// 8-point transforms over l: X[k2 + 16 k1]) -- the data movement of fft128_x8 written as plain loops
+extern "C" void fft_host_128(const double *in_re_im, double *out_re_im) {
+  cd2 z[8][16];
+  for (int l = 0; l < 8; ++l) {
+    cd2 x[16];
+    for (int j = 0; j < 16; ++j) x[j] = mk(in_re_im[2 * (l + 8 * j)], in_re_im[2 * (l + 8 * j) + 1]);
+    fft16(x);
+    for (int k2 = 0; k2 < 16; ++k2) {
+      const double a = -M_PI * (double)(l * k2) / 64.0;
+      z[l][k2] = k2 ? cmul(fft16_out(x, k2), mk(cos(a), sin(a))) : fft16_out(x, k2);
+    }
+  }
+  for (int k2 = 0; k2 < 16; ++k2) {
+    cd2 y[8];
+    for (int l = 0; l < 8; ++l) y[l] = z[l][k2];
+    fft8(y);
+    for (int k1 = 0; k1 < 8; ++k1) { out_re_im[2 * (k2 + 16 * k1)] = y[k1].re; out_re_im[2 * (k2 + 16 * k1) + 1] = y[k1].im; }
+  }
+}
+extern "C" void cis_small_host(double x, double *out) { const cd2 v = cis_small(x); out[0] = v.re; out[1] = v.im; }

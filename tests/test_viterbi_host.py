@@ -123,3 +123,29 @@ def test_decodes_clean_codewords_and_crc(libs):
         for p in (1, 2, 4):
             want = int(p == n_ports)
             assert H.vit_host_crc_ok(word, p) == want == O.orc_pbch_crc_ok(c_est.ctypes.data_as(C.POINTER(C.c_uint8)), p)
+
+
+def test_register_transform_building_blocks_on_the_host(libs):
+    """fft16 / fft8 of lte_device.h (the in-register halves of the kernels' 128-point transform) and their composition with the
+    W128 twiddles against numpy's FFT; cis_small (the polynomial exp(jx) the grid kernel uses for |x| <= 0.4) against libm over
+    its whole stated range |x| <= 1."""
+    L = libs[0]
+    dp = C.POINTER(C.c_double)
+    rng = np.random.default_rng(5)
+    for n, fn in ((16, L.fft_host_16), (8, L.fft_host_8), (128, L.fft_host_128)):
+        fn.argtypes = [dp, dp]
+        fn.restype = None
+        for _ in range(20):
+            x = rng.normal(size=n) + 1j * rng.normal(size=n)
+            o = np.empty(n, np.complex128)
+            fn(np.ascontiguousarray(x).ctypes.data_as(dp), o.ctypes.data_as(dp))
+            ref = np.fft.fft(x)
+            assert np.abs(o - ref).max() < 4e-14 * np.abs(ref).max(), n
+    L.cis_small_host.argtypes = [C.c_double, dp]
+    L.cis_small_host.restype = None
+    out = np.empty(2)
+    worst = 0.0
+    for x in np.concatenate([np.linspace(-1.0, 1.0, 20001), rng.uniform(-0.4, 0.4, 20000), [0.0, 1e-300, -1e-9]]):
+        L.cis_small_host(float(x), out.ctypes.data_as(dp))
+        worst = max(worst, abs(out[0] - np.cos(x)), abs(out[1] - np.sin(x)))
+    assert worst < 2.5e-16, worst       # 1.5e-16 against extended precision + libm's own half ulp
