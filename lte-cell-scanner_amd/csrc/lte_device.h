@@ -32,6 +32,14 @@ __host__ __device__ __forceinline__ cd2 cis_small(double x) {
   c_ = fma(c_, z, 1.0);
   return mk(c_, x * s_);
 }
+// Real calls, not inlined.  An inlined sincos / atan2 expansion (and cis_small's eighteen coefficients) is ~100 instructions whose
+// 64-bit literals the compiler materialises in VGPR pairs and hoists out of the kernel's job loop: every inlined copy costs a
+// kernel tens of registers for its whole lifetime (round 5 measured: k_tfg 164 -> 126, k_tfoec_est 161 -> 121, k_chan_est
+// 155 -> 127 with the calls below -- the difference between one workgroup and two in the slot a retired correlation workgroup
+// leaves, tests/test_tables_abi.py).  Same instructions, same values.
+__device__ __attribute__((noinline)) static cd2 cis_call(double x) { return cis(x); }
+__device__ __attribute__((noinline)) static cd2 cis_small_call(double x) { return cis_small(x); }
+__device__ __attribute__((noinline)) static double atan2_call(double y, double x) { return atan2(y, x); }
 __host__ __device__ __forceinline__ cd2 cadd(cd2 a, cd2 b) { return mk(a.re + b.re, a.im + b.im); }
 __host__ __device__ __forceinline__ cd2 csub(cd2 a, cd2 b) { return mk(a.re - b.re, a.im - b.im); }
 __host__ __device__ __forceinline__ cd2 cmul(cd2 a, cd2 b) { return mk(a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re); }

@@ -74,9 +74,8 @@ __device__ __forceinline__ void win_load16(const CapView &cap, long loc, int l, 
 }
 // trot: this wave's [8][16] table in LDS.  The factors are computed BEFORE the samples are loaded (four sincos expansions with
 // sixteen samples live beside them needed every register the wave can have).
-// (a real call, not inlined: four inlined sincos expansions pushed k_sss_win to 256 + 26 registers -- 288 as allocated, more than the
+// (cis_call is a real call, not inlined, lte_device.h: four inlined sincos expansions pushed k_sss_win to 256 + 26 registers -- 288 as allocated, more than the
 // 284 a SIMD has free beside one resident correlation workgroup, tests/test_tables_abi.py)
-__device__ __attribute__((noinline)) cd2 cis_call(double x) { return cis(x); }
 struct WinRot { cd2 cu, cw; };
 __device__ __forceinline__ WinRot win_rot_prepare(double k, int lane, cd2 *trot) {
   const int w = lane >> 3, l = lane & 7;
@@ -334,8 +333,8 @@ __global__ __launch_bounds__(SF_THREADS) void k_sss_ml(lcs_cell *__restrict__ pe
         const double tv = (double)(i < 62 ? first[i] : second[i - 62]);
         acc = cadd(acc, cmul(cconj(est[i]), mk(tv, 0)));
       }
-      const double ang = atan2(acc.im, acc.re);
-      const cd2 rot = cis(-ang);
+      const double ang = atan2_call(acc.im, acc.re);
+      const cd2 rot = cis_call(-ang);
       double s1 = 0, s2 = 0;
       for (int i = 0; i < 124; ++i) {      // the two sums of ref :649 keep their own order; x/np as x*(1/np)
         const double tv = (double)(i < 62 ? first[i] : second[i - 62]);

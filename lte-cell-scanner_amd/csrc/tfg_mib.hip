@@ -349,8 +349,8 @@ __global__ __launch_bounds__(TFG_THREADS) void k_tfg(const WorkItem *__restrict_
       k_im = k_im * 2; k_im = k_im * M_PI; k_im = k_im * late; k_im = k_im / 128;
       // the timing phase ramp cis(k_im cn), cn = bin (1..36) or bin - 128 (-36..-1), bin = (l + 8 c) + 16 k1: cis(k_im (l + 8 c))
       // x cis(16 k_im m) with m = k1 or k1 - 8 in -3 .. 2; |k_im| <= pi / 128, so every argument below is < 0.4
-      const cd2 e0 = cis_small(k_im * (double)l), e1 = cis_small(k_im * (double)(l + 8));
-      const cd2 f1 = cis_small(k_im * 16.0), f2 = cmul(f1, f1), f3 = cmul(f2, f1);
+      const cd2 e0 = cis_small_call(k_im * (double)l), g8 = cis_small_call(k_im * 8.0), e1 = cmul(e0, g8);     // cis(k_im (l + 8))
+      const cd2 f1 = cmul(g8, g8), f2 = cmul(f1, f1), f3 = cmul(f2, f1);
       double2 *out = tfg + ((size_t)it * ROWS + row) * NSC;
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
@@ -391,7 +391,7 @@ __device__ __forceinline__ cd2 foc_row_rot(double ts_t, double k_res, double res
   const double tc = k_res * ts_t;
   double a_im = 1.0;
   a_im = a_im * 2; a_im = a_im * M_PI; a_im = a_im * (-residual_f); a_im = a_im * tc; a_im = a_im / (FS_LTE / 16);
-  return cis(a_im);
+  return cis_call(a_im);
 }
 __device__ __forceinline__ cd2 foc_value(const double2 *g, int t, int i, double ts_t, double k_res, cd2 rot_f) {
   const double tc = k_res * ts_t;
@@ -400,7 +400,7 @@ __device__ __forceinline__ cd2 foc_value(const double2 *g, int t, int i, double 
   k_im = k_im * 2; k_im = k_im * M_PI; k_im = k_im * late; k_im = k_im / 128;
   const double ph = k_im * (double)cn_of(i);
   const cd2 v = cmul(ld(&g[(size_t)t * NSC + i]), rot_f);
-  return cmul(v, cis(ph));
+  return cmul(v, cis_call(ph));
 }
 
 #define TF_THREADS 256
@@ -502,7 +502,7 @@ __device__ __forceinline__ cd2 toc_subcarrier_rot(double delay, int i) {
   double k_im = 1.0;
   k_im = k_im * 2; k_im = k_im * M_PI; k_im = k_im / 128; k_im = k_im * delay;
   const double ph = k_im * (double)cn_of(i);
-  return cis(ph);
+  return cis_call(ph);
 }
 
 #define TFA_ROWS 8

@@ -88,24 +88,39 @@ def test_chain_kernels_fit_beside_one_correlation_workgroup():
     import subprocess
     csrc = os.path.join(ROOT, "lte-cell-scanner_amd", "csrc")
     limits = {"k_sss_win": None, "k_foe_win": None, "k_tfg": None}
+    pairs = {"k_tfg": None, "k_tfoec_est": None, "k_chan_est": None, "k_sss_ml": None}       # two workgroups per freed slot (below)
     for f in ("sss_foe.hip", "tfg_mib.hip"):
         p = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-c", "--cuda-device-only",
                             "-Rpass-analysis=kernel-resource-usage", os.path.join(csrc, f), "-o", os.devnull], capture_output=True, text=True, timeout=900)
         assert p.returncode == 0, p.stderr[-2000:]
         cur = None
         for line in p.stderr.splitlines():
-            m = re.search(r"remark:\s+(Function Name|VGPRs|AGPRs|LDS Size \[bytes/block\]): (\S+)", line)
+            m = re.search(r"remark:\s+(Function Name|VGPRs|AGPRs|ScratchSize \[bytes/lane\]|LDS Size \[bytes/block\]): (\S+)", line)
             if not m:
                 continue
             if m.group(1) == "Function Name":
                 cur = next((k for k in limits if f"{len(k)}{k}" in m.group(2)), None)      # every instantiation (one per source format)
+                cur2 = next((k for k in pairs if f"{len(k)}{k}" in m.group(2)), None)
                 if cur:
                     limits[cur] = (limits[cur] or []) + [{"name": m.group(2)}]
-            elif cur:
-                limits[cur][-1][m.group(1).split()[0]] = int(m.group(2))
+                if cur2:
+                    pairs[cur2] = (pairs[cur2] or []) + [{"name": m.group(2)}]
+            else:
+                if cur:
+                    limits[cur][-1][m.group(1).split()[0]] = int(m.group(2))
+                if cur2:
+                    pairs[cur2][-1][m.group(1).split()[0]] = int(m.group(2))
     for k, insts in limits.items():
         assert insts and len(insts) == 3, (k, insts)
         for v in insts:
             regs = -(-(v["VGPRs"] + v.get("AGPRs", 0)) // 8) * 8
             assert regs <= 280, f"{v['name']}: {v['VGPRs']} + {v.get('AGPRs', 0)} registers -> {regs} allocated: does not fit beside a resident correlation workgroup (284 free)"
             assert v["LDS"] <= 77 * 1024, (k, v)
+    # The kernels of which TWO workgroups fit that slot (2 x 136 <= 284 registers, 2 x 43264 <= 163840 - 77312 bytes of LDS): they were
+    # 155-164 registers wide until their sincos / atan2 / polynomial expansions became real calls (lte_device.h: cis_call ...), whose
+    # 64-bit literals the compiler had kept in registers for the kernels' whole lifetime (profiles/r05/experiments: dense band + 2.5 %).
+    for k, insts in pairs.items():
+        assert insts, k
+        for v in insts:
+            regs = -(-(v["VGPRs"] + v.get("AGPRs", 0)) // 8) * 8
+            assert regs <= 136 and v["LDS"] <= 43264 and v.get("ScratchSize", 0) == 0, (k, v)
