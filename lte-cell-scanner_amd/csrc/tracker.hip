@@ -835,13 +835,22 @@ extern "C" int lcs_track_stream_block(lcs_ctx *c, lcs_track_cell *cells, int n_c
     if (n_tail > 0)
       HIPCHK(c, hipMemcpy2DAsync(c->trk_syms, sizeof(double2) * 72 * (size_t)L, st->d_tail[cp], sizeof(double2) * 72 * (size_t)n_tail,
                                  sizeof(double2) * 72 * (size_t)n_tail, G, hipMemcpyDeviceToDevice, c->stream));
+    // the new samples: the group's cells are consecutive in td when the stream has one CP type (the usual case) -- then ONE strided
+    // copy places them all behind their carried rows (64 cells: 64 copies of 2 MB each were 0.3-0.5 ms of a call's host and
+    // copy-engine time); cells of a mixed stream go one by one
+    bool one_copy = true;
+    for (int g = 1; g < G; ++g) one_copy = one_copy && idx[g] == idx[0] + g;
+    if (one_copy)
+      HIPCHK(c, hipMemcpy2DAsync(c->trk_td + (size_t)n_tail * 128, sizeof(double2) * 128 * (size_t)L, tdv + (size_t)idx[0] * n_sym * 256,
+                                 sizeof(double2) * 128 * (size_t)n_sym, sizeof(double2) * 128 * (size_t)n_sym, G, hipMemcpyDefault, c->stream));
     for (int g = 0; g < G; ++g) {
       const TrkStreamCell &sc = st->cells[idx[g]];
       gc[g] = cells[idx[g]];
       gc[g].bulk_phase_offset = sc.bpo_before_tail;
       // (hipMemcpyDefault: td may be pageable host memory, page-locked host memory -- DMA'd in place -- or device memory)
-      HIPCHK(c, hipMemcpyAsync(c->trk_td + ((size_t)g * L + n_tail) * 128, tdv + (size_t)idx[g] * n_sym * 256, sizeof(double2) * 128 * (size_t)n_sym,
-                               hipMemcpyDefault, c->stream));
+      if (!one_copy)
+        HIPCHK(c, hipMemcpyAsync(c->trk_td + ((size_t)g * L + n_tail) * 128, tdv + (size_t)idx[g] * n_sym * 256, sizeof(double2) * 128 * (size_t)n_sym,
+                                 hipMemcpyDefault, c->stream));
       auto join = [&](const std::vector<double> &tail, const double *fresh, std::vector<double> &out) {
         std::copy(tail.begin(), tail.end(), out.begin() + (size_t)g * L);
         std::copy(fresh + (size_t)idx[g] * n_sym, fresh + (size_t)(idx[g] + 1) * n_sym, out.begin() + (size_t)g * L + n_tail);
