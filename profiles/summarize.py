@@ -24,8 +24,16 @@ for name in ("bench_full_n1.json", "bench_forced_dist_n1.json", "bench_full_n1_i
 for d, out in (("stats_full_p1", "kernel_stats_full_chain_b64_nf31_pipeline1.csv"),
                ("stats_full_default", "kernel_stats_full_chain_b128_nf31_default_command.csv"),
                ("stats_dense_default", "kernel_stats_dense_band_b128_nf31_default_command.csv"),
-               ("stats_c64_p1", "kernel_stats_full_chain_b64_nf31_c64_pipeline1.csv")):
+               ("stats_c64_p1", "kernel_stats_full_chain_b64_nf31_c64_pipeline1.csv"),
+               ("stats_track", "kernel_stats_tracker_block_64cells_980sym.csv"),
+               ("stats_stream", "kernel_stats_streaming_mode_nf1.csv")):
     f = sorted(glob.glob(os.path.join(src, d, "*", "*_kernel_stats.csv")), key=os.path.getmtime)     # newest collection wins
+    if f and d == "stats_track":
+        # two traced processes: bench.py itself (the stream form, the Python loop) and host/TrackBench, whose C++ loop is the timed
+        # one -- the file with the most tracker launches
+        def n_trk(path):
+            return sum(int(r["Calls"]) for r in csv.DictReader(open(path)) if r["Name"].startswith("k_trk_ce"))
+        f = sorted(f, key=n_trk)
     if f:
         shutil.copy(f[-1], os.path.join(dst, out))
 f = sorted(glob.glob(os.path.join(src, "stats_full_p1", "*", "*_agent_info.csv")), key=os.path.getmtime)
