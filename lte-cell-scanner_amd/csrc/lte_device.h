@@ -32,6 +32,22 @@ __host__ __device__ __forceinline__ cd2 cis_small(double x) {
   c_ = fma(c_, z, 1.0);
   return mk(c_, x * s_);
 }
+// WRAP of the reference (include/macros.h): x folded into [sm, lg)
+__host__ __device__ __forceinline__ double trk_wrap(double x, double sm, double lg) {
+  const double k = x - sm, n = lg - sm;
+  return ((n == 0) ? k : (k - n * (double)(int)floor(k / n))) + sm;
+}
+// The interval of k = x + pi in which the floor of WRAP(x, -pi, pi)'s quotient k / n is CERTAINLY fl: 1e-9 n inside the quotient's
+// integer bounds (the division is correctly rounded; 1e-9 is six orders of magnitude more than it or the bounds' own rounding can
+// move anything).  nf = n * fl as WRAP forms it.  k_trk_prep's walk subtracts nf where k lies inside and runs WRAP as written otherwise
+// (tests/test_viterbi_host.py: no k inside an interval whose fl is not WRAP's).
+__host__ __device__ __forceinline__ void trk_wrap_certain_interval(double fl, double &nf, double &lo, double &hi) {
+  const double n = M_PI - (-M_PI), g = n * 1e-9;
+  const bool sane = fl > -1e6 && fl < 1e6;                 // (double)(int) of WRAP is the identity there
+  nf = n * (double)(int)(sane ? fl : 0.0);
+  lo = sane ? nf + g : INFINITY;                           // not sane (or not finite): no k passes
+  hi = (nf + n) - g;
+}
 // Real calls, not inlined.  An inlined sincos / atan2 expansion (and cis_small's eighteen coefficients) is ~100 instructions whose
 // 64-bit literals the compiler materialises in VGPR pairs and hoists out of the kernel's job loop: every inlined copy costs a
 // kernel tens of registers for its whole lifetime (round 5 measured: k_tfg 164 -> 126, k_tfoec_est 161 -> 121, k_chan_est

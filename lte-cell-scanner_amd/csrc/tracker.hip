@@ -20,10 +20,7 @@
 #define FS_LTE 30720000.0
 #define TRK_MEAS 9
 
-__device__ __forceinline__ double trk_wrap(double x, double sm, double lg) {     // WRAP, include/macros.h
-  const double k = x - sm, n = lg - sm;
-  return ((n == 0) ? k : (k - n * (double)(int)floor(k / n))) + sm;
-}
+// (trk_wrap, trk_wrap_certain_interval: lte_device.h)
 __device__ __forceinline__ int trk_n_symb(const lcs_track_cell &c) { return c.cp_type == LCS_CP_NORMAL ? 7 : 6; }
 __device__ __forceinline__ double trk_sym_len(int cp_type, int sym) {            // samples from the previous DFT to this one's
   return (cp_type == LCS_CP_EXTENDED) ? 128 + 32 : ((sym == 0) ? 128 + 10 : 128 + 9);
@@ -34,13 +31,15 @@ __device__ __forceinline__ double trk_sym_len(int cp_type, int sym) {           
 // as the reference does), but nothing else about it is serial: the per-symbol increments are formed by all lanes into LDS
 // first and the results leave through LDS afterwards (round 3 loaded a frequency offset and stored a phase inside every step
 // of the walk: 0.29 us per step, the latency of the load -- 282 us of the block's 1.09 ms), and a port's symbol list is one
-// frame's pattern repeated (round 3: four lanes walking all symbols with a global read each).
+// frame's pattern repeated (round 3: four lanes walking all symbols with a global read each).  Round 5: a step of the walk was
+// still 0.15 us -- the fp64 DIVISION inside WRAP, whose only use is its floor: below.
 #define TRK_PREP_CHUNK 1024
 __global__ __launch_bounds__(128) void k_trk_prep(lcs_track_cell *__restrict__ cells, int n_sym, const double *__restrict__ freq_off,
                                                  const uint32_t *__restrict__ pn_jump, double *__restrict__ rs /*[c][140][24]*/,
                                                  double *__restrict__ shift /*[c][140][4]*/, double *__restrict__ bpo /*[c][n_sym]*/,
                                                  int *__restrict__ rs_idx /*[c][4][max_rs]*/, int *__restrict__ n_rs /*[c][4]*/, int max_rs) {
-  __shared__ double s_inc[TRK_PREP_CHUNK], s_b[TRK_PREP_CHUNK];
+  __shared__ double s_inc[TRK_PREP_CHUNK], s_b[TRK_PREP_CHUNK], s_w[TRK_PREP_CHUNK], s_nf[TRK_PREP_CHUNK], s_lo[TRK_PREP_CHUNK], s_hi[TRK_PREP_CHUNK];
+  __shared__ double s_part[128], s_start;
   __shared__ double s_sh[140 * 4];
   __shared__ int s_fl[4][44], s_cnt[4];
   const int cell = blockIdx.x, tid = threadIdx.x;
@@ -54,17 +53,65 @@ __global__ __launch_bounds__(128) void k_trk_prep(lcs_track_cell *__restrict__ c
     const int sym = (t == 2) ? (n_symb - 3) : t, row = slot * n_symb + sym;
     rs_dl_row(slot, t, id, c.cp_type, n_symb, pn_jump, rs + ((size_t)cell * 140 + row) * 24, sh + row * 4);
   }
-  // the bulk phase, TRK_PREP_CHUNK symbols at a time
+  // the bulk phase, TRK_PREP_CHUNK symbols at a time.  WRAP's quotient floor (how many turns a step folds away) does not need the
+  // walk: all lanes form the unwrapped phase by a prefix sum, its turn count after every step and so each step's
+  // n * floor -- with the SAME product WRAP forms -- and the interval of k in which that floor is certainly the one WRAP's division
+  // gives (1e-9 n inside the quotient's integer bounds; the prefix sum is good to 1e-12).  The walk is then four dependent additions a
+  // step on WRAP's own values and checks every k against its interval; a step outside it (never seen) sends the chunk through
+  // WRAP as written.
   double b = c.bulk_phase_offset;                     // carried by thread 64
+  if (tid == 64) s_start = b;
+  const double wn = M_PI - (-M_PI);
   for (int base = 0; base < n_sym; base += TRK_PREP_CHUNK) {
     const int n = min(TRK_PREP_CHUNK, n_sym - base);
-    for (int e = tid; e < n; e += 128) {
-      const int i = base + e;
-      s_inc[e] = 2 * M_PI * trk_sym_len(c.cp_type, i % n_symb) * (1 / (FS_LTE / 16)) * -freq_off[(size_t)cell * n_sym + i];
+    constexpr int PER = TRK_PREP_CHUNK / 128;
+    double loc[PER], run = 0;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      const int e = tid * PER + q, i = base + e;
+      const double inc = (e < n) ? 2 * M_PI * trk_sym_len(c.cp_type, i % n_symb) * (1 / (FS_LTE / 16)) * -freq_off[(size_t)cell * n_sym + i] : 0.0;
+      if (e < n) s_inc[e] = inc;
+      run += inc;
+      loc[q] = run;
+    }
+    s_part[tid] = run;
+    __syncthreads();
+    double off = 0;
+    for (int t = 0; t < tid; ++t) off += s_part[t];
+    const double start = s_start;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      const int e = tid * PER + q;
+      if (e < n) s_w[e] = floor((start + (off + loc[q]) + M_PI) / wn);            // turns folded away up to and including step e
     }
     __syncthreads();
-    if (tid == 64)
-      for (int e = 0; e < n; ++e) { b = trk_wrap(b + s_inc[e], -M_PI, M_PI); s_b[e] = b; }
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      const int e = tid * PER + q;
+      if (e < n) {
+        double nf, lo, hi;
+        trk_wrap_certain_interval(s_w[e] - (e ? s_w[e - 1] : 0.0), nf, lo, hi);
+        s_nf[e] = nf; s_lo[e] = lo; s_hi[e] = hi;
+      }
+    }
+    __syncthreads();
+    if (tid == 64) {
+      const double b0 = b;
+      int certain = 1;                                  // (no short-circuit: a branch per step would put the loads of a step in sequence)
+#pragma unroll 4
+      for (int e = 0; e < n; ++e) {
+        const double inc = s_inc[e], nf = s_nf[e], lo = s_lo[e], hi = s_hi[e];
+        const double k = (b + inc) - (-M_PI);
+        certain &= (int)(k >= lo) & (int)(k < hi);
+        b = (k - nf) + (-M_PI);
+        s_b[e] = b;
+      }
+      if (!certain) {
+        b = b0;
+        for (int e = 0; e < n; ++e) { b = trk_wrap(b + s_inc[e], -M_PI, M_PI); s_b[e] = b; }
+      }
+      s_start = b;
+    }
     __syncthreads();
     for (int e = tid; e < n; e += 128) bpo[(size_t)cell * n_sym + base + e] = s_b[e];
     __syncthreads();

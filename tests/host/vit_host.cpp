@@ -2,6 +2,7 @@
 // runs, with the 64 lanes walked sequentially): tests/test_viterbi_host.py compares it with the oracle's
 // exhaustive tail-biting decoder on random, quantised (tie-prone) and saturated inputs.  Test infrastructure.
 #include "../../lte-cell-scanner_amd/csrc/lte_device.h"
+#include <cstring>
 #include <vector>
 
 extern "C" int vit_host_decode(const double *d_est /*[3][40]*/, unsigned long long *bits40, int *best_ss, double *best_metric) {
@@ -67,3 +68,28 @@ extern "C" void fft_host_128(const double *in_re_im, double *out_re_im) {
   }
 }
 extern "C" void cis_small_host(double x, double *out) { const cd2 v = cis_small(x); out[0] = v.re; out[1] = v.im; }
+
+// the phase walk's WRAP without its division (lte_device.h: trk_wrap_certain_interval): for every x and every candidate floor
+// around WRAP's own, a k = x + pi inside the candidate's interval must have that candidate as WRAP's floor, and the walk's value
+// (k - nf) - pi must be WRAP's bit for bit.  Returns the violations; *n_inside = how often WRAP's own floor was accepted.
+extern "C" long trk_wrap_interval_violations(const double *x, long n, long *n_inside) {
+  long bad = 0;
+  *n_inside = 0;
+  const double wn = M_PI - (-M_PI);
+  for (long i = 0; i < n; ++i) {
+    const double k = x[i] - (-M_PI);
+    const double q = floor(k / wn);
+    const double want = trk_wrap(x[i], -M_PI, M_PI);
+    for (int d = -2; d <= 2; ++d) {
+      double nf, lo, hi;
+      trk_wrap_certain_interval(q + d, nf, lo, hi);
+      if (!(k >= lo && k < hi)) continue;
+      const double got = (k - nf) + (-M_PI);
+      unsigned long long ua, ub;
+      memcpy(&ua, &want, 8); memcpy(&ub, &got, 8);
+      if (d != 0 || ua != ub) ++bad;
+      if (d == 0) ++*n_inside;
+    }
+  }
+  return bad;
+}

@@ -149,3 +149,32 @@ def test_register_transform_building_blocks_on_the_host(libs):
         L.cis_small_host(float(x), out.ctypes.data_as(dp))
         worst = max(worst, abs(out[0] - np.cos(x)), abs(out[1] - np.sin(x)))
     assert worst < 2.5e-16, worst       # 1.5e-16 against extended precision + libm's own half ulp
+
+
+def test_phase_walk_wrap_without_its_division_is_the_same_function(libs):
+    """k_trk_prep walks the bulk phase symbol by symbol through the reference's WRAP (include/macros.h) but takes the floor of
+    WRAP's quotient from a parallel prefix sum, guarded by trk_wrap_certain_interval: a k inside the interval of a floor value
+    must have exactly that floor in WRAP's own arithmetic, and the walk's value must be WRAP's bit for bit.  Random phases over
+    many turns (a 35 kHz LO error advances the phase by 2.5 turns per symbol), the neighbourhoods of every multiple of pi (ulp by
+    ulp and across the guard band), zeros, huge values, non-finite ones."""
+    L = libs[0]
+    L.trk_wrap_interval_violations.argtypes = [C.POINTER(C.c_double), C.c_long, C.POINTER(C.c_long)]
+    L.trk_wrap_interval_violations.restype = C.c_long
+    rng = np.random.default_rng(11)
+    parts = [rng.uniform(-40 * np.pi, 40 * np.pi, 3_000_000), rng.uniform(-np.pi, np.pi, 500_000), rng.normal(0, 1e-3, 100_000),
+             rng.uniform(-1e5, 1e5, 200_000)]
+    for mult in range(-9, 10):
+        base = mult * np.pi
+        near = [base]
+        up, dn = base, base
+        for _ in range(2000):
+            up = np.nextafter(up, np.inf); dn = np.nextafter(dn, -np.inf)
+            near += [up, dn]
+        parts.append(np.array(near))
+        parts.append(base + np.linspace(-2e-8, 2e-8, 20001))
+    parts.append(np.array([0.0, -0.0, 1e300, -1e300, 1e-320, -1e-320, np.inf, -np.inf, np.nan, 2 ** 31 * 6.3, -2 ** 31 * 6.3, 1e7, -1e7]))
+    x = np.ascontiguousarray(np.concatenate(parts))
+    assert x.size > 4_000_000
+    n_inside = C.c_long()
+    assert L.trk_wrap_interval_violations(x.ctypes.data_as(C.POINTER(C.c_double)), x.size, C.byref(n_inside)) == 0
+    assert n_inside.value > 0.8 * x.size          # (within 1e-9 of a turn boundary, beyond 1e6 turns, non-finite: WRAP itself)
