@@ -154,6 +154,44 @@ def test_oracle_tracker_statistics_on_the_golden_cells(tracked):
     assert snr[0] > snr[1] and snr[0] > 5.0                                # cell 277 is the strong one (doc/CellSearch.html:75-82)
 
 
+def _wrap_walk(b, fov, cp_normal=True):
+    """get_fd's bulk phase (tracker_thread.cpp:151-153) in IEEE doubles, expression by expression: WRAP of include/macros.h."""
+    import math
+    sm, lg = -math.pi, math.pi
+    n = lg - sm
+    for i, f in enumerate(fov):
+        L = (128 + 32) if not cp_normal else ((128 + 10) if i % 7 == 0 else (128 + 9))
+        x = b + 2 * math.pi * L * (1 / (30720000.0 / 16)) * -float(f)
+        k = x - sm
+        b = (k - n * float(int(math.floor(k / n)))) + sm
+    return b
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("start", [0.0, 2.5, -17.25, 3.0e7])
+def test_gpu_bulk_phase_walk_is_wrap_bit_for_bit(tracked, start):
+    """k_trk_prep takes the turns each step folds away from a parallel prefix sum and walks with additions only; the phase it
+    hands back must be the reference's sequential WRAP walk to the last bit -- from a phase inside [-pi, pi), from ones outside it
+    (the first step then folds several turns), and from 3e7 (4.8 M turns: beyond the range in which the kernel trusts its turn
+    count, so that chunk runs WRAP as written)."""
+    import types
+    pkg = load_pkg()
+    _, cells = tracked
+    recs = []
+    for c, *_ in cells:
+        recs.append(types.SimpleNamespace(bulk_phase_offset=start, **{k: int(getattr(c, k)) for k in
+                    ("n_id_1", "n_id_2", "cp_type", "n_ports", "n_rb_dl", "phich_duration", "phich_resource")}))
+    td = np.stack([x[1] for x in cells]); late = np.stack([x[2] for x in cells])
+    ftv = np.stack([x[3] for x in cells]); fov = np.stack([x[4] for x in cells])
+    assert np.abs(fov).max() > 2e4            # the golden capture's LO error: more than two turns per symbol
+    with pkg.Searcher(0) as S:
+        g = S.track_block(recs, td, fov, ftv, late, FC, FC, FS, want_syms=False, want_ce=False)
+    for i, (c, *_rest) in enumerate(cells):
+        assert int(c.cp_type) == 1            # LCS_CP_NORMAL: both golden cells
+        want = _wrap_walk(start, fov[i])
+        assert g["bpo"][i] == want, (i, g["bpo"][i], want)
+
+
 @pytest.mark.gpu
 def test_gpu_track_stats_match_oracle(tracked):
     pkg = load_pkg()
