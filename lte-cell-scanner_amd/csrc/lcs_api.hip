@@ -554,7 +554,7 @@ int lcs_batch_enqueue(lcs_ctx *c, const void *d_capbufs, int fmt, int n_buf, uin
 // context, one synchronisation; a second copy only when the batch returned more.  No allocation, no pageable staging
 // (rounds 1-4 copied n_buf x 64 records, 786 KB per 128-buffer batch, into a vector built inside the call).
 int lcs_batch_collect(lcs_ctx *c, lcs_cell *cells, int max_cells_per_buf, int *n_cells) {
-  if (!c || !n_cells || c->last_n_buf <= 0) return LCS_ERR_BAD_ARG;
+  if (!c || !n_cells || c->last_n_buf <= 0 || max_cells_per_buf < 0 || (!cells && max_cells_per_buf > 0)) return LCS_ERR_BAD_ARG;
   HIPCHK(c, hipSetDevice(c->device));
   const int nb = c->last_n_buf;
   const bool full = (c->last_stage_mask & 2) != 0;
