@@ -254,6 +254,13 @@ int lcs_batch_readback(lcs_ctx *ctx, int buf, float *xc_incoherent_single /*[3][
  * the peak list is exact all the same, and the latency of the repair stays off the single-buffer path.  lcs_foe_partial does not
  * repair (a near-tie may span two ranks' shares): lcs_foe_contend / lcs_foe_resolve settle those after the all-reduce. */
 int lcs_last_frq_repairs(lcs_ctx *ctx, int *n_positions);
+/* The repair's work is bounded: real captures list ~2 positions per buffer, but a degenerate input (duplicated entries of
+ * f_search_set make every position an exact tie) lists all 3 x 9600.  Once a call lists more than 32 positions per repair
+ * workgroup (256 for one buffer, 16384 for a 128-buffer batch) only positions whose power reaches their Z_th1 -- the ones a peak can
+ * come from -- are recomputed, and each workgroup stops after 256 candidates; *n_unrepaired counts the listed positions left with
+ * the correlation kernel's own arg-max (0 on any real data; for exact duplicates that arg-max is the reference's anyway:
+ * identical templates give identical values and the first one wins). */
+int lcs_last_frq_repair_stats(lcs_ctx *ctx, int *n_listed, int *n_unrepaired);
 /* HIP-event time (ms) of the PSS correlation kernel launches of the last enqueue, and the
  * number of launches it covers; used by bench.py for the roofline figure. */
 int lcs_last_xcorr_ms(lcs_ctx *ctx, float *ms, int *n_launches);

@@ -457,6 +457,13 @@ class Searcher:
         self._chk(self._lib.lcs_last_frq_repairs(self._h, C.byref(n)), "lcs_last_frq_repairs")
         return n.value
 
+    def last_frq_repair_stats(self):
+        """-> (positions listed as near-ties, positions left unrepaired by the work bound) of the last correlation call
+        (lcs_last_frq_repair_stats; the second is 0 on any real data)."""
+        a, b = C.c_int(0), C.c_int(0)
+        self._chk(self._lib.lcs_last_frq_repair_stats(self._h, C.byref(a), C.byref(b)), "lcs_last_frq_repair_stats")
+        return a.value, b.value
+
     def last_collect_host_us(self) -> float:
         """Host microseconds the last batch_collect spent outside its wait for the GPU (lcs_last_collect_host_us)."""
         us = C.c_double(0)

@@ -65,12 +65,15 @@ int ensure_ws(lcs_ctx *c, int n_slots, uint32_t n_cap, int n_f, bool debug, int 
   A(cap32, S * n_cap);
   A(cap64, (size_t)n_cap);
   A(params, S);
-  A(fset, (size_t)LCS_NF_MAX);
-  A(tmpl, S * LCS_NF_MAX * 3 * 137);
-  A(start, S * LCS_NW_MAX * LCS_NF_MAX);
-  A(smin, S * LCS_NW_MAX * LCS_G_MAX);
-  A(kp2, S * LCS_NW_MAX * LCS_G_MAX);
-  A(btab, S * LCS_NW_MAX * G * LCS_KP2_MAX * 64);
+  // per-hypothesis / per-group tables: sized for the largest grid seen; every call lays its own grid out with its own
+  // strides n_f and G (k_prep_tables rebuilds them per call)
+  A(fset, (size_t)n_f);
+  A(tmpl, S * n_f * 3 * 137);
+  A(start, S * LCS_NW_MAX * n_f);
+  A(smin, S * LCS_NW_MAX * G);
+  A(kp2, S * LCS_NW_MAX * G);
+  if (c->btab) { (void)hipFree(c->btab); c->btab = nullptr; }      // fp32 kernel's operand tables (0.5 MB per slot and group): allocated by its first launch (lcs_launch_xcorr)
+  c->btab_elems = 0;
   A(single, S * G * LCS_N_IDX * LCS_TG);
   A(sref, NE * n_f);
   A(sp, S * LCS_NW_MAX * LCS_N_IDX);
@@ -80,7 +83,6 @@ int ensure_ws(lcs_ctx *c, int n_slots, uint32_t n_cap, int n_f, bool debug, int 
   A(fix_list, S * NE);
   A(n_fix, 4);
   A(second32, S * NE);
-  A(fset_g, (size_t)LCS_NF_MAX);
   A(spinc, S * LCS_N_IDX);
   A(zth, S * LCS_N_IDX);
   A(peaks, S * LCS_MAXP);
@@ -116,8 +118,8 @@ int ensure_i8(lcs_ctx *c) {
   const size_t n8 = S * lcs_cap8_stride(c->cap_n_cap);
   if ((rc = dev_alloc(c, &c->cap8, n8)) || (rc = dev_alloc(c, &c->cap8s, n8))) return rc;
   if ((rc = dev_alloc(c, &c->brow8, S * G * (size_t)LCS_I8_IMG))) return rc;
-  if ((rc = dev_alloc(c, &c->tq, S * LCS_G_MAX * LCS_TG))) return rc;
-  if ((rc = dev_alloc(c, &c->tsc, S * LCS_G_MAX * LCS_TG))) return rc;
+  if ((rc = dev_alloc(c, &c->tq, S * G * LCS_TG))) return rc;
+  if ((rc = dev_alloc(c, &c->tsc, S * G * LCS_TG))) return rc;
   c->i8_ready = true;
   return LCS_OK;
 }
@@ -131,7 +133,7 @@ int ensure_f16(lcs_ctx *c) {
   const size_t n16 = S * lcs_cap8_stride(c->cap_n_cap);
   if ((rc = dev_alloc(c, &c->cap16h, n16)) || (rc = dev_alloc(c, &c->cap16l, n16))) return rc;
   if ((rc = dev_alloc(c, &c->brow16, S * c->cap_G * (size_t)LCS_F16_IMG))) return rc;
-  if ((rc = dev_alloc(c, &c->texp16, S * LCS_G_MAX * LCS_TG)) || (rc = dev_alloc(c, &c->tsc16, S * LCS_G_MAX * LCS_TG))) return rc;
+  if ((rc = dev_alloc(c, &c->texp16, S * c->cap_G * LCS_TG)) || (rc = dev_alloc(c, &c->tsc16, S * c->cap_G * LCS_TG))) return rc;
   if ((rc = dev_alloc(c, &c->xmax16, S)) || (rc = dev_alloc(c, &c->xpart16, S * 128))) return rc;
   c->f16_ready = true;
   return LCS_OK;
@@ -139,12 +141,11 @@ int ensure_f16(lcs_ctx *c) {
 
 // Buffers of the per-cell stages, allocated on first use for c->max_work cells (~6 MB each: 3 GB at the default 512) and
 // again when the limit was raised since (lcs_set_max_cells_in_flight, or by itself after a batch that carried more cells).
-int ensure_percell(lcs_ctx *c) {
-  if (c->percell_ready && c->max_work <= c->percell_cap) return LCS_OK;
-  if (c->st_open && c->percell_ready) return LCS_OK;      // the open stream's graph holds these addresses: keep what it was captured with
+int alloc_percell(lcs_ctx *c, size_t W) {
   int rc;
-  if (c->percell_ready) HIPCHK(c, hipStreamSynchronize(c->stream));
-  const size_t W = (size_t)std::max(c->max_work, c->percell_cap), GRID = (size_t)LCS_TFG_ROWS * LCS_TFG_NSC;
+  const size_t GRID = (size_t)LCS_TFG_ROWS * LCS_TFG_NSC;
+  c->percell_ready = false;      // until every buffer exists: a failure part-way leaves a context that allocates again, not one
+  c->percell_cap = 0;            // that runs kernels on a null pointer
 #define A(p, n) if ((rc = dev_alloc(c, &c->p, (n))) != LCS_OK) return rc
   A(work_items, W);
   A(n_work, 4);
@@ -161,6 +162,23 @@ int ensure_percell(lcs_ctx *c) {
   c->percell_ready = true;
   c->percell_cap = (int)W;
   return LCS_OK;
+}
+int ensure_percell(lcs_ctx *c) {
+  if (c->percell_ready && c->max_work <= c->percell_cap) return LCS_OK;
+  if (c->st_open && c->percell_ready) return LCS_OK;      // the open stream's graph holds these addresses: keep what it was captured with
+  const int prev = c->percell_ready ? c->percell_cap : 0;
+  if (c->percell_ready) HIPCHK(c, hipStreamSynchronize(c->stream));
+  const size_t W = (size_t)std::max(c->max_work, prev);
+  int rc = alloc_percell(c, W);
+  if (rc != LCS_OK && prev > 0 && W > (size_t)prev) {
+    // growing failed (6 MB per cell: 512 -> 1024 cells asks for 3 GB more): back to the capacity that worked, and the limit stays
+    // there -- more rounds per batch instead of a failed batch
+    (void)hipGetLastError();
+    c->max_work = prev;
+    c->max_work_pinned = true;
+    rc = alloc_percell(c, (size_t)prev);
+  }
+  return rc;
 }
 
 // Device block the results of a batch are compacted into (k_pack_results) and its page-locked mirror, sized for the worst case
@@ -271,7 +289,7 @@ int upload_host_capbuf(lcs_ctx *c, const double *capbuf, uint32_t n_cap, const d
 
 int check_common(lcs_ctx *c, uint32_t n_cap, int n_f) {
   if (!c) return LCS_ERR_BAD_ARG;
-  if (n_f < 1 || n_f > LCS_NF_MAX) { c->err = "n_f out of range (1..128)"; return LCS_ERR_BAD_ARG; }
+  if (n_f < 1 || n_f > LCS_NF_LIMIT) { c->err = "n_f out of range (1..1024)"; return LCS_ERR_BAD_ARG; }
   if (n_cap < 136 + 137 + 9600 + 100) { c->err = "capture buffer shorter than one 5 ms window"; return LCS_ERR_BAD_ARG; }
   if ((n_cap - 136 - 100) / 9600 > LCS_NW_MAX) { c->err = "capture buffer longer than 16 combining windows"; return LCS_ERR_BAD_ARG; }
   return LCS_OK;
@@ -445,7 +463,7 @@ int lcs_peak_search(lcs_ctx *c, const double *pow_, const int32_t *frq, const do
                     uint16_t n_f, double fc_req, double fc_prog, const float *single, uint8_t ds_comb_arm,
                     lcs_cell *cells, int max_cells, int *n_cells) {
   if (!c) return LCS_ERR_BAD_ARG;
-  if (n_f < 1 || n_f > LCS_NF_MAX) { c->err = "n_f out of range (1..128)"; return LCS_ERR_BAD_ARG; }
+  if (n_f < 1 || n_f > LCS_NF_LIMIT) { c->err = "n_f out of range (1..1024)"; return LCS_ERR_BAD_ARG; }
   if (!pow_ || !frq || !Z_th1 || !f_search_set || !single || !n_cells || (max_cells > 0 && !cells)) { c->err = "null argument"; return LCS_ERR_BAD_ARG; }
   HIPCHK(c, hipSetDevice(c->device));
   int rc;
@@ -498,7 +516,7 @@ int lcs_batch_enqueue(lcs_ctx *c, const void *d_capbufs, int fmt, int n_buf, uin
                                n_buf, fs_programmed, kMaxTapsI8);      // the fp16 kernel holds 160 taps per group and shares the int8 kernel's packing
   if ((rc = ensure_ws(c, n_buf, n_cap, n_f, false, geo.G))) return rc;
   if ((rc = ensure_res_pack(c, n_buf))) return rc;
-  if ((rc = pinned(c, sizeof(SlotParams) * n_buf + sizeof(double) * LCS_NF_MAX))) return rc;
+  if ((rc = pinned(c, sizeof(SlotParams) * n_buf + sizeof(double) * n_f))) return rc;
   SlotParams *hp = (SlotParams *)c->h_pinned;
   double *hf = (double *)(hp + n_buf);
   for (int i = 0; i < n_buf; ++i) hp[i] = SlotParams{fc_requested[i], fc_programmed[i], fs_programmed};
@@ -1009,8 +1027,14 @@ int lcs_foe_partial(lcs_ctx *c, const double *capbuf, uint32_t n_cap, const doub
 int lcs_foe_contend(lcs_ctx *c, const double *f_search_set, uint16_t n_f, const void *d_words, void *d_words2) {
   if (!c) return LCS_ERR_BAD_ARG;
   if (!c->foe_ready) { c->err = "lcs_foe_contend needs the lcs_foe_partial call of the same buffer first"; return LCS_ERR_BAD_ARG; }
-  if (!f_search_set || !d_words || !d_words2 || n_f < 1 || n_f > LCS_NF_MAX) { c->err = "bad argument"; return LCS_ERR_BAD_ARG; }
+  if (!f_search_set || !d_words || !d_words2 || n_f < 1 || n_f > LCS_NF_LIMIT) { c->err = "bad argument"; return LCS_ERR_BAD_ARG; }
   HIPCHK(c, hipSetDevice(c->device));
+  if (n_f > c->fset_g_cap) {      // the whole grid (fset holds this rank's share)
+    int rc_;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if ((rc_ = dev_alloc(c, &c->fset_g, (size_t)n_f))) return rc_;
+    c->fset_g_cap = n_f;
+  }
   HIPCHK(c, hipMemcpyAsync(c->fset_g, f_search_set, sizeof(double) * n_f, hipMemcpyHostToDevice, c->stream));
   int rc;
   if ((rc = lcs_launch_foe_contend(c, c->foe_geo, c->fset_g, static_cast<const long long *>(d_words), static_cast<long long *>(d_words2)))) return rc;
@@ -1031,7 +1055,7 @@ int lcs_foe_finish(lcs_ctx *c, const void *d_words, const double *d_meta, const 
                    int32_t *order, int max_cells, int *n_cells, lcs_cell *peaks, int max_peaks, int *n_peaks) {
   if (!c) return LCS_ERR_BAD_ARG;
   if (!c->foe_ready) { c->err = "lcs_foe_finish needs the lcs_foe_partial call of the same buffer first"; return LCS_ERR_BAD_ARG; }
-  if (!d_words || !d_meta || !f_search_set || !n_cells || (max_cells > 0 && (!cells || !order)) || n_f < 1 || n_f > LCS_NF_MAX) { c->err = "bad argument"; return LCS_ERR_BAD_ARG; }
+  if (!d_words || !d_meta || !f_search_set || !n_cells || (max_cells > 0 && (!cells || !order)) || n_f < 1 || n_f > LCS_NF_LIMIT) { c->err = "bad argument"; return LCS_ERR_BAD_ARG; }
   HIPCHK(c, hipSetDevice(c->device));
   c->foe_ready = false;
   const XcGeom geo = c->foe_geo;
@@ -1146,6 +1170,7 @@ int lcs_stream_open(lcs_ctx *c, int fmt, uint32_t n_cap, double fc_requested, do
   if ((rc = ensure_ws(c, 1, n_cap, 1, false))) return rc;
   if ((rc = ensure_percell(c))) return rc;
   if (fmt == LCS_FMT_IQ_U8 && (rc = ensure_i8(c))) return rc;
+  if ((rc = lcs_ensure_btab(c))) return rc;      // host buffers that are not dongle data take the fp32 kernel, also while the stream is open
   c->st_fmt = fmt;
   c->st_n_cap = n_cap;
   c->st_in_bytes = (size_t)n_cap * (fmt == LCS_FMT_IQ_U8 ? 2 : sizeof(float2));
@@ -1240,6 +1265,17 @@ int lcs_last_frq_repairs(lcs_ctx *c, int *n_positions) {
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipMemcpyAsync(n_positions, c->n_fix, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  return LCS_OK;
+}
+
+int lcs_last_frq_repair_stats(lcs_ctx *c, int *n_listed, int *n_unrepaired) {
+  if (!c || !n_listed || !n_unrepaired || !c->n_fix) return LCS_ERR_BAD_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  int v[2] = {0, 0};
+  HIPCHK(c, hipMemcpyAsync(v, c->n_fix, sizeof(v), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  *n_listed = v[0];
+  *n_unrepaired = v[1];
   return LCS_OK;
 }
 

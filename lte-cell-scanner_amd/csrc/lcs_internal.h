@@ -22,13 +22,16 @@
 #include "../../include/lcs.h"
 
 #define LCS_NW_MAX 16        // incoherent-combining windows (15 for a 153600-sample buffer)
-#define LCS_NF_MAX 128       // frequency hypotheses per call
+// Frequency hypotheses per call: the reference loops over whatever f_search_set holds (src/searcher.cpp:113-174; CellSearch builds
+// n_f = 2 floor((fc ppm / 1e6 + 2500) / 5000) + 1, src/CellSearch.cpp:463-465: 125 at 2.6 GHz, 289 at 6 GHz for the default 120 ppm).
+// Every table is sized per call (lcs_api.hip: ensure_ws) and laid out with the call's own strides; this is a sanity bound only
+// (+-2.56 MHz of search span, ~120 MB of xc_incoherent_single per buffer).
+#define LCS_NF_LIMIT 1024
 // Every kernel other than the PSS correlation is small and latency-bound; in the pipelined chain it
 // shares CUs with the next batch's correlation waves.  Raising the wave priority lets the SIMD
 // arbiter issue these few waves ahead of the MFMA stream instead of round-robin behind 4-5 of them.
 #define LCS_TAIL_PRIO() __builtin_amdgcn_s_setprio(3)
 #define LCS_TG 16            // templates per MFMA column group
-#define LCS_G_MAX LCS_NF_MAX   // template groups per buffer: ceil(3 n_f / 16) when packed densely, up to n_f when one hypothesis takes a group
 #define LCS_KP2_MAX 128      // tap pairs per (window, group): 137 taps + up to 119 samples of spread
 #define LCS_KP2_UNROLL 4
 #define LCS_LAG_TILE 64      // lags per wave
@@ -184,14 +187,16 @@ struct lcs_ctx {
   double *fset = nullptr;
   float2 *tmpl = nullptr;
   int *start = nullptr, *smin = nullptr, *kp2 = nullptr;
-  float *btab = nullptr;
+  float *btab = nullptr;             // fp32 kernel only: allocated by its first launch for the workspace's slots and groups
+  size_t btab_elems = 0;
   float *single = nullptr, *incoh = nullptr, *sref = nullptr;
   double *pow_ = nullptr, *work = nullptr, *spinc = nullptr, *zth = nullptr, *sp = nullptr;
   int *frq = nullptr;
   unsigned *fix_list = nullptr;      // [S][3][9600]: positions (slot * 3 + t) * 9600 + idx whose arg-max is a near-tie (capacity: every position)
   int *n_fix = nullptr;              // [4]: entries on the list (zeroed by k_prep_tables)
   float *second32 = nullptr;         // [S][3][9600]: the runner-up of the collapse's maximum (written for lcs_foe_partial only: lcs_foe_contend reads it)
-  double *fset_g = nullptr;          // [LCS_NF_MAX]: the whole grid, for lcs_foe_contend (fset holds the rank's share then)
+  double *fset_g = nullptr;          // the whole grid, for lcs_foe_contend (fset holds the rank's share then)
+  int fset_g_cap = 0;
   bool repair_peaks_only = false;    // lcs_search_capbuf / the streaming chain: list only the near-ties at or above their position's Z_th1 (pss_xcorr.hip: collapse_flag)
   bool skip_frq_repair = false;      // lcs_foe_partial: a rank sees only its share of the hypotheses (a near-tie may span two ranks)
   lcs_cell *peaks = nullptr;
@@ -322,6 +327,7 @@ CapSrc lcs_cap_src(const lcs_ctx *c, uint32_t n_cap);   // which copy of the cap
 int lcs_launch_ingest(lcs_ctx *c, const void *d_src, int fmt, int n_buf, uint32_t n_cap);
 int lcs_launch_ingest_c128(lcs_ctx *c, uint32_t n_cap, bool *exact);   // cap64 -> cap32 + int8 copies; exact: every component is (u8 - 127) / 128
 int lcs_launch_xcorr(lcs_ctx *c, int n_buf, const XcGeom &geo, bool want_incoh, bool time_it);
+int lcs_ensure_btab(lcs_ctx *c);   // fp32 kernel's operand tables for the current workspace (allocated on first use)
 int lcs_launch_single_layout(lcs_ctx *c, const XcGeom &geo, int slot, float *ref_layout, int to_ref);   // group-major <-> [t][idx][foi]
 int lcs_launch_foe_contend(lcs_ctx *c, const XcGeom &geo, const double *fset_g, const long long *d_words, long long *d_words2);
 int lcs_launch_foe_resolve(lcs_ctx *c, long long *d_words, const long long *d_words2);

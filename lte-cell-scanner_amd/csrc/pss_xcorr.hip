@@ -29,8 +29,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // cache lines and k_collapse reads them back fully coalesced.  The reference layout
 // [t][idx][foi] is produced by k_single_to_ref only when a caller asks for that debug output.
 #define NW LCS_NW_MAX
-#define NFM LCS_NF_MAX
-#define GM LCS_G_MAX
+// strides of the per-hypothesis / per-group tables: the call's own grid (every call rebuilds its tables: k_prep_tables)
+#define NFM geo.n_f
+#define GM geo.G
 
 // ------------------------------------------------------------------------------ ingest
 // fmt 0: complex<float> in HBM -> cap32; fmt 2: complex<double> already copied into cap64 (host entry points, slot 0
@@ -140,9 +141,8 @@ __global__ __launch_bounds__(256) void k_prep_tables(const SlotParams *__restric
                                                       int *__restrict__ kp2, int *__restrict__ n_fix, XcGeom geo) {
   LCS_TAIL_PRIO();
   const int slot = blockIdx.x;
-  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *n_fix = 0;      // this call's list of near-tied positions (k_collapse*, k_frq_repair)
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { n_fix[0] = 0; n_fix[1] = 0; }      // this call's list of near-tied positions (k_collapse*, k_frq_repair) and the count of positions left unrepaired
   const SlotParams p = params[slot];
-  __shared__ int s_start[NW][NFM];
   // the templates (3 x 137 sincos per hypothesis, the long part) are spread over gridDim.y workgroups; the window
   // starts and per-group offsets are few: workgroup y = 0 does them
   for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < geo.n_f * 3 * 137; i += gridDim.y * blockDim.x) {
@@ -158,23 +158,18 @@ __global__ __launch_bounds__(256) void k_prep_tables(const SlotParams *__restric
     tmpl[(((size_t)slot * NFM + foi) * 3 + t) * 137 + m] = make_float2((float)(rr / 137), (float)(-ri / 137));
   }
   if (blockIdx.y != 0) return;
-  for (int foi = threadIdx.x; foi < geo.n_f; foi += blockDim.x) {
-    const double kf = (p.fc_req - fset[foi]) / p.fc_prog;
-    for (int w = 0; w < geo.n_comb; ++w) {
-      // round_i(m*.005*k_factor*fs_programmed), evaluated left to right
-      const double v = (((double)w * .005) * kf) * p.fs_prog;
-      const int s = (int)rint(v);
-      s_start[w][foi] = s;
-      start[((size_t)slot * NW + w) * NFM + foi] = s;
-    }
+  // round_i(m*.005*k_factor*fs_programmed), evaluated left to right (ref :298)
+  auto win_start = [&](int w, int foi) { return (int)rint((((double)w * .005) * ((p.fc_req - fset[foi]) / p.fc_prog)) * p.fs_prog); };
+  for (int i = threadIdx.x; i < geo.n_f * geo.n_comb; i += blockDim.x) {
+    const int w = i / geo.n_f, foi = i - w * geo.n_f;
+    start[((size_t)slot * NW + w) * NFM + foi] = win_start(w, foi);
   }
-  __syncthreads();
   for (int i = threadIdx.x; i < geo.n_comb * geo.G; i += blockDim.x) {
     const int w = i / geo.G, g = i % geo.G;
     const int c_hi = min(g * geo.cpg + geo.cpg - 1, geo.n_tmpl - 1);
     const int f_lo = (g * geo.cpg) / 3, f_hi = c_hi / 3;
-    int mn = s_start[w][f_lo], mx = mn;
-    for (int f = f_lo + 1; f <= f_hi; ++f) { mn = min(mn, s_start[w][f]); mx = max(mx, s_start[w][f]); }
+    int mn = win_start(w, f_lo), mx = mn;       // (any grid size: recomputed, a group spans at most 7 hypotheses)
+    for (int f = f_lo + 1; f <= f_hi; ++f) { const int s = win_start(w, f); mn = min(mn, s); mx = max(mx, s); }
     int k2 = (137 + (mx - mn) + 1) / 2;
     if (k2 > LCS_KP2_MAX - LCS_KP2_UNROLL) k2 = LCS_KP2_MAX - LCS_KP2_UNROLL;   // rejected on the host before launch (lcs_api.hip)
     smin[((size_t)slot * NW + w) * GM + g] = mn;
@@ -804,6 +799,8 @@ __device__ __forceinline__ float repair_gpu_value(const float *__restrict__ sgs,
 #define REPAIR_MAX_LAGS 17          // 2 * 8 + 1: lcs_xcorr_pss refuses arms beyond 8
 #define REPAIR_SPAN (137 + REPAIR_MAX_LAGS - 1)
 #define REPAIR_THREADS 256
+#define REPAIR_CROWDED 32          // listed positions per workgroup beyond which the work is bounded (see k_frq_repair)
+#define REPAIR_WG_BUDGET 256       // candidates a workgroup recomputes at most once the list is crowded
 template <int KIND> struct RepairSample;
 template <> struct RepairSample<0> { typedef uint16_t T; static __device__ __forceinline__ double2 cvt(uint16_t p) { return make_double2(-(double)(int)(int8_t)(p & 255u) / 128.0, -(double)(int)(int8_t)(p >> 8) / 128.0); } };
 template <> struct RepairSample<1> { typedef float2 T; static __device__ __forceinline__ double2 cvt(float2 f) { return make_double2((double)f.x, (double)f.y); } };
@@ -819,7 +816,7 @@ __global__ __launch_bounds__(REPAIR_THREADS) void k_frq_repair(const float *__re
                                                                const double2 *__restrict__ pss_td, const int *__restrict__ start,
                                                                double *__restrict__ pow_, float *__restrict__ pow32, int *__restrict__ frq,
                                                                const long long *__restrict__ words, long long *__restrict__ words2,
-                                                               XcGeom geo) {
+                                                               const double *__restrict__ zth, int *__restrict__ n_skipped, XcGeom geo) {
   LCS_TAIL_PRIO();
   typedef typename RepairSample<KIND>::T ST;
   __shared__ double2 s_tmpl[137];
@@ -831,17 +828,32 @@ __global__ __launch_bounds__(REPAIR_THREADS) void k_frq_repair(const float *__re
   const size_t cap_stride = KIND == 0 ? lcs_cap8_stride(src.n_cap) : (size_t)src.n_cap;
   const int n = *n_fix;
   const int n_lag = 2 * geo.ds + 1, span = 137 + n_lag - 1;
+  // Bounded work.  Real data list ~2 positions per buffer.  A degenerate input -- duplicated entries of f_search_set
+  // make every position an exact tie -- lists all 28800 per buffer: once the list is longer than REPAIR_CROWDED positions per
+  // workgroup, only positions that can become a peak (power at or above their Z_th1, ref :449) are recomputed, and a workgroup
+  // stops after REPAIR_WG_BUDGET candidates; the rest keep the collapse kernel's arg-max (for exact duplicates that IS the
+  // reference's: identical templates give identical values and the first one wins) and are counted in *n_skipped
+  // (lcs_last_frq_repair_stats).
+  const bool crowded = n > REPAIR_CROWDED * (int)gridDim.x;
+  int spent = 0, skipped = 0;
   for (int e = blockIdx.x; e < n; e += gridDim.x) {
     const unsigned pos = fix_list[e];
     const int idx = (int)(pos % LCS_N_IDX), t = (int)((pos / LCS_N_IDX) % 3), slot = (int)(pos / (3 * LCS_N_IDX));
+    if (crowded) {
+      const float pv = SPLIT ? __uint_as_float((unsigned)(words[pos] >> 32)) : pow32[pos];
+      if (spent >= REPAIR_WG_BUDGET || (double)pv < 0.999 * zth[(size_t)slot * LCS_N_IDX + idx]) { ++skipped; continue; }
+    }
     const float *sgs = sg + (size_t)slot * geo.G * LCS_N_IDX * LCS_TG;
     const SlotParams p = params[slot];
     const ST *cap = capbase + (size_t)slot * cap_stride;
-    // the values the collapse kernel compared (same expression, same rounding), lane f and f + 64; every wave computes the same
-    // candidate masks (no exchange needed)
-    const float x0 = lane < geo.n_f ? repair_gpu_value(sgs, geo, 3 * lane + t, idx) : -INFINITY;
-    const float x1 = lane + 64 < geo.n_f ? repair_gpu_value(sgs, geo, 3 * (lane + 64) + t, idx) : -INFINITY;
-    float mx = fmaxf(x0, x1);
+    // the values the collapse kernel compared (same expression, same rounding), 64 hypotheses per pass; every wave computes the
+    // same candidate masks (no exchange needed)
+    const int n_ch = (geo.n_f + 63) >> 6;
+    float mx = -INFINITY;
+    for (int ch = 0; ch < n_ch; ++ch) {
+      const int fl = lane + 64 * ch;
+      mx = fmaxf(mx, fl < geo.n_f ? repair_gpu_value(sgs, geo, 3 * fl + t, idx) : -INFINITY);
+    }
     for (int o = 32; o; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
     int g_win = -1;                                                      // SPLIT: the global winner's index in the whole grid
     if (SPLIT) {
@@ -850,16 +862,22 @@ __global__ __launch_bounds__(REPAIR_THREADS) void k_frq_repair(const float *__re
       g_win = (int)(0xFFFFFFFFu - (unsigned)(gw & 0xFFFFFFFFll));
     }
     const float lim = mx * (1.0f - LCS_FRQ_TIE_EPS);
-    const unsigned long long m0 = (SPLIT && geo.foi0 < 0) ? 0ull : __ballot(x0 >= lim), m1 = (SPLIT && geo.foi0 < 0) ? 0ull : __ballot(x1 >= lim);
     const bool win_remote = SPLIT && (geo.foi0 < 0 || g_win < geo.foi0 || g_win >= geo.foi0 + geo.n_f);
     float best = -INFINITY;
     int best_f = 0;
-    for (int half = 0; half < (SPLIT ? 3 : 2); ++half) {
-      unsigned long long m = half == 2 ? (win_remote ? 1ull : 0ull) : (half ? m1 : m0);
+    for (int ch = 0; ch < n_ch + (SPLIT ? 1 : 0); ++ch) {               // SPLIT: one more pass for the remote winner
+      unsigned long long m;
+      if (ch == n_ch) m = win_remote ? 1ull : 0ull;
+      else {
+        const int fl = lane + 64 * ch;
+        const float x = fl < geo.n_f ? repair_gpu_value(sgs, geo, 3 * fl + t, idx) : -INFINITY;
+        m = (SPLIT && geo.foi0 < 0) ? 0ull : __ballot(x >= lim);
+      }
       while (m) {                                                        // ascending in foi: the reference's scan order
-        const int f_loc = half == 2 ? -1 : __builtin_ctzll(m) + 64 * half;        // -1: the remote winner
+        const int f_loc = ch == n_ch ? -1 : __builtin_ctzll(m) + 64 * ch;          // -1: the remote winner
         m &= m - 1;
         const int f = SPLIT ? (f_loc < 0 ? g_win : geo.foi0 + f_loc) : f_loc;      // index into fset
+        ++spent;
         // conj(fshift(pss_td, f_off, fs_programmed * k_factor)) / 137 in double (ref :146-151, dsp.h:40-53)
         const double f_off = fset[f];
         const double kf = (p.fc_req - f_off) / p.fc_prog;
@@ -871,9 +889,9 @@ __global__ __launch_bounds__(REPAIR_THREADS) void k_frq_repair(const float *__re
           s_tmpl[tid] = make_double2((s.x * cs - s.y * sn) / 137, -(s.x * sn + s.y * cs) / 137);
         }
         // window starts: from the table (this rank's own hypotheses) or, for a hypothesis of another rank, by k_prep_tables' expression
-        const int *st = start + ((size_t)slot * LCS_NW_MAX) * LCS_NF_MAX + (SPLIT ? max(f_loc, 0) : f);
+        const int *st = start + ((size_t)slot * LCS_NW_MAX) * NFM + (SPLIT ? max(f_loc, 0) : f);
         __shared__ int s_st[LCS_NW_MAX];
-        if (tid < LCS_NW_MAX) s_st[tid] = (SPLIT && f_loc < 0) ? (int)rint((((double)tid * .005) * kf) * p.fs_prog) : (tid < geo.n_comb ? st[(size_t)tid * LCS_NF_MAX] : 0);
+        if (tid < LCS_NW_MAX) s_st[tid] = (SPLIT && f_loc < 0) ? (int)rint((((double)tid * .005) * kf) * p.fs_prog) : (tid < geo.n_comb ? st[(size_t)tid * NFM] : 0);
         __syncthreads();
         {
           // thread -> sample o of window w, all of a thread's loads in flight together.  Sample o of window w is what the positions
@@ -944,6 +962,7 @@ __global__ __launch_bounds__(REPAIR_THREADS) void k_frq_repair(const float *__re
       }
     }
   }
+  if (tid == 0 && skipped) atomicAdd(n_skipped, skipped);
 }
 
 // lcs_foe_contend, first kernel: which positions does this rank contend for?  The owner of the global winner where its own
@@ -1013,6 +1032,19 @@ int lcs_launch_ingest(lcs_ctx *c, const void *d_src, int fmt, int n_buf, uint32_
 static std::mutex g_xc_mutex;
 static hipEvent_t g_xc_done[64] = {};
 
+// The fp32 kernel's operand tables: one per (slot, window, group), 0.5 MB each -- only contexts that take this kernel pay for them.
+int lcs_ensure_btab(lcs_ctx *c) {
+  const size_t need = (size_t)c->cap_slots * LCS_NW_MAX * c->cap_G * LCS_KP2_MAX * 64;
+  if (need <= c->btab_elems) return LCS_OK;
+  if (c->st_open) { c->err = "the fp32 correlation tables cannot be allocated while a stream is open: lcs_stream_close first"; return LCS_ERR_BAD_ARG; }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->btab) (void)hipFree(c->btab);
+  c->btab = nullptr; c->btab_elems = 0;
+  HIPCHK(c, hipMalloc((void **)&c->btab, need * sizeof(float)));
+  c->btab_elems = need;
+  return LCS_OK;
+}
+
 int lcs_launch_xcorr(lcs_ctx *c, int n_buf, const XcGeom &geo, bool want_incoh, bool time_it) {
   hipLaunchKernelGGL(k_prep_tables, dim3(n_buf, 4), dim3(256), 0, c->stream, c->params, c->fset, c->d_pss_td, c->tmpl,
                      c->start, c->smin, c->kp2, c->n_fix, geo);
@@ -1022,9 +1054,11 @@ int lcs_launch_xcorr(lcs_ctx *c, int n_buf, const XcGeom &geo, bool want_incoh, 
   } else if (c->use_f16) {
     int rc_ = lcs_launch_fill_brow_f16(c, n_buf, geo);
     if (rc_) return rc_;
-  } else
+  } else {
+    { int rc_ = lcs_ensure_btab(c); if (rc_) return rc_; }
     hipLaunchKernelGGL(k_fill_btab, dim3(geo.n_comb * geo.G * n_buf), dim3(256), 0, c->stream, c->tmpl,
                        c->start, c->smin, c->kp2, c->btab, geo, n_buf);
+  }
   // signal-power estimate and threshold do not depend on the correlation: enqueue them first
   SpArgs a;
   a.n_comb_sp = (int)((geo.n_cap - 136 - 137) / 9600);
@@ -1100,7 +1134,7 @@ int lcs_launch_xcorr(lcs_ctx *c, int n_buf, const XcGeom &geo, bool want_incoh, 
       const CapSrc cs = lcs_cap_src(c, geo.n_cap);
       const int ng = std::min(512, 8 * n_buf);
 #define REPAIR_LAUNCH(KIND) hipLaunchKernelGGL((k_frq_repair<KIND, false>), dim3(ng), dim3(REPAIR_THREADS), 0, c->stream, c->single, c->fix_list, \
-                                               c->n_fix, cs, c->params, c->fset, c->d_pss_td, c->start, c->pow_, pow32, c->frq, nullptr, nullptr, geo)
+                                               c->n_fix, cs, c->params, c->fset, c->d_pss_td, c->start, c->pow_, pow32, c->frq, nullptr, nullptr, c->zth, c->n_fix + 1, geo)
       if (cs.c8) REPAIR_LAUNCH(0);
       else if (cs.c32) REPAIR_LAUNCH(1);
       else REPAIR_LAUNCH(2);
@@ -1113,12 +1147,12 @@ int lcs_launch_xcorr(lcs_ctx *c, int n_buf, const XcGeom &geo, bool want_incoh, 
 
 // lcs_foe_contend / lcs_foe_resolve (lcs_api.hip): fset_g = the WHOLE grid on the device
 int lcs_launch_foe_contend(lcs_ctx *c, const XcGeom &geo, const double *fset_g, const long long *d_words, long long *d_words2) {
-  HIPCHK(c, hipMemsetAsync(c->n_fix, 0, sizeof(int), c->stream));
+  HIPCHK(c, hipMemsetAsync(c->n_fix, 0, 2 * sizeof(int), c->stream));
   float *pow32 = reinterpret_cast<float *>(c->work);
   hipLaunchKernelGGL(k_foe_flag, dim3((3 * LCS_N_IDX + 255) / 256), dim3(256), 0, c->stream, d_words, pow32, c->second32, d_words2, c->fix_list, c->n_fix, geo);
   const CapSrc cs = lcs_cap_src(c, geo.n_cap);
 #define CONTEND_LAUNCH(KIND) hipLaunchKernelGGL((k_frq_repair<KIND, true>), dim3(512), dim3(REPAIR_THREADS), 0, c->stream, c->single, c->fix_list, c->n_fix, cs, \
-                                                c->params, fset_g, c->d_pss_td, c->start, c->pow_, pow32, c->frq, d_words, d_words2, geo)
+                                                c->params, fset_g, c->d_pss_td, c->start, c->pow_, pow32, c->frq, d_words, d_words2, c->zth, c->n_fix + 1, geo)
   if (cs.c8) CONTEND_LAUNCH(0);
   else if (cs.c32) CONTEND_LAUNCH(1);
   else CONTEND_LAUNCH(2);

@@ -25,8 +25,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 
 #define NW LCS_NW_MAX
-#define NFM LCS_NF_MAX
-#define GM LCS_G_MAX
+#define NFM geo.n_f      // strides of the per-hypothesis / per-group tables: the call's own grid
+#define GM geo.G
 
 #define F16_MT 8
 #define F16_LAGS (4 * F16_MT * 16)

@@ -45,8 +45,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 #define NW LCS_NW_MAX
-#define NFM LCS_NF_MAX
-#define GM LCS_G_MAX
+#define NFM geo.n_f      // strides of the per-hypothesis / per-group tables: the call's own grid
+#define GM geo.G
 
 #ifndef I8_MT
 #define I8_MT 8                                          // 16-lag sub-tiles per wave
