@@ -58,16 +58,23 @@ def synth_batch(pkg, n_buf, seed, fc_list, dense=False):
     return pkg.synth.make_batch_u8(n_buf, seed, fc_list)
 
 
-def cpu_baseline(pkg, host_u8, f, fcs, stage, n_sample=4):
-    """The CPU oracle (a C port of the reference's path, oracle/lcs_oracle.c) on the first `n_sample` buffers of
-    the same workload, single thread, then with OpenMP over the lags as the reference does, on this host.
-    Reported next to the GPU number; never part of `value`.  Returns (report, the oracle's cells of buffer 0)."""
+def cpu_baseline(pkg, host_u8, f, fcs, stage, sample=None):
+    """The CPU oracle (a C port of the reference's path, oracle/lcs_oracle.c) on a bounded sample of the same workload --
+    the first 8 buffers of the bench batch (two of them occupied, the band scan's own 1-in-4 ratio; 4 buffers, two occupied,
+    on grids above 48 hypotheses so that the leg stays within ~30 s) -- single thread, then with OpenMP over the lags as
+    the reference does, on this host.  Reported next to the GPU number; never part of `value`.
+    Returns (report, the oracle's cells of buffer 0)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as O
+    if sample is None:
+        sample = list(range(8)) if f.size <= 48 else [0, 1, 4, 5]
+    sample = [b for b in sample if b < len(host_u8)]
+    n_sample = len(sample)
     caps = []
-    for b in range(n_sample):
+    for b in sample:
         iq = host_u8[b].astype(np.float64)
         caps.append(((iq[0::2] - 127.0) / 128.0) + 1j * ((iq[1::2] - 127.0) / 128.0))
+    fcs = [fcs[b] for b in sample]
 
     def one(cap, fc):
         if stage == "full":
@@ -100,12 +107,13 @@ def cpu_baseline(pkg, host_u8, f, fcs, stage, n_sample=4):
                 break
     except OSError:
         pass
-    cpu_baseline.results = res       # the oracle's cells of the sampled buffers (the verification leg reuses them)
+    cpu_baseline.results = dict(zip(sample, res))       # the oracle's cells of the sampled buffers (the verification leg reuses them)
     cpu_baseline.threads = ncpu
     return ({"value": n_sample / dt, "unit": "capture-buffers/s", "cores": 1, "kind": "port",
-             "sample": f"{n_sample} synthetic buffers of the bench batch, n_f={f.size}, stage={stage}, {dt:.2f} s single-thread "
-                       f"(C oracle, gcc -O3); {ncpu} threads (OpenMP over lags as the reference): {n_sample / dt_mt:.3f} buffers/s",
-             "cpu_model": model, "n_results": [len(r) for r in res]}, res[0])
+             "sample": f"buffers {sample} of the bench batch ({sum(1 for r in res if r)} of them with detections), n_f={f.size}, stage={stage}, "
+                       f"{dt:.2f} s single-thread (C oracle, gcc -O3); {ncpu} threads (OpenMP over lags as the reference): {n_sample / dt_mt:.3f} buffers/s",
+             "cpu_model": model, "nproc": os.cpu_count(), "threads_allowed": ncpu, "multi_thread_value": n_sample / dt_mt,
+             "n_results": [len(r) for r in res]}, res[0])
 
 
 def stream_bench(pkg, args, rank, world, local_rank, dist):
@@ -561,6 +569,9 @@ def main():
                     help="enqueues per step: a step is batch x this many buffers per GPU; default 12800 // batch")
     ap.add_argument("--distinct", type=int, default=4, help="distinct resident batches the enqueues cycle through")
     ap.add_argument("--ppm", type=float, default=100.0)
+    ap.add_argument("--fc", type=float, default=FC,
+                    help="first carrier of the batch (default 739 MHz: BASELINE configs[2], n_f = 31 at --ppm 100); e.g. --fc 2.6e9 --ppm 120 "
+                         "is the CLI's band-7 grid, n_f = 125 (src/CellSearch.cpp:463-465)")
     ap.add_argument("--stage", choices=["pss", "full", "single", "stream", "track"], default="full",
                     help="full = BASELINE configs[2], the whole CellSearch chain (default); pss = configs[1], xcorr_pss + "
                          "peak_search only; single = configs[1] as written, ONE 153600-sample host buffer per step through "
@@ -646,12 +657,12 @@ def main():
         return track_bench(pkg, args, rank, world, local_rank, dist)
     if args.stage == "single":
         return single_bench(pkg, args, rank, world, local_rank, dist)
-    f = pkg.f_search_set_for(FC, args.ppm)
+    f = pkg.f_search_set_for(args.fc, args.ppm)
     stage_mask = pkg.STAGE_FULL if args.stage == "full" else pkg.STAGE_PSS
     B, K, D = args.batch, args.batches_per_step, max(1, args.distinct)
     fmt = pkg.FMT_IQ_U8 if args.input == "u8" else pkg.FMT_C64
     # rank r searches carriers FC + 100 kHz * (r*B + b): the sweep's carrier axis is the shard axis
-    fcs = FC + 100e3 * (np.arange(B) + rank * B)
+    fcs = args.fc + 100e3 * (np.arange(B) + rank * B)
     cache = os.path.join(args.synth_cache, f"batch_{B}_{1234 + rank}{'_dense' if args.dense_main else ''}.npy") if args.synth_cache else None
     if cache and os.path.exists(cache):
         host = np.load(cache)
@@ -782,6 +793,9 @@ def main():
         pending["work"] = None
     torch.cuda.synchronize()
     dt_own = time.perf_counter() - t0
+    mem_free, mem_total = torch.cuda.mem_get_info(dev)      # everything the run holds: resident batches + the contexts' workspaces
+    hbm_in_use = {"after_timed_region_GB": (mem_total - mem_free) / 1e9, "resident_input_GB": sum(x.numel() * x.element_size() for x in d_caps) / 1e9,
+                  "contexts": len(ctxs)}
     if multi:
         # identity check of the record all-gather (outside the clock): this rank's row of the last step's gather must be
         # what it contributed, and every rank's row must carry a plausible count
@@ -861,6 +875,8 @@ def main():
         seen.clear(); seen.update(seen_saved)
         state["mismatch"], state["collected"] = mism0, coll_saved
         host_t.update(host_saved)
+    mem_free, _ = torch.cuda.mem_get_info(dev)
+    hbm_in_use["after_dense_band_GB"] = (mem_total - mem_free) / 1e9      # the dense batches grow the per-cell buffers (512 -> 1024 cells per context)
     verify = {"pipelined_collects": state["collected"], "pipelined_mismatches": state["mismatch"],
               "sequential_run_identical": bool(seq_ok), "oracle_buffer0": None, "oracle_buffers_checked": [], "oracle_buffers_differing": []}
 
@@ -910,8 +926,9 @@ def main():
             "config": {"workload": ("configs[2]: full searcher chain (PSS+SSS+FOE+TFG+MIB)" if args.stage == "full" else
                                     "configs[1]: xcorr_pss + peak_search over the full +-100 ppm foe grid") +
                                    (" -- DENSE BAND (2-3 cells planted in every buffer; not the headline workload)" if args.dense_main else "") +
+                                   ("" if (args.fc == FC and args.ppm == 100.0) else f" -- NOT the headline grid: the CLI's grid for fc {args.fc / 1e6:g} MHz at {args.ppm:g} ppm, n_f = {f.size}") +
                                    f", one MI355X per rank, step = {K} batches x {B} = {K * B} 153600-sample capbufs per GPU, "
-                                   f"fc 739 MHz + 100 kHz raster, {D} distinct resident batches",
+                                   f"fc {args.fc / 1e6:g} MHz + 100 kHz raster, +-{args.ppm:g} ppm, {D} distinct resident batches",
                        "n_f": int(n_f), "batch_per_gpu": B, "batches_per_step": K, "buffers_per_step_per_gpu": B * K,
                        "buffers_timed": n_buffers, "timed_region_s": dt, "stage": args.stage,
                        "ingest": ("u8 I/Q in page-locked host memory, PCIe copy of every batch inside the timed region" if args.input_host else
@@ -927,6 +944,7 @@ def main():
                        "cells_per_distinct_batch": n_cells_per_batch,
                        "cells_per_buffer": float(np.mean(n_cells_per_batch)) / B,
                        "dense_band": dense,
+                       "hbm_in_use": hbm_in_use,
                        "per_rank_buffers_per_s": [B * K * args.steps / x for x in dt_ranks],
                        "devices": devices,
                        "ms_per_batch": 1e3 * dt / (args.steps * K),
@@ -1000,7 +1018,7 @@ def main():
             checked, bad = [], []
             main_ids = [b for b in (0, 1, 2, 3, 4, 8, 12, 16, 20, 24, 28, 5) if b < B]
             for b in main_ids:
-                oc = cpu_baseline.results[b] if b < len(cpu_baseline.results) else oracle_cells(host[b], float(fcs[b]))
+                oc = cpu_baseline.results[b] if b in cpu_baseline.results else oracle_cells(host[b], float(fcs[b]))
                 checked.append(f"timed/{b}")
                 if not same(rec0[b, :cnt0[b]], oc):
                     bad.append(f"timed/{b}")

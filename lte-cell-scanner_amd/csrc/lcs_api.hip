@@ -100,6 +100,7 @@ int ensure_ws(lcs_ctx *c, int n_slots, uint32_t n_cap, int n_f, bool debug, int 
   for (void **q : {(void **)&c->cap16h, (void **)&c->cap16l, (void **)&c->brow16, (void **)&c->texp16, (void **)&c->tsc16, (void **)&c->xmax16, (void **)&c->xpart16})
     if (*q) { (void)hipFree(*q); *q = nullptr; }
   c->f16_ready = false;
+  c->foe_ready = false;      // (a pending lcs_foe_partial result lived in the buffers just replaced)
   c->cap_slots = n_slots;
   c->cap_n_cap = n_cap;
   c->cap_n_f = n_f;
@@ -1000,6 +1001,7 @@ int lcs_foe_partial(lcs_ctx *c, const double *capbuf, uint32_t n_cap, const doub
   // estimate exist, and contributes words that never win
   const int cnt = std::max(1, f_count), first = f_count ? f_first : 0;
   XcGeom geo;
+  if ((rc = ensure_ws(c, 1, n_cap, n_f, false))) return rc;      // lcs_foe_finish puts the WHOLE grid into fset (this rank correlates its share only)
   if ((rc = upload_host_capbuf(c, capbuf, n_cap, f_search_set + first, cnt, 2, fc_req, fc_prog, fs_prog, false, &geo))) return rc;
   if ((rc = ensure_percell(c))) return rc;
   // no tie repair here: a near-tie may span two ranks' shares -- lcs_foe_contend settles them after the all-reduce, identically

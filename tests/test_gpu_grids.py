@@ -176,3 +176,41 @@ def test_cli_on_a_band_3_carrier(tmp_path, pkg):
     assert [c.n_id_cell() for c in exp] == [185]
     rows = r.stdout.split("CrystalCorrectionFactor\n")[1].splitlines()
     assert len(rows) == 1 and re.match(r"^185 2   1800M\s+-18\dk", rows[0]) and " N  75 " in rows[0], r.stdout
+
+
+def test_hypothesis_split_of_a_169_hypothesis_grid_over_eight_shares(pkg):
+    """SURVEY 8(e) latency mode on a band-42 grid: the 169 hypotheses of one buffer split over eight contexts (the shares an
+    8-GPU node would take: 22 x 7 + 15), MAX of the packed words standing in for the all-reduce, near-ties settled by
+    lcs_foe_contend / _resolve: every index equals the oracle's, and the eight ranks' cells together are the fused chain's."""
+    import torch
+    fc, n_f = 3.5e9, 169
+    f = f_search_set_for(fc, 120)
+    bufs, _ = _planted(pkg, fc, n_f, int(fc / 1e7))
+    cap = iq_u8_to_capbuf(bufs[0])
+    ro = O.xcorr_pss(cap, f, 2, fc, fc, FS)
+    exp, exp_pk = O.search_capbuf(cap, f, fc, fc, FS)
+    shares = [(22 * r, 22 if r < 7 else n_f - 154) for r in range(8)]
+    ctxs = [pkg.Searcher(0) for _ in shares]
+    try:
+        words = [torch.empty(3 * 9600, dtype=torch.int64, device="cuda") for _ in ctxs]
+        meta = [torch.empty(9601, dtype=torch.float64, device="cuda") for _ in ctxs]
+        for S_, (a, n), w, m in zip(ctxs, shares, words, meta):
+            S_.foe_partial(cap, f, a, n, fc, fc, FS, w.data_ptr(), m.data_ptr())
+        red = torch.stack(words).max(dim=0).values
+        w2 = [torch.empty(3 * 9600, dtype=torch.int64, device="cuda") for _ in ctxs]
+        for S_, x in zip(ctxs, w2):
+            S_.foe_contend(f, red.data_ptr(), x.data_ptr())
+        red2 = torch.stack(w2).max(dim=0).values
+        ctxs[0].foe_resolve(red.data_ptr(), red2.data_ptr())
+        pw, fq = pkg.sweep.unpack_pow_frq(red.cpu().numpy().reshape(3, 9600))
+        assert np.array_equal(fq, ro["frq"]) and (np.abs(pw - ro["pow"]) / ro["pow"]).max() < 1e-5
+        got = []
+        for S_ in ctxs:
+            cells, order, peaks = S_.foe_finish(red.data_ptr(), meta[0].data_ptr(), f)
+            got += list(zip(order.tolist(), cells))
+            assert [(p.n_id_2, p.freq) for p in peaks] == [(p.n_id_2, p.freq) for p in exp_pk]
+        got.sort(key=lambda x: x[0])
+        assert [KEY(c) for _, c in got] == [KEY(c) for c in exp] and len(exp) >= 1
+    finally:
+        for S_ in ctxs:
+            S_.close()
