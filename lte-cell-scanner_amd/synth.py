@@ -125,18 +125,22 @@ def _crs(n_id_cell, slot, sym, cp_normal):
 
 
 def cell_waveform(n_frames, n_id_1, n_id_2, cp_normal=True, n_ports=2, n_rb_dl=50, phich_duration_ext=0,
-                  phich_res=2, sfn0=0, load=0.5, rng=None, port_gains=None):
-    """Baseband samples at the nominal 1.92 Msps, n_frames*19200 long, starting at the boundary of frame sfn0."""
+                  phich_res=2, sfn0=0, load=0.5, rng=None, port_gains=None, per_port=False):
+    """Baseband samples at the nominal 1.92 Msps, n_frames*19200 long, starting at the boundary of frame sfn0.
+    per_port: the antenna ports' waveforms separately, [n_ports, n] each scaled by 1/sqrt(n_ports) and without the flat
+    per-port gains -- what a channel model per (cell, port) starts from (fading_channel)."""
     rng = rng or np.random.default_rng(0)
     n_id_cell = n_id_2 + 3 * n_id_1
     n_symb = 7 if cp_normal else 6
     v_shift = n_id_cell % 6
-    if port_gains is None:
+    if per_port:
+        port_gains = np.eye(n_ports)
+    elif port_gains is None:
         port_gains = np.exp(2j * np.pi * rng.random(n_ports)) * (0.8 + 0.4 * rng.random(n_ports))
     port_gains = np.asarray(port_gains, np.complex128) / np.sqrt(n_ports)
     pss = _pss_fd(n_id_2)
     crs_cache = {}
-    out = np.zeros(n_frames * 19200, np.complex128)
+    out = np.zeros((n_ports, n_frames * 19200) if per_port else n_frames * 19200, np.complex128)
     pos = 0
     pbch = None
     for fr in range(n_frames):
@@ -198,16 +202,54 @@ def cell_waveform(n_frames, n_id_1, n_id_2, cp_normal=True, n_ports=2, n_rb_dl=5
                     on = free[rng.random(free.size) < load]
                     d = ((1 - 2.0 * rng.integers(0, 2, on.size)) + 1j * (1 - 2.0 * rng.integers(0, 2, on.size))) / np.sqrt(2.0)
                     grid[0, on] = d * np.sqrt(n_ports)     # single-layer data through port 0
-                X = np.zeros(128, np.complex128)
-                mix = port_gains @ grid
-                X[92:128] = mix[:36]
-                X[1:37] = mix[36:]
-                td = np.fft.ifft(X) * np.sqrt(128.0)
+                mix = port_gains @ grid                      # per_port: [n_ports, 72], otherwise the ports' sum [72]
+                X = np.zeros(mix.shape[:-1] + (128,), np.complex128)
+                X[..., 92:128] = mix[..., :36]
+                X[..., 1:37] = mix[..., 36:]
+                td = np.fft.ifft(X, axis=-1) * np.sqrt(128.0)
                 cp = (10 if sym == 0 else 9) if cp_normal else 32
-                out[pos:pos + cp] = td[-cp:]
-                out[pos + cp:pos + cp + 128] = td
+                out[..., pos:pos + cp] = td[..., -cp:]
+                out[..., pos + cp:pos + cp + 128] = td
                 pos += cp + 128
-    assert pos == out.size
+    assert pos == out.shape[-1]
+    return out
+
+
+# Multipath delay profiles of 36.101 Annex B.2 (excess tap delay [ns], relative power [dB]): Extended Pedestrian A, Extended
+# Vehicular A, Extended Typical Urban.  At 1.92 Msps a sample is 521 ns: EPA stays inside one sample, EVA spreads over 4.8,
+# ETU over 9.6 -- just beyond the normal cyclic prefix of 9 samples.
+CHANNEL_PROFILES = {
+    "EPA": ((0, 30, 70, 90, 110, 190, 410), (0.0, -1.0, -2.0, -3.0, -8.0, -17.2, -20.8)),
+    "EVA": ((0, 30, 150, 310, 370, 710, 1090, 1730, 2510), (0.0, -1.5, -1.4, -3.6, -0.6, -9.1, -7.0, -12.0, -16.9)),
+    "ETU": ((0, 50, 120, 200, 230, 500, 1600, 2300, 5000), (-1.0, -1.0, -1.0, 0.0, 0.0, 0.0, -3.0, -5.0, -7.0)),
+}
+
+
+def fading_channel(rng, w, profile, doppler_hz=0.0, fs=FS, n_sin=16):
+    """One transmit waveform (nominal rate fs) through a tapped delay line with independent Rayleigh taps: tap k delays by
+    profile's tau_k (a fraction of a sample in general: applied as a linear phase over the whole waveform's spectrum) and
+    multiplies by a_k(t) = sqrt(P_k / n_sin) sum_m exp(j (2 pi f_d cos(alpha_m) t + phi_m)) -- a sum-of-sinusoids Jakes process
+    with maximum Doppler f_d (f_d = 0: a constant complex Gaussian-like gain).  Total average power 1.
+    profile: a CHANNEL_PROFILES name or (delays_ns, powers_db)."""
+    delays_ns, powers_db = CHANNEL_PROFILES[profile] if isinstance(profile, str) else profile
+    p = 10.0 ** (np.asarray(powers_db, np.float64) / 10.0)
+    p /= p.sum()
+    n = w.size
+    W = np.fft.fft(w)
+    fr = np.fft.fftfreq(n, 1.0 / fs)
+    t = np.arange(n, dtype=np.float64) / fs
+    out = np.zeros(n, np.complex128)
+    for tau_ns, pk in zip(delays_ns, p):
+        wk = np.fft.ifft(W * np.exp(-2j * np.pi * fr * (tau_ns * 1e-9))) if tau_ns else w
+        alpha = rng.uniform(0.0, 2 * np.pi, n_sin)
+        phi = rng.uniform(0.0, 2 * np.pi, n_sin)
+        if doppler_hz:
+            a = np.zeros(n, np.complex128)
+            for am, pm in zip(alpha, phi):
+                a += np.exp(1j * (2 * np.pi * doppler_hz * np.cos(am) * t + pm))
+        else:
+            a = np.exp(1j * phi).sum()
+        out += np.sqrt(pk / n_sin) * a * wk
     return out
 
 
@@ -240,9 +282,12 @@ def make_signal(rng, fc, cells=(), n_cap=N_CAP, fc_programmed=None, fs_programme
         rate = k_factor if fs_programmed == FS else fs_programmed * k_factor / FS      # receiver samples per nominal 1.92 MHz transmitter sample
         t0 = float(cd.get("t0", rng.uniform(0, 19200)))
         n_frames = int(np.ceil((n_cap / rate + t0) / 19200)) + 1
+        chan = cd.get("channel")
         w = cell_waveform(n_frames, cd["n_id_1"], cd["n_id_2"], cd.get("cp_normal", True), cd.get("n_ports", 2),
                           cd.get("n_rb_dl", 50), cd.get("phich_duration_ext", 0), cd.get("phich_res", 2),
-                          cd.get("sfn0", int(rng.integers(0, 1024))), cd.get("load", 0.5), rng, cd.get("port_gains"))
+                          cd.get("sfn0", int(rng.integers(0, 1024))), cd.get("load", 0.5), rng, cd.get("port_gains"), per_port=chan is not None)
+        if chan is not None:      # an independent fading multipath channel per (cell, antenna port), 36.101 B.2
+            w = sum(fading_channel(rng, wp, chan, float(cd.get("doppler_hz", 0.0))) for wp in w)
         # receiver sample n is taken at transmitter time (t0 + n / rate) nominal samples
         y = frac_resample(w, t0 + n / rate)
         y = y * np.exp(2j * np.pi * f_off * n / (fs_programmed * k_factor))
@@ -254,13 +299,21 @@ def make_signal(rng, fc, cells=(), n_cap=N_CAP, fc_programmed=None, fs_programme
     return sig, ref_pow, truth
 
 
-def add_noise_and_quantise(rng, sig, ref_pow, snr_db=10.0, rms=0.15, quantise=True):
+def add_noise_and_quantise(rng, sig, ref_pow, snr_db=10.0, rms=0.15, quantise=True, front_end=None):
     """AWGN at `snr_db` below the first cell's PSS/SSS sample power (unit noise without cells), AGC to `rms`, and the
-    RTL-SDR's 8-bit quantisation (x -> clip(round(128 x + 127)), ref src/capbuf.cpp:174)."""
+    RTL-SDR's 8-bit quantisation (x -> clip(round(128 x + 127)), ref src/capbuf.cpp:174).
+    front_end (optional dict): what a zero-IF dongle adds before its ADC -- dc (complex, in units of the signal's rms: the LO
+    leakage spike at 0 Hz), iq_gain_db / iq_phase_deg (gain and quadrature error of the Q branch: an image at -f).  Hard
+    clipping needs no switch: rms >= ~0.35 drives the 8-bit range into saturation."""
     n_cap = sig.size
     noise_pow = 1.0 if ref_pow is None else ref_pow / 10 ** (snr_db / 10)
     x = sig + np.sqrt(noise_pow / 2) * (rng.standard_normal(n_cap) + 1j * rng.standard_normal(n_cap))
     x *= rms / np.sqrt(np.mean(np.abs(x) ** 2))
+    if front_end:
+        g = 10.0 ** (float(front_end.get("iq_gain_db", 0.0)) / 20.0)
+        ph = np.deg2rad(float(front_end.get("iq_phase_deg", 0.0)))
+        x = x.real + 1j * g * (x.imag * np.cos(ph) + x.real * np.sin(ph))
+        x = x + complex(front_end.get("dc", 0.0)) * rms
     if not quantise:
         return x
     iq = np.empty(2 * n_cap, np.uint8)
@@ -269,7 +322,7 @@ def add_noise_and_quantise(rng, sig, ref_pow, snr_db=10.0, rms=0.15, quantise=Tr
     return iq
 
 
-def make_capbuf(seed, fc, cells=(), snr_db=10.0, n_cap=N_CAP, rms=0.15, quantise=True, fc_programmed=None, fs_programmed=FS):
+def make_capbuf(seed, fc, cells=(), snr_db=10.0, n_cap=N_CAP, rms=0.15, quantise=True, fc_programmed=None, fs_programmed=FS, front_end=None):
     """One capture buffer as the receiver would record it.
 
     fc is the frequency the caller asked for (fc_requested); fc_programmed / fs_programmed are what the dongle reports
@@ -278,10 +331,12 @@ def make_capbuf(seed, fc, cells=(), snr_db=10.0, n_cap=N_CAP, rms=0.15, quantise
 
     cells: dicts with n_id_1, n_id_2 and optionally cp_normal, n_ports, n_rb_dl, phich_duration_ext,
     phich_res, sfn0, load, f_off (Hz, the dongle's LO error: +f_off means the cell appears f_off
-    above DC), t0 (samples into the first frame), gain_db.  Returns (iq_u8 or complex128, truth)."""
+    above DC), t0 (samples into the first frame), gain_db, channel ("EPA" / "EVA" / "ETU" or (delays_ns, powers_db): an
+    independent Rayleigh tapped delay line per antenna port, fading_channel) with doppler_hz.  front_end: see
+    add_noise_and_quantise.  Returns (iq_u8 or complex128, truth)."""
     rng = np.random.default_rng(seed)
     sig, ref_pow, truth = make_signal(rng, fc, cells, n_cap, fc_programmed, fs_programmed)
-    return add_noise_and_quantise(rng, sig, ref_pow, snr_db, rms, quantise), truth
+    return add_noise_and_quantise(rng, sig, ref_pow, snr_db, rms, quantise, front_end), truth
 
 
 def iq_u8_to_complex(iq):

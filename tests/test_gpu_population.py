@@ -29,3 +29,25 @@ def test_population_cut_has_no_disagreement(tmp_path):
     assert r.returncode == 0
     # every index of xc_incoherent_collapsed_frq was compared, near-ties included, and the library repaired some of them
     assert t["frq_positions"] == t["buffers"] * 3 * 9600 and t["frq_near_ties_4e_6"] > 0 and j["gpu_frq_positions_repaired"] > 0
+
+
+def test_population_on_fading_multipath_channels_has_no_disagreement(tmp_path):
+    """Round 6: a 64-buffer cut (8 scenes x 8 noise realisations) of the `channels` group -- every cell through an independent
+    Rayleigh tapped delay line per antenna port (EPA / EVA / ETU, Doppler 5 / 70 / 300 Hz), DC spike, I/Q imbalance, clipped
+    ADC.  Everything the tool compares for the other groups, plus the ARRAYS of every decoded cell through the stage entry
+    points: extract_tfg 1e-10, tfoec's tfg_comp 1e-9, chan_est's ce_tfg of every port 1e-9 and its noise power 1e-11.  The
+    whole group (512 buffers): profiles/r06/parity_population_channels.json."""
+    out = tmp_path / "population_channels.json"
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "parity_population.py"), "--groups", "channels", "--limit", "64", "--out", str(out)],
+                       env=env, capture_output=True, text=True, timeout=1800)
+    assert out.exists(), (r.stdout[-2000:], r.stderr[-3000:])
+    j = json.loads(out.read_text())
+    t = j["totals"]
+    assert t["buffers"] == 64 and t["cells"] >= 30 and t["peaks"] > 2 * t["cells"]      # fading: many PSS peaks, some cells lost at low SNR
+    assert j["disagreements"] == 0, j["details"][:10]
+    sa = j["stage_arrays"]
+    assert sa["cells_compared"] == t["cells"] and sa["disagreements"] == 0
+    w = sa["worst_relative_deviation"]
+    assert w["tfg"] <= 1e-10 and w["tfg_comp"] <= 1e-9 and w["ce_tfg"] <= 1e-9 and w["np"] <= 1e-11
+    assert r.returncode == 0

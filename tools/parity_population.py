@@ -10,6 +10,15 @@ The buffers:
              a third of the scenes with fc_programmed != fc_requested and fs_programmed != 1.92 MHz, grids n_f = 31 / 35 / 37
   bench      the 4 x 128 buffers bench.py times (its base batch and the three rolled copies)
   dense      the 128 buffers of bench.py's dense band (2-3 cells planted in every buffer)
+  channels   (round 6) 512 buffers whose cells went through a RADIO CHANNEL, not a gain: 64 scenes x 8 noise realisations -- per
+             (cell, antenna port) an independent Rayleigh tapped delay line with the EPA / EVA / ETU delay profile of 36.101 B.2
+             (up to 9.6 samples of delay spread: beyond the normal CP) and Jakes Doppler 5 / 70 / 300 Hz, 1-3 cells, both CP
+             types, 1 / 2 / 4 ports, SNR -9 .. +10 dB, and the front end of a zero-IF dongle: DC spike, I/Q gain and phase
+             imbalance, hard clipping of the 8-bit range.  These are the stages the reference's fixtures do not pin:
+             ce_interp_hex on a frequency-selective, time-varying channel (src/searcher.cpp:1223-1362), tfoec's timing estimate
+             (:1013-1058), 4-port SFBC (:1582-1611).  For every cell the oracle decodes in this group the ARRAYS are compared
+             too: extract_tfg's grid (1e-10), tfoec's compensated grid (1e-9), chan_est's estimate of every port (1e-9) and its
+             noise power (1e-11), through the stage entry points on the oracle's own inputs.
 
 Per buffer, GPU (lcs_batch_enqueue / lcs_batch_collect / lcs_batch_readback) against oracle (oracle/lcs_oracle.c, one
 process per host core):
@@ -73,7 +82,41 @@ def synthetic_scene(synth, s, seed_offset=0):
     return dict(sig=sig, ref_pow=ref_pow, f=f, fc_req=fc_req, fc_prog=fc_prog, fs_prog=fs_prog, planted=cells)
 
 
-def build_population(pkg, groups, limit=None, dense_limit=None, seed_offset=0):
+CH_SNRS = (-9.0, -6.0, -3.0, 0.0, 3.0, 6.0, 10.0, 10.0)
+CH_PROFILES = ("EPA", "EVA", "ETU")
+CH_DOPPLER = (5.0, 70.0, 300.0)
+
+
+def channel_scene(synth, s, seed_offset=0):
+    """Scene s of 64 of the `channels` group: 1-3 cells, each antenna port of each cell through its own fading multipath channel."""
+    rng = np.random.default_rng(70_000 + s + 1000 * seed_offset)
+    fc, ppm = GRIDS[s % 3]
+    f = f_grid(fc, ppm)
+    fc_req = fc + 100e3 * (s % 5)
+    dongle = (s % 4 == 3)
+    fc_prog = fc_req * (1 - 11e-6) if dongle else fc_req
+    fs_prog = FS * (1 + 19e-6) if dongle else FS
+    n_cells = 1 + (s // 9) % 3
+    cells = []
+    for j in range(n_cells):
+        cells.append(dict(n_id_1=int(rng.integers(0, 168)), n_id_2=int(rng.integers(0, 3)), cp_normal=bool((s + j) % 4 != 1),
+                          n_ports=int((2, 1, 4, 2, 4)[(s + j) % 5]), n_rb_dl=int((6, 15, 25, 50, 75, 100)[(s + j) % 6]),
+                          phich_duration_ext=int((s + j) % 2), phich_res=int((s + 3 * j) % 4),
+                          f_off=float(rng.uniform(-0.9, 0.9) * f[-1]), gain_db=-2.5 * j,
+                          channel=CH_PROFILES[(s + j) % 3], doppler_hz=CH_DOPPLER[((s // 3) + j) % 3]))
+    sig, ref_pow, _ = synth.make_signal(rng, fc_req, cells, N_CAP, fc_prog, fs_prog)
+    # the front end: none / DC spike / I-Q imbalance / both
+    fe = (None, dict(dc=0.25 - 0.15j), dict(iq_gain_db=0.6, iq_phase_deg=4.0), dict(dc=-0.1 + 0.4j, iq_gain_db=-0.4, iq_phase_deg=-3.0))[s % 4]
+    return dict(sig=sig, ref_pow=ref_pow, f=f, fc_req=fc_req, fc_prog=fc_prog, fs_prog=fs_prog, planted=cells, front_end=fe)
+
+
+def _channel_scene_job(args):
+    import __graft_entry__ as ge
+    s, seed_offset = args
+    return channel_scene(ge.load_package().synth, s, seed_offset)
+
+
+def build_population(pkg, groups, limit=None, dense_limit=None, seed_offset=0, pool=None):
     """-> list of dict(name, group, iq (uint8 [2 n_cap]), f, fc_req, fc_prog, fs_prog, n_planted)."""
     import bench
     synth = pkg.synth
@@ -89,6 +132,20 @@ def build_population(pkg, groups, limit=None, dense_limit=None, seed_offset=0):
                 items.append(dict(name=f"synthetic/scene{s:02d}/snr{SNRS[v]:+.0f}dB/v{v}", group="synthetic", iq=iq, f=sc["f"],
                                   fc_req=sc["fc_req"], fc_prog=sc["fc_prog"], fs_prog=sc["fs_prog"], n_planted=len(sc["planted"]),
                                   snr_db=SNRS[v]))
+    if "channels" in groups:
+        n_scenes = 64 if limit is None else max(1, min(64, limit // 8))
+        jobs = [(s, seed_offset) for s in range(n_scenes)]
+        scenes = pool.map(_channel_scene_job, jobs, chunksize=1) if pool is not None else [_channel_scene_job(j) for j in jobs]
+        for s, sc in enumerate(scenes):
+            for v in range(8):
+                rng = np.random.default_rng(95_000 + 8 * s + v + 10_000 * seed_offset)
+                sig = np.roll(sc["sig"], int(rng.integers(0, N_CAP))) if v else sc["sig"]
+                # realisations 6 and 7 drive the ADC into its rails (0.8 % / 5 % of the bytes at the 0 / 255 stops)
+                rms = (0.5, 0.75)[v - 6] if v >= 6 else float(rng.uniform(0.08, 0.22))
+                iq = synth.add_noise_and_quantise(rng, sig, sc["ref_pow"], CH_SNRS[v], rms=rms, front_end=sc["front_end"])
+                items.append(dict(name=f"channels/scene{s:02d}/snr{CH_SNRS[v]:+.0f}dB/v{v}", group="channels", iq=iq, f=sc["f"],
+                                  fc_req=sc["fc_req"], fc_prog=sc["fc_prog"], fs_prog=sc["fs_prog"], n_planted=len(sc["planted"]),
+                                  snr_db=CH_SNRS[v], arrays=True))
     fcs = FC + 100e3 * np.arange(128)
     f31 = f_grid(FC, 100.0)
     if "bench" in groups:
@@ -160,6 +217,10 @@ def oracle_job(it):
             c4 = O.decode_mib(c3, tfgc)
             rec["mib_found"] = bool(c4.n_rb_dl != -1)
             rec["cell"] = cell_to_dict(c4)
+            if it.get("arrays") and rec["mib_found"]:
+                # the stage arrays of a decoded cell, for the comparison through the GPU's stage entry points (on THESE inputs)
+                ce = [O.chan_est(c3, tfgc, port) for port in range(int(c4.n_ports))]
+                rec["arrays"] = dict(c2=cell_to_dict(c2), c3=cell_to_dict(c3), tfg=tfg, ts=ts, tfgc=tfgc, ce=[x[0] for x in ce], np=[float(x[1]) for x in ce])
         out_peaks.append(rec)
     return dict(name=it["name"], frq=ro["frq"].astype(np.int16), pow=ro["pow"].astype(np.float32), zth=Z, peaks=out_peaks,
                 z_rejected=z_rejected, seconds=time.perf_counter() - t0, frq_margin=_frq_margins(ro))
@@ -206,6 +267,46 @@ def gpu_pass(pkg, items, batch=128):
                     out[i] = dict(frq=arr[b]["frq"], pow=arr[b]["pow"], zth=arr[b]["z_th1"], peaks=[cell_to_dict(c) for c in pk[b]],
                                   cells=[cell_to_dict(c) for c in full[b]])
     return out, n_repairs, t_gpu
+
+
+def compare_arrays(pkg, S, it, o):
+    """The `channels` group: for every cell the oracle decoded, the GPU's stage entry points on the oracle's own inputs --
+    extract_tfg on the oracle's post-FOE cell, tfoec on the oracle's grid, chan_est of every port on the oracle's compensated
+    grid -- at the stage tests' tolerances (tests/test_gpu_cells.py).  -> (disagreements, cells compared, worst deviations)"""
+    dis, n = [], 0
+    worst = dict(tfg=0.0, tfg_comp=0.0, ce_tfg=0.0, np=0.0)
+    x = it["iq"].astype(np.float64)
+    cap = ((x[0::2] - 127.0) / 128.0) + 1j * ((x[1::2] - 127.0) / 128.0)
+    fr, fp, fs = it["fc_req"], it["fc_prog"], it["fs_prog"]
+
+    def dev(a, b):
+        return float(np.abs(np.asarray(a) - np.asarray(b)).max() / np.abs(np.asarray(b)).max())
+
+    for p in o["peaks"]:
+        a = p.pop("arrays", None)
+        if a is None:
+            continue
+        n += 1
+        tag = f"{it['name']} peak ({p['peak']['n_id_2']}, {p['peak']['ind']})"
+        c2 = pkg.new_cell(fc_requested=fr, fc_programmed=fp, **a["c2"])
+        c3 = pkg.new_cell(fc_requested=fr, fc_programmed=fp, **a["c3"])
+        tfg_g, ts_g = S.extract_tfg(c2, cap, fr, fp, fs)
+        d = dev(tfg_g, a["tfg"])
+        worst["tfg"] = max(worst["tfg"], d)
+        if not (d <= 1e-10 and np.array_equal(ts_g, a["ts"])):
+            dis.append(dict(buffer=tag, stage="extract_tfg", what=f"grid deviates by {d:.3e} of its largest element", margin=None, threshold="1e-10"))
+        c3g, tfgc_g, _ = S.tfoec(c2, a["tfg"], a["ts"], fr, fp)
+        d = dev(tfgc_g, a["tfgc"])
+        worst["tfg_comp"] = max(worst["tfg_comp"], d)
+        if not (d <= 1e-9 and abs(c3g.freq_superfine - a["c3"]["freq_superfine"]) < 1e-7):
+            dis.append(dict(buffer=tag, stage="tfoec", what=f"tfg_comp deviates by {d:.3e}; freq_superfine {c3g.freq_superfine!r} vs {a['c3']['freq_superfine']!r}", margin=None, threshold="1e-9 / 1e-7 Hz"))
+        for port, (ce_o, np_o) in enumerate(zip(a["ce"], a["np"])):
+            ce_g, np_g = S.chan_est(c3, a["tfgc"], port)
+            d, dn = dev(ce_g, ce_o), abs(np_g - np_o) / np_o
+            worst["ce_tfg"], worst["np"] = max(worst["ce_tfg"], d), max(worst["np"], dn)
+            if not (d <= 1e-9 and dn <= 1e-11):
+                dis.append(dict(buffer=tag, stage="chan_est", what=f"port {port}: ce_tfg deviates by {d:.3e}, np by {dn:.3e}", margin=None, threshold="1e-9 / 1e-11"))
+    return dis, n, worst
 
 
 # ------------------------------------------------------------------------------------------------------ comparison
@@ -277,15 +378,26 @@ def run(groups=("synthetic", "bench", "dense"), limit=None, workers=None, out_pa
     pool = mp.get_context("fork").Pool(workers)
     import __graft_entry__ as ge
     pkg = ge.load_package()
-    items = build_population(pkg, groups, limit, dense_limit, seed_offset)
+    items = build_population(pkg, groups, limit, dense_limit, seed_offset, pool)
     t_built = time.perf_counter()
     res_async = pool.imap(oracle_job, items, chunksize=1)
     gpu, n_repairs, t_gpu = gpu_pass(pkg, items)
-    orc = list(res_async)
+    # results are taken as they arrive: the stage arrays of the `channels` group (a few MB per decoded cell) are compared through
+    # the GPU's stage entry points at once and dropped
+    orc, arr_dis, arr_cells = [], [], 0
+    arr_worst = dict(tfg=0.0, tfg_comp=0.0, ce_tfg=0.0, np=0.0)
+    with pkg.Searcher(0) as S_arr:
+        for it, o in zip(items, res_async):
+            if it.get("arrays"):
+                d_, n_, w_ = compare_arrays(pkg, S_arr, it, o)
+                arr_dis += d_
+                arr_cells += n_
+                arr_worst = {k: max(arr_worst[k], w_[k]) for k in arr_worst}
+            orc.append(o)
     pool.close()
     pool.join()
     t_done = time.perf_counter()
-    all_dis, per_group = [], {}
+    all_dis, per_group = list(arr_dis), {}
     tot = dict(buffers=0, peaks=0, sss_found=0, cells=0, frq_positions=0, frq_near_ties_1e_5=0, frq_near_ties_4e_6=0, frq_near_ties_1e_6=0)
     min_sss, min_z, min_frq = None, None, None
     for it, g, o in zip(items, gpu, orc):
@@ -315,6 +427,9 @@ def run(groups=("synthetic", "bench", "dense"), limit=None, workers=None, out_pa
         totals=tot, per_group=per_group, disagreements=len(all_dis), disagreements_by_stage=by_stage,
         disagreement_rate_per_buffer=len(all_dis) / max(1, tot["buffers"]),
         gpu_frq_positions_repaired=n_repairs,
+        stage_arrays=dict(cells_compared=arr_cells, disagreements=len(arr_dis), worst_relative_deviation=arr_worst,
+                          tolerances=dict(tfg=1e-10, tfg_comp=1e-9, ce_tfg=1e-9, np=1e-11),
+                          note="channels group: extract_tfg / tfoec / chan_est (every port) of every cell the oracle decoded, GPU stage entry points on the oracle's inputs"),
         closest_calls=dict(sss_abs_sigma_minus_3_min=min_sss, z_th1_abs_ratio_minus_1_min=min_z, frq_best_vs_second_min_rel=min_frq),
         details=all_dis[:200],
         seconds=dict(population=t_built - t_start, gpu_and_oracle=t_done - t_built, gpu_calls=t_gpu,
@@ -332,7 +447,7 @@ def run(groups=("synthetic", "bench", "dense"), limit=None, workers=None, out_pa
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--groups", default="synthetic,bench,dense")
+    ap.add_argument("--groups", default="synthetic,bench,dense", help="any of synthetic, bench, dense, channels")
     ap.add_argument("--limit", type=int, default=None, help="quick runs: at most this many buffers per group (synthetic: whole scenes of 8; bench: a quarter of it from each of the four batches)")
     ap.add_argument("--dense-limit", type=int, default=None)
     ap.add_argument("--workers", type=int, default=None)
