@@ -382,13 +382,25 @@ def track_bench(pkg, args, rank, world, local_rank, dist):
         t0 = time.perf_counter()
         # (at least 120 untimed blocks first: ~50 ms of load, the time the shader clock takes to come up from idle -- with 6 the 60
         # timed blocks of the collection command measured the ramp, 95 M symbols/s instead of 155 M)
-        r = subprocess.run([exe, blk_path, str(depth), str(args.steps), str(max(depth, args.warmup, 120)), str(dev_i)], capture_output=True, text=True, timeout=600)
-        os.unlink(blk_path)
         try:
+            r = subprocess.run([exe, blk_path, str(depth), str(args.steps), str(max(depth, args.warmup, 120)), str(dev_i)], capture_output=True, text=True, timeout=600)
             cxx = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-        except Exception:
-            sys.stderr.write("bench.py: host/TrackBench failed (%s): the Python loop's figure is reported\n" % r.stderr[-300:])
+            # a run that lost blocks is no measurement: its JSON counts only the blocks that succeeded
+            if r.returncode != 0 or cxx.get("failed", 0) or cxx.get("blocks") != args.steps:
+                sys.stderr.write("bench.py: host/TrackBench reported failed blocks (rc %d, %s): the Python loop's figure is reported\n" % (r.returncode, cxx))
+                cxx = None
+        except Exception as e:
+            cxx = None
+            sys.stderr.write("bench.py: host/TrackBench failed (%r): the Python loop's figure is reported\n" % (e,))
+        finally:
+            if os.path.exists(blk_path):
+                os.unlink(blk_path)
     if dist is not None:
+        # one clock for every rank: the C++ loop's only if EVERY rank's C++ run was clean
+        ok_t = torch.tensor([1.0 if cxx else 0.0], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
+        dist.all_reduce(ok_t, op=dist.ReduceOp.MIN)
+        if ok_t.item() == 0.0:
+            cxx = None
         dist.barrier()
     dt = cxx["seconds"] if cxx else dt_py
     if dist is not None:

@@ -779,10 +779,10 @@ int put_single_work_item(lcs_ctx *c, const lcs_cell *cell, int n_ofdm) {
   int rc;
   if ((rc = ensure_percell(c))) return rc;
   const WorkItem wi{0, 0};
-  const int one = 1;
+  const int nw[4] = {1, 1, 0, 0};      // one cell taken of one; no re-detections
   const double hdr[3] = {(double)n_ofdm, 0.0, 0.0};
   HIPCHK(c, hipMemcpyAsync(c->work_items, &wi, sizeof(wi), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->n_work, &one, sizeof(int), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->n_work, nw, sizeof(nw), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->cells_out, cell, sizeof(lcs_cell), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->cell_scratch, hdr, sizeof(hdr), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));   // the sources above are stack variables
@@ -893,6 +893,7 @@ int lcs_decode_mib(lcs_ctx *c, const lcs_cell *cell, const double *tfg, int n_of
   }
   HIPCHK(c, hipSetDevice(c->device));
   int rc;
+  if ((rc = ensure_ws(c, 1, std::max<uint32_t>(c->cap_n_cap, 153600), std::max(1, c->cap_n_f), false))) return rc;      // (a fresh context: the kernels read the slot's parameter record)
   if ((rc = put_single_work_item(c, cell, n_ofdm))) return rc;
   HIPCHK(c, hipMemcpyAsync(c->tfg_comp, tfg, sizeof(double2) * n_ofdm * LCS_TFG_NSC, hipMemcpyHostToDevice, c->stream));
   if ((rc = lcs_launch_rs_build(c))) return rc;
@@ -915,6 +916,7 @@ int lcs_chan_est(lcs_ctx *c, const lcs_cell *cell, const double *tfg, int n_ofdm
   }
   HIPCHK(c, hipSetDevice(c->device));
   int rc;
+  if ((rc = ensure_ws(c, 1, std::max<uint32_t>(c->cap_n_cap, 153600), std::max(1, c->cap_n_f), false))) return rc;      // (a fresh context: the kernels read the slot's parameter record)
   if ((rc = put_single_work_item(c, cell, n_ofdm))) return rc;
   HIPCHK(c, hipMemcpyAsync(c->tfg_comp, tfg, sizeof(double2) * n_ofdm * LCS_TFG_NSC, hipMemcpyHostToDevice, c->stream));
   if ((rc = lcs_launch_rs_build(c))) return rc;

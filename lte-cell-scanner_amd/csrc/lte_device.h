@@ -239,41 +239,49 @@ __device__ __forceinline__ void qpsk_llr(cd2 sym, double np, double &l0, double 
   l1 = trunc_log(metric[0] + metric[2]) - trunc_log(metric[1] + metric[3]);
 }
 
-// ---- tail-biting Viterbi of the PBCH decoder, one trellis per LANE (K = 7, G = (133,171,165)o, 40 steps; ref
-// src/lte_lib.cpp:538-551 -> itpp decode_tailbite: one trellis pass per start state, end state forced equal).
-// Lane ss runs the trellis that starts in state ss and keeps all 64 path metrics in registers, so a step is 32
-// butterflies of plain fp64 adds with no cross-lane traffic (the lane-per-state form moves every metric through
-// ds_bpermute: measured LDS-pipe bound, ~100 us of a whole CU per candidate).  Butterfly j reads old states 2j,
-// 2j+1 and writes new states j, j+32 INTO THE SAME TWO REGISTERS, so after k steps state s lives in slot
+// ---- tail-biting Viterbi of the PBCH decoder (K = 7, G = (133,171,165)o, 40 steps; ref src/lte_lib.cpp:538-551 -> itpp
+// decode_tailbite: one trellis pass per start state, end state forced equal, the best end metric wins).
+// PASS 1, one trellis per LANE: lane ss runs the trellis that starts in state ss and keeps all 64 path metrics in registers,
+// so a step is 32 butterflies of plain fp64 adds with no cross-lane traffic (the lane-per-state form of all 64 trellises moves
+// every metric through ds_bpermute: measured LDS-pipe bound, ~100 us of a whole CU per candidate).  Butterfly j reads old
+// states 2j, 2j+1 and writes new states j, j+32 INTO THE SAME TWO REGISTERS, so after k steps state s lives in slot
 // rotl6(s, k); the slot pattern repeats every 6 steps, which is the unroll depth.  Branch metrics as IT++ forms them
 // (Convolutional_Code::calc_metric: the metrics of all 2^n output words of a step are built first, from the LAST
 // generator's observation to the first, and a path metric is old + that one value): d(o) = ((+-r2) + (+-r1)) + (+-r0),
 // d(~o) = -d(o) exactly; all three generators tap the input bit and the oldest register bit, so a butterfly needs one
-// value and its negative -- 4 fp64 adds per butterfly (round 2 added the three observations to every path metric one
-// by one: 12).  Ties keep predecessor 2j.
+// value and its negative -- 4 fp64 adds and 2 minima per butterfly.
+// Round 6: pass 1 keeps NO survivors -- only the end metric of each start state is needed to pick the winner (rounds 1-5
+// pushed a decision bit per new state into survivor words, 2 of 5 instructions per state, and parked 20 KB of them per
+// candidate in LDS: 64 trellises' worth, of which one is ever traced back).  PASS 2 (vit_retrace_*) runs the ONE winning
+// trellis again, one STATE per lane (64 lanes, metrics exchanged by two wave shuffles a step), forms the same sums in the same
+// order -- so the same metrics and the same decisions, ties included (the lower-numbered predecessor stays on equal metrics,
+// as the reference's strict <) -- keeps each state's 40 decisions in a register and traces back from the forced end state.
 #define VIT_ROTL6(s, k) ((((s) << (k)) | ((s) >> (6 - (k)))) & 63)
-// Survivor words are built by PUSHING decisions (word = 2 word + decision): within a step the decision of new state
-// 32 b + j is pushed j-th into word b, so it ends at bit 31 - j of that word = bit (n ^ 31) of the 64-bit word for state n.
-// FAST (every observation finite: path metrics are finite or +inf, never NaN): the survivor metric is min(m0, m1) -- equal
-// to the select for every such pair, ties included -- and on the device the decision goes from the compare's carry
-// straight into the word (v_cmp writes VCC, v_addc shifts it in): 4 instructions per new state instead of 5.5, and no
-// compare result travels through an SGPR pair into three v_cndmask (round 3: 410 hazard s_nop per 6 steps).  !FAST keeps
-// the compare-and-select form, whose NaN behaviour is the reference's `<`.
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
-#error "vit_push: the carry-chain form is gfx9 / wave64 assembly (VCC is a 64-bit pair): this library is built for gfx950 only"
-#endif
-__host__ __device__ __forceinline__ void vit_push(unsigned &word, double m1, double m0) {
+// output word (o0 + 2 o1 + 4 o2) of the transition (input bit b, old state p)
+__host__ __device__ __forceinline__ int vit_word(int b, int p) {
+  const int g = (b << 6) | p;
+  return __builtin_parity(g & 0133) | (__builtin_parity(g & 0171) << 1) | (__builtin_parity(g & 0165) << 2);
+}
+// FAST (every observation finite: path metrics are finite or +inf, never NaN): the survivor metric is min(m0, m1) (v_min_f64) --
+// equal to the select for every such pair up to the SIGN of a zero, which no later comparison sees.  !FAST keeps the
+// compare-and-select form, whose NaN behaviour is the reference's `<`.
+// the four branch values of a step, d[i] for the output words i = o0 + 2 o1 (o2 = 0); the other four words are their negatives.
+// They are the same for every lane (the observations come from LDS): on the device they are moved into SCALAR registers, where
+// they cost no vector register and every v_add_f64 reads one as its scalar operand (held in vector registers the compiler
+// fetched the observations of many steps ahead: 139 registers beyond the 256 a wave may have).
+struct VitBranch { double d[4]; };
+__host__ __device__ __forceinline__ VitBranch vit_branch(double r0, double r1, double r2) {
+  VitBranch v;
+  v.d[0] = (-r2 + -r1) + -r0; v.d[1] = (-r2 + -r1) + r0; v.d[2] = (-r2 + r1) + -r0; v.d[3] = (-r2 + r1) + r0;
 #if defined(__HIP_DEVICE_COMPILE__)
-  asm("v_cmp_lt_f64 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(word) : "v"(m1), "v"(m0) : "vcc");
-#else
-  word = (word << 1) | ((m1 < m0) ? 1u : 0u);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    v.d[i] = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v.d[i])), __builtin_amdgcn_readfirstlane(__double2loint(v.d[i])));
 #endif
+  return v;
 }
 template <int K, bool FAST>
-__host__ __device__ __forceinline__ void vit_step(double (&pm)[64], double r0, double r1, double r2, unsigned &lo, unsigned &hi) {
-  lo = 0u; hi = 0u;
-  // d[i], i = o0 + 2 o1 (o2 = 0): the four words whose last output bit is 0; the others are their negatives
-  const double d[4] = {(-r2 + -r1) + -r0, (-r2 + -r1) + r0, (-r2 + r1) + -r0, (-r2 + r1) + r0};
+__host__ __device__ __forceinline__ void vit_step(double (&pm)[64], const VitBranch &br) {
 #pragma unroll
   for (int j = 0; j < 32; ++j) {
     const int p0 = 2 * j, p1 = 2 * j + 1;
@@ -281,36 +289,33 @@ __host__ __device__ __forceinline__ void vit_step(double (&pm)[64], double r0, d
     const double o0 = pm[sa], o1 = pm[sb];
 #pragma unroll
     for (int b = 0; b < 2; ++b) {                      // new state j + 32 b <- (input bit b, predecessor p0 / p1)
-      const int g0 = (b << 6) | p0, g1 = (b << 6) | p1;
-      const int w0 = __builtin_parity(g0 & 0133) | (__builtin_parity(g0 & 0171) << 1) | (__builtin_parity(g0 & 0165) << 2);
-      const int w1 = __builtin_parity(g1 & 0133) | (__builtin_parity(g1 & 0171) << 1) | (__builtin_parity(g1 & 0165) << 2);
-      const double m0 = o0 + ((w0 < 4) ? d[w0 & 3] : -d[(7 - w0) & 3]);
-      const double m1 = o1 + ((w1 < 4) ? d[w1 & 3] : -d[(7 - w1) & 3]);
-      if (FAST) {
+      const int w0 = vit_word(b, p0), w1 = vit_word(b, p1);
+      const double m0 = o0 + ((w0 < 4) ? br.d[w0 & 3] : -br.d[(7 - w0) & 3]);
+      const double m1 = o1 + ((w1 < 4) ? br.d[w1 & 3] : -br.d[(7 - w1) & 3]);
 #if defined(__HIP_DEVICE_COMPILE__)
-        pm[b ? sb : sa] = fmin(m0, m1);                // v_min_f64; differs from the select below at most in the SIGN of a zero metric (+0 / -0 tie)
+      pm[b ? sb : sa] = FAST ? fmin(m0, m1) : ((m1 < m0) ? m1 : m0);
 #else
-        pm[b ? sb : sa] = (m1 < m0) ? m1 : m0;         // the host twin: the decision's own comparison (C's fmin leaves the zero's sign open)
+      pm[b ? sb : sa] = (m1 < m0) ? m1 : m0;           // the host twin: the decision's own comparison (C's fmin leaves the zero's sign open)
 #endif
-        vit_push(b ? hi : lo, m1, m0);
-      } else {
-        const bool take1 = m1 < m0;                    // ties keep the lower-numbered predecessor
-        pm[b ? sb : sa] = take1 ? m1 : m0;
-        if (b) hi = (hi << 1) | (take1 ? 1u : 0u); else lo = (lo << 1) | (take1 ? 1u : 0u);
-      }
     }
+#if defined(__HIP_DEVICE_COMPILE__)
+    // four butterflies (24 independent fp64 operations) are all the instruction-level parallelism a SIMD can use; left alone the
+    // scheduler interleaves all 32 of a step and several steps, and the temporaries of that cost 140 registers more than a wave has
+    if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+#endif
   }
 }
-// all 40 steps of the trellis that starts in state ss; surv[t * stride]: bit n ^ 31 = decision of new state n at step t.
-// Returns the metric of the forced end state ss.
+// all 40 steps of the trellis that starts in state ss: the metric of the forced end state ss
 template <bool FAST>
-__host__ __device__ __forceinline__ double vit_trellis(const double *d0, const double *d1, const double *d2, int ss,
-                                                       unsigned long long *surv, int stride) {
+__host__ __device__ __forceinline__ double vit_end_metric(const double *d0, const double *d1, const double *d2, int ss) {
   double pm[64];
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+v"(ss));      // (the 64 initial metrics are formed HERE: hoisted out of a caller's loop as invariants they are 128 registers spilled across it)
+#endif
 #pragma unroll
   for (int s = 0; s < 64; ++s) pm[s] = (s == ss) ? 0.0 : INFINITY;
-  unsigned lo, hi;
-#define VIT_S(K, T) do { vit_step<K, FAST>(pm, d0[T], d1[T], d2[T], lo, hi); surv[(size_t)(T) * stride] = ((unsigned long long)hi << 32) | lo; } while (0)
+#define VIT_S(K, T) vit_step<K, FAST>(pm, vit_branch(d0[T], d1[T], d2[T]))
+#pragma unroll 1
   for (int t6 = 0; t6 < 42; t6 += 6) {
     VIT_S(0, t6); VIT_S(1, t6 + 1); VIT_S(2, t6 + 2); VIT_S(3, t6 + 3);
     if (t6 + 4 < 40) { VIT_S(4, t6 + 4); VIT_S(5, t6 + 5); }
@@ -324,17 +329,78 @@ __host__ __device__ __forceinline__ double vit_trellis(const double *d0, const d
 }
 // true when every one of the 3 x 40 observations is finite (the FAST form is then exact)
 __host__ __device__ __forceinline__ bool vit_finite(double x) { return x - x == 0.0; }
-// decoded bits of the trellis whose survivor words are surv[t * stride] and whose start = end state is ss
-__host__ __device__ __forceinline__ unsigned long long vit_traceback(const unsigned long long *surv, int stride, int ss) {
-  int s = ss;
+
+// PASS 2, what new state n does in one step: its two predecessors, and which of the step's four branch values (and sign) each
+// transition takes -- constants of the state.
+struct VitState { int p0, p1, i0, i1; bool neg0, neg1; };
+__host__ __device__ __forceinline__ VitState vit_state(int n) {
+  VitState v;
+  const int b = n >> 5;
+  v.p0 = (2 * n) & 63;
+  v.p1 = v.p0 | 1;
+  const int w0 = vit_word(b, v.p0), w1 = vit_word(b, v.p1);
+  v.neg0 = w0 >= 4; v.i0 = v.neg0 ? ((7 - w0) & 3) : (w0 & 3);
+  v.neg1 = w1 >= 4; v.i1 = v.neg1 ? ((7 - w1) & 3) : (w1 & 3);
+  return v;
+}
+// the survivor of new state n given its predecessors' metrics: the same sums as vit_step (old + one branch value); *take1 = the
+// decision (predecessor p1 only when STRICTLY better)
+__host__ __device__ __forceinline__ double vit_state_step(const VitState &v, double o0, double o1, double r0, double r1, double r2, bool *take1) {
+  const double d[4] = {(-r2 + -r1) + -r0, (-r2 + -r1) + r0, (-r2 + r1) + -r0, (-r2 + r1) + r0};
+  const double s0 = (v.i0 == 0) ? d[0] : (v.i0 == 1) ? d[1] : (v.i0 == 2) ? d[2] : d[3];
+  const double s1 = (v.i1 == 0) ? d[0] : (v.i1 == 1) ? d[1] : (v.i1 == 2) ? d[2] : d[3];
+  const double m0 = o0 + (v.neg0 ? -s0 : s0);
+  const double m1 = o1 + (v.neg1 ? -s1 : s1);
+  *take1 = m1 < m0;
+  return *take1 ? m1 : m0;
+}
+// decoded bits from the 64 states' decision words (bit t of dec[n] = decision of new state n at step t), start = end state ss
+#define VIT_TRACE_STEP(bits, s, t, word_of_s) do { (bits) |= (unsigned long long)(((s) >> 5) & 1) << (t); \
+                                                   (s) = (((s) << 1) & 63) | (int)(((word_of_s) >> (t)) & 1ull); } while (0)
+// host twin of the wave's retrace (the 64 lanes walked in a loop): decoded bits, and the end metric of state ss for the tests
+__host__ inline unsigned long long vit_retrace_host(const double *d0, const double *d1, const double *d2, int ss, double *end_metric) {
+  double pm[64], nx[64];
+  unsigned long long dec[64];
+  for (int n = 0; n < 64; ++n) { pm[n] = (n == ss) ? 0.0 : INFINITY; dec[n] = 0ull; }
+  for (int t = 0; t < 40; ++t) {
+    for (int n = 0; n < 64; ++n) {
+      const VitState v = vit_state(n);
+      bool take1;
+      nx[n] = vit_state_step(v, pm[v.p0], pm[v.p1], d0[t], d1[t], d2[t], &take1);
+      dec[n] |= (unsigned long long)(take1 ? 1 : 0) << t;
+    }
+    for (int n = 0; n < 64; ++n) pm[n] = nx[n];
+  }
+  if (end_metric) *end_metric = pm[ss];
   unsigned long long bits = 0ull;                      // bit t = decoded bit c_est(t)
+  int s = ss;
+  for (int t = 39; t >= 0; --t) VIT_TRACE_STEP(bits, s, t, dec[s]);
+  return bits;
+}
+#if defined(__HIPCC__)
+// the wave's form: lane = state; all 64 lanes call it with the same (wave-uniform) ss; the decoded bits come back on every lane
+__device__ __forceinline__ unsigned long long vit_retrace_wave(const double *d0, const double *d1, const double *d2, int ss, int lane) {
+  const VitState v = vit_state(lane);
+  double pm = (lane == ss) ? 0.0 : INFINITY;
+  unsigned dlo = 0u, dhi = 0u;                         // this state's decisions, bit t (mod 32) of the word for step t
+#pragma unroll 4
+  for (int t = 0; t < 40; ++t) {
+    const double o0 = __shfl(pm, v.p0), o1 = __shfl(pm, v.p1);
+    bool take1;
+    pm = vit_state_step(v, o0, o1, d0[t], d1[t], d2[t], &take1);
+    if (t < 32) dlo |= (take1 ? 1u : 0u) << t; else dhi |= (take1 ? 1u : 0u) << (t - 32);
+  }
+  // traceback on the scalar unit: the state walked is the same on every lane, its decision word comes by v_readlane
+  unsigned long long bits = 0ull;
+  int s = __builtin_amdgcn_readfirstlane(ss);
   for (int t = 39; t >= 0; --t) {
+    const unsigned w = (unsigned)__builtin_amdgcn_readlane((int)(t < 32 ? dlo : dhi), s);
     bits |= (unsigned long long)((s >> 5) & 1) << t;
-    const int dec = (int)((surv[(size_t)t * stride] >> (s ^ 31)) & 1ull);
-    s = ((s << 1) & 63) | dec;
+    s = ((s << 1) & 63) | (int)((w >> (t & 31)) & 1u);
   }
   return bits;
 }
+#endif
 // CRC-16 (x^16+x^12+x^5+1, zero init) of the 24 payload bits against the received 16, with the antenna-port mask
 // (ref src/lte_lib.cpp:637-663, src/searcher.cpp:1628-1636)
 __host__ __device__ __forceinline__ int pbch_crc_ok(unsigned long long bits, int n_ports) {
@@ -352,40 +418,49 @@ __host__ __device__ __forceinline__ int pbch_crc_ok(unsigned long long bits, int
 }
 
 // ---- PBCH decode by ONE wave from the descrambled LLRs (LDS) to the 40 decoded bits: de-ratematch, the 64 tail-biting
-// trellises one per lane, CRC-16 with the antenna-port mask (ref src/lte_lib.cpp:469-518, 538-551, 637-663;
-// src/searcher.cpp:1617-1636).  `surv` is 40 x 64 survivor words of LDS whose first m_bit doubles hold the LLRs on
-// entry (they are dead once de-ratematched); called by all 64 lanes after a barrier behind the LLR writes; ok / bits40
-// are valid on every lane afterwards.
-// The trellis pass stays out of line: it takes ~240 registers of its own; inlined, whatever lives across it spills.
+// trellises one per lane (end metrics), the winner once more one state per lane (decisions, traceback), CRC-16 with the
+// antenna-port mask (ref src/lte_lib.cpp:469-518, 538-551, 637-663; src/searcher.cpp:1617-1636).  e_est: the wave's m_bit LLRs in
+// LDS, d_est: 3 x 40 doubles of LDS of the wave's own.  Called by all 64 lanes of ONE wave after the LLR writes; only wave-level
+// synchronisation inside (the waves of a workgroup run independent candidates); ok / bits40 are valid on every lane afterwards.
+// The trellis pass stays out of line: it takes ~170 registers of its own; inlined, whatever lives across it would spill.
 template <bool FAST>
-static __device__ __noinline__ double pbch_trellis_pass(const double (*d_est)[40], int ss, unsigned long long *surv) {
-  return vit_trellis<FAST>(d_est[0], d_est[1], d_est[2], ss, surv, 64);
+static __device__ __forceinline__ double pbch_trellis_pass(const double (*d_est)[40], int ss) {
+  return vit_end_metric<FAST>(d_est[0], d_est[1], d_est[2], ss);
 }
-__device__ __forceinline__ void pbch_decode_wave(unsigned long long *surv, double (*d_est)[40], const int16_t *__restrict__ derm_inv,
+__device__ __forceinline__ void pbch_decode_wave(const double *e_est, double (*d_est)[40], const int16_t *__restrict__ derm_inv,
                                                  int m_bit, int n_ports, int lane, int &ok, unsigned long long &bits40) {
-  const double *e_est = reinterpret_cast<const double *>(surv);
-  // de-ratematch: average all observations of each coded bit (ref src/lte_lib.cpp:497-509); the sums wait in registers
-  // until every lane has read its LLRs, because the survivor words reuse that LDS
-  double dsum[2];
+  // de-ratematch: average all observations of each coded bit, added in ascending position (ref src/lte_lib.cpp:497-509); the
+  // (up to 16) LLRs of a bit are fetched first, all in flight together, and summed in order
+  lcs_wave_sync();
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     const int bit = lane + 64 * q;
-    double s = 0; int cnt = 0;
     if (bit < 120) {
-      const int16_t *lst = derm_inv + ((m_bit == 1920) ? 0 : 120 * 16) + bit * 16;   // ascending bit positions
-      for (int k = 0; k < 16; ++k) { const int t = lst[k]; if (t < 0) break; s += e_est[t]; ++cnt; }
+      const int16_t *lst = derm_inv + ((m_bit == 1920) ? 0 : 120 * 16) + bit * 16;   // ascending bit positions, -1 padded
+      double v[16];
+      int cnt = 0;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) { const int t = lst[k]; v[k] = (t >= 0) ? e_est[t] : 0.0; cnt += (t >= 0); }
+      double s = 0;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) if (k < cnt) s += v[k];
       if (cnt > 1) s = s / cnt;
+      d_est[bit / 40][bit % 40] = s;
     }
-    dsum[q] = s;
   }
-  __syncthreads();
-  d_est[lane / 40][lane % 40] = dsum[0];
-  if (lane + 64 < 120) d_est[(lane + 64) / 40][(lane + 64) % 40] = dsum[1];
-  __syncthreads();
+  lcs_wave_sync();
+#ifdef PH
+  PH(2);
+#endif
   // lane = start state; the best end metric wins, the lowest start state among equals (ascending, strict < in the reference).
-  // Finite observations (every real capture) take the min / carry form of the step; anything else the compare-and-select form.
-  const bool finite = !__any(!(vit_finite(dsum[0]) && vit_finite(dsum[1])));
-  const double fin = finite ? pbch_trellis_pass<true>(d_est, lane, surv + lane) : pbch_trellis_pass<false>(d_est, lane, surv + lane);
+  // Finite observations (every real capture) take the min form of the step; anything else the compare-and-select form.
+  bool fin_in = true;
+  for (int k = lane; k < 120; k += 64) fin_in = fin_in && vit_finite(d_est[k / 40][k % 40]);
+  const bool finite = !__any(!fin_in);
+  const double fin = finite ? pbch_trellis_pass<true>(d_est, lane) : pbch_trellis_pass<false>(d_est, lane);
+#ifdef PH
+  PH(3);
+#endif
   double best = (fin < INFINITY) ? fin : INFINITY;       // NaN / unreachable never win
   int best_ss = lane;
 #pragma unroll
@@ -394,11 +469,10 @@ __device__ __forceinline__ void pbch_decode_wave(unsigned long long *surv, doubl
     const int oi = __shfl_xor(best_ss, off);
     if (ov < best || (ov == best && oi < best_ss)) { best = ov; best_ss = oi; }
   }
-  __syncthreads();
   ok = 0;
   bits40 = 0ull;
   if (best < INFINITY) {
-    bits40 = vit_traceback(surv + best_ss, 64, best_ss);
+    bits40 = vit_retrace_wave(d_est[0], d_est[1], d_est[2], __builtin_amdgcn_readfirstlane(best_ss), lane);
     ok = pbch_crc_ok(bits40, n_ports);
   }
 }

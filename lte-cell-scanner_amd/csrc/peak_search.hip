@@ -130,7 +130,7 @@ __global__ __launch_bounds__(PS_THREADS) void k_peak_search(const double *__rest
 #define PSR_THREADS 256
 #define PSR_RPR ((LCS_N_IDX + PSR_THREADS - 1) / PSR_THREADS)   // registers per PSS row (38, last one half padding)
 #define PSR_REGS (3 * PSR_RPR)
-__global__ __launch_bounds__(PSR_THREADS) __attribute__((amdgpu_waves_per_eu(3, 8))) void k_peak_search_reg(const float *__restrict__ pow32, const int *__restrict__ frq,
+__global__ __launch_bounds__(PSR_THREADS) __attribute__((amdgpu_waves_per_eu(2, 8))) void k_peak_search_reg(const float *__restrict__ pow32, const int *__restrict__ frq,
                                                                  const double *__restrict__ zth,
                                                                  const float *__restrict__ single,
                                                                  const double *__restrict__ fset,

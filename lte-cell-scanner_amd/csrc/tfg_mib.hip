@@ -206,6 +206,7 @@ __global__ __launch_bounds__(CP_THREADS) void k_cell_prep(const lcs_cell *__rest
     double *sc = scratch + (size_t)it * CS_SIZE;
     const SlotParams p = params[items[it].slot];
     const int n_symb = cell_n_symb(c), id = cell_id(c);
+    if (tid >= 128 && tid < 140) sc[CS_CAND + (tid - 128) * 4] = 0.0;     // no PBCH candidate of this cell has passed yet (k_pbch's early exit reads these)
     // wave 1, lane 0: the timestamp walk; wave 0 meanwhile: the CRS table
     if ((mode & 1) && tid == 64) tfg_timestamps(c, p, ts + (size_t)it * ROWS, s_ts, sc);
     if ((mode & 2) && tid < 64 && n_symb >= 0 && id >= 0) {
@@ -861,113 +862,115 @@ __device__ __forceinline__ double np_from_partials(const double *sc, int port) {
 // ------------------------------------------------------------------------ PBCH decode
 // One WAVE per (cell, candidate): candidate = frame_timing_guess*3 + {1,2,4 ports}.  The equalised symbols stay in
 // registers (symbol pairs go straight through the soft demodulator), the 1920 LLRs go through LDS, and the 64
-// tail-biting trellises run one per lane with their path metrics in registers (lte_device.h).  < 256 VGPRs and 21 KB of
-// LDS per wave.  FOUR candidates share a workgroup, one wave (= one SIMD) each: in the pipelined chain a workgroup of
-// this kernel can only start where a resident correlation workgroup (4 waves x 228 VGPRs, 68 KB) has retired, and keeps
-// the next one out for its whole ~160 us -- as 264 one-wave workgroups spread over the chip that emptied up to 264
-// correlation slots, as 66 four-wave workgroups it empties 66 (profiles/r03/experiments: the chain's cost is the slots
-// it keeps empty, not slower workgroups).
+// tail-biting trellises run one per lane with their path metrics in registers (lte_device.h).  Four waves (= one per
+// SIMD) share a workgroup: in the pipelined chain a workgroup of this kernel can only start where a resident
+// correlation workgroup has retired, and a workgroup should fill the slot it takes (profiles/r03/experiments: the chain's
+// cost is the slots it keeps empty, not slower workgroups).
+// Round 6: the waves are INDEPENDENT workers on one task list, candidate-major: task k = (candidate k / n, cell k % n); wave w of
+// workgroup b takes tasks 4 b + w, + 4 gridDim, ...  Workgroups are dispatched in ascending order, so the list is worked through
+// in ascending order as slots free up.  The reference tries the candidates of a cell in order and stops at the first that passes
+// (ref :1547, :1567, :1638-1686): a candidate behind a passing one can never be chosen, so a task whose cell already shows a
+// passing earlier candidate is skipped -- by the time candidate c of a cell comes up, its candidate c - 1 was dispatched a whole
+// sweep over the cells earlier.  (A flag that is not visible yet costs a decode, never a result: k_mib_select takes the first
+// passing candidate in order.)  Rounds 4-5 ran three launches of four candidates and skipped whole ranges: 8.0 of 12
+// candidates decoded per decodable cell on average, now ~6.5-7, in one launch.
+// No survivor words (lte_device.h: two-pass decoder): 15 KB of LLRs + 1 KB per wave, no scratch.
 #define PB_THREADS 64                 // lanes of one candidate
-#define PB_CANDS 4                    // candidates (waves) per workgroup
+#define PB_CANDS 4                    // independent waves per workgroup
+// pbch_extract (ref :1503-1520) + equalisation (ref :1571-1612) + soft demodulation + descrambling of one candidate by one wave: the
+// LLRs go to e_est (LDS).
+static __device__ __forceinline__ void pbch_llr_wave(const lcs_cell &c, const double *__restrict__ sc, const double2 *__restrict__ g, const double2 *__restrict__ cep,
+                                                  const uint8_t *__restrict__ scr, int guess, int n_ports, int tid, double *__restrict__ e_est) {
+  const int n_symb = cell_n_symb(c), id = cell_id(c);
+  const int m_bit = (c.cp_type == LCS_CP_NORMAL) ? 1920 : 1728;
+  const int n_sym = m_bit / 2, per_frame = n_sym / 4;
+  const int v3 = d_imod(id, 3);
+  const int r0 = (v3 == 0) ? 1 : 0, r1 = (v3 == 2) ? 1 : 2;     // the two residues != v3, ascending
+  const double np0 = np_from_partials(sc, 0), np1 = np_from_partials(sc, 1), np2 = np_from_partials(sc, 2), np3 = np_from_partials(sc, 3);
+  const int start = guess * 10 * 2 * n_symb;
+  for (int pr = tid; pr < n_sym / 2; pr += PB_THREADS) {         // one symbol pair per lane and round
+    cd2 x[2], ha[2], hb[2], syms[2];
+    double npv[2];
+    const int t = 2 * pr;
+    // the two antenna ports this pair is equalised with (ref :1582-1611): port 0 (and 1) for one / two ports; with four, pairs
+    // alternate between ports (0, 2) and (1, 3)
+    const int pa = (n_ports == 4 && (t & 3) != 0) ? 1 : 0, pb = (n_ports == 2) ? 1 : (n_ports == 4 ? pa + 2 : 0);
+    for (int q = 0; q < 2; ++q) {
+      const int idx = t + q;
+      const int fr = idx / per_frame;
+      int rem = idx % per_frame, sym;
+      if (rem < 48) sym = 0; else if (rem < 96) { sym = 1; rem -= 48; } else if (rem < 168) { sym = 2; rem -= 96; } else { sym = 3; rem -= 168; }
+      const bool has_rs = (sym == 0) || (sym == 1) || (sym == 3 && n_symb == 6);
+      const int scx = has_rs ? (3 * (rem / 2) + ((rem & 1) ? r1 : r0)) : rem;
+      const int row = start + fr * 10 * 2 * n_symb + n_symb + sym;
+      x[q] = ld(&g[(size_t)row * NSC + scx]);
+      ha[q] = ld(&cep[((size_t)pa * ROWS + row) * NSC + scx]);
+      hb[q] = ld(&cep[((size_t)pb * ROWS + row) * NSC + scx]);
+    }
+    if (n_ports == 1) {
+      for (int q = 0; q < 2; ++q) {
+        const cd2 gain = cconj(cdiv(ha[q], mk(cabs2(ha[q]), 0)));
+        syms[q] = cmul(x[q], gain);
+        npv[q] = np0 * cabs2(gain);
+      }
+    } else {
+      const cd2 h1 = cdivr(cadd(ha[0], ha[1]), 2), h2 = cdivr(cadd(hb[0], hb[1]), 2);
+      const double np_temp = (n_ports == 2) ? (np0 + np1) / 2 : (pa == 0 ? (np0 + np2) / 2 : (np1 + np3) / 2);
+      const double scale = h1.re * h1.re + h1.im * h1.im + h2.re * h2.re + h2.im * h2.im;
+      const cd2 s0 = cdivr(cadd(cmul(cconj(h1), x[0]), cmul(h2, cconj(x[1]))), scale);
+      const cd2 s1 = cconj(cdivr(cadd(cmul(mk(-h2.re, h2.im), x[0]), cmul(h1, cconj(x[1]))), scale));
+      const double a1 = hypot(h1.re, h1.im) / scale, a2 = hypot(h2.re, h2.im) / scale;
+      const double npp = (a1 * a1 + a2 * a2) * np_temp;
+      const double s2 = pow(2.0, 0.5);
+      syms[0] = cscale(s0, s2); syms[1] = cscale(s1, s2);
+      npv[0] = npp; npv[1] = npp;
+    }
+    // soft demodulation (exact log-MAP, lte_device.h) and descrambling
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int l = t + q;
+      double l0, l1;
+      qpsk_llr(syms[q], npv[q], l0, l1);
+      if (scr[2 * l]) l0 = -l0;
+      if (scr[2 * l + 1]) l1 = -l1;
+      e_est[2 * l] = l0; e_est[2 * l + 1] = l1;
+    }
+  }
+}
 __global__ __launch_bounds__(PB_THREADS * PB_CANDS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_pbch(const lcs_cell *__restrict__ cells, const int *__restrict__ n_work,
                                                       const double2 *__restrict__ tfg_comp, const double2 *__restrict__ ce,
                                                       double *__restrict__ scratch, const uint8_t *__restrict__ pbch_scr,
-                                                      const int16_t *__restrict__ derm_inv /*[2][120][16]*/, int y0) {
+                                                      const int16_t *__restrict__ derm_inv /*[2][120][16]*/) {
   LCS_TAIL_PRIO();
-  __shared__ unsigned long long surv_all[PB_CANDS][40 * 64];      // per wave: survivor words [step][trellis]; holds the LLRs until they are de-ratematched
+  __shared__ double llr_all[PB_CANDS][1920];
   __shared__ double d_est_all[PB_CANDS][3][40];
-  // y0 >= 0: this launch runs candidate range y0 (grid.y = 1) and may skip decoded cells; y0 < 0: all ranges in one launch
-  const int wv = threadIdx.x >> 6, tid = threadIdx.x & 63, cand0 = (y0 < 0 ? (int)blockIdx.y : y0) * PB_CANDS, cand = cand0 + wv;
-  unsigned long long *surv = surv_all[wv];
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), tid = threadIdx.x & 63;
+  double *e_est = llr_all[wv];
   double (*d_est)[40] = d_est_all[wv];
-  double *e_est = reinterpret_cast<double *>(surv);  // 1920 doubles = 15 KB of the 20 KB
-  const int guess = cand / 3, n_ports = (cand % 3 == 2) ? 4 : (cand % 3) + 1;
-  for (int it = blockIdx.x; it < *n_work; it += gridDim.x) {
-    const lcs_cell c = cells[it];
+  const int n_cells = n_work[0], n_tasks = 12 * n_cells;
+  for (int task = (int)blockIdx.x * PB_CANDS + wv; task < n_tasks; task += (int)gridDim.x * PB_CANDS) {
+    const int cand = task / n_cells, it = task - cand * n_cells;
+    const int guess = cand / 3, n_ports = (cand % 3 == 2) ? 4 : (cand % 3) + 1;
     double *sc = scratch + (size_t)it * CS_SIZE;
-    // The reference tries the candidates in order and stops at the first that passes (ref :1547, :1567, :1638-1686): a
-    // candidate behind a passing one can never be chosen.  The launches of the later candidate ranges therefore skip the cells
-    // an earlier range (an earlier launch on this stream) already decoded -- the same for every wave of the workgroup.
-    if (y0 > 0) {
-      bool decided = false;
-      for (int k = 0; k < cand0; ++k) decided |= sc[CS_CAND + k * 4] != 0.0;
-      if (decided) {
-        if (tid == 0) { sc[CS_CAND + cand * 4 + 0] = 0.0; sc[CS_CAND + cand * 4 + 1] = 0.0; }
-        continue;
+    bool decided = false;
+    for (int k = 0; k < cand; ++k) decided |= __hip_atomic_load(&sc[CS_CAND + k * 4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0.0;
+    if (!decided) {                   // (a skipped candidate's flag stays 0, as k_cell_prep left it)
+      const lcs_cell c = cells[it];
+      const int m_bit = (c.cp_type == LCS_CP_NORMAL) ? 1920 : 1728;
+      lcs_wave_sync();                // the previous task's LLRs are no longer read
+      PH(0);
+      pbch_llr_wave(c, sc, tfg_comp + (size_t)it * ROWS * NSC, ce + ((size_t)it * 4) * ROWS * NSC, pbch_scr + (size_t)cell_id(c) * 1920, guess, n_ports, tid, e_est);
+      PH(1);
+      int ok = 0;
+      unsigned long long bits40 = 0ull;
+      pbch_decode_wave(e_est, d_est, derm_inv, m_bit, n_ports, tid, ok, bits40);
+      if (tid == 0) {
+        const unsigned bits24 = (unsigned)(bits40 & 0xffffffull);
+        sc[CS_CAND + cand * 4 + 1] = (double)bits24;
+        __hip_atomic_store(&sc[CS_CAND + cand * 4 + 0], (double)ok, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
       }
+      PH(4);
     }
-    const int n_symb = cell_n_symb(c), id = cell_id(c);
-    const int m_bit = (c.cp_type == LCS_CP_NORMAL) ? 1920 : 1728;
-    const int n_sym = m_bit / 2, per_frame = n_sym / 4;
-    const int v3 = d_imod(id, 3);
-    const int r0 = (v3 == 0) ? 1 : 0, r1 = (v3 == 2) ? 1 : 2;     // the two residues != v3, ascending
-    const double2 *g = tfg_comp + (size_t)it * ROWS * NSC;
-    const double2 *cep = ce + ((size_t)it * 4) * ROWS * NSC;
-    const double np0 = np_from_partials(sc, 0), np1 = np_from_partials(sc, 1), np2 = np_from_partials(sc, 2), np3 = np_from_partials(sc, 3);
-    const int start = guess * 10 * 2 * n_symb;
-    __syncthreads();
-    PH(0);
-    // pbch_extract (ref :1503-1520) + equalisation (ref :1571-1612), one symbol pair per thread and round
-    for (int pr = tid; pr < n_sym / 2; pr += PB_THREADS) {
-      cd2 x[2], h[4][2], syms[2];
-      double npv[2];
-      for (int q = 0; q < 2; ++q) {
-        const int idx = 2 * pr + q;
-        const int fr = idx / per_frame;
-        int rem = idx % per_frame, sym;
-        if (rem < 48) sym = 0; else if (rem < 96) { sym = 1; rem -= 48; } else if (rem < 168) { sym = 2; rem -= 96; } else { sym = 3; rem -= 168; }
-        const bool has_rs = (sym == 0) || (sym == 1) || (sym == 3 && n_symb == 6);
-        const int scx = has_rs ? (3 * (rem / 2) + ((rem & 1) ? r1 : r0)) : rem;
-        const int row = start + fr * 10 * 2 * n_symb + n_symb + sym;
-        x[q] = ld(&g[(size_t)row * NSC + scx]);
-        for (int pp = 0; pp < 4; ++pp) h[pp][q] = ld(&cep[((size_t)pp * ROWS + row) * NSC + scx]);
-      }
-      const int t = 2 * pr;
-      if (n_ports == 1) {
-        for (int q = 0; q < 2; ++q) {
-          const cd2 gain = cconj(cdiv(h[0][q], mk(cabs2(h[0][q]), 0)));
-          syms[q] = cmul(x[q], gain);
-          npv[q] = np0 * cabs2(gain);
-        }
-      } else {
-        cd2 h1, h2;
-        double np_temp;
-        if (n_ports == 2) { h1 = cdivr(cadd(h[0][0], h[0][1]), 2); h2 = cdivr(cadd(h[1][0], h[1][1]), 2); np_temp = (np0 + np1) / 2; }
-        else if ((t & 3) == 0) { h1 = cdivr(cadd(h[0][0], h[0][1]), 2); h2 = cdivr(cadd(h[2][0], h[2][1]), 2); np_temp = (np0 + np2) / 2; }
-        else { h1 = cdivr(cadd(h[1][0], h[1][1]), 2); h2 = cdivr(cadd(h[3][0], h[3][1]), 2); np_temp = (np1 + np3) / 2; }
-        const double scale = h1.re * h1.re + h1.im * h1.im + h2.re * h2.re + h2.im * h2.im;
-        const cd2 s0 = cdivr(cadd(cmul(cconj(h1), x[0]), cmul(h2, cconj(x[1]))), scale);
-        const cd2 s1 = cconj(cdivr(cadd(cmul(mk(-h2.re, h2.im), x[0]), cmul(h1, cconj(x[1]))), scale));
-        const double a1 = hypot(h1.re, h1.im) / scale, a2 = hypot(h2.re, h2.im) / scale;
-        const double npp = (a1 * a1 + a2 * a2) * np_temp;
-        const double s2 = pow(2.0, 0.5);
-        syms[0] = cscale(s0, s2); syms[1] = cscale(s1, s2);
-        npv[0] = npp; npv[1] = npp;
-      }
-      // soft demodulation (exact log-MAP, lte_device.h) and descrambling
-      const uint8_t *scr = pbch_scr + (size_t)id * 1920;
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const int l = t + q;
-        double l0, l1;
-        qpsk_llr(syms[q], npv[q], l0, l1);
-        if (scr[2 * l]) l0 = -l0;
-        if (scr[2 * l + 1]) l1 = -l1;
-        e_est[2 * l] = l0; e_est[2 * l + 1] = l1;
-      }
-    }
-    __syncthreads();
-    PH(1);
-    int ok = 0;
-    unsigned long long bits40 = 0ull;
-    pbch_decode_wave(surv, d_est, derm_inv, m_bit, n_ports, tid, ok, bits40);
-    if (tid == 0) {
-      const unsigned bits24 = (unsigned)(bits40 & 0xffffffull);
-      sc[CS_CAND + cand * 4 + 0] = (double)ok;
-      sc[CS_CAND + cand * 4 + 1] = (double)bits24;
-    }
-    __syncthreads();
-    PH(4);
   }
 }
 
@@ -1059,16 +1062,10 @@ int lcs_launch_mib(lcs_ctx *c, bool fused) {
   hipLaunchKernelGGL(k_chan_est, dim3(c->grid_items, 4, CE_NCHUNK), dim3(CE_THREADS), 0, c->stream, c->cells_out, c->n_work,
                      c->tfg_comp, fused ? (const double2 *)c->tfg : (const double2 *)nullptr, (const double *)c->tfg_ts, c->cell_scratch,
                      c->ce, c->needed_rows_only ? 1 : 0);
-  // batches: one launch per range of four candidates, in the reference's order -- a range skips the cells an earlier one
-  // decoded (default band + 0.4 %, dense band + 0.7 %: profiles/r04/experiments/ab_pbch_candidate_ranges.txt); the streaming
-  // mode's graph replays every launch for every buffer, mostly on empty work lists: one launch there
-  if (c->single_stream)
-    hipLaunchKernelGGL(k_pbch, dim3(c->grid_items, 12 / PB_CANDS), dim3(PB_THREADS * PB_CANDS), 0, c->stream, c->cells_out, c->n_work, c->tfg_comp,
-                       c->ce, c->cell_scratch, c->d_pbch_scr, c->d_derm_inv, -1);
-  else
-    for (int y = 0; y < 12 / PB_CANDS; ++y)
-      hipLaunchKernelGGL(k_pbch, dim3(c->grid_items, 1), dim3(PB_THREADS * PB_CANDS), 0, c->stream, c->cells_out, c->n_work, c->tfg_comp,
-                         c->ce, c->cell_scratch, c->d_pbch_scr, c->d_derm_inv, y);
+  // one launch: independent waves on a candidate-major task list (k_pbch), one task per wave when the work list is as long as the
+  // previous batch said (grid_items ~ cells expected + 1/8); a longer list only makes the waves loop
+  hipLaunchKernelGGL(k_pbch, dim3(std::max(32, 3 * c->grid_items)), dim3(PB_THREADS * PB_CANDS), 0, c->stream, c->cells_out, c->n_work, c->tfg_comp,
+                     c->ce, c->cell_scratch, c->d_pbch_scr, c->d_derm_inv);
   hipLaunchKernelGGL(k_mib_select, dim3((LCS_MAX_WORK + 63) / 64), dim3(64), 0, c->stream, c->cells_out, c->n_work,
                      c->cell_scratch, scatter_back ? c->peaks : nullptr, c->work_items);
   HIPCHK(c, hipGetLastError());

@@ -370,15 +370,14 @@ __global__ __launch_bounds__(TRK_CE_THREADS) void k_trk_ce(const lcs_track_cell 
 
 // One MIB attempt per (frame offset, cell): pbch_extract_rt (:494-529) + the decoder of do_mib_decode (:555-705).
 #define TRK_PB_THREADS 64       // one wave: LLRs through LDS, then the 64 trellises one per lane (lte_device.h)
-__global__ __launch_bounds__(TRK_PB_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_trk_mib(const lcs_track_cell *__restrict__ cells, int n_sym, int n_off,
+__global__ __launch_bounds__(TRK_PB_THREADS) void k_trk_mib(const lcs_track_cell *__restrict__ cells, int n_sym, int n_off,
                                                            const double2 *__restrict__ syms, const double2 *__restrict__ ce,
                                                            const double *__restrict__ ce_pw, const int *__restrict__ ce_upto,
                                                            const uint8_t *__restrict__ pbch_scr, const int16_t *__restrict__ derm_inv,
                                                            int *__restrict__ mib_ok, unsigned long long *__restrict__ mib_bits,
                                                            const int *__restrict__ mib_first /* nullable */) {
-  __shared__ unsigned long long surv[40 * 64];      // survivor words [step][trellis]; holds the LLRs until they are de-ratematched
+  __shared__ double e_est[1920];                    // the attempt's LLRs (the decoder keeps no survivor words: lte_device.h)
   __shared__ double d_est[3][40];
-  double *e_est = reinterpret_cast<double *>(surv);
   const int off = blockIdx.x, cell = blockIdx.y, tid = threadIdx.x;
   if (mib_first && off < mib_first[cell]) {          // continuous tracking: an earlier call attempted this frame offset already
     if (tid == 0) { mib_ok[(size_t)cell * n_off + off] = -1; mib_bits[(size_t)cell * n_off + off] = 0ull; }
@@ -399,9 +398,12 @@ __global__ __launch_bounds__(TRK_PB_THREADS) __attribute__((amdgpu_waves_per_eu(
   const int r0 = (v3 == 0) ? 1 : 0, r1 = (v3 == 2) ? 1 : 2;       // the two residues != v3, ascending
   const uint8_t *scr = pbch_scr + (size_t)id * 1920;
   for (int pr = tid; pr < n_syms / 2; pr += TRK_PB_THREADS) {
-    cd2 x[2], h[4][2], sy[2];
-    double npp[4], npv[2];
+    cd2 x[2], ha[2], hb[2], sy[2];
+    double npa = 0, npb = 0, npv[2];
     const int t = 2 * pr;
+    // the two antenna ports this pair is equalised with: port 0 (and 1) for one / two ports; with four, pairs alternate between
+    // ports (0, 2) and (1, 3) (the array form h[port][q] indexed by a run-time port lived in scratch memory)
+    const int pa = (c.n_ports == 4 && (t & 3) != 0) ? 1 : 0, pb = (c.n_ports == 2) ? 1 : (c.n_ports == 4 ? pa + 2 : 0);
     for (int q = 0; q < 2; ++q) {
       const int ix = t + q, fr = ix / per_fr;
       int rem = ix % per_fr, symn;
@@ -410,23 +412,22 @@ __global__ __launch_bounds__(TRK_PB_THREADS) __attribute__((amdgpu_waves_per_eu(
       const int scx = has_rs ? (3 * (rem / 2) + ((rem & 1) ? r1 : r0)) : rem;
       const int i = (off + fr) * per_frame + n_symb + symn;
       x[q] = ld(&syms[((size_t)cell * n_sym + i) * 72 + scx]);
-      for (int p = 0; p < c.n_ports; ++p) {
-        h[p][q] = ld(&ce[(((size_t)cell * 4 + p) * n_sym + i) * 72 + scx]);
-        if (q == 0) npp[p] = ce_pw[(((size_t)cell * 4 + p) * n_sym + i) * 4 + 3];       // np_pre(port, t): the symbol pair shares an OFDM symbol
+      ha[q] = ld(&ce[(((size_t)cell * 4 + pa) * n_sym + i) * 72 + scx]);
+      hb[q] = ld(&ce[(((size_t)cell * 4 + pb) * n_sym + i) * 72 + scx]);
+      if (q == 0) {                                                  // np_pre(port, t): the symbol pair shares an OFDM symbol
+        npa = ce_pw[(((size_t)cell * 4 + pa) * n_sym + i) * 4 + 3];
+        npb = ce_pw[(((size_t)cell * 4 + pb) * n_sym + i) * 4 + 3];
       }
     }
     if (c.n_ports == 1) {
       for (int q = 0; q < 2; ++q) {
-        const cd2 gain = cconj(cdiv(h[0][q], mk(cabs2(h[0][q]), 0)));
+        const cd2 gain = cconj(cdiv(ha[q], mk(cabs2(ha[q]), 0)));
         sy[q] = cmul(x[q], gain);
-        npv[q] = npp[0] * cabs2(gain);
+        npv[q] = npa * cabs2(gain);
       }
     } else {
-      cd2 h1, h2;
-      double np_temp;
-      if (c.n_ports == 2) { h1 = cdivr(cadd(h[0][0], h[0][1]), 2); h2 = cdivr(cadd(h[1][0], h[1][1]), 2); np_temp = (npp[0] + npp[1]) / 2; }
-      else if ((t & 3) == 0) { h1 = cdivr(cadd(h[0][0], h[0][1]), 2); h2 = cdivr(cadd(h[2][0], h[2][1]), 2); np_temp = (npp[0] + npp[2]) / 2; }
-      else { h1 = cdivr(cadd(h[1][0], h[1][1]), 2); h2 = cdivr(cadd(h[3][0], h[3][1]), 2); np_temp = (npp[1] + npp[3]) / 2; }
+      const cd2 h1 = cdivr(cadd(ha[0], ha[1]), 2), h2 = cdivr(cadd(hb[0], hb[1]), 2);
+      const double np_temp = (npa + npb) / 2;
       const double scale = pow(h1.re, 2) + pow(h1.im, 2) + pow(h2.re, 2) + pow(h2.im, 2);
       const cd2 s0 = cdivr(cadd(cmul(cconj(h1), x[0]), cmul(h2, cconj(x[1]))), scale);
       const cd2 s1 = cconj(cdivr(cadd(cmul(mk(-h2.re, h2.im), x[0]), cmul(h1, cconj(x[1]))), scale));
@@ -445,10 +446,9 @@ __global__ __launch_bounds__(TRK_PB_THREADS) __attribute__((amdgpu_waves_per_eu(
       e_est[2 * l] = l0; e_est[2 * l + 1] = l1;
     }
   }
-  __syncthreads();
   int ok = 0;
   unsigned long long bits40 = 0;
-  pbch_decode_wave(surv, d_est, derm_inv, m_bit, c.n_ports, tid, ok, bits40);
+  pbch_decode_wave(e_est, d_est, derm_inv, m_bit, c.n_ports, tid, ok, bits40);
   if (tid == 0) {
     const int bw[8] = {6, 15, 25, 50, 75, 100, 0, 0};
     const int b0 = (int)(bits40 & 1), b1 = (int)((bits40 >> 1) & 1), b2 = (int)((bits40 >> 2) & 1);

@@ -36,7 +36,8 @@ def both(libs, d):
     H, O = libs
     d = np.ascontiguousarray(d, np.float64).reshape(3, 40)
     bits, ss, met = C.c_uint64(), C.c_int(), C.c_double()
-    H.vit_host_decode(d.ctypes.data_as(C.POINTER(C.c_double)), C.byref(bits), C.byref(ss), C.byref(met))
+    rc = H.vit_host_decode(d.ctypes.data_as(C.POINTER(C.c_double)), C.byref(bits), C.byref(ss), C.byref(met))
+    assert rc in (0, 1), "the retrace of the winning trellis (pass 2) did not reproduce pass 1's end metric"
     got = np.array([(bits.value >> t) & 1 for t in range(40)], np.uint8)
     ref = np.zeros(40, np.uint8)
     O.orc_conv_decode_tailbite(d.ctypes.data_as(C.POINTER(C.c_double)), 40, ref.ctypes.data_as(C.POINTER(C.c_uint8)))
@@ -74,7 +75,8 @@ def test_matches_oracle_on_random_and_tied_inputs(libs):
             d = -encode(msg) * 4.0 + rng.normal(0, 2.0, (3, 40))
         got, ref, _ = both(libs, d)
         assert np.array_equal(got, ref), f"case {k}"
-        # the two forms of the step (min + carry-chain survivor words / compare-and-select) agree bit for bit on finite input
+        # the two forms of the step (min / compare-and-select) agree bit for bit on finite input, and the one-state-per-lane retrace
+        # of EVERY start state ends on pass 1's metric
         dd = np.ascontiguousarray(d, np.float64)
         assert libs[0].vit_host_forms_agree(dd.ctypes.data_as(C.POINTER(C.c_double))) == 1, f"case {k}"
     assert n_tie_cases == 40

@@ -22,7 +22,7 @@ with pkg.Searcher(0) as S:
     print("rc", lib.lcs_debug_phase_ts(ts), "cells", [c.n_id_cell() for c in cells])
     t = np.array(ts[:], dtype=np.float64)
     def d_us(a, b): return (t[b] - t[a]) / 100.0          # wall_clock64: 100 MHz
-    print("k_pbch   LLR phase %.1f us, decode (de-ratematch + 64 trellises + traceback + CRC) %.1f us" % (d_us(0, 1), d_us(1, 4)))
+    print("k_pbch   LLR phase %.1f us, de-ratematch %.1f us, 64 trellises %.1f us, traceback + CRC %.1f us" % (d_us(0, 1), d_us(1, 2), d_us(2, 3), d_us(3, 4)))
     print("k_tfg    fill %.1f us, FFT + output %.1f us" % (d_us(30, 31), d_us(31, 32)))
     print("k_tfoec  %.1f / %.1f / %.1f us" % (d_us(10, 11), d_us(11, 13), d_us(13, 14)))
     print("k_chan_est  corrections + PBCH rows %.1f | raw estimates %.1f | filter %.1f | noise + first row %.1f | interpolation %.1f us" % (d_us(19, 20), d_us(20, 21), d_us(21, 22), d_us(22, 23), d_us(23, 24)))
