@@ -204,18 +204,27 @@ __global__ __launch_bounds__(64 * TRK_FD_SYM) void k_trk_fd(const lcs_track_cell
   }
 }
 
-// interp72 (:383-400) evaluated at subcarrier t: the segment the reference's running pointers have reached there
-__device__ __forceinline__ cd2 trk_interp72(const double2 *__restrict__ filt, int shift, int t) {
+// interp72 (:383-400) evaluated at subcarrier t: the segment the reference's running pointers have reached there; slope[a] =
+// (filt[a + 1] - filt[a]) / 6, formed once per row (the two divisions were 2/3 of an interpolated element's instructions)
+__device__ __forceinline__ cd2 trk_interp72(const cd2 *filt, const cd2 *slope, int shift, int t) {
   int a = (t - shift - 1 >= 0) ? (t - shift - 1) / 6 : 0;
   if (a > 10) a = 10;
-  const cd2 l_y = ld(&filt[a]), r_y = ld(&filt[a + 1]);
-  return cadd(cscale(cdivr(csub(r_y, l_y), 6.0), (double)(t - (shift + 6 * a))), l_y);
+  return cadd(cscale(slope[a], (double)(t - (shift + 6 * a))), filt[a]);
 }
 
-// One workgroup per (port, cell): raw channel estimates on the reference symbols, filter_ce + powers + FOE/TOE
-// measurements for every reference symbol that has both neighbours, then the 2-D interpolation onto every symbol.
-#define TRK_CE_THREADS 512
-#define TRK_CE_SYMS 512       // symbols whose interpolation brackets are held in LDS at a time
+// Raw channel estimates on the reference symbols, filter_ce + powers + FOE/TOE measurements for every reference symbol that has
+// both neighbours, then the 2-D interpolation onto every symbol.
+// Round 6: one workgroup per (port, cell, CHUNK of TRK_CE_CH filtered reference symbols) -- rounds 3-5 ran one 512-thread
+// workgroup per (port, cell): 256 workgroups on 256 CUs, the filter stage on ~280 of its 512 threads with four 12-tap rows
+// (192 registers) per thread and 22 of them spilled, the interpolation 138 sequential rounds of dependent global loads per thread
+// (422 us of the block's kernel time).  A chunk stages the raw estimates of its rows (+ 3 rows of halo) in LDS, filters them one
+// (row, subcarrier) per thread, takes the per-row measurements from LDS (no arrays in registers, no spills), keeps its filtered
+// rows in LDS and interpolates the symbols they bracket from there.  Every value is formed by the same expression in the same
+// order as before (the rows are bit-identical; tests/test_tracker.py, test_gpu_configs.py); what a chunk shares with its
+// neighbours (the halo rows) it computes again and leaves to its owner to write.
+#define TRK_CE_THREADS 256
+#define TRK_CE_CH 24          // filtered reference symbols (and interpolation brackets) per workgroup
+#define TRK_CE_SYMS 64        // symbols whose brackets are held in LDS at a time
 __global__ __launch_bounds__(TRK_CE_THREADS) void k_trk_ce(const lcs_track_cell *__restrict__ cells, int n_sym, const double2 *__restrict__ syms,
                                                           const double *__restrict__ freq_off, const double *__restrict__ frame_timing,
                                                           const double *__restrict__ rs, const double *__restrict__ shift,
@@ -224,121 +233,173 @@ __global__ __launch_bounds__(TRK_CE_THREADS) void k_trk_ce(const lcs_track_cell 
                                                           double2 *__restrict__ filt, double *__restrict__ fmeta /*[..][max_rs][4]: tp, sp, sp_raw, np*/,
                                                           double *__restrict__ meas, int *__restrict__ n_meas, double2 *__restrict__ ce,
                                                           double *__restrict__ ce_pw, int *__restrict__ ce_upto) {
-  const int port = blockIdx.x, cell = blockIdx.y, tid = threadIdx.x;
+  const int port = blockIdx.x, cell = blockIdx.y, chunk = blockIdx.z, tid = threadIdx.x;
   const lcs_track_cell c = cells[cell];
   const size_t cp = (size_t)cell * 4 + port;
-  if (port >= c.n_ports) { if (tid == 0) { n_meas[cp] = 0; ce_upto[cp] = 0; } return; }
+  if (port >= c.n_ports) { if (tid == 0 && chunk == 0) { n_meas[cp] = 0; ce_upto[cp] = 0; } return; }
   const int n_symb = trk_n_symb(c), per_frame = 20 * n_symb;
   const int m = n_rs[cp];
+  const int nf = (m >= 3) ? m - 2 : 0;
+  const int f0 = chunk * TRK_CE_CH;                               // first filtered row (= first bracket) of this chunk
+  if (f0 >= nf && chunk > 0) return;                              // (chunk 0 always runs: it owns the raw rows of a port with < 3 reference symbols)
   const int *idx = rs_idx + cp * max_rs;
   const double *sh = shift + (size_t)cell * 140 * 4;
   const double *fo = freq_off + (size_t)cell * n_sym, *ft = frame_timing + (size_t)cell * n_sym;
   double2 *raw_p = raw + cp * max_rs * 12, *filt_p = filt + cp * max_rs * 12;
   double *fm = fmeta + cp * max_rs * 4, *ms = meas + cp * max_rs * TRK_MEAS;
-  // raw channel estimates (:874-880)
-  for (int e = tid; e < m * 12; e += TRK_CE_THREADS) {
-    const int r = e / 12, k = e % 12, i = idx[r], row = i % per_frame;
-    const int s = d_round_i(sh[row * 4 + port]);
+  const bool last = f0 + TRK_CE_CH >= nf;                         // the chunk that owns the tail
+  const int nfl = min(TRK_CE_CH + 1, nf - f0);                    // filtered rows computed here: f0 .. f0 + nfl - 1 (one row of halo)
+  const int f_own = last ? max(nf - f0, 0) : TRK_CE_CH;           // ... of which it writes the first f_own
+  const int r_end = last ? m : min(f0 + nfl + 2, m);              // raw rows staged: f0 .. r_end - 1
+  const int r_own = last ? m - f0 : TRK_CE_CH;                    // ... of which it writes the first r_own
+  __shared__ cd2 s_raw[(TRK_CE_CH + 3) * 12];
+  __shared__ cd2 s_filt[(TRK_CE_CH + 1) * 12];
+  __shared__ cd2 s_slope[(TRK_CE_CH + 1) * 12];                   // 11 per row: (filt[a + 1] - filt[a]) / 6
+  __shared__ double s_fm[(TRK_CE_CH + 1) * 4];
+  __shared__ int s_idx[TRK_CE_CH + 3];
+  __shared__ double s_sh[TRK_CE_CH + 3];
+  // raw channel estimates (:874-880) of the rows f0 .. r_end - 1 (at most TRK_CE_CH + 3: the filtered rows, their two neighbours and
+  // the halo row's)
+  for (int e = tid; e < (r_end - f0) * 12; e += TRK_CE_THREADS) {
+    const int rl = e / 12, k = e % 12, i = idx[f0 + rl], row = i % per_frame;
+    const double shv = sh[row * 4 + port];
+    const int sft = d_round_i(shv);
     const cd2 ref = mk(rs[((size_t)cell * 140 + row) * 24 + 2 * k], rs[((size_t)cell * 140 + row) * 24 + 2 * k + 1]);
-    st(&raw_p[e], cmul(ld(&syms[((size_t)cell * n_sym + i) * 72 + s + 6 * k]), cconj(ref)));
+    const cd2 v = cmul(ld(&syms[((size_t)cell * n_sym + i) * 72 + sft + 6 * k]), cconj(ref));
+    s_raw[e] = v;
+    if (k == 0) { s_idx[rl] = i; s_sh[rl] = shv; }
+    if (rl < r_own) st(&raw_p[(size_t)(f0 + rl) * 12 + k], v);
   }
   __syncthreads();
-  const int nf = (m >= 3) ? m - 2 : 0;
-  for (int f = tid; f < nf; f += TRK_CE_THREADS) {
-    const int r = f + 1;
-    const int ip = idx[r - 1], ic = idx[r], in = idx[r + 1];
-    const double sh_p = sh[(ip % per_frame) * 4 + port], sh_c = sh[(ic % per_frame) * 4 + port];
-    cd2 P[12], Cq[12], N[12], F[12];
-#pragma unroll
-    for (int k = 0; k < 12; ++k) { P[k] = ld(&raw_p[(r - 1) * 12 + k]); Cq[k] = ld(&raw_p[r * 12 + k]); N[k] = ld(&raw_p[(r + 1) * 12 + k]); }
-    const bool up = sh_p < sh_c;
-#pragma unroll
-    for (int t = 0; t < 12; ++t) {                                // filter_ce :176-201
-      cd2 total = mk(0, 0);
-      int n_total = 0;
-#pragma unroll
-      for (int k = t - 1; k <= t + 1; ++k) if (k >= 0 && k <= 11) { total = cadd(total, Cq[k]); ++n_total; }
-      const int lo = up ? t : t - 1;
-      cd2 sp_ = mk(0, 0), sn_ = mk(0, 0);
-      int n_ind = 0;
-#pragma unroll
-      for (int k = lo; k <= lo + 1; ++k) if (k >= 0 && k <= 11) { sp_ = cadd(sp_, P[k]); sn_ = cadd(sn_, N[k]); ++n_ind; }
-      total = cadd(total, sp_);
-      total = cadd(total, sn_);
-      n_total += 2 * n_ind;
-      F[t] = cdivr(total, (double)n_total);
+  // filter_ce :176-201, one (row, subcarrier) per thread: row fl uses the raw rows fl (previous), fl + 1 (current), fl + 2 (next)
+  for (int e = tid; e < nfl * 12; e += TRK_CE_THREADS) {
+    const int fl = e / 12, t = e % 12;
+    const cd2 *P = s_raw + fl * 12, *Cq = P + 12, *N = P + 24;
+    const bool up = s_sh[fl] < s_sh[fl + 1];
+    cd2 total = mk(0, 0);
+    int n_total = 0;
+    for (int k = t - 1; k <= t + 1; ++k) if (k >= 0 && k <= 11) { total = cadd(total, Cq[k]); ++n_total; }
+    const int lo = up ? t : t - 1;
+    cd2 sp_ = mk(0, 0), sn_ = mk(0, 0);
+    int n_ind = 0;
+    for (int k = lo; k <= lo + 1; ++k) if (k >= 0 && k <= 11) { sp_ = cadd(sp_, P[k]); sn_ = cadd(sn_, N[k]); ++n_ind; }
+    total = cadd(total, sp_);
+    total = cadd(total, sn_);
+    n_total += 2 * n_ind;
+    const cd2 F = cdivr(total, (double)n_total);
+    s_filt[e] = F;
+    if (fl < f_own) st(&filt_p[(size_t)(f0 + fl) * 12 + t], F);
+  }
+  __syncthreads();
+  for (int e = tid; e < nfl * 12; e += TRK_CE_THREADS)
+    if (e % 12 < 11) s_slope[e] = cdivr(csub(s_filt[e + 1], s_filt[e]), 6.0);
+  // Powers and the FOE / TOE measurements of a row (:908-912, do_foe :203-243, do_toe_v2 :245-288): sixteen lanes per row.  The
+  // twelve per-subcarrier terms of every sum are formed in parallel (lane k: subcarrier k) and parked in LDS; each sum is then
+  // added up by ONE lane in the reference's order, k = 0 .. 11 from zero -- the same additions, so the same values bit for bit
+  // (one thread per row walked ~1500 dependent fp64 instructions: 100 of the kernel's 160 us).
+  __shared__ double s_t1[16][12], s_t2[16][12];
+  __shared__ cd2 s_c1[16][12], s_c2[16][12], s_c3[16][12];
+  __shared__ double s_row[16][4];                                  // np, tp, sp_raw, sp of the row being measured
+  __shared__ cd2 s_toe[16][2];
+  for (int pass = 0; pass < nfl; pass += 16) {
+    const int g = tid >> 4, k = tid & 15, fl = pass + g;          // (a 16-lane group never straddles a wave)
+    const bool row_ok = fl < nfl, on = row_ok && k < 12;
+    const cd2 *P = s_raw + (row_ok ? fl : 0) * 12, *Cq = P + 12, *N = P + 24, *F = s_filt + (row_ok ? fl : 0) * 12;
+    const bool up = row_ok && s_sh[fl] < s_sh[fl + 1];
+    const cd2 *A = up ? P : Cq, *B = up ? Cq : P;
+    __syncthreads();
+    if (on) {
+      const cd2 d = csub(Cq[k], F[k]);
+      s_t1[g][k] = pow(d.re, 2) + pow(d.im, 2);
+      s_t2[g][k] = pow(F[k].re, 2) + pow(F[k].im, 2);
+      s_c1[g][k] = cmul(cconj(A[k]), B[k]);
+      if (k <= 10) s_c2[g][k] = cmul(cconj(B[k]), A[k + 1]);
+      s_c3[g][k] = cmul(cconj(P[k]), N[k]);                       // foe
     }
-    double d2 = 0, f2s = 0;
-#pragma unroll
-    for (int k = 0; k < 12; ++k) { const cd2 d = csub(Cq[k], F[k]); d2 += pow(d.re, 2) + pow(d.im, 2); }
-#pragma unroll
-    for (int k = 0; k < 12; ++k) f2s += pow(F[k].re, 2) + pow(F[k].im, 2);
-    const double np = (d2 / 12) * 7 / 6, tp = f2s / 12;           // :908-912
-    const double sp_raw = tp - np / 7, sp = (.00001 > sp_raw) ? .00001 : sp_raw;
-    // do_foe :203-243
-    cd2 foe_comb = mk(0, 0);
-    double foe_comb_np = 0, wsum = 0;
-#pragma unroll
-    for (int k = 0; k < 12; ++k) {
-      const cd2 foe = cmul(cconj(P[k]), N[k]);
+    __syncthreads();
+    if (row_ok && k == 0) {
+      double d2 = 0, f2s = 0;
+      for (int q = 0; q < 12; ++q) d2 += s_t1[g][q];
+      for (int q = 0; q < 12; ++q) f2s += s_t2[g][q];
+      const double np = (d2 / 12) * 7 / 6, tp = f2s / 12;         // :908-912
+      const double sp_raw = tp - np / 7, sp = (.00001 > sp_raw) ? .00001 : sp_raw;
+      s_row[g][0] = np; s_row[g][1] = tp; s_row[g][2] = sp_raw; s_row[g][3] = sp;
+      s_fm[fl * 4] = tp; s_fm[fl * 4 + 1] = sp; s_fm[fl * 4 + 2] = sp_raw; s_fm[fl * 4 + 3] = np;
+    }
+    if (row_ok && k == 1) {
+      cd2 toe1 = mk(0, 0);
+      for (int q = 0; q < 12; ++q) toe1 = cadd(toe1, s_c1[g][q]);
+      s_toe[g][0] = cdivr(toe1, 12);
+    }
+    if (row_ok && k == 2) {
+      cd2 s1 = mk(0, 0), s2 = mk(0, 0);
+      for (int q = 0; q <= 4; ++q) s1 = cadd(s1, s_c2[g][q]);
+      for (int q = 6; q <= 10; ++q) s2 = cadd(s2, s_c2[g][q]);
+      s_toe[g][1] = cdivr(cadd(s1, s2), 10);
+    }
+    __syncthreads();
+    const bool own = row_ok && fl < f_own;                         // the halo row: its owner writes the measurements
+    if (on && own) {                                               // the weighted FOE terms need the row's noise power
+      const double np = s_row[g][0];
       const double f2 = cabs2(F[k]);
       const double foe_np = np * np + 2 * np * f2;
       const double weight = f2 / foe_np;
-      foe_comb = cadd(foe_comb, cscale(foe, weight));
-      foe_comb_np += foe_np * weight * weight;
-      wsum += f2 * weight;
+      s_c1[g][k] = cscale(s_c3[g][k], weight);
+      s_t1[g][k] = foe_np * weight * weight;
+      s_t2[g][k] = f2 * weight;
     }
-    const double scale = 1 / wsum;
-    foe_comb = cscale(foe_comb, scale);
-    foe_comb_np = foe_comb_np * scale * scale;
-    const double frequency_offset = fo[ip];
-    const double k_factor = (fc_req - frequency_offset) / fc_prog;
-    const double residual_f = atan2(foe_comb.im, foe_comb.re) / (2 * M_PI) /
-                              (0.0005 + trk_wrap(ft[in] - ft[ip], -19200.0 / 2, 19200.0 / 2) * (1 / (fs_prog * k_factor)));
-    const double residual_f_np = (foe_comb_np / 2 > .001) ? foe_comb_np / 2 : .001;
-    // do_toe_v2 :245-288
-    cd2 toe1 = mk(0, 0), s1 = mk(0, 0), s2 = mk(0, 0);
-    const cd2 *A = up ? P : Cq, *B = up ? Cq : P;
-#pragma unroll
-    for (int k = 0; k < 12; ++k) toe1 = cadd(toe1, cmul(cconj(A[k]), B[k]));
-    toe1 = cdivr(toe1, 12);
-#pragma unroll
-    for (int k = 0; k <= 4; ++k) s1 = cadd(s1, cmul(cconj(B[k]), A[k + 1]));
-#pragma unroll
-    for (int k = 6; k <= 10; ++k) s2 = cadd(s2, cmul(cconj(B[k]), A[k + 1]));
-    cd2 toe2 = cdivr(cadd(s1, s2), 10);
-    toe1 = cdivr(toe1, sqrt(sp));
-    toe2 = cdivr(toe2, sqrt(sp));
-    const double delay = -(atan2(toe1.im, toe1.re) + atan2(toe2.im, toe2.re)) / 2 / 3 / (2 * M_PI / 128);
-    const double delay_np = (np / sp / 2 / 12 > .001) ? np / sp / 2 / 12 : .001;
-#pragma unroll
-    for (int k = 0; k < 12; ++k) st(&filt_p[f * 12 + k], F[k]);
-    fm[f * 4] = tp; fm[f * 4 + 1] = sp; fm[f * 4 + 2] = sp_raw; fm[f * 4 + 3] = np;
-    double *mrow = ms + (size_t)f * TRK_MEAS;
-    mrow[0] = ic; mrow[1] = np; mrow[2] = tp; mrow[3] = sp_raw; mrow[4] = sp;
-    mrow[5] = frequency_offset + residual_f; mrow[6] = residual_f_np; mrow[7] = ft[ic] + delay; mrow[8] = delay_np;
+    __syncthreads();
+    if (own && k == 0) {
+      const double np = s_row[g][0], tp = s_row[g][1], sp_raw = s_row[g][2], sp = s_row[g][3];
+      const int ip = s_idx[fl], ic = s_idx[fl + 1], in = s_idx[fl + 2];
+      cd2 foe_comb = mk(0, 0);
+      double foe_comb_np = 0, wsum = 0;
+      for (int q = 0; q < 12; ++q) { foe_comb = cadd(foe_comb, s_c1[g][q]); foe_comb_np += s_t1[g][q]; wsum += s_t2[g][q]; }
+      const double scale = 1 / wsum;
+      foe_comb = cscale(foe_comb, scale);
+      foe_comb_np = foe_comb_np * scale * scale;
+      const double frequency_offset = fo[ip];
+      const double k_factor = (fc_req - frequency_offset) / fc_prog;
+      const double residual_f = atan2(foe_comb.im, foe_comb.re) / (2 * M_PI) /
+                                (0.0005 + trk_wrap(ft[in] - ft[ip], -19200.0 / 2, 19200.0 / 2) * (1 / (fs_prog * k_factor)));
+      const double residual_f_np = (foe_comb_np / 2 > .001) ? foe_comb_np / 2 : .001;
+      const int f = f0 + fl;
+      fm[f * 4] = tp; fm[f * 4 + 1] = sp; fm[f * 4 + 2] = sp_raw; fm[f * 4 + 3] = np;
+      double *mrow = ms + (size_t)f * TRK_MEAS;
+      mrow[0] = ic; mrow[1] = np; mrow[2] = tp; mrow[3] = sp_raw; mrow[4] = sp;
+      mrow[5] = frequency_offset + residual_f; mrow[6] = residual_f_np;
+    }
+    if (own && k == 1) {
+      const double np = s_row[g][0], sp = s_row[g][3];
+      const cd2 toe1 = cdivr(s_toe[g][0], sqrt(sp)), toe2 = cdivr(s_toe[g][1], sqrt(sp));
+      const double delay = -(atan2(toe1.im, toe1.re) + atan2(toe2.im, toe2.re)) / 2 / 3 / (2 * M_PI / 128);
+      const double delay_np = (np / sp / 2 / 12 > .001) ? np / sp / 2 / 12 : .001;
+      double *mrow = ms + (size_t)(f0 + fl) * TRK_MEAS;
+      mrow[7] = ft[s_idx[fl + 1]] + delay; mrow[8] = delay_np;
+    }
   }
   __syncthreads();
   // interp2d :402-477: symbol i lies between filtered reference symbols j and j + 1 (idx[j + 1] <= i < idx[j + 2]);
   // symbols in front of the first one repeat its estimate; nothing is produced from the last one on
   const int upto = (nf >= 2) ? idx[nf] : 0;
-  if (tid == 0) { n_meas[cp] = nf; ce_upto[cp] = upto; }
+  if (tid == 0 && chunk == 0) { n_meas[cp] = nf; ce_upto[cp] = upto; }
+  if (nf < 2 || f0 > nf - 2) return;                              // no bracket starts in this chunk
   double2 *ce_p = ce + cp * n_sym * 72;
   double *pw_p = ce_pw + cp * n_sym * 4;
-  // Per SYMBOL first (round 3 repeated this for each of its 72 subcarriers -- a binary search over the symbol list in
-  // global memory and the running time sum, 70 k times per port): the bracketing pair j and the weight, TRK_CE_SYMS symbols
-  // at a time into LDS; then the 72 subcarriers of those symbols.
+  // this chunk's brackets j = f0 .. j_hi - 1 and the symbols they cover; reference symbol j + 1 sits in s_idx[j - f0 + 1]
+  const int j_hi = min(f0 + TRK_CE_CH, nf - 1);
+  const int i_lo = (chunk == 0) ? 0 : s_idx[1], i_hi = idx[j_hi + 1];
   __shared__ int s_j[TRK_CE_SYMS];
   __shared__ double s_w[TRK_CE_SYMS];
-  for (int base = 0; base < upto; base += TRK_CE_SYMS) {
-    const int ns = min(TRK_CE_SYMS, upto - base);
+  for (int base = i_lo; base < i_hi; base += TRK_CE_SYMS) {
+    const int ns = min(TRK_CE_SYMS, i_hi - base);
     __syncthreads();
     for (int q0 = tid; q0 < ns; q0 += TRK_CE_THREADS) {
       const int i = base + q0;
-      int lo = 0, hi = nf - 2;                                    // largest j <= nf - 2 with idx[j + 1] <= i (0 when i is in front of all)
-      while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (idx[mid + 1] <= i) lo = mid; else hi = mid - 1; }
+      int lo = f0, hi = j_hi - 1;                                 // largest j in the chunk with idx[j + 1] <= i (f0 when i is in front of all)
+      while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_idx[mid - f0 + 1] <= i) lo = mid; else hi = mid - 1; }
       const int j = lo;
-      const int i_prev = idx[j + 1];
+      const int i_prev = s_idx[j - f0 + 1];
       const int sym_prev = i_prev % n_symb;
       double time_diff;
       if (port > 2) time_diff = 0.0005;                           // the reference's `port_num>2`
@@ -352,18 +413,18 @@ __global__ __launch_bounds__(TRK_CE_THREADS) void k_trk_ce(const lcs_track_cell 
         else if (sy == 6) time_offset += (128 + 10) * (1 / (FS_LTE / 16));
         else time_offset += (128 + 9) * (1 / (FS_LTE / 16));
       }
-      s_j[q0] = j;
+      s_j[q0] = j - f0;
       s_w[q0] = time_offset / time_diff;
     }
     __syncthreads();
     for (int e = tid; e < ns * 72; e += TRK_CE_THREADS) {
       const int q0 = e / 72, t = e % 72, i = base + q0;
-      const int j = s_j[q0];
+      const int jl = s_j[q0];
       const double w = s_w[q0];
-      const int sh_a = (int)sh[(idx[j + 1] % per_frame) * 4 + port], sh_b = (int)sh[(idx[j + 2] % per_frame) * 4 + port];
-      const cd2 a = trk_interp72(filt_p + j * 12, sh_a, t), b = trk_interp72(filt_p + (j + 1) * 12, sh_b, t);
+      const int sh_a = (int)s_sh[jl + 1], sh_b = (int)s_sh[jl + 2];
+      const cd2 a = trk_interp72(s_filt + jl * 12, s_slope + jl * 12, sh_a, t), b = trk_interp72(s_filt + (jl + 1) * 12, s_slope + (jl + 1) * 12, sh_b, t);
       st(&ce_p[(size_t)i * 72 + t], cadd(a, cscale(csub(b, a), w)));
-      if (t < 4) pw_p[i * 4 + t] = fm[j * 4 + t] + (fm[(j + 1) * 4 + t] - fm[j * 4 + t]) * w;
+      if (t < 4) pw_p[i * 4 + t] = s_fm[jl * 4 + t] + (s_fm[(jl + 1) * 4 + t] - s_fm[jl * 4 + t]) * w;
     }
   }
 }
@@ -653,7 +714,7 @@ int trk_block(lcs_ctx *c, lcs_track_cell *cells, int n_cells, int n_sym, const v
   if (n_sym > sym_first)
     hipLaunchKernelGGL(k_trk_fd, dim3((n_sym - sym_first + TRK_FD_SYM - 1) / TRK_FD_SYM, n_cells), dim3(64 * TRK_FD_SYM), 0, c->stream, c->trk_cells, n_sym,
                        sym_first, d_td, d_fo, d_late, d_bpo, fc_requested, fc_programmed, fs_programmed, c->trk_syms);
-  hipLaunchKernelGGL(k_trk_ce, dim3(4, n_cells), dim3(TRK_CE_THREADS), 0, c->stream, c->trk_cells, n_sym, c->trk_syms, d_fo, d_ft, d_rs, d_shift,
+  hipLaunchKernelGGL(k_trk_ce, dim3(4, n_cells, std::max(1, (rs_cap - 2 + TRK_CE_CH - 1) / TRK_CE_CH)), dim3(TRK_CE_THREADS), 0, c->stream, c->trk_cells, n_sym, c->trk_syms, d_fo, d_ft, d_rs, d_shift,
                      d_idx, d_nrs, rs_cap, fc_requested, fc_programmed, fs_programmed, d_raw, d_filt, d_fm, d_meas, d_nmeas, c->trk_ce,
                      c->trk_pw, d_upto);
   if (n_off > 0)
