@@ -853,6 +853,7 @@ def main():
         if d == 0:
             rec0, cnt0 = rec.copy(), cnt.copy()
     kname, executed_ops = ctxs[0].last_xcorr_info()
+    st_main = ctxs[0].last_batch_stats() if stage_mask == pkg.STAGE_FULL and hasattr(pkg.capi.load(), "lcs_last_batch_stats") else None
     # ---- dense band (reported next to the default, never part of `value`): 2-3 cells planted in EVERY buffer, so the
     # per-cell stages carry ~8x the cells of the band-scan workload above
     dense, dense_rec, dense_host = None, None, None
@@ -880,7 +881,10 @@ def main():
         ctxs[0].batch_enqueue(dd.data_ptr(), fmt, B, N_CAP, f, fcs, fcs, FS, stage_mask)       # the un-rolled dense batch once more, alone: the
         dense_rec = ctxs[0].batch_collect_raw(B, MAXC)                                        # records the oracle leg below checks
         dense_host = dh
+        st_d = ctxs[0].last_batch_stats() if hasattr(ctxs[0], "last_batch_stats") and hasattr(pkg.capi.load(), "lcs_last_batch_stats") else None
         dense = {"buffers_per_s": B / (min(dms) * 1e-3), "ms_per_batch": min(dms), "cells_decoded_per_buffer": cells_d / B,
+                 "cells_past_sss_per_buffer": (st_d["cells_past_sss"] / B) if st_d else None,
+                 "pbch_candidates_decoded_per_cell_past_sss": (st_d["pbch_candidates_decoded"] / max(1, st_d["cells_past_sss"])) if st_d else None,
                  "cells_planted_per_buffer": 2.5, "batches_timed": K_, "pipelined_mismatches": state["mismatch"] - mism0,
                  "note": f"same chain, same grid; every one of the {B} buffers of a batch carries 2-3 synthetic cells (SNR 0-10 dB)"}
         work.clear(); work.update(work_saved)
@@ -955,6 +959,8 @@ def main():
                        "baseline_note": "vs_baseline = value / (1 buffer per ~6 s), doc/CellSearch.html:52-54 (dual-core i7-2640, ppm 100; BASELINE.md section 1)",
                        "cells_per_distinct_batch": n_cells_per_batch,
                        "cells_per_buffer": float(np.mean(n_cells_per_batch)) / B,
+                       "cells_past_sss_per_buffer": (st_main["cells_past_sss"] / B) if st_main else None,
+                       "pbch_candidates_decoded_per_cell_past_sss": (st_main["pbch_candidates_decoded"] / max(1, st_main["cells_past_sss"])) if st_main else None,
                        "dense_band": dense,
                        "hbm_in_use": hbm_in_use,
                        "per_rank_buffers_per_s": [B * K * args.steps / x for x in dt_ranks],

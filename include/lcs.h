@@ -237,6 +237,12 @@ int lcs_batch_collect(lcs_ctx *ctx, lcs_cell *cells, int max_cells_per_buf, int 
 /* Host time (microseconds) the last lcs_batch_collect of the context spent OUTSIDE its wait for the GPU: queueing the copy
  * and scattering the records into the caller's array (bench.py reports it as host_ms_per_batch.collect_excl_wait). */
 int lcs_last_collect_host_us(lcs_ctx *ctx, double *us);
+/* Counters of the last collected batch: stats[0] = records returned, [1] = 1 if a buffer overflowed LCS_MAX_PEAKS, [4] = cells the
+ * last per-cell round took, [5] = peaks of the whole batch that passed sss_detect (the cells carried into extract_tfg .. decode_mib),
+ * [6] = cells skipped as already tracked (streaming mode), [7] = PBCH candidates (frame timing x port count, 12 per cell:
+ * src/searcher.cpp:1547, :1567) actually decoded -- the reference stops at the first candidate that passes, the batch kernel skips
+ * a candidate whose cell already shows an earlier pass. */
+int lcs_last_batch_stats(lcs_ctx *ctx, int stats[8]);
 /* Debug readback of the last batch (after lcs_batch_collect / lcs_search_batch_*): the xcorr_pss outputs of
  * buffer `buf` in the layouts of lcs_xcorr_pss, plus the detection threshold Z_th1 (src/CellSearch.cpp:500-503).
  * Every pointer may be NULL.  This is how the tests pin the batched kernels to the oracle array by array. */

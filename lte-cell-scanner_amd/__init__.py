@@ -464,6 +464,12 @@ class Searcher:
         self._chk(self._lib.lcs_last_frq_repair_stats(self._h, C.byref(a), C.byref(b)), "lcs_last_frq_repair_stats")
         return a.value, b.value
 
+    def last_batch_stats(self):
+        """Counters of the last collected batch (lcs_last_batch_stats): dict with cells_past_sss and pbch_candidates_decoded among them."""
+        a = (C.c_int * 8)()
+        self._chk(self._lib.lcs_last_batch_stats(self._h, a), "lcs_last_batch_stats")
+        return dict(records=a[0], overflow=a[1], cells_last_round=a[4], cells_past_sss=a[5], redetected=a[6], pbch_candidates_decoded=a[7])
+
     def last_collect_host_us(self) -> float:
         """Host microseconds the last batch_collect spent outside its wait for the GPU (lcs_last_collect_host_us)."""
         us = C.c_double(0)

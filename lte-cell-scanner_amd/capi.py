@@ -67,7 +67,7 @@ EXPORTS = [
     "lcs_decode_mib", "lcs_chan_est", "lcs_search_capbuf", "lcs_search_batch_dev", "lcs_search_batch_host", "lcs_batch_enqueue",
     "lcs_batch_collect", "lcs_batch_readback", "lcs_batch_enqueue_host", "lcs_host_alloc", "lcs_host_free", "lcs_device_alloc", "lcs_device_free", "lcs_device_upload", "lcs_device_count",
     "lcs_foe_partial", "lcs_foe_finish", "lcs_foe_contend", "lcs_foe_resolve", "lcs_track_block", "lcs_track_stats", "lcs_track_stream_block", "lcs_track_stream_reset", "lcs_stream_open", "lcs_stream_push", "lcs_stream_collect", "lcs_stream_close",
-    "lcs_last_xcorr_ms", "lcs_last_xcorr_info", "lcs_last_frq_repairs", "lcs_last_frq_repair_stats", "lcs_last_collect_host_us", "lcs_stream", "lcs_sync", "lcs_table_pss_td", "lcs_table_pss_fd", "lcs_table_sss_fd",
+    "lcs_last_xcorr_ms", "lcs_last_xcorr_info", "lcs_last_frq_repairs", "lcs_last_frq_repair_stats", "lcs_last_batch_stats", "lcs_last_collect_host_us", "lcs_stream", "lcs_sync", "lcs_table_pss_td", "lcs_table_pss_fd", "lcs_table_sss_fd",
     "lcs_table_lte_pn", "lcs_chi2cdf_inv",
 ]
 
@@ -149,6 +149,8 @@ def load() -> C.CDLL:
     if hasattr(L, "lcs_last_frq_repairs"):      # (absent from older developer builds loaded through bench.py --lib)
         L.lcs_last_frq_repairs.argtypes = [vp, C.POINTER(C.c_int)]
         L.lcs_last_collect_host_us.argtypes = [vp, dp]
+    if hasattr(L, "lcs_last_batch_stats"):
+        L.lcs_last_batch_stats.argtypes = [vp, C.POINTER(C.c_int)]
     if hasattr(L, "lcs_last_frq_repair_stats"):
         L.lcs_last_frq_repair_stats.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.lcs_stream.argtypes = [vp]

@@ -629,6 +629,12 @@ int lcs_batch_collect(lcs_ctx *c, lcs_cell *cells, int max_cells_per_buf, int *n
   return rc;
 }
 
+int lcs_last_batch_stats(lcs_ctx *c, int stats[8]) {
+  if (!c || !stats || !c->h_res || c->last_n_buf <= 0) return LCS_ERR_BAD_ARG;
+  std::memcpy(stats, c->h_res, 8 * sizeof(int));      // the header lcs_batch_collect brought over (k_pack_results)
+  return LCS_OK;
+}
+
 int lcs_last_collect_host_us(lcs_ctx *c, double *us) {
   if (!c || !us) return LCS_ERR_BAD_ARG;
   *us = c->last_collect_host_us;

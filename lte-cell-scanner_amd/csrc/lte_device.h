@@ -55,6 +55,12 @@ __host__ __device__ __forceinline__ void trk_wrap_certain_interval(double fl, do
 // leaves, tests/test_tables_abi.py).  Same instructions, same values.
 __device__ __attribute__((noinline)) static cd2 cis_call(double x) { return cis(x); }
 __device__ __attribute__((noinline)) static cd2 cis_small_call(double x) { return cis_small(x); }
+// exp(j x) where x is USUALLY small (the phase ramps of a timing offset of a fraction of a sample): the 21-instruction polynomial
+// when every lane's |x| <= 1 (1.5e-16, as cis_small), the library's sincos (~150 instructions) for the wave otherwise
+__device__ __attribute__((noinline)) static cd2 cis_auto_call(double x) {
+  if (__builtin_amdgcn_ballot_w64(!(fabs(x) <= 1.0)) == 0ull) return cis_small(x);
+  return cis(x);
+}
 __device__ __attribute__((noinline)) static double atan2_call(double y, double x) { return atan2(y, x); }
 __host__ __device__ __forceinline__ cd2 cadd(cd2 a, cd2 b) { return mk(a.re + b.re, a.im + b.im); }
 __host__ __device__ __forceinline__ cd2 csub(cd2 a, cd2 b) { return mk(a.re - b.re, a.im - b.im); }
@@ -330,71 +336,81 @@ __host__ __device__ __forceinline__ double vit_end_metric(const double *d0, cons
 // true when every one of the 3 x 40 observations is finite (the FAST form is then exact)
 __host__ __device__ __forceinline__ bool vit_finite(double x) { return x - x == 0.0; }
 
-// PASS 2, what new state n does in one step: its two predecessors, and which of the step's four branch values (and sign) each
-// transition takes -- constants of the state.
-struct VitState { int p0, p1, i0, i1; bool neg0, neg1; };
-__host__ __device__ __forceinline__ VitState vit_state(int n) {
-  VitState v;
-  const int b = n >> 5;
-  v.p0 = (2 * n) & 63;
-  v.p1 = v.p0 | 1;
-  const int w0 = vit_word(b, v.p0), w1 = vit_word(b, v.p1);
-  v.neg0 = w0 >= 4; v.i0 = v.neg0 ? ((7 - w0) & 3) : (w0 & 3);
-  v.neg1 = w1 >= 4; v.i1 = v.neg1 ? ((7 - w1) & 3) : (w1 & 3);
-  return v;
+// PASS 2: the ONE winning trellis again, one state per lane, with the lane <-> state map of pass 1's registers: after k steps state s
+// lives in lane rotl6(s, k).  The butterfly of old states 2j, 2j + 1 then sits in two lanes that differ in ONE bit (bit k mod 6),
+// new state j is formed where 2j was and j + 32 where 2j + 1 was: a step is one exchange with the lane across that bit (a DPP
+// move for bits 0-1, a swizzle / permute for the others) instead of two gathers from lanes 2n, 2n + 1 (measured: 8.6 us of
+// dependent ds_bpermute round trips per candidate).  Same sums as vit_step -- old + one branch value -- so the same metrics and
+// the same decisions; each lane keeps the decisions it took (bit t of a 64-bit word) and the traceback follows the map.
+#define VIT_ROTR6(s, k) ((((s) >> (k)) | ((s) << (6 - (k)))) & 63)
+// what the lane holding old state s does: which new state it forms (input bit b = s & 1, new state (s >> 1) + 32 b), and which of
+// the step's four branch values (and sign) the transitions from 2j and 2j + 1 take.  Packed: i0 | i1 << 2 | neg0 << 4 | neg1 << 5 | b << 6.
+__host__ __device__ __forceinline__ int vit_lane_desc(int s) {
+  const int b = s & 1, p0 = s & ~1, p1 = s | 1;
+  const int w0 = vit_word(b, p0), w1 = vit_word(b, p1);
+  const int n0 = w0 >= 4, n1 = w1 >= 4;
+  return (n0 ? ((7 - w0) & 3) : (w0 & 3)) | ((n1 ? ((7 - w1) & 3) : (w1 & 3)) << 2) | (n0 << 4) | (n1 << 5) | (b << 6);
 }
-// the survivor of new state n given its predecessors' metrics: the same sums as vit_step (old + one branch value); *take1 = the
-// decision (predecessor p1 only when STRICTLY better)
-__host__ __device__ __forceinline__ double vit_state_step(const VitState &v, double o0, double o1, double r0, double r1, double r2, bool *take1) {
-  const double d[4] = {(-r2 + -r1) + -r0, (-r2 + -r1) + r0, (-r2 + r1) + -r0, (-r2 + r1) + r0};
-  const double s0 = (v.i0 == 0) ? d[0] : (v.i0 == 1) ? d[1] : (v.i0 == 2) ? d[2] : d[3];
-  const double s1 = (v.i1 == 0) ? d[0] : (v.i1 == 1) ? d[1] : (v.i1 == 2) ? d[2] : d[3];
-  const double m0 = o0 + (v.neg0 ? -s0 : s0);
-  const double m1 = o1 + (v.neg1 ? -s1 : s1);
+// the survivor this lane forms from its own metric and its partner's; *take1 = the decision (predecessor 2j + 1 only when STRICTLY better)
+__host__ __device__ __forceinline__ double vit_lane_step(int desc, double self, double partner, const double (&d)[4], bool *take1) {
+  const int i0 = desc & 3, i1 = (desc >> 2) & 3;
+  const double s0 = (i0 == 0) ? d[0] : (i0 == 1) ? d[1] : (i0 == 2) ? d[2] : d[3];
+  const double s1 = (i1 == 0) ? d[0] : (i1 == 1) ? d[1] : (i1 == 2) ? d[2] : d[3];
+  const bool odd = (desc >> 6) & 1;                    // this lane holds old state 2j + 1
+  const double o0 = odd ? partner : self, o1 = odd ? self : partner;
+  const double m0 = o0 + (((desc >> 4) & 1) ? -s0 : s0);
+  const double m1 = o1 + (((desc >> 5) & 1) ? -s1 : s1);
   *take1 = m1 < m0;
   return *take1 ? m1 : m0;
 }
-// decoded bits from the 64 states' decision words (bit t of dec[n] = decision of new state n at step t), start = end state ss
-#define VIT_TRACE_STEP(bits, s, t, word_of_s) do { (bits) |= (unsigned long long)(((s) >> 5) & 1) << (t); \
-                                                   (s) = (((s) << 1) & 63) | (int)(((word_of_s) >> (t)) & 1ull); } while (0)
+// one traceback step: state s was formed at step t in lane rotl6(s, (t + 1) mod 6); its decision bit names the predecessor
+#define VIT_TRACE_LANE(s, t) VIT_ROTL6((s), ((t) + 1) % 6)
+#define VIT_TRACE_STEP(bits, s, t, word_of_lane) do { (bits) |= (unsigned long long)(((s) >> 5) & 1) << (t); \
+                                                      (s) = (((s) << 1) & 63) | (int)(((word_of_lane) >> (t)) & 1ull); } while (0)
 // host twin of the wave's retrace (the 64 lanes walked in a loop): decoded bits, and the end metric of state ss for the tests
 __host__ inline unsigned long long vit_retrace_host(const double *d0, const double *d1, const double *d2, int ss, double *end_metric) {
   double pm[64], nx[64];
   unsigned long long dec[64];
-  for (int n = 0; n < 64; ++n) { pm[n] = (n == ss) ? 0.0 : INFINITY; dec[n] = 0ull; }
+  for (int l = 0; l < 64; ++l) { pm[l] = (l == ss) ? 0.0 : INFINITY; dec[l] = 0ull; }
   for (int t = 0; t < 40; ++t) {
-    for (int n = 0; n < 64; ++n) {
-      const VitState v = vit_state(n);
+    const int k = t % 6;
+    const VitBranch br = vit_branch(d0[t], d1[t], d2[t]);
+    for (int l = 0; l < 64; ++l) {
       bool take1;
-      nx[n] = vit_state_step(v, pm[v.p0], pm[v.p1], d0[t], d1[t], d2[t], &take1);
-      dec[n] |= (unsigned long long)(take1 ? 1 : 0) << t;
+      nx[l] = vit_lane_step(vit_lane_desc(VIT_ROTR6(l, k)), pm[l], pm[l ^ (1 << k)], br.d, &take1);
+      dec[l] |= (unsigned long long)(take1 ? 1 : 0) << t;
     }
-    for (int n = 0; n < 64; ++n) pm[n] = nx[n];
+    for (int l = 0; l < 64; ++l) pm[l] = nx[l];
   }
-  if (end_metric) *end_metric = pm[ss];
+  if (end_metric) *end_metric = pm[VIT_ROTL6(ss, 40 % 6)];
   unsigned long long bits = 0ull;                      // bit t = decoded bit c_est(t)
   int s = ss;
-  for (int t = 39; t >= 0; --t) VIT_TRACE_STEP(bits, s, t, dec[s]);
+  for (int t = 39; t >= 0; --t) { const int l = VIT_TRACE_LANE(s, t); VIT_TRACE_STEP(bits, s, t, dec[l]); }
   return bits;
 }
 #if defined(__HIPCC__)
-// the wave's form: lane = state; all 64 lanes call it with the same (wave-uniform) ss; the decoded bits come back on every lane
+// the wave's form; all 64 lanes call it with the same (wave-uniform) ss; the decoded bits come back on every lane
 __device__ __forceinline__ unsigned long long vit_retrace_wave(const double *d0, const double *d1, const double *d2, int ss, int lane) {
-  const VitState v = vit_state(lane);
+  int desc[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) desc[k] = vit_lane_desc(VIT_ROTR6(lane, k));
   double pm = (lane == ss) ? 0.0 : INFINITY;
-  unsigned dlo = 0u, dhi = 0u;                         // this state's decisions, bit t (mod 32) of the word for step t
-#pragma unroll 4
-  for (int t = 0; t < 40; ++t) {
-    const double o0 = __shfl(pm, v.p0), o1 = __shfl(pm, v.p1);
-    bool take1;
-    pm = vit_state_step(v, o0, o1, d0[t], d1[t], d2[t], &take1);
-    if (t < 32) dlo |= (take1 ? 1u : 0u) << t; else dhi |= (take1 ? 1u : 0u) << (t - 32);
-  }
+  unsigned dlo = 0u, dhi = 0u;                         // the decisions this lane took, bit t (mod 32) of the word for step t
+#define VIT_R(K, T) do { const VitBranch br = vit_branch(d0[T], d1[T], d2[T]); bool tk;                                     \
+                         pm = vit_lane_step(desc[K], pm, __shfl_xor(pm, 1 << (K)), br.d, &tk);                              \
+                         if ((T) < 32) dlo |= (tk ? 1u : 0u) << ((T) & 31); else dhi |= (tk ? 1u : 0u) << ((T) & 31); } while (0)
+#pragma unroll 1
+  for (int t6 = 0; t6 < 36; t6 += 6) { VIT_R(0, t6); VIT_R(1, t6 + 1); VIT_R(2, t6 + 2); VIT_R(3, t6 + 3); VIT_R(4, t6 + 4); VIT_R(5, t6 + 5); }
+  VIT_R(0, 36); VIT_R(1, 37); VIT_R(2, 38); VIT_R(3, 39);
+#undef VIT_R
+#ifdef PH
+  PH(6);
+#endif
   // traceback on the scalar unit: the state walked is the same on every lane, its decision word comes by v_readlane
   unsigned long long bits = 0ull;
   int s = __builtin_amdgcn_readfirstlane(ss);
   for (int t = 39; t >= 0; --t) {
-    const unsigned w = (unsigned)__builtin_amdgcn_readlane((int)(t < 32 ? dlo : dhi), s);
+    const unsigned w = (unsigned)__builtin_amdgcn_readlane((int)(t < 32 ? dlo : dhi), VIT_TRACE_LANE(s, t));
     bits |= (unsigned long long)((s >> 5) & 1) << t;
     s = ((s << 1) & 63) | (int)((w >> (t & 31)) & 1u);
   }
@@ -469,10 +485,16 @@ __device__ __forceinline__ void pbch_decode_wave(const double *e_est, double (*d
     const int oi = __shfl_xor(best_ss, off);
     if (ov < best || (ov == best && oi < best_ss)) { best = ov; best_ss = oi; }
   }
+#ifdef PH
+  PH(5);
+#endif
   ok = 0;
   bits40 = 0ull;
   if (best < INFINITY) {
     bits40 = vit_retrace_wave(d_est[0], d_est[1], d_est[2], __builtin_amdgcn_readfirstlane(best_ss), lane);
+#ifdef PH
+    PH(7);
+#endif
     ok = pbch_crc_ok(bits40, n_ports);
   }
 }

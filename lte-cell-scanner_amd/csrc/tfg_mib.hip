@@ -95,7 +95,7 @@ __global__ __launch_bounds__(64) void k_gather_work(const lcs_cell *__restrict__
     base += __shfl(incl, 63);
   }
   for (int off = 32; off > 0; off >>= 1) dup += __shfl_down(dup, off);
-  if (lane == 0) { n_work[0] = min(max(base - skip, 0), limit); n_work[1] = base; n_work[2] = dup; }
+  if (lane == 0) { n_work[0] = min(max(base - skip, 0), limit); n_work[1] = base; n_work[2] = dup; if (skip == 0) n_work[3] = 0; /* PBCH candidates decoded by the batch (k_pbch counts) */ }
 }
 // Results of a batch, compacted on the device for lcs_batch_collect: hdr[0] = records written, hdr[1] = 1 if a buffer
 // found more peaks than LCS_MAXP holds (impossible for a buffer with positive thresholds, lcs.h), hdr[4..7] = n_work;
@@ -401,11 +401,11 @@ __device__ __forceinline__ cd2 foc_value(const double2 *g, int t, int i, double 
   k_im = k_im * 2; k_im = k_im * M_PI; k_im = k_im * late; k_im = k_im / 128;
   const double ph = k_im * (double)cn_of(i);
   const cd2 v = cmul(ld(&g[(size_t)t * NSC + i]), rot_f);
-  return cmul(v, cis_call(ph));
+  return cmul(v, cis_auto_call(ph));
 }
 
 #define TF_THREADS 256
-#define TF_PARTS 4
+#define TF_PARTS 2
 __global__ __launch_bounds__(TF_THREADS) void k_tfoec_est(lcs_cell *__restrict__ cells, const WorkItem *__restrict__ items,
                                                           const int *__restrict__ n_work,
                                                           const SlotParams *__restrict__ params,
@@ -503,7 +503,7 @@ __device__ __forceinline__ cd2 toc_subcarrier_rot(double delay, int i) {
   double k_im = 1.0;
   k_im = k_im * 2; k_im = k_im * M_PI; k_im = k_im / 128; k_im = k_im * delay;
   const double ph = k_im * (double)cn_of(i);
-  return cis_call(ph);
+  return cis_auto_call(ph);
 }
 
 #define TFA_ROWS 8
@@ -660,12 +660,18 @@ __global__ __launch_bounds__(CE_THREADS) void k_chan_est(const lcs_cell *__restr
       __syncthreads();
       if (port == 0) {          // the PBCH rows of frame f (slot 20 f + 1, symbols 0..3), frames dealt round-robin to the chunks
         double2 *gw = tfg_comp + (size_t)it * ROWS * NSC;
-        for (int f = chunk; (20 * f + 1) * n_symb < n_ofdm; f += CE_NCHUNK)
+        for (int f = chunk; (20 * f + 1) * n_symb < n_ofdm; f += CE_NCHUNK) {
+          __syncthreads();
+          if (tid < 4 && (20 * f + 1) * n_symb + tid < n_ofdm)                      // the row's frequency rotation once, not per element
+            foc_rot[tid] = foc_row_rot(tsi[(20 * f + 1) * n_symb + tid], corr.k_res, corr.residual_f);
+          __syncthreads();
           for (int e = tid; e < 4 * NSC; e += CE_THREADS) {
             const int t = (20 * f + 1) * n_symb + e / NSC, i = e % NSC;
             if (t < n_ofdm)
-              st(&gw[(size_t)t * NSC + i], cmul(foc_value(graw, t, i, tsi[t], corr.k_res, foc_row_rot(tsi[t], corr.k_res, corr.residual_f)), toc_rot[i]));
+              st(&gw[(size_t)t * NSC + i], cmul(foc_value(graw, t, i, tsi[t], corr.k_res, foc_rot[e / NSC]), toc_rot[i]));
           }
+        }
+        __syncthreads();
       }
     }
 #define rs_set(t) ce_rs_row(port, n_symb, (t))
@@ -937,7 +943,7 @@ static __device__ __forceinline__ void pbch_llr_wave(const lcs_cell &c, const do
     }
   }
 }
-__global__ __launch_bounds__(PB_THREADS * PB_CANDS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_pbch(const lcs_cell *__restrict__ cells, const int *__restrict__ n_work,
+__global__ __launch_bounds__(PB_THREADS * PB_CANDS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_pbch(const lcs_cell *__restrict__ cells, int *__restrict__ n_work,
                                                       const double2 *__restrict__ tfg_comp, const double2 *__restrict__ ce,
                                                       double *__restrict__ scratch, const uint8_t *__restrict__ pbch_scr,
                                                       const int16_t *__restrict__ derm_inv /*[2][120][16]*/) {
@@ -968,6 +974,7 @@ __global__ __launch_bounds__(PB_THREADS * PB_CANDS) __attribute__((amdgpu_waves_
         const unsigned bits24 = (unsigned)(bits40 & 0xffffffull);
         sc[CS_CAND + cand * 4 + 1] = (double)bits24;
         __hip_atomic_store(&sc[CS_CAND + cand * 4 + 0], (double)ok, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        atomicAdd(&n_work[3], 1);       // statistics only (lcs_last_batch_stats): candidates decoded, i.e. not skipped by the early exit
       }
       PH(4);
     }

@@ -14,7 +14,7 @@ for spec in sys.argv[2:]:
         c, r = j["config"], j.get("roofline", {})
         line += (f"value {j['value']:9.0f}  ms/batch64 {1e3 * 64 / j['value']:.4f}  ms_per_batch {c.get('ms_per_batch', 0):.3f}  xc_in {r.get('kernel_ms', 0):.3f} "
                  f"xc_iso {r.get('kernel_ms_isolated', 0):.3f}  verified {j.get('verified')}  dense {(c.get('dense_band') or {}).get('ms_per_batch', 0):.3f}  "
-                 f"step_ms {'/'.join('%.1f' % v for v in (c.get('step_ms') or {}).values())}")
+                 f"step_ms {'/'.join('%.1f' % v for v in (c.get('step_ms') or {}).values())}  pbch/cell {c.get('pbch_candidates_decoded_per_cell_past_sss')} cells/buf {c.get('cells_past_sss_per_buffer')}")
     except Exception as e:
         line += f"FAILED rc={p.returncode} {e!r} :: {p.stderr[-400:]!r}"
     line += f"  [{time.time() - t0:.0f}s]"

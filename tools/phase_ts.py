@@ -22,6 +22,7 @@ with pkg.Searcher(0) as S:
     print("rc", lib.lcs_debug_phase_ts(ts), "cells", [c.n_id_cell() for c in cells])
     t = np.array(ts[:], dtype=np.float64)
     def d_us(a, b): return (t[b] - t[a]) / 100.0          # wall_clock64: 100 MHz
+    print("k_pbch   after the trellises: winner reduction %.1f us, retrace forward %.1f us, traceback %.1f us, CRC + stores %.1f us" % (d_us(3, 5), d_us(5, 6), d_us(6, 7), d_us(7, 4)))
     print("k_pbch   LLR phase %.1f us, de-ratematch %.1f us, 64 trellises %.1f us, traceback + CRC %.1f us" % (d_us(0, 1), d_us(1, 2), d_us(2, 3), d_us(3, 4)))
     print("k_tfg    fill %.1f us, FFT + output %.1f us" % (d_us(30, 31), d_us(31, 32)))
     print("k_tfoec  %.1f / %.1f / %.1f us" % (d_us(10, 11), d_us(11, 13), d_us(13, 14)))
