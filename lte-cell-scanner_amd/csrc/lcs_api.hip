@@ -497,7 +497,7 @@ static int percell_round(lcs_ctx *c, int n_buf, uint32_t n_cap, int r) {
   int rc;
   if ((rc = lcs_launch_gather_work(c, n_buf, r * c->round_cells, c->round_cells))) return rc;
   if ((rc = lcs_launch_tfg(c, n_cap, true))) return rc;
-  if ((rc = lcs_launch_tfoec(c, false))) return rc;
+  if ((rc = lcs_launch_tfoec(c, false, 2))) return rc;
   return lcs_launch_mib(c, true);
 }
 
@@ -1117,7 +1117,20 @@ int lcs_foe_finish(lcs_ctx *c, const void *d_words, const double *d_meta, const 
 // that the graph's copy nodes read at execution time.
 namespace {
 // the chain as slot k sees it: its own pinned input buffer and parameter / result block, the shared device workspace
+int stream_chain_launches(lcs_ctx *c, int k);
 int stream_chain(lcs_ctx *c, int k) {
+  // the chain's kernels take the slot parameters and the hypothesis from the stream's device mirror (one copy per push), not from
+  // the workspace arrays the other entry points fill: the context's pointers are swapped while the launches are issued / recorded
+  SlotParams *params = c->params;
+  double *fset = c->fset;
+  c->params = reinterpret_cast<SlotParams *>(c->st_dmirror + offsetof(StreamHost, p));
+  c->fset = reinterpret_cast<double *>(c->st_dmirror + offsetof(StreamHost, f));
+  const int rc = stream_chain_launches(c, k);
+  c->params = params;
+  c->fset = fset;
+  return rc;
+}
+int stream_chain_launches(lcs_ctx *c, int k) {
   StreamHost *h = c->st_host[k];
   const XcGeom geo = make_geo(c->st_n_cap, 1, 2);
   int rc;
@@ -1125,10 +1138,7 @@ int stream_chain(lcs_ctx *c, int k) {
   c->use_f16 = false;
   c->foe_ready = false;
   HIPCHK(c, hipMemcpyAsync(c->st_din, c->st_hin[k], c->st_in_bytes, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->params, &h->p, sizeof(SlotParams), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->fset, &h->f, sizeof(double), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->st_dntracked, &h->n_tracked, sizeof(int), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->st_dtracked, h->tracked, sizeof(h->tracked), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->st_dmirror, h, LCS_STREAM_IN_BYTES, hipMemcpyHostToDevice, c->stream));      // parameters, tracked list, hypothesis: one copy
   if ((rc = lcs_launch_ingest(c, c->st_din, c->st_fmt, 1, c->st_n_cap))) return rc;
   if ((rc = lcs_launch_xcorr(c, 1, geo, false, false))) return rc;
   if ((rc = lcs_launch_peak_search(c, 1, geo, std::pow(10.0, -12.0 / 10.0), true))) return rc;
@@ -1159,9 +1169,8 @@ int lcs_stream_close(lcs_ctx *c) {
     c->st_exec[k] = nullptr; c->st_graph[k] = nullptr; c->st_hin[k] = nullptr; c->st_host[k] = nullptr; c->st_ev0[k] = c->st_ev1[k] = nullptr;
   }
   if (c->st_din) (void)hipFree(c->st_din);
-  if (c->st_dtracked) (void)hipFree(c->st_dtracked);
-  if (c->st_dntracked) (void)hipFree(c->st_dntracked);
-  c->st_din = nullptr; c->st_dtracked = nullptr; c->st_dntracked = nullptr;
+  if (c->st_dmirror) (void)hipFree(c->st_dmirror);
+  c->st_din = nullptr; c->st_dtracked = nullptr; c->st_dntracked = nullptr; c->st_dmirror = nullptr;
   c->st_open = false;
   c->st_head = c->st_count = 0;
   c->single_stream = false;
@@ -1185,8 +1194,9 @@ int lcs_stream_open(lcs_ctx *c, int fmt, uint32_t n_cap, double fc_requested, do
   c->st_n_cap = n_cap;
   c->st_in_bytes = (size_t)n_cap * (fmt == LCS_FMT_IQ_U8 ? 2 : sizeof(float2));
   HIPCHK(c, hipMalloc(&c->st_din, c->st_in_bytes));
-  HIPCHK(c, hipMalloc((void **)&c->st_dtracked, sizeof(c->st_host[0]->tracked)));
-  HIPCHK(c, hipMalloc((void **)&c->st_dntracked, sizeof(int)));
+  HIPCHK(c, hipMalloc((void **)&c->st_dmirror, LCS_STREAM_IN_BYTES));
+  c->st_dntracked = reinterpret_cast<int *>(c->st_dmirror + offsetof(StreamHost, n_tracked));
+  c->st_dtracked = reinterpret_cast<int16_t *>(c->st_dmirror + offsetof(StreamHost, tracked));
   for (int k = 0; k < 2; ++k) {
     HIPCHK(c, hipHostMalloc(&c->st_hin[k], c->st_in_bytes, hipHostMallocDefault));
     HIPCHK(c, hipHostMalloc((void **)&c->st_host[k], sizeof(StreamHost), hipHostMallocDefault));

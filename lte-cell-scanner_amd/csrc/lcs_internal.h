@@ -17,6 +17,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstddef>
 #include <string>
 #include <vector>
 #include "../../include/lcs.h"
@@ -139,15 +140,21 @@ struct WorkItem {
 };
 
 // Pinned block shared with the captured graph of the streaming mode.
+// The first LCS_STREAM_IN_BYTES of it (parameters, tracked identities, the frequency hypothesis LAST) go to a device mirror of the same
+// layout in ONE copy per push (rounds 2-5: four copy nodes per replay); the captured chain's kernels read their parameters and
+// hypothesis from that mirror (stream_chain points the context's `params` / `fset` at it while the launches are recorded).
 struct StreamHost {
   SlotParams p;
-  double f;
   int n_tracked;
+  int pad_;
   int16_t tracked[504];
+  double f;
   lcs_cell res[LCS_MAXP];
   int n_peaks;
   int n_work[4];
 };
+
+#define LCS_STREAM_IN_BYTES (offsetof(StreamHost, f) + sizeof(double))
 
 struct lcs_ctx {
   int device = 0;
@@ -240,8 +247,9 @@ struct lcs_ctx {
   void *st_din = nullptr;                         // device copy (shared: the graph launches serialise)
   size_t st_in_bytes = 0;
   struct StreamHost *st_host[2] = {nullptr, nullptr};   // pinned parameter + result blocks
-  int16_t *st_dtracked = nullptr;
+  int16_t *st_dtracked = nullptr;     // (both point into st_dmirror)
   int *st_dntracked = nullptr;
+  char *st_dmirror = nullptr;        // device mirror of StreamHost's input part
   hipGraph_t st_graph[2] = {nullptr, nullptr};
   hipGraphExec_t st_exec[2] = {nullptr, nullptr};
   hipEvent_t st_ev0[2] = {nullptr, nullptr}, st_ev1[2] = {nullptr, nullptr};
@@ -355,7 +363,7 @@ __host__ __device__ static inline size_t lcs_pack_rec_offset(int n_buf) { return
 int lcs_launch_pack_results(lcs_ctx *c, int n_buf, bool full);   // peaks / npeaks (+ n_work) -> c->res_pack
 int lcs_launch_rs_build(lcs_ctx *c);
 int lcs_launch_tfg(lcs_ctx *c, uint32_t n_cap, bool with_rs /* also build RS_DL (the fused chain) */);
-int lcs_launch_tfoec(lcs_ctx *c, bool apply_grid);
+int lcs_launch_tfoec(lcs_ctx *c, bool apply_grid, int parts = 4 /* workgroups per cell for the timing estimate: 2 in batches */);
 int lcs_launch_mib(lcs_ctx *c, bool fused);   // chan_est + PBCH candidates + selection (+ record back into the peak table)
 int lcs_launch_chan_est(lcs_ctx *c);
 void lcs_chan_est_np_layout(int *first, int *per_port, int *n_rs_first);   // where k_chan_est leaves its noise-power partial sums in cell_scratch

@@ -1059,36 +1059,44 @@ int lcs_launch_xcorr(lcs_ctx *c, int n_buf, const XcGeom &geo, bool want_incoh, 
     hipLaunchKernelGGL(k_fill_btab, dim3(geo.n_comb * geo.G * n_buf), dim3(256), 0, c->stream, c->tmpl,
                        c->start, c->smin, c->kp2, c->btab, geo, n_buf);
   }
-  // signal-power estimate and threshold do not depend on the correlation: enqueue them first
+  // The signal-power estimate and the threshold need the capture buffer only, not the correlation: in the batch / single-buffer chains
+  // the correlation sits on stream_xc and they run BESIDE it on the main stream, behind the hand-over event (rounds 1-5 enqueued
+  // them in front of it: the correlation of a single buffer waited 26 us for them; lcs_search_capbuf 0.377 -> 0.337 ms same-box).
+  // The streaming mode's captured chain keeps everything on one stream: as a parallel branch of the graph (fork to stream_xc, join
+  // before the collapse) a replay took 0.315 instead of 0.273 ms -- the runtime replays a forked graph over several streams.
   SpArgs a;
   a.n_comb_sp = (int)((geo.n_cap - 136 - 137) / 9600);
   a.n_comb_xc = geo.n_comb;
   a.ds = geo.ds;
   a.R_th1 = lcs_tables::chi2cdf_inv(1 - pow(10.0, -12), 2.0 * geo.n_comb * (2 * geo.ds + 1));
   a.rx_cutoff = (6 * 12 * 15e3 / 2 + 4 * 15e3) / (30720000.0 / 16 / 2);
-  if (c->src_u8 && !c->cap64_valid) {
-    hipLaunchKernelGGL(k_sp_i8, dim3(LCS_N_IDX / SPI_TILE, n_buf), dim3(256), 0, c->stream, c->cap8, geo.n_cap, c->spinc, c->zth, a);
-  } else {
-  hipLaunchKernelGGL(k_sp_sums, dim3(((LCS_N_IDX + SP_TILE - 1) / SP_TILE) * a.n_comb_sp * n_buf), dim3(64), 0,
-                     c->stream, lcs_cap_src(c, geo.n_cap), c->sp, geo.n_cap, a.n_comb_sp, n_buf);       // one-wave workgroups
-  hipLaunchKernelGGL(k_sp_fold, dim3((n_buf * LCS_N_IDX + 255) / 256), dim3(256), 0, c->stream, c->sp, c->spinc,
-                     c->zth, a, n_buf);
-  }
+  auto launch_sp = [&](hipStream_t st) {
+    if (c->src_u8 && !c->cap64_valid) {
+      hipLaunchKernelGGL(k_sp_i8, dim3(LCS_N_IDX / SPI_TILE, n_buf), dim3(256), 0, st, c->cap8, geo.n_cap, c->spinc, c->zth, a);
+    } else {
+      hipLaunchKernelGGL(k_sp_sums, dim3(((LCS_N_IDX + SP_TILE - 1) / SP_TILE) * a.n_comb_sp * n_buf), dim3(64), 0,
+                         st, lcs_cap_src(c, geo.n_cap), c->sp, geo.n_cap, a.n_comb_sp, n_buf);       // one-wave workgroups
+      hipLaunchKernelGGL(k_sp_fold, dim3((n_buf * LCS_N_IDX + 255) / 256), dim3(256), 0, st, c->sp, c->spinc, c->zth, a, n_buf);
+    }
+  };
 
   // slots [0, n8) with the XCD-aware mapping, the remainder with the plain one
   const int n8 = (n_buf >= 8) ? (n_buf & ~7) : 0;
-  // main stream -> correlation stream hand-off (tables and capture buffer are ready); the streaming mode runs
-  // everything on one stream with no events, so that the chain can be captured as a graph
+  // main stream -> correlation stream hand-off (tables and capture buffer are ready)
   const bool single_stream = c->single_stream;
   hipStream_t sxc = single_stream ? c->stream : c->stream_xc;
   if (!single_stream) {
     HIPCHK(c, hipEventRecord(c->ev_pre, c->stream));
     HIPCHK(c, hipStreamWaitEvent(sxc, c->ev_pre, 0));
-    std::lock_guard<std::mutex> lk(g_xc_mutex);
-    hipEvent_t &ev = g_xc_done[c->device & 63];
-    if (!ev) HIPCHK(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming | LCS_EVENT_NOFENCE));
-    else HIPCHK(c, hipStreamWaitEvent(sxc, ev, 0));
-  }
+    {
+      std::lock_guard<std::mutex> lk(g_xc_mutex);
+      hipEvent_t &ev = g_xc_done[c->device & 63];
+      if (!ev) HIPCHK(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming | LCS_EVENT_NOFENCE));
+      else HIPCHK(c, hipStreamWaitEvent(sxc, ev, 0));
+    }
+    launch_sp(c->stream);
+  } else
+    launch_sp(c->stream);
   if (time_it) HIPCHK(c, hipEventRecord(c->ev_xc0, sxc));
   int launches = 0;
   c->last_xc_ops = 0;

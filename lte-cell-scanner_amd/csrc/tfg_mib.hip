@@ -405,7 +405,8 @@ __device__ __forceinline__ cd2 foc_value(const double2 *g, int t, int i, double 
 }
 
 #define TF_THREADS 256
-#define TF_PARTS 2
+#define TF_PARTS 4           // at most: the timing-estimate sum of a cell is split over gridDim.y <= TF_PARTS workgroups (2 in batches -- every part repeats the
+                             // frequency estimate, 4 cost a dense batch 1 % -- and 4 where one buffer's latency counts)
 __global__ __launch_bounds__(TF_THREADS) void k_tfoec_est(lcs_cell *__restrict__ cells, const WorkItem *__restrict__ items,
                                                           const int *__restrict__ n_work,
                                                           const SlotParams *__restrict__ params,
@@ -414,7 +415,7 @@ __global__ __launch_bounds__(TF_THREADS) void k_tfoec_est(lcs_cell *__restrict__
   LCS_TAIL_PRIO();
   __shared__ cd2 red[TF_THREADS / 64];
   __shared__ cd2 rowrot[ROWS];
-  const int tid = threadIdx.x, part_idx = blockIdx.y;     // the timing-estimate sum is split over TF_PARTS workgroups
+  const int tid = threadIdx.x, part_idx = blockIdx.y, n_parts = gridDim.y;     // the timing-estimate sum is split over n_parts workgroups
   for (int it = blockIdx.x; it < *n_work; it += gridDim.x) {
     const lcs_cell c = cells[it];
     const SlotParams p = params[items[it].slot];
@@ -449,7 +450,7 @@ __global__ __launch_bounds__(TF_THREADS) void k_tfoec_est(lcs_cell *__restrict__
     // TOE (ref :1012-1058) on the frequency-corrected RS samples
 #define GC(row, col) foc_value(g, (row), (col), tsi[(row)], k_res, rowrot[(row)])
     part = mk(0, 0);
-    const int n_toe = (2 * n_slot - 1) * 23, per_part = (n_toe + TF_PARTS - 1) / TF_PARTS;
+    const int n_toe = (2 * n_slot - 1) * 23, per_part = (n_toe + n_parts - 1) / n_parts;
     for (int e = part_idx * per_part + tid; e < min(n_toe, (part_idx + 1) * per_part); e += TF_THREADS) {
       const int t = e / 23, j = e % 23;
       const int cur_sym = (t & 1) ? (n_symb - 3) : 0, cur_slot = d_imod(t >> 1, 20), cur_off = (t >> 1) * n_symb + cur_sym;
@@ -477,6 +478,7 @@ __global__ __launch_bounds__(TF_THREADS) void k_tfoec_est(lcs_cell *__restrict__
       sc[CS_TF_TOE + 2 * part_idx] = toe.re;
       sc[CS_TF_TOE + 2 * part_idx + 1] = toe.im;
       if (part_idx == 0) {
+        for (int q = n_parts; q < TF_PARTS; ++q) { sc[CS_TF_TOE + 2 * q] = 0.0; sc[CS_TF_TOE + 2 * q + 1] = 0.0; }      // the consumers add TF_PARTS partial sums
         sc[CS_TF_RES] = residual_f;
         sc[CS_TF_KRES] = k_res;
         cells[it].freq_superfine = c.freq_fine + residual_f;
@@ -1047,8 +1049,8 @@ int lcs_launch_rs_build(lcs_ctx *c) {
   return LCS_OK;
 }
 // apply_grid: also write the corrected grid (the stage entry point); the fused chain leaves the correction to k_chan_est
-int lcs_launch_tfoec(lcs_ctx *c, bool apply_grid) {
-  hipLaunchKernelGGL(k_tfoec_est, dim3(c->grid_items, TF_PARTS), dim3(TF_THREADS), 0, c->stream, c->cells_out, c->work_items, c->n_work,
+int lcs_launch_tfoec(lcs_ctx *c, bool apply_grid, int parts) {
+  hipLaunchKernelGGL(k_tfoec_est, dim3(c->grid_items, std::min(std::max(parts, 1), TF_PARTS)), dim3(TF_THREADS), 0, c->stream, c->cells_out, c->work_items, c->n_work,
                      c->params, c->tfg, c->tfg_ts, c->cell_scratch, c->tfg_ts_comp);
   if (apply_grid) hipLaunchKernelGGL(k_tfoec_apply, dim3(LCS_TFA_GRID), dim3(TFA_THREADS), 0, c->stream, c->n_work, c->tfg, c->tfg_ts, c->cell_scratch,
                      c->cells_out, c->tfg_comp, c->needed_rows_only ? 1 : 0);
