@@ -914,7 +914,7 @@ def main():
         # corrected as MI355X_MICROARCH.md prescribes), taken from the committed summary ONLY if it was collected from
         # exactly the kernel sources that are running now.
         traffic, traffic_src = None, None
-        for tag in ("r05", "r04", "r03", "r02", "r01"):
+        for tag in ("r06", "r05", "r04", "r03", "r02", "r01"):
             try:
                 pmj = json.load(open(os.path.join(ROOT, "profiles", tag, "pmc_summary.json")))
                 if pmj.get("kernel_source_sha") != kernel_source_sha():

@@ -64,6 +64,9 @@ extern "C" {
  * for a buffer whose thresholds are positive fits.  (A buffer of zeros has Z_th1 == 0 everywhere: the reference's loop then
  * never ends; here it stops at LCS_MAX_PEAKS peaks and the call reports LCS_ERR_OVERFLOW.) */
 #define LCS_MAX_PEAKS 104
+/* Footprint that follows from that bound: the SSS / FOE stage keeps 60 KB of window records per POSSIBLE peak of a batch
+ * (n_buf x LCS_MAX_PEAKS x 8 half-frame occurrences x 3 KB -- 800 MB for a 128-buffer context, allocated by the first full-chain
+ * batch), the peak table 104 x 104 B per buffer.  Real buffers carry a handful of peaks; the worst case is what is reserved. */
 
 /* POD mirror of class Cell -- include/common.h.in:101-129, defaults src/common.cpp:36-56. */
 typedef struct lcs_cell {
@@ -387,7 +390,10 @@ int lcs_track_stats(lcs_ctx *ctx, int n_cells, int n_sym, double *ac_fd, double 
  *   ce, ce_pw [n_cells][4][ce_cap][72 complex | 4]: row r = symbol ce_from[cell][port] + r of the stream, ce_n rows
  *   mib_ok, mib_bits [n_cells][max_off]: entry k = frame offset mib_from[cell] + k of the stream (frames o..o+3), n_mib entries
  * cells[].bulk_phase_offset: in at the first call, out after every call.  td may be ordinary host memory, page-locked host
- * memory (lcs_host_alloc: DMA'd in place) or device memory (the kind is detected).  lcs_track_stream_reset forgets the
+ * memory (lcs_host_alloc: DMA'd in place) or device memory (the kind is detected).  LIFETIME: page-locked and device memory
+ * are copied asynchronously -- td must stay valid and unchanged until the call returns (the call synchronises with its stream
+ * before it returns, so nothing of td is referenced afterwards); layout [n_cells][n_sym][128] complex<double>, rows exactly
+ * n_sym * 128 elements apart.  lcs_track_stream_reset forgets the
  * stream (the next call starts a new one).  The PSS/SSS statistics (do_pss_sss_sigpower_ce) have no state across symbols
  * and stay with lcs_track_stats. */
 int lcs_track_stream_block(lcs_ctx *ctx, lcs_track_cell *cells, int n_cells, int n_sym, const void *td, const double *freq_off,

@@ -1,12 +1,12 @@
 #!/bin/bash
 # Collect a round's profiling artifacts on a GPU box (run from the repository root through gpurun):
-#   bash profiles/collect.sh r05
+#   bash profiles/collect.sh r06
 # GPU tests first, then the bench lines, the kernel-trace statistics (one context = isolated kernel times, default
 # pipeline = under load) and the PMC counters -- kernel-trace statistics and counters in SEPARATE rocprofv3 runs, one
 # counter group per pass, as MI355X_MICROARCH.md prescribes.  Outputs land in gpurun_out/<tag>/; profiles/summarize.py
 # reduces them to the small files kept under profiles/<tag>/.
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 REPO=$PWD
 OUT=$REPO/gpurun_out/$TAG
 mkdir -p "$OUT"
@@ -38,8 +38,10 @@ for grp in "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
   timeout 200 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d "$OUT/pmcf_$i" -- $B --steps 1 --warmup 0 --batch 64 --batches-per-step 4 --pipeline 1 --no-cpu-baseline --no-dense --no-power-probe --input c64 > "$OUT/pmcf_$i.log" 2>&1
 done
-# population parity (tools/parity_population.py: 1152 buffers, GPU chain against the oracle) and BASELINE configs[3]'s sweep on this library
+# population parity (tools/parity_population.py: 1152 buffers, GPU chain against the oracle; round 6: + 512 buffers through fading multipath
+# channels with the stage arrays of every decoded cell) and BASELINE configs[3]'s sweep on this library
 (cd "$REPO" && timeout 1500 python tools/parity_population.py --out "$OUT/parity_population.json" > "$OUT/parity_population.log" 2>&1)
+(cd "$REPO" && timeout 900 python tools/parity_population.py --groups channels --out "$OUT/parity_population_channels.json" > "$OUT/parity_population_channels.log" 2>&1)
 (cd "$REPO" && timeout 900 bash profiles/sweep_cli.sh "$TAG" > "$OUT/sweep_cli.log" 2>&1)
 # the bench lines last: bench.py reports roofline.traffic only from a PMC summary taken from the running kernel sources
 (cd "$REPO" && python profiles/summarize.py "$TAG" > /dev/null 2>&1)
@@ -52,5 +54,7 @@ timeout 120 $B --stage pss --no-cpu-baseline > "$OUT/bench_pss_n1.json" 2> "$OUT
 timeout 120 $B --stage single --steps 200 --warmup 20 > "$OUT/bench_single_n1.json" 2> "$OUT/bench_single_n1.err"
 timeout 120 $B --stage stream --steps 400 --warmup 20 > "$OUT/bench_stream_n1.json" 2> "$OUT/bench_stream_n1.err"
 timeout 120 $B --stage track --steps 60 --warmup 6 > "$OUT/bench_track_n1.json" 2> "$OUT/bench_track_n1.err"
-timeout 200 $B --steps 10 --warmup 2 --batches-per-step 20 --input c64 --no-cpu-baseline > "$OUT/bench_full_n1_c64_f16_kernel.json" 2> "$OUT/bench_c64.err"
+timeout 300 $B --steps 20 --warmup 3 --input c64 --no-cpu-baseline > "$OUT/bench_full_n1_c64_f16_kernel.json" 2> "$OUT/bench_c64.err"      # the driver's own command shape
+# the CLI's band-7 grid: fc 2.6 GHz at the default 120 ppm -> n_f = 125 (24 template groups per buffer, 1.8 GB of xc_incoherent_single per batch)
+timeout 400 $B --fc 2.6e9 --ppm 120 --steps 5 --warmup 1 > "$OUT/bench_full_n1_fc2600MHz_ppm120_nf125.json" 2> "$OUT/bench_nf125.err"
 echo collected > "$OUT/done"

@@ -310,6 +310,24 @@ def test_track_stream_mixed_cp_types_and_dongle_parameters(pkg, mixed):
         for n in (333, 200, 307):
             parts.append(S.track_stream_block(cells, td[:, a:a + n], fov[:, a:a + n], ftv[:, a:a + n], late[:, a:a + n], FC, FCP, FSP))
             a += n
+        # the same stream with the symbols handed over in DEVICE memory (asynchronous copies inside the call; the two CP types go
+        # through the per-cell copy path, not the one strided copy of a one-CP-type stream): identical rows
+        import torch
+        S.track_stream_reset()
+        parts_dev, a = [], 0
+        for n in (333, 200, 307):
+            d_td = torch.from_numpy(np.ascontiguousarray(td[:, a:a + n])).cuda()
+            parts_dev.append(S.track_stream_block(cells, None, fov[:, a:a + n], ftv[:, a:a + n], late[:, a:a + n], FC, FCP, FSP, td_device_ptr=d_td.data_ptr()))
+            del d_td
+            a += n
+    for q, qd in zip(parts, parts_dev):
+        for k in ("syms", "n_meas", "ce_n", "n_mib"):
+            assert np.array_equal(q[k], qd[k]), k
+        for i in range(len(cells)):
+            for p in range(4):
+                assert np.array_equal(q["meas"][i, p, :q["n_meas"][i, p]], qd["meas"][i, p, :qd["n_meas"][i, p]])
+                assert np.array_equal(q["ce"][i, p, :q["ce_n"][i, p]], qd["ce"][i, p, :qd["ce_n"][i, p]])
+            assert np.array_equal(q["mib_ok"][i, :q["n_mib"][i]], qd["mib_ok"][i, :qd["n_mib"][i]])
     for i, c in enumerate(cells):
         one = ones[i]
         assert np.array_equal(np.concatenate([q["syms"][i] for q in parts]), one["syms"][0])
