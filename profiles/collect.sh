@@ -42,6 +42,7 @@ done
 # channels with the stage arrays of every decoded cell) and BASELINE configs[3]'s sweep on this library
 (cd "$REPO" && timeout 1500 python tools/parity_population.py --out "$OUT/parity_population.json" > "$OUT/parity_population.log" 2>&1)
 (cd "$REPO" && timeout 900 python tools/parity_population.py --groups channels --out "$OUT/parity_population_channels.json" > "$OUT/parity_population_channels.log" 2>&1)
+(cd "$REPO" && timeout 900 python tools/parity_population.py --groups highband --out "$OUT/parity_population_highband.json" > "$OUT/parity_population_highband.log" 2>&1)
 (cd "$REPO" && timeout 900 bash profiles/sweep_cli.sh "$TAG" > "$OUT/sweep_cli.log" 2>&1)
 # the bench lines last: bench.py reports roofline.traffic only from a PMC summary taken from the running kernel sources
 (cd "$REPO" && python profiles/summarize.py "$TAG" > /dev/null 2>&1)

@@ -10,7 +10,7 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(root, "gpurun_out", tag), os.path.join(root, "profiles", tag)
 os.makedirs(dst, exist_ok=True)
 
-for name in ("parity_population.json", "parity_population_channels.json", "sweep_715_768_n1.json", "cli_time.txt", "cli_sweep_table.txt"):
+for name in ("parity_population.json", "parity_population_channels.json", "parity_population_highband.json", "sweep_715_768_n1.json", "cli_time.txt", "cli_sweep_table.txt"):
     p = os.path.join(src, name)
     if os.path.exists(p):
         shutil.copy(p, os.path.join(dst, name))

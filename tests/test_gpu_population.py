@@ -51,3 +51,22 @@ def test_population_on_fading_multipath_channels_has_no_disagreement(tmp_path):
     w = sa["worst_relative_deviation"]
     assert w["tfg"] <= 1e-10 and w["tfg_comp"] <= 1e-9 and w["ce_tfg"] <= 1e-9 and w["np"] <= 1e-11
     assert r.returncode == 0
+
+
+def test_population_on_wide_grids_has_no_disagreement(tmp_path):
+    """Round 6: a 32-buffer cut (4 scenes x 8 noise realisations: n_f = 61, 87, 103, 125 -- 1.25 / 1.8 / 2.14 / 2.6 GHz at the CLI's
+    default 120 ppm, src/CellSearch.cpp:463-465) of the `highband` group: cells through fading channels with LO errors out to 0.9
+    of the grid's edge, every decision and every collapsed index compared, the stage arrays of every decoded cell too.  The
+    whole group (96 buffers, also n_f = 169 and 141 with dongle parameters): profiles/r06/parity_population_highband.json."""
+    out = tmp_path / "population_highband.json"
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "parity_population.py"), "--groups", "highband", "--limit", "32", "--out", str(out)],
+                       env=env, capture_output=True, text=True, timeout=1800)
+    assert out.exists(), (r.stdout[-2000:], r.stderr[-3000:])
+    j = json.loads(out.read_text())
+    t = j["totals"]
+    assert t["buffers"] == 32 and t["cells"] >= 12 and t["frq_positions"] == 32 * 3 * 9600
+    assert j["disagreements"] == 0, j["details"][:10]
+    sa = j["stage_arrays"]
+    assert sa["cells_compared"] == t["cells"] and sa["disagreements"] == 0
+    assert r.returncode == 0

@@ -1,0 +1,126 @@
+"""The tracker block on cells that went through a RADIO CHANNEL.
+
+tests/test_tracker.py runs lcs_track_block on the two cells of the reference's recorded capture (both normal CP, two ports, a
+static channel) and tests/test_gpu_configs.py on one synthetic pair behind flat gains.  The stages of src/tracker_thread.cpp
+that a frequency-selective, time-varying channel stresses -- filter_ce's 12-tap rows and its power / FOE / TOE measurements
+(:176-288), interp2d between reference symbols that differ (:318-371), the SFBC combining of pbch_extract_rt on four ports --
+see such a channel here: per (cell, antenna port) an independent Rayleigh tapped delay line (EPA / EVA / ETU of 36.101 B.2)
+with Jakes Doppler 5 / 70 / 300 Hz, plus the zero-IF front end's DC spike and I/Q imbalance (lte-cell-scanner_amd/synth.py),
+1 / 2 / 4 ports, both CP types, dongle parameters on two of the captures.  Every output array of the block against the oracle
+(oracle/lcs_oracle.c: trk_get_fd / trk_chan_est / trk_mib)."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle as O
+from conftest import iq_u8_to_capbuf, load_pkg
+
+pytestmark = pytest.mark.gpu
+FS, FC = 1.92e6, 739e6
+
+#        n_id_1 n_id_2 cp_normal ports n_rb  channel doppler f_off    front end                                   dongle
+SCENES = [(17, 0, True, 1, 6, "EPA", 5.0, 12.3e3, None, False),
+          (101, 1, True, 2, 50, "EVA", 70.0, -31.0e3, dict(dc=0.2 - 0.1j), False),
+          (160, 2, True, 4, 100, "ETU", 300.0, 4.4e3, dict(iq_gain_db=0.5, iq_phase_deg=3.0), True),
+          (54, 1, False, 2, 25, "ETU", 70.0, -18.7e3, None, False),
+          (7, 2, False, 4, 15, "EVA", 300.0, 27.1e3, dict(dc=-0.1 + 0.3j, iq_gain_db=-0.4, iq_phase_deg=-2.0), True),
+          (88, 0, False, 1, 75, "EPA", 300.0, -2.0e3, None, False)]
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    return load_pkg()
+
+
+@pytest.fixture(scope="module")
+def blocks(pkg):
+    """Per scene: (searcher record of the planted cell, its symbols as the producer cuts them, the capture's parameters)."""
+    O.set_legacy(False)
+    O.set_threads(min(16, os.cpu_count() or 1))
+    out = []
+    for k, (n1, n2, cpn, ports, nrb, chan, dop, f_off, fe, dongle) in enumerate(SCENES):
+        fcp = FC * (1 + 13e-6) if dongle else FC
+        fsp = FS * (1 - 21e-6) if dongle else FS
+        cell = dict(n_id_1=n1, n_id_2=n2, cp_normal=cpn, n_ports=ports, n_rb_dl=nrb, f_off=f_off, t0=900.0 + 777.7 * k, channel=chan, doppler_hz=dop)
+        iq, _ = pkg.synth.make_capbuf(9100 + k, FC, [cell], 12.0, fc_programmed=fcp, fs_programmed=fsp, front_end=fe)
+        cap = iq_u8_to_capbuf(iq)
+        f = 5e3 * np.round(f_off / 5e3) + 5e3 * np.arange(-1, 2)
+        found = [c for c in O.search_capbuf(cap, f, FC, fcp, fsp)[0] if c.n_id_cell() == 3 * n1 + n2]
+        assert len(found) == 1 and found[0].n_ports == ports and found[0].cp_type == (1 if cpn else 2), (k, chan, dop)
+        c = found[0]
+        k_factor = (FC - c.freq_superfine) / fcp
+        ft = c.frame_start * (30.72e6 / 16) / (fsp * k_factor)                       # src/searcher_thread.cpp:224
+        per_frame = 140 if cpn else 120
+        td, late, ftv, fov = pkg.tracker.cut_symbols(cap, ft, c.cp_type, c.freq_superfine, FC, fcp, fsp, 7 * per_frame)
+        out.append(dict(c=c, td=td, late=late, ftv=ftv, fov=fov, fcp=fcp, fsp=fsp, per_frame=per_frame, tag=f"scene {k} ({chan}, {dop:.0f} Hz, {ports} ports)"))
+    return out
+
+
+def _oracle_block(b):
+    c = b["c"]
+    syms, bpo, _ = O.trk_get_fd(c, b["td"], 0, 0, b["fov"], b["late"], FC, b["fcp"], b["fsp"])
+    r = O.trk_chan_est(c, syms, 0, 0, b["fov"], b["ftv"], FC, b["fcp"], b["fsp"])
+    r.update(syms=syms, bpo=bpo)
+    per_frame, nsd = b["per_frame"], b["per_frame"] // 20
+    upto = int(min(r["ce_upto"][:c.n_ports]))
+    mib = []
+    for o in range(b["td"].shape[0] // per_frame - 3):
+        ii = [(o + fr) * per_frame + nsd + s for fr in range(4) for s in range(4)]
+        mib.append(None if ii[-1] >= upto else O.trk_mib(c, syms[ii], r["ce"][:c.n_ports][:, ii], r["ce_pw"][:c.n_ports][:, ii, 3]))
+    r["mib"] = mib
+    return r
+
+
+def test_track_block_on_fading_channels_matches_oracle(pkg, blocks):
+    locks = 0
+    with pkg.Searcher(0) as S:
+        for b in blocks:
+            c, tag = b["c"], b["tag"]
+            g = S.track_block([c], b["td"], b["fov"], b["ftv"], b["late"], FC, b["fcp"], b["fsp"])
+            r = _oracle_block(b)
+            assert np.abs(g["syms"][0] - r["syms"]).max() < 1e-11 * np.abs(r["syms"]).max(), tag
+            assert abs(g["bpo"][0] - r["bpo"]) < 1e-9, tag
+            assert np.array_equal(g["n_meas"][0], r["n_meas"]) and np.array_equal(g["ce_upto"][0], r["ce_upto"]), tag
+            for p in range(c.n_ports):
+                n = r["n_meas"][p]
+                gm, om = g["meas"][0, p, :n], r["meas"][p, :n]
+                assert np.array_equal(gm[:, 0], om[:, 0]), (tag, p)
+                assert np.abs(gm[:, 1:5] - om[:, 1:5]).max() < 1e-11 * om[:, 2].max(), (tag, p)
+                assert np.abs(gm[:, 5] - om[:, 5]).max() < 1e-6 and np.abs(gm[:, 7] - om[:, 7]).max() < 1e-8, (tag, p)       # Hz, samples
+                u = r["ce_upto"][p]
+                assert np.abs(g["ce"][0, p, :u] - r["ce"][p, :u]).max() < 1e-11 * np.abs(r["ce"][p, :u]).max(), (tag, p)
+                assert np.abs(g["ce_pw"][0, p, :u] - r["ce_pw"][p, :u]).max() < 1e-11 * np.abs(r["ce_pw"][p, :u]).max(), (tag, p)
+            for o, m in enumerate(r["mib"]):
+                if m is None:
+                    assert g["mib_ok"][0, o] == -1, (tag, o)
+                    continue
+                assert g["mib_ok"][0, o] == (1 if m[1] else 0) | (2 if m[2] else 0), (tag, o)
+                assert [(int(g["mib_bits"][0, o]) >> k) & 1 for k in range(40)] == list(m[0]), (tag, o)
+                locks += int(g["mib_ok"][0, o] == 3)
+    # the channel really varied: the fast scenes lose some decodes, the slow ones must lock
+    assert locks >= 3
+
+
+def test_track_block_of_all_scenes_in_one_call_equals_the_single_calls(pkg, blocks):
+    """Two normal-CP scenes in ONE call (a 1-port and a 2-port cell side by side), then two extended-CP ones: the rows of each
+    cell are those of its own call, bit for bit -- no cell's channel leaks into another's chunk of k_trk_ce."""
+    with pkg.Searcher(0) as S:
+        for per_frame in (140, 120):
+            grp = [b for b in blocks if b["per_frame"] == per_frame and b["fcp"] == FC]
+            assert len(grp) == 2
+            both = S.track_block([b["c"] for b in grp], np.stack([b["td"] for b in grp]), np.stack([b["fov"] for b in grp]),
+                                 np.stack([b["ftv"] for b in grp]), np.stack([b["late"] for b in grp]), FC, FC, FS)
+            for i, b in enumerate(grp):
+                one = S.track_block([b["c"]], b["td"], b["fov"], b["ftv"], b["late"], FC, FC, FS)
+                tag = b["tag"]
+                assert np.array_equal(both["syms"][i], one["syms"][0]) and both["bpo"][i] == one["bpo"][0], tag
+                assert np.array_equal(both["n_meas"][i], one["n_meas"][0]) and np.array_equal(both["ce_upto"][i], one["ce_upto"][0]), tag
+                assert np.array_equal(both["mib_ok"][i], one["mib_ok"][0]), tag
+                ok = one["mib_ok"][0] >= 0
+                assert np.array_equal(both["mib_bits"][i][ok], one["mib_bits"][0][ok]), tag
+                for p in range(b["c"].n_ports):
+                    n, u = one["n_meas"][0][p], one["ce_upto"][0][p]
+                    assert np.array_equal(both["meas"][i, p, :n], one["meas"][0, p, :n]), (tag, p)
+                    assert np.array_equal(both["ce"][i, p, :u], one["ce"][0, p, :u]), (tag, p)
+                    assert np.array_equal(both["ce_pw"][i, p, :u], one["ce_pw"][0, p, :u]), (tag, p)

@@ -20,6 +20,12 @@ The buffers:
              too: extract_tfg's grid (1e-10), tfoec's compensated grid (1e-9), chan_est's estimate of every port (1e-9) and its
              noise power (1e-11), through the stage entry points on the oracle's own inputs.
 
+  highband   (round 6) 96 buffers on the WIDE grids the reference's CLI builds at its default 120 ppm above 1 GHz
+             (src/CellSearch.cpp:463-465): n_f = 61 (1.25 GHz), 87 (1.8 GHz, band 3), 103 (2.14 GHz, band 1), 125 (2.6 GHz, band 7),
+             169 (3.5 GHz, bands 42 / 43), 141 (2.9 GHz on a 120 ppm crystal that the dongle programmes 9 ppm off) -- 12 scenes x 8
+             noise realisations, 1-2 cells through the fading channels of the `channels` group, LO errors out to 0.9 of the
+             grid's edge (up to 380 kHz), the stage arrays of every decoded cell compared as there.
+
 Per buffer, GPU (lcs_batch_enqueue / lcs_batch_collect / lcs_batch_readback) against oracle (oracle/lcs_oracle.c, one
 process per host core):
   xc_incoherent_collapsed_frq   every one of the 3 x 9600 indices EQUAL
@@ -110,6 +116,37 @@ def channel_scene(synth, s, seed_offset=0):
     return dict(sig=sig, ref_pow=ref_pow, f=f, fc_req=fc_req, fc_prog=fc_prog, fs_prog=fs_prog, planted=cells, front_end=fe)
 
 
+HB_GRIDS = ((1.25e9, 120.0), (1.8e9, 120.0), (2.14e9, 120.0), (2.6e9, 120.0), (3.5e9, 120.0), (2.9e9, 120.0))     # n_f = 61, 87, 103, 125, 169, 141
+
+
+def highband_scene(synth, s, seed_offset=0):
+    """Scene s of 12 of the `highband` group: a wide hypothesis grid, 1-2 cells through fading channels, large LO errors."""
+    rng = np.random.default_rng(80_000 + s + 1000 * seed_offset)
+    fc, ppm = HB_GRIDS[s % 6]
+    f = f_grid(fc, ppm)
+    fc_req = fc + 100e3 * (s % 3)
+    dongle = (s % 6 == 5)
+    fc_prog = fc_req * (1 + 9e-6) if dongle else fc_req
+    fs_prog = FS * (1 - 14e-6) if dongle else FS
+    cells = []
+    for j in range(1 + (s // 6)):
+        # the first cell of a scene sits near an EDGE of the grid (alternating sides), the second anywhere
+        off = (0.9 if s % 2 else -0.9) * f[-1] + float(rng.uniform(-6e3, 6e3)) if j == 0 else float(rng.uniform(-0.9, 0.9) * f[-1])
+        cells.append(dict(n_id_1=int(rng.integers(0, 168)), n_id_2=int(rng.integers(0, 3)), cp_normal=bool((s + j) % 3 != 2),
+                          n_ports=int((1, 2, 4)[(s + j) % 3]), n_rb_dl=int((6, 15, 25, 50, 75, 100)[(s + 4 * j) % 6]),
+                          phich_duration_ext=int((s + j) % 2), phich_res=int((s + j) % 4), f_off=off, gain_db=-3.0 * j,
+                          channel=CH_PROFILES[(s + j) % 3], doppler_hz=CH_DOPPLER[(s + j) % 3]))
+    sig, ref_pow, _ = synth.make_signal(rng, fc_req, cells, N_CAP, fc_prog, fs_prog)
+    fe = (None, dict(dc=0.2 + 0.1j), dict(iq_gain_db=0.5, iq_phase_deg=-3.0))[s % 3]
+    return dict(sig=sig, ref_pow=ref_pow, f=f, fc_req=fc_req, fc_prog=fc_prog, fs_prog=fs_prog, planted=cells, front_end=fe)
+
+
+def _highband_scene_job(args):
+    import __graft_entry__ as ge
+    s, seed_offset = args
+    return highband_scene(ge.load_package().synth, s, seed_offset)
+
+
 def _channel_scene_job(args):
     import __graft_entry__ as ge
     s, seed_offset = args
@@ -144,6 +181,18 @@ def build_population(pkg, groups, limit=None, dense_limit=None, seed_offset=0, p
                 rms = (0.5, 0.75)[v - 6] if v >= 6 else float(rng.uniform(0.08, 0.22))
                 iq = synth.add_noise_and_quantise(rng, sig, sc["ref_pow"], CH_SNRS[v], rms=rms, front_end=sc["front_end"])
                 items.append(dict(name=f"channels/scene{s:02d}/snr{CH_SNRS[v]:+.0f}dB/v{v}", group="channels", iq=iq, f=sc["f"],
+                                  fc_req=sc["fc_req"], fc_prog=sc["fc_prog"], fs_prog=sc["fs_prog"], n_planted=len(sc["planted"]),
+                                  snr_db=CH_SNRS[v], arrays=True))
+    if "highband" in groups:
+        n_scenes = 12 if limit is None else max(1, min(12, limit // 8))
+        jobs = [(s, seed_offset) for s in range(n_scenes)]
+        scenes = pool.map(_highband_scene_job, jobs, chunksize=1) if pool is not None else [_highband_scene_job(j) for j in jobs]
+        for s, sc in enumerate(scenes):
+            for v in range(8):
+                rng = np.random.default_rng(97_000 + 8 * s + v + 10_000 * seed_offset)
+                sig = np.roll(sc["sig"], int(rng.integers(0, N_CAP))) if v else sc["sig"]
+                iq = synth.add_noise_and_quantise(rng, sig, sc["ref_pow"], CH_SNRS[v], rms=float(rng.uniform(0.08, 0.22)), front_end=sc["front_end"])
+                items.append(dict(name=f"highband/scene{s:02d}/nf{sc['f'].size}/snr{CH_SNRS[v]:+.0f}dB/v{v}", group="highband", iq=iq, f=sc["f"],
                                   fc_req=sc["fc_req"], fc_prog=sc["fc_prog"], fs_prog=sc["fs_prog"], n_planted=len(sc["planted"]),
                                   snr_db=CH_SNRS[v], arrays=True))
     fcs = FC + 100e3 * np.arange(128)
@@ -429,7 +478,7 @@ def run(groups=("synthetic", "bench", "dense"), limit=None, workers=None, out_pa
         gpu_frq_positions_repaired=n_repairs,
         stage_arrays=dict(cells_compared=arr_cells, disagreements=len(arr_dis), worst_relative_deviation=arr_worst,
                           tolerances=dict(tfg=1e-10, tfg_comp=1e-9, ce_tfg=1e-9, np=1e-11),
-                          note="channels group: extract_tfg / tfoec / chan_est (every port) of every cell the oracle decoded, GPU stage entry points on the oracle's inputs"),
+                          note="channels / highband groups: extract_tfg / tfoec / chan_est (every port) of every cell the oracle decoded, GPU stage entry points on the oracle's inputs"),
         closest_calls=dict(sss_abs_sigma_minus_3_min=min_sss, z_th1_abs_ratio_minus_1_min=min_z, frq_best_vs_second_min_rel=min_frq),
         details=all_dis[:200],
         seconds=dict(population=t_built - t_start, gpu_and_oracle=t_done - t_built, gpu_calls=t_gpu,
@@ -447,7 +496,7 @@ def run(groups=("synthetic", "bench", "dense"), limit=None, workers=None, out_pa
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--groups", default="synthetic,bench,dense", help="any of synthetic, bench, dense, channels")
+    ap.add_argument("--groups", default="synthetic,bench,dense", help="any of synthetic, bench, dense, channels, highband")
     ap.add_argument("--limit", type=int, default=None, help="quick runs: at most this many buffers per group (synthetic: whole scenes of 8; bench: a quarter of it from each of the four batches)")
     ap.add_argument("--dense-limit", type=int, default=None)
     ap.add_argument("--workers", type=int, default=None)
