@@ -54,7 +54,7 @@ timeout 200 $B --steps 20 --warmup 5 --input-host --no-cpu-baseline --no-dense >
 timeout 120 $B --stage pss --no-cpu-baseline > "$OUT/bench_pss_n1.json" 2> "$OUT/bench_pss_n1.err"
 timeout 120 $B --stage single --steps 200 --warmup 20 > "$OUT/bench_single_n1.json" 2> "$OUT/bench_single_n1.err"
 timeout 120 $B --stage stream --steps 400 --warmup 20 > "$OUT/bench_stream_n1.json" 2> "$OUT/bench_stream_n1.err"
-timeout 120 $B --stage track --steps 60 --warmup 6 > "$OUT/bench_track_n1.json" 2> "$OUT/bench_track_n1.err"
+timeout 120 $B --stage track --steps 400 --warmup 40 > "$OUT/bench_track_n1.json" 2> "$OUT/bench_track_n1.err"
 timeout 300 $B --steps 20 --warmup 3 --input c64 --no-cpu-baseline > "$OUT/bench_full_n1_c64_f16_kernel.json" 2> "$OUT/bench_c64.err"      # the driver's own command shape
 # the CLI's band-7 grid: fc 2.6 GHz at the default 120 ppm -> n_f = 125 (24 template groups per buffer, 1.8 GB of xc_incoherent_single per batch)
 timeout 400 $B --fc 2.6e9 --ppm 120 --steps 5 --warmup 1 > "$OUT/bench_full_n1_fc2600MHz_ppm120_nf125.json" 2> "$OUT/bench_nf125.err"

@@ -10,11 +10,11 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(root, "gpurun_out", tag), os.path.join(root, "profiles", tag)
 os.makedirs(dst, exist_ok=True)
 
-for name in ("parity_population.json", "parity_population_channels.json", "parity_population_highband.json", "sweep_715_768_n1.json", "cli_time.txt", "cli_sweep_table.txt"):
+for name in ("parity_population.json", "parity_population_channels.json", "parity_population_highband.json", "parity_population_highband_seed1.json", "parity_population_c64.json", "parity_population_channels_seed1.json", "parity_population_channels_seed2.json", "sweep_715_768_n1.json", "cli_time.txt", "cli_sweep_table.txt"):
     p = os.path.join(src, name)
     if os.path.exists(p):
         shutil.copy(p, os.path.join(dst, name))
-for name in ("bench_full_n1.json", "bench_forced_dist_n1.json", "bench_full_n1_input_host.json", "bench_single_n1.json", "bench_pss_n1.json", "bench_stream_n1.json", "bench_track_n1.json", "bench_full_n1_c64_f16_kernel.json", "bench_full_n1_fc2600MHz_ppm120_nf125.json", "pytest_gpu.log"):
+for name in ("bench_full_n1.json", "bench_forced_dist_n1.json", "bench_full_n1_input_host.json", "bench_single_n1.json", "bench_pss_n1.json", "bench_stream_n1.json", "bench_track_n1.json", "bench_full_n1_c64_f16_kernel.json", "bench_full_n1_fc2600MHz_ppm120_nf125.json", "pytest_gpu.log", "pytest_gpu_new_tests.log"):
     p = os.path.join(src, name)
     if os.path.exists(p):
         lines = [l for l in open(p).read().splitlines() if l.startswith("{")] if name.endswith(".json") else open(p).read().splitlines()[-6:]

@@ -287,8 +287,10 @@ def _frq_margins(ro):
 
 
 # -------------------------------------------------------------------------------------------------------- GPU side
-def gpu_pass(pkg, items, batch=128):
-    """Every buffer through the batched, device-resident chain; buffers that share (grid, fs_programmed) share batches."""
+def gpu_pass(pkg, items, batch=128, input_fmt="u8"):
+    """Every buffer through the batched, device-resident chain; buffers that share (grid, fs_programmed) share batches.
+    input_fmt "c64": the same samples handed over as complex<float> ((u8 - 127) / 128 is exact in fp32) -- LCS_FMT_C64 batches take
+    the fp16 three-product kernel (k_xcorr_f16x3) and every later stage reads the float buffer in place."""
     import torch
     out = [None] * len(items)
     keys = {}
@@ -296,26 +298,33 @@ def gpu_pass(pkg, items, batch=128):
         keys.setdefault((it["f"].tobytes(), it["fs_prog"]), []).append(i)
     n_repairs = 0
     t_gpu = 0.0
+    kernels = set()
     with pkg.Searcher(0) as S:
         for (_, fs), idx in keys.items():
             f = items[idx[0]]["f"]
             for a in range(0, len(idx), batch):
                 ids = idx[a:a + batch]
                 host = np.stack([items[i]["iq"] for i in ids])
+                fmt = pkg.FMT_IQ_U8
+                if input_fmt == "c64":
+                    x = (host.astype(np.float32) - 127.0) / 128.0
+                    host = np.ascontiguousarray(x).view(np.complex64)
+                    fmt = pkg.FMT_C64
                 d = torch.from_numpy(host).cuda()
                 fr = np.array([items[i]["fc_req"] for i in ids])
                 fp = np.array([items[i]["fc_prog"] for i in ids])
                 t0 = time.perf_counter()
-                pk = S.search_batch(d.data_ptr(), pkg.FMT_IQ_U8, len(ids), N_CAP, f, fr, fp, fs, pkg.STAGE_PSS, max_cells_per_buf=pkg.MAX_PEAKS)
+                pk = S.search_batch(d.data_ptr(), fmt, len(ids), N_CAP, f, fr, fp, fs, pkg.STAGE_PSS, max_cells_per_buf=pkg.MAX_PEAKS)
+                kernels.add(S.last_xcorr_info()[0])
                 n_repairs += S.last_frq_repairs()
                 arr = [S.batch_readback(b, f.size) for b in range(len(ids))]
-                full = S.search_batch(d.data_ptr(), pkg.FMT_IQ_U8, len(ids), N_CAP, f, fr, fp, fs, pkg.STAGE_FULL, max_cells_per_buf=pkg.MAX_PEAKS)
+                full = S.search_batch(d.data_ptr(), fmt, len(ids), N_CAP, f, fr, fp, fs, pkg.STAGE_FULL, max_cells_per_buf=pkg.MAX_PEAKS)
                 t_gpu += time.perf_counter() - t0
                 assert not S.last_overflow
                 for b, i in enumerate(ids):
                     out[i] = dict(frq=arr[b]["frq"], pow=arr[b]["pow"], zth=arr[b]["z_th1"], peaks=[cell_to_dict(c) for c in pk[b]],
                                   cells=[cell_to_dict(c) for c in full[b]])
-    return out, n_repairs, t_gpu
+    return out, n_repairs, t_gpu, sorted(kernels)
 
 
 def compare_arrays(pkg, S, it, o):
@@ -420,7 +429,7 @@ def compare(it, g, o):
                      frq_near_ties_1e_6=int(np.count_nonzero(o["frq_margin"] < 1e-6)), frq_min_margin=float(o["frq_margin"].min()))
 
 
-def run(groups=("synthetic", "bench", "dense"), limit=None, workers=None, out_path=None, quiet=False, dense_limit=None, seed_offset=0):
+def run(groups=("synthetic", "bench", "dense"), limit=None, workers=None, out_path=None, quiet=False, dense_limit=None, seed_offset=0, input_fmt="u8"):
     t_start = time.perf_counter()
     workers = workers or max(1, min(len(os.sched_getaffinity(0)), 32))
     # the oracle's worker processes start BEFORE this process touches the GPU runtime (fork of a process with live HIP threads is unsafe)
@@ -430,7 +439,7 @@ def run(groups=("synthetic", "bench", "dense"), limit=None, workers=None, out_pa
     items = build_population(pkg, groups, limit, dense_limit, seed_offset, pool)
     t_built = time.perf_counter()
     res_async = pool.imap(oracle_job, items, chunksize=1)
-    gpu, n_repairs, t_gpu = gpu_pass(pkg, items)
+    gpu, n_repairs, t_gpu, kernels = gpu_pass(pkg, items, input_fmt=input_fmt)
     # results are taken as they arrive: the stage arrays of the `channels` group (a few MB per decoded cell) are compared through
     # the GPU's stage entry points at once and dropped
     orc, arr_dis, arr_cells = [], [], 0
@@ -472,7 +481,7 @@ def run(groups=("synthetic", "bench", "dense"), limit=None, workers=None, out_pa
         by_stage[d["stage"]] = by_stage.get(d["stage"], 0) + 1
     report = dict(
         what="GPU chain (lcs_batch_enqueue / _collect / _readback) against oracle/lcs_oracle.c on the same capture buffers",
-        groups=list(groups), seed_offset=seed_offset,
+        groups=list(groups), seed_offset=seed_offset, input=input_fmt, correlation_kernels=kernels,
         totals=tot, per_group=per_group, disagreements=len(all_dis), disagreements_by_stage=by_stage,
         disagreement_rate_per_buffer=len(all_dis) / max(1, tot["buffers"]),
         gpu_frq_positions_repaired=n_repairs,
@@ -501,7 +510,8 @@ if __name__ == "__main__":
     ap.add_argument("--dense-limit", type=int, default=None)
     ap.add_argument("--workers", type=int, default=None)
     ap.add_argument("--seed-offset", type=int, default=0, help="other synthetic scenes and noise realisations (the bench's and the dense band's buffers are fixed)")
+    ap.add_argument("--input", default="u8", choices=("u8", "c64"), help="c64: the same samples as complex<float> batches (the fp16 three-product kernel)")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "parity_population.json"))
     a = ap.parse_args()
-    r = run(tuple(a.groups.split(",")), a.limit, a.workers, a.out, dense_limit=a.dense_limit, seed_offset=a.seed_offset)
+    r = run(tuple(a.groups.split(",")), a.limit, a.workers, a.out, dense_limit=a.dense_limit, seed_offset=a.seed_offset, input_fmt=a.input)
     sys.exit(0 if r["disagreements"] == 0 else 1)
