@@ -965,6 +965,78 @@ __global__ __launch_bounds__(REPAIR_THREADS) void k_frq_repair(const float *__re
   if (tid == 0 && skipped) atomicAdd(n_skipped, skipped);
 }
 
+// ------------------------------------------------- one-window buffers: xc_incoherent_single in the reference's own arithmetic
+// A capture of fewer than 2 x 9600 + 236 samples has ONE combining window (n_comb_xc = 1, ref src/searcher.cpp:276): nothing
+// averages over windows, and xc_incoherent_single IS |xc|^2 of one 137-tap sum -- exponentially distributed, so a few hundred of
+// its 2.7 M values lie 40 dB and more below the mean.  There the matrix-core kernels' fixed-point templates (24-bit integers, fp16
+// hi + lo pairs: an absolute floor of ~1e-7 of the buffer's largest value) show as 1e-4 .. 1e-3 RELATIVE, outside the 1e-5 the
+// full-length buffers meet on every element (rounds 1-5 documented that as an exception).  Such a buffer costs 0.5 G fp64
+// multiply-adds in all: this kernel forms every element as the reference does (k_frq_repair's arithmetic, element for element: the
+// template in double (ref :146-151), the 137 terms added in tap order in double, xc stored as complex<float> (:160-169), the
+// square in double, the float running sum over the windows, / n_comb (:299-305)) -- bit for bit the oracle's values.
+// One workgroup per (chunk of positions, template group, buffer): thread = (position within a tile of 16, column of the group),
+// so a tile's 16 x 16 outputs are sixteen contiguous 64-byte rows; the group's sixteen templates sit in LDS (stride 137 double2:
+// the sixteen columns of a wave read sixteen different bank quads).
+#define EXS_CHUNKS 32
+template <int KIND>
+__global__ __launch_bounds__(256) void k_single_exact(const CapSrc src, const SlotParams *__restrict__ params, const double *__restrict__ fset,
+                                                       const double2 *__restrict__ pss_td, const int *__restrict__ start,
+                                                       float *__restrict__ single, XcGeom geo) {
+  typedef typename RepairSample<KIND>::T ST;
+  __shared__ double2 s_tmpl[LCS_TG][137];
+  __shared__ int s_st[LCS_TG][LCS_NW_MAX];
+  const int tid = threadIdx.x, j = tid & (LCS_TG - 1), pp = tid / LCS_TG;
+  const int g = blockIdx.y, slot = blockIdx.z;
+  const ST *capbase = KIND == 0 ? reinterpret_cast<const ST *>(src.c8) : (KIND == 1 ? reinterpret_cast<const ST *>(src.c32) : reinterpret_cast<const ST *>(src.c64));
+  const ST *cap = capbase + (size_t)slot * (KIND == 0 ? lcs_cap8_stride(src.n_cap) : (size_t)src.n_cap);
+  const SlotParams p = params[slot];
+  for (int e = tid; e < LCS_TG * 137; e += 256) {
+    const int jj = e / 137, m = e - jj * 137;
+    const int c = lcs_col_tmpl(geo, g, jj);
+    double2 v = make_double2(0.0, 0.0);
+    if (c >= 0) {
+      const int foi = c / 3, t = c - 3 * foi;
+      const double f_off = fset[foi];
+      const double kf = (p.fc_req - f_off) / p.fc_prog;
+      const double k = M_PI * f_off / ((p.fs_prog * kf) / 2);
+      double sn, cs;
+      sincos(k * (double)m, &sn, &cs);
+      const double2 s = pss_td[t * 137 + m];
+      v = make_double2((s.x * cs - s.y * sn) / 137, -(s.x * sn + s.y * cs) / 137);
+    }
+    s_tmpl[jj][m] = v;
+  }
+  for (int e = tid; e < LCS_TG * LCS_NW_MAX; e += 256) {
+    const int jj = e / LCS_NW_MAX, w = e - jj * LCS_NW_MAX;
+    const int c = lcs_col_tmpl(geo, g, jj);
+    s_st[jj][w] = (c >= 0 && w < geo.n_comb) ? start[((size_t)slot * LCS_NW_MAX + w) * NFM + c / 3] : 0;
+  }
+  __syncthreads();
+  const bool live = lcs_col_tmpl(geo, g, j) >= 0;
+  float *out = single + ((size_t)slot * geo.G + g) * LCS_N_IDX * LCS_TG;
+  const int per = (LCS_N_IDX + EXS_CHUNKS - 1) / EXS_CHUNKS;
+  const int i0 = blockIdx.x * per, i1 = min(LCS_N_IDX, i0 + per);
+  for (int idx = i0 + pp; idx < i1; idx += 256 / LCS_TG) {
+    float o = 0.f;
+    if (live) {
+      for (int w = 0; w < geo.n_comb; ++w) {
+        const ST *x = cap + (size_t)idx + (size_t)s_st[j][w];
+        double ar = 0, ai = 0;
+#pragma unroll 8
+        for (int m = 0; m < 137; ++m) {
+          const double2 a = s_tmpl[j][m], b = RepairSample<KIND>::cvt(x[m]);
+          ar += a.x * b.x - a.y * b.y;
+          ai += a.x * b.y + a.y * b.x;
+        }
+        const float fr = (float)ar, fi = (float)ai;                      // xc is complex<float>
+        o = (float)((double)o + ((double)fr * (double)fr + (double)fi * (double)fi));
+      }
+      o = __fdiv_rn(o, (float)geo.n_comb);
+    }
+    out[(size_t)idx * LCS_TG + j] = o;
+  }
+}
+
 // lcs_foe_contend, first kernel: which positions does this rank contend for?  The owner of the global winner where its own
 // runner-up lies within the distance of the maximum; any other rank where its best does.  words2 starts at -1 (below every word).
 __global__ __launch_bounds__(256) void k_foe_flag(const long long *__restrict__ words, const float *__restrict__ pow32, const float *__restrict__ second32,
@@ -1048,7 +1120,10 @@ int lcs_ensure_btab(lcs_ctx *c) {
 int lcs_launch_xcorr(lcs_ctx *c, int n_buf, const XcGeom &geo, bool want_incoh, bool time_it) {
   hipLaunchKernelGGL(k_prep_tables, dim3(n_buf, 4), dim3(256), 0, c->stream, c->params, c->fset, c->d_pss_td, c->tmpl,
                      c->start, c->smin, c->kp2, c->n_fix, geo);
-  if (c->use_i8) {
+  // one combining window: every element in the reference's own arithmetic (k_single_exact); no operand tables needed
+  const bool exact_single = geo.n_comb == 1;
+  if (exact_single) ;
+  else if (c->use_i8) {
     int rc_ = lcs_launch_fill_brow_i8(c, n_buf, geo);
     if (rc_) return rc_;
   } else if (c->use_f16) {
@@ -1101,7 +1176,16 @@ int lcs_launch_xcorr(lcs_ctx *c, int n_buf, const XcGeom &geo, bool want_incoh, 
   int launches = 0;
   c->last_xc_ops = 0;
   c->last_xc_kernel = "k_xcorr_mfma_blk<4,4,32>";
-  for (int part = 0; part < 2; ++part) {
+  if (exact_single) {
+    const CapSrc cs = lcs_cap_src(c, geo.n_cap);
+    const dim3 grid(EXS_CHUNKS, geo.G, n_buf);
+    if (cs.c8) hipLaunchKernelGGL(k_single_exact<0>, grid, dim3(256), 0, sxc, cs, c->params, c->fset, c->d_pss_td, c->start, c->single, geo);
+    else if (cs.c32) hipLaunchKernelGGL(k_single_exact<1>, grid, dim3(256), 0, sxc, cs, c->params, c->fset, c->d_pss_td, c->start, c->single, geo);
+    else hipLaunchKernelGGL(k_single_exact<2>, grid, dim3(256), 0, sxc, cs, c->params, c->fset, c->d_pss_td, c->start, c->single, geo);
+    c->last_xc_kernel = "k_single_exact";
+    launches = 1;
+  }
+  for (int part = 0; part < 2 && !exact_single; ++part) {
     const int s0 = part ? n8 : 0, ns = part ? n_buf - n8 : n8;
     if (ns <= 0) continue;
     if (c->use_i8) {                                                            // u8 sources: int8 three-digit kernel

@@ -175,16 +175,60 @@ def test_xcorr_pss_edge_grids(S, capbuf_0000):
 
 
 def test_xcorr_pss_minimum_length_buffer(S, capbuf_0000):
+    """A buffer with exactly ONE combining window: nothing averages over windows, xc_incoherent_single is |xc|^2 of one 137-tap sum
+    and a few hundred of its elements lie 40 dB and more below the mean -- where fixed-point templates (rounds 1-5: up to 1e-3
+    relative there, a documented exception) cannot follow the reference's floating-point ones.  Since round 6 such buffers take
+    k_single_exact: every element in the reference's own arithmetic (fp64 sums in tap order stored as complex<float>,
+    src/searcher.cpp:160-169, 299-305).  Every element within 1e-6 (a last-bit difference of a template's sincos may flip one float
+    rounding), the usual bars for the rest."""
     cap, fc = capbuf_0000
     n = 9600 + 136 + 137 + 100            # exactly one combining window
     f = np.array([30e3, 35e3, 40e3])
     r = S.xcorr_pss(cap[:n], f, 2, fc, fc, FS)
     ro = O.xcorr_pss(cap[:n], f, 2, fc, fc, FS)
-    assert r["n_comb_xc"] == 1
-    # With a single window nothing averages the fp32 rounding of one 137-tap dot product: lags whose
-    # correlation nearly cancels (|xc|^2 ~1e-4 of the typical value) carry up to ~1e-4 relative error
-    # (1e-7 of the buffer's largest value).  The 1e-5 bar is stated for full 80 ms buffers.
-    _check_xcorr(r, ro, "one-window buffer", rtol=1e-3)
+    assert r["n_comb_xc"] == 1 and S.last_xcorr_info()[0] == "k_single_exact"
+    _check_xcorr(r, ro, "one-window buffer")
+    err = np.abs(r["single"].astype(np.float64) - ro["single"]) / ro["single"]
+    assert err.max() < 1e-6, err.max()
+    assert ro["single"].min() < 1e-4 * ro["single"].mean()          # the deep nulls are really there
+
+
+@pytest.mark.parametrize("n_win", [2, 3])
+def test_xcorr_pss_two_and_three_window_buffers(S, capbuf_0000, n_win):
+    """The shortest buffers that DO take the matrix-core kernel: with two windows the sum of two exponentials leaves no element
+    deep enough in a null for the fixed-point templates' floor to show -- every element within the usual 1e-5."""
+    cap, fc = capbuf_0000
+    n = n_win * 9600 + 136 + 100 + 41
+    f = np.array([30e3, 35e3, 40e3])
+    r = S.xcorr_pss(cap[:n], f, 2, fc, fc, FS)
+    ro = O.xcorr_pss(cap[:n], f, 2, fc, fc, FS)
+    assert r["n_comb_xc"] == n_win and S.last_xcorr_info()[0] == "k_xcorr_i8x3"
+    _check_xcorr(r, ro, f"{n_win}-window buffer")
+
+
+def test_one_window_buffers_in_batches(S):
+    """The same through the batch entry point, as raw u8 I/Q and as complex<float>, on the CLI's 37-hypothesis grid (7 template
+    groups, the last one partly empty), two buffers with different carriers: every element of single / pow / frq / Z_th1."""
+    import torch
+    pkg = load_pkg()
+    n = 9600 + 136 + 137 + 100 + 57
+    f = f_search_set_for(739e6, 120)
+    fcs = np.array([739e6, 739.3e6])
+    bufs = [pkg.synth.make_capbuf(60 + k, fcs[k], [dict(n_id_1=11 + k, n_id_2=k, f_off=(-1) ** k * 52e3)], 3.0)[0][:2 * n] for k in range(2)]
+    d8 = torch.from_numpy(np.ascontiguousarray(np.stack(bufs))).cuda()
+    d32 = torch.from_numpy(np.stack([iq_u8_to_capbuf(b).astype(np.complex64) for b in bufs])).cuda()
+    for fmt, dptr in ((pkg.FMT_IQ_U8, d8.data_ptr()), (pkg.FMT_C64, d32.data_ptr())):
+        S.search_batch(dptr, fmt, 2, n, f, fcs, fcs, FS, pkg.STAGE_PSS, max_cells_per_buf=64)
+        assert S.last_xcorr_info()[0] == "k_single_exact"
+        for b in range(2):
+            ro = O.xcorr_pss(iq_u8_to_capbuf(bufs[b]), f, 2, fcs[b], fcs[b], FS)
+            r = S.batch_readback(b, f.size)
+            err = np.abs(r["single"].astype(np.float64) - ro["single"]) / ro["single"]
+            assert err.max() < 1e-6, (fmt, b, err.max())
+            _check_frq(r["frq"], ro, f"one-window batch buffer {b}")
+            assert (np.abs(r["pow"] - ro["pow"]) / ro["pow"]).max() < 1e-6
+            zo = O.z_th1(ro["sp_incoherent"], ro["n_comb_xc"])
+            assert (np.abs(r["z_th1"] - zo) / zo).max() < 1e-10
 
 
 def test_debug_outputs_xc_and_sp(S, capbuf_0000):
