@@ -445,6 +445,36 @@ def track_bench(pkg, args, rank, world, local_rank, dist):
                                "the PCIe copy is most of it); ms_per_call_symbols_in_hbm: the same call on symbols already resident in HBM.  The three carried "
                                "frames are not transformed again (their frequency-domain rows stay on the device) and no frame offset is decoded twice"}
         ctxs[0].track_stream_reset()
+    # the producer thread's symbol extraction on the device (lcs_track_cut, round 6): the 80 ms capture as the dongle's BYTES in HBM
+    # (0.3 MB), the symbols of all C tracked cells cut into [C][n_sym][128] complex<double> there -- checked against the host-cut
+    # symbols the timed blocks ran on -- and the block on them
+    cutter = None
+    if hasattr(pkg.capi.load(), "lcs_track_cut") and not args.no_dense:
+        d_iq = torch.from_numpy(np.ascontiguousarray(g["iq_u8"])).to(torch.device("cuda", dev_i))
+        d_cut = torch.empty((C, n_sym, 128), dtype=torch.complex128, device=torch.device("cuda", dev_i))
+        cps = [int(c.cp_type) for c in cells]
+        args_cut = (d_iq.data_ptr(), pkg.FMT_IQ_U8, cap.size, cps, ftv[:, 0], fov[:, 0], fc, fc, FS, n_sym, d_cut.data_ptr())
+        late_d, n_cut = ctxs[0].track_cut(*args_cut)
+        same = bool(np.all(n_cut == n_sym) and np.array_equal(late_d, late) and torch.equal(d_cut, d_td))
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(10):
+            ctxs[0].track_cut(*args_cut)
+        torch.cuda.synchronize()
+        dtc_ = (time.perf_counter() - t1) / 10
+        t1 = time.perf_counter()
+        for _ in range(10):
+            lt_, _n = ctxs[0].track_cut(*args_cut)
+            ctxs[0].track_block(cells, None, fov, ftv, lt_, fc, fc, FS, want_syms=False, want_ce=False, td_device_ptr=d_cut.data_ptr(), n_sym=n_sym, out=outs[0])
+        torch.cuda.synchronize()
+        dte_ = (time.perf_counter() - t1) / 10
+        cutter = {"ms_per_block": 1e3 * dtc_, "cut_plus_block_ms": 1e3 * dte_, "symbols_per_s_cut_plus_block": C * n_sym / dte_,
+                  "identical_to_host_cut": same, "capture_bytes_in_hbm": int(d_iq.numel()), "symbols_bytes_written": int(d_cut.numel() * 16),
+                  "note": "lcs_track_cut: one thread per (cell, symbol) locates the capture's first sample in closed form (the host walks the "
+                          "samples one by one), one wave per symbol converts and copies its 128 samples; one context, one thread, the "
+                          "call synchronous (late / n_cut come back to the host)"}
+        if not same:
+            sys.stderr.write("bench.py: lcs_track_cut's symbols differ from the host cutter's\n")
     if rank == 0:
         value = world * C * n_sym * args.steps / dt
         out = {"metric": "OFDM symbols/s, LTE-Tracker per-symbol pipeline (get_fd + CRS channel estimate + FOE/TOE + MIB re-decode)",
@@ -453,7 +483,7 @@ def track_bench(pkg, args, rank, world, local_rank, dist):
                "data": "symbols cut from tests/golden/capbuf_0000 (cells 277, 271), tiled over the tracked cells",
                "config": {"workload": f"SURVEY 8 f4: {C} tracked cells x {n_sym} OFDM symbols (70 ms) per step, time-domain symbols resident in HBM",
                           "tracked_cells": C, "symbols_per_block": n_sym, "gpu_ms_per_block": alone_ms,
-                          "gpu_ms_per_block_in_the_pipelined_run": pipelined_ms, "contexts_in_flight": depth, "stream_form": stream_form,
+                          "gpu_ms_per_block_in_the_pipelined_run": pipelined_ms, "contexts_in_flight": depth, "stream_form": stream_form, "cutter": cutter,
                           "mib_locks_per_block": locks, "cells_in_real_time": value / world / 14000.0,
                           "timed_loop": ("host/TrackBench (C++): one host thread per context" if cxx else "Python threads (host/TrackBench not built)"),
                           "cxx_driver": cxx, "python_loop_symbols_per_s": python_rate,

@@ -7,8 +7,10 @@
 // ref src/tracker_thread.cpp:823-1068).  The three slow loops those measurements feed -- global frequency offset, frame
 // timing, MIB lock -- are the scalar recurrences of lcs::track (include/searcher_amd.h).
 //
-//   TrackCells [-g gpu] [-b symbols_per_block] [-p ppm] <capbuf_0000.it>
+//   TrackCells [-g gpu] [-b symbols_per_block] [-p ppm] [-D] <capbuf_0000.it>
 // prints one line per (block, cell): symbols consumed, frequency offset, frame timing, MIB lock state.
+// -D: the symbols are cut ON THE DEVICE (lcs_track_cut: the capture is uploaded once, the symbols of every cell stay in HBM and
+// lcs_track_stream_block reads them there); the whole stream then goes through as ONE block.
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -68,14 +70,16 @@ void cut_symbols(const std::vector<std::complex<double> > &cap, double fc_reques
 int main(int argc, char **argv) {
   int gpu = -1, block = 140;
   double ppm = 120.0;
+  bool device_cut = false;
   std::string file;
   for (int i = 1; i < argc; ++i) {
     if (!std::strcmp(argv[i], "-g") && i + 1 < argc) gpu = std::atoi(argv[++i]);
     else if (!std::strcmp(argv[i], "-b") && i + 1 < argc) block = std::atoi(argv[++i]);
     else if (!std::strcmp(argv[i], "-p") && i + 1 < argc) ppm = std::atof(argv[++i]);
+    else if (!std::strcmp(argv[i], "-D")) device_cut = true;
     else file = argv[i];
   }
-  if (file.empty() || block < 1) { std::fprintf(stderr, "usage: TrackCells [-g gpu] [-b symbols_per_block] [-p ppm] capbuf_0000.it\n"); return 2; }
+  if (file.empty() || block < 1) { std::fprintf(stderr, "usage: TrackCells [-g gpu] [-b symbols_per_block] [-p ppm] [-D] capbuf_0000.it\n"); return 2; }
   try {
     std::map<std::string, itfile::Var> vars = itfile::read_all(file);
     const std::vector<std::complex<double> > cap = itfile::get_dcvec(vars, "capbuf");
@@ -107,6 +111,29 @@ int main(int argc, char **argv) {
     int n_total = feeds[0].n;
     for (size_t i = 1; i < feeds.size(); ++i) n_total = std::min(n_total, feeds[i].n);
     const int C = (int)feeds.size();
+    // -D: the same symbols cut on the device.  The capture goes up once (complex<double>, as the file holds it); a first call finds
+    // how many symbols every cell has in the buffer, the second leaves [cell][n_total][128] in HBM for ONE block over the whole stream.
+    void *d_cap = 0, *d_td = 0;
+    std::vector<double> dev_late;
+    if (device_cut) {
+      std::vector<int32_t> cp(C), n_cut;
+      std::vector<double> ft(C), fo(C);
+      for (int i = 0; i < C; ++i) { cp[i] = feeds[i].cell.cp_type; ft[i] = feeds[i].frame_timing; fo[i] = feeds[i].frequency_offset; }
+      const size_t cap_bytes = cap.size() * sizeof(std::complex<double>);
+      const int probe = (int)(cap.size() / 137 + 2);
+      if (lcs_device_alloc(searcher.handle(), cap_bytes, &d_cap) != LCS_OK || lcs_device_upload(searcher.handle(), d_cap, cap.data(), cap_bytes) != LCS_OK ||
+          lcs_device_alloc(searcher.handle(), (size_t)C * probe * 128 * sizeof(std::complex<double>), &d_td) != LCS_OK)
+        throw lcs::error(std::string("liblcs_amd: ") + lcs_last_error(searcher.handle()));
+      searcher.track_cut(d_cap, LCS_FMT_C128, (uint32_t)cap.size(), cp, ft, fo, fc, fc, fs, probe, d_td, dev_late, n_cut);
+      for (int i = 0; i < C; ++i)
+        if (n_cut[i] != feeds[i].n) { std::fprintf(stderr, "Error: device cutter found %d symbols of cell %d, host cutter %d\n", n_cut[i], i, feeds[i].n); return 3; }
+      searcher.track_cut(d_cap, LCS_FMT_C128, (uint32_t)cap.size(), cp, ft, fo, fc, fc, fs, n_total, d_td, dev_late, n_cut);
+      for (int i = 0; i < C; ++i)
+        for (int k = 0; k < n_total; ++k)
+          if (dev_late[(size_t)i * n_total + k] != feeds[i].late[k]) { std::fprintf(stderr, "Error: device cutter: late differs at symbol %d of cell %d\n", k, i); return 3; }
+      block = n_total;
+      std::printf("device cutter: %d symbols of %d cell(s) in HBM\n", n_total, C);
+    }
     std::printf("tracking %d cell(s), %d OFDM symbols each, %d per block\n", C, n_total, block);
 
     std::vector<lcs_track_cell> tc(C);
@@ -131,7 +158,7 @@ int main(int argc, char **argv) {
         std::copy(feeds[i].td.begin() + (size_t)s0 * 128, feeds[i].td.begin() + (size_t)(s0 + n) * 128, td.begin() + (size_t)i * n * 128);
         for (int k = 0; k < n; ++k) { fo[(size_t)i * n + k] = feeds[i].frequency_offset; ft[(size_t)i * n + k] = feeds[i].frame_timing; lt[(size_t)i * n + k] = feeds[i].late[s0 + k]; }
       }
-      searcher.track_stream_block(tc, n, td.data(), fo.data(), ft.data(), lt.data(), fc, fc, fs, rows);
+      searcher.track_stream_block(tc, n, device_cut ? static_cast<const std::complex<double> *>(d_td) : td.data(), fo.data(), ft.data(), lt.data(), fc, fc, fs, rows);
       for (int i = 0; i < C; ++i) {
         // port 0's filtered reference symbols drive the two loops (every port measures the same offsets; the reference
         // runs the recurrences in symbol order over the ports it tracks, port 0 first)
@@ -144,6 +171,8 @@ int main(int argc, char **argv) {
                     lock[i].synchronized ? "LOCKED" : "searching");
       }
     }
+    if (d_td) (void)lcs_device_free(searcher.handle(), d_td);
+    if (d_cap) (void)lcs_device_free(searcher.handle(), d_cap);
   } catch (const std::exception &e) {
     std::fprintf(stderr, "Error: %s\n", e.what());
     return 2;

@@ -20,7 +20,7 @@ from . import synth
 from . import sweep
 from . import itfile
 from . import tracker
-from .capi import LcsCell, LcsTrackCell, FMT_C64, FMT_IQ_U8, STAGE_PSS, STAGE_FULL, MAX_PEAKS
+from .capi import LcsCell, LcsTrackCell, FMT_C64, FMT_IQ_U8, FMT_C128, STAGE_PSS, STAGE_FULL, MAX_PEAKS
 
 FS_LTE = 30720000.0        # include/constants.h:32
 DS_COMB_ARM = 2            # src/CellSearch.cpp:484
@@ -357,6 +357,24 @@ class Searcher:
         out["bpo"] = np.array([tc[i].bulk_phase_offset for i in range(n_cells)])
         out["gpu_ms"] = ms.value
         return out
+
+    def track_cut(self, d_capbuf_ptr, fmt, n_cap, cp_types, frame_timing, freq_off, fc_requested, fc_programmed, fs_programmed, n_sym,
+                  d_td_ptr):
+        """The producer thread's symbol extraction on the device (lcs_track_cut, src/producer_thread.cpp:96-131, 196-246): the
+        OFDM symbols of len(cp_types) tracked cells cut out of ONE capture buffer resident in HBM (fmt FMT_IQ_U8 / FMT_C64 /
+        FMT_C128 at device pointer d_capbuf_ptr) into the device array d_td_ptr [n_cells][n_sym][128] complex128 -- what
+        track_block takes as td_device_ptr.  Returns (late [n_cells][n_sym], n_cut [n_cells])."""
+        n_cells = len(cp_types)
+        cp = np.ascontiguousarray(cp_types, np.int32)
+        ft = np.ascontiguousarray(frame_timing, np.float64).reshape(n_cells)
+        fo = np.ascontiguousarray(freq_off, np.float64).reshape(n_cells)
+        late = np.zeros((n_cells, n_sym), np.float64)
+        n_cut = np.zeros(n_cells, np.int32)
+        rc = self._lib.lcs_track_cut(self._h, C.c_void_p(d_capbuf_ptr), int(fmt), int(n_cap), n_cells, _ip(cp), _dp(ft), _dp(fo),
+                                     float(fc_requested), float(fc_programmed), float(fs_programmed), int(n_sym), C.c_void_p(d_td_ptr),
+                                     _dp(late), _ip(n_cut))
+        self._chk(rc, "lcs_track_cut")
+        return late, n_cut
 
     def track_stream_block(self, cells, td, freq_off, frame_timing, late, fc_requested, fc_programmed, fs_programmed, want_stats=False,
                            want_syms=True, want_ce=True, td_device_ptr=None):

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblcs_amd.so")
 
 LCS_OK = 0
-FMT_C64, FMT_IQ_U8 = 0, 1
+FMT_C64, FMT_IQ_U8, FMT_C128 = 0, 1, 2      # FMT_C128: lcs_track_cut only
 STAGE_PSS, STAGE_FULL = 1, 3
 MAX_PEAKS = 104            # LCS_MAX_PEAKS: the longest list peak_search can return (include/lcs.h)
 ERRORS = {-1: "LCS_ERR_NO_DEVICE", -2: "LCS_ERR_BAD_ARG", -3: "LCS_ERR_HIP", -4: "LCS_ERR_OVERFLOW", -5: "LCS_ERR_NOMEM"}
@@ -66,7 +66,7 @@ EXPORTS = [
     "lcs_xcorr_pss", "lcs_peak_search", "lcs_sss_detect", "lcs_pss_sss_foe", "lcs_extract_tfg", "lcs_tfoec",
     "lcs_decode_mib", "lcs_chan_est", "lcs_search_capbuf", "lcs_search_batch_dev", "lcs_search_batch_host", "lcs_batch_enqueue",
     "lcs_batch_collect", "lcs_batch_readback", "lcs_batch_enqueue_host", "lcs_host_alloc", "lcs_host_free", "lcs_device_alloc", "lcs_device_free", "lcs_device_upload", "lcs_device_count",
-    "lcs_foe_partial", "lcs_foe_finish", "lcs_foe_contend", "lcs_foe_resolve", "lcs_track_block", "lcs_track_stats", "lcs_track_stream_block", "lcs_track_stream_reset", "lcs_stream_open", "lcs_stream_push", "lcs_stream_collect", "lcs_stream_close",
+    "lcs_foe_partial", "lcs_foe_finish", "lcs_foe_contend", "lcs_foe_resolve", "lcs_track_block", "lcs_track_stats", "lcs_track_stream_block", "lcs_track_stream_reset", "lcs_track_cut", "lcs_stream_open", "lcs_stream_push", "lcs_stream_collect", "lcs_stream_close",
     "lcs_last_xcorr_ms", "lcs_last_xcorr_info", "lcs_last_frq_repairs", "lcs_last_frq_repair_stats", "lcs_last_batch_stats", "lcs_last_collect_host_us", "lcs_stream", "lcs_sync", "lcs_table_pss_td", "lcs_table_pss_fd", "lcs_table_sss_fd",
     "lcs_table_lte_pn", "lcs_chi2cdf_inv",
 ]
@@ -140,6 +140,8 @@ def load() -> C.CDLL:
     L.lcs_track_stream_block.argtypes = [vp, C.POINTER(LcsTrackCell), C.c_int, C.c_int, vp, dp, dp, dp, C.c_double, C.c_double, C.c_double,
                                          dp, dp, dp, C.c_int, i64p, ip, dp, dp, dp, C.c_int, ip, ip, C.POINTER(C.c_uint64), C.c_int, i64p, ip]
     L.lcs_track_stream_reset.argtypes = [vp]
+    if hasattr(L, "lcs_track_cut"):
+        L.lcs_track_cut.argtypes = [vp, vp, C.c_int, C.c_uint32, C.c_int, ip, dp, dp, C.c_double, C.c_double, C.c_double, C.c_int, vp, dp, ip]
     L.lcs_stream_open.argtypes = [vp, C.c_int, C.c_uint32, C.c_double, C.c_double, C.c_double]
     L.lcs_stream_push.argtypes = [vp, vp, C.c_double, C.POINTER(C.c_int16), C.c_int]
     L.lcs_stream_collect.argtypes = [vp, cp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_float)]

@@ -266,6 +266,10 @@ struct lcs_ctx {
   void *trk_stream = nullptr;        // carried state of lcs_track_stream_block (tracker.hip)
   void *trk_hpin = nullptr;          // reusable host staging block of lcs_track_block (malloc): metadata up, measurement tables down
   size_t trk_hpin_bytes = 0;
+  int *trk_cut_hit = nullptr;       // lcs_track_cut: first sample of every symbol [cells][symbols], per-cell flag / count behind it
+  double *trk_cut_meta = nullptr;   // lcs_track_cut: late [cells][symbols], then frame_timing, freq_off [cells]
+  size_t trk_cut_cap = 0;           // symbols x cells the two hold
+  int trk_cut_cells_cap = 0;
   // results of a batch, compacted on the device (k_pack_results): [8 ints header][n_buf counts][records]; h_res = its page-locked mirror
   void *res_pack = nullptr, *h_res = nullptr;
   size_t res_pack_bytes = 0;

@@ -595,6 +595,74 @@ __global__ __launch_bounds__(64) void k_trk_sync(const lcs_track_cell *__restric
   if (sync) { double *o = sync + ((size_t)cell * max_hf + k) * 4; o[0] = tp; o[1] = tp - np / 13; o[2] = np; o[3] = np_blank; }
 }
 
+// ----------------------------------------------------------------------------------- the producer thread's symbol cutter
+// LTE-Tracker's producer thread (src/producer_thread.cpp:96-131) stamps every sample of the dongle's stream with a time on the
+// cell-independent 1.92 MHz time base -- sample n of a buffer whose first sample has timestamp 0: WRAP(n step, 0, 19200), step =
+// (FS_LTE / 16) / (fs_programmed k_factor) -- and, per tracked cell (:196-246), starts a 128-sample capture at the first sample
+// at or after the end of the previous capture whose
+//     tdiff = WRAP(timestamp - (frame_timing + target), -9600, 9600)   satisfies   |tdiff| < 0.5  or  0 < tdiff < 3      (:203-213)
+// with target = 10 (normal CP) / 32 (extended) for slot 0 symbol 0 and advancing by 137 / 138 / 160 per symbol (:236-241);
+// tdiff at the hit travels with the symbol as `late`.  The host cutters (tracker.py cut_symbols, host/TrackCells.cpp) walk the
+// samples one by one.  Here: the predicate is a window of ~3.5 samples per symbol period whose position is known in closed form,
+// so one thread per (cell, symbol) evaluates the SAME double expressions on the five candidates around the window's start and
+// takes the first that passes -- equal to the walk as long as every capture ends before the next window begins, which the kernel
+// checks (hit_k >= hit_(k-1) + 128 and the sample before the hit fails the predicate); a cell that violates it (a sample rate far
+// off 1.92 MHz) is walked by one thread exactly as the host does (k_trk_cut_walk).  Then one wave per symbol copies its 128 samples.
+// (TrkCutCell, trk_cut_cell / _target / _pass / _first / _symbol / _walk: lte_device.h -- __host__ __device__, pinned on the CPU by
+// tests/test_track_cut_host.py against the sample-by-sample walk and tracker.py's cutter)
+// hit[cell][k], late[cell][k]; flags[cell] |= 1 when the closed form's premise does not hold for the cell
+__global__ __launch_bounds__(256) void k_trk_cut_hits(const int *__restrict__ cp_type, const double *__restrict__ ftv, const double *__restrict__ fov,
+                                                      double fc_req, double fc_prog, double fs_prog, uint32_t n_cap, int n_sym,
+                                                      int *__restrict__ hit, double *__restrict__ late, int *__restrict__ flags) {
+  const int cell = blockIdx.y, k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n_sym) return;
+  const TrkCutCell q = trk_cut_cell(cp_type[cell], ftv[cell], fov[cell], fc_req, fc_prog, fs_prog);
+  double l0, lt;
+  const long h0 = trk_cut_first(q, n_cap, &l0);
+  long h;
+  if (!trk_cut_symbol(q, n_cap, k, h0, l0, &h, &lt)) atomicOr(&flags[cell], 1);
+  hit[(size_t)cell * n_sym + k] = (int)h;
+  late[(size_t)cell * n_sym + k] = lt;
+}
+// The sample-by-sample walk of the host cutters for the cells k_trk_cut_hits flagged (none at any sample rate a dongle produces),
+// and the count of symbols found: one thread per cell.
+__global__ __launch_bounds__(64) void k_trk_cut_walk(const int *__restrict__ cp_type, const double *__restrict__ ftv, const double *__restrict__ fov,
+                                                     double fc_req, double fc_prog, double fs_prog, uint32_t n_cap, int n_sym, int n_cells,
+                                                     int *__restrict__ hit, double *__restrict__ late, int *__restrict__ flags, int *__restrict__ n_cut) {
+  const int cell = blockIdx.x * blockDim.x + threadIdx.x;
+  if (cell >= n_cells) return;
+  int *h = hit + (size_t)cell * n_sym;
+  double *lt = late + (size_t)cell * n_sym;
+  if (flags[cell] & 1) (void)trk_cut_walk(trk_cut_cell(cp_type[cell], ftv[cell], fov[cell], fc_req, fc_prog, fs_prog), n_cap, n_sym, h, lt);
+  int n = 0;
+  while (n < n_sym && h[n] >= 0) ++n;
+  for (int k = n; k < n_sym; ++k) { h[k] = -1; lt[k] = 0.0; }      // nothing behind the first symbol that does not fit
+  n_cut[cell] = n;
+}
+// one wave per (symbol, cell): 128 samples -> complex<double>; FMT 1: the dongle's bytes, (u8 - 127) / 128 (src/producer_thread.cpp:121-124)
+template <int FMT>
+__global__ __launch_bounds__(256) void k_trk_cut_copy(const void *__restrict__ cap, int n_sym, const int *__restrict__ hit, double2 *__restrict__ td) {
+  const int cell = blockIdx.y, k = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (k >= n_sym) return;
+  const int h = hit[(size_t)cell * n_sym + k];
+  double2 *out = td + ((size_t)cell * n_sym + k) * 128;
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int m = lane + 64 * u;
+    double2 v = make_double2(0.0, 0.0);
+    if (h >= 0) {
+      if (FMT == LCS_FMT_IQ_U8) {
+        const uchar2 b = reinterpret_cast<const uchar2 *>(cap)[(size_t)h + m];
+        v = make_double2(((double)b.x - 127.0) / 128.0, ((double)b.y - 127.0) / 128.0);
+      } else if (FMT == LCS_FMT_C64) {
+        const float2 f = reinterpret_cast<const float2 *>(cap)[(size_t)h + m];
+        v = make_double2((double)f.x, (double)f.y);
+      } else v = reinterpret_cast<const double2 *>(cap)[(size_t)h + m];
+    }
+    out[m] = v;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------------ host
 namespace {
 // Where lcs_track_block leaves its intermediate results in the block workspace (lcs_track_stats reads them back)
@@ -767,6 +835,50 @@ extern "C" int lcs_track_block(lcs_ctx *c, lcs_track_cell *cells, int n_cells, i
   HIPCHK(c, hipSetDevice(c->device));
   return trk_block(c, cells, n_cells, n_sym, td, td_on_device ? 1 : 0, freq_off, frame_timing, late, fc_requested, fc_programmed, fs_programmed, syms, ce,
                    ce_pw, ce_upto, meas, max_rs, n_meas, mib_ok, mib_bits, max_off, gpu_ms, nullptr);
+}
+
+// The producer thread's symbol extraction (see k_trk_cut_hits): d_capbuf and d_td are DEVICE memory.
+extern "C" int lcs_track_cut(lcs_ctx *c, const void *d_capbuf, int fmt, uint32_t n_cap, int n_cells, const int32_t *cp_type,
+                             const double *frame_timing, const double *freq_off, double fc_requested, double fc_programmed,
+                             double fs_programmed, int n_sym, void *d_td, double *late, int32_t *n_cut) {
+  if (!c) return LCS_ERR_BAD_ARG;
+  if (!d_capbuf || !cp_type || !frame_timing || !freq_off || !d_td || !n_cut || n_cells < 1 || n_sym < 1 || n_cap < 128 ||
+      (fmt != LCS_FMT_C64 && fmt != LCS_FMT_IQ_U8 && fmt != LCS_FMT_C128)) { c->err = "bad argument"; return LCS_ERR_BAD_ARG; }
+  for (int i = 0; i < n_cells; ++i) {
+    if (cp_type[i] != LCS_CP_NORMAL && cp_type[i] != LCS_CP_EXTENDED) { c->err = "the cutter needs a known cp_type per cell"; return LCS_ERR_BAD_ARG; }
+    const double kf = (fc_requested - freq_off[i]) / fc_programmed;
+    if (!(fs_programmed * kf > 0) || !std::isfinite(frame_timing[i])) { c->err = "the cutter needs a positive sample rate and a finite frame_timing"; return LCS_ERR_BAD_ARG; }
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t N = (size_t)n_cells * n_sym;
+  if (N > c->trk_cut_cap || n_cells > c->trk_cut_cells_cap) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const size_t capN = std::max(N, c->trk_cut_cap);
+    const int capC = std::max(n_cells, c->trk_cut_cells_cap);
+    c->trk_cut_cap = 0; c->trk_cut_cells_cap = 0;
+    int rc;
+    if ((rc = trk_alloc(c, &c->trk_cut_hit, capN + 3 * (size_t)capC)) || (rc = trk_alloc(c, &c->trk_cut_meta, capN + 2 * (size_t)capC))) return rc;
+    c->trk_cut_cap = capN; c->trk_cut_cells_cap = capC;
+  }
+  int *d_hit = c->trk_cut_hit, *d_flags = d_hit + N, *d_ncut = d_flags + n_cells, *d_cp = d_ncut + n_cells;
+  double *d_late = c->trk_cut_meta, *d_ft = d_late + N, *d_fo = d_ft + n_cells;
+  HIPCHK(c, hipMemsetAsync(d_flags, 0, sizeof(int) * n_cells, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d_cp, cp_type, sizeof(int) * n_cells, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d_ft, frame_timing, sizeof(double) * n_cells, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d_fo, freq_off, sizeof(double) * n_cells, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_trk_cut_hits, dim3((n_sym + 255) / 256, n_cells), dim3(256), 0, c->stream, d_cp, d_ft, d_fo, fc_requested, fc_programmed,
+                     fs_programmed, n_cap, n_sym, d_hit, d_late, d_flags);
+  hipLaunchKernelGGL(k_trk_cut_walk, dim3((n_cells + 63) / 64), dim3(64), 0, c->stream, d_cp, d_ft, d_fo, fc_requested, fc_programmed,
+                     fs_programmed, n_cap, n_sym, n_cells, d_hit, d_late, d_flags, d_ncut);
+  const dim3 grid((n_sym + 3) / 4, n_cells);
+  if (fmt == LCS_FMT_IQ_U8) hipLaunchKernelGGL(k_trk_cut_copy<LCS_FMT_IQ_U8>, grid, dim3(256), 0, c->stream, d_capbuf, n_sym, d_hit, (double2 *)d_td);
+  else if (fmt == LCS_FMT_C64) hipLaunchKernelGGL(k_trk_cut_copy<LCS_FMT_C64>, grid, dim3(256), 0, c->stream, d_capbuf, n_sym, d_hit, (double2 *)d_td);
+  else hipLaunchKernelGGL(k_trk_cut_copy<LCS_FMT_C128>, grid, dim3(256), 0, c->stream, d_capbuf, n_sym, d_hit, (double2 *)d_td);
+  HIPCHK(c, hipGetLastError());
+  if (late) HIPCHK(c, hipMemcpyAsync(late, d_late, sizeof(double) * N, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(n_cut, d_ncut, sizeof(int) * n_cells, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return LCS_OK;
 }
 
 // Statistics of the block the last lcs_track_block call on this context processed (its workspace is read, not recomputed).

@@ -300,6 +300,15 @@ def test_track_cells_consumer_loop(tmp_path):
         assert int(l[10]) == w[4] and abs(float(l[12]) - w[5]) < 0.01 and l[13] == w[6]
     assert want[-1][6] == "LOCKED" and want[-2][6] == "LOCKED"          # 80 ms hold four full frames from some offset: both cells lock
     assert subprocess.run([exe], capture_output=True, text=True).returncode == 2
+    # -D: the symbols cut ON THE DEVICE (lcs_track_cut through lcs::Searcher::track_cut: the capture uploaded once, [cell][symbol][128]
+    # left in HBM, lcs_track_stream_block reading it there) -- the tool checks symbol counts and every `late` against its host cutter
+    # and then tracks the whole stream as one block: the same lines as the host-cut run with one block
+    one = subprocess.run([exe, "-b", "100000", str(tmp_path / "capbuf_0000.it")], capture_output=True, text=True, timeout=600)
+    dev = subprocess.run([exe, "-D", str(tmp_path / "capbuf_0000.it")], capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0 and dev.returncode == 0, dev.stderr
+    assert f"device cutter: {n_total} symbols of 2 cell(s) in HBM" in dev.stdout
+    sym = lambda out: [l for l in out.splitlines() if l.startswith("symbols ")]
+    assert len(sym(dev.stdout)) == 2 and sym(dev.stdout) == sym(one.stdout)
 
 
 @pytest.mark.gpu

@@ -1,0 +1,96 @@
+"""The producer thread's symbol cutter (lcs_track_cut; src/producer_thread.cpp:96-131, 196-246) pinned on the CPU: the device code
+of lte-cell-scanner_amd/csrc/lte_device.h is __host__ __device__, so the closed form k_trk_cut_hits evaluates (one thread per
+symbol) is compared here -- compiled for the host -- with the sample-by-sample walk on thousands of parameter draws, and the walk
+with lte-cell-scanner_amd/tracker.py's cutter (the definition host/TrackCells.cpp shares).  The GPU leg is
+tests/test_gpu_track_cut.py."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import load_pkg
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "tests", "host", "cut_host.cpp")
+LIB = os.path.join(ROOT, "tests", "host", "libcut_host.so")
+FS, FC = 1.92e6, 739e6
+
+
+@pytest.fixture(scope="module")
+def H():
+    dep = [SRC, os.path.join(ROOT, "lte-cell-scanner_amd", "csrc", "lte_device.h")]
+    if not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in dep):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC",
+                               "-shared", "-I" + os.path.join(ROOT, "include"), "-o", LIB, SRC])
+    h = C.CDLL(LIB)
+    sig = [C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_uint, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double)]
+    h.cut_host_closed.argtypes = sig
+    h.cut_host_walk.argtypes = sig
+    return h
+
+
+def _run(fn, cp, ft, fo, fc, fcp, fsp, n_cap, n_sym):
+    hit = np.zeros(n_sym, np.int32)
+    late = np.zeros(n_sym, np.float64)
+    r = fn(cp, ft, fo, fc, fcp, fsp, n_cap, n_sym, hit.ctypes.data_as(C.POINTER(C.c_int)), late.ctypes.data_as(C.POINTER(C.c_double)))
+    return r, hit, late
+
+
+def test_closed_form_equals_the_walk(H):
+    """3000 draws: frame timings over the whole 10 ms frame (and the values that put symbol 0's window on the buffer's first
+    samples), frequency offsets over +-60 kHz, dongle sample rates within +-200 ppm, both CP types, buffers from one symbol to
+    80 ms: wherever the closed form reports its premise as holding -- always, at such rates -- hits and `late` are the walk's."""
+    rng = np.random.default_rng(11)
+    n_ok = 0
+    for it in range(3000):
+        cp = 1 + int(rng.integers(0, 2))
+        ft = float(rng.uniform(0, 19200)) if it % 5 else float(19200 - (10 if cp == 1 else 32) + rng.uniform(-4, 4)) % 19200.0
+        fo = float(rng.uniform(-60e3, 60e3))
+        fcp = FC * (1 + float(rng.uniform(-3e-5, 3e-5)))
+        fsp = FS * (1 + float(rng.uniform(-2e-4, 2e-4)))
+        n_cap = int(rng.choice([153600, 153600, 40000, 9973, 300, 128, 131]))
+        n_sym = int(rng.choice([980, 1200, 140, 7]))
+        ok, hc, lc = _run(H.cut_host_closed, cp, ft, fo, FC, fcp, fsp, n_cap, n_sym)
+        nw, hw, lw = _run(H.cut_host_walk, cp, ft, fo, FC, fcp, fsp, n_cap, n_sym)
+        assert ok == 1, (it, cp, ft, fo, fsp)
+        assert np.array_equal(hc, hw) and np.array_equal(lc, lw), (it, cp, ft, fo, fsp, n_cap, np.flatnonzero(hc != hw)[:4])
+        assert nw == int(np.count_nonzero(hw >= 0))
+        n_ok += 1
+    assert n_ok == 3000
+
+
+def test_sample_rates_far_from_nominal_are_walked(H):
+    """A sample rate far off 1.92 MHz breaks the closed form's premise (captures would overlap the next window, or the candidate
+    ranges miss): the closed form must SAY so (the kernel then walks the cell), never return a wrong hit silently."""
+    rng = np.random.default_rng(12)
+    flagged = 0
+    for it in range(300):
+        cp = 1 + int(rng.integers(0, 2))
+        ft, fo = float(rng.uniform(0, 19200)), float(rng.uniform(-30e3, 30e3))
+        fsp = FS * float(rng.choice([0.5, 0.8, 0.93, 1.07, 1.25, 2.0]))
+        ok, hc, lc = _run(H.cut_host_closed, cp, ft, fo, FC, FC, fsp, 60000, 200)
+        _, hw, lw = _run(H.cut_host_walk, cp, ft, fo, FC, FC, fsp, 60000, 200)
+        if ok:
+            assert np.array_equal(hc, hw) and np.array_equal(lc, lw), (it, fsp)
+        else:
+            flagged += 1
+    assert flagged >= 100
+
+
+def test_walk_equals_the_python_cutter(H):
+    """The walk (and so the closed form) against lte-cell-scanner_amd/tracker.py cut_symbols: same first samples, same `late`, bit
+    for bit -- the definition the tracker tests and host/TrackCells.cpp share."""
+    pkg = load_pkg()
+    rng = np.random.default_rng(13)
+    cap = (rng.standard_normal(153600) + 1j * rng.standard_normal(153600)).astype(np.complex128)
+    for it in range(12):
+        cp = 1 + it % 2
+        ft, fo = float(rng.uniform(0, 19200)), float(rng.uniform(-40e3, 40e3))
+        fcp, fsp = FC * (1 + 1e-5 * (it % 3)), FS * (1 - 2e-5 * (it % 4))
+        n_sym = 7 * (140 if cp == 1 else 120)
+        td, late, _, _ = pkg.tracker.cut_symbols(cap, ft, cp, fo, FC, fcp, fsp, n_sym)
+        n, hw, lw = _run(H.cut_host_walk, cp, ft, fo, FC, fcp, fsp, cap.size, n_sym)
+        assert n == td.shape[0] and np.array_equal(lw[:n], late)
+        assert all(np.array_equal(td[k], cap[hw[k]:hw[k] + 128]) for k in range(0, n, 37))
