@@ -611,33 +611,49 @@ __global__ __launch_bounds__(64) void k_trk_sync(const lcs_track_cell *__restric
 // (TrkCutCell, trk_cut_cell / _target / _pass / _first / _symbol / _walk: lte_device.h -- __host__ __device__, pinned on the CPU by
 // tests/test_track_cut_host.py against the sample-by-sample walk and tracker.py's cutter)
 // hit[cell][k], late[cell][k]; flags[cell] |= 1 when the closed form's premise does not hold for the cell
-__global__ __launch_bounds__(256) void k_trk_cut_hits(const int *__restrict__ cp_type, const double *__restrict__ ftv, const double *__restrict__ fov,
-                                                      double fc_req, double fc_prog, double fs_prog, uint32_t n_cap, int n_sym,
+// cells [n_cells][3] = (cp_type, frame_timing, freq_off) as doubles: one host -> device copy per call
+__global__ __launch_bounds__(256) void k_trk_cut_hits(const double *__restrict__ cells, double fc_req, double fc_prog, double fs_prog, uint32_t n_cap, int n_sym,
                                                       int *__restrict__ hit, double *__restrict__ late, int *__restrict__ flags) {
   const int cell = blockIdx.y, k = blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ long s_h0;
+  __shared__ double s_l0;
+  const TrkCutCell q = trk_cut_cell((int)cells[3 * cell], cells[3 * cell + 1], cells[3 * cell + 2], fc_req, fc_prog, fs_prog);
+  if (threadIdx.x == 0) { double l; s_h0 = trk_cut_first(q, n_cap, &l); s_l0 = l; }      // symbol 0's capture: once per workgroup
+  __syncthreads();
   if (k >= n_sym) return;
-  const TrkCutCell q = trk_cut_cell(cp_type[cell], ftv[cell], fov[cell], fc_req, fc_prog, fs_prog);
-  double l0, lt;
-  const long h0 = trk_cut_first(q, n_cap, &l0);
+  const long h0 = s_h0;
+  const double l0 = s_l0;
+  double lt;
   long h;
   if (!trk_cut_symbol(q, n_cap, k, h0, l0, &h, &lt)) atomicOr(&flags[cell], 1);
   hit[(size_t)cell * n_sym + k] = (int)h;
   late[(size_t)cell * n_sym + k] = lt;
 }
 // The sample-by-sample walk of the host cutters for the cells k_trk_cut_hits flagged (none at any sample rate a dongle produces),
-// and the count of symbols found: one thread per cell.
-__global__ __launch_bounds__(64) void k_trk_cut_walk(const int *__restrict__ cp_type, const double *__restrict__ ftv, const double *__restrict__ fov,
-                                                     double fc_req, double fc_prog, double fs_prog, uint32_t n_cap, int n_sym, int n_cells,
-                                                     int *__restrict__ hit, double *__restrict__ late, int *__restrict__ flags, int *__restrict__ n_cut) {
-  const int cell = blockIdx.x * blockDim.x + threadIdx.x;
-  if (cell >= n_cells) return;
+// and the count of symbols found: one WAVE per cell (lane 0 walks; the count and the clean-up behind it run over all lanes -- one
+// thread per cell scanning its 980 entries took 160 us).
+__global__ __launch_bounds__(64) void k_trk_cut_walk(const double *__restrict__ cells, double fc_req, double fc_prog, double fs_prog, uint32_t n_cap, int n_sym,
+                                                     int n_cells, int *__restrict__ hit, double *__restrict__ late, int *__restrict__ flags, int *__restrict__ n_cut) {
+  const int cell = blockIdx.x, lane = threadIdx.x;
   int *h = hit + (size_t)cell * n_sym;
   double *lt = late + (size_t)cell * n_sym;
-  if (flags[cell] & 1) (void)trk_cut_walk(trk_cut_cell(cp_type[cell], ftv[cell], fov[cell], fc_req, fc_prog, fs_prog), n_cap, n_sym, h, lt);
-  int n = 0;
-  while (n < n_sym && h[n] >= 0) ++n;
-  for (int k = n; k < n_sym; ++k) { h[k] = -1; lt[k] = 0.0; }      // nothing behind the first symbol that does not fit
-  n_cut[cell] = n;
+  if (flags[cell] & 1) {                                   // (uniform over the wave)
+    if (lane == 0) {
+      (void)trk_cut_walk(trk_cut_cell((int)cells[3 * cell], cells[3 * cell + 1], cells[3 * cell + 2], fc_req, fc_prog, fs_prog), n_cap, n_sym, h, lt);
+      flags[cell] = 0;                                     // the flags start at zero for the next call: no memset per call
+    }
+    __threadfence_block();
+    __builtin_amdgcn_s_barrier();
+  }
+  // the first symbol that was not found / does not fit; nothing behind it counts
+  int n = n_sym;
+  for (int k0 = 0; k0 < n_sym && n == n_sym; k0 += 64) {
+    const int k = k0 + lane;
+    const unsigned long long miss = __ballot(k < n_sym && h[k] < 0);
+    if (miss) n = k0 + (int)__builtin_ctzll(miss);
+  }
+  for (int k = n + lane; k < n_sym; k += 64) { h[k] = -1; lt[k] = 0.0; }
+  if (lane == 0) n_cut[cell] = n;
 }
 // one wave per (symbol, cell): 128 samples -> complex<double>; FMT 1: the dongle's bytes, (u8 - 127) / 128 (src/producer_thread.cpp:121-124)
 template <int FMT>
@@ -857,18 +873,19 @@ extern "C" int lcs_track_cut(lcs_ctx *c, const void *d_capbuf, int fmt, uint32_t
     const int capC = std::max(n_cells, c->trk_cut_cells_cap);
     c->trk_cut_cap = 0; c->trk_cut_cells_cap = 0;
     int rc;
-    if ((rc = trk_alloc(c, &c->trk_cut_hit, capN + 3 * (size_t)capC)) || (rc = trk_alloc(c, &c->trk_cut_meta, capN + 2 * (size_t)capC))) return rc;
+    if ((rc = trk_alloc(c, &c->trk_cut_hit, capN + 2 * (size_t)capC)) || (rc = trk_alloc(c, &c->trk_cut_meta, capN + 3 * (size_t)capC))) return rc;
+    HIPCHK(c, hipMemsetAsync(c->trk_cut_hit, 0, sizeof(int) * (capN + 2 * (size_t)capC), c->stream));      // the per-cell flags start at zero
     c->trk_cut_cap = capN; c->trk_cut_cells_cap = capC;
   }
-  int *d_hit = c->trk_cut_hit, *d_flags = d_hit + N, *d_ncut = d_flags + n_cells, *d_cp = d_ncut + n_cells;
-  double *d_late = c->trk_cut_meta, *d_ft = d_late + N, *d_fo = d_ft + n_cells;
-  HIPCHK(c, hipMemsetAsync(d_flags, 0, sizeof(int) * n_cells, c->stream));
-  HIPCHK(c, hipMemcpyAsync(d_cp, cp_type, sizeof(int) * n_cells, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(d_ft, frame_timing, sizeof(double) * n_cells, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(d_fo, freq_off, sizeof(double) * n_cells, hipMemcpyHostToDevice, c->stream));
-  hipLaunchKernelGGL(k_trk_cut_hits, dim3((n_sym + 255) / 256, n_cells), dim3(256), 0, c->stream, d_cp, d_ft, d_fo, fc_requested, fc_programmed,
+  // hit [cells][symbols], then the per-cell counts and flags at FIXED offsets (the flags keep their zeros from call to call)
+  int *d_hit = c->trk_cut_hit, *d_ncut = d_hit + c->trk_cut_cap, *d_flags = d_ncut + c->trk_cut_cells_cap;
+  double *d_late = c->trk_cut_meta, *d_cells = d_late + c->trk_cut_cap;
+  std::vector<double> h_cells((size_t)3 * n_cells);
+  for (int i = 0; i < n_cells; ++i) { h_cells[3 * i] = (double)cp_type[i]; h_cells[3 * i + 1] = frame_timing[i]; h_cells[3 * i + 2] = freq_off[i]; }
+  HIPCHK(c, hipMemcpyAsync(d_cells, h_cells.data(), sizeof(double) * 3 * n_cells, hipMemcpyHostToDevice, c->stream));      // (pageable: staged before the call returns)
+  hipLaunchKernelGGL(k_trk_cut_hits, dim3((n_sym + 255) / 256, n_cells), dim3(256), 0, c->stream, d_cells, fc_requested, fc_programmed,
                      fs_programmed, n_cap, n_sym, d_hit, d_late, d_flags);
-  hipLaunchKernelGGL(k_trk_cut_walk, dim3((n_cells + 63) / 64), dim3(64), 0, c->stream, d_cp, d_ft, d_fo, fc_requested, fc_programmed,
+  hipLaunchKernelGGL(k_trk_cut_walk, dim3(n_cells), dim3(64), 0, c->stream, d_cells, fc_requested, fc_programmed,
                      fs_programmed, n_cap, n_sym, n_cells, d_hit, d_late, d_flags, d_ncut);
   const dim3 grid((n_sym + 3) / 4, n_cells);
   if (fmt == LCS_FMT_IQ_U8) hipLaunchKernelGGL(k_trk_cut_copy<LCS_FMT_IQ_U8>, grid, dim3(256), 0, c->stream, d_capbuf, n_sym, d_hit, (double2 *)d_td);
