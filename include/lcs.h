@@ -361,23 +361,32 @@ int lcs_track_block(lcs_ctx *ctx, lcs_track_cell *cells, int n_cells, int n_sym,
 
 /* The producer thread's symbol extraction on the device (src/producer_thread.cpp:96-131, 196-246).  LTE-Tracker's producer stamps
  * every sample of the dongle's stream with a time on the cell-independent 1.92 MHz time base -- sample n of a buffer whose first
- * sample has timestamp 0: WRAP(n step, 0, 19200), step = (FS_LTE/16) / (fs_programmed k_factor), k_factor = (fc_requested -
- * freq_off) / fc_programmed (:99, :127-131) -- and, per tracked cell, starts a 128-sample capture at the first sample behind the
- * previous capture whose tdiff = WRAP(timestamp - (frame_timing + target), -9600, 9600) satisfies |tdiff| < 0.5 or 0 < tdiff < 3
- * (:203-213); target = 10 (normal CP) / 32 (extended) for slot 0 symbol 0, advancing by 137 / 138 / 160 per symbol (:236-241);
- * tdiff at that sample is the symbol's `late`.  lcs_track_cut does this for n_cells cells on ONE capture buffer that is already in
- * HBM -- 0.3 MB of dongle bytes per 80 ms instead of 2 KB per symbol and cell over PCIe -- and leaves the symbols where
+ * sample has timestamp ts_first: WRAP(ts_first + n step, 0, 19200), step = (FS_LTE/16) / (fs_programmed k_factor), k_factor =
+ * (fc_requested - freq_off) / fc_programmed (:99, :127-131) -- and, per tracked cell, starts a 128-sample capture at the first sample
+ * behind the previous capture whose tdiff = WRAP(timestamp - (frame_timing + target), -9600, 9600) satisfies |tdiff| < 0.5 or
+ * 0 < tdiff < 3 (:203-213); target = 10 (normal CP) / 32 (extended) for slot 0 symbol 0, advancing by 137 / 138 / 160 per symbol
+ * (:236-241); tdiff at that sample is the symbol's `late`.  lcs_track_cut does this for n_cells cells on ONE capture buffer that is
+ * already in HBM -- 0.3 MB of dongle bytes per 80 ms instead of 2 KB per symbol and cell over PCIe -- and leaves the symbols where
  * lcs_track_block (td_on_device = 1) and lcs_track_stream_block read them:
  *   d_capbuf      DEVICE memory, n_cap samples: LCS_FMT_IQ_U8 (2 bytes per sample, (u8 - 127) / 128 as :121-124), LCS_FMT_C64,
  *                 LCS_FMT_C128
+ *   ts_first      timestamp of the buffer's first sample (0 for a buffer cut from its start)
  *   cp_type, frame_timing, freq_off [n_cells] (host): the values in force while the buffer was recorded
+ *   sym_first, pos_first [n_cells] (host; NULL = zeros): the first symbol to cut, counted from slot 0 symbol 0 of the stream's first
+ *                 frame, and the sample of THIS buffer its search starts at
  *   d_td          DEVICE memory [n_cells][n_sym][128] complex<double>; rows from n_cut[cell] on are zero
- *   late          host [n_cells][n_sym] (may be NULL); n_cut [n_cells]: symbols found before the buffer ends (<= n_sym)
+ *   late          host [n_cells][n_sym] (may be NULL); n_cut [n_cells]: symbols found before the buffer ends (<= n_sym);
+ *                 pos_next [n_cells] (may be NULL): the sample behind the last capture
+ * A stream longer than one buffer: hand over the next buffer starting o samples into this one (o <= the smallest pos_next, so that a
+ * capture the buffer's end cut off is whole in the next one) with ts_first' = WRAP(ts_first + o step, 0, 19200), sym_first' =
+ * sym_first + n_cut, pos_first' = pos_next - o -- the producer's state between two blocks of samples, with the frame_timing and
+ * frequency offset then in force.
  * Sample for sample what the host cutters produce (lte-cell-scanner_amd/tracker.py cut_symbols, host/TrackCells.cpp): the
  * window's position is known in closed form, the predicate itself is evaluated in the same double arithmetic on the candidates. */
-int lcs_track_cut(lcs_ctx *ctx, const void *d_capbuf, int fmt, uint32_t n_cap, int n_cells, const int32_t *cp_type,
-                  const double *frame_timing, const double *freq_off, double fc_requested, double fc_programmed, double fs_programmed,
-                  int n_sym, void *d_td, double *late, int32_t *n_cut);
+int lcs_track_cut(lcs_ctx *ctx, const void *d_capbuf, int fmt, uint32_t n_cap, double ts_first, int n_cells, const int32_t *cp_type,
+                  const double *frame_timing, const double *freq_off, const int64_t *sym_first, const int64_t *pos_first,
+                  double fc_requested, double fc_programmed, double fs_programmed, int n_sym, void *d_td, double *late, int32_t *n_cut,
+                  int64_t *pos_next);
 
 /* Display statistics of the tracker thread for the block the LAST lcs_track_block call on this context processed (same
  * n_cells, n_sym; its symbols and raw reference-signal estimates are read from the workspace, nothing is recomputed):

@@ -308,17 +308,27 @@ class Searcher {
   void track_stream_reset() { check(lcs_track_stream_reset(h_)); }
 
   // The producer thread's symbol extraction on the device (lcs_track_cut; src/producer_thread.cpp:96-131, 196-246): the symbols of
-  // cp_type.size() tracked cells cut out of ONE capture buffer in HBM (d_capbuf: n_cap samples of format fmt) into the device array
-  // d_td [cell][n_sym][128] complex<double> -- what lcs_track_block (td_on_device) / lcs_track_stream_block take.  late [cell][n_sym],
-  // n_cut [cell] = symbols found before the buffer ends.
+  // cp_type.size() tracked cells cut out of ONE capture buffer in HBM (d_capbuf: n_cap samples of format fmt, the first with timestamp
+  // ts_first) into the device array d_td [cell][n_sym][128] complex<double> -- what lcs_track_block (td_on_device) /
+  // lcs_track_stream_block take.  late [cell][n_sym], n_cut [cell] = symbols found before the buffer ends.  state: NULL for a buffer
+  // cut from its start; otherwise in = (sym_first, pos_first) per cell, out = where the next buffer of the stream continues.
+  struct CutState { std::vector<int64_t> sym, pos; };
   void track_cut(const void *d_capbuf, int fmt, uint32_t n_cap, const std::vector<int32_t> &cp_type, const std::vector<double> &frame_timing,
                  const std::vector<double> &freq_off, double fc_requested, double fc_programmed, double fs_programmed, int n_sym, void *d_td,
-                 std::vector<double> &late, std::vector<int32_t> &n_cut) {
+                 std::vector<double> &late, std::vector<int32_t> &n_cut, double ts_first = 0.0, CutState *state = 0) {
     const int n = (int)cp_type.size();
     late.assign((size_t)n * n_sym, 0.0);
     n_cut.assign(n, 0);
-    check(lcs_track_cut(h_, d_capbuf, fmt, n_cap, n, cp_type.data(), frame_timing.data(), freq_off.data(), fc_requested, fc_programmed,
-                        fs_programmed, n_sym, d_td, late.data(), n_cut.data()));
+    std::vector<int64_t> pos_next(n, 0);
+    const bool cont = state && (int)state->sym.size() == n && (int)state->pos.size() == n;
+    check(lcs_track_cut(h_, d_capbuf, fmt, n_cap, ts_first, n, cp_type.data(), frame_timing.data(), freq_off.data(), cont ? state->sym.data() : 0,
+                        cont ? state->pos.data() : 0, fc_requested, fc_programmed, fs_programmed, n_sym, d_td, late.data(), n_cut.data(),
+                        pos_next.data()));
+    if (state) {
+      if (!cont) state->sym.assign(n, 0);
+      for (int i = 0; i < n; ++i) state->sym[i] += n_cut[i];
+      state->pos = pos_next;
+    }
   }
 
  private:

@@ -359,22 +359,27 @@ class Searcher:
         return out
 
     def track_cut(self, d_capbuf_ptr, fmt, n_cap, cp_types, frame_timing, freq_off, fc_requested, fc_programmed, fs_programmed, n_sym,
-                  d_td_ptr):
+                  d_td_ptr, ts_first=0.0, sym_first=None, pos_first=None, want_state=False):
         """The producer thread's symbol extraction on the device (lcs_track_cut, src/producer_thread.cpp:96-131, 196-246): the
         OFDM symbols of len(cp_types) tracked cells cut out of ONE capture buffer resident in HBM (fmt FMT_IQ_U8 / FMT_C64 /
         FMT_C128 at device pointer d_capbuf_ptr) into the device array d_td_ptr [n_cells][n_sym][128] complex128 -- what
-        track_block takes as td_device_ptr.  Returns (late [n_cells][n_sym], n_cut [n_cells])."""
+        track_block takes as td_device_ptr.  ts_first / sym_first / pos_first continue a stream over several buffers (see
+        include/lcs.h).  Returns (late [n_cells][n_sym], n_cut [n_cells]) and, with want_state, pos_next [n_cells]."""
         n_cells = len(cp_types)
         cp = np.ascontiguousarray(cp_types, np.int32)
         ft = np.ascontiguousarray(frame_timing, np.float64).reshape(n_cells)
         fo = np.ascontiguousarray(freq_off, np.float64).reshape(n_cells)
+        sf = None if sym_first is None else np.ascontiguousarray(sym_first, np.int64).reshape(n_cells)
+        pf = None if pos_first is None else np.ascontiguousarray(pos_first, np.int64).reshape(n_cells)
         late = np.zeros((n_cells, n_sym), np.float64)
         n_cut = np.zeros(n_cells, np.int32)
-        rc = self._lib.lcs_track_cut(self._h, C.c_void_p(d_capbuf_ptr), int(fmt), int(n_cap), n_cells, _ip(cp), _dp(ft), _dp(fo),
-                                     float(fc_requested), float(fc_programmed), float(fs_programmed), int(n_sym), C.c_void_p(d_td_ptr),
-                                     _dp(late), _ip(n_cut))
+        pos_next = np.zeros(n_cells, np.int64)
+        i64 = lambda a: a.ctypes.data_as(C.POINTER(C.c_int64)) if a is not None else None
+        rc = self._lib.lcs_track_cut(self._h, C.c_void_p(d_capbuf_ptr), int(fmt), int(n_cap), float(ts_first), n_cells, _ip(cp), _dp(ft), _dp(fo),
+                                     i64(sf), i64(pf), float(fc_requested), float(fc_programmed), float(fs_programmed), int(n_sym),
+                                     C.c_void_p(d_td_ptr), _dp(late), _ip(n_cut), i64(pos_next))
         self._chk(rc, "lcs_track_cut")
-        return late, n_cut
+        return (late, n_cut, pos_next) if want_state else (late, n_cut)
 
     def track_stream_block(self, cells, td, freq_off, frame_timing, late, fc_requested, fc_programmed, fs_programmed, want_stats=False,
                            want_syms=True, want_ce=True, td_device_ptr=None):

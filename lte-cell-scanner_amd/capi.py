@@ -141,7 +141,8 @@ def load() -> C.CDLL:
                                          dp, dp, dp, C.c_int, i64p, ip, dp, dp, dp, C.c_int, ip, ip, C.POINTER(C.c_uint64), C.c_int, i64p, ip]
     L.lcs_track_stream_reset.argtypes = [vp]
     if hasattr(L, "lcs_track_cut"):
-        L.lcs_track_cut.argtypes = [vp, vp, C.c_int, C.c_uint32, C.c_int, ip, dp, dp, C.c_double, C.c_double, C.c_double, C.c_int, vp, dp, ip]
+        L.lcs_track_cut.argtypes = [vp, vp, C.c_int, C.c_uint32, C.c_double, C.c_int, ip, dp, dp, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                    C.c_double, C.c_double, C.c_double, C.c_int, vp, dp, ip, C.POINTER(C.c_int64)]
     L.lcs_stream_open.argtypes = [vp, C.c_int, C.c_uint32, C.c_double, C.c_double, C.c_double]
     L.lcs_stream_push.argtypes = [vp, vp, C.c_double, C.POINTER(C.c_int16), C.c_int]
     L.lcs_stream_collect.argtypes = [vp, cp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_float)]

@@ -49,66 +49,75 @@ __host__ __device__ __forceinline__ void trk_wrap_certain_interval(double fl, do
   hi = (nf + n) - g;
 }
 // ---- the producer thread's symbol cutter (tracker.hip: k_trk_cut_hits / k_trk_cut_walk; src/producer_thread.cpp:96-131, 196-246).
-// Sample n of a buffer whose first sample has timestamp 0 carries WRAP(n step, 0, 19200); a capture of symbol k starts at the first
-// sample behind the previous capture whose tdiff = WRAP(timestamp - (frame_timing + target_k), -9600, 9600) passes
-// |tdiff| < 0.5 or 0 < tdiff < 3.  The same double expressions as lte-cell-scanner_amd/tracker.py cut_symbols and host/TrackCells.cpp.
-struct TrkCutCell { double step, ft; int normal; };
-__host__ __device__ __forceinline__ TrkCutCell trk_cut_cell(int cp_type, double frame_timing, double freq_off, double fc_req, double fc_prog, double fs_prog) {
+// Sample n of a buffer whose first sample has timestamp ts0 carries WRAP(ts0 + n step, 0, 19200); the capture of symbol k (counted
+// from slot 0 symbol 0 of the stream's first frame) starts at the first sample behind the previous capture whose tdiff =
+// WRAP(timestamp - (frame_timing + target_k), -9600, 9600) passes |tdiff| < 0.5 or 0 < tdiff < 3.  A call cuts symbols k0, k0 + 1, ...
+// searching from sample pos0 (0, 0 and ts0 = 0 for a buffer cut from its start; a later buffer of the same stream continues with
+// the state the previous call returned).  The same double expressions as lte-cell-scanner_amd/tracker.py cut_symbols and
+// host/TrackCells.cpp.
+struct TrkCutCell { double step, ft, ts0; int normal; long k0, pos0; };
+__host__ __device__ __forceinline__ TrkCutCell trk_cut_cell(int cp_type, double frame_timing, double freq_off, double fc_req, double fc_prog, double fs_prog,
+                                                            double ts0, long k0, long pos0) {
   TrkCutCell r;
   const double k_factor = (fc_req - freq_off) / fc_prog;
   r.step = (30720000.0 / 16) / (fs_prog * k_factor);
   r.ft = frame_timing;
+  r.ts0 = ts0;
   r.normal = cp_type == LCS_CP_NORMAL;
+  r.k0 = k0;
+  r.pos0 = pos0;
   return r;
 }
-// target time of symbol k of the stream (slot 0 symbol 0 first): the host's fmod chain runs on integers + 10 / 32 and is exact
-__host__ __device__ __forceinline__ double trk_cut_target(const TrkCutCell &q, int k, double *cum) {
+// target time of symbol k of the stream: the host's fmod chain runs on integers + 10 / 32 and is exact; *cum = ticks since symbol 0's target
+__host__ __device__ __forceinline__ double trk_cut_target(const TrkCutCell &q, long k, double *cum) {
   const double c = q.normal ? 960.0 * (double)(k / 7) + 137.0 * (double)(k % 7) : 160.0 * (double)k;
   *cum = c;
   return fmod((q.normal ? 10.0 : 32.0) + c, 19200.0);
 }
 __host__ __device__ __forceinline__ bool trk_cut_pass(const TrkCutCell &q, long n, double target, double *tdiff) {
-  const double ts = trk_wrap((double)n * q.step, 0.0, 19200.0);
+  const double ts = trk_wrap(q.ts0 + (double)n * q.step, 0.0, 19200.0);
   const double d = trk_wrap(ts - (q.ft + target), -9600.0, 9600.0);
   *tdiff = d;
   return fabs(d) < 0.5 || (d > 0 && d < 3);
 }
-// symbol 0: the first sample >= 0 that passes, searched as the host does (up to 25000 samples, the buffer's end permitting)
+// the call's first symbol (k0): the first sample >= pos0 that passes, searched as the host does (up to 25000 samples, the buffer's
+// end permitting).  The window (tdiff in (-0.5, 3): under four samples wide) is either open within the first samples from pos0 or
+// opens where the timestamp next passes target - 0.5.
 __host__ __device__ inline long trk_cut_first(const TrkCutCell &q, uint32_t n_cap, double *late) {
-  const double t0 = q.normal ? 10.0 : 32.0;
-  const long end = (long)n_cap - 128, limit = end < 25000L ? end : 25000L;
-  double d;
+  double cum, d;
+  const double t0 = trk_cut_target(q, q.k0, &cum);
+  const long end = (long)n_cap - 128, limit = end < q.pos0 + 25000 ? end : q.pos0 + 25000;
   *late = 0.0;
   if (q.step > 0.9 && q.step < 1.1) {
-    // the window (tdiff in (-0.5, 3)) either covers the buffer's first samples or opens where the timestamp passes target - 0.5
-    for (long n = 0; n <= 3 && n <= limit; ++n) if (trk_cut_pass(q, n, t0, &d)) { *late = d; return n; }
-    const double x = trk_wrap(q.ft + t0, 0.0, 19200.0);
-    const long ne = (long)ceil((x - 0.5) / q.step);
-    for (long n = (ne - 3 > 4 ? ne - 3 : 4); n <= ne + 3 && n <= limit; ++n) if (trk_cut_pass(q, n, t0, &d)) { *late = d; return n; }
+    for (long n = q.pos0; n <= q.pos0 + 7 && n <= limit; ++n) if (trk_cut_pass(q, n, t0, &d)) { *late = d; return n; }
+    const double u = trk_wrap((q.ft + t0 - 0.5) - (q.ts0 + (double)(q.pos0 + 4) * q.step), 0.0, 19200.0);      // ticks from sample pos0 + 4 to the opening
+    const long ne = q.pos0 + 4 + (long)ceil(u / q.step);
+    for (long n = (ne - 3 > q.pos0 + 8 ? ne - 3 : q.pos0 + 8); n <= ne + 3 && n <= limit; ++n) if (trk_cut_pass(q, n, t0, &d)) { *late = d; return n; }
   }
-  return -1;      // (a step outside the range: trk_cut_symbol reports the premise as broken and the cell is walked)
+  return -1;      // (nothing before the limit -- or a step outside the range: trk_cut_symbol reports the premise as broken and the cell is walked)
 }
-// symbol k by the closed form, given symbol 0's hit (h0, l0).  *h = first sample of the capture or -1 (not found / does not fit in the
-// buffer), *lt = its tdiff.  Returns false when the closed form's premise does not hold -- the sample before the hit passes too, or
-// the previous symbol's capture (located the same way) had not ended -- and the cell must be walked sample by sample.
-__host__ __device__ inline bool trk_cut_symbol(const TrkCutCell &q, uint32_t n_cap, int k, long h0, double l0, long *h, double *lt) {
+// symbol k0 + j by the closed form, given the first symbol's hit (h0, l0).  *h = first sample of the capture or -1 (not found / does not
+// fit in the buffer), *lt = its tdiff.  Returns false when the closed form's premise does not hold -- the sample before the hit passes
+// too, or the previous symbol's capture (located the same way) had not ended -- and the cell must be walked sample by sample.
+__host__ __device__ inline bool trk_cut_symbol(const TrkCutCell &q, uint32_t n_cap, int j, long h0, double l0, long *h, double *lt) {
   bool premise = q.step > 0.9 && q.step < 1.1;      // the candidate ranges assume about one sample per 1.92 MHz tick
   long hk = -1;
   double lk = 0.0;
-  if (k == 0) { hk = h0; lk = l0; }
+  if (j == 0) { hk = h0; lk = l0; }
   else if (h0 >= 0) {
-    const double T0 = (double)h0 * q.step - l0;      // absolute time of symbol 0's target; symbol k's window opens at T0 + cum - 0.5
-    double cum, d, dp;
-    const double target = trk_cut_target(q, k, &cum);
-    const long ne = (long)ceil((T0 + cum - 0.5) / q.step);
+    double cum0, cum, d, dp;
+    (void)trk_cut_target(q, q.k0, &cum0);
+    const double T0 = (double)h0 * q.step - l0;      // the first symbol's target on the buffer's own clock; symbol k's window opens cum - cum0 - 0.5 later
+    const double target = trk_cut_target(q, q.k0 + j, &cum);
+    const long ne = (long)ceil((T0 + (cum - cum0) - 0.5) / q.step);
     for (long n = (ne - 2 > 0 ? ne - 2 : 0); n <= ne + 2; ++n) if (trk_cut_pass(q, n, target, &d)) { hk = n; lk = d; break; }
     if (hk < 1 || trk_cut_pass(q, hk - 1, target, &dp)) premise = false;
     else {
       double cumq;
-      const double tq = trk_cut_target(q, k - 1, &cumq);
-      long hq = (k == 1) ? h0 : -1;
-      if (k > 1) {
-        const long nq = (long)ceil((T0 + cumq - 0.5) / q.step);
+      const double tq = trk_cut_target(q, q.k0 + j - 1, &cumq);
+      long hq = (j == 1) ? h0 : -1;
+      if (j > 1) {
+        const long nq = (long)ceil((T0 + (cumq - cum0) - 0.5) / q.step);
         for (long n = (nq - 2 > 0 ? nq - 2 : 0); n <= nq + 2; ++n) if (trk_cut_pass(q, n, tq, &dp)) { hq = n; break; }
       }
       if (hq < 0 || hq + 128 > hk) premise = false;
@@ -121,20 +130,20 @@ __host__ __device__ inline bool trk_cut_symbol(const TrkCutCell &q, uint32_t n_c
 }
 // the walk of the host cutters, sample by sample; returns the number of symbols found (entries behind it: -1 / 0)
 __host__ __device__ inline int trk_cut_walk(const TrkCutCell &q, uint32_t n_cap, int n_sym, int *hit, double *late) {
-  long pos = 0;
-  int k = 0;
-  for (; k < n_sym && pos + 128 <= (long)n_cap; ++k) {
+  long pos = q.pos0;
+  int j = 0;
+  for (; j < n_sym && pos + 128 <= (long)n_cap; ++j) {
     double cum, d = 0.0;
-    const double target = trk_cut_target(q, k, &cum);
+    const double target = trk_cut_target(q, q.k0 + j, &cum);
     const long end = (long)n_cap - 128, limit = end < pos + 25000 ? end : pos + 25000;
     long found = -1;
     for (long n = pos; n <= limit; ++n) if (trk_cut_pass(q, n, target, &d)) { found = n; break; }
     if (found < 0) break;
-    hit[k] = (int)found; late[k] = d;
+    hit[j] = (int)found; late[j] = d;
     pos = found + 128;
   }
-  const int n_found = k;
-  for (; k < n_sym; ++k) { hit[k] = -1; late[k] = 0.0; }
+  const int n_found = j;
+  for (; j < n_sym; ++j) { hit[j] = -1; late[j] = 0.0; }
   return n_found;
 }
 

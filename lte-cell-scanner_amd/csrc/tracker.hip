@@ -611,14 +611,16 @@ __global__ __launch_bounds__(64) void k_trk_sync(const lcs_track_cell *__restric
 // (TrkCutCell, trk_cut_cell / _target / _pass / _first / _symbol / _walk: lte_device.h -- __host__ __device__, pinned on the CPU by
 // tests/test_track_cut_host.py against the sample-by-sample walk and tracker.py's cutter)
 // hit[cell][k], late[cell][k]; flags[cell] |= 1 when the closed form's premise does not hold for the cell
-// cells [n_cells][3] = (cp_type, frame_timing, freq_off) as doubles: one host -> device copy per call
-__global__ __launch_bounds__(256) void k_trk_cut_hits(const double *__restrict__ cells, double fc_req, double fc_prog, double fs_prog, uint32_t n_cap, int n_sym,
-                                                      int *__restrict__ hit, double *__restrict__ late, int *__restrict__ flags) {
+// cells [n_cells][5] = (cp_type, frame_timing, freq_off, first symbol, first sample) as doubles: one host -> device copy per call
+#define TRK_CUT_CELL(cell) trk_cut_cell((int)cells[5 * (cell)], cells[5 * (cell) + 1], cells[5 * (cell) + 2], fc_req, fc_prog, fs_prog, ts0, \
+                                        (long)cells[5 * (cell) + 3], (long)cells[5 * (cell) + 4])
+__global__ __launch_bounds__(256) void k_trk_cut_hits(const double *__restrict__ cells, double fc_req, double fc_prog, double fs_prog, double ts0, uint32_t n_cap,
+                                                      int n_sym, int *__restrict__ hit, double *__restrict__ late, int *__restrict__ flags) {
   const int cell = blockIdx.y, k = blockIdx.x * blockDim.x + threadIdx.x;
   __shared__ long s_h0;
   __shared__ double s_l0;
-  const TrkCutCell q = trk_cut_cell((int)cells[3 * cell], cells[3 * cell + 1], cells[3 * cell + 2], fc_req, fc_prog, fs_prog);
-  if (threadIdx.x == 0) { double l; s_h0 = trk_cut_first(q, n_cap, &l); s_l0 = l; }      // symbol 0's capture: once per workgroup
+  const TrkCutCell q = TRK_CUT_CELL(cell);
+  if (threadIdx.x == 0) { double l; s_h0 = trk_cut_first(q, n_cap, &l); s_l0 = l; }      // the call's first capture: once per workgroup
   __syncthreads();
   if (k >= n_sym) return;
   const long h0 = s_h0;
@@ -632,14 +634,15 @@ __global__ __launch_bounds__(256) void k_trk_cut_hits(const double *__restrict__
 // The sample-by-sample walk of the host cutters for the cells k_trk_cut_hits flagged (none at any sample rate a dongle produces),
 // and the count of symbols found: one WAVE per cell (lane 0 walks; the count and the clean-up behind it run over all lanes -- one
 // thread per cell scanning its 980 entries took 160 us).
-__global__ __launch_bounds__(64) void k_trk_cut_walk(const double *__restrict__ cells, double fc_req, double fc_prog, double fs_prog, uint32_t n_cap, int n_sym,
-                                                     int n_cells, int *__restrict__ hit, double *__restrict__ late, int *__restrict__ flags, int *__restrict__ n_cut) {
+__global__ __launch_bounds__(64) void k_trk_cut_walk(const double *__restrict__ cells, double fc_req, double fc_prog, double fs_prog, double ts0, uint32_t n_cap,
+                                                     int n_sym, int n_cells, int *__restrict__ hit, double *__restrict__ late, int *__restrict__ flags,
+                                                     int *__restrict__ n_cut, long long *__restrict__ pos_next) {
   const int cell = blockIdx.x, lane = threadIdx.x;
   int *h = hit + (size_t)cell * n_sym;
   double *lt = late + (size_t)cell * n_sym;
   if (flags[cell] & 1) {                                   // (uniform over the wave)
     if (lane == 0) {
-      (void)trk_cut_walk(trk_cut_cell((int)cells[3 * cell], cells[3 * cell + 1], cells[3 * cell + 2], fc_req, fc_prog, fs_prog), n_cap, n_sym, h, lt);
+      (void)trk_cut_walk(TRK_CUT_CELL(cell), n_cap, n_sym, h, lt);
       flags[cell] = 0;                                     // the flags start at zero for the next call: no memset per call
     }
     __threadfence_block();
@@ -653,7 +656,10 @@ __global__ __launch_bounds__(64) void k_trk_cut_walk(const double *__restrict__ 
     if (miss) n = k0 + (int)__builtin_ctzll(miss);
   }
   for (int k = n + lane; k < n_sym; k += 64) { h[k] = -1; lt[k] = 0.0; }
-  if (lane == 0) n_cut[cell] = n;
+  if (lane == 0) {
+    n_cut[cell] = n;
+    pos_next[cell] = n > 0 ? (long long)h[n - 1] + 128 : (long long)cells[5 * cell + 4];      // where the next call's search starts (this buffer's indices)
+  }
 }
 // one wave per (symbol, cell): 128 samples -> complex<double>; FMT 1: the dongle's bytes, (u8 - 127) / 128 (src/producer_thread.cpp:121-124)
 template <int FMT>
@@ -854,16 +860,20 @@ extern "C" int lcs_track_block(lcs_ctx *c, lcs_track_cell *cells, int n_cells, i
 }
 
 // The producer thread's symbol extraction (see k_trk_cut_hits): d_capbuf and d_td are DEVICE memory.
-extern "C" int lcs_track_cut(lcs_ctx *c, const void *d_capbuf, int fmt, uint32_t n_cap, int n_cells, const int32_t *cp_type,
-                             const double *frame_timing, const double *freq_off, double fc_requested, double fc_programmed,
-                             double fs_programmed, int n_sym, void *d_td, double *late, int32_t *n_cut) {
+extern "C" int lcs_track_cut(lcs_ctx *c, const void *d_capbuf, int fmt, uint32_t n_cap, double ts_first, int n_cells, const int32_t *cp_type,
+                             const double *frame_timing, const double *freq_off, const int64_t *sym_first, const int64_t *pos_first,
+                             double fc_requested, double fc_programmed, double fs_programmed, int n_sym, void *d_td, double *late,
+                             int32_t *n_cut, int64_t *pos_next) {
   if (!c) return LCS_ERR_BAD_ARG;
-  if (!d_capbuf || !cp_type || !frame_timing || !freq_off || !d_td || !n_cut || n_cells < 1 || n_sym < 1 || n_cap < 128 ||
+  if (!d_capbuf || !cp_type || !frame_timing || !freq_off || !d_td || !n_cut || n_cells < 1 || n_sym < 1 || n_cap < 128 || !std::isfinite(ts_first) ||
       (fmt != LCS_FMT_C64 && fmt != LCS_FMT_IQ_U8 && fmt != LCS_FMT_C128)) { c->err = "bad argument"; return LCS_ERR_BAD_ARG; }
   for (int i = 0; i < n_cells; ++i) {
     if (cp_type[i] != LCS_CP_NORMAL && cp_type[i] != LCS_CP_EXTENDED) { c->err = "the cutter needs a known cp_type per cell"; return LCS_ERR_BAD_ARG; }
     const double kf = (fc_requested - freq_off[i]) / fc_programmed;
     if (!(fs_programmed * kf > 0) || !std::isfinite(frame_timing[i])) { c->err = "the cutter needs a positive sample rate and a finite frame_timing"; return LCS_ERR_BAD_ARG; }
+    if ((sym_first && (sym_first[i] < 0 || sym_first[i] > (int64_t)1 << 40)) || (pos_first && (pos_first[i] < 0 || pos_first[i] > (int64_t)n_cap))) {
+      c->err = "sym_first / pos_first out of range (pos_first counts samples of THIS buffer)"; return LCS_ERR_BAD_ARG;
+    }
   }
   HIPCHK(c, hipSetDevice(c->device));
   const size_t N = (size_t)n_cells * n_sym;
@@ -873,20 +883,24 @@ extern "C" int lcs_track_cut(lcs_ctx *c, const void *d_capbuf, int fmt, uint32_t
     const int capC = std::max(n_cells, c->trk_cut_cells_cap);
     c->trk_cut_cap = 0; c->trk_cut_cells_cap = 0;
     int rc;
-    if ((rc = trk_alloc(c, &c->trk_cut_hit, capN + 2 * (size_t)capC)) || (rc = trk_alloc(c, &c->trk_cut_meta, capN + 3 * (size_t)capC))) return rc;
-    HIPCHK(c, hipMemsetAsync(c->trk_cut_hit, 0, sizeof(int) * (capN + 2 * (size_t)capC), c->stream));      // the per-cell flags start at zero
+    if ((rc = trk_alloc(c, &c->trk_cut_hit, capN + 4 * (size_t)capC + 2)) || (rc = trk_alloc(c, &c->trk_cut_meta, capN + 5 * (size_t)capC))) return rc;
+    HIPCHK(c, hipMemsetAsync(c->trk_cut_hit, 0, sizeof(int) * (capN + 4 * (size_t)capC + 2), c->stream));      // the per-cell flags start at zero
     c->trk_cut_cap = capN; c->trk_cut_cells_cap = capC;
   }
-  // hit [cells][symbols], then the per-cell counts and flags at FIXED offsets (the flags keep their zeros from call to call)
+  // hit [cells][symbols], then the per-cell counts, flags and next positions at FIXED offsets (the flags keep their zeros from call to call)
   int *d_hit = c->trk_cut_hit, *d_ncut = d_hit + c->trk_cut_cap, *d_flags = d_ncut + c->trk_cut_cells_cap;
+  long long *d_pos = reinterpret_cast<long long *>(d_hit + ((c->trk_cut_cap + 2 * (size_t)c->trk_cut_cells_cap + 1) & ~(size_t)1));
   double *d_late = c->trk_cut_meta, *d_cells = d_late + c->trk_cut_cap;
-  std::vector<double> h_cells((size_t)3 * n_cells);
-  for (int i = 0; i < n_cells; ++i) { h_cells[3 * i] = (double)cp_type[i]; h_cells[3 * i + 1] = frame_timing[i]; h_cells[3 * i + 2] = freq_off[i]; }
-  HIPCHK(c, hipMemcpyAsync(d_cells, h_cells.data(), sizeof(double) * 3 * n_cells, hipMemcpyHostToDevice, c->stream));      // (pageable: staged before the call returns)
+  std::vector<double> h_cells((size_t)5 * n_cells);
+  for (int i = 0; i < n_cells; ++i) {
+    h_cells[5 * i] = (double)cp_type[i]; h_cells[5 * i + 1] = frame_timing[i]; h_cells[5 * i + 2] = freq_off[i];
+    h_cells[5 * i + 3] = sym_first ? (double)sym_first[i] : 0.0; h_cells[5 * i + 4] = pos_first ? (double)pos_first[i] : 0.0;
+  }
+  HIPCHK(c, hipMemcpyAsync(d_cells, h_cells.data(), sizeof(double) * 5 * n_cells, hipMemcpyHostToDevice, c->stream));      // (pageable: staged before the call returns)
   hipLaunchKernelGGL(k_trk_cut_hits, dim3((n_sym + 255) / 256, n_cells), dim3(256), 0, c->stream, d_cells, fc_requested, fc_programmed,
-                     fs_programmed, n_cap, n_sym, d_hit, d_late, d_flags);
+                     fs_programmed, ts_first, n_cap, n_sym, d_hit, d_late, d_flags);
   hipLaunchKernelGGL(k_trk_cut_walk, dim3(n_cells), dim3(64), 0, c->stream, d_cells, fc_requested, fc_programmed,
-                     fs_programmed, n_cap, n_sym, n_cells, d_hit, d_late, d_flags, d_ncut);
+                     fs_programmed, ts_first, n_cap, n_sym, n_cells, d_hit, d_late, d_flags, d_ncut, d_pos);
   const dim3 grid((n_sym + 3) / 4, n_cells);
   if (fmt == LCS_FMT_IQ_U8) hipLaunchKernelGGL(k_trk_cut_copy<LCS_FMT_IQ_U8>, grid, dim3(256), 0, c->stream, d_capbuf, n_sym, d_hit, (double2 *)d_td);
   else if (fmt == LCS_FMT_C64) hipLaunchKernelGGL(k_trk_cut_copy<LCS_FMT_C64>, grid, dim3(256), 0, c->stream, d_capbuf, n_sym, d_hit, (double2 *)d_td);
@@ -894,6 +908,7 @@ extern "C" int lcs_track_cut(lcs_ctx *c, const void *d_capbuf, int fmt, uint32_t
   HIPCHK(c, hipGetLastError());
   if (late) HIPCHK(c, hipMemcpyAsync(late, d_late, sizeof(double) * N, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(n_cut, d_ncut, sizeof(int) * n_cells, hipMemcpyDeviceToHost, c->stream));
+  if (pos_next) HIPCHK(c, hipMemcpyAsync(pos_next, d_pos, sizeof(long long) * n_cells, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return LCS_OK;
 }

@@ -25,18 +25,25 @@ def n_symb_dl(cp_type: int) -> int:
 
 
 def cut_symbols(capbuf, frame_timing: float, cp_type: int, frequency_offset: float, fc_requested: float, fc_programmed: float,
-                fs_programmed: float, n_sym: int):
+                fs_programmed: float, n_sym: int, ts_first: float = 0.0, sym_first: int = 0, pos_first: int = 0, want_state: bool = False):
     """What the producer thread queues for one tracked cell (src/producer_thread.cpp:96-131, 196-246), for a capture
-    buffer whose first sample has timestamp 0: up to n_sym OFDM symbols starting at slot 0 symbol 0 of the first
-    frame boundary in the buffer.  Returns (td [n][128] complex128, late [n], frame_timing [n], frequency_offset [n])."""
+    buffer whose first sample has timestamp ts_first: up to n_sym OFDM symbols starting with symbol sym_first of the stream
+    (counted from slot 0 symbol 0 of its first frame), searched from sample pos_first on -- for the defaults: the symbols from
+    the first frame boundary in the buffer.  Returns (td [n][128] complex128, late [n], frame_timing [n], frequency_offset
+    [n]) and, with want_state, pos_next (the sample behind the last capture; sym_first + n and pos_next - o continue the
+    stream on a buffer that starts o samples into this one, with timestamp wrap(ts_first + o * step, 0, 19200))."""
     cap = np.asarray(capbuf, np.complex128)
     k_factor = (fc_requested - frequency_offset) / fc_programmed
     step = (FS_LTE / 16) / (fs_programmed * k_factor)
-    ts = wrap(np.arange(cap.size) * step, 0.0, 19200.0)     # timestamp of sample n on the cell-independent 1.92 MHz time base
+    ts = wrap(ts_first + np.arange(cap.size) * step, 0.0, 19200.0)     # timestamp of sample n on the cell-independent 1.92 MHz time base
     td, late = [], []
-    target = 10.0 if cp_type == 1 else 32.0
-    sym, pos = 0, 0
     nsd = n_symb_dl(cp_type)
+    target = 10.0 if cp_type == 1 else 32.0
+    sym = 0
+    for _ in range(int(sym_first)):                                     # (the producer's own chain; the values are integers + 10 / 32: exact)
+        target = (target + (160.0 if cp_type != 1 else (138.0 if sym == 6 else 137.0))) % 19200.0
+        sym = (sym + 1) % nsd
+    pos = int(pos_first)
     while len(td) < n_sym:
         # first sample at or after `pos` whose timestamp is within half a sample of the target (or just past it)
         hit = -1
@@ -58,8 +65,9 @@ def cut_symbols(capbuf, frame_timing: float, cp_type: int, frequency_offset: flo
         target = (target + (160.0 if cp_type != 1 else (138.0 if sym == 6 else 137.0))) % 19200.0
         sym = (sym + 1) % nsd
     n = len(td)
-    return (np.array(td, np.complex128).reshape(n, 128), np.array(late), np.full(n, float(frame_timing)),
-            np.full(n, float(frequency_offset)))
+    out = (np.array(td, np.complex128).reshape(n, 128), np.array(late), np.full(n, float(frame_timing)),
+           np.full(n, float(frequency_offset)))
+    return out + (pos,) if want_state else out
 
 
 def fold_frequency_offset(f0: float, meas: np.ndarray) -> float:

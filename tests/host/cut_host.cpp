@@ -5,8 +5,8 @@
 
 // closed form for every symbol; returns 1 when the premise held for all of them (then hit / late are final), 0 otherwise
 extern "C" int cut_host_closed(int cp_type, double frame_timing, double freq_off, double fc_req, double fc_prog, double fs_prog,
-                               unsigned n_cap, int n_sym, int *hit, double *late) {
-  const TrkCutCell q = trk_cut_cell(cp_type, frame_timing, freq_off, fc_req, fc_prog, fs_prog);
+                               unsigned n_cap, int n_sym, double ts0, long long k0, long long pos0, int *hit, double *late) {
+  const TrkCutCell q = trk_cut_cell(cp_type, frame_timing, freq_off, fc_req, fc_prog, fs_prog, ts0, (long)k0, (long)pos0);
   double l0;
   const long h0 = trk_cut_first(q, n_cap, &l0);
   int ok = 1;
@@ -24,6 +24,6 @@ extern "C" int cut_host_closed(int cp_type, double frame_timing, double freq_off
   return ok;
 }
 extern "C" int cut_host_walk(int cp_type, double frame_timing, double freq_off, double fc_req, double fc_prog, double fs_prog,
-                             unsigned n_cap, int n_sym, int *hit, double *late) {
-  return trk_cut_walk(trk_cut_cell(cp_type, frame_timing, freq_off, fc_req, fc_prog, fs_prog), n_cap, n_sym, hit, late);
+                             unsigned n_cap, int n_sym, double ts0, long long k0, long long pos0, int *hit, double *late) {
+  return trk_cut_walk(trk_cut_cell(cp_type, frame_timing, freq_off, fc_req, fc_prog, fs_prog, ts0, (long)k0, (long)pos0), n_cap, n_sym, hit, late);
 }

@@ -69,6 +69,51 @@ def test_cut_walks_a_cell_whose_sample_rate_breaks_the_closed_form(pkg):
                 assert np.array_equal(late[i, :n], w_late) and np.array_equal(tdh[i, :n], w_td), (fsp, i)
 
 
+def test_cut_continues_a_stream_over_several_buffers(pkg):
+    """The producer's state between two blocks of samples, on the device: the recorded capture handed over as four overlapping
+    buffers (sub-ranges of the bytes in HBM), each call continuing with ts_first / sym_first / pos_first from the previous call's
+    n_cut / pos_next -- per buffer equal to the host cutter given the same state (samples and `late` bit for bit), and together the
+    symbols of the capture cut in one go."""
+    import torch
+    iq = golden("capbuf_0000")["iq_u8"]
+    cap = iq_u8_to_capbuf(iq)
+    d = torch.from_numpy(np.ascontiguousarray(iq)).cuda()
+    cps, fts, fos = [1, 2, 1], [4321.75, 18000.5, 77.0], [12e3, -7e3, 31e3]
+    fsp = FS * (1 - 2e-5)
+    steps = [(30.72e6 / 16) / (fsp * ((FC - fo) / FC)) for fo in fos]
+    whole = [pkg.tracker.cut_symbols(cap, fts[i], cps[i], fos[i], FC, FC, fsp, 10 ** 6) for i in range(3)]
+    n_sym = 400
+    td = torch.empty((3, n_sym, 128), dtype=torch.complex128, device="cuda")
+    got = [[], [], []]
+    with pkg.Searcher(0) as S:
+        o, ts0 = 0, 0.0
+        sym, pos = np.zeros(3, np.int64), np.zeros(3, np.int64)
+        while True:
+            n = min(45000, cap.size - o)
+            late, n_cut, pos_next = S.track_cut(d.data_ptr() + 2 * o, pkg.FMT_IQ_U8, n, cps, fts, fos, FC, FC, fsp, n_sym, td.data_ptr(), ts_first=ts0,
+                                                sym_first=sym, pos_first=pos, want_state=True)
+            tdh = td.cpu().numpy()
+            for i in range(3):
+                w = pkg.tracker.cut_symbols(cap[o:o + n], fts[i], cps[i], fos[i], FC, FC, fsp, n_sym, ts_first=ts0, sym_first=int(sym[i]), pos_first=int(pos[i]),
+                                            want_state=True)
+                assert n_cut[i] == w[0].shape[0] and pos_next[i] == w[4], (o, i)
+                assert np.array_equal(tdh[i, :n_cut[i]], w[0]) and np.array_equal(late[i, :n_cut[i]], w[1]), (o, i)
+                got[i].append(tdh[i, :n_cut[i]].copy())
+            if o + n >= cap.size:
+                break
+            sym = sym + n_cut
+            adv = int(min(pos_next.min(), n - 300))                         # one stream: every cell continues from the same sample
+            # (one timestamp base per stream: the reference's producer steps it with the GLOBAL frequency offset; here the three
+            # 'cells' carry different offsets, so each gets the base of its own step -- the first cell's is used for all, the others'
+            # targets simply sit elsewhere: host and device are given the same state either way)
+            ts0 = float(pkg.tracker.wrap(ts0 + adv * steps[0], 0.0, 19200.0))
+            pos = pos_next - adv
+            o += adv
+    # cell 0 (whose step stamped the buffers): the chunks together are the capture cut in one go
+    all0 = np.concatenate(got[0])
+    assert all0.shape == whole[0][0].shape and np.array_equal(all0, whole[0][0])
+
+
 def test_track_block_on_device_cut_symbols_equals_host_cut(pkg):
     """The two cells of the recorded capture: symbols cut on the device from the dongle's BYTES and handed to lcs_track_block as a
     device pointer -- every output array equal to the block on the host-cut symbols (which tests/test_tracker.py holds against the

@@ -25,16 +25,17 @@ def H():
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC",
                                "-shared", "-I" + os.path.join(ROOT, "include"), "-o", LIB, SRC])
     h = C.CDLL(LIB)
-    sig = [C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_uint, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double)]
+    sig = [C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_uint, C.c_int, C.c_double, C.c_longlong, C.c_longlong,
+           C.POINTER(C.c_int), C.POINTER(C.c_double)]
     h.cut_host_closed.argtypes = sig
     h.cut_host_walk.argtypes = sig
     return h
 
 
-def _run(fn, cp, ft, fo, fc, fcp, fsp, n_cap, n_sym):
+def _run(fn, cp, ft, fo, fc, fcp, fsp, n_cap, n_sym, ts0=0.0, k0=0, pos0=0):
     hit = np.zeros(n_sym, np.int32)
     late = np.zeros(n_sym, np.float64)
-    r = fn(cp, ft, fo, fc, fcp, fsp, n_cap, n_sym, hit.ctypes.data_as(C.POINTER(C.c_int)), late.ctypes.data_as(C.POINTER(C.c_double)))
+    r = fn(cp, ft, fo, fc, fcp, fsp, n_cap, n_sym, ts0, k0, pos0, hit.ctypes.data_as(C.POINTER(C.c_int)), late.ctypes.data_as(C.POINTER(C.c_double)))
     return r, hit, late
 
 
@@ -59,6 +60,33 @@ def test_closed_form_equals_the_walk(H):
         assert nw == int(np.count_nonzero(hw >= 0))
         n_ok += 1
     assert n_ok == 3000
+
+
+def test_closed_form_equals_the_walk_on_continued_streams(H):
+    """The same with the state of a stream that continues from an earlier buffer: any first-sample timestamp, the first symbol
+    anywhere in the stream (frames into it), the search starting anywhere in the buffer -- incl. inside the symbol's window and
+    just behind it (the capture then waits a whole frame)."""
+    rng = np.random.default_rng(21)
+    for it in range(3000):
+        cp = 1 + int(rng.integers(0, 2))
+        ft, fo = float(rng.uniform(0, 19200)), float(rng.uniform(-60e3, 60e3))
+        fcp, fsp = FC * (1 + float(rng.uniform(-3e-5, 3e-5))), FS * (1 + float(rng.uniform(-2e-4, 2e-4)))
+        ts0 = float(rng.uniform(0, 19200))
+        k0 = int(rng.integers(0, 100000))
+        n_cap = int(rng.choice([153600, 60000, 9973, 300]))
+        pos0 = int(rng.integers(0, min(n_cap, 30000)))
+        if it % 4 == 0:
+            # put the search start within a few samples of the first symbol's window: target time = ts0 + pos0 step + a few ticks
+            nsd = 7 if cp == 1 else 6
+            cum = 960.0 * (k0 // 7) + 137.0 * (k0 % 7) if cp == 1 else 160.0 * k0
+            target = ((10.0 if cp == 1 else 32.0) + cum) % 19200.0
+            step = (30.72e6 / 16) / (fsp * ((FC - fo) / fcp))
+            ft = float((ts0 + pos0 * step + rng.uniform(-5, 5) - target) % 19200.0)
+        n_sym = int(rng.choice([980, 140, 7]))
+        ok, hc, lc = _run(H.cut_host_closed, cp, ft, fo, FC, fcp, fsp, n_cap, n_sym, ts0, k0, pos0)
+        nw, hw, lw = _run(H.cut_host_walk, cp, ft, fo, FC, fcp, fsp, n_cap, n_sym, ts0, k0, pos0)
+        assert ok == 1, (it, cp, ft, fo, fsp, ts0, k0, pos0)
+        assert np.array_equal(hc, hw) and np.array_equal(lc, lw), (it, cp, ft, ts0, k0, pos0, n_cap, np.flatnonzero(hc != hw)[:4], hc[:3], hw[:3])
 
 
 def test_sample_rates_far_from_nominal_are_walked(H):
@@ -94,3 +122,39 @@ def test_walk_equals_the_python_cutter(H):
         n, hw, lw = _run(H.cut_host_walk, cp, ft, fo, FC, fcp, fsp, cap.size, n_sym)
         assert n == td.shape[0] and np.array_equal(lw[:n], late)
         assert all(np.array_equal(td[k], cap[hw[k]:hw[k] + 128]) for k in range(0, n, 37))
+        # ... and with a continued stream's state
+        ts0, k0, pos0 = float(rng.uniform(0, 19200)), int(rng.integers(0, 5000)), int(rng.integers(0, 40000))
+        td, late, _, _, pos_next = pkg.tracker.cut_symbols(cap, ft, cp, fo, FC, fcp, fsp, 400, ts_first=ts0, sym_first=k0, pos_first=pos0, want_state=True)
+        n, hw, lw = _run(H.cut_host_walk, cp, ft, fo, FC, fcp, fsp, cap.size, 400, ts0, k0, pos0)
+        assert n == td.shape[0] == 400 and np.array_equal(lw[:n], late) and pos_next == hw[n - 1] + 128
+        assert all(np.array_equal(td[k], cap[hw[k]:hw[k] + 128]) for k in range(0, n, 41))
+
+
+def test_a_stream_cut_in_chunks_is_the_stream_cut_at_once():
+    """The producer's state between two blocks of samples: an 80 ms capture cut in one go, and as four overlapping chunks each
+    continuing with (timestamp of its first sample, next symbol, next search position) -- the same captures, symbol for symbol
+    (`late` to 1e-9: the chunk's own timestamp origin rounds differently)."""
+    pkg = load_pkg()
+    rng = np.random.default_rng(14)
+    cap = (rng.standard_normal(153600) + 1j * rng.standard_normal(153600)).astype(np.complex128)
+    for it, cp in enumerate((1, 2, 1)):
+        ft, fo = float(rng.uniform(0, 19200)), float(rng.uniform(-30e3, 30e3))
+        fsp = FS * (1 + 3e-5 * it)
+        step = (30.72e6 / 16) / (fsp * ((FC - fo) / FC))
+        td_all, late_all, _, _ = pkg.tracker.cut_symbols(cap, ft, cp, fo, FC, FC, fsp, 10 ** 6)
+        got_td, got_late = [], []
+        o, ts0, k0, pos0 = 0, 0.0, 0, 0                 # chunk origin in the whole capture, its state
+        while o < cap.size:
+            chunk = cap[o:o + 40000]
+            td, late, _, _, pos_next = pkg.tracker.cut_symbols(chunk, ft, cp, fo, FC, FC, fsp, 10 ** 6, ts_first=ts0, sym_first=k0, pos_first=pos0, want_state=True)
+            got_td.append(td); got_late.append(late)
+            k0 += td.shape[0]
+            if o + 40000 >= cap.size:
+                break
+            adv = min(pos_next, chunk.size - 300)        # keep the tail: a capture the chunk's end cut off is whole in the next one
+            ts0 = float(pkg.tracker.wrap(ts0 + adv * step, 0.0, 19200.0))
+            pos0 = pos_next - adv
+            o += adv
+        got_td, got_late = np.concatenate(got_td), np.concatenate(got_late)
+        assert got_td.shape == td_all.shape and np.array_equal(got_td, td_all)
+        assert np.abs(got_late - late_all).max() < 1e-9
