@@ -1769,6 +1769,49 @@ int orc_trk_mib(const orc_cell *cell, const double *syms16, const double *ce16, 
 
 /* ---- thin exports of two third-party-arithmetic restatements, so that the tests can pin them to independent
  * implementations (numpy.linalg.solve; the closed form of the QPSK log-MAP LLR) ---- */
+/* ---- the producer thread's sample loop for ONE tracked cell (ref src/producer_thread.cpp:96-131, 196-246) ---------------------
+ * Restated as written there: the timestamp is ACCUMULATED -- sample_time += (FS_LTE/16) / (fs_programmed k_factor), minus 19200 once it
+ * exceeds 19200 (:127-131; the reference starts at -1, here the caller gives the timestamp of the buffer's first sample and the
+ * accumulator starts one step before it) -- and every sample is examined in turn (:200): while not filling, a capture starts when
+ * tdiff = WRAP(timestamp - (frame_timing + target_cap_start_time), -9600, 9600) satisfies |tdiff| < 0.5 or 0 < tdiff < 3 (:203-213),
+ * with late = tdiff (:216); 128 samples later (:225) the target advances by 32 + 128 (extended CP), 128 + 10 (after symbol 6) or
+ * 128 + 9, modulo 19200 (:236-241), and slot_sym_inc steps the symbol number (:242).  frame_timing and the frequency offset are held
+ * (a recorded buffer: the values at the beginning of the capture, :219-220).  A capture the buffer's end cuts off is not reported.
+ * hit[k] = index of the first sample of symbol k's capture.  Returns the number of complete captures. */
+int orc_producer_cut(uint32_t n_cap, double ts_first, double frame_timing, int cp_type, double frequency_offset, double fc_requested,
+                     double fc_programmed, double fs_programmed, int n_sym_max, int32_t *hit, double *late) {
+  const double k_factor = (fc_requested - frequency_offset) / fc_programmed;      /* :99 */
+  const double step = (FS_LTE / 16) / (fs_programmed * k_factor);                  /* :127 */
+  double sample_time = ts_first - step;
+  double target_cap_start_time = (cp_type == ORC_CP_NORMAL) ? 10 : 32;             /* :172 */
+  int sym_num = 0, filling = 0, buffer_offset = 0, n = 0;
+  const int n_symb_dl = (cp_type == ORC_CP_NORMAL) ? 7 : 6;
+  for (uint32_t t = 0; t < n_cap && n < n_sym_max; ++t) {
+    sample_time += step;                                                           /* :127 */
+    if (sample_time > 19200.0) sample_time -= 19200.0;                             /* :129-130 */
+    if (!filling) {                                                                /* :202 */
+      const double tdiff = WRAP(sample_time - (frame_timing + target_cap_start_time), -19200.0 / 2, 19200.0 / 2);
+      if (fabs(tdiff) < 0.5 || (tdiff > 0 && tdiff < 3)) {                         /* :204-210 */
+        filling = 1;
+        buffer_offset = 0;
+        hit[n] = (int32_t)t;
+        late[n] = tdiff;                                                           /* :216 */
+      }
+    }
+    if (filling) {                                                                 /* :225 */
+      if (++buffer_offset == 128) {                                                /* :227 */
+        ++n;
+        filling = 0;
+        if (cp_type == ORC_CP_EXTENDED) target_cap_start_time += 32 + 128;         /* :237 */
+        else target_cap_start_time += (sym_num == 6) ? 128 + 10 : 128 + 9;         /* :239 */
+        target_cap_start_time = fmod(target_cap_start_time, 19200);                /* :241 (itpp mod on a non-negative value) */
+        sym_num = (sym_num + 1) % n_symb_dl;                                       /* :242 slot_sym_inc */
+      }
+    }
+  }
+  return n;
+}
+
 void orc_solve3(const double *M_re_im /*[3][3]*/, const double *V_re_im /*[3]*/, double *out_re_im /*[3]*/) {
   cd M[3][3], V[3], o[3];
   memcpy(M, M_re_im, sizeof(M));

@@ -388,6 +388,19 @@ def trk_mib(cell, syms16, ce16, np16):
     return bits, bool(a.value), bool(b.value)
 
 
+def producer_cut(n_cap, frame_timing, cp_type, frequency_offset, fc_requested, fc_programmed, fs_programmed, n_sym_max, ts_first=0.0):
+    """The producer thread's sample loop for one tracked cell (src/producer_thread.cpp:96-131, 196-246) on a buffer of n_cap samples
+    whose first sample has timestamp ts_first: -> (hit [n] int32: first sample of every complete 128-sample capture, late [n])."""
+    hit = np.zeros(n_sym_max, np.int32)
+    late = np.zeros(n_sym_max, np.float64)
+    L = lib()
+    L.orc_producer_cut.argtypes = [C.c_uint32, C.c_double, C.c_double, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int,
+                                   C.POINTER(C.c_int32), C.POINTER(C.c_double)]
+    n = L.orc_producer_cut(int(n_cap), float(ts_first), float(frame_timing), int(cp_type), float(frequency_offset), float(fc_requested),
+                           float(fc_programmed), float(fs_programmed), int(n_sym_max), _ip(hit), _dp(late))
+    return hit[:n], late[:n]
+
+
 def solve3(M, V):
     M = np.ascontiguousarray(M, np.complex128); V = np.ascontiguousarray(V, np.complex128)
     o = np.empty(3, np.complex128)

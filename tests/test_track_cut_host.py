@@ -158,3 +158,27 @@ def test_a_stream_cut_in_chunks_is_the_stream_cut_at_once():
         got_td, got_late = np.concatenate(got_td), np.concatenate(got_late)
         assert got_td.shape == td_all.shape and np.array_equal(got_td, td_all)
         assert np.abs(got_late - late_all).max() < 1e-9
+
+
+def test_cutter_against_the_oracle_restatement_of_the_producer_loop(H):
+    """oracle/lcs_oracle.c orc_producer_cut restates the reference's sample loop as written (src/producer_thread.cpp:96-131,
+    196-246): the timestamp ACCUMULATED sample by sample (+= step, - 19200 past 19200), every sample examined in turn.  The
+    product's cutters form the timestamp as WRAP(ts_first + n step) instead (no 153600-step dependency chain: what lets the GPU give
+    every symbol a thread): the same captures -- every first sample equal -- and `late` within 1e-7 samples (the accumulated
+    rounding of 153600 additions)."""
+    import oracle as O
+    rng = np.random.default_rng(31)
+    n_sym_total = 0
+    for it in range(200):
+        cp = 1 + int(rng.integers(0, 2))
+        ft, fo = float(rng.uniform(0, 19200)), float(rng.uniform(-60e3, 60e3))
+        fcp, fsp = FC * (1 + float(rng.uniform(-3e-5, 3e-5))), FS * (1 + float(rng.uniform(-2e-4, 2e-4)))
+        ts0 = 0.0 if it % 2 else float(rng.uniform(0, 19200))
+        ho, lo = O.producer_cut(153600, ft, cp, fo, FC, fcp, fsp, 2000, ts_first=ts0)
+        n, hw, lw = _run(H.cut_host_walk, cp, ft, fo, FC, fcp, fsp, 153600, 2000, ts0, 0, 0)
+        ok, hc, lc = _run(H.cut_host_closed, cp, ft, fo, FC, fcp, fsp, 153600, 2000, ts0, 0, 0)
+        assert ok == 1 and n == ho.size and n >= 800, (it, n, ho.size)
+        assert np.array_equal(hw[:n], ho) and np.array_equal(hc[:n], ho), (it, np.flatnonzero(hw[:n] != ho)[:4])
+        assert np.abs(lw[:n] - lo).max() < 1e-7, (it, np.abs(lw[:n] - lo).max())
+        n_sym_total += n
+    assert n_sym_total > 150000
