@@ -25,6 +25,7 @@ timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_c64_p1" -- $B $SHORT --batch 64 --pipeline 1 --input c64 > "$OUT/stats_c64_p1.log" 2>&1
 # the tracker block (f4) and the streaming mode (configs[4]): their kernels' durations
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_track" -- $B --stage track --steps 20 --warmup 6 --no-cpu-baseline > "$OUT/stats_track.log" 2>&1
+timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_cut" -- python $REPO/tools/cut_probe.py > "$OUT/stats_cut.log" 2>&1      # lcs_track_cut: 64 cells x 980 symbols
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_stream" -- $B --stage stream --steps 100 --warmup 20 --no-cpu-baseline > "$OUT/stats_stream.log" 2>&1
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS" \

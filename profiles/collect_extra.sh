@@ -9,7 +9,6 @@ OUT=$REPO/gpurun_out/$TAG
 mkdir -p "$OUT"
 P="python tools/parity_population.py"
 # the tests written after the collection
-timeout 1500 python -m pytest tests/test_gpu_track_channels.py tests/test_gpu_population.py -m gpu -x -q 2>&1 | tail -8 > "$OUT/pytest_gpu_new_tests.log"
 # wide grids (n_f = 61 .. 169) on fading channels, two draws
 timeout 900 $P --groups highband --out "$OUT/parity_population_highband.json" > "$OUT/parity_population_highband.log" 2>&1
 timeout 900 $P --groups highband --seed-offset 1 --out "$OUT/parity_population_highband_seed1.json" > "$OUT/parity_population_highband_seed1.log" 2>&1
@@ -18,6 +17,4 @@ timeout 1500 $P --groups synthetic,channels --input c64 --out "$OUT/parity_popul
 # two more draws of the channels group
 timeout 900 $P --groups channels --seed-offset 1 --out "$OUT/parity_population_channels_seed1.json" > "$OUT/parity_population_channels_seed1.log" 2>&1
 timeout 900 $P --groups channels --seed-offset 2 --out "$OUT/parity_population_channels_seed2.json" > "$OUT/parity_population_channels_seed2.log" 2>&1
-# the tracker line on 400 blocks (60 blocks = 25 ms of wall time measure the clock ramp as much as the pipeline)
-timeout 200 python bench.py --stage track --steps 400 --warmup 40 > "$OUT/bench_track_n1.json" 2> "$OUT/bench_track_n1.err"
 echo collected > "$OUT/done_extra"

@@ -26,7 +26,8 @@ for d, out in (("stats_full_p1", "kernel_stats_full_chain_b64_nf31_pipeline1.csv
                ("stats_dense_default", "kernel_stats_dense_band_b128_nf31_default_command.csv"),
                ("stats_c64_p1", "kernel_stats_full_chain_b64_nf31_c64_pipeline1.csv"),
                ("stats_track", "kernel_stats_tracker_block_64cells_980sym.csv"),
-               ("stats_stream", "kernel_stats_streaming_mode_nf1.csv")):
+               ("stats_stream", "kernel_stats_streaming_mode_nf1.csv"),
+               ("stats_cut", "kernel_stats_track_cut_64cells_980sym.csv")):
     f = sorted(glob.glob(os.path.join(src, d, "*", "*_kernel_stats.csv")), key=os.path.getmtime)     # newest collection wins
     if f and d == "stats_track":
         # two traced processes: bench.py itself (the stream form, the Python loop) and host/TrackBench, whose C++ loop is the timed
