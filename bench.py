@@ -351,7 +351,7 @@ def track_bench(pkg, args, rank, world, local_rank, dist):
     # Round 5: the timed loop runs in C++ (host/TrackBench: one host thread per context calling lcs_track_block on the same block,
     # symbols resident in HBM) -- round 4's Python threads made the figure follow the box's host (91-150 M symbols/s for the
     # same 0.50 ms of GPU time per block).  The Python loop below stays as the fallback and as `python_loop_symbols_per_s`.
-    cxx = None
+    cxx = cxx_bytes = None
     exe = os.path.join(ROOT, "host", "TrackBench")
     if os.path.exists(exe) and not args.lib:
         import struct, subprocess, tempfile
@@ -389,6 +389,22 @@ def track_bench(pkg, args, rank, world, local_rank, dist):
             if r.returncode != 0 or cxx.get("failed", 0) or cxx.get("blocks") != args.steps:
                 sys.stderr.write("bench.py: host/TrackBench reported failed blocks (rc %d, %s): the Python loop's figure is reported\n" % (r.returncode, cxx))
                 cxx = None
+            # the same loop STARTING FROM THE DONGLE'S BYTES (round 6): per block lcs_track_cut on the capture resident in HBM, then the block
+            # on the symbols it left there -- untimed for `value`, reported as config.cutter.cxx_from_bytes
+            if cxx and hasattr(pkg.capi.load(), "lcs_track_cut") and not args.no_dense:
+                with tempfile.NamedTemporaryFile(suffix=".u8", delete=False) as fh:
+                    fh.write(np.ascontiguousarray(g["iq_u8"]).tobytes())
+                    cap_path = fh.name
+                try:
+                    r2 = subprocess.run([exe, blk_path, str(depth), str(args.steps), str(max(depth, args.warmup, 120)), str(dev_i), cap_path], capture_output=True, text=True, timeout=600)
+                    cxx_bytes = json.loads([l for l in r2.stdout.splitlines() if l.startswith("{")][-1])
+                    if r2.returncode != 0 or cxx_bytes.get("failed", 0) or cxx_bytes.get("blocks") != args.steps:
+                        cxx_bytes = None
+                except Exception as e:
+                    cxx_bytes = None
+                    sys.stderr.write("bench.py: host/TrackBench (from bytes) failed: %r\n" % (e,))
+                finally:
+                    os.unlink(cap_path)
         except Exception as e:
             cxx = None
             sys.stderr.write("bench.py: host/TrackBench failed (%r): the Python loop's figure is reported\n" % (e,))
@@ -469,7 +485,7 @@ def track_bench(pkg, args, rank, world, local_rank, dist):
         torch.cuda.synchronize()
         dte_ = (time.perf_counter() - t1) / 10
         cutter = {"ms_per_block": 1e3 * dtc_, "cut_plus_block_ms": 1e3 * dte_, "symbols_per_s_cut_plus_block": C * n_sym / dte_,
-                  "identical_to_host_cut": same, "capture_bytes_in_hbm": int(d_iq.numel()), "symbols_bytes_written": int(d_cut.numel() * 16),
+                  "identical_to_host_cut": same, "cxx_from_bytes": cxx_bytes, "capture_bytes_in_hbm": int(d_iq.numel()), "symbols_bytes_written": int(d_cut.numel() * 16),
                   "note": "lcs_track_cut: one thread per (cell, symbol) locates the capture's first sample in closed form (the host walks the "
                           "samples one by one), one wave per symbol converts and copies its 128 samples; one context, one thread, the "
                           "call synchronous (late / n_cut come back to the host)"}

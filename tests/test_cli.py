@@ -346,5 +346,14 @@ def test_track_bench_cxx_driver(tmp_path):
     assert r.returncode == 0, r.stderr
     j = json.loads(r.stdout.strip().splitlines()[-1])
     assert j["blocks"] == 6 and j["failed"] == 0 and j["contexts"] == 2 and j["mib_locks_per_block"] == want and want >= 4
-    assert j["symbols_per_s"] > 0 and j["gpu_ms_per_block_alone"] > 0
+    assert j["symbols_per_s"] > 0 and j["gpu_ms_per_block_alone"] > 0 and j["from_bytes"] is False
+    # every block STARTING FROM THE DONGLE'S BYTES: lcs_track_cut on the capture in HBM, then the block on the symbols it left there --
+    # the same locks, and the cutter's `late` equal to the block file's (the host cutter's) bit for bit
+    capf = tmp_path / "capture.u8"
+    capf.write_bytes(np.ascontiguousarray(g["iq_u8"]).tobytes())
+    r = subprocess.run([os.path.join(ROOT, "host", "TrackBench"), str(blk), "2", "6", "2", "0", str(capf)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    j = json.loads(r.stdout.strip().splitlines()[-1])
+    assert j["blocks"] == 6 and j["failed"] == 0 and j["from_bytes"] is True and j["late_identical_to_host_cut"] is True
+    assert j["mib_locks_per_block"] == want
     assert subprocess.run([os.path.join(ROOT, "host", "TrackBench")], capture_output=True, text=True).returncode == 2
