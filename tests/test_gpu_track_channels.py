@@ -124,3 +124,43 @@ def test_track_block_of_all_scenes_in_one_call_equals_the_single_calls(pkg, bloc
                     assert np.array_equal(both["meas"][i, p, :n], one["meas"][0, p, :n]), (tag, p)
                     assert np.array_equal(both["ce"][i, p, :u], one["ce"][0, p, :u]), (tag, p)
                     assert np.array_equal(both["ce_pw"][i, p, :u], one["ce_pw"][0, p, :u]), (tag, p)
+
+
+@pytest.mark.parametrize("n_sym", [1, 6, 7, 121, 139, 140, 141, 500, 839])
+def test_track_block_of_any_length_with_both_cp_types_in_one_call(pkg, blocks, n_sym):
+    """Blocks that are not a whole number of frames -- one symbol, one slot less a symbol, a frame plus one -- and a normal-CP and an
+    extended-CP cell (140 / 120 symbols per frame: different reference-symbol lists, different numbers of PBCH offsets) in ONE call:
+    every array of each cell against the oracle on its own truncated block."""
+    grp = [blocks[1], blocks[3]]                       # EVA 70 Hz 2 ports normal CP; ETU 70 Hz 2 ports extended CP (both nominal parameters)
+    assert grp[0]["per_frame"] == 140 and grp[1]["per_frame"] == 120 and grp[0]["fcp"] == FC and grp[1]["fcp"] == FC
+    cut = [dict(b, td=b["td"][:n_sym], late=b["late"][:n_sym], ftv=b["ftv"][:n_sym], fov=b["fov"][:n_sym]) for b in grp]
+    with pkg.Searcher(0) as S:
+        g = S.track_block([b["c"] for b in cut], np.stack([b["td"] for b in cut]), np.stack([b["fov"] for b in cut]), np.stack([b["ftv"] for b in cut]),
+                          np.stack([b["late"] for b in cut]), FC, FC, FS)
+    for i, b in enumerate(cut):
+        r = _oracle_block(b)
+        tag = (n_sym, b["tag"])
+        assert np.abs(g["syms"][i] - r["syms"]).max() < 1e-11 * np.abs(r["syms"]).max(), tag
+        assert abs(g["bpo"][i] - r["bpo"]) < 1e-9, tag
+        assert np.array_equal(g["n_meas"][i], r["n_meas"]) and np.array_equal(g["ce_upto"][i], r["ce_upto"]), (tag, g["n_meas"][i], r["n_meas"], g["ce_upto"][i], r["ce_upto"])
+        for p in range(b["c"].n_ports):
+            n, u = r["n_meas"][p], r["ce_upto"][p]
+            if n:
+                gm, om = g["meas"][i, p, :n], r["meas"][p, :n]
+                assert np.array_equal(gm[:, 0], om[:, 0]) and np.abs(gm[:, 1:5] - om[:, 1:5]).max() < 1e-11 * om[:, 2].max(), (tag, p)
+                assert np.abs(gm[:, 5] - om[:, 5]).max() < 1e-6 and np.abs(gm[:, 7] - om[:, 7]).max() < 1e-8, (tag, p)
+            if u:
+                assert np.abs(g["ce"][i, p, :u] - r["ce"][p, :u]).max() < 1e-11 * np.abs(r["ce"][p, :u]).max(), (tag, p)
+        # a frame offset is attempted as soon as the block holds the PBCH symbols of its four frames and their channel estimates --
+        # the fourth frame need not be complete (the reference decodes when the fourth frame's PBCH symbols have arrived,
+        # src/tracker_thread.cpp:552-745)
+        per_frame, nsd = b["per_frame"], b["per_frame"] // 20
+        upto = int(min(r["ce_upto"][:b["c"].n_ports]))
+        for o in range(g["mib_ok"].shape[1]):
+            ii = [(o + fr) * per_frame + nsd + s for fr in range(4) for s in range(4)]
+            if ii[-1] >= upto:
+                assert g["mib_ok"][i, o] == -1, (tag, o)
+                continue
+            m = O.trk_mib(b["c"], r["syms"][ii], r["ce"][:b["c"].n_ports][:, ii], r["ce_pw"][:b["c"].n_ports][:, ii, 3])
+            assert g["mib_ok"][i, o] == (1 if m[1] else 0) | (2 if m[2] else 0), (tag, o)
+            assert [(int(g["mib_bits"][i, o]) >> k) & 1 for k in range(40)] == list(m[0]), (tag, o)
