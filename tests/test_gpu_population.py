@@ -70,3 +70,59 @@ def test_population_on_wide_grids_has_no_disagreement(tmp_path):
     sa = j["stage_arrays"]
     assert sa["cells_compared"] == t["cells"] and sa["disagreements"] == 0
     assert r.returncode == 0
+
+
+def test_streaming_mode_on_fading_channels():
+    """BASELINE configs[4] (the searcher thread's loop, src/searcher_thread.cpp:83-246: one buffer at a time, ONE frequency hypothesis,
+    the hipGraph-captured chain, two buffers in flight) on the `channels` population's scenes: six scenes x four noise realisations,
+    pushed two at a time, every collected cell against the oracle's chain with the same single hypothesis; then the same buffers with
+    the decoded identities handed over as already tracked (:157-177): no cell comes back, each is counted as seen again."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as O
+    import parity_population as P
+    import __graft_entry__ as ge
+    pkg = ge.load_package()
+    O.set_legacy(False)
+    O.set_threads(min(16, os.cpu_count() or 1))
+    INT = ("ind", "n_id_2", "n_id_1", "cp_type", "n_ports", "n_rb_dl", "phich_duration", "phich_resource", "sfn")
+    n_cells = n_dup = 0
+    with pkg.Searcher(0) as S:
+        for s in (0, 2, 3, 5, 7, 11):
+            sc = P.channel_scene(pkg.synth, s)
+            f_hyp = float(5e3 * np.round(sc["planted"][0]["f_off"] / 5e3))                 # the tracked frequency offset, on the searcher's raster
+            bufs = []
+            for v in (1, 3, 4, 5):
+                rng = np.random.default_rng(95_000 + 8 * s + v)
+                sig = np.roll(sc["sig"], int(rng.integers(0, P.N_CAP)))
+                bufs.append(pkg.synth.add_noise_and_quantise(rng, sig, sc["ref_pow"], P.CH_SNRS[v], rms=float(rng.uniform(0.08, 0.22)), front_end=sc["front_end"]))
+            exp = []
+            for b in bufs:
+                x = b.astype(np.float64)
+                cap = ((x[0::2] - 127.0) / 128.0) + 1j * ((x[1::2] - 127.0) / 128.0)
+                exp.append(O.search_capbuf(cap, np.array([f_hyp]), sc["fc_req"], sc["fc_prog"], sc["fs_prog"])[0])
+            S.stream_open(pkg.FMT_IQ_U8, P.N_CAP, sc["fc_req"], sc["fc_prog"], sc["fs_prog"])
+            got = []
+            for k in (0, 2):                                                                 # two buffers in flight
+                S.stream_push(bufs[k], f_hyp)
+                S.stream_push(bufs[k + 1], f_hyp)
+                got.append(S.stream_collect())
+                got.append(S.stream_collect())
+            for k, ((cells, dup, _), e) in enumerate(zip(got, exp)):
+                tag = f"scene {s} buffer {k}"
+                assert [tuple(getattr(c, f) for f in INT) for c in cells] == [tuple(getattr(c, f) for f in INT) for c in e], tag
+                assert dup == 0, tag
+                for a, b in zip(cells, e):
+                    assert abs(a.frame_start - b.frame_start) < 1e-6 and abs(a.freq_superfine - b.freq_superfine) < 1e-3 and abs(a.pss_pow - b.pss_pow) <= 1e-5 * b.pss_pow, tag
+                n_cells += len(e)
+            # the decoded identities as tracked cells: skipped (not decoded again), counted
+            for k in (0, 1):
+                ids = [c.n_id_cell() for c in exp[k]]
+                S.stream_push(bufs[k], f_hyp, tracked=ids)
+                cells, dup, _ = S.stream_collect()
+                assert cells == [] or all(c.n_id_cell() not in ids for c in cells), (s, k)
+                assert dup >= len(set(ids)), (s, k, dup, ids)
+                n_dup += dup
+            S.stream_close()
+    assert n_cells >= 12 and n_dup >= 6
