@@ -315,7 +315,9 @@ int lcs_foe_resolve(lcs_ctx *ctx, void *d_words, const void *d_words2);
  * lcs_stream_push copies the HOST buffer (fmt LCS_FMT_C64: n_cap complex<float>, LCS_FMT_IQ_U8: 2*n_cap bytes) into
  * pinned memory and replays the graph asynchronously -- up to TWO buffers may be in flight, so the host fills and
  * launches buffer i + 1 while buffer i is on the GPU; lcs_stream_collect waits for the OLDEST buffer in flight and
- * returns its NEW cells (SSS and MIB decoded), the number of tracked cells seen again and the GPU time of the pass.
+ * returns its NEW cells (SSS and MIB decoded; one record per identity -- the first decoded peak in peak order, as the reference's
+ * loop keeps it: it appends a decoded cell to the tracked list at once, :233-236, so later peaks of the same identity in the same
+ * buffer count as seen again), the number of tracked cells seen again and the GPU time of the pass.
  * frame_start is in samples of the pushed buffer; the tracker's 1.92 MHz time base is
  * frame_start*(FS_LTE/16)/(fs_programmed*k_factor) + capture latency (:224).
  * While a stream is open the captured graph holds the context's workspace addresses: any other call on the

@@ -1260,14 +1260,25 @@ int lcs_stream_collect(lcs_ctx *c, lcs_cell *cells, int max_cells, int *n_cells,
   int rc = LCS_OK, n = 0;
   const int np = std::min(h->n_peaks, (int)LCS_MAXP);
   if (h->n_peaks > LCS_MAXP || h->n_work[1] > std::min(c->max_work, c->percell_cap)) rc = LCS_ERR_OVERFLOW;
+  // The reference appends a decoded cell to the tracked list AT ONCE (ref src/searcher_thread.cpp:233-236), so a later peak of the
+  // same buffer that sss_detect gives the same identity -- a second path of a fading channel, a sidelobe -- meets "already being
+  // tracked" (:157-177) before anything else is done with it.  The chain here decodes every peak in parallel; in peak order the
+  // first decoded record of an identity is the one the reference keeps, the later peaks of that identity count as seen again.
+  int seen[LCS_MAXP], n_seen = 0, again = 0;
   for (int i = 0; i < np; ++i) {
     const lcs_cell &pc = h->res[i];
-    if (pc.n_id_1 == -1 || pc.n_rb_dl == -1) continue;     // no SSS / no MIB / already tracked (never decoded)
+    if (pc.n_id_1 == -1) continue;                          // no SSS
+    const int id = pc.n_id_2 + 3 * pc.n_id_1;
+    bool known = false;
+    for (int q = 0; q < n_seen; ++q) known = known || seen[q] == id;
+    if (known) { ++again; continue; }
+    if (pc.n_rb_dl == -1) continue;                         // no MIB / tracked before this buffer (never decoded: counted on the device)
     if (n < max_cells) cells[n] = pc; else rc = LCS_ERR_OVERFLOW;
     ++n;
+    seen[n_seen++] = id;
   }
   *n_cells = n;
-  if (n_redetected) *n_redetected = h->n_work[2];
+  if (n_redetected) *n_redetected = h->n_work[2] + again;
   if (rc) c->err = "more results than the output array holds";
   return rc;
 }

