@@ -151,3 +151,87 @@ def mib_lock_walk(mib_ok, failures: float = 0.0, synchronized: bool = False, dro
         if failures >= drop_threshold:
             return failures, synchronized, attempts, True
     return failures, synchronized, attempts, False
+
+
+class DeviceTracker:
+    """LTE-Tracker's producer thread + tracker threads as ONE data path with the samples on the device (round 6).
+
+    The reference (src/producer_thread.cpp, src/tracker_thread.cpp) moves every sample through a fifo, cuts each tracked cell's
+    OFDM symbols out on the host and queues them to that cell's thread.  Here the dongle's bytes go up once per buffer (0.3 MB per
+    80 ms) and stay in HBM: `push` appends a buffer to the stream, cuts the symbols of all tracked cells there (Searcher.track_cut,
+    continuing from the previous buffer: timestamp of the first kept sample, next symbol, next search position per cell -- the tail
+    of the previous buffer is kept so that a capture its end cut off is whole), runs the tracker block on them where they lie
+    (Searcher.track_stream_block on the device pointer) and folds the measurements into the two slow loops the reference closes
+    around the producer: the GLOBAL frequency offset (one crystal: do_foe's recurrence over every cell's rows, src/tracker_thread.cpp:
+    235-242; it sets the time base's step, src/producer_thread.cpp:99, 127) and every cell's frame timing (do_toe_v2, :283-287).
+
+    cells: searcher records (n_id_1/2, cp_type, n_ports, n_rb_dl, PHICH fields); frame_timing [n_cells] on the 1.92 MHz time base
+    (frame_start * (FS_LTE/16) / (fs_programmed * k_factor), src/searcher_thread.cpp:224); frequency_offset: the global one.
+    feedback=False holds both (a recorded buffer replayed open loop).  Needs torch for the device buffers (plumbing)."""
+
+    KEEP = 512      # samples kept behind the last complete capture at least (a capture is 128 samples, a window opens < 4 samples wide)
+
+    def __init__(self, searcher, cells, frame_timing, frequency_offset, fc_requested, fc_programmed, fs_programmed, device=0, feedback=True):
+        import torch
+        self._torch, self.S, self.cells = torch, searcher, list(cells)
+        self.dev = torch.device("cuda", device)
+        self.fc, self.fcp, self.fsp, self.feedback = float(fc_requested), float(fc_programmed), float(fs_programmed), bool(feedback)
+        self.frame_timing = np.array(frame_timing, np.float64).reshape(len(self.cells))
+        self.frequency_offset = float(frequency_offset)
+        self.cp = np.array([int(c.cp_type) for c in self.cells], np.int32)
+        self.ts_first = 0.0                                        # timestamp of the first sample of the kept buffer
+        self.sym_next = np.zeros(len(self.cells), np.int64)        # next symbol of each cell (counted from slot 0 symbol 0 of the stream's first frame)
+        self.pos_next = np.zeros(len(self.cells), np.int64)        # ... and where its search starts in the kept buffer
+        self._buf = torch.empty(0, dtype=torch.uint8, device=self.dev)
+        self._td = None
+        self.mib_codes = [[] for _ in self.cells]
+        self.lock = [(0.0, False, 0, False) for _ in self.cells]
+        self.symbols_done = 0
+        searcher.track_stream_reset()
+
+    def _step(self):
+        return (FS_LTE / 16) / (self.fsp * ((self.fc - self.frequency_offset) / self.fcp))
+
+    def push(self, iq_u8, want_ce=False):
+        """iq_u8: the next bytes of the stream (2 per sample), a host array or a torch uint8 tensor already on the device.
+        Returns None when no cell has a complete symbol yet, else the dict of Searcher.track_stream_block for the symbols cut from
+        the stream so far (+ 'n_sym', 'late'); the loops (frequency_offset, frame_timing, lock) are updated on the object."""
+        torch = self._torch
+        new = iq_u8 if isinstance(iq_u8, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(iq_u8, np.uint8))
+        self._buf = torch.cat([self._buf, new.to(self.dev).reshape(-1)])
+        n_cap = self._buf.numel() // 2
+        if n_cap < 128:
+            return None
+        C_ = len(self.cells)
+        fo = np.full(C_, self.frequency_offset)
+        probe = n_cap // 137 + 2
+        if self._td is None or self._td.shape[1] < probe:
+            self._td = torch.empty((C_, probe, 128), dtype=torch.complex128, device=self.dev)
+        cut = lambda n: self.S.track_cut(self._buf.data_ptr(), 1, n_cap, self.cp, self.frame_timing, fo, self.fc, self.fcp, self.fsp, n,
+                                         self._td.data_ptr(), ts_first=self.ts_first, sym_first=self.sym_next, pos_first=self.pos_next, want_state=True)
+        _, n_cut, _ = cut(probe)
+        n = int(n_cut.min())                                       # the block moves all cells by the same number of symbols
+        out = None
+        pos_next = self.pos_next
+        if n > 0:
+            late, _, pos_next = cut(n)                             # [cell][n][128] contiguous; pos_next = behind symbol n - 1 of every cell
+            out = self.S.track_stream_block(self.cells, None, np.repeat(fo[:, None], n, 1), np.repeat(self.frame_timing[:, None], n, 1), late[:, :n],
+                                            self.fc, self.fcp, self.fsp, want_syms=False, want_ce=want_ce, td_device_ptr=self._td.data_ptr())
+            out["n_sym"], out["late"] = n, late[:, :n]
+            self.sym_next = self.sym_next + n
+            self.symbols_done += n
+            for i in range(C_):
+                self.mib_codes[i] += [int(v) for v in out["mib_ok"][i, :out["n_mib"][i]]]
+                self.lock[i] = mib_lock_walk(np.array(self.mib_codes[i], np.int32)) if self.mib_codes[i] else self.lock[i]
+            if self.feedback:
+                for i in range(C_):                                # port 0's filtered reference symbols drive the loops
+                    m = out["meas"][i, 0, :out["n_meas"][i, 0]]
+                    self.frequency_offset = fold_frequency_offset(self.frequency_offset, m)
+                    self.frame_timing[i] = fold_frame_timing(self.frame_timing[i], m)
+        # drop what every cell is done with, keep the tail; the time base moved on with the step in force while the samples were stamped
+        adv = int(max(0, min(int(pos_next.min()), n_cap - self.KEEP)))
+        step = (FS_LTE / 16) / (self.fsp * ((self.fc - fo[0]) / self.fcp))
+        self.ts_first = float(wrap(self.ts_first + adv * step, 0.0, 19200.0))
+        self.pos_next = pos_next - adv
+        self._buf = self._buf[2 * adv:].clone()
+        return out

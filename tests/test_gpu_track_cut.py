@@ -158,3 +158,54 @@ def test_cut_rejects_bad_arguments(pkg):
                 S.track_cut(d.data_ptr(), a["fmt"], a["n_cap"], a["cps"], a["fts"], [0.0], FC, FC, a["fsp"], 4, td.data_ptr())
         late, n_cut = S.track_cut(d.data_ptr(), pkg.FMT_IQ_U8, 2048, [1], [0.0], [0.0], FC, FC, FS, 4, td.data_ptr())
         assert n_cut[0] == 4 and np.all(np.abs(late[0]) < 0.5)
+
+
+def test_device_tracker_from_bytes_in_chunks(pkg):
+    """tracker.DeviceTracker: the producer + tracker data path with the samples on the device.  The recorded capture's BYTES pushed
+    as five chunks (cut anywhere, not at symbol or frame boundaries), both cells tracked open loop (feedback off): the measurement
+    rows and MIB attempts that come out over the pushes are those of the host path on the whole capture -- symbols cut by
+    tracker.cut_symbols, ONE Searcher.track_stream_block call -- to 1e-9 (the chunks' timestamp origins round differently: `late`
+    moves by 1e-12 samples); then closed loop: both cells lock and the global frequency offset stays with the searcher's estimate."""
+    iq = golden("capbuf_0000")["iq_u8"]
+    cap = iq_u8_to_capbuf(iq)
+    O.set_legacy(False)
+    O.set_threads(8)
+    cells, _ = O.search_capbuf(cap, np.array([30e3, 35e3, 40e3]), FC, FC, FS)
+    cells = [pkg.new_cell(**c.as_dict()) for c in cells]
+    fo = float(cells[0].freq_superfine)                                    # one crystal: the global frequency offset
+    fts = [c.frame_start * (30.72e6 / 16) / (FS * ((FC - fo) / FC)) for c in cells]
+    # the host path on the whole capture
+    host = [pkg.tracker.cut_symbols(cap, fts[i], cells[i].cp_type, fo, FC, FC, FS, 10 ** 6) for i in range(2)]
+    n_all = min(h[0].shape[0] for h in host)
+    with pkg.Searcher(0) as S:
+        S.track_stream_reset()
+        ref = S.track_stream_block(cells, np.stack([h[0][:n_all] for h in host]), np.full((2, n_all), fo), np.repeat(np.array(fts)[:, None], n_all, 1),
+                                   np.stack([h[1][:n_all] for h in host]), FC, FC, FS, want_syms=False, want_ce=False)
+    with pkg.Searcher(0) as S:
+        T = pkg.tracker.DeviceTracker(S, cells, fts, fo, FC, FC, FS, feedback=False)
+        cuts = [0, 51234, 120001, 170002, 260000, iq.size]                 # bytes; even offsets = whole samples
+        meas = [[], []]
+        mib = [[], []]
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            o = T.push(iq[a:b])
+            if o is None:
+                continue
+            for i in range(2):
+                meas[i].append(o["meas"][i, 0, :o["n_meas"][i, 0]])
+                mib[i] += [int(v) for v in o["mib_ok"][i, :o["n_mib"][i]]]
+        assert n_all - 2 <= T.symbols_done <= n_all      # (the block moves both cells by the same number of symbols: the later cell's last one may wait)
+        for i in range(2):
+            got = np.concatenate(meas[i])
+            want = ref["meas"][i, 0, :ref["n_meas"][i, 0]]
+            n = got.shape[0]
+            assert n >= want.shape[0] - 2 and np.array_equal(got[:, 0], want[:n, 0])
+            assert np.abs(got[:, 1:5] - want[:n, 1:5]).max() < 1e-9 * want[:, 2].max()
+            assert np.abs(got[:, 5] - want[:n, 5]).max() < 1e-4 and np.abs(got[:, 7] - want[:n, 7]).max() < 1e-6              # Hz, samples
+            assert mib[i] == [int(v) for v in ref["mib_ok"][i, :ref["n_mib"][i]]][:len(mib[i])] and 3 in mib[i]
+            assert T.lock[i][1], i                                          # synchronised
+    with pkg.Searcher(0) as S:
+        T = pkg.tracker.DeviceTracker(S, cells, fts, fo, FC, FC, FS, feedback=True)
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            T.push(iq[a:b])
+        assert all(l[1] for l in T.lock)
+        assert abs(T.frequency_offset - fo) < 200.0 and np.all(np.abs(pkg.tracker.wrap(T.frame_timing - np.array(fts), -9600.0, 9600.0)) < 2.0)
