@@ -597,8 +597,9 @@ __global__ __launch_bounds__(64) void k_trk_sync(const lcs_track_cell *__restric
 
 // ----------------------------------------------------------------------------------- the producer thread's symbol cutter
 // LTE-Tracker's producer thread (src/producer_thread.cpp:96-131) stamps every sample of the dongle's stream with a time on the
-// cell-independent 1.92 MHz time base -- sample n of a buffer whose first sample has timestamp 0: WRAP(n step, 0, 19200), step =
-// (FS_LTE / 16) / (fs_programmed k_factor) -- and, per tracked cell (:196-246), starts a 128-sample capture at the first sample
+// cell-independent 1.92 MHz time base -- sample n of a buffer whose first sample has timestamp ts0: WRAP(ts0 + n step, 0, 19200), step =
+// (FS_LTE / 16) / (fs_programmed k_factor); a call cuts the symbols k0, k0 + 1, .. of each cell searching from its sample pos0 (a buffer
+// cut from its start: 0, 0, 0; a later buffer of the stream: the state the previous call returned) -- and, per tracked cell (:196-246), starts a 128-sample capture at the first sample
 // at or after the end of the previous capture whose
 //     tdiff = WRAP(timestamp - (frame_timing + target), -9600, 9600)   satisfies   |tdiff| < 0.5  or  0 < tdiff < 3      (:203-213)
 // with target = 10 (normal CP) / 32 (extended) for slot 0 symbol 0 and advancing by 137 / 138 / 160 per symbol (:236-241);
