@@ -429,7 +429,7 @@ def compare(it, g, o):
                      frq_near_ties_1e_6=int(np.count_nonzero(o["frq_margin"] < 1e-6)), frq_min_margin=float(o["frq_margin"].min()))
 
 
-def run(groups=("synthetic", "bench", "dense"), limit=None, workers=None, out_path=None, quiet=False, dense_limit=None, seed_offset=0, input_fmt="u8"):
+def run(groups=("synthetic", "bench", "dense"), limit=None, workers=None, out_path=None, quiet=False, dense_limit=None, seed_offset=0, input_fmt="u8", batch=128):
     t_start = time.perf_counter()
     workers = workers or max(1, min(len(os.sched_getaffinity(0)), 32))
     # the oracle's worker processes start BEFORE this process touches the GPU runtime (fork of a process with live HIP threads is unsafe)
@@ -439,7 +439,7 @@ def run(groups=("synthetic", "bench", "dense"), limit=None, workers=None, out_pa
     items = build_population(pkg, groups, limit, dense_limit, seed_offset, pool)
     t_built = time.perf_counter()
     res_async = pool.imap(oracle_job, items, chunksize=1)
-    gpu, n_repairs, t_gpu, kernels = gpu_pass(pkg, items, input_fmt=input_fmt)
+    gpu, n_repairs, t_gpu, kernels = gpu_pass(pkg, items, batch=batch, input_fmt=input_fmt)
     # results are taken as they arrive: the stage arrays of the `channels` group (a few MB per decoded cell) are compared through
     # the GPU's stage entry points at once and dropped
     orc, arr_dis, arr_cells = [], [], 0
@@ -481,7 +481,7 @@ def run(groups=("synthetic", "bench", "dense"), limit=None, workers=None, out_pa
         by_stage[d["stage"]] = by_stage.get(d["stage"], 0) + 1
     report = dict(
         what="GPU chain (lcs_batch_enqueue / _collect / _readback) against oracle/lcs_oracle.c on the same capture buffers",
-        groups=list(groups), seed_offset=seed_offset, input=input_fmt, correlation_kernels=kernels,
+        groups=list(groups), seed_offset=seed_offset, input=input_fmt, correlation_kernels=kernels, buffers_per_batch=batch,
         totals=tot, per_group=per_group, disagreements=len(all_dis), disagreements_by_stage=by_stage,
         disagreement_rate_per_buffer=len(all_dis) / max(1, tot["buffers"]),
         gpu_frq_positions_repaired=n_repairs,
@@ -511,7 +511,8 @@ if __name__ == "__main__":
     ap.add_argument("--workers", type=int, default=None)
     ap.add_argument("--seed-offset", type=int, default=0, help="other synthetic scenes and noise realisations (the bench's and the dense band's buffers are fixed)")
     ap.add_argument("--input", default="u8", choices=("u8", "c64"), help="c64: the same samples as complex<float> batches (the fp16 three-product kernel)")
+    ap.add_argument("--batch", type=int, default=128, help="buffers per lcs_batch_enqueue call (any number: 1, an odd one, more than 128)")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "parity_population.json"))
     a = ap.parse_args()
-    r = run(tuple(a.groups.split(",")), a.limit, a.workers, a.out, dense_limit=a.dense_limit, seed_offset=a.seed_offset, input_fmt=a.input)
+    r = run(tuple(a.groups.split(",")), a.limit, a.workers, a.out, dense_limit=a.dense_limit, seed_offset=a.seed_offset, input_fmt=a.input, batch=a.batch)
     sys.exit(0 if r["disagreements"] == 0 else 1)
