@@ -639,6 +639,9 @@ def main():
     ap.add_argument("--input", choices=["u8", "c64"], default="u8",
                     help="resident input format: raw RTL-SDR u8 I/Q (int8 MFMA correlation kernel, default) or complex<float> "
                          "(fp16 three-product MFMA correlation kernel)")
+    ap.add_argument("--c64-probe", action="store_true",
+                    help="with --input c64: lcs_set_float_batch_probe -- the batches (dongle data held as complex<float>) are recognised on the "
+                         "device and take the u8 / int8 route; without it --input c64 measures the fp16 kernel")
     ap.add_argument("--pipeline", type=int, default=None,
                     help="contexts (streams + workspaces) used round-robin: the latency-bound per-cell "
                          "stages of batch i overlap the PSS correlation of batch i+1")
@@ -737,6 +740,9 @@ def main():
         d_caps = [torch.view_as_complex(((x.to(torch.float32) - 127.0) / 128.0).view(B, N_CAP, 2).contiguous()) for x in d_caps]
     torch.cuda.synchronize()
     ctxs = [pkg.Searcher(local_rank if multi else 0) for _ in range(max(1, args.pipeline))]
+    if args.c64_probe and hasattr(pkg.capi.load(), "lcs_set_float_batch_probe"):
+        for x in ctxs:
+            x.set_float_batch_probe(True)
     MAXC = 16
     # one fixed-size record block per step for the all-gather: [n, then n x (n_id_cell, fc, f_off, pss_pow, sfn)]
     MAXREC = max(64, B) * K
@@ -993,6 +999,7 @@ def main():
                                    f"fc {args.fc / 1e6:g} MHz + 100 kHz raster, +-{args.ppm:g} ppm, {D} distinct resident batches",
                        "n_f": int(n_f), "batch_per_gpu": B, "batches_per_step": K, "buffers_per_step_per_gpu": B * K,
                        "buffers_timed": n_buffers, "timed_region_s": dt, "stage": args.stage,
+                       "float_batch_probe": bool(args.c64_probe),
                        "ingest": ("u8 I/Q in page-locked host memory, PCIe copy of every batch inside the timed region" if args.input_host else
                                   "u8 I/Q resident in HBM") if fmt == pkg.FMT_IQ_U8 else "complex<float> resident in HBM",
                        "xcorr_kernel": "mfma_i32_16x16x64_i8, three int8 digits per 24-bit integer template tap" if i8 else

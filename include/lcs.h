@@ -106,6 +106,15 @@ void lcs_cell_init(lcs_cell *c);                      /* src/common.cpp:36-56 */
  * lcs_batch_collect launches the rest if the device-side count says the batch had more.  Results do not depend on it and
  * no batch is truncated. */
 int lcs_set_max_cells_in_flight(lcs_ctx *ctx, int n);
+/* complex<float> BATCHES that are dongle data.  A float pipeline in front of the searcher often still carries RTL-SDR samples --
+ * every component exactly (u8 - 127) / 128 (src/capbuf.cpp:172-181).  The host entry points recognise such data in complex<double> by
+ * themselves and correlate the bytes (int8 kernel); for device-resident LCS_FMT_C64 batches the same check is opt-in, because it costs
+ * lcs_batch_enqueue a host synchronisation: with on != 0 every such batch is first checked on the device (one pass that also writes the
+ * bytes; the host waits for the verdict while the other contexts' kernels keep the GPU busy) and, if every component of every buffer
+ * is on the 8-bit grid, takes the u8 route from there -- the same numbers through the int8 kernel (1.4 x the fp16 kernel's rate) and
+ * the caller's buffer is not read again after the call returns; anything else takes the fp16 kernel as before (and the next fifteen
+ * batches of the context are not checked).  Off by default.  Results do not depend on it. */
+int lcs_set_float_batch_probe(lcs_ctx *ctx, int on);
 
 /* ---- stage entry points (host buffers in / out) ------------------------------------ */
 

@@ -358,6 +358,11 @@ class Searcher:
         out["gpu_ms"] = ms.value
         return out
 
+    def set_float_batch_probe(self, on: bool):
+        """complex<float> batches (FMT_C64) are checked for dongle data on the device and then take the u8 / int8 route
+        (lcs_set_float_batch_probe, include/lcs.h); off by default."""
+        self._chk(self._lib.lcs_set_float_batch_probe(self._h, 1 if on else 0), "lcs_set_float_batch_probe")
+
     def track_cut(self, d_capbuf_ptr, fmt, n_cap, cp_types, frame_timing, freq_off, fc_requested, fc_programmed, fs_programmed, n_sym,
                   d_td_ptr, ts_first=0.0, sym_first=None, pos_first=None, want_state=False):
         """The producer thread's symbol extraction on the device (lcs_track_cut, src/producer_thread.cpp:96-131, 196-246): the

@@ -62,7 +62,7 @@ class LcsTrackCell(C.Structure):
 
 
 EXPORTS = [
-    "lcs_create", "lcs_destroy", "lcs_last_error", "lcs_version", "lcs_cell_init", "lcs_set_max_cells_in_flight",
+    "lcs_create", "lcs_destroy", "lcs_last_error", "lcs_version", "lcs_cell_init", "lcs_set_max_cells_in_flight", "lcs_set_float_batch_probe",
     "lcs_xcorr_pss", "lcs_peak_search", "lcs_sss_detect", "lcs_pss_sss_foe", "lcs_extract_tfg", "lcs_tfoec",
     "lcs_decode_mib", "lcs_chan_est", "lcs_search_capbuf", "lcs_search_batch_dev", "lcs_search_batch_host", "lcs_batch_enqueue",
     "lcs_batch_collect", "lcs_batch_readback", "lcs_batch_enqueue_host", "lcs_host_alloc", "lcs_host_free", "lcs_device_alloc", "lcs_device_free", "lcs_device_upload", "lcs_device_count",
@@ -140,6 +140,8 @@ def load() -> C.CDLL:
     L.lcs_track_stream_block.argtypes = [vp, C.POINTER(LcsTrackCell), C.c_int, C.c_int, vp, dp, dp, dp, C.c_double, C.c_double, C.c_double,
                                          dp, dp, dp, C.c_int, i64p, ip, dp, dp, dp, C.c_int, ip, ip, C.POINTER(C.c_uint64), C.c_int, i64p, ip]
     L.lcs_track_stream_reset.argtypes = [vp]
+    if hasattr(L, "lcs_set_float_batch_probe"):
+        L.lcs_set_float_batch_probe.argtypes = [vp, C.c_int]
     if hasattr(L, "lcs_track_cut"):
         L.lcs_track_cut.argtypes = [vp, vp, C.c_int, C.c_uint32, C.c_double, C.c_int, ip, dp, dp, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
                                     C.c_double, C.c_double, C.c_double, C.c_int, vp, dp, ip, C.POINTER(C.c_int64)]

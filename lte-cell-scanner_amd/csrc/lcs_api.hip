@@ -261,6 +261,28 @@ XcGeom pack_grid(uint32_t n_cap, int n_f, int ds, const double *fset, const doub
 constexpr int kMaxTapsI8 = LCS_I8_MAX_TAPS;                               // int8 kernel: 137 taps + delays below LCS_I8_OFF (the fp16 kernel holds 160)
 constexpr int kMaxTapsF32 = 2 * (LCS_KP2_MAX - LCS_KP2_UNROLL);          // fp32 kernel: 124 tap pairs
 
+// lcs_set_float_batch_probe: is a batch of complex<float> buffers dongle data -- every component exactly (u8 - 127) / 128 (ref
+// src/capbuf.cpp:172-181)?  One pass: the byte each component would have come from, and whether it reproduces the component exactly
+// (x 128 + 127 is exact in fp32 for such values; NaN, infinities and anything off the 8-bit grid fail).  The bytes are then handed to
+// the u8 route unchanged (int8 copies, int8 correlation kernel, the fp64 stages on the int8 pairs): the same numbers, the faster kernel.
+__global__ __launch_bounds__(256) void k_c64_probe_u8(const float *__restrict__ src, size_t n_comp, uint8_t *__restrict__ dst, int *__restrict__ flag) {
+  bool ok = true;
+  for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n_comp; i += (size_t)gridDim.x * blockDim.x * 4) {
+    const float4 x = *reinterpret_cast<const float4 *>(src + i);      // (n_comp = 2 n_cap n_buf is a multiple of 4 for the batch shapes the library takes: checked by the caller)
+    const float v[4] = {x.x * 128.0f + 127.0f, x.y * 128.0f + 127.0f, x.z * 128.0f + 127.0f, x.w * 128.0f + 127.0f};
+    uchar4 b;
+    unsigned char *pb = reinterpret_cast<unsigned char *>(&b);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float r = rintf(v[q]);
+      ok = ok && v[q] == r && r >= 0.0f && r <= 255.0f;
+      pb[q] = (unsigned char)(int)fminf(fmaxf(r, 0.0f), 255.0f);
+    }
+    *reinterpret_cast<uchar4 *>(dst + i) = b;
+  }
+  if (__any(!ok) && (threadIdx.x & 63) == 0) atomicAnd(flag, 0);
+}
+
 // complex<double> host buffer -> device (cap64, slot 0) and the choice of the correlation kernel: a buffer whose every
 // component is exactly (u8 - 127) / 128 -- any dongle capture -- takes the int8 kernel, anything else the fp32 one.
 // Returns the geometry to correlate with; c->use_i8 is set accordingly.
@@ -388,7 +410,7 @@ void lcs_destroy(lcs_ctx *c) {
                   c->cells_out, c->d_pss_td, c->d_pss_fd, c->d_sss_fd, c->d_pbch_scr, c->d_derm_inv, c->d_dbg, c->pk_items, c->n_pk,
                   c->sss_ws, c->d_pn_jump, c->cap8, c->cap8s, c->brow8, c->tq, c->tsc, c->cap16h, c->cap16l, c->brow16, c->texp16, c->tsc16, c->xmax16, c->xpart16, c->h2d, c->trk_td, c->trk_syms, c->trk_raw, c->trk_ce,
                   c->trk_meta, c->trk_rs, c->trk_fmeta, c->trk_pw, c->trk_idx, c->trk_small, c->trk_cells, c->trk_acfd, c->trk_actd,
-                  c->trk_syncce, c->trk_sync, c->d_flag, c->trk_cut_hit, c->trk_cut_meta};
+                  c->trk_syncce, c->trk_sync, c->d_flag, c->trk_cut_hit, c->trk_cut_meta, c->c64_u8};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   if (c->h_pinned) (void)hipHostFree(c->h_pinned);
   if (c->res_pack) (void)hipFree(c->res_pack);
@@ -408,6 +430,13 @@ void lcs_destroy(lcs_ctx *c) {
 }
 
 const char *lcs_last_error(const lcs_ctx *c) { return c ? c->err.c_str() : "null context"; }
+
+int lcs_set_float_batch_probe(lcs_ctx *c, int on) {
+  if (!c) return LCS_ERR_BAD_ARG;
+  c->c64_probe = on != 0;
+  c->c64_skip = 0;
+  return LCS_OK;
+}
 
 int lcs_set_max_cells_in_flight(lcs_ctx *c, int n) {
   if (!c || n < 1) return LCS_ERR_BAD_ARG;
@@ -525,6 +554,30 @@ int lcs_batch_enqueue(lcs_ctx *c, const void *d_capbufs, int fmt, int n_buf, uin
   HIPCHK(c, hipMemcpyAsync(c->params, hp, sizeof(SlotParams) * n_buf, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->fset, hf, sizeof(double) * n_f, hipMemcpyHostToDevice, c->stream));
   c->cap64_valid = false;
+  // lcs_set_float_batch_probe: a complex<float> batch that is dongle data becomes the u8 batch it came from (one pass + one small
+  // read-back: the host waits for it -- while the other contexts' kernels keep the GPU busy -- before it knows which kernels to queue)
+  c->last_c64_routed = false;
+  if (fmt == LCS_FMT_C64 && c->c64_probe && (c->i8_ready || !c->st_open) && ((size_t)n_buf * n_cap) % 2 == 0 && (reinterpret_cast<uintptr_t>(d_capbufs) & 15) == 0) {
+    if (c->c64_skip > 0) --c->c64_skip;
+    else {
+      const size_t n_comp = (size_t)2 * n_cap * n_buf;
+      if (n_comp > c->c64_u8_bytes) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->c64_u8) (void)hipFree(c->c64_u8);
+        c->c64_u8 = nullptr; c->c64_u8_bytes = 0;
+        HIPCHK(c, hipMalloc((void **)&c->c64_u8, n_comp));
+        c->c64_u8_bytes = n_comp;
+      }
+      int flag = 1;
+      HIPCHK(c, hipMemcpyAsync(c->d_flag, &flag, sizeof(int), hipMemcpyHostToDevice, c->stream));
+      hipLaunchKernelGGL(k_c64_probe_u8, dim3(2048), dim3(256), 0, c->stream, (const float *)d_capbufs, n_comp, c->c64_u8, c->d_flag);
+      HIPCHK(c, hipMemcpyAsync(&flag, c->d_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      if (flag) { d_capbufs = c->c64_u8; fmt = LCS_FMT_IQ_U8; c->last_c64_routed = true; }
+      else c->c64_skip = 15;      // a float front end: the next batches are not probed (one in sixteen is)
+    }
+  }
+  const int fmt_in = c->last_c64_routed ? LCS_FMT_C64 : fmt;      // what the caller handed over: the hint bookkeeping goes by it
   c->use_i8 = fmt == LCS_FMT_IQ_U8;
   // complex<float> sources: fp16 hi / lo operands, three products (pss_xcorr_f16.hip) -- unless its buffers would have to be
   // allocated under an open stream's graph: such a context keeps the fp32 kernel for them (160 taps per group fit it too)
@@ -544,7 +597,7 @@ int lcs_batch_enqueue(lcs_ctx *c, const void *d_capbufs, int fmt, int n_buf, uin
     // missing rounds, so no batch overflows and sparse batches pay for no empty rounds.  The hint was measured on a batch
     // of hint_n_buf buffers of one format and stage mask: it is scaled to this batch's size and forgotten when the shape changed.
     int hint = 0;
-    if (c->hint_n_buf > 0 && c->hint_fmt == fmt && c->hint_stage == stage_mask)
+    if (c->hint_n_buf > 0 && c->hint_fmt == fmt_in && c->hint_stage == stage_mask)
       hint = (int)std::min<long long>((long long)c->work_hint * n_buf / c->hint_n_buf, (long long)n_buf * LCS_MAXP);
     // a batch that carried more cells than a round holds: the limit doubles (up to LCS_MAX_WORK) unless the caller pinned it
     if (!c->max_work_pinned && !c->st_open && hint > c->max_work && c->max_work < LCS_MAX_WORK)
@@ -563,7 +616,7 @@ int lcs_batch_enqueue(lcs_ctx *c, const void *d_capbufs, int fmt, int n_buf, uin
   if ((rc = lcs_launch_pack_results(c, n_buf, (stage_mask & 2) != 0))) return rc;
   c->last_n_buf = n_buf;
   c->last_stage_mask = stage_mask;
-  c->last_fmt = fmt;
+  c->last_fmt = fmt_in;
   c->last_geo = geo;
   return LCS_OK;
 }

@@ -235,6 +235,11 @@ struct lcs_ctx {
   int16_t *d_derm_inv = nullptr;    // [2][120][16]: for every coded bit (stream*40+col) the rate-matched PBCH bit positions carrying it (ascending, -1 padded)
   double *d_dbg = nullptr;          // debug outputs of the single-cell stage entry points
   int *d_flag = nullptr;            // exactness verdict of k_ingest_c128
+  bool c64_probe = false;           // lcs_set_float_batch_probe: complex<float> batches are checked for dongle data (every component k/128) and then take the u8 route
+  uint8_t *c64_u8 = nullptr;        // ... the bytes such a batch is turned into
+  size_t c64_u8_bytes = 0;
+  int c64_skip = 0;                 // batches left before the next probe (after a batch that was NOT dongle data)
+  bool last_c64_routed = false;     // the last lcs_batch_enqueue of a complex<float> batch took the u8 route
   bool percell_ready = false;
   // streaming mode (lcs_stream_*): the one-buffer, n_f = 1 chain captured once as a hipGraph; every
   // per-push input reaches the device through fixed pinned buffers, so the graph never changes

@@ -342,3 +342,50 @@ def test_track_stream_mixed_cp_types_and_dongle_parameters(pkg, mixed):
         tried = one["mib_ok"][0] != -1
         assert np.array_equal(ok, one["mib_ok"][0][tried]) and np.array_equal(
             np.concatenate([q["mib_bits"][i, :q["n_mib"][i]] for q in parts]), one["mib_bits"][0][tried])
+
+
+# ------------------------------------------------------------------------ complex<float> batches that are dongle data
+def test_float_batches_of_dongle_data_take_the_u8_route(pkg):
+    """lcs_set_float_batch_probe: a device-resident LCS_FMT_C64 batch whose every component is (u8 - 127) / 128 is recognised on the
+    device and handed to the u8 route -- the int8 kernel, byte-identical records to the same captures handed over as bytes, equal to
+    the oracle; a batch with ONE component off the 8-bit grid (or a NaN) takes the fp16 kernel as before; off by default."""
+    import torch
+    f = f_search_set_for(FC, 100)
+    fcs = FC + 100e3 * np.arange(4)
+    cells = [[dict(n_id_1=31, n_id_2=1, f_off=22e3)], [], [dict(n_id_1=140, n_id_2=0, cp_normal=False, n_ports=4, f_off=-48e3), dict(n_id_1=7, n_id_2=2, f_off=9e3, gain_db=-4)], []]
+    bufs = [pkg.synth.make_capbuf(900 + k, fcs[k], cells[k], 5.0)[0] for k in range(4)]
+    d8 = torch.from_numpy(np.ascontiguousarray(np.stack(bufs))).cuda()
+    h32 = np.stack([iq_u8_to_capbuf(b).astype(np.complex64) for b in bufs])
+    d32 = torch.from_numpy(h32).cuda()
+    with pkg.Searcher(0) as S:
+        as_bytes = S.search_batch(d8.data_ptr(), pkg.FMT_IQ_U8, 4, 153600, f, fcs, fcs, FS, pkg.STAGE_FULL)
+        S.search_batch(d32.data_ptr(), pkg.FMT_C64, 4, 153600, f, fcs, fcs, FS, pkg.STAGE_FULL)
+        assert S.last_xcorr_info()[0] == "k_xcorr_f16x3"                          # off by default
+        S.set_float_batch_probe(True)
+        routed = S.search_batch(d32.data_ptr(), pkg.FMT_C64, 4, 153600, f, fcs, fcs, FS, pkg.STAGE_FULL)
+        assert S.last_xcorr_info()[0] == "k_xcorr_i8x3"
+        for b in range(4):
+            assert [bytes(c) for c in routed[b]] == [bytes(c) for c in as_bytes[b]], b      # the same records, NaNs and all
+            _same_cells(routed[b], O.search_capbuf(iq_u8_to_capbuf(bufs[b]), f, fcs[b], fcs[b], FS)[0], f"routed buffer {b}")
+            r, r8 = S.batch_readback(b, f.size), None
+            ro = O.xcorr_pss(iq_u8_to_capbuf(bufs[b]), f, 2, fcs[b], fcs[b], FS)
+            assert (np.abs(r["single"].astype(np.float64) - ro["single"]) / ro["single"]).max() < 1e-5 and np.array_equal(r["frq"], ro["frq"]), b
+        assert sum(len(x) for x in routed) >= 3
+        # one component off the grid (half a step), then a NaN: the fp16 kernel, and the results of a float front end
+        for bad in (np.float32(0.5 / 128), np.float32(np.nan)):
+            h = h32.copy()
+            h[2, 77777] = h[2, 77777] + bad
+            dd = torch.from_numpy(h).cuda()
+            S.set_float_batch_probe(True)                                          # (resets the skip counter)
+            got = S.search_batch(dd.data_ptr(), pkg.FMT_C64, 4, 153600, f, fcs, fcs, FS, pkg.STAGE_PSS)
+            assert S.last_xcorr_info()[0] == "k_xcorr_f16x3", bad
+            if not np.isnan(bad):
+                po = O.peak_search(*(lambda ro: (ro["pow"], ro["frq"], O.z_th1(ro["sp_incoherent"], ro["n_comb_xc"])))(O.xcorr_pss(h[2].astype(np.complex128), f, 2, fcs[2], fcs[2], FS)),
+                                   f, fcs[2], fcs[2], O.xcorr_pss(h[2].astype(np.complex128), f, 2, fcs[2], fcs[2], FS)["single"], 2)
+                assert [(c.n_id_2, c.ind) for c in got[2]] == [(c.n_id_2, c.ind) for c in po]
+        # after a batch that was not dongle data the next batches are not probed
+        S.search_batch(d32.data_ptr(), pkg.FMT_C64, 4, 153600, f, fcs, fcs, FS, pkg.STAGE_PSS)
+        assert S.last_xcorr_info()[0] == "k_xcorr_f16x3"
+        S.set_float_batch_probe(True)
+        S.search_batch(d32.data_ptr(), pkg.FMT_C64, 4, 153600, f, fcs, fcs, FS, pkg.STAGE_PSS)
+        assert S.last_xcorr_info()[0] == "k_xcorr_i8x3"
