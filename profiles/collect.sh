@@ -57,6 +57,10 @@ timeout 120 $B --stage single --steps 200 --warmup 20 > "$OUT/bench_single_n1.js
 timeout 120 $B --stage stream --steps 400 --warmup 20 > "$OUT/bench_stream_n1.json" 2> "$OUT/bench_stream_n1.err"
 timeout 120 $B --stage track --steps 400 --warmup 40 > "$OUT/bench_track_n1.json" 2> "$OUT/bench_track_n1.err"
 timeout 300 $B --steps 20 --warmup 3 --input c64 --no-cpu-baseline > "$OUT/bench_full_n1_c64_f16_kernel.json" 2> "$OUT/bench_c64.err"      # the driver's own command shape
+# complex<float> batches that are dongle data, recognised on the device (lcs_set_float_batch_probe): the int8 route
+timeout 300 $B --steps 20 --warmup 3 --input c64 --c64-probe --no-cpu-baseline > "$OUT/bench_full_n1_c64_probe_int8_route.json" 2> "$OUT/bench_c64p.err"
+# the rate over a long run, and the tracker line (C++ loop: blocks alone, and every block from the dongle's bytes)
+timeout 300 $B --steps 200 --warmup 5 --no-cpu-baseline > "$OUT/bench_full_n1_steps200.json" 2> "$OUT/bench_steps200.err"
 # the CLI's band-7 grid: fc 2.6 GHz at the default 120 ppm -> n_f = 125 (24 template groups per buffer, 1.8 GB of xc_incoherent_single per batch)
 timeout 400 $B --fc 2.6e9 --ppm 120 --steps 5 --warmup 1 > "$OUT/bench_full_n1_fc2600MHz_ppm120_nf125.json" 2> "$OUT/bench_nf125.err"
 echo collected > "$OUT/done"

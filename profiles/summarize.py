@@ -14,7 +14,7 @@ for name in ("parity_population.json", "parity_population_channels.json", "parit
     p = os.path.join(src, name)
     if os.path.exists(p):
         shutil.copy(p, os.path.join(dst, name))
-for name in ("bench_full_n1.json", "bench_forced_dist_n1.json", "bench_full_n1_input_host.json", "bench_single_n1.json", "bench_pss_n1.json", "bench_stream_n1.json", "bench_track_n1.json", "bench_full_n1_c64_f16_kernel.json", "bench_full_n1_fc2600MHz_ppm120_nf125.json", "pytest_gpu.log", "pytest_gpu_new_tests.log"):
+for name in ("bench_full_n1.json", "bench_forced_dist_n1.json", "bench_full_n1_input_host.json", "bench_single_n1.json", "bench_pss_n1.json", "bench_stream_n1.json", "bench_track_n1.json", "bench_full_n1_c64_f16_kernel.json", "bench_full_n1_fc2600MHz_ppm120_nf125.json", "bench_full_n1_c64_probe_int8_route.json", "bench_full_n1_steps200.json", "pytest_gpu.log", "pytest_gpu_new_tests.log"):
     p = os.path.join(src, name)
     if os.path.exists(p):
         lines = [l for l in open(p).read().splitlines() if l.startswith("{")] if name.endswith(".json") else open(p).read().splitlines()[-6:]
