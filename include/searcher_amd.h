@@ -58,6 +58,9 @@ class Searcher {
   Searcher(const Searcher &) = delete;               // a context has one owner
   Searcher &operator=(const Searcher &) = delete;
   lcs_ctx *handle() { return h_; }
+  // context settings (include/lcs.h): the per-cell stages' footprint limit; device-resident complex<float> batches checked for dongle data
+  void set_max_cells_in_flight(int n) { check(lcs_set_max_cells_in_flight(h_, n)); }
+  void set_float_batch_probe(bool on) { check(lcs_set_float_batch_probe(h_, on ? 1 : 0)); }
 
   // include/searcher.h:22-41
   void xcorr_pss(const cn::cvec &capbuf, const cn::vec &f_search_set, unsigned char ds_comb_arm, double fc_requested,
