@@ -91,3 +91,48 @@ def test_cellsearch_cli_eight_device_threads(tmp_path):
     eight = subprocess.run(base + ["-g", "0,0,0,0,0,0,0,0", "-B", "1"], capture_output=True, text=True, timeout=1500)
     assert eight.returncode == 0, eight.stderr[-2000:]
     assert one.stdout == eight.stdout and "277" in one.stdout and "271" in one.stdout
+
+
+def test_contexts_give_their_memory_back():
+    """Twelve contexts created, driven through differently shaped calls (single buffers, batches as bytes and floats with the probe on, a wide
+    grid, the streaming graph, tracker block + cutter) and destroyed: the device's free memory returns to where it was -- every buffer a
+    context grows (per-cell stages, operand tables, tracker / cutter workspaces, the float-batch bytes, graphs) goes with it."""
+    import numpy as np
+    import torch
+    from conftest import golden, iq_u8_to_capbuf, f_search_set_for, load_pkg
+    pkg = load_pkg()
+    iq = golden("capbuf_0000")["iq_u8"]
+    cap = iq_u8_to_capbuf(iq)
+    FC, FS = 739e6, 1.92e6
+    d8 = torch.from_numpy(np.ascontiguousarray(np.stack([iq] * 6))).cuda()
+    d32 = torch.from_numpy(np.stack([cap.astype(np.complex64)] * 6)).cuda()
+    td = torch.empty((2, 300, 128), dtype=torch.complex128, device="cuda")
+    torch.cuda.synchronize()
+
+    def one(k):
+        with pkg.Searcher(0) as S:
+            f = f_search_set_for(FC, 100) if k % 3 else f_search_set_for(2.6e9, 120)
+            fcs = np.full(6, FC)
+            if k % 2:
+                S.set_float_batch_probe(True)
+            S.search_batch(d8.data_ptr(), pkg.FMT_IQ_U8, 6, 153600, f, fcs, fcs, FS, pkg.STAGE_FULL)
+            S.search_batch(d32.data_ptr(), pkg.FMT_C64, 3 + k % 3, 153600, f, fcs[:3 + k % 3], fcs[:3 + k % 3], FS, pkg.STAGE_FULL)
+            cells, _ = S.search_capbuf(cap[:153600 - 1000 * k], np.array([30e3, 35e3, 40e3]), FC, FC, FS)
+            S.stream_open(pkg.FMT_IQ_U8, 153600, FC, FC, FS)
+            S.stream_push(iq, 35e3)
+            S.stream_collect()
+            S.stream_close()
+            tr = [c for c in cells if c.n_rb_dl > 0][:2]
+            if len(tr) == 2:
+                late, n_cut = S.track_cut(d8.data_ptr(), pkg.FMT_IQ_U8, 153600, [c.cp_type for c in tr], [100.0, 7000.5], [c.freq_superfine for c in tr], FC, FC, FS,
+                                          300, td.data_ptr())
+                S.track_block(tr, None, np.zeros((2, 300)) + 35e3, np.zeros((2, 300)), late, FC, FC, FS, td_device_ptr=td.data_ptr(), n_sym=300, want_ce=False)
+
+    one(0)                                  # first use pays for one-off allocations of the runtime itself
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for k in range(1, 13):
+        one(k)
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert abs(free1 - free0) < 64 << 20, (free0, free1)
