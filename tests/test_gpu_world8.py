@@ -136,3 +136,46 @@ def test_contexts_give_their_memory_back():
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info()
     assert abs(free1 - free0) < 64 << 20, (free0, free1)
+
+
+def test_searcher_and_tracker_contexts_side_by_side_from_two_threads():
+    """A searcher context (full-chain batches) and a tracker context (cutter + block) driven from two host threads at once -- the shape of
+    LTE-Tracker's searcher and tracker threads on one GPU: every result identical to the same calls made alone."""
+    import threading
+    import numpy as np
+    import torch
+    from conftest import golden, iq_u8_to_capbuf, f_search_set_for, load_pkg
+    pkg = load_pkg()
+    iq = golden("capbuf_0000")["iq_u8"]
+    cap = iq_u8_to_capbuf(iq)
+    FC, FS = 739e6, 1.92e6
+    f = f_search_set_for(FC, 100)
+    fcs = np.full(8, FC)
+    d8 = torch.from_numpy(np.ascontiguousarray(np.stack([np.roll(iq, 2 * 1000 * k) for k in range(8)]))).cuda()
+    td = torch.empty((2, 600, 128), dtype=torch.complex128, device="cuda")
+    torch.cuda.synchronize()
+    with pkg.Searcher(0) as A, pkg.Searcher(0) as B:
+        cells, _ = A.search_capbuf(cap, np.array([30e3, 35e3, 40e3]), FC, FC, FS)
+        tr = [c for c in cells if c.n_rb_dl > 0]
+        assert len(tr) == 2
+        fts = [c.frame_start * (30.72e6 / 16) / (FS * ((FC - c.freq_superfine) / FC)) for c in tr]
+        fos = [c.freq_superfine for c in tr]
+
+        def search():
+            r = A.search_batch(d8.data_ptr(), pkg.FMT_IQ_U8, 8, 153600, f, fcs, fcs, FS, pkg.STAGE_FULL)
+            return [[bytes(c) for c in b] for b in r]
+
+        def track():
+            late, n_cut = B.track_cut(d8.data_ptr(), pkg.FMT_IQ_U8, 153600, [c.cp_type for c in tr], fts, fos, FC, FC, FS, 600, td.data_ptr())
+            o = B.track_block(tr, None, np.repeat(np.array(fos)[:, None], 600, 1), np.repeat(np.array(fts)[:, None], 600, 1), late, FC, FC, FS,
+                              td_device_ptr=td.data_ptr(), n_sym=600, want_ce=False)
+            return late.tobytes(), o["syms"].tobytes(), o["mib_ok"].tobytes(), o["meas"][:, :2, :100].tobytes()
+
+        want_s, want_t = search(), track()
+        got = {"s": [], "t": []}
+        ts = [threading.Thread(target=lambda: got["s"].extend(search() for _ in range(20))), threading.Thread(target=lambda: got["t"].extend(track() for _ in range(40)))]
+        for t in ts: t.start()
+        for t in ts: t.join()
+        assert len(got["s"]) == 20 and all(x == want_s for x in got["s"])
+        assert len(got["t"]) == 40 and all(x == want_t for x in got["t"])
+        assert sum(len(b) for b in want_s) >= 8
